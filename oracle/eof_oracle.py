@@ -1,0 +1,461 @@
+"""CPU oracle: numpy/scipy restatement of the xeofs hot path.
+
+TEST INFRASTRUCTURE ONLY -- never imported by the product (`xeofs_amd/`).
+
+Every function cites the reference file:line (relative to /root/reference) it
+follows.  The reference (xeofs 3.0.4) is pure Python and its arithmetic lives
+in third-party solvers that are NOT under /root/reference:
+
+  * scikit-learn ``sklearn.utils.extmath.randomized_svd`` (pin >=1.0.2 in
+    pyproject.toml:17; 1.7.2 installed here) -- restated in `randomized_svd`
+    below from its published algorithm (Halko et al. 2009, as implemented in
+    sklearn/utils/extmath.py `_randomized_range_finder` / `_randomized_svd`).
+  * ``scipy.sparse.linalg.svds(solver="lobpcg")`` (scipy 1.15.3 here) -- called,
+    not restated (`complex_svds`), it is the solver itself.
+  * ``scipy.signal.hilbert`` -- restated with numpy FFT in `analytic_signal`.
+
+Pinning status.  xeofs itself cannot be imported in the build container (no
+xarray / dask), and the reference's own tests hold no golden numeric vectors
+(only invariants: shapes, determinism, round trips).  The
+restatement is therefore pinned (tests/test_oracle.py, tests/golden/*.npz made
+by oracle/make_golden.py) against
+  (a) the real third-party solvers run in the build container: bit-for-bit
+      against sklearn's `randomized_svd`, to rounding against scipy `hilbert`,
+      `svds` and exact LAPACK SVDs;
+  (b) every invariant the reference's tests state for this path.
+The thin xeofs wrapper semantics (policy, sign rule, scaling, NaN handling) are
+restated from source and are "parity unpinned" by reference-run outputs.
+"""
+
+from __future__ import annotations
+
+import warnings
+
+import numpy as np
+import scipy.linalg as sla
+
+FLOAT32_EPS = float(np.finfo(np.float32).eps)
+
+
+# --------------------------------------------------------------------------- #
+# R1/R2  Scaler                                                                #
+# --------------------------------------------------------------------------- #
+def sqrt_cos_lat_weights(lat_deg):
+    """xeofs/utils/xarray_utils.py:256-270 `_np_sqrt_cos_lat_weights`."""
+    return np.sqrt(np.cos(np.deg2rad(np.asarray(lat_deg, dtype=float))).clip(0, 1))
+
+
+def scaler_fit(X, with_center=True, with_std=False):
+    """xeofs/preprocessing/scaler.py:69-126 on the stacked (sample, feature) view.
+
+    xarray float reductions default to skipna=True -> nanmean / nanstd(ddof=0);
+    std is clipped below at float32 eps (:106-108).  Statistics keep the input
+    dtype (float32 in, float32 out), as numpy does.
+    """
+    X = np.asarray(X)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        mean = np.nanmean(X, axis=0) if with_center else None
+        std = None
+        if with_std:
+            std = np.clip(np.nanstd(X, axis=0), FLOAT32_EPS, None)
+    return mean, std
+
+
+def scaler_transform(X, mean=None, std=None, feature_weights=None):
+    """xeofs/preprocessing/scaler.py:128-154.
+
+    `weights_` is float64 ones when the user gives none
+    (xeofs/utils/xarray_utils.py:78-100), so the result is always float64 (H2).
+    `feature_weights` is the product coslat*weights broadcast to the feature axis.
+    """
+    X = np.asarray(X)
+    if mean is not None:
+        X = X - mean
+    if std is not None:
+        X = X / std
+    w = np.ones(X.shape[1], dtype=np.float64) if feature_weights is None else np.asarray(feature_weights, dtype=np.float64)
+    return X * w
+
+
+# --------------------------------------------------------------------------- #
+# R4  Sanitizer                                                                #
+# --------------------------------------------------------------------------- #
+def sanitizer_fit_transform(Xs, check_nans=True):
+    """xeofs/preprocessing/sanitizer.py:46-126 (fit + transform on the same data).
+
+    Returns (X_compact, valid_feature[P], valid_sample[n]).
+    Raises ValueError("Input data contains partial NaN entries ...") like :115-122.
+    """
+    notnull = ~np.isnan(Xs)
+    valid_feature = notnull.any(axis=0)
+    valid_sample = notnull.any(axis=1)
+    if not check_nans:
+        return Xs, valid_feature, valid_sample
+    per_sample = notnull.sum(axis=1)
+    n_valid = int(valid_feature.sum())
+    if (~np.isin(per_sample, [0, n_valid])).any():
+        raise ValueError(
+            "Input data contains partial NaN entries, which will cause the the SVD to fail."
+        )
+    return Xs[np.ix_(valid_sample, valid_feature)], valid_feature, valid_sample
+
+
+def sanitizer_transform(Xs, valid_feature_fit, check_nans=True):
+    """xeofs/preprocessing/sanitizer.py:80-126 on new data with a fitted mask."""
+    notnull = ~np.isnan(Xs)
+    valid_feature = notnull.any(axis=0)
+    valid_sample = notnull.any(axis=1)
+    if not check_nans:
+        return Xs, valid_sample
+    if not np.array_equal(valid_feature, valid_feature_fit):
+        raise ValueError(
+            "Input data had NaN features in different locations than the original data."
+        )
+    per_sample = notnull.sum(axis=1)
+    if (~np.isin(per_sample, [0, int(valid_feature.sum())])).any():
+        raise ValueError(
+            "Input data contains partial NaN entries, which will cause the the SVD to fail."
+        )
+    return Xs[np.ix_(valid_sample, valid_feature)], valid_sample
+
+
+def preprocess(X, center=True, standardize=False, feature_weights=None, check_nans=True):
+    """Scaler -> Stacker(reshape, done by caller) -> Sanitizer, R1-R5.
+
+    X: (n, P) stacked raw field (may hold NaN).  Returns dict with the float64
+    compacted matrix and every fitted quantity.
+    """
+    mean, std = scaler_fit(X, center, standardize)
+    Xs = scaler_transform(X, mean, std, feature_weights)
+    Xc, vf, vs = sanitizer_fit_transform(Xs, check_nans)
+    return dict(X=Xc, mean=mean, std=std, valid_feature=vf, valid_sample=vs)
+
+
+# --------------------------------------------------------------------------- #
+# R6  total variance                                                           #
+# --------------------------------------------------------------------------- #
+def total_variance(X):
+    """xeofs/utils/xarray_utils.py:236-253: `data.var(dim, ddof=1).sum()`."""
+    return np.var(X, axis=0, ddof=1).sum()
+
+
+# --------------------------------------------------------------------------- #
+# R8  randomized SVD (scikit-learn algorithm)                                  #
+# --------------------------------------------------------------------------- #
+def svd_flip(u, v, u_based_decision=True):
+    """sklearn/utils/extmath.py `svd_flip` (sign so that largest-|.| entry is +)."""
+    if u_based_decision:
+        max_abs = np.argmax(np.abs(u.T), axis=1)
+        signs = np.sign(u[max_abs, np.arange(u.shape[1])])
+    else:
+        max_abs = np.argmax(np.abs(v), axis=1)
+        signs = np.sign(v[np.arange(v.shape[0]), max_abs])
+    u = u * signs[np.newaxis, :]
+    v = v * signs[:, np.newaxis]
+    return u, v
+
+
+def sketch_matrix(n_rows, size, random_state, dtype):
+    """The Gaussian test matrix exactly as sklearn draws it
+    (extmath.py `_randomized_range_finder`: `random_state.normal(size=(A.shape[1], size))`
+    from a legacy `np.random.RandomState`, cast to the data dtype)."""
+    if isinstance(random_state, np.random.RandomState):
+        rs = random_state
+    else:
+        rs = np.random.RandomState(random_state)
+    Q = rs.normal(size=(n_rows, size))
+    if np.issubdtype(dtype, np.floating):
+        Q = Q.astype(dtype, copy=False)
+    return Q
+
+
+def rsvd_n_iter(n_components, shape):
+    """extmath.py `_randomized_svd`: n_iter = 7 if k < 0.1*min(shape) else 4."""
+    return 7 if n_components < 0.1 * min(shape) else 4
+
+
+def randomized_svd(M, n_components, n_oversamples=10, n_iter="auto",
+                   power_iteration_normalizer="auto", transpose="auto",
+                   flip_sign=True, random_state=None):
+    """Restatement of sklearn.utils.extmath.randomized_svd (the callable the
+    reference hands to apply_ufunc at xeofs/linalg/decomposer.py:141-146).
+
+    Returns (U[n,k], s[k], Vt[k,p]) in M's dtype.  Checked bit-for-bit against
+    scikit-learn 1.7.2 in tests/test_oracle.py.
+    """
+    M = np.asarray(M)
+    n_random = n_components + n_oversamples
+    n_samples, n_features = M.shape
+    if n_iter == "auto":
+        n_iter = rsvd_n_iter(n_components, M.shape)
+    if transpose == "auto":
+        transpose = n_samples < n_features
+    if transpose:
+        M = M.T
+    Q = sketch_matrix(M.shape[1], n_random, random_state, M.dtype)
+    if power_iteration_normalizer == "auto":
+        power_iteration_normalizer = "none" if n_iter <= 2 else "LU"
+    if power_iteration_normalizer == "QR":
+        normalizer = lambda x: sla.qr(x, mode="economic", check_finite=False)
+    elif power_iteration_normalizer == "LU":
+        normalizer = lambda x: sla.lu(x, permute_l=True, check_finite=False)
+    else:
+        normalizer = lambda x: (x, None)
+    for _ in range(n_iter):
+        Q, _ = normalizer(M @ Q)
+        Q, _ = normalizer(M.T @ Q)
+    Q, _ = sla.qr(M @ Q, mode="economic", check_finite=False)
+    B = Q.T @ M
+    Uhat, s, Vt = sla.svd(B, full_matrices=False, lapack_driver="gesdd")
+    del B
+    U = Q @ Uhat
+    if flip_sign:
+        U, Vt = svd_flip(U, Vt, u_based_decision=not transpose)
+    if transpose:
+        return Vt[:n_components, :].T, s[:n_components], U[:, :n_components].T
+    return U[:, :n_components], s[:n_components], Vt[:n_components, :]
+
+
+# --------------------------------------------------------------------------- #
+# R9  complex branch                                                           #
+# --------------------------------------------------------------------------- #
+def complex_svds(X, k, random_state=None):
+    """xeofs/linalg/decomposer.py:149-160: scipy svds(lobpcg) + descending sort."""
+    from scipy.sparse.linalg import svds
+
+    U, s, VT = svds(X, k=k, solver="lobpcg", random_state=random_state)
+    idx = np.argsort(s)[::-1]
+    return U[:, idx], s[idx], VT[idx, :]
+
+
+# --------------------------------------------------------------------------- #
+# R11  sign rule                                                               #
+# --------------------------------------------------------------------------- #
+def deterministic_sign_multiplier(VT):
+    """xeofs/utils/xarray_utils.py:273-301.
+
+    Per mode: m = max_f VT, mi = min_f VT (numpy complex max/min are
+    lexicographic); +1 if |m| >= |mi| (idxmax over coords [1, -1] returns the
+    first maximum on ties) else -1.
+    """
+    m = VT.max(axis=1)
+    mi = VT.min(axis=1)
+    return np.where(np.abs(m) >= np.abs(mi), 1, -1)
+
+
+# --------------------------------------------------------------------------- #
+# R7/R11  Decomposer                                                           #
+# --------------------------------------------------------------------------- #
+def decomposer_fit(X, n_modes, init_rank_reduction=0.3, flip_signs=True,
+                   solver="auto", random_state=None, solver_kwargs=None):
+    """xeofs/linalg/decomposer.py:76-226 on a plain (sample, feature) ndarray.
+
+    Returns (U[n,k], s[k], V[p,k]) with V = conj(VT).T (:226).
+    """
+    solver_kwargs = dict(solver_kwargs or {})
+    X = np.asarray(X)
+    is_based_on_variance = not isinstance(n_modes, (int, np.integer))
+    if is_based_on_variance and not (0 < init_rank_reduction <= 1.0):
+        raise ValueError("init_rank_reduction must be in the half open interval (0, 1].")
+    rank = min(X.shape)
+    n_pre = n_modes
+    if is_based_on_variance:
+        n_pre = int(rank * init_rank_reduction)
+        if n_pre < 1:
+            warnings.warn(
+                f"`init_rank_reduction={init_rank_reduction}` is too low resulting in zero components. One component will be computed instead."
+            )
+            n_pre = 1
+    if n_pre > rank:
+        raise ValueError(
+            f"n_modes must be less than or equal to the rank of the dataset (rank = {rank})."
+        )
+    use_complex = np.iscomplexobj(X)
+    is_small = max(X.shape) < 500
+    if solver == "auto":
+        use_exact = bool(is_small and n_pre > int(0.8 * rank))
+    elif solver == "full":
+        use_exact = True
+    elif solver == "randomized":
+        use_exact = False
+    else:
+        raise ValueError(
+            f"Unrecognized solver '{solver}'. Valid options are 'auto', 'full', and 'randomized'."
+        )
+    if use_exact:
+        U, s, VT = np.linalg.svd(X, **solver_kwargs)  # full_matrices=True default, then sliced
+        U, s, VT = U[:, :n_pre], s[:n_pre], VT[:n_pre, :]
+    elif not use_complex:
+        U, s, VT = randomized_svd(X, n_components=n_pre, random_state=random_state, **solver_kwargs)
+    else:
+        U, s, VT = complex_svds(X, n_pre, random_state=random_state)
+
+    if is_based_on_variance:
+        N = X.shape[0] - 1
+        tv = np.var(X, axis=0, ddof=1).sum()
+        cum = np.cumsum(s ** 2 / N / tv)
+        n_req = n_pre - int((cum >= n_modes).sum()) + 1
+        if n_req > n_pre:
+            warnings.warn(
+                f"Dataset has {n_pre} components, explaining {cum[-1]:.2%} of the variance. However, {n_modes:.2%} explained variance was requested. Please consider increasing `init_rank_reduction`."
+            )
+            n_req = n_pre
+        U, s, VT = U[:, :n_req], s[:n_req], VT[:n_req, :]
+    if flip_signs:
+        sgn = deterministic_sign_multiplier(VT)
+        VT = VT * sgn[:, None]
+        U = U * sgn[None, :]
+    return U, s, VT.conj().T
+
+
+# --------------------------------------------------------------------------- #
+# R12/R13  EOF model                                                           #
+# --------------------------------------------------------------------------- #
+def eof_fit(X, n_modes, center=True, standardize=False, feature_weights=None,
+            random_state=None, solver="auto", solver_kwargs=None, check_nans=True):
+    """xeofs/single/base_model_single_set.py:123-161 + xeofs/single/eof.py:85-118.
+
+    X: raw stacked (n, P).  Returns dict keyed like the reference DataContainer
+    (eof.py:110-115) plus the fitted preprocessing state.
+    """
+    pre = preprocess(X, center, standardize, feature_weights, check_nans)
+    Xc = pre["X"]
+    tv = total_variance(Xc)
+    U, s, V = decomposer_fit(Xc, n_modes, random_state=random_state, solver=solver,
+                             solver_kwargs=solver_kwargs)
+    n = Xc.shape[0]
+    return dict(
+        input_data=Xc, components=V, scores=U * s, norms=s,
+        explained_variance=s ** 2 / (n - 1), total_variance=tv,
+        explained_variance_ratio=s ** 2 / (n - 1) / tv,
+        U=U, **{k: pre[k] for k in ("mean", "std", "valid_feature", "valid_sample")},
+    )
+
+
+def eof_transform(Xc_new, components, norms=None, normalized=False):
+    """xeofs/single/eof.py:123-132 (+ base_model_single_set.py:180-203 /norms)."""
+    proj = Xc_new @ components
+    if normalized:
+        proj = proj / norms
+    return proj
+
+
+def eof_inverse_transform(scores, components):
+    """xeofs/single/eof.py:134-156: xr.dot(comps.conj(), scores, dims='mode')."""
+    return scores @ components.conj().T
+
+
+# --------------------------------------------------------------------------- #
+# R14/R15  cross-covariance + MCA                                              #
+# --------------------------------------------------------------------------- #
+def cross_covariance(X, Y):
+    """xeofs/cross/cpcca.py:1007-1015 `_compute_cross_covariance_numpy`."""
+    if X.shape[0] != Y.shape[0]:
+        raise ValueError(
+            f"Both data matrices must have the same number of samples but found {X.shape[0]} in the first and {Y.shape[0]} in the second."
+        )
+    return X.conj().T @ Y / (X.shape[0] - 1)
+
+
+def mca_fit(X, Y, n_modes, standardize=False, feature_weights_x=None, feature_weights_y=None,
+            random_state=None, solver="auto", solver_kwargs=None, check_nans=True):
+    """xeofs/cross/base_model_cross_set.py:269-321 with use_pca=False, alpha=1
+    (MCA, cross/mca.py:107) + xeofs/cross/cpcca.py:168-225.  CPCCA always
+    centres (cpcca.py:145)."""
+    px = preprocess(X, True, standardize, feature_weights_x, check_nans)
+    py = preprocess(Y, True, standardize, feature_weights_y, check_nans)
+    Xc, Yc = px["X"], py["X"]
+    C = cross_covariance(Xc, Yc)
+    Q1, s, Q2 = decomposer_fit(C, n_modes, random_state=random_state, solver=solver,
+                               solver_kwargs=solver_kwargs)
+    tsc = (np.abs(C) ** 2).sum()
+    scores1 = Xc @ Q1
+    scores2 = Yc @ Q2
+    norm1 = np.sqrt((scores1.conj() * scores1).sum(axis=0)).real
+    norm2 = np.sqrt((scores2.conj() * scores2).sum(axis=0)).real
+    return dict(
+        input_data1=Xc, input_data2=Yc, components1=Q1, components2=Q2,
+        scores1=scores1, scores2=scores2, singular_values=s, squared_covariance=s ** 2,
+        total_squared_covariance=tsc, idx_modes_sorted=np.argsort(s)[::-1],
+        norm1=norm1, norm2=norm2, C=C, pre_x=px, pre_y=py,
+    )
+
+
+# --------------------------------------------------------------------------- #
+# R16  Hilbert transform                                                       #
+# --------------------------------------------------------------------------- #
+def analytic_signal(y):
+    """scipy.signal.hilbert(y, axis=0): FFT, zero negative freqs, double positive."""
+    N = y.shape[0]
+    Yf = np.fft.fft(y, axis=0)
+    h = np.zeros(N, dtype=Yf.real.dtype)
+    if N % 2 == 0:
+        h[0] = h[N // 2] = 1
+        h[1:N // 2] = 2
+    else:
+        h[0] = 1
+        h[1:(N + 1) // 2] = 2
+    return np.fft.ifft(Yf * h[:, None], axis=0)
+
+
+def pad_exp(y, decay_factor=0.2):
+    """xeofs/utils/hilbert_transform.py:75-114 `_pad_exp`."""
+    n = y.shape[0]
+    x = np.arange(n)
+    x_ext = np.arange(-n, 2 * n)
+    coefs = np.polynomial.polynomial.polyfit(x, y, deg=1)
+    yfit = np.polynomial.polynomial.polyval(x, coefs).T
+    yfit_ext = np.polynomial.polynomial.polyval(x_ext, coefs).T
+    y_ano = y - yfit
+    amp_pre = y_ano[0][:, None]
+    amp_pos = y_ano[-1][:, None]
+    exp_ext = np.exp(-x / n / decay_factor)
+    pad_pre = amp_pre * exp_ext[::-1]
+    pad_pos = amp_pos * exp_ext
+    y_ext = np.concatenate([pad_pre.T, y_ano, pad_pos.T], axis=0)
+    return y_ext + yfit_ext
+
+
+def hilbert_transform(y, padding="exp", decay_factor=0.2):
+    """xeofs/utils/hilbert_transform.py:40-72 `_hilbert_transform_with_padding`."""
+    n = y.shape[0]
+    if padding == "exp":
+        y = pad_exp(y, decay_factor)
+    y = analytic_signal(y)
+    if padding == "exp":
+        y = y[n:2 * n]
+    return y - y.mean(axis=0)
+
+
+# --------------------------------------------------------------------------- #
+# synthetic field of SURVEY.md §8d (shared by tests and bench)                 #
+# --------------------------------------------------------------------------- #
+def synthetic_field(n, n_lat, n_lon, rank=100, seed=0, dtype=np.float32, nan_frac=0.0):
+    """Low-rank + noise field with a decaying spectrum."""
+    p = n_lat * n_lon
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((n, p)).astype(dtype)
+    lat = np.linspace(-89.75, 89.75, n_lat)
+    for j in range(rank):
+        rj = np.random.default_rng(1000 + j)
+        e = rj.standard_normal(n)
+        t = np.empty(n)
+        t[0] = e[0]
+        for i in range(1, n):
+            t[i] = 0.8 * t[i - 1] + 0.6 * e[i]
+        t = (t - t.mean()) / t.std()
+        gj = np.random.default_rng(2000 + j)
+        # smooth spatial pattern: sum of a few random low-wavenumber harmonics
+        yy, xx = np.meshgrid(np.linspace(0, np.pi, n_lat), np.linspace(0, 2 * np.pi, n_lon, endpoint=False), indexing="ij")
+        g = np.zeros((n_lat, n_lon))
+        for _ in range(4):
+            ky, kx = gj.integers(1, 6, size=2)
+            g += gj.standard_normal() * np.sin(ky * yy + gj.uniform(0, 2 * np.pi)) * np.cos(kx * xx + gj.uniform(0, 2 * np.pi))
+        g = (g / np.linalg.norm(g)).ravel()
+        X += (10.0 * 0.93 ** j) * np.outer(t, g).astype(dtype)
+    X += (15.0 + 10.0 * np.cos(np.deg2rad(lat)))[None, :, None].repeat(n_lon, axis=2).reshape(1, p).astype(dtype)
+    if nan_frac > 0:
+        mask = np.random.default_rng(seed + 77).random(p) < nan_frac
+        X[:, mask] = np.nan
+    return X, lat
