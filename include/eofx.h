@@ -1,0 +1,167 @@
+/*
+ * eofx.h -- C ABI of the MI355X-native EOF / randomized-SVD engine (libeofx.so).
+ *
+ * This is the drop-in boundary for the one hot path of xarray-contrib/xeofs
+ * (reference v3.0.4, paths relative to /root/reference):
+ *
+ *   preprocess  : Scaler.fit/transform      xeofs/preprocessing/scaler.py:69-154
+ *                 Sanitizer.fit/transform   xeofs/preprocessing/sanitizer.py:46-126
+ *                 total_variance            xeofs/utils/xarray_utils.py:236-253
+ *   decompose   : the callable handed to xr.apply_ufunc in Decomposer._svd
+ *                 xeofs/linalg/decomposer.py:141-146,252-263
+ *                 (= sklearn.utils.extmath.randomized_svd(X, n_components, random_state))
+ *                 + sign rule xeofs/utils/xarray_utils.py:273-301
+ *   project     : xr.dot(X, components)     xeofs/single/eof.py:129, cross/cpcca.py:204-205
+ *   cross-cov   : X^H Y/(n-1) + its rSVD    xeofs/cross/cpcca.py:168-225,1007-1015
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch / xarray types.
+ *   - every function returns an int status: 0 = ok, negative = error
+ *     (see EOFX_ERR_*; eofx_last_error() gives the message).  The Python shell
+ *     maps the codes onto the reference's exception types.
+ *   - data pointers documented "host|device" may point to host memory or to HIP
+ *     device memory of the context's GPU; the library detects which
+ *     (hipPointerGetAttributes) and never frees caller memory.
+ *   - matrices are row-major.  `sample` = rows (time), `feature` = columns (space).
+ *   - all work is enqueued on the context's HIP stream; functions that write host
+ *     outputs synchronise that stream before returning, the others do not.
+ *   - deterministic: no floating-point atomics, fixed reduction trees; the same
+ *     inputs give bitwise identical outputs (reference contract
+ *     tests/linalg/test_decomposer.py:164-192).
+ */
+#ifndef EOFX_H
+#define EOFX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EOFX_ABI_VERSION 1
+
+#define EOFX_OK 0
+#define EOFX_ERR_ARG (-1)          /* bad argument                       -> ValueError        */
+#define EOFX_ERR_HIP (-2)          /* HIP runtime failure                -> RuntimeError      */
+#define EOFX_ERR_PARTIAL_NAN (-3)  /* sanitizer.py:115-122               -> ValueError        */
+#define EOFX_ERR_NAN_MISMATCH (-4) /* sanitizer.py:109-113               -> ValueError        */
+#define EOFX_ERR_RANK (-5)         /* decomposer.py:97-100               -> ValueError        */
+#define EOFX_ERR_LINALG (-6)       /* decomposer.py:265-270              -> LinAlgError       */
+#define EOFX_ERR_NOMEM (-7)        /* device allocation failed           -> MemoryError       */
+#define EOFX_ERR_SHAPE (-8)        /* cpcca.py:1012-1014 sample mismatch -> ValueError        */
+
+typedef struct eofx_ctx eofx_ctx; /* one GPU + one stream + scratch            */
+typedef struct eofx_mat eofx_mat; /* a resident preprocessed (sample x feature) matrix */
+
+/* ---- context ----------------------------------------------------------- */
+int eofx_abi_version(void);
+/* stream: a hipStream_t (NULL = the device's default stream). */
+int eofx_ctx_create(int device, void *stream, eofx_ctx **out);
+int eofx_ctx_destroy(eofx_ctx *ctx);
+int eofx_ctx_synchronize(eofx_ctx *ctx);
+const char *eofx_last_error(const eofx_ctx *ctx);
+
+/* ---- resident matrix ---------------------------------------------------
+ * An eofx_mat holds the preprocessed matrix twice in HBM, zero padded:
+ *   X  [n_pad x p_pad] feature-contiguous   (streams X^T Z)
+ *   Xt [p_pad x n_pad] sample-contiguous    (streams X Y)
+ * with n_pad, p_pad multiples of 512.  See DESIGN.md "Data layout".       */
+
+/* Scaler + Sanitizer + total variance, fused (R1,R2,R4,R6 of SURVEY.md 8a).
+ *   X              host|device, n x P float32, may contain NaN
+ *   center/standardize  Scaler with_center / with_std
+ *   feat_weights   host, P doubles (coslat*weights) or NULL (= ones)
+ *   check_nans     1: raise EOFX_ERR_PARTIAL_NAN on isolated NaNs, drop all-NaN
+ *                  features and samples
+ * outputs (host, each may be NULL):
+ *   mean[P], std[P]      fitted statistics (NaN for all-NaN features)
+ *   valid_feature[P], valid_sample[n]   0/1 masks
+ *   n_out, p_out         shape of the compacted matrix
+ *   total_variance       sum_f var(X_f, ddof=1) of the transformed matrix        */
+int eofx_preprocess_f32(eofx_ctx *ctx, const float *X, int64_t n, int64_t P, int center,
+                        int standardize, const double *feat_weights, int check_nans,
+                        eofx_mat **out, double *mean, double *std, uint8_t *valid_feature,
+                        uint8_t *valid_sample, int64_t *n_out, int64_t *p_out,
+                        double *total_variance);
+
+/* Preprocessor.transform on new data with fitted state (scaler.py:128-154,
+ * sanitizer.py:80-126).  mean/std may be NULL (no centring / no scaling).
+ * Raises EOFX_ERR_NAN_MISMATCH if the NaN-feature pattern differs from
+ * valid_feature, EOFX_ERR_PARTIAL_NAN on isolated NaNs.                       */
+int eofx_apply_f32(eofx_ctx *ctx, const float *X, int64_t n, int64_t P, const double *mean,
+                   const double *std, const double *feat_weights, const uint8_t *valid_feature,
+                   int check_nans, eofx_mat **out, uint8_t *valid_sample, int64_t *n_out);
+
+/* Adopt an already preprocessed dense matrix (host|device, n x p, leading dim ld). */
+int eofx_mat_from_dense_f32(eofx_ctx *ctx, const float *X, int64_t n, int64_t p, int64_t ld,
+                            eofx_mat **out);
+int eofx_mat_destroy(eofx_ctx *ctx, eofx_mat *m);
+int eofx_mat_shape(const eofx_mat *m, int64_t *n, int64_t *p, int64_t *n_pad, int64_t *p_pad);
+/* copy the resident matrix back (host|device dst, n x p dense).                */
+int eofx_mat_download_f32(eofx_ctx *ctx, const eofx_mat *m, float *dst);
+
+/* ---- randomized SVD (the decomposer seam) ------------------------------
+ * Replaces randomized_svd(X, n_components=k, random_state) at decomposer.py:146.
+ *   omega   host, (min(n,p) x (k+n_oversamples)) float32 Gaussian test matrix, drawn
+ *           by the caller exactly as sklearn does so results are seed-compatible:
+ *           RandomState(seed).normal(size=(min(n,p), k+n_oversamples)).astype(float32)
+ *   n_iter  power iterations; <0 = sklearn "auto" (7 if k < 0.1*min(n,p) else 4)
+ *   flip    1: apply the xeofs sign rule (xarray_utils.py:273-301) to U and V
+ * outputs host|device: U [n x k], s [k], V [p x k] (V = VT^T, decomposer.py:226). */
+int eofx_rsvd_f32(eofx_ctx *ctx, const eofx_mat *m, int k, int n_oversamples, int n_iter,
+                  const float *omega, int flip, float *U, float *s, float *V);
+
+/* scores = X V (eof.py:129).  V host|device [p x k]; out host|device [n x k].   */
+int eofx_project_f32(eofx_ctx *ctx, const eofx_mat *m, const float *V, int k, float *out);
+/* Xhat = S V^T (eof.py:151-153).  S [n x k], V [p x k] -> out [n x p] host|device. */
+int eofx_reconstruct_f32(eofx_ctx *ctx, const float *S, const float *V, int64_t n, int64_t p,
+                         int k, float *out);
+
+/* ---- cross-covariance path (MCA) ---------------------------------------
+ * Matrix-free rSVD of C = X^T Y/(n-1) (cpcca.py:1007-1015) -- C is never formed.
+ *   omega   host, (min(p1,p2) x (k+n_oversamples)) as above for C's shape (p1 x p2)
+ * outputs host|device: Q1 [p1 x k], s [k], Q2 [p2 x k], scores1/2 [n x k],
+ * norm1/2 [k] (cpcca.py:204-208); tsc = sum |C|^2 (cpcca.py:991-1000), host.   */
+int eofx_crosscov_rsvd_f32(eofx_ctx *ctx, const eofx_mat *x, const eofx_mat *y, int k,
+                           int n_oversamples, int n_iter, const float *omega, int flip, float *Q1,
+                           float *s, float *Q2, float *scores1, float *scores2, float *norm1,
+                           float *norm2, double *tsc);
+
+/* ---- panel-level steps (device pointers only) ---------------------------
+ * Building blocks of eofx_rsvd_f32, exported so a host shell can insert
+ * collectives between them when the feature axis is sharded over GPUs
+ * (one RCCL all-reduce of the n x L panel per pass).
+ * A panel is a row-major float32 [rows_pad x L] device buffer, L a multiple of
+ * 32, rows_pad = the matrix's n_pad or p_pad; pad rows/columns hold zeros.    */
+int eofx_panel_tmul_f32(eofx_ctx *ctx, const eofx_mat *m, const float *Zn, float *Yp,
+                        int L); /* Yp[p_pad x L] = X^T Zn[n_pad x L] */
+int eofx_panel_mul_f32(eofx_ctx *ctx, const eofx_mat *m, const float *Yp, float *Wn,
+                       int L); /* Wn[n_pad x L] = X Yp[p_pad x L]   */
+/* G[L x L] (device, float64) = P^T P, accumulated in float64 with a fixed tree. */
+int eofx_panel_gram_f64(eofx_ctx *ctx, const float *P, int64_t rows_pad, int L, double *G);
+/* Cholesky-QR step from a (possibly all-reduced) Gram matrix: out = P R^-1 with
+ * G = R^T R restricted to the leading l x l block; rank-deficient columns -> 0. */
+int eofx_panel_cholqr_f32(eofx_ctx *ctx, const float *P, int64_t rows_pad, int L, int l,
+                          const double *G, float *out);
+/* out[rows_pad x Lo] = P[rows_pad x L] * M[L x Lo]  (M device float64 row-major). */
+int eofx_panel_matmul_f32(eofx_ctx *ctx, const float *P, int64_t rows_pad, int L,
+                          const double *M, int Lo, float *out);
+/* per-column max and min over the first `rows` rows: mx[L], mn[L] device float32. */
+int eofx_panel_colminmax_f32(eofx_ctx *ctx, const float *P, int64_t rows, int L, float *mx,
+                             float *mn);
+/* dst[rows x k] (host|device, dense) = P[:, :k] * sign[k] (host doubles or NULL). */
+int eofx_panel_export_f32(eofx_ctx *ctx, const float *P, int64_t rows, int L, int k,
+                          const double *sign, float *dst);
+/* P[rows_pad x L] (device) <- src[rows x l] (host|device dense), zero padded.   */
+int eofx_panel_import_f32(eofx_ctx *ctx, const float *src, int64_t rows, int l, float *P,
+                          int64_t rows_pad, int L);
+
+/* ---- small host linear algebra used by the drivers ---------------------- */
+/* symmetric eigen-decomposition (cyclic Jacobi, float64): A[n x n] row-major ->
+ * eigenvalues w[n] descending, eigenvectors as columns of Vec[n x n].          */
+int eofx_host_eigh_f64(const double *A, int n, double *w, double *Vec);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EOFX_H */

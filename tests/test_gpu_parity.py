@@ -1,0 +1,282 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same
+seeded inputs.  Tolerances (stated once):
+
+  singular values          rel 1e-5 vs the float64 oracle
+  gap-separated vectors    |cos| >= 1 - 1e-5
+  elementwise GEMM panels  1e-5 * sum|a||b| (float32 fma-chain class)
+  preprocessing            float32 rounding of the float64 oracle value (rel 2e-6)
+"""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import eof_oracle as orc  # noqa: E402  (checker only)
+
+
+def _field(n, p, rank=8, seed=0, scale=3.0, noise=1.0, dtype=np.float32):
+    rng = np.random.default_rng(seed)
+    amp = scale * 0.8 ** np.arange(rank)
+    X = (rng.standard_normal((n, rank)) * amp) @ rng.standard_normal((rank, p)) / np.sqrt(rank)
+    X = X * np.sqrt(max(n, p)) ** 0.5 + noise * rng.standard_normal((n, p)) + 5.0
+    return X.astype(dtype)
+
+
+def _gap_ok(s, j, tol=1e-3):
+    lo = abs(s[j] - s[j + 1]) / s[j] if j + 1 < len(s) else 1.0
+    hi = abs(s[j - 1] - s[j]) / s[j] if j > 0 else 1.0
+    return min(lo, hi) > tol
+
+
+# --------------------------------------------------------------------------- kernels
+@pytest.mark.parametrize("n,p,L", [(100, 700, 32), (300, 1500, 64), (1000, 520, 64), (64, 3000, 96)])
+def test_panel_tmul_mul(ctx, n, p, L):
+    import torch
+    from xeofs_amd import engine
+
+    rng = np.random.default_rng(1)
+    X = rng.standard_normal((n, p)).astype(np.float32)
+    mat = engine.from_dense(ctx, X)
+    assert np.array_equal(mat.download(), X)
+    Z = rng.standard_normal((n, L)).astype(np.float32)
+    Y = rng.standard_normal((p, L)).astype(np.float32)
+    Zp = engine.panel_import(ctx, Z, mat.n_pad, L)
+    Yp = engine.panel_import(ctx, Y, mat.p_pad, L)
+    out_t = engine.panel_tmul(ctx, mat, Zp)
+    out_m = engine.panel_mul(ctx, mat, Yp)
+    torch.cuda.synchronize()
+    got_t = out_t.cpu().numpy()
+    got_m = out_m.cpu().numpy()
+    ref_t = X.astype(np.float64).T @ Z.astype(np.float64)
+    ref_m = X.astype(np.float64) @ Y.astype(np.float64)
+    bound_t = np.abs(X).astype(np.float64).T @ np.abs(Z)
+    bound_m = np.abs(X).astype(np.float64) @ np.abs(Y)
+    assert np.all(np.abs(got_t[:p] - ref_t) <= 1e-5 * bound_t + 1e-30)
+    assert np.all(np.abs(got_m[:n] - ref_m) <= 1e-5 * bound_m + 1e-30)
+    # padding rows of the outputs must be exact zeros (they feed the next product)
+    assert not got_t[p:].any() and not got_m[n:].any()
+
+
+def test_panel_gram_cholqr(ctx):
+    import torch
+    from xeofs_amd import engine
+
+    rng = np.random.default_rng(2)
+    rows, l, L = 5000, 60, 64
+    W = (rng.standard_normal((rows, l)) * (10.0 ** rng.uniform(-2, 2, size=l))).astype(np.float32)
+    W[:, 7] = W[:, 3] * 2.0  # exactly dependent column -> must come out as zeros
+    rows_pad = 5120
+    P = engine.panel_import(ctx, W, rows_pad, L)
+    G = engine.panel_gram(ctx, P)
+    Q = engine.panel_cholqr(ctx, P, l, G)
+    torch.cuda.synchronize()
+    Gh = G.cpu().numpy()
+    ref = W.astype(np.float64).T @ W.astype(np.float64)
+    assert np.allclose(Gh[:l, :l], ref, rtol=1e-12, atol=1e-12 * np.abs(ref).max())
+    Qh = Q.cpu().numpy().astype(np.float64)
+    assert not Qh[:, 7].any()
+    keep = [j for j in range(l) if j != 7]
+    QtQ = Qh[:, keep].T @ Qh[:, keep]
+    assert np.abs(QtQ - np.eye(len(keep))).max() < 5e-5
+    # same column space
+    coef = np.linalg.lstsq(Qh[:rows, keep], W[:, keep].astype(np.float64), rcond=None)[0]
+    assert np.abs(Qh[:rows, keep] @ coef - W[:, keep]).max() < 1e-4 * np.abs(W).max()
+
+
+# --------------------------------------------------------------------------- preprocess
+@pytest.mark.parametrize("center,standardize,weights", [(True, False, False), (True, True, True), (False, False, True)])
+@pytest.mark.parametrize("nan_kind", ["none", "features", "features+samples"])
+def test_preprocess_vs_oracle(ctx, center, standardize, weights, nan_kind):
+    from xeofs_amd import engine
+
+    n, nlat, nlon = 120, 9, 14
+    P = nlat * nlon
+    X = _field(n, P, seed=3)
+    X += 250.0  # temperatures: large mean, small variance
+    if nan_kind != "none":
+        X[:, [3, 17, 50, 51, 125]] = np.nan
+    if nan_kind == "features+samples":
+        X[[0, 77], :] = np.nan
+    w = None
+    if weights:
+        lat = np.linspace(-80, 80, nlat)
+        w = np.repeat(orc.sqrt_cos_lat_weights(lat), nlon)
+    ref = orc.preprocess(X, center, standardize, w)
+    mat, st = engine.preprocess(ctx, X, center, standardize, w)
+    assert np.array_equal(st["valid_feature"], ref["valid_feature"])
+    assert np.array_equal(st["valid_sample"], ref["valid_sample"])
+    got = mat.download()
+    assert got.shape == ref["X"].shape
+    scale = np.abs(ref["X"]).max()
+    # float32 statistics in the reference (numpy nanmean on float32) vs float64 here: the
+    # difference is bounded by float32 rounding of the mean, ~1e-7 * |mean| / std-scale
+    tol = 4e-5 if not standardize else 2e-3
+    assert np.abs(got - ref["X"]).max() <= tol * max(scale, 1.0)
+    vf = ref["valid_feature"]
+    if center:
+        assert np.allclose(st["mean"][vf], ref["mean"][vf], rtol=2e-6)
+        assert np.isnan(st["mean"][~vf]).all()
+    exact = orc.preprocess(X.astype(np.float64), center, standardize, w)
+    # against the float64-statistics oracle only the final float32 rounding remains
+    assert np.abs(got - exact["X"]).max() <= 2e-6 * max(np.abs(exact["X"]).max(), 1.0)
+    tv = orc.total_variance(exact["X"])
+    assert abs(st["total_variance"] - tv) <= 1e-6 * tv
+
+
+def test_preprocess_isolated_nan_raises(ctx):
+    from xeofs_amd import engine
+
+    X = _field(50, 40, seed=4)
+    X[3, 7] = np.nan
+    with pytest.raises(ValueError, match="partial NaN"):
+        engine.preprocess(ctx, X)
+    X = _field(50, 40, seed=4)
+    X[:, 5] = np.nan
+    X[10, :] = np.nan
+    X[11, 3] = np.nan
+    with pytest.raises(ValueError, match="partial NaN"):
+        engine.preprocess(ctx, X)
+
+
+def test_apply_new_data(ctx):
+    from xeofs_amd import engine
+
+    X = _field(80, 60, seed=5)
+    X[:, [4, 9]] = np.nan
+    mat, st = engine.preprocess(ctx, X, True, True, None)
+    Xn = _field(30, 60, seed=6)
+    Xn[:, [4, 9]] = np.nan
+    m2, vs = engine.apply(ctx, Xn, st["mean"], st["std"], None, st["valid_feature"])
+    vf = st["valid_feature"]
+    ref = (Xn[:, vf].astype(np.float64) - st["mean"][vf]) / st["std"][vf]
+    assert np.abs(m2.download() - ref).max() < 1e-5 * np.abs(ref).max()
+    Xbad = Xn.copy()
+    Xbad[:, 20] = np.nan
+    with pytest.raises(ValueError, match="different locations"):
+        engine.apply(ctx, Xbad, st["mean"], st["std"], None, st["valid_feature"])
+
+
+# --------------------------------------------------------------------------- rSVD
+def _check_svd(U, s, V, Uo, so, Vo, X64, k):
+    assert np.abs(s - so).max() <= 1e-5 * so[0], (s, so)
+    assert np.all(np.abs(s - so) <= 1e-5 * so + 2e-6 * so[0])
+    for j in range(k):
+        if _gap_ok(so, j):
+            assert abs(np.dot(V[:, j].astype(np.float64), Vo[:, j])) >= 1 - 1e-5, j
+            assert abs(np.dot(U[:, j].astype(np.float64), Uo[:, j])) >= 1 - 1e-5, j
+            # identical sign convention
+            assert np.dot(V[:, j].astype(np.float64), Vo[:, j]) > 0, j
+    rec = (U.astype(np.float64) * s) @ V.astype(np.float64).T
+    rec_o = (Uo * so) @ Vo.T
+    e, eo = np.linalg.norm(X64 - rec), np.linalg.norm(X64 - rec_o)
+    assert e <= eo * (1 + 1e-4)
+    # orthonormality
+    assert np.abs(U.astype(np.float64).T @ U - np.eye(k)).max() < 2e-5
+    assert np.abs(V.astype(np.float64).T @ V - np.eye(k)).max() < 2e-5
+
+
+@pytest.mark.parametrize("n,p,k", [(512, 2048, 10), (300, 4000, 40), (2500, 700, 20), (600, 600, 5)])
+def test_rsvd_vs_oracle(ctx, n, p, k):
+    from xeofs_amd import engine
+
+    X = _field(n, p, rank=12, seed=10 + k)
+    X = X - X.mean(axis=0, dtype=np.float64).astype(np.float32)
+    mat = engine.from_dense(ctx, X)
+    U, s, V = engine.rsvd(ctx, mat, k, random_state=42)
+    X64 = X.astype(np.float64)
+    Uo, so, Vo = orc.decomposer_fit(X64, k, random_state=42, solver="randomized")
+    _check_svd(U, s, V, Uo, so, Vo, X64, k)
+    # vs the exact SVD as well
+    se = np.linalg.svd(X64, compute_uv=False)[:k]
+    assert np.abs(s - se).max() <= 1e-4 * se[0]
+
+
+def test_rsvd_bitwise_deterministic(ctx):
+    from xeofs_amd import engine
+
+    X = _field(700, 3000, seed=21)
+    mat = engine.from_dense(ctx, X)
+    a = engine.rsvd(ctx, mat, 12, random_state=5)
+    b = engine.rsvd(ctx, mat, 12, random_state=5)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
+def test_rsvd_rank_error_and_wide_sketch(ctx):
+    from xeofs_amd import engine
+
+    X = _field(25, 20, rank=20, seed=22)
+    mat = engine.from_dense(ctx, X)
+    with pytest.raises(ValueError, match="rank"):
+        engine.rsvd(ctx, mat, 21, random_state=0)
+    # sketch wider than the rank (k + 10 > 20): results equal the exact SVD
+    U, s, V = engine.rsvd(ctx, mat, 15, random_state=0)
+    se = np.linalg.svd(X.astype(np.float64), compute_uv=False)[:15]
+    assert np.abs(s - se).max() <= 2e-5 * se[0]
+
+
+def test_eof_fit_pipeline_vs_oracle(ctx):
+    """raw field with land-mask NaNs -> preprocess -> rSVD -> EOF quantities."""
+    from xeofs_amd import engine
+
+    n, nlat, nlon = 400, 24, 40
+    X, lat = orc.synthetic_field(n, nlat, nlon, rank=20, seed=0, nan_frac=0.3)
+    w = np.repeat(orc.sqrt_cos_lat_weights(lat), nlon)
+    k = 10
+    ref = orc.eof_fit(X.astype(np.float64), k, feature_weights=w, random_state=5)
+    mat, st = engine.preprocess(ctx, X, True, False, w)
+    U, s, V = engine.rsvd(ctx, mat, k, random_state=5)
+    assert abs(st["total_variance"] - ref["total_variance"]) <= 1e-5 * ref["total_variance"]
+    Xc = ref["input_data"]
+    _check_svd(U, s, V, ref["U"], ref["norms"], ref["components"], Xc, k)
+    scores = U * s
+    for j in range(k):
+        if _gap_ok(ref["norms"], j):
+            assert np.abs(scores[:, j] - ref["scores"][:, j]).max() <= 2e-4 * np.abs(ref["scores"][:, j]).max()
+    # projection of the training data reproduces the scores (reference test_eof.py:364-391, rtol 1e-3)
+    proj = engine.project(ctx, mat, V)
+    assert np.allclose(proj, scores, rtol=1e-3, atol=1e-3 * np.abs(scores).max())
+    # reconstruction kernel
+    rec = engine.reconstruct(ctx, scores, V)
+    assert np.abs(rec - (scores.astype(np.float64) @ V.astype(np.float64).T)).max() <= 1e-5 * np.abs(rec).max()
+
+
+# --------------------------------------------------------------------------- cross-covariance / MCA
+@pytest.mark.parametrize("p1,p2", [(900, 1400), (1300, 800)])
+def test_crosscov_vs_oracle(ctx, p1, p2):
+    from xeofs_amd import engine
+
+    n, k = 300, 6
+    rng = np.random.default_rng(31)
+    T = rng.standard_normal((n, 8)) * (4.0 * 0.7 ** np.arange(8))
+    X = (T @ rng.standard_normal((8, p1)) + rng.standard_normal((n, p1))).astype(np.float32)
+    Y = (T @ rng.standard_normal((8, p2)) + rng.standard_normal((n, p2))).astype(np.float32)
+    ref = orc.mca_fit(X.astype(np.float64), Y.astype(np.float64), k, random_state=7, solver="randomized")
+    mx, _ = engine.preprocess(ctx, X)
+    my, _ = engine.preprocess(ctx, Y)
+    out = engine.crosscov_rsvd(ctx, mx, my, k, random_state=7)
+    so = ref["singular_values"]
+    assert np.all(np.abs(out["s"] - so) <= 1e-5 * so + 2e-6 * so[0])
+    for j in range(k):
+        if _gap_ok(so, j):
+            c1 = np.dot(out["Q1"][:, j].astype(np.float64), ref["components1"][:, j])
+            c2 = np.dot(out["Q2"][:, j].astype(np.float64), ref["components2"][:, j])
+            assert c1 >= 1 - 1e-5 and c2 >= 1 - 1e-5, (j, c1, c2)
+            assert np.abs(out["scores1"][:, j] - ref["scores1"][:, j]).max() <= 3e-4 * np.abs(ref["scores1"][:, j]).max()
+            assert np.abs(out["scores2"][:, j] - ref["scores2"][:, j]).max() <= 3e-4 * np.abs(ref["scores2"][:, j]).max()
+            assert abs(out["norm1"][j] - ref["norm1"][j]) <= 1e-4 * ref["norm1"][j]
+            assert abs(out["norm2"][j] - ref["norm2"][j]) <= 1e-4 * ref["norm2"][j]
+    tsc = ref["total_squared_covariance"]
+    assert abs(out["total_squared_covariance"] - tsc) <= 1e-5 * tsc
+    # reference invariant tests/models/cross/test_cpcca.py:152-164
+    assert out["total_squared_covariance"] >= (out["s"].astype(np.float64) ** 2).sum() * (1 - 1e-6)
+
+
+def test_crosscov_sample_mismatch(ctx):
+    from xeofs_amd import engine
+
+    mx, _ = engine.preprocess(ctx, _field(40, 600, seed=1))
+    my, _ = engine.preprocess(ctx, _field(41, 600, seed=2))
+    with pytest.raises(ValueError, match="same number of samples"):
+        engine.crosscov_rsvd(ctx, mx, my, 3, random_state=0)

@@ -1,0 +1,1083 @@
+// eofx_abi.hip -- C ABI (include/eofx.h) of the MI355X-native EOF / randomized-SVD engine:
+// launch logic, the randomized-SVD drivers and the small host-side linear algebra.
+// Kernels live in eofx_kernels.hpp.  gfx950 only.
+#include "eofx_kernels.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "eofx.h"
+
+using namespace eofx;
+
+// ------------------------------------------------------------------------------------
+// context, arena, helpers
+// ------------------------------------------------------------------------------------
+struct eofx_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  char* arena = nullptr;
+  size_t arena_size = 0;
+  size_t arena_off = 0;
+  std::string err;
+};
+
+struct eofx_mat {
+  int64_t n = 0, p = 0, n_pad = 0, p_pad = 0;
+  float* X = nullptr;   // [n_pad x p_pad]
+  float* Xt = nullptr;  // [p_pad x n_pad]
+};
+
+static int set_err(eofx_ctx* ctx, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (ctx) ctx->err = buf;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                          \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess)                                                                     \
+      return set_err(ctx, _e == hipErrorOutOfMemory ? EOFX_ERR_NOMEM : EOFX_ERR_HIP,           \
+                     "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+#define CHK(expr)           \
+  do {                      \
+    int _rc = (expr);       \
+    if (_rc != EOFX_OK) return _rc; \
+  } while (0)
+#define KCHK() HIPCHK(hipGetLastError())
+
+static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+static bool is_device_ptr(const void* p) {
+  if (!p) return false;
+  hipPointerAttribute_t attr;
+  hipError_t e = hipPointerGetAttributes(&attr, p);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged ||
+         attr.type == hipMemoryTypeUnified;
+}
+
+// Stack allocator over one grow-only device buffer.  Growing is only legal with an empty
+// stack (nothing carved is live), which every public entry point guarantees by reserving first.
+static int arena_reserve(eofx_ctx* ctx, size_t bytes) {
+  bytes = (size_t)round_up((int64_t)bytes, 256);
+  if (bytes <= ctx->arena_size) return EOFX_OK;
+  if (ctx->arena_off != 0) return set_err(ctx, EOFX_ERR_ARG, "internal: arena grown while in use");
+  if (ctx->arena) {
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipFree(ctx->arena));
+    ctx->arena = nullptr;
+    ctx->arena_size = 0;
+  }
+  HIPCHK(hipMalloc((void**)&ctx->arena, bytes));
+  ctx->arena_size = bytes;
+  return EOFX_OK;
+}
+template <typename T>
+static T* arena_alloc(eofx_ctx* ctx, size_t count) {
+  size_t bytes = (size_t)round_up((int64_t)(count * sizeof(T)), 256);
+  if (ctx->arena_off + bytes > ctx->arena_size) return nullptr;
+  T* p = reinterpret_cast<T*>(ctx->arena + ctx->arena_off);
+  ctx->arena_off += bytes;
+  return p;
+}
+struct ArenaScope {
+  eofx_ctx* ctx;
+  size_t mark;
+  explicit ArenaScope(eofx_ctx* c) : ctx(c), mark(c->arena_off) {}
+  ~ArenaScope() { ctx->arena_off = mark; }
+};
+#define ARENA(T, var, count)                                                     \
+  T* var = arena_alloc<T>(ctx, (size_t)(count));                                 \
+  if (!var) return set_err(ctx, EOFX_ERR_NOMEM, "internal: arena exhausted (%s)", #var)
+
+static int set_device(eofx_ctx* ctx) {
+  HIPCHK(hipSetDevice(ctx->device));
+  return EOFX_OK;
+}
+
+extern "C" int eofx_abi_version(void) { return EOFX_ABI_VERSION; }
+
+extern "C" int eofx_ctx_create(int device, void* stream, eofx_ctx** out) {
+  if (!out) return EOFX_ERR_ARG;
+  eofx_ctx* ctx = new eofx_ctx();
+  ctx->device = device;
+  ctx->stream = (hipStream_t)stream;
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess) {
+    delete ctx;
+    *out = nullptr;
+    return EOFX_ERR_HIP;
+  }
+  *out = ctx;
+  return EOFX_OK;
+}
+extern "C" int eofx_ctx_destroy(eofx_ctx* ctx) {
+  if (!ctx) return EOFX_OK;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->arena) {
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(ctx->arena);
+  }
+  delete ctx;
+  return EOFX_OK;
+}
+extern "C" int eofx_ctx_synchronize(eofx_ctx* ctx) {
+  if (!ctx) return EOFX_ERR_ARG;
+  CHK(set_device(ctx));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return EOFX_OK;
+}
+extern "C" const char* eofx_last_error(const eofx_ctx* ctx) { return ctx ? ctx->err.c_str() : ""; }
+
+// copy device -> user pointer (host or device)
+static int copy_out(eofx_ctx* ctx, void* dst, const void* src_dev, size_t bytes) {
+  if (!dst || bytes == 0) return EOFX_OK;
+  HIPCHK(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDefault, ctx->stream));
+  return EOFX_OK;
+}
+static int copy_in(eofx_ctx* ctx, void* dst_dev, const void* src, size_t bytes) {
+  if (bytes == 0) return EOFX_OK;
+  HIPCHK(hipMemcpyAsync(dst_dev, src, bytes, hipMemcpyDefault, ctx->stream));
+  return EOFX_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// small host linear algebra
+// ------------------------------------------------------------------------------------
+extern "C" int eofx_host_eigh_f64(const double* Ain, int n, double* w, double* Vec) {
+  if (!Ain || !w || !Vec || n <= 0) return EOFX_ERR_ARG;
+  std::vector<double> A(Ain, Ain + (size_t)n * n), V((size_t)n * n, 0.0);
+  for (int i = 0; i < n; ++i) V[(size_t)i * n + i] = 1.0;
+  double total = 0.0;
+  for (size_t i = 0; i < A.size(); ++i) total += A[i] * A[i];
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0.0;
+    for (int i = 0; i < n; ++i)
+      for (int j = i + 1; j < n; ++j) off += A[(size_t)i * n + j] * A[(size_t)i * n + j];
+    if (off <= 1e-32 * total || off == 0.0) break;
+    for (int p = 0; p < n - 1; ++p)
+      for (int q = p + 1; q < n; ++q) {
+        const double apq = A[(size_t)p * n + q];
+        if (apq == 0.0) continue;
+        const double app = A[(size_t)p * n + p], aqq = A[(size_t)q * n + q];
+        const double tau = (aqq - app) / (2.0 * apq);
+        const double t = (tau >= 0 ? 1.0 : -1.0) / (std::fabs(tau) + std::sqrt(1.0 + tau * tau));
+        const double c = 1.0 / std::sqrt(1.0 + t * t), s = t * c;
+        for (int k = 0; k < n; ++k) {
+          const double akp = A[(size_t)k * n + p], akq = A[(size_t)k * n + q];
+          A[(size_t)k * n + p] = c * akp - s * akq;
+          A[(size_t)k * n + q] = s * akp + c * akq;
+        }
+        for (int k = 0; k < n; ++k) {
+          const double apk = A[(size_t)p * n + k], aqk = A[(size_t)q * n + k];
+          A[(size_t)p * n + k] = c * apk - s * aqk;
+          A[(size_t)q * n + k] = s * apk + c * aqk;
+        }
+        for (int k = 0; k < n; ++k) {
+          const double vkp = V[(size_t)k * n + p], vkq = V[(size_t)k * n + q];
+          V[(size_t)k * n + p] = c * vkp - s * vkq;
+          V[(size_t)k * n + q] = s * vkp + c * vkq;
+        }
+      }
+  }
+  std::vector<int> idx(n);
+  for (int i = 0; i < n; ++i) idx[i] = i;
+  std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) {
+    return A[(size_t)a * n + a] > A[(size_t)b * n + b];
+  });
+  for (int j = 0; j < n; ++j) {
+    w[j] = A[(size_t)idx[j] * n + idx[j]];
+    for (int i = 0; i < n; ++i) Vec[(size_t)i * n + j] = V[(size_t)i * n + idx[j]];
+  }
+  return EOFX_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// kernel launchers
+// ------------------------------------------------------------------------------------
+struct AtbPlan {
+  int S;
+  int64_t kps;
+};
+// split-K factor from a small cost model: 512 resident workgroups, ~10 GB/s of A per
+// workgroup slot, partial-sum traffic at ~4 TB/s.
+static AtbPlan atb_plan(int64_t M, int64_t K, int L) {
+  const int bx = (int)(M / ATB_BM);
+  const int bz = (L + 63) / 64;
+  AtbPlan best{1, K};
+  double best_t = 1e30;
+  for (int S = 1; S <= 128; ++S) {
+    const int64_t kps = round_up((K + S - 1) / S, ATB_KG);
+    const int s_eff = (int)((K + kps - 1) / kps);
+    if (s_eff != S) continue;
+    const double blocks = (double)bx * bz * s_eff;
+    const double rounds = std::ceil(blocks / 512.0);
+    double t = rounds * (double)kps * 2048.0 / 1.0e10;
+    if (s_eff > 1) t += (2.0 * s_eff + 1.0) * (double)M * L * 4.0 / 4.0e12;
+    if (t < best_t * 0.98) {
+      best_t = t;
+      best = {s_eff, kps};
+    }
+  }
+  return best;
+}
+static size_t atb_scratch_bytes(int64_t M, int64_t K, int L) {
+  const AtbPlan pl = atb_plan(M, K, L);
+  return pl.S > 1 ? (size_t)pl.S * M * L * sizeof(float) + 4096 : 4096;
+}
+
+// C[M x L] = A[K x M]^T B[K x L]; M multiple of 512, K multiple of 16, L multiple of 32.
+static int launch_atb(eofx_ctx* ctx, const float* A, int64_t lda, int64_t K, int64_t M,
+                      const float* B, int ldb, int L, float* C) {
+  if (M % ATB_BM || K % ATB_KG || L % 32 || L <= 0)
+    return set_err(ctx, EOFX_ERR_ARG, "atb: bad geometry M=%lld K=%lld L=%d", (long long)M,
+                   (long long)K, L);
+  const int bx = (int)(M / ATB_BM);
+  const int nfull = L / 64, rem = L % 64;
+  const AtbPlan plan = atb_plan(M, K, L);
+  int best_s = plan.S;
+  int64_t best_kps = plan.kps;
+  ArenaScope scope(ctx);
+  float* out = C;
+  if (best_s > 1) {
+    out = arena_alloc<float>(ctx, (size_t)best_s * M * L);
+    if (!out) {  // no room for partials: fall back to a single split (still correct)
+      best_s = 1;
+      best_kps = K;
+      out = C;
+    }
+  }
+  if (nfull > 0) {
+    dim3 grid(bx, best_s, nfull);
+    hipLaunchKernelGGL(atb_f32_kernel<2>, grid, dim3(256), 0, ctx->stream, A, lda, B, ldb, out, L, M,
+                       K, best_kps, 0);
+    KCHK();
+  }
+  if (rem) {
+    dim3 grid(bx, best_s, 1);
+    hipLaunchKernelGGL(atb_f32_kernel<1>, grid, dim3(256), 0, ctx->stream, A, lda, B, ldb, out, L, M,
+                       K, best_kps, nfull * 64);
+    KCHK();
+  }
+  if (best_s > 1) {
+    const int64_t count4 = M * L / 4;
+    const int blocks = (int)std::min<int64_t>((count4 + 255) / 256, 4096);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, ctx->stream, out, C, count4,
+                       best_s);
+    KCHK();
+  }
+  return EOFX_OK;
+}
+
+
+static int launch_gram(eofx_ctx* ctx, const float* P, int64_t rows, int L, double* G) {
+  const int nb = (L + 63) / 64;
+  const int nbx = (int)std::min<int64_t>((rows + 31) / 32, 256);
+  ArenaScope scope(ctx);
+  ARENA(double, part, (size_t)nbx * L * L);
+  hipLaunchKernelGGL(gram_f64_kernel, dim3(nbx, nb * nb), dim3(256), 0, ctx->stream, P, rows, L, part);
+  KCHK();
+  const int64_t count = (int64_t)L * L;
+  hipLaunchKernelGGL(f64_reduce_kernel, dim3((int)((count + 255) / 256)), dim3(256), 0, ctx->stream,
+                     part, G, count, nbx);
+  KCHK();
+  return EOFX_OK;
+}
+
+static int launch_matmul(eofx_ctx* ctx, const float* P, int64_t rows, int L, const double* Mx, int Lo,
+                         float* out) {
+  dim3 grid((int)((rows + 63) / 64), (Lo + 63) / 64);
+  hipLaunchKernelGGL(panel_matmul_kernel, grid, dim3(256), 0, ctx->stream, P, rows, L, Mx, Lo, out);
+  KCHK();
+  return EOFX_OK;
+}
+
+// out = P R^-1 with G = R^T R (leading l x l block)
+static int launch_cholqr(eofx_ctx* ctx, const float* P, int64_t rows, int L, int l, const double* G,
+                         float* out) {
+  if (l > 64) return set_err(ctx, EOFX_ERR_ARG, "cholqr: sketch width %d > 64 not supported yet", l);
+  ArenaScope scope(ctx);
+  ARENA(double, Rinv, (size_t)L * L);
+  hipLaunchKernelGGL(chol_rinv_kernel, dim3(1), dim3(256), 0, ctx->stream, G, L, l, Rinv, 1e-13);
+  KCHK();
+  return launch_matmul(ctx, P, rows, L, Rinv, L, out);
+}
+
+static int launch_colminmax(eofx_ctx* ctx, const float* P, int64_t rows, int L, float* mx, float* mn) {
+  const int nparts = (int)std::min<int64_t>((rows + 3) / 4, 512);
+  ArenaScope scope(ctx);
+  ARENA(float, pmx, (size_t)nparts * L);
+  ARENA(float, pmn, (size_t)nparts * L);
+  hipLaunchKernelGGL(colminmax_part_kernel, dim3(nparts, (L + 63) / 64), dim3(256), 0, ctx->stream, P,
+                     rows, L, pmx, pmn);
+  KCHK();
+  hipLaunchKernelGGL(colminmax_final_kernel, dim3((L + 63) / 64), dim3(64), 0, ctx->stream, pmx, pmn,
+                     nparts, L, mx, mn);
+  KCHK();
+  return EOFX_OK;
+}
+
+// dense [rows x k] export to a host|device destination, optional column signs (host doubles)
+static int export_panel(eofx_ctx* ctx, const float* P, int64_t rows, int L, int k, const double* sign,
+                        float* dst) {
+  if (!dst) return EOFX_OK;
+  ArenaScope scope(ctx);
+  double* dsign = nullptr;
+  if (sign) {
+    dsign = arena_alloc<double>(ctx, k);
+    if (!dsign) return set_err(ctx, EOFX_ERR_NOMEM, "arena exhausted (export sign)");
+    CHK(copy_in(ctx, dsign, sign, sizeof(double) * k));
+  }
+  float* tmp = dst;
+  const bool dev = is_device_ptr(dst);
+  if (!dev) {
+    tmp = arena_alloc<float>(ctx, (size_t)rows * k);
+    if (!tmp) return set_err(ctx, EOFX_ERR_NOMEM, "arena exhausted (export staging)");
+  }
+  const int64_t total = rows * k;
+  const int blocks = (int)std::min<int64_t>((total + 255) / 256, 8192);
+  hipLaunchKernelGGL(panel_export_kernel, dim3(blocks), dim3(256), 0, ctx->stream, P, rows, L, k, dsign,
+                     tmp);
+  KCHK();
+  if (!dev) {
+    CHK(copy_out(ctx, dst, tmp, sizeof(float) * total));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
+  return EOFX_OK;
+}
+
+static int import_panel(eofx_ctx* ctx, const float* src, int64_t rows, int l, float* P, int64_t rows_pad,
+                        int L) {
+  ArenaScope scope(ctx);
+  const float* dsrc = src;
+  if (!is_device_ptr(src)) {
+    float* tmp = arena_alloc<float>(ctx, (size_t)rows * l);
+    if (!tmp) return set_err(ctx, EOFX_ERR_NOMEM, "arena exhausted (import staging)");
+    CHK(copy_in(ctx, tmp, src, sizeof(float) * rows * l));
+    dsrc = tmp;
+  }
+  const int64_t total = rows_pad * L;
+  const int blocks = (int)std::min<int64_t>((total + 255) / 256, 8192);
+  hipLaunchKernelGGL(panel_import_kernel, dim3(blocks), dim3(256), 0, ctx->stream, dsrc, rows, l, P,
+                     rows_pad, L);
+  KCHK();
+  if (dsrc != src) HIPCHK(hipStreamSynchronize(ctx->stream));  // staging is released on return
+  return EOFX_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// resident matrix
+// ------------------------------------------------------------------------------------
+static int mat_alloc(eofx_ctx* ctx, int64_t n, int64_t p, eofx_mat** out) {
+  eofx_mat* m = new eofx_mat();
+  m->n = n;
+  m->p = p;
+  m->n_pad = round_up(n, ATB_BM);
+  m->p_pad = round_up(p, ATB_BM);
+  const size_t bytes = (size_t)m->n_pad * m->p_pad * sizeof(float);
+  hipError_t e = hipMalloc((void**)&m->X, bytes);
+  if (e == hipSuccess) e = hipMalloc((void**)&m->Xt, bytes);
+  if (e != hipSuccess) {
+    if (m->X) (void)hipFree(m->X);
+    delete m;
+    (void)hipGetLastError();
+    return set_err(ctx, EOFX_ERR_NOMEM, "cannot allocate resident matrix %lld x %lld (2 x %.2f GB): %s",
+                   (long long)n, (long long)p, bytes / 1e9, hipGetErrorString(e));
+  }
+  *out = m;
+  return EOFX_OK;
+}
+
+extern "C" int eofx_mat_destroy(eofx_ctx* ctx, eofx_mat* m) {
+  if (!m) return EOFX_OK;
+  if (ctx) {
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+  }
+  if (m->X) (void)hipFree(m->X);
+  if (m->Xt) (void)hipFree(m->Xt);
+  delete m;
+  return EOFX_OK;
+}
+extern "C" int eofx_mat_shape(const eofx_mat* m, int64_t* n, int64_t* p, int64_t* n_pad, int64_t* p_pad) {
+  if (!m) return EOFX_ERR_ARG;
+  if (n) *n = m->n;
+  if (p) *p = m->p;
+  if (n_pad) *n_pad = m->n_pad;
+  if (p_pad) *p_pad = m->p_pad;
+  return EOFX_OK;
+}
+
+// stage a host matrix on the device (hipMalloc'ed, caller frees); device input passes through
+struct Staged {
+  const float* dev = nullptr;
+  float* owned = nullptr;
+  ~Staged() {
+    if (owned) (void)hipFree(owned);
+  }
+};
+static int stage_input(eofx_ctx* ctx, const float* X, size_t count, Staged& st) {
+  if (is_device_ptr(X)) {
+    st.dev = X;
+    return EOFX_OK;
+  }
+  HIPCHK(hipMalloc((void**)&st.owned, count * sizeof(float)));
+  HIPCHK(hipMemcpyAsync(st.owned, X, count * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  st.dev = st.owned;
+  return EOFX_OK;
+}
+
+static int launch_apply(eofx_ctx* ctx, const float* Xsrc, int64_t ld_src, const int64_t* row_map,
+                        const int64_t* col_map, const double* shift, const double* scale, eofx_mat* m,
+                        int* nan_flag) {
+  dim3 grid((int)(m->p_pad / 64), (int)(m->n_pad / 64));
+  hipLaunchKernelGGL(apply_kernel, grid, dim3(256), 0, ctx->stream, Xsrc, ld_src, row_map, col_map,
+                     shift, scale, m->n, m->p, m->X, m->p_pad, m->Xt, m->n_pad, nan_flag);
+  KCHK();
+  return EOFX_OK;
+}
+
+extern "C" int eofx_mat_from_dense_f32(eofx_ctx* ctx, const float* X, int64_t n, int64_t p, int64_t ld,
+                                       eofx_mat** out) {
+  if (!ctx || !X || !out || n <= 0 || p <= 0 || ld < p) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  CHK(set_device(ctx));
+  Staged st;
+  CHK(stage_input(ctx, X, (size_t)n * ld, st));
+  eofx_mat* m = nullptr;
+  CHK(mat_alloc(ctx, n, p, &m));
+  CHK(arena_reserve(ctx, 1 << 20));
+  ArenaScope scope(ctx);
+  ARENA(int, flag, 1);
+  HIPCHK(hipMemsetAsync(flag, 0, sizeof(int), ctx->stream));
+  int rc = launch_apply(ctx, st.dev, ld, nullptr, nullptr, nullptr, nullptr, m, flag);
+  if (rc == EOFX_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = EOFX_ERR_HIP;
+  if (rc != EOFX_OK) {
+    eofx_mat_destroy(ctx, m);
+    return rc;
+  }
+  *out = m;
+  return EOFX_OK;
+}
+
+extern "C" int eofx_mat_download_f32(eofx_ctx* ctx, const eofx_mat* m, float* dst) {
+  if (!ctx || !m || !dst) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  CHK(set_device(ctx));
+  const int64_t total = m->n * m->p;
+  const bool dev = is_device_ptr(dst);
+  float* tmp = dst;
+  if (!dev) HIPCHK(hipMalloc((void**)&tmp, total * sizeof(float)));
+  const int blocks = (int)std::min<int64_t>((total + 255) / 256, 16384);
+  hipLaunchKernelGGL(mat_download_kernel, dim3(blocks), dim3(256), 0, ctx->stream, m->X, m->p_pad, m->n,
+                     m->p, tmp);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess && !dev) e = hipMemcpyAsync(dst, tmp, total * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (!dev) (void)hipFree(tmp);
+  if (e != hipSuccess) return set_err(ctx, EOFX_ERR_HIP, "download failed: %s", hipGetErrorString(e));
+  return EOFX_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// fused preprocessor
+// ------------------------------------------------------------------------------------
+struct PreState {  // device arrays of length P
+  int* cnt;
+  double *mean, *stdv, *shift, *scale, *m2;
+};
+
+static int run_colstats(eofx_ctx* ctx, const float* Xd, int64_t n, int64_t P, int center, int standardize,
+                        const double* w_dev, PreState& ps) {
+  const int gx = (int)((P + 255) / 256);
+  int64_t RS = std::max<int64_t>(1, (2048 + gx - 1) / gx);
+  RS = std::min<int64_t>(RS, std::max<int64_t>(1, n / 64));
+  const int64_t rps = (n + RS - 1) / RS;
+  RS = (n + rps - 1) / rps;
+  ArenaScope scope(ctx);
+  ARENA(int, cnt_p, (size_t)RS * P);
+  ARENA(double, sum_p, (size_t)RS * P);
+  ARENA(double, sq_p, (size_t)RS * P);
+  hipLaunchKernelGGL(colstats_kernel, dim3(gx, (int)RS), dim3(256), 0, ctx->stream, Xd, n, P, rps, cnt_p,
+                     sum_p, sq_p);
+  KCHK();
+  hipLaunchKernelGGL(colstats_finalize_kernel, dim3(gx), dim3(256), 0, ctx->stream, cnt_p, sum_p, sq_p,
+                     (int)RS, P, center, standardize, w_dev, (double)1.1920928955078125e-07, ps.cnt,
+                     ps.mean, ps.stdv, ps.shift, ps.scale, ps.m2);
+  KCHK();
+  return EOFX_OK;
+}
+
+static size_t colstats_scratch(int64_t n, int64_t P) {
+  const int64_t gx = (P + 255) / 256;
+  int64_t RS = std::max<int64_t>(1, (2048 + gx - 1) / gx);
+  RS = std::min<int64_t>(RS, std::max<int64_t>(1, n / 64));
+  return (size_t)(RS + 1) * P * 24 + (size_t)P * 64 + (size_t)n * 16 + (1 << 20);
+}
+
+// shared tail of preprocess/apply: NaN policy, maps, allocation, apply kernel
+static int sanitize_and_apply(eofx_ctx* ctx, const float* Xd, int64_t n, int64_t P, PreState& ps,
+                              const uint8_t* expect_valid, int check_nans, eofx_mat** out,
+                              uint8_t* valid_feature, uint8_t* valid_sample, int64_t* n_out,
+                              int64_t* p_out, std::vector<int>& hcnt) {
+  hcnt.resize(P);
+  HIPCHK(hipMemcpyAsync(hcnt.data(), ps.cnt, sizeof(int) * P, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  int64_t pv = 0;
+  int cmax = 0, cmin = INT32_MAX;
+  for (int64_t c = 0; c < P; ++c) {
+    const int k = hcnt[c];
+    if (k > 0) {
+      ++pv;
+      cmax = std::max(cmax, k);
+      cmin = std::min(cmin, k);
+    }
+    if (valid_feature) valid_feature[c] = k > 0;
+    if (expect_valid && check_nans && (expect_valid[c] != 0) != (k > 0))
+      return set_err(ctx, EOFX_ERR_NAN_MISMATCH,
+                     "Input data had NaN features in different locations than the original data.");
+  }
+  if (pv == 0) return set_err(ctx, EOFX_ERR_ARG, "input has no valid (non-NaN) feature");
+  static const char* kPartial =
+      "Input data contains partial NaN entries, which will cause the the SVD to fail.";
+  if (check_nans && cmin != cmax) return set_err(ctx, EOFX_ERR_PARTIAL_NAN, kPartial);
+  std::vector<int64_t> row_map;
+  int64_t ns = n;
+  if (check_nans && cmax < n) {  // some samples are missing entirely: find which
+    ArenaScope scope(ctx);
+    ARENA(int, rowcnt, (size_t)n);
+    hipLaunchKernelGGL(rowcount_kernel, dim3((int)n), dim3(256), 0, ctx->stream, Xd, n, P, ps.cnt, rowcnt);
+    KCHK();
+    std::vector<int> hrow(n);
+    HIPCHK(hipMemcpyAsync(hrow.data(), rowcnt, sizeof(int) * n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ns = 0;
+    for (int64_t r = 0; r < n; ++r) {
+      if (hrow[r] != 0 && hrow[r] != pv) return set_err(ctx, EOFX_ERR_PARTIAL_NAN, kPartial);
+      if (hrow[r] > 0) {
+        row_map.push_back(r);
+        ++ns;
+      }
+      if (valid_sample) valid_sample[r] = hrow[r] > 0;
+    }
+  } else if (valid_sample) {
+    std::memset(valid_sample, 1, (size_t)n);
+  }
+  if (n_out) *n_out = ns;
+  if (p_out) *p_out = pv;
+  if (!out) return EOFX_OK;
+
+  eofx_mat* m = nullptr;
+  CHK(mat_alloc(ctx, ns, pv, &m));
+  int rc = EOFX_OK;
+  {
+    ArenaScope scope(ctx);
+    int64_t* dcol = nullptr;
+    int64_t* drow = nullptr;
+    int* flag = arena_alloc<int>(ctx, 1);
+    if (pv < P) {
+      std::vector<int64_t> col_map;
+      col_map.reserve(pv);
+      for (int64_t c = 0; c < P; ++c)
+        if (hcnt[c] > 0) col_map.push_back(c);
+      dcol = arena_alloc<int64_t>(ctx, pv);
+      if (dcol && hipMemcpyAsync(dcol, col_map.data(), sizeof(int64_t) * pv, hipMemcpyHostToDevice,
+                                 ctx->stream) != hipSuccess)
+        rc = EOFX_ERR_HIP;
+      if (rc == EOFX_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = EOFX_ERR_HIP;
+    }
+    if (rc == EOFX_OK && !row_map.empty() && ns < n) {
+      drow = arena_alloc<int64_t>(ctx, ns);
+      if (drow && hipMemcpyAsync(drow, row_map.data(), sizeof(int64_t) * ns, hipMemcpyHostToDevice,
+                                 ctx->stream) != hipSuccess)
+        rc = EOFX_ERR_HIP;
+      if (rc == EOFX_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = EOFX_ERR_HIP;
+    }
+    if (!flag || (pv < P && !dcol) || (ns < n && !drow)) rc = set_err(ctx, EOFX_ERR_NOMEM, "arena exhausted (maps)");
+    if (rc == EOFX_OK && hipMemsetAsync(flag, 0, sizeof(int), ctx->stream) != hipSuccess) rc = EOFX_ERR_HIP;
+    if (rc == EOFX_OK) rc = launch_apply(ctx, Xd, P, drow, dcol, ps.shift, ps.scale, m, flag);
+    if (rc == EOFX_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = EOFX_ERR_HIP;
+  }
+  if (rc != EOFX_OK) {
+    eofx_mat_destroy(ctx, m);
+    if (rc == EOFX_ERR_HIP) set_err(ctx, rc, "HIP failure in apply: %s", hipGetErrorString(hipGetLastError()));
+    return rc;
+  }
+  *out = m;
+  return EOFX_OK;
+}
+
+extern "C" int eofx_preprocess_f32(eofx_ctx* ctx, const float* X, int64_t n, int64_t P, int center,
+                                   int standardize, const double* feat_weights, int check_nans,
+                                   eofx_mat** out, double* mean, double* std_, uint8_t* valid_feature,
+                                   uint8_t* valid_sample, int64_t* n_out, int64_t* p_out,
+                                   double* total_variance) {
+  if (!ctx || !X || n <= 0 || P <= 0) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  CHK(set_device(ctx));
+  Staged st;
+  CHK(stage_input(ctx, X, (size_t)n * P, st));
+  CHK(arena_reserve(ctx, colstats_scratch(n, P)));
+  ArenaScope scope(ctx);
+  PreState ps;
+  ARENA(int, cnt, P);
+  ARENA(double, dmean, P);
+  ARENA(double, dstd, P);
+  ARENA(double, dshift, P);
+  ARENA(double, dscale, P);
+  ARENA(double, dm2, P);
+  ps = {cnt, dmean, dstd, dshift, dscale, dm2};
+  double* wdev = nullptr;
+  if (feat_weights) {
+    wdev = arena_alloc<double>(ctx, P);
+    if (!wdev) return set_err(ctx, EOFX_ERR_NOMEM, "arena exhausted (weights)");
+    CHK(copy_in(ctx, wdev, feat_weights, sizeof(double) * P));
+  }
+  CHK(run_colstats(ctx, st.dev, n, P, center, standardize, wdev, ps));
+  std::vector<int> hcnt;
+  int64_t ns = 0, pv = 0;
+  CHK(sanitize_and_apply(ctx, st.dev, n, P, ps, nullptr, check_nans, out, valid_feature, valid_sample, &ns,
+                         &pv, hcnt));
+  if (n_out) *n_out = ns;
+  if (p_out) *p_out = pv;
+  if (mean) HIPCHK(hipMemcpyAsync(mean, ps.mean, sizeof(double) * P, hipMemcpyDeviceToHost, ctx->stream));
+  if (std_) HIPCHK(hipMemcpyAsync(std_, ps.stdv, sizeof(double) * P, hipMemcpyDeviceToHost, ctx->stream));
+  if (total_variance) {
+    std::vector<double> hm2(P), hsc(P);
+    HIPCHK(hipMemcpyAsync(hm2.data(), ps.m2, sizeof(double) * P, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(hsc.data(), ps.scale, sizeof(double) * P, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    double tv = 0.0;
+    for (int64_t c = 0; c < P; ++c)
+      if (hcnt[c] > 0) tv += hsc[c] * hsc[c] * hm2[c] / (double)(hcnt[c] - 1);
+    *total_variance = tv;
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return EOFX_OK;
+}
+
+extern "C" int eofx_apply_f32(eofx_ctx* ctx, const float* X, int64_t n, int64_t P, const double* mean,
+                              const double* std_, const double* feat_weights, const uint8_t* valid_feature,
+                              int check_nans, eofx_mat** out, uint8_t* valid_sample, int64_t* n_out) {
+  if (!ctx || !X || !out || n <= 0 || P <= 0) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  CHK(set_device(ctx));
+  Staged st;
+  CHK(stage_input(ctx, X, (size_t)n * P, st));
+  CHK(arena_reserve(ctx, colstats_scratch(n, P)));
+  ArenaScope scope(ctx);
+  PreState ps;
+  ARENA(int, cnt, P);
+  ARENA(double, dmean, P);
+  ARENA(double, dstd, P);
+  ARENA(double, dshift, P);
+  ARENA(double, dscale, P);
+  ARENA(double, dm2, P);
+  ps = {cnt, dmean, dstd, dshift, dscale, dm2};
+  CHK(run_colstats(ctx, st.dev, n, P, 0, 0, nullptr, ps));
+  // overwrite shift/scale with the fitted state
+  std::vector<double> hshift(P, 0.0), hscale(P, 1.0);
+  for (int64_t c = 0; c < P; ++c) {
+    if (mean) hshift[c] = mean[c];
+    double s = 1.0;
+    if (std_) s /= std_[c];
+    if (feat_weights) s *= feat_weights[c];
+    hscale[c] = s;
+    if (!(hshift[c] == hshift[c])) hshift[c] = 0.0;  // NaN stats belong to dropped features
+    if (!(hscale[c] == hscale[c])) hscale[c] = 0.0;
+  }
+  CHK(copy_in(ctx, ps.shift, hshift.data(), sizeof(double) * P));
+  CHK(copy_in(ctx, ps.scale, hscale.data(), sizeof(double) * P));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  std::vector<int> hcnt;
+  int64_t ns = 0, pv = 0;
+  CHK(sanitize_and_apply(ctx, st.dev, n, P, ps, valid_feature, check_nans, out, nullptr, valid_sample, &ns,
+                         &pv, hcnt));
+  if (n_out) *n_out = ns;
+  return EOFX_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// panel-level ABI
+// ------------------------------------------------------------------------------------
+static int panel_tmul(eofx_ctx* ctx, const eofx_mat* m, const float* Zn, float* Yp, int L) {
+  return launch_atb(ctx, m->X, m->p_pad, round_up(m->n, ATB_KG), m->p_pad, Zn, L, L, Yp);
+}
+static int panel_mul(eofx_ctx* ctx, const eofx_mat* m, const float* Yp, float* Wn, int L) {
+  return launch_atb(ctx, m->Xt, m->n_pad, round_up(m->p, ATB_KG), m->n_pad, Yp, L, L, Wn);
+}
+
+extern "C" int eofx_panel_tmul_f32(eofx_ctx* ctx, const eofx_mat* m, const float* Zn, float* Yp, int L) {
+  if (!ctx || !m || !Zn || !Yp) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  CHK(set_device(ctx));
+  CHK(arena_reserve(ctx, atb_scratch_bytes(m->p_pad, round_up(m->n, ATB_KG), L)));
+  return panel_tmul(ctx, m, Zn, Yp, L);
+}
+extern "C" int eofx_panel_mul_f32(eofx_ctx* ctx, const eofx_mat* m, const float* Yp, float* Wn, int L) {
+  if (!ctx || !m || !Wn || !Yp) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  CHK(set_device(ctx));
+  CHK(arena_reserve(ctx, atb_scratch_bytes(m->n_pad, round_up(m->p, ATB_KG), L)));
+  return panel_mul(ctx, m, Yp, Wn, L);
+}
+extern "C" int eofx_panel_gram_f64(eofx_ctx* ctx, const float* P, int64_t rows_pad, int L, double* G) {
+  if (!ctx || !P || !G || L % 32) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  CHK(set_device(ctx));
+  CHK(arena_reserve(ctx, (size_t)257 * L * L * sizeof(double)));
+  return launch_gram(ctx, P, rows_pad, L, G);
+}
+extern "C" int eofx_panel_cholqr_f32(eofx_ctx* ctx, const float* P, int64_t rows_pad, int L, int l,
+                                     const double* G, float* out) {
+  if (!ctx || !P || !G || !out || P == out) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  CHK(set_device(ctx));
+  CHK(arena_reserve(ctx, (size_t)2 * L * L * sizeof(double)));
+  return launch_cholqr(ctx, P, rows_pad, L, l, G, out);
+}
+extern "C" int eofx_panel_matmul_f32(eofx_ctx* ctx, const float* P, int64_t rows_pad, int L,
+                                     const double* M, int Lo, float* out) {
+  if (!ctx || !P || !M || !out || P == out) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  CHK(set_device(ctx));
+  return launch_matmul(ctx, P, rows_pad, L, M, Lo, out);
+}
+extern "C" int eofx_panel_colminmax_f32(eofx_ctx* ctx, const float* P, int64_t rows, int L, float* mx,
+                                        float* mn) {
+  if (!ctx || !P || !mx || !mn) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  CHK(set_device(ctx));
+  CHK(arena_reserve(ctx, (size_t)2 * 512 * L * sizeof(float) + 4096));
+  return launch_colminmax(ctx, P, rows, L, mx, mn);
+}
+extern "C" int eofx_panel_export_f32(eofx_ctx* ctx, const float* P, int64_t rows, int L, int k,
+                                     const double* sign, float* dst) {
+  if (!ctx || !P || !dst || k > L) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  CHK(set_device(ctx));
+  CHK(arena_reserve(ctx, (size_t)rows * k * sizeof(float) + 8192));
+  return export_panel(ctx, P, rows, L, k, sign, dst);
+}
+extern "C" int eofx_panel_import_f32(eofx_ctx* ctx, const float* src, int64_t rows, int l, float* P,
+                                     int64_t rows_pad, int L) {
+  if (!ctx || !P || !src || l > L || rows > rows_pad) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  CHK(set_device(ctx));
+  CHK(arena_reserve(ctx, (size_t)rows * l * sizeof(float) + 8192));
+  return import_panel(ctx, src, rows, l, P, rows_pad, L);
+}
+
+// ------------------------------------------------------------------------------------
+// randomized SVD core on an abstract tall operator A (tall x small)
+// ------------------------------------------------------------------------------------
+struct LinOp {
+  int64_t tall, small, tall_pad, small_pad;
+  std::function<int(const float*, float*, int)> fwd;  // tall panel  = A   * small panel
+  std::function<int(const float*, float*, int)> bwd;  // small panel = A^T * tall panel
+};
+
+struct RsvdOut {
+  float* Tvec;  // [tall_pad x Lo]   singular vectors on the tall side
+  float* Svec;  // [small_pad x Lo]  singular vectors on the small side
+  int Lo;
+  std::vector<double> s;  // singular values, descending (k of them)
+};
+
+static int rsvd_auto_iters(int k, int64_t n, int64_t p) {
+  // sklearn extmath._randomized_svd: n_iter = 7 if n_components < 0.1 * min(M.shape) else 4
+  return ((double)k < 0.1 * (double)std::min(n, p)) ? 7 : 4;
+}
+
+// All panels are carved from the arena by the caller-visible drivers (reserve first).
+static int rsvd_core(eofx_ctx* ctx, const LinOp& op, int k, int l, int n_iter, const float* omega,
+                     RsvdOut& out) {
+  const int L = (int)round_up(l, 32);
+  const int Lo = (int)round_up(k, 32);
+  ARENA(float, Zs, (size_t)op.small_pad * L);
+  ARENA(float, Ws, (size_t)op.small_pad * L);
+  ARENA(float, Yt, (size_t)op.tall_pad * L);
+  ARENA(float, Qt, (size_t)op.tall_pad * L);
+  ARENA(float, Tv, (size_t)op.tall_pad * Lo);
+  ARENA(float, Sv, (size_t)op.small_pad * Lo);
+  ARENA(double, G, (size_t)L * L);
+  ARENA(double, Md, (size_t)L * Lo);
+
+  CHK(import_panel(ctx, omega, op.small, l, Zs, op.small_pad, L));
+  // power iterations: Z <- orth(A^T (A Z)).  Only the small-side panel is orthonormalised
+  // (Cholesky-QR with a float64 Gram matrix); the tall panel is never factorised here.
+  for (int it = 0; it < n_iter; ++it) {
+    CHK(op.fwd(Zs, Yt, L));
+    CHK(op.bwd(Yt, Ws, L));
+    CHK(launch_gram(ctx, Ws, op.small_pad, L, G));
+    CHK(launch_cholqr(ctx, Ws, op.small_pad, L, l, G, Zs));
+  }
+  // range basis on the tall side: Q = orth(A Z), CholeskyQR2
+  CHK(op.fwd(Zs, Yt, L));
+  CHK(launch_gram(ctx, Yt, op.tall_pad, L, G));
+  CHK(launch_cholqr(ctx, Yt, op.tall_pad, L, l, G, Qt));
+  CHK(launch_gram(ctx, Qt, op.tall_pad, L, G));
+  CHK(launch_cholqr(ctx, Qt, op.tall_pad, L, l, G, Yt));  // Q now in Yt
+  // B^T = A^T Q  (small x l);  B B^T = (B^T)^T (B^T)
+  CHK(op.bwd(Yt, Ws, L));
+  CHK(launch_gram(ctx, Ws, op.small_pad, L, G));
+  std::vector<double> hG((size_t)L * L);
+  HIPCHK(hipMemcpyAsync(hG.data(), G, sizeof(double) * L * L, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  std::vector<double> Gl((size_t)l * l), w(l), Uh((size_t)l * l);
+  for (int i = 0; i < l; ++i)
+    for (int j = 0; j < l; ++j) {
+      const double v = 0.5 * (hG[(size_t)i * L + j] + hG[(size_t)j * L + i]);
+      if (!std::isfinite(v))
+        return set_err(ctx, EOFX_ERR_LINALG,
+                       "SVD failed. This may be due to isolated NaN values in the data.");
+      Gl[(size_t)i * l + j] = v;
+    }
+  eofx_host_eigh_f64(Gl.data(), l, w.data(), Uh.data());
+  out.s.assign(k, 0.0);
+  std::vector<double> M1((size_t)L * Lo, 0.0), M2((size_t)L * Lo, 0.0);
+  for (int j = 0; j < k; ++j) {
+    const double sv = std::sqrt(std::max(w[j], 0.0));
+    out.s[j] = sv;
+    const double inv = sv > 0.0 ? 1.0 / sv : 0.0;
+    for (int i = 0; i < l; ++i) {
+      M1[(size_t)i * Lo + j] = Uh[(size_t)i * l + j];
+      M2[(size_t)i * Lo + j] = Uh[(size_t)i * l + j] * inv;
+    }
+  }
+  HIPCHK(hipMemcpyAsync(Md, M1.data(), sizeof(double) * L * Lo, hipMemcpyHostToDevice, ctx->stream));
+  CHK(launch_matmul(ctx, Yt, op.tall_pad, L, Md, Lo, Tv));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipMemcpyAsync(Md, M2.data(), sizeof(double) * L * Lo, hipMemcpyHostToDevice, ctx->stream));
+  CHK(launch_matmul(ctx, Ws, op.small_pad, L, Md, Lo, Sv));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  out.Tvec = Tv;
+  out.Svec = Sv;
+  out.Lo = Lo;
+  return EOFX_OK;
+}
+
+static size_t rsvd_scratch_bytes(int64_t tall_pad, int64_t small_pad, int l, int k) {
+  const size_t L = (size_t)round_up(l, 32), Lo = (size_t)round_up(k, 32);
+  size_t b = 0;
+  b += 2 * small_pad * L * 4 + 2 * tall_pad * L * 4 + tall_pad * Lo * 4 + small_pad * Lo * 4;
+  b += atb_scratch_bytes(small_pad, tall_pad, (int)L);        // split-K partials (small side)
+  b += atb_scratch_bytes(tall_pad, small_pad, (int)L);        // split-K partials (tall side)
+  b += atb_scratch_bytes(small_pad, tall_pad, (int)Lo);
+  b += 260 * L * L * 8 + L * Lo * 8;                          // gram partials, Rinv, M
+  b += (size_t)std::max(tall_pad, small_pad) * (Lo + L) * 4;  // export / import staging
+  b += 4 << 20;
+  return b;
+}
+
+// xeofs sign rule (xarray_utils.py:273-301) from the per-mode max/min of VT
+static int sign_rule(eofx_ctx* ctx, const float* Vpanel, int64_t rows, int Lo, int k,
+                     std::vector<double>& sign) {
+  ArenaScope scope(ctx);
+  ARENA(float, mx, Lo);
+  ARENA(float, mn, Lo);
+  CHK(launch_colminmax(ctx, Vpanel, rows, Lo, mx, mn));
+  std::vector<float> hmx(Lo), hmn(Lo);
+  HIPCHK(hipMemcpyAsync(hmx.data(), mx, sizeof(float) * Lo, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(hmn.data(), mn, sizeof(float) * Lo, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  sign.assign(k, 1.0);
+  for (int j = 0; j < k; ++j) sign[j] = (std::fabs(hmx[j]) >= std::fabs(hmn[j])) ? 1.0 : -1.0;
+  return EOFX_OK;
+}
+
+extern "C" int eofx_rsvd_f32(eofx_ctx* ctx, const eofx_mat* m, int k, int n_oversamples, int n_iter,
+                             const float* omega, int flip, float* U, float* s, float* V) {
+  if (!ctx || !m || !omega || k <= 0 || n_oversamples < 0) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  CHK(set_device(ctx));
+  const int64_t n = m->n, p = m->p, r = std::min(n, p);
+  if (k > r)
+    return set_err(ctx, EOFX_ERR_RANK,
+                   "n_modes must be less than or equal to the rank of the dataset (rank = %lld).", (long long)r);
+  const int l_req = k + n_oversamples;
+  const int l = (int)std::min<int64_t>(l_req, r);
+  if (l > 64) return set_err(ctx, EOFX_ERR_ARG, "sketch width k+n_oversamples = %d > 64 not supported yet", l);
+  if (n_iter < 0) n_iter = rsvd_auto_iters(k, n, p);
+  const bool transposed = n < p;  // sklearn: transpose = n_samples < n_features
+  LinOp op;
+  if (transposed) {
+    op = {p, n, m->p_pad, m->n_pad,
+          [&](const float* z, float* y, int L) { return panel_tmul(ctx, m, z, y, L); },
+          [&](const float* y, float* w, int L) { return panel_mul(ctx, m, y, w, L); }};
+  } else {
+    op = {n, p, m->n_pad, m->p_pad,
+          [&](const float* z, float* y, int L) { return panel_mul(ctx, m, z, y, L); },
+          [&](const float* y, float* w, int L) { return panel_tmul(ctx, m, y, w, L); }};
+  }
+  CHK(arena_reserve(ctx, rsvd_scratch_bytes(op.tall_pad, op.small_pad, l, k)));
+  ArenaScope scope(ctx);
+  // omega arrives as (small x l_req); when l was clamped only its first l columns are used
+  std::vector<float> om_clamped;
+  const float* om = omega;
+  if (l != l_req) {
+    if (is_device_ptr(omega)) return set_err(ctx, EOFX_ERR_ARG, "omega must be a host pointer");
+    om_clamped.resize((size_t)op.small * l);
+    for (int64_t i = 0; i < op.small; ++i)
+      for (int j = 0; j < l; ++j) om_clamped[(size_t)i * l + j] = omega[(size_t)i * l_req + j];
+    om = om_clamped.data();
+  }
+  RsvdOut ro;
+  CHK(rsvd_core(ctx, op, k, l, n_iter, om, ro));
+  const float* Vp = transposed ? ro.Tvec : ro.Svec;
+  const float* Up = transposed ? ro.Svec : ro.Tvec;
+  std::vector<double> sign;
+  if (flip) CHK(sign_rule(ctx, Vp, p, ro.Lo, k, sign));
+  CHK(export_panel(ctx, Up, n, ro.Lo, k, flip ? sign.data() : nullptr, U));
+  CHK(export_panel(ctx, Vp, p, ro.Lo, k, flip ? sign.data() : nullptr, V));
+  if (s) {
+    std::vector<float> hs(k);
+    for (int j = 0; j < k; ++j) hs[j] = (float)ro.s[j];
+    HIPCHK(hipMemcpy(s, hs.data(), sizeof(float) * k, hipMemcpyDefault));
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return EOFX_OK;
+}
+
+extern "C" int eofx_project_f32(eofx_ctx* ctx, const eofx_mat* m, const float* V, int k, float* out) {
+  if (!ctx || !m || !V || !out || k <= 0) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  CHK(set_device(ctx));
+  const int Lo = (int)round_up(k, 32);
+  CHK(arena_reserve(ctx, (size_t)(m->p_pad + m->n_pad) * Lo * 4 * 2 + atb_scratch_bytes(m->n_pad, round_up(m->p, ATB_KG), Lo) +
+                             (size_t)(m->p + m->n) * k * 4 + (1 << 20)));
+  ArenaScope scope(ctx);
+  ARENA(float, Vp, (size_t)m->p_pad * Lo);
+  ARENA(float, Sn, (size_t)m->n_pad * Lo);
+  CHK(import_panel(ctx, V, m->p, k, Vp, m->p_pad, Lo));
+  CHK(panel_mul(ctx, m, Vp, Sn, Lo));
+  CHK(export_panel(ctx, Sn, m->n, Lo, k, nullptr, out));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return EOFX_OK;
+}
+
+extern "C" int eofx_reconstruct_f32(eofx_ctx* ctx, const float* S, const float* V, int64_t n, int64_t p,
+                                    int k, float* out) {
+  if (!ctx || !S || !V || !out || k <= 0) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  CHK(set_device(ctx));
+  Staged ss, sv;
+  CHK(stage_input(ctx, S, (size_t)n * k, ss));
+  CHK(stage_input(ctx, V, (size_t)p * k, sv));
+  const bool dev = is_device_ptr(out);
+  float* tmp = out;
+  if (!dev) HIPCHK(hipMalloc((void**)&tmp, (size_t)n * p * sizeof(float)));
+  dim3 grid((int)((p + 63) / 64), (int)((n + 63) / 64));
+  hipLaunchKernelGGL(reconstruct_kernel, grid, dim3(256), 0, ctx->stream, ss.dev, sv.dev, n, p, k, tmp);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess && !dev)
+    e = hipMemcpyAsync(out, tmp, (size_t)n * p * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (!dev) (void)hipFree(tmp);
+  if (e != hipSuccess) return set_err(ctx, EOFX_ERR_HIP, "reconstruct failed: %s", hipGetErrorString(e));
+  return EOFX_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// cross-covariance path (MCA): matrix-free rSVD of C = X^T Y / (n-1)
+// ------------------------------------------------------------------------------------
+extern "C" int eofx_crosscov_rsvd_f32(eofx_ctx* ctx, const eofx_mat* x, const eofx_mat* y, int k,
+                                      int n_oversamples, int n_iter, const float* omega, int flip,
+                                      float* Q1, float* s, float* Q2, float* scores1, float* scores2,
+                                      float* norm1, float* norm2, double* tsc) {
+  if (!ctx || !x || !y || !omega || k <= 0) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  CHK(set_device(ctx));
+  if (x->n != y->n)
+    return set_err(ctx, EOFX_ERR_SHAPE,
+                   "Both data matrices must have the same number of samples but found %lld in the first and %lld in the second.",
+                   (long long)x->n, (long long)y->n);
+  const int64_t n = x->n, p1 = x->p, p2 = y->p, r = std::min(p1, p2);
+  if (k > r)
+    return set_err(ctx, EOFX_ERR_RANK,
+                   "n_modes must be less than or equal to the rank of the dataset (rank = %lld).", (long long)r);
+  const int l_req = k + n_oversamples;
+  const int l = (int)std::min<int64_t>(l_req, r);
+  if (l > 64) return set_err(ctx, EOFX_ERR_ARG, "sketch width %d > 64 not supported yet", l);
+  if (l != l_req) return set_err(ctx, EOFX_ERR_ARG, "sketch wider than rank not supported on the cross path");
+  if (n_iter < 0) n_iter = rsvd_auto_iters(k, p1, p2);
+  const int L = (int)round_up(l, 32);
+  const bool transposed = p1 < p2;  // C is (p1 x p2): sklearn transposes when rows < cols
+  const int64_t npad = x->n_pad;
+  size_t need = rsvd_scratch_bytes(std::max(x->p_pad, y->p_pad), std::max(x->p_pad, y->p_pad), l, k) +
+                (size_t)npad * L * 4 * 2 + atb_scratch_bytes(npad, std::max(x->p_pad, y->p_pad), L);
+  if (tsc) need += (size_t)npad * npad * 4 * 2 + atb_scratch_bytes(npad, std::max(x->p_pad, y->p_pad), (int)npad) + (1 << 20);
+  CHK(arena_reserve(ctx, need));
+  ArenaScope scope(ctx);
+  ARENA(float, Tn, (size_t)npad * L);
+  // C   Z = X^T (Y Z);   C^T W = Y^T (X W)     (scaling by 1/(n-1) is applied to s at the end)
+  auto C_mul = [&](const float* z2, float* out1, int LL) {
+    CHK(panel_mul(ctx, y, z2, Tn, LL));
+    return panel_tmul(ctx, x, Tn, out1, LL);
+  };
+  auto Ct_mul = [&](const float* z1, float* out2, int LL) {
+    CHK(panel_mul(ctx, x, z1, Tn, LL));
+    return panel_tmul(ctx, y, Tn, out2, LL);
+  };
+  LinOp op;
+  if (transposed)
+    op = {p2, p1, y->p_pad, x->p_pad, Ct_mul, C_mul};  // A = C^T (p2 x p1)
+  else
+    op = {p1, p2, x->p_pad, y->p_pad, C_mul, Ct_mul};  // A = C   (p1 x p2)
+  RsvdOut ro;
+  CHK(rsvd_core(ctx, op, k, l, n_iter, omega, ro));
+  const float* Q1p = transposed ? ro.Svec : ro.Tvec;  // left vectors of C  (p1)
+  const float* Q2p = transposed ? ro.Tvec : ro.Svec;  // right vectors of C (p2)
+  std::vector<double> sign;
+  if (flip) CHK(sign_rule(ctx, Q2p, p2, ro.Lo, k, sign));
+  const double* sg = flip ? sign.data() : nullptr;
+  CHK(export_panel(ctx, Q1p, p1, ro.Lo, k, sg, Q1));
+  CHK(export_panel(ctx, Q2p, p2, ro.Lo, k, sg, Q2));
+  if (s) {
+    std::vector<float> hs(k);
+    for (int j = 0; j < k; ++j) hs[j] = (float)(ro.s[j] / (double)(n - 1));
+    HIPCHK(hipMemcpy(s, hs.data(), sizeof(float) * k, hipMemcpyDefault));
+  }
+  // scores and norms (cpcca.py:204-208)
+  if (scores1 || scores2 || norm1 || norm2) {
+    ARENA(float, Sn, (size_t)npad * ro.Lo);
+    ARENA(double, Gs, (size_t)ro.Lo * ro.Lo);
+    for (int which = 0; which < 2; ++which) {
+      const eofx_mat* mm = which ? y : x;
+      const float* Qp = which ? Q2p : Q1p;
+      float* sc = which ? scores2 : scores1;
+      float* nr = which ? norm2 : norm1;
+      if (!sc && !nr) continue;
+      CHK(panel_mul(ctx, mm, Qp, Sn, ro.Lo));
+      CHK(export_panel(ctx, Sn, n, ro.Lo, k, sg, sc));
+      if (nr) {
+        CHK(launch_gram(ctx, Sn, npad, ro.Lo, Gs));
+        std::vector<double> hg((size_t)ro.Lo * ro.Lo);
+        HIPCHK(hipMemcpyAsync(hg.data(), Gs, sizeof(double) * hg.size(), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        std::vector<float> hn(k);
+        for (int j = 0; j < k; ++j) hn[j] = (float)std::sqrt(hg[(size_t)j * ro.Lo + j]);
+        HIPCHK(hipMemcpy(nr, hn.data(), sizeof(float) * k, hipMemcpyDefault));
+      }
+    }
+  }
+  // total squared covariance ||X^T Y||_F^2/(n-1)^2 = <X X^T, Y Y^T>/(n-1)^2 : two n x n Grams
+  if (tsc) {
+    ARENA(float, Gx, (size_t)npad * npad);
+    ARENA(float, Gy, (size_t)npad * npad);
+    CHK(launch_atb(ctx, x->Xt, npad, round_up(p1, ATB_KG), npad, x->Xt, (int)npad, (int)npad, Gx));
+    CHK(launch_atb(ctx, y->Xt, npad, round_up(p2, ATB_KG), npad, y->Xt, (int)npad, (int)npad, Gy));
+    const int nb = 1024;
+    ARENA(double, part, nb);
+    hipLaunchKernelGGL(dotprod_part_kernel, dim3(nb), dim3(256), 0, ctx->stream, Gx, Gy, npad * npad, part);
+    KCHK();
+    std::vector<double> hp(nb);
+    HIPCHK(hipMemcpyAsync(hp.data(), part, sizeof(double) * nb, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    double t = 0.0;
+    for (int i = 0; i < nb; ++i) t += hp[i];
+    *tsc = t / ((double)(n - 1) * (double)(n - 1));
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return EOFX_OK;
+}

@@ -1,0 +1,631 @@
+// eofx_kernels.hpp -- hand-written gfx950 (CDNA4) kernels of the EOF / randomized-SVD engine.
+//
+// Everything here is written for MI355X only: 64-wide wavefronts, the exact-f32
+// MFMA v_mfma_f32_32x32x2_f32 (157 TFLOP/s peak, bitwise an fmaf chain), LDS-staged
+// sketch panels, coalesced 16 B/lane HBM streams.  See DESIGN.md for the roofline of
+// each kernel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace eofx {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------
+// atb_f32: C[M x L] = A[K x M]^T * B[K x L]        (the dominant kernel)
+//
+//   A  row-major, M contiguous (lda), streamed from HBM exactly once per launch:
+//      each lane loads 16 B (4 consecutive m) of two consecutive k-rows straight into
+//      the MFMA A-operand registers -- for v_mfma_f32_32x32x2_f32 lane l supplies
+//      A[i = l&31][k = l>>5], so the register image of a coalesced row read IS the
+//      fragment (row i of sub-tile j is column m0 + 4 i + j).  No LDS round trip for A.
+//   B  the sketch panel (K x L, L = 32*NB per z-block), staged through LDS in 16-row
+//      slabs shared by the 4 waves of the workgroup, double buffered.
+//   C  written once in the epilogue (or as a split-K partial, reduced by a fixed-order
+//      second kernel: deterministic, no atomics).
+//
+//   X^T Z  (tall-skinny sketch/projection):  A = X  [n_pad x p_pad], B = Z [n_pad x L]
+//   X  Y   (power-iteration back-product):   A = Xt [p_pad x n_pad], B = Y [p_pad x L]
+//
+//   grid  = (M/512, splits, ceil(L/64)) ; block = 256 = 4 waves x 128 columns of A.
+//   Per wave and 2 k-rows: 1 KiB of A -> 4*NB MFMAs (64 cycles each on its SIMD).
+// ---------------------------------------------------------------------------------
+constexpr int ATB_KC = 16;    // k-rows per pipeline stage (slab)
+constexpr int ATB_KG = 32;    // K granularity: slabs are consumed in pairs
+constexpr int ATB_WM = 128;   // A columns per wave
+constexpr int ATB_BM = 512;   // A columns per workgroup
+
+template <int NB>
+__global__ __launch_bounds__(256, 2) void atb_f32_kernel(const float* __restrict__ A, int64_t lda,
+                                                          const float* __restrict__ B, int ldb,
+                                                          float* __restrict__ C, int ldc, int64_t M,
+                                                          int64_t K, int64_t k_per_split,
+                                                          int col_base) {
+  __shared__ __attribute__((aligned(16))) float Bs[2][ATB_KC][32 * NB];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int64_t m0 = (int64_t)blockIdx.x * ATB_BM + wave * ATB_WM;
+  const int64_t kb = (int64_t)blockIdx.y * k_per_split;
+  const int64_t ke = (kb + k_per_split < K) ? kb + k_per_split : K;
+  const int nchunks = (int)((ke - kb) / ATB_KC);
+  const int bcol0 = col_base + blockIdx.z * 64;
+
+  f32x16 acc[4][NB];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][b][r] = 0.f;
+
+  const float* Ap = A + (kb + lh) * lda + m0 + 4 * li;
+  // B slab loader: 16 rows x (8*NB) float4 ; threads [0, 128*NB) take one float4 each
+  constexpr int BV = 8 * NB;
+  const bool b_loader = tid < 16 * BV;
+  const int brow = tid / BV, bc4 = tid % BV;
+  const float* Bp = B + (kb + brow) * (int64_t)ldb + bcol0 + 4 * bc4;
+
+  // Two A-fragment register sets (a0/a1): the loads of slab c+1 are issued, and pinned with a
+  // scheduling barrier, BEFORE the 32*NB MFMAs of slab c, so a full slab of matrix work
+  // (~4k cycles) covers their HBM latency.  Slabs are processed in pairs (the host guarantees
+  // an even slab count); the last prefetch index is clamped (a harmless re-read), so the loop
+  // body has no data-dependent control flow.
+  f32x4 a0[8], a1[8];
+  f32x4 bn = {0.f, 0.f, 0.f, 0.f};
+#define EOFX_LOAD_SLAB(areg, chunk)                                                              \
+  do {                                                                                           \
+    if (b_loader) bn = *reinterpret_cast<const f32x4*>(Bp + (int64_t)(chunk) * ATB_KC * ldb);   \
+    const float* pa_ = Ap + (int64_t)(chunk) * ATB_KC * lda;                                     \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) areg[i] =                                      \
+        *reinterpret_cast<const f32x4*>(pa_ + (int64_t)(2 * i) * lda);                           \
+  } while (0)
+#define EOFX_COMPUTE_SLAB(areg, buf)                                                             \
+  do {                                                                                           \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                              \
+      float b_[NB];                                                                              \
+      _Pragma("unroll") for (int q = 0; q < NB; ++q) b_[q] = Bs[buf][2 * i + lh][32 * q + li];   \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) _Pragma("unroll") for (int q = 0; q < NB; ++q) \
+          acc[j][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[i][j], b_[q], acc[j][q], 0, 0, 0); \
+    }                                                                                            \
+  } while (0)
+#define EOFX_STORE_B(buf)                                                                        \
+  do {                                                                                           \
+    if (b_loader) *reinterpret_cast<f32x4*>(&Bs[buf][brow][4 * bc4]) = bn;                       \
+  } while (0)
+
+  if (nchunks > 0) {
+    EOFX_LOAD_SLAB(a0, 0);
+    EOFX_STORE_B(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; c += 2) {
+      EOFX_LOAD_SLAB(a1, c + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      EOFX_COMPUTE_SLAB(a0, 0);
+      EOFX_STORE_B(1);
+      __syncthreads();
+      const int c2 = (c + 2 < nchunks) ? c + 2 : c + 1;
+      EOFX_LOAD_SLAB(a0, c2);
+      __builtin_amdgcn_sched_barrier(0);
+      EOFX_COMPUTE_SLAB(a1, 1);
+      EOFX_STORE_B(0);
+      __syncthreads();
+    }
+  }
+#undef EOFX_LOAD_SLAB
+#undef EOFX_COMPUTE_SLAB
+#undef EOFX_STORE_B
+
+  // epilogue: D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  float* Cs = C + (int64_t)blockIdx.y * M * ldc;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int q = 0; q < NB; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ii = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int64_t m = m0 + 4 * ii + j;
+        Cs[m * ldc + bcol0 + 32 * q + li] = acc[j][q][r];
+      }
+}
+
+// out[i] = sum_s part[s][i], fixed order, float64 accumulate.  count4 = elements / 4.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part,
+                                                            float* __restrict__ out,
+                                                            int64_t count4, int splits) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count4; i += stride) {
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    for (int s = 0; s < splits; ++s) {
+      const f32x4 v = reinterpret_cast<const f32x4*>(part)[(int64_t)s * count4 + i];
+      s0 += v[0];
+      s1 += v[1];
+      s2 += v[2];
+      s3 += v[3];
+    }
+    f32x4 o = {(float)s0, (float)s1, (float)s2, (float)s3};
+    reinterpret_cast<f32x4*>(out)[i] = o;
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// gram_f64: Gpart[bx][L x L] = sum over this block's rows of P[r,:]^T P[r,:]  (float64)
+//   grid = (nbx, nb*nb) where nb = ceil(L/64); each block owns one 64x64 sub-block of G
+//   and a strided set of 32-row slabs.  HBM-bound on P (rows x L x 4 B), tiny.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gram_f64_kernel(const float* __restrict__ P, int64_t rows,
+                                                        int L, double* __restrict__ Gpart) {
+  __shared__ __attribute__((aligned(16))) float Pa[32][64];
+  __shared__ __attribute__((aligned(16))) float Pb[32][64];
+  const int nb = (L + 63) / 64;
+  const int bi = blockIdx.y / nb, bj = blockIdx.y % nb;
+  const int tid = threadIdx.x;
+  const int ti = tid >> 4, tj = tid & 15;
+  double acc[4][4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) acc[x][y] = 0.0;
+  const int lr = tid >> 4;         // 0..15  (two passes -> 32 rows)
+  const int lc = (tid & 15) * 4;   // float4 column
+  for (int64_t r0 = (int64_t)blockIdx.x * 32; r0 < rows; r0 += (int64_t)gridDim.x * 32) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int rr = lr + 16 * h;
+      const int64_t r = r0 + rr;
+      f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
+      if (r < rows) {
+        const int ca = bi * 64 + lc, cb = bj * 64 + lc;
+        if (ca < L) va = *reinterpret_cast<const f32x4*>(P + r * L + ca);
+        if (cb < L) vb = *reinterpret_cast<const f32x4*>(P + r * L + cb);
+      }
+      *reinterpret_cast<f32x4*>(&Pa[rr][lc]) = va;
+      *reinterpret_cast<f32x4*>(&Pb[rr][lc]) = vb;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int r = 0; r < 32; ++r) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(&Pa[r][4 * ti]);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(&Pb[r][4 * tj]);
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) acc[x][y] += (double)a[x] * (double)b[y];
+    }
+    __syncthreads();
+  }
+  double* G = Gpart + (int64_t)blockIdx.x * L * L;
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) {
+      const int gi = bi * 64 + 4 * ti + x, gj = bj * 64 + 4 * tj + y;
+      if (gi < L && gj < L) G[(int64_t)gi * L + gj] = acc[x][y];
+    }
+}
+
+__global__ __launch_bounds__(256) void f64_reduce_kernel(const double* __restrict__ part,
+                                                         double* __restrict__ out, int64_t count,
+                                                         int nparts) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  double s = 0;
+  for (int b = 0; b < nparts; ++b) s += part[(int64_t)b * count + i];
+  out[i] = s;
+}
+
+// ---------------------------------------------------------------------------------
+// chol_rinv: single workgroup.  G (L x L float64, leading l x l block used) -> Rinv with
+// G = R^T R, Rinv = R^-1 (upper triangular), zero outside l x l.  A pivot that falls below
+// tol * G[j][j] marks column j as linearly dependent: its Q column becomes exactly zero.
+// l <= 64.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void chol_rinv_kernel(const double* __restrict__ G, int L, int l,
+                                                        double* __restrict__ Rinv, double tol) {
+  // R lives in the upper triangle of A; R^-1 (also upper triangular) is built into the
+  // unused strict lower triangle (Xi[r][c] -> A[c][r]) with its diagonal in xdiag.
+  __shared__ double A[64][65];
+  __shared__ double diag0[64];
+  __shared__ double xdiag[64];
+  __shared__ int dead[64];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 64 * 64; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    A[r][c] = (r < l && c < l && c >= r) ? G[(int64_t)r * L + c] : 0.0;
+  }
+  __syncthreads();
+  if (tid < 64) {
+    diag0[tid] = A[tid][tid];
+    dead[tid] = 0;
+  }
+  __syncthreads();
+  for (int j = 0; j < l; ++j) {
+    if (tid == 0) {
+      const double d = A[j][j];
+      if (!(d > tol * diag0[j]) || !(diag0[j] > 0.0)) {
+        dead[j] = 1;
+        A[j][j] = 1.0;
+      } else {
+        A[j][j] = sqrt(d);
+      }
+    }
+    __syncthreads();
+    const double piv = dead[j] ? 0.0 : 1.0 / A[j][j];
+    for (int c = j + 1 + tid; c < l; c += 256) A[j][c] *= piv;
+    __syncthreads();
+    const int w = l - j - 1;
+    for (int i = tid; i < w * w; i += 256) {
+      const int r = j + 1 + i / w, c = j + 1 + i % w;
+      if (c >= r) A[r][c] -= A[j][r] * A[j][c];
+    }
+    __syncthreads();
+  }
+  // back substitution, one column per thread: R X = I
+  if (tid < l) {
+    const int c = tid;
+    if (!dead[c]) {
+      const double xd = 1.0 / A[c][c];
+      xdiag[c] = xd;
+      for (int r = c - 1; r >= 0; --r) {
+        double s = A[r][c] * xd;
+        for (int t = r + 1; t < c; ++t) s += A[r][t] * A[c][t];
+        A[c][r] = -s / A[r][r];
+      }
+    } else {
+      xdiag[c] = 0.0;
+      for (int r = 0; r < c; ++r) A[c][r] = 0.0;
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < L * L; i += 256) {
+    const int r = i / L, c = i % L;
+    double v = 0.0;
+    if (r < l && c < l) v = (r == c) ? xdiag[c] : (r < c ? A[c][r] : 0.0);
+    Rinv[i] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// panel_matmul: out[rows x Lo] = P[rows x L] * Mx[L x Lo]  (Mx float64, accumulate float64)
+//   grid = (rows/64, ceil(Lo/64)); 64x64 output tile, 4x4 per thread.  out must not alias P.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void panel_matmul_kernel(const float* __restrict__ P,
+                                                           int64_t rows, int L,
+                                                           const double* __restrict__ Mx, int Lo,
+                                                           float* __restrict__ out) {
+  __shared__ float Ps[64][65];
+  __shared__ double Ms[64][64];
+  const int tid = threadIdx.x;
+  const int ti = tid >> 4, tj = tid & 15;
+  const int64_t r0 = (int64_t)blockIdx.x * 64;
+  const int c0 = blockIdx.y * 64;
+  double acc[4][4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) acc[x][y] = 0.0;
+  for (int k0 = 0; k0 < L; k0 += 64) {
+    for (int i = tid; i < 64 * 64; i += 256) {
+      const int r = i >> 6, c = i & 63;
+      Ps[r][c] = (r0 + r < rows && k0 + c < L) ? P[(r0 + r) * L + k0 + c] : 0.f;
+      Ms[r][c] = (k0 + r < L && c0 + c < Lo) ? Mx[(int64_t)(k0 + r) * Lo + c0 + c] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int k = 0; k < 64; ++k) {
+      double a[4], b[4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) a[x] = (double)Ps[4 * ti + x][k];
+#pragma unroll
+      for (int y = 0; y < 4; ++y) b[y] = Ms[k][4 * tj + y];
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) acc[x][y] += a[x] * b[y];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int x = 0; x < 4; ++x) {
+    const int64_t r = r0 + 4 * ti + x;
+    if (r >= rows) continue;
+#pragma unroll
+    for (int y = 0; y < 4; ++y) {
+      const int c = c0 + 4 * tj + y;
+      if (c < Lo) out[r * Lo + c] = (float)acc[x][y];
+    }
+  }
+}
+
+// per-column max/min over rows [0, rows): partial per block, then a second tiny pass.
+__global__ __launch_bounds__(256) void colminmax_part_kernel(const float* __restrict__ P,
+                                                             int64_t rows, int L,
+                                                             float* __restrict__ pmx,
+                                                             float* __restrict__ pmn) {
+  __shared__ float smx[4][64], smn[4][64];
+  const int tid = threadIdx.x;
+  const int c = blockIdx.y * 64 + (tid & 63);
+  const int rl = tid >> 6;
+  float mx = -INFINITY, mn = INFINITY;
+  if (c < L)
+    for (int64_t r = (int64_t)blockIdx.x * 4 + rl; r < rows; r += (int64_t)gridDim.x * 4) {
+      const float v = P[r * L + c];
+      mx = fmaxf(mx, v);
+      mn = fminf(mn, v);
+    }
+  smx[rl][tid & 63] = mx;
+  smn[rl][tid & 63] = mn;
+  __syncthreads();
+  if (rl == 0 && c < L) {
+    for (int q = 1; q < 4; ++q) {
+      mx = fmaxf(mx, smx[q][tid]);
+      mn = fminf(mn, smn[q][tid]);
+    }
+    pmx[(int64_t)blockIdx.x * L + c] = mx;
+    pmn[(int64_t)blockIdx.x * L + c] = mn;
+  }
+}
+__global__ void colminmax_final_kernel(const float* __restrict__ pmx, const float* __restrict__ pmn,
+                                       int nparts, int L, float* __restrict__ mx,
+                                       float* __restrict__ mn) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= L) return;
+  float a = -INFINITY, b = INFINITY;
+  for (int q = 0; q < nparts; ++q) {
+    a = fmaxf(a, pmx[(int64_t)q * L + c]);
+    b = fminf(b, pmn[(int64_t)q * L + c]);
+  }
+  mx[c] = a;
+  mn[c] = b;
+}
+
+// dst[r*k + c] = P[r*L + c] * sign[c]   (dense export, drops padding)
+__global__ __launch_bounds__(256) void panel_export_kernel(const float* __restrict__ P,
+                                                           int64_t rows, int L, int k,
+                                                           const double* __restrict__ sign,
+                                                           float* __restrict__ dst) {
+  const int64_t total = rows * k;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t r = i / k;
+    const int c = (int)(i - r * k);
+    float v = P[r * L + c];
+    if (sign) v *= (float)sign[c];
+    dst[i] = v;
+  }
+}
+// P[rows_pad x L] <- src[rows x l] zero padded
+__global__ __launch_bounds__(256) void panel_import_kernel(const float* __restrict__ src,
+                                                           int64_t rows, int l,
+                                                           float* __restrict__ P, int64_t rows_pad,
+                                                           int L) {
+  const int64_t total = rows_pad * L;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t r = i / L;
+    const int c = (int)(i - r * L);
+    P[i] = (r < rows && c < l) ? src[r * l + c] : 0.f;
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Fused preprocessor (Scaler + Sanitizer), HBM-bound.
+//   colstats : NaN-aware count / sum / sum of squares per feature in float64,
+//              one thread per feature column, rows split over gridDim.y.
+//   finalize : combine row-splits in fixed order -> mean, std, shift, scale, variance term.
+//   rowcount : valid-feature count per sample (only launched when samples are missing).
+//   apply    : gather valid rows/cols, (x - shift) * scale, write X and X^T zero padded.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__ X, int64_t n,
+                                                        int64_t P, int64_t rows_per_split,
+                                                        int* __restrict__ cnt,
+                                                        double* __restrict__ sum,
+                                                        double* __restrict__ sumsq) {
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= P) return;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_split;
+  const int64_t r1 = (r0 + rows_per_split < n) ? r0 + rows_per_split : n;
+  int k = 0;
+  double s = 0.0, q = 0.0;
+  const float* p = X + r0 * P + c;
+  int64_t r = r0;
+  for (; r + 8 <= r1; r += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)u * P];
+    p += 8 * P;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (v[u] == v[u]) {
+        const double d = (double)v[u];
+        ++k;
+        s += d;
+        q += d * d;
+      }
+  }
+  for (; r < r1; ++r, p += P) {
+    const float v = *p;
+    if (v == v) {
+      const double d = (double)v;
+      ++k;
+      s += d;
+      q += d * d;
+    }
+  }
+  const int64_t o = (int64_t)blockIdx.y * P + c;
+  cnt[o] = k;
+  sum[o] = s;
+  sumsq[o] = q;
+}
+
+// One thread per feature.  weights may be null (ones).  Outputs per (uncompacted) feature.
+__global__ __launch_bounds__(256) void colstats_finalize_kernel(
+    const int* __restrict__ cnt_p, const double* __restrict__ sum_p,
+    const double* __restrict__ sumsq_p, int splits, int64_t P, int center, int standardize,
+    const double* __restrict__ weights, double eps, int* __restrict__ cnt, double* __restrict__ mean,
+    double* __restrict__ stdv, double* __restrict__ shift, double* __restrict__ scale,
+    double* __restrict__ m2) {
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= P) return;
+  int k = 0;
+  double s = 0.0, q = 0.0;
+  for (int sp = 0; sp < splits; ++sp) {
+    k += cnt_p[(int64_t)sp * P + c];
+    s += sum_p[(int64_t)sp * P + c];
+    q += sumsq_p[(int64_t)sp * P + c];
+  }
+  cnt[c] = k;
+  double mu = NAN, sd = NAN, M2 = 0.0;
+  if (k > 0) {
+    mu = s / k;
+    M2 = q - s * mu;
+    if (M2 < 0.0) M2 = 0.0;
+    sd = sqrt(M2 / k);
+    if (sd < eps) sd = eps;
+  }
+  mean[c] = mu;
+  stdv[c] = sd;
+  const double w = weights ? weights[c] : 1.0;
+  shift[c] = center ? mu : 0.0;
+  scale[c] = (standardize ? 1.0 / sd : 1.0) * w;
+  m2[c] = M2;
+}
+
+// count of non-NaN entries per row restricted to valid feature columns
+__global__ __launch_bounds__(256) void rowcount_kernel(const float* __restrict__ X, int64_t n,
+                                                        int64_t P, const int* __restrict__ colcnt,
+                                                        int* __restrict__ rowcnt) {
+  __shared__ int red[256];
+  const int64_t r = blockIdx.x;
+  int k = 0;
+  for (int64_t c = threadIdx.x; c < P; c += 256) {
+    const float v = X[r * P + c];
+    if (colcnt[c] > 0 && v == v) ++k;
+  }
+  red[threadIdx.x] = k;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) rowcnt[r] = red[0];
+}
+
+// grid = (p_pad/64, n_pad/64): 64x64 tile of the compacted matrix.
+// col_map/row_map: compact index -> source index (null = identity).  shift/scale indexed by
+// SOURCE column (null = 0 / 1).  nan_flag set (atomicOr) when a NaN lands on a kept entry.
+__global__ __launch_bounds__(256) void apply_kernel(const float* __restrict__ X, int64_t ldx_src,
+                                                     const int64_t* __restrict__ row_map,
+                                                     const int64_t* __restrict__ col_map,
+                                                     const double* __restrict__ shift,
+                                                     const double* __restrict__ scale, int64_t n,
+                                                     int64_t p, float* __restrict__ Xc,
+                                                     int64_t p_pad, float* __restrict__ Xt,
+                                                     int64_t n_pad, int* __restrict__ nan_flag) {
+  __shared__ float T[64][65];
+  const int tid = threadIdx.x;
+  const int tc = tid & 63, tr = tid >> 6;
+  const int64_t c0 = (int64_t)blockIdx.x * 64, r0 = (int64_t)blockIdx.y * 64;
+  const int64_t c = c0 + tc;
+  int64_t sc = -1;
+  double sh = 0.0, sl = 1.0;
+  if (c < p) {
+    sc = col_map ? col_map[c] : c;
+    if (shift) sh = shift[sc];
+    if (scale) sl = scale[sc];
+  }
+  bool bad = false;
+#pragma unroll 4
+  for (int q = 0; q < 16; ++q) {
+    const int rr = tr + 4 * q;
+    const int64_t r = r0 + rr;
+    float v = 0.f;
+    if (sc >= 0 && r < n) {
+      const int64_t sr = row_map ? row_map[r] : r;
+      const float x = X[sr * ldx_src + sc];
+      if (x != x) bad = true;
+      v = (float)(((double)x - sh) * sl);
+    }
+    T[rr][tc] = v;
+    Xc[r * p_pad + c] = v;
+  }
+  if (bad) atomicOr(nan_flag, 1);
+  __syncthreads();
+#pragma unroll 4
+  for (int q = 0; q < 16; ++q) {
+    const int cc = tr + 4 * q;
+    Xt[(c0 + cc) * n_pad + r0 + tc] = T[tc][cc];
+  }
+}
+
+// dense download of the resident matrix: dst[n x p]
+__global__ __launch_bounds__(256) void mat_download_kernel(const float* __restrict__ Xc,
+                                                           int64_t p_pad, int64_t n, int64_t p,
+                                                           float* __restrict__ dst) {
+  const int64_t total = n * p;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t r = i / p, c = i - r * p;
+    dst[i] = Xc[r * p_pad + c];
+  }
+}
+
+// out[n x p] = S[n x k] V[p x k]^T  (k <= 64 per pass; HBM-write bound)
+__global__ __launch_bounds__(256) void reconstruct_kernel(const float* __restrict__ S,
+                                                          const float* __restrict__ V, int64_t n,
+                                                          int64_t p, int k,
+                                                          float* __restrict__ out) {
+  __shared__ float Ss[64][65];
+  __shared__ float Vs[64][65];
+  const int tid = threadIdx.x;
+  const int tc = tid & 63, tr = tid >> 6;
+  const int64_t c0 = (int64_t)blockIdx.x * 64, r0 = (int64_t)blockIdx.y * 64;
+  float acc[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+  for (int k0 = 0; k0 < k; k0 += 64) {
+    for (int i = tid; i < 64 * 64; i += 256) {
+      const int r = i >> 6, c = i & 63;
+      Ss[r][c] = (r0 + r < n && k0 + c < k) ? S[(r0 + r) * k + k0 + c] : 0.f;
+      Vs[r][c] = (c0 + r < p && k0 + c < k) ? V[(c0 + r) * k + k0 + c] : 0.f;
+    }
+    __syncthreads();
+    const int kk = (k - k0 < 64) ? k - k0 : 64;
+    for (int j = 0; j < kk; ++j) {
+      const float v = Vs[tc][j];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[q] += Ss[tr + 4 * q][j] * v;
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int64_t r = r0 + tr + 4 * q, c = c0 + tc;
+    if (r < n && c < p) out[r * p + c] = acc[q];
+  }
+}
+
+// sum_i a[i]*b[i] in float64 over float32 inputs, fixed tree: partial per block
+__global__ __launch_bounds__(256) void dotprod_part_kernel(const float* __restrict__ a,
+                                                           const float* __restrict__ b,
+                                                           int64_t count,
+                                                           double* __restrict__ part) {
+  __shared__ double red[256];
+  double s = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride)
+    s += (double)a[i] * (double)b[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+
+}  // namespace eofx

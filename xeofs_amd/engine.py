@@ -1,0 +1,321 @@
+"""Thin Python handles over the C ABI (include/eofx.h): context, resident matrix, and the
+hot-path calls.  numpy arrays are host buffers, torch CUDA tensors are device buffers; the
+library detects which.  No arithmetic happens in this file.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import numbers
+
+import numpy as np
+
+from . import _lib
+from ._lib import ptr, raise_for
+
+
+def _f32c(a):
+    """float32 C-contiguous host array or a device tensor, unchanged if already so."""
+    if isinstance(a, np.ndarray):
+        return np.ascontiguousarray(a, dtype=np.float32)
+    if hasattr(a, "data_ptr"):  # torch tensor
+        import torch
+
+        if a.dtype != torch.float32 or not a.is_contiguous():
+            a = a.to(torch.float32).contiguous()
+        return a
+    return np.ascontiguousarray(np.asarray(a), dtype=np.float32)
+
+
+class Context:
+    """One GPU + one HIP stream (eofx_ctx)."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        rc = self.lib.eofx_ctx_create(int(device), C.c_void_p(stream or 0), C.byref(h))
+        if rc != 0:
+            raise _lib.EofxError(
+                f"eofx_ctx_create(device={device}) failed ({rc}): no usable MI355X / HIP runtime. "
+                "xeofs_amd has no CPU fallback.")
+        self.handle = h
+        self.device = int(device)
+
+    def synchronize(self):
+        raise_for(self.lib.eofx_ctx_synchronize(self.handle), self.handle)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.eofx_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = {}
+
+
+def default_context(device: int = 0) -> Context:
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]
+
+
+class ResidentMatrix:
+    """A preprocessed (sample x feature) matrix resident in HBM (eofx_mat)."""
+
+    def __init__(self, ctx: Context, handle):
+        self.ctx = ctx
+        self.handle = handle
+        n, p, npad, ppad = (C.c_int64() for _ in range(4))
+        ctx.lib.eofx_mat_shape(handle, C.byref(n), C.byref(p), C.byref(npad), C.byref(ppad))
+        self.n, self.p, self.n_pad, self.p_pad = n.value, p.value, npad.value, ppad.value
+
+    @property
+    def shape(self):
+        return (self.n, self.p)
+
+    def download(self) -> np.ndarray:
+        out = np.empty((self.n, self.p), dtype=np.float32)
+        raise_for(self.ctx.lib.eofx_mat_download_f32(self.ctx.handle, self.handle, ptr(out)), self.ctx.handle)
+        return out
+
+    def free(self):
+        if getattr(self, "handle", None) and getattr(self.ctx, "handle", None):
+            self.ctx.lib.eofx_mat_destroy(self.ctx.handle, self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def sketch_matrix(rows: int, size: int, random_state=None) -> np.ndarray:
+    """The Gaussian test matrix exactly as scikit-learn draws it for
+    randomized_svd (sklearn/utils/extmath.py `_randomized_range_finder`):
+    ``check_random_state(seed).normal(size=(A.shape[1], size))`` cast to float32,
+    so a given `random_state` means the same thing as in the reference
+    (xeofs/linalg/decomposer.py:141-146)."""
+    if random_state is None or random_state is np.random:
+        rs = np.random.mtrand._rand
+    elif isinstance(random_state, numbers.Integral):
+        rs = np.random.RandomState(int(random_state))
+    elif isinstance(random_state, np.random.RandomState):
+        rs = random_state
+    else:
+        raise ValueError(f"{random_state!r} cannot be used to seed a numpy.random.RandomState instance")
+    return np.ascontiguousarray(rs.normal(size=(rows, size)).astype(np.float32))
+
+
+def from_dense(ctx: Context, X) -> ResidentMatrix:
+    X = _f32c(X)
+    n, p = X.shape
+    h = C.c_void_p()
+    raise_for(ctx.lib.eofx_mat_from_dense_f32(ctx.handle, ptr(X), n, p, p, C.byref(h)), ctx.handle)
+    return ResidentMatrix(ctx, h)
+
+
+def preprocess(ctx: Context, X, center=True, standardize=False, feature_weights=None,
+               check_nans=True, want_stats=True, build=True):
+    """Scaler + Sanitizer + total variance on the stacked raw (n, P) field.
+    Returns (ResidentMatrix | None, stats dict)."""
+    X = _f32c(X)
+    n, P = X.shape
+    w = None if feature_weights is None else np.ascontiguousarray(feature_weights, dtype=np.float64)
+    if w is not None and w.shape != (P,):
+        raise ValueError("feature_weights must have one entry per stacked feature")
+    mean = np.empty(P, np.float64) if want_stats else None
+    std = np.empty(P, np.float64) if want_stats else None
+    vf = np.empty(P, np.uint8)
+    vs = np.empty(n, np.uint8)
+    n_out, p_out = C.c_int64(), C.c_int64()
+    tv = C.c_double()
+    h = C.c_void_p()
+    rc = ctx.lib.eofx_preprocess_f32(ctx.handle, ptr(X), n, P, int(center), int(standardize), ptr(w),
+                                     int(check_nans), C.byref(h) if build else None, ptr(mean), ptr(std),
+                                     ptr(vf), ptr(vs), C.byref(n_out), C.byref(p_out), C.byref(tv))
+    raise_for(rc, ctx.handle)
+    stats = dict(mean=mean, std=std, valid_feature=vf.astype(bool), valid_sample=vs.astype(bool),
+                 n=n_out.value, p=p_out.value, total_variance=tv.value)
+    return (ResidentMatrix(ctx, h) if build else None), stats
+
+
+def apply(ctx: Context, X, mean, std, feature_weights, valid_feature, check_nans=True):
+    """Preprocessor.transform on new data with fitted state."""
+    X = _f32c(X)
+    n, P = X.shape
+    f64 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+    mean, std, w = f64(mean), f64(std), f64(feature_weights)
+    vf = np.ascontiguousarray(valid_feature, dtype=np.uint8)
+    vs = np.empty(n, np.uint8)
+    n_out = C.c_int64()
+    h = C.c_void_p()
+    rc = ctx.lib.eofx_apply_f32(ctx.handle, ptr(X), n, P, ptr(mean), ptr(std), ptr(w), ptr(vf),
+                                int(check_nans), C.byref(h), ptr(vs), C.byref(n_out))
+    raise_for(rc, ctx.handle)
+    return ResidentMatrix(ctx, h), vs.astype(bool)
+
+
+def rsvd(ctx: Context, mat: ResidentMatrix, k: int, n_oversamples: int = 10, n_iter: int | str = "auto",
+         random_state=None, flip: bool = True, omega=None):
+    """randomized SVD of the resident matrix -> (U[n,k], s[k], V[p,k]) float32 host arrays."""
+    k = int(k)
+    small = min(mat.n, mat.p)
+    if omega is None:
+        omega = sketch_matrix(small, k + n_oversamples, random_state)
+    omega = np.ascontiguousarray(omega, dtype=np.float32)
+    if omega.shape != (small, k + n_oversamples):
+        raise ValueError(f"omega must have shape {(small, k + n_oversamples)}")
+    U = np.empty((mat.n, k), np.float32)
+    s = np.empty(k, np.float32)
+    V = np.empty((mat.p, k), np.float32)
+    it = -1 if n_iter == "auto" else int(n_iter)
+    rc = ctx.lib.eofx_rsvd_f32(ctx.handle, mat.handle, k, int(n_oversamples), it, ptr(omega), int(flip),
+                               ptr(U), ptr(s), ptr(V))
+    raise_for(rc, ctx.handle)
+    return U, s, V
+
+
+def project(ctx: Context, mat: ResidentMatrix, V) -> np.ndarray:
+    V = _f32c(V)
+    k = V.shape[1]
+    out = np.empty((mat.n, k), np.float32)
+    raise_for(ctx.lib.eofx_project_f32(ctx.handle, mat.handle, ptr(V), k, ptr(out)), ctx.handle)
+    return out
+
+
+def reconstruct(ctx: Context, S, V) -> np.ndarray:
+    S, V = _f32c(S), _f32c(V)
+    n, k = S.shape
+    p = V.shape[0]
+    out = np.empty((n, p), np.float32)
+    raise_for(ctx.lib.eofx_reconstruct_f32(ctx.handle, ptr(S), ptr(V), n, p, k, ptr(out)), ctx.handle)
+    return out
+
+
+def crosscov_rsvd(ctx: Context, x: ResidentMatrix, y: ResidentMatrix, k: int, n_oversamples: int = 10,
+                  n_iter: int | str = "auto", random_state=None, flip: bool = True, omega=None,
+                  want_tsc: bool = True):
+    """Matrix-free rSVD of C = X^T Y/(n-1) -> dict (cpcca.py:168-225 quantities)."""
+    k = int(k)
+    small = min(x.p, y.p)
+    if omega is None:
+        omega = sketch_matrix(small, k + n_oversamples, random_state)
+    omega = np.ascontiguousarray(omega, dtype=np.float32)
+    n = x.n
+    Q1 = np.empty((x.p, k), np.float32)
+    Q2 = np.empty((y.p, k), np.float32)
+    s = np.empty(k, np.float32)
+    s1 = np.empty((n, k), np.float32)
+    s2 = np.empty((n, k), np.float32)
+    n1 = np.empty(k, np.float32)
+    n2 = np.empty(k, np.float32)
+    tsc = C.c_double(float("nan"))
+    it = -1 if n_iter == "auto" else int(n_iter)
+    rc = ctx.lib.eofx_crosscov_rsvd_f32(ctx.handle, x.handle, y.handle, k, int(n_oversamples), it, ptr(omega),
+                                        int(flip), ptr(Q1), ptr(s), ptr(Q2), ptr(s1), ptr(s2), ptr(n1), ptr(n2),
+                                        C.byref(tsc) if want_tsc else None)
+    raise_for(rc, ctx.handle)
+    return dict(Q1=Q1, Q2=Q2, s=s, scores1=s1, scores2=s2, norm1=n1, norm2=n2,
+                total_squared_covariance=tsc.value)
+
+
+def host_eigh(A: np.ndarray):
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    n = A.shape[0]
+    w = np.empty(n)
+    V = np.empty((n, n))
+    raise_for(_lib.load().eofx_host_eigh_f64(ptr(A), n, ptr(w), ptr(V)))
+    return w, V
+
+
+# --------------------------------------------------------------------------- #
+# panel-level steps on torch device tensors (used by the feature-sharded path)  #
+# --------------------------------------------------------------------------- #
+def _torch():
+    import torch
+
+    return torch
+
+
+def panel_width(l: int) -> int:
+    return (int(l) + 31) // 32 * 32
+
+
+def panel_import(ctx: Context, src, rows_pad: int, L: int):
+    torch = _torch()
+    src = _f32c(src)
+    rows, l = src.shape
+    P = torch.empty((rows_pad, L), dtype=torch.float32, device=f"cuda:{ctx.device}")
+    raise_for(ctx.lib.eofx_panel_import_f32(ctx.handle, ptr(src), rows, l, ptr(P), rows_pad, L), ctx.handle)
+    return P
+
+
+def panel_export(ctx: Context, P, rows: int, k: int, sign=None) -> np.ndarray:
+    out = np.empty((rows, k), np.float32)
+    sg = None if sign is None else np.ascontiguousarray(sign, dtype=np.float64)
+    raise_for(ctx.lib.eofx_panel_export_f32(ctx.handle, ptr(P), rows, P.shape[1], k, ptr(sg), ptr(out)), ctx.handle)
+    return out
+
+
+def panel_tmul(ctx: Context, mat: ResidentMatrix, Zn, out=None):
+    """Yp[p_pad, L] = X^T Zn[n_pad, L]"""
+    torch = _torch()
+    L = Zn.shape[1]
+    if out is None:
+        out = torch.empty((mat.p_pad, L), dtype=torch.float32, device=Zn.device)
+    raise_for(ctx.lib.eofx_panel_tmul_f32(ctx.handle, mat.handle, ptr(Zn), ptr(out), L), ctx.handle)
+    return out
+
+
+def panel_mul(ctx: Context, mat: ResidentMatrix, Yp, out=None):
+    """Wn[n_pad, L] = X Yp[p_pad, L]"""
+    torch = _torch()
+    L = Yp.shape[1]
+    if out is None:
+        out = torch.empty((mat.n_pad, L), dtype=torch.float32, device=Yp.device)
+    raise_for(ctx.lib.eofx_panel_mul_f32(ctx.handle, mat.handle, ptr(Yp), ptr(out), L), ctx.handle)
+    return out
+
+
+def panel_gram(ctx: Context, P, out=None):
+    torch = _torch()
+    L = P.shape[1]
+    if out is None:
+        out = torch.empty((L, L), dtype=torch.float64, device=P.device)
+    raise_for(ctx.lib.eofx_panel_gram_f64(ctx.handle, ptr(P), P.shape[0], L, ptr(out)), ctx.handle)
+    return out
+
+
+def panel_cholqr(ctx: Context, P, l: int, G, out=None):
+    torch = _torch()
+    if out is None:
+        out = torch.empty_like(P)
+    raise_for(ctx.lib.eofx_panel_cholqr_f32(ctx.handle, ptr(P), P.shape[0], P.shape[1], int(l), ptr(G), ptr(out)),
+              ctx.handle)
+    return out
+
+
+def panel_matmul(ctx: Context, P, M, out=None):
+    torch = _torch()
+    Lo = M.shape[1]
+    if out is None:
+        out = torch.empty((P.shape[0], Lo), dtype=torch.float32, device=P.device)
+    raise_for(ctx.lib.eofx_panel_matmul_f32(ctx.handle, ptr(P), P.shape[0], P.shape[1], ptr(M), Lo, ptr(out)),
+              ctx.handle)
+    return out
+
+
+def panel_colminmax(ctx: Context, P, rows: int):
+    torch = _torch()
+    L = P.shape[1]
+    mx = torch.empty(L, dtype=torch.float32, device=P.device)
+    mn = torch.empty(L, dtype=torch.float32, device=P.device)
+    raise_for(ctx.lib.eofx_panel_colminmax_f32(ctx.handle, ptr(P), int(rows), L, ptr(mx), ptr(mn)), ctx.handle)
+    return mx, mn
