@@ -1,0 +1,301 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the MI355X-native EOF / randomized-SVD engine.
+
+Metric (BASELINE.json): "EOF randomized-SVD GB/s + modes/s, 10000 x 1.0M grid, n_modes=50".
+Workload: xe.single.EOF(n_modes=50, random_state=5).fit on a synthetic fp32 field
+10000 x (720 x 1440) (decaying-spectrum low-rank + unit noise + mean field),
+space axis sharded over the ranks (strong scaling: the grid is fixed, each of N GPUs holds
+p/N grid points).
+
+A "step" is one whole fit of the hot path with the raw field resident in HBM:
+    fused preprocess (NaN mask / centre / weight / transpose)  ->  randomized SVD (n_iter=7:
+    16 passes over the matrix, sklearn's algorithm)  ->  sign rule, U, s, V (device resident).
+value = algorithmic SVD bytes (16 * n * p * 4 B, the reference's 16 GEMM passes) / step time.
+
+One JSON line on rank 0; see the task contract for the fields.  Extra objects:
+  roofline      dominant kernel atb_f32 (exact-f32 MFMA): algorithmic flops per launch
+                (2 n p_local 60) / mean launch duration from HIP events on the launch stream.
+  cpu_baseline  the oracle's sklearn-restated randomized_svd (oracle/, "port") timed on the host
+                cores on a bounded sample (C2 shape 5000 x 259200 fp32), same algorithm.
+  parity        size-independent checks at full size + singular values vs the CPU run on the
+                sample.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_OVERSAMPLES = 10
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBPS = 8000.0
+
+
+def ar1_series(n, r):
+    """unit-variance AR(1) (phi=0.8) time series t_j, seeds 1000+j."""
+    from scipy.signal import lfilter
+
+    T = np.empty((n, r), dtype=np.float64)
+    for j in range(r):
+        e = np.random.default_rng(1000 + j).standard_normal(n)
+        t = lfilter([0.6], [1.0, -0.8], e)
+        T[:, j] = (t - t.mean()) / t.std()
+    return T
+
+
+def spatial_patterns(n_lat, n_lon, r, device):
+    """smooth unit-norm spatial patterns g_j on the full grid, seeds 2000+j -> (r, P) tensor."""
+    import torch
+
+    yy = torch.linspace(0, np.pi, n_lat, device=device, dtype=torch.float32)[:, None]
+    xx = (torch.arange(n_lon, device=device, dtype=torch.float32) * (2 * np.pi / n_lon))[None, :]
+    G = torch.empty((r, n_lat * n_lon), device=device, dtype=torch.float32)
+    for j in range(r):
+        rg = np.random.default_rng(2000 + j)
+        g = torch.zeros((n_lat, n_lon), device=device, dtype=torch.float32)
+        for _ in range(4):
+            ky, kx = rg.integers(1, 6, size=2)
+            c, ph1, ph2 = rg.standard_normal(), rg.uniform(0, 2 * np.pi), rg.uniform(0, 2 * np.pi)
+            g += float(c) * torch.sin(float(ky) * yy + float(ph1)) * torch.cos(float(kx) * xx + float(ph2))
+        G[j] = (g / g.norm()).reshape(-1)
+    return G
+
+
+def make_field(n, n_lat, n_lon, lo, hi, device, rank_r=100, row_chunk=500):
+    """Columns [lo, hi) of the global synthetic field, generated on the GPU.  Every rank draws
+    the full-width noise of a row chunk from the same seed and keeps its slice, so the global
+    field is independent of the number of ranks."""
+    import torch
+
+    P = n_lat * n_lon
+    T = torch.as_tensor(ar1_series(n, rank_r) * (10.0 * 0.93 ** np.arange(rank_r)), dtype=torch.float32,
+                        device=device)
+    G = spatial_patterns(n_lat, n_lon, rank_r, device)
+    lat = torch.linspace(-89.75, 89.75, n_lat, device=device, dtype=torch.float32)
+    meanf = (15.0 + 10.0 * torch.cos(torch.deg2rad(lat)))[:, None].expand(n_lat, n_lon).reshape(-1)
+    X = torch.empty((n, hi - lo), dtype=torch.float32, device=device)
+    gen = torch.Generator(device=device)
+    for r0 in range(0, n, row_chunk):
+        r1 = min(n, r0 + row_chunk)
+        gen.manual_seed(77_000 + r0)
+        full = torch.randn((r1 - r0, P), generator=gen, device=device, dtype=torch.float32)
+        full.addmm_(T[r0:r1], G)
+        full += meanf
+        X[r0:r1] = full[:, lo:hi]
+        del full
+    return X
+
+
+def blas_threads():
+    try:
+        from threadpoolctl import threadpool_info
+
+        return max([i.get("num_threads", 1) for i in threadpool_info() if i.get("user_api") == "blas"] or [1])
+    except Exception:
+        return os.cpu_count() or 1
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=10000)
+    ap.add_argument("--nlat", type=int, default=720)
+    ap.add_argument("--nlon", type=int, default=1440)
+    ap.add_argument("--modes", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sample-parity", action="store_true",
+                    help="also decompose the CPU-baseline sample on the GPU and compare singular values "
+                         "(adds smaller launches of the dominant kernel; tests/test_gpu_parity.py covers it)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from xeofs_amd import engine, sharded
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible (xeofs_amd has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device(f"cuda:{local_rank}")
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    if args.gpus != world:
+        if rank == 0:
+            print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+
+    n, k = args.n, args.modes
+    P = args.nlat * args.nlon
+    lo, hi = sharded.shard_bounds(P, world, rank)
+    ctx = engine.Context(local_rank)
+    comm = sharded.Comm()
+
+    t0 = time.perf_counter()
+    Xraw = make_field(n, args.nlat, args.nlon, lo, hi, device)
+    torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t0
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    phase = {"pre": 0.0, "svd": 0.0}
+
+    def step():
+        a = time.perf_counter()
+        mat, st = engine.preprocess(ctx, Xraw, center=True, standardize=False, feature_weights=None,
+                                    want_stats=False)
+        torch.cuda.synchronize()
+        b = time.perf_counter()
+        if world == 1:
+            U, s, V = engine.rsvd(ctx, mat, k, N_OVERSAMPLES, "auto", random_state=5, device_out=True)
+        else:
+            ops = sharded.HipPanelOps(ctx, mat)
+            U, s, V = sharded.sharded_rsvd(ops, comm, k, P, lo, N_OVERSAMPLES, "auto", random_state=5)
+        torch.cuda.synchronize()
+        c = time.perf_counter()
+        phase["pre"] += b - a
+        phase["svd"] += c - b
+        return mat, st, U, s, V
+
+    for _ in range(args.warmup):
+        out = step()
+        out[0].free()
+        del out
+    ctx.profile(True)
+    phase["pre"] = phase["svd"] = 0.0
+    barrier()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        if last is not None:
+            last[0].free()
+        last = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = ctx.profile_read()
+    ctx.profile(False)
+    tt = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    ms_step = 1e3 * dt / args.steps
+    mat, st, U, s, V = last
+
+    # ---- size-independent parity checks at full size: X V = U diag(s), orthonormal U ----------
+    Ud = U if torch.is_tensor(U) else torch.as_tensor(U, device=device)
+    Vd = V if torch.is_tensor(V) else torch.as_tensor(V, device=device)
+    sd = torch.as_tensor(np.asarray(s, dtype=np.float64), device=device)
+    XV = torch.as_tensor(engine.project(ctx, mat, Vd), device=device).double()
+    if world > 1:
+        dist.all_reduce(XV)
+    Us = Ud.double() * sd
+    relres = float((XV - Us).norm() / Us.norm())
+    orth_u = float((Ud.double().T @ Ud.double() - torch.eye(k, device=device, dtype=torch.float64)).abs().max())
+    vtv = Vd.double().T @ Vd.double()
+    if world > 1:
+        dist.all_reduce(vtv)
+    orth_v = float((vtv - torch.eye(k, device=device, dtype=torch.float64)).abs().max())
+    parity = {"XV_eq_Us_relerr": relres, "orth_U_maxabs": orth_u, "orth_V_maxabs": orth_v,
+              "s_head": [float(x) for x in np.asarray(s)[:3]]}
+
+    n_iter = sharded.rsvd_auto_iters(k, n, P)
+    passes = 2 * n_iter + 2
+    alg_bytes = passes * n * P * 4.0
+    alg_flops_launch = 2.0 * n * (hi - lo) * (k + N_OVERSAMPLES)   # per pass, per rank
+    launch_ms = prof["ms"] / max(prof["launches"], 1)
+    achieved_tflops = alg_flops_launch / (launch_ms * 1e-3) / 1e12 if launch_ms > 0 else 0.0
+    pmc_traffic = None
+    tfile = os.path.join(ROOT, "profiles", "r01_atb_hbm_traffic.json")
+    if os.path.exists(tfile):
+        try:
+            with open(tfile) as f:
+                tj = json.load(f)
+            if tj.get("workload") == f"{n}x{args.nlat}x{args.nlon}" and tj.get("n_gpus") == world:
+                pmc_traffic = tj.get("bytes_per_launch")
+        except Exception:
+            pmc_traffic = None
+    roofline = {
+        "kernel": "atb_f32_kernel<2> (C = A^T B, exact-f32 MFMA 32x32x2)",
+        "bound": "mfma", "achieved": round(achieved_tflops, 3), "peak": PEAK_F32_MFMA_TFLOPS,
+        "unit": "TFLOP/s", "frac": round(achieved_tflops / PEAK_F32_MFMA_TFLOPS, 4),
+        "traffic": pmc_traffic,
+        "launches_timed": prof["launches"], "mean_launch_ms": round(launch_ms, 4),
+        "alg_flops_per_launch": alg_flops_launch,
+        "hbm_alg_GBps": round(n * (hi - lo) * 4.0 / (launch_ms * 1e-3) / 1e9, 1) if launch_ms > 0 else 0.0,
+    }
+
+    # ---- CPU baseline + parity on a bounded sample (rank 0, N=1 only) -------------------------
+    cpu_baseline = None
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import eof_oracle as orc   # checker / baseline only
+
+        mat.free()
+        del Xraw, last, XV, Us
+        torch.cuda.empty_cache()
+        ns, nlat_s, nlon_s, ks = 5000, 360, 720, 50
+        Xs = make_field(ns, nlat_s, nlon_s, 0, nlat_s * nlon_s, device)
+        mat_s, _ = engine.preprocess(ctx, Xs, want_stats=False)
+        sg = None
+        if args.sample_parity:
+            Ug, sg, Vg = engine.rsvd(ctx, mat_s, ks, N_OVERSAMPLES, "auto", random_state=5)
+        Xc = mat_s.download()           # the centred float32 matrix the GPU decomposed
+        mat_s.free()
+        del Xs
+        t0 = time.perf_counter()
+        Uc, sc, Vtc = orc.randomized_svd(Xc, ks, random_state=5)
+        t_cpu = time.perf_counter() - t0
+        bytes_s = (2 * sharded.rsvd_auto_iters(ks, ns, nlat_s * nlon_s) + 2) * ns * nlat_s * nlon_s * 4.0
+        cpu_baseline = {
+            "value": round(bytes_s / t_cpu / 1e9, 3), "unit": "GB/s", "cores": blas_threads(),
+            "kind": "port",
+            "sample": f"oracle randomized_svd (sklearn restatement, fp32, n_iter=7, k=50) on the {ns}x({nlat_s}x{nlon_s}) "
+                      f"config-2 field, {t_cpu:.2f} s wall, {ks / t_cpu:.2f} modes/s",
+            "host_cpus": os.cpu_count(),
+        }
+        if sg is not None:
+            parity["sample_sv_relerr_vs_cpu_max"] = float(np.max(np.abs(sg - sc) / sc))
+
+    if rank == 0:
+        line = {
+            "metric": "EOF randomized-SVD GB/s (algorithmic: 16 passes x n x p x 4 B per fit / fit time)",
+            "value": round(alg_bytes / (ms_step * 1e-3) / 1e9, 2), "unit": "GB/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"xe.single.EOF n_modes={k} on synthetic fp32 {n}x({args.nlat}x{args.nlon}), "
+                                   f"feature axis sharded over {world} GPU(s), n_iter={n_iter}, n_oversamples=10, "
+                                   f"random_state=5",
+                       "n_samples": n, "n_features": P, "n_modes": k, "passes": passes},
+            "modes_per_s": round(k / (ms_step * 1e-3), 2),
+            "phase_ms": {"preprocess": round(1e3 * phase["pre"] / args.steps, 3),
+                         "svd": round(1e3 * phase["svd"] / args.steps, 3)},
+            "svd_only_GBps": round(alg_bytes / (phase["svd"] / args.steps) / 1e9, 2),
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,
+            "datagen_s": round(t_gen, 2),
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -60,6 +60,16 @@ int eofx_ctx_create(int device, void *stream, eofx_ctx **out);
 int eofx_ctx_destroy(eofx_ctx *ctx);
 int eofx_ctx_synchronize(eofx_ctx *ctx);
 const char *eofx_last_error(const eofx_ctx *ctx);
+/* Destroyed resident matrices leave their HBM buffers in a per-context cache (allocating
+ * tens of GB costs more than a fit); eofx_ctx_trim returns that cache to the device. */
+int eofx_ctx_trim(eofx_ctx *ctx);
+/* Measurement aid: when enabled, every launch of the dominant kernel (atb_f32, the
+ * A^T B product that streams the matrix) is bracketed by HIP events on the context
+ * stream.  _read synchronises, returns and resets: the number of launches, their summed
+ * duration, the flops issued (2*K*M*L on padded sizes) and the matrix bytes streamed.  */
+int eofx_ctx_profile(eofx_ctx *ctx, int enable);
+int eofx_ctx_profile_read(eofx_ctx *ctx, int64_t *launches, double *total_ms, double *flops,
+                          double *bytes);
 
 /* ---- resident matrix ---------------------------------------------------
  * An eofx_mat holds the preprocessed matrix twice in HBM, zero padded:

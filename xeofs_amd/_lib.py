@@ -31,6 +31,9 @@ SIGNATURES = {
     "eofx_ctx_destroy": (_int, [_vp]),
     "eofx_ctx_synchronize": (_int, [_vp]),
     "eofx_last_error": (C.c_char_p, [_vp]),
+    "eofx_ctx_trim": (_int, [_vp]),
+    "eofx_ctx_profile": (_int, [_vp, _int]),
+    "eofx_ctx_profile_read": (_int, [_vp, _pi64, _pd, _pd, _pd]),
     "eofx_preprocess_f32": (_int, [_vp, _vp, _i64, _i64, _int, _int, _vp, _int, C.POINTER(_vp),
                                    _vp, _vp, _vp, _vp, _pi64, _pi64, _pd]),
     "eofx_apply_f32": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _int, C.POINTER(_vp), _vp, _pi64]),

@@ -26,6 +26,16 @@ struct eofx_ctx {
   size_t arena_size = 0;
   size_t arena_off = 0;
   std::string err;
+  // released resident-matrix buffers, kept for reuse: hipMalloc/hipFree of tens of GB cost
+  // ~1 s, far more than a fit.  Bounded by pool_cap bytes; eofx_ctx_trim() empties it.
+  std::vector<std::pair<void*, size_t>> pool;
+  size_t pool_bytes = 0;
+  size_t pool_cap = (size_t)160 << 30;
+  // optional per-launch timing of the dominant kernel (atb_f32) with HIP events on `stream`
+  bool profile = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+  double prof_flops = 0.0;  // 2*K*M*L summed over profiled launches (padded sizes)
+  double prof_bytes = 0.0;  // K*M*4 (the A stream) summed over profiled launches
 };
 
 struct eofx_mat {
@@ -106,6 +116,8 @@ struct ArenaScope {
   T* var = arena_alloc<T>(ctx, (size_t)(count));                                 \
   if (!var) return set_err(ctx, EOFX_ERR_NOMEM, "internal: arena exhausted (%s)", #var)
 
+static void pool_trim(eofx_ctx* ctx);
+
 static int set_device(eofx_ctx* ctx) {
   HIPCHK(hipSetDevice(ctx->device));
   return EOFX_OK;
@@ -134,6 +146,7 @@ extern "C" int eofx_ctx_destroy(eofx_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(ctx->arena);
   }
+  pool_trim(ctx);
   delete ctx;
   return EOFX_OK;
 }
@@ -144,6 +157,34 @@ extern "C" int eofx_ctx_synchronize(eofx_ctx* ctx) {
   return EOFX_OK;
 }
 extern "C" const char* eofx_last_error(const eofx_ctx* ctx) { return ctx ? ctx->err.c_str() : ""; }
+
+extern "C" int eofx_ctx_profile(eofx_ctx* ctx, int enable) {
+  if (!ctx) return EOFX_ERR_ARG;
+  ctx->profile = enable != 0;
+  return EOFX_OK;
+}
+extern "C" int eofx_ctx_profile_read(eofx_ctx* ctx, int64_t* launches, double* total_ms, double* flops,
+                                     double* bytes) {
+  if (!ctx) return EOFX_ERR_ARG;
+  CHK(set_device(ctx));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  double ms = 0.0;
+  for (auto& pr : ctx->prof_events) {
+    float t = 0.f;
+    HIPCHK(hipEventElapsedTime(&t, pr.first, pr.second));
+    ms += t;
+    (void)hipEventDestroy(pr.first);
+    (void)hipEventDestroy(pr.second);
+  }
+  if (launches) *launches = (int64_t)ctx->prof_events.size();
+  if (total_ms) *total_ms = ms;
+  if (flops) *flops = ctx->prof_flops;
+  if (bytes) *bytes = ctx->prof_bytes;
+  ctx->prof_events.clear();
+  ctx->prof_flops = 0.0;
+  ctx->prof_bytes = 0.0;
+  return EOFX_OK;
+}
 
 // copy device -> user pointer (host or device)
 static int copy_out(eofx_ctx* ctx, void* dst, const void* src_dev, size_t bytes) {
@@ -263,6 +304,12 @@ static int launch_atb(eofx_ctx* ctx, const float* A, int64_t lda, int64_t K, int
       out = C;
     }
   }
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (ctx->profile) {
+    HIPCHK(hipEventCreate(&ev0));
+    HIPCHK(hipEventCreate(&ev1));
+    HIPCHK(hipEventRecord(ev0, ctx->stream));
+  }
   if (nfull > 0) {
     dim3 grid(bx, best_s, nfull);
     hipLaunchKernelGGL(atb_f32_kernel<2>, grid, dim3(256), 0, ctx->stream, A, lda, B, ldb, out, L, M,
@@ -274,6 +321,12 @@ static int launch_atb(eofx_ctx* ctx, const float* A, int64_t lda, int64_t K, int
     hipLaunchKernelGGL(atb_f32_kernel<1>, grid, dim3(256), 0, ctx->stream, A, lda, B, ldb, out, L, M,
                        K, best_kps, nfull * 64);
     KCHK();
+  }
+  if (ctx->profile) {
+    HIPCHK(hipEventRecord(ev1, ctx->stream));
+    ctx->prof_events.emplace_back(ev0, ev1);
+    ctx->prof_flops += 2.0 * (double)K * (double)M * (double)L;
+    ctx->prof_bytes += (double)K * (double)M * 4.0 * (nfull + (rem ? 1 : 0));
   }
   if (best_s > 1) {
     const int64_t count4 = M * L / 4;
@@ -384,6 +437,56 @@ static int import_panel(eofx_ctx* ctx, const float* src, int64_t rows, int l, fl
 // ------------------------------------------------------------------------------------
 // resident matrix
 // ------------------------------------------------------------------------------------
+static void* pool_take(eofx_ctx* ctx, size_t bytes) {
+  for (size_t i = 0; i < ctx->pool.size(); ++i)
+    if (ctx->pool[i].second == bytes) {
+      void* p = ctx->pool[i].first;
+      ctx->pool_bytes -= bytes;
+      ctx->pool.erase(ctx->pool.begin() + i);
+      return p;
+    }
+  return nullptr;
+}
+static void pool_trim(eofx_ctx* ctx) {
+  if (ctx->pool.empty()) return;
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto& e : ctx->pool) (void)hipFree(e.first);
+  ctx->pool.clear();
+  ctx->pool_bytes = 0;
+}
+static void pool_give(eofx_ctx* ctx, void* p, size_t bytes) {
+  if (!p) return;
+  if (!ctx || bytes > ctx->pool_cap) {
+    (void)hipFree(p);
+    return;
+  }
+  while (!ctx->pool.empty() && ctx->pool_bytes + bytes > ctx->pool_cap) {
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(ctx->pool.front().first);
+    ctx->pool_bytes -= ctx->pool.front().second;
+    ctx->pool.erase(ctx->pool.begin());
+  }
+  ctx->pool.emplace_back(p, bytes);
+  ctx->pool_bytes += bytes;
+}
+static hipError_t pool_malloc(eofx_ctx* ctx, void** out, size_t bytes) {
+  *out = pool_take(ctx, bytes);
+  if (*out) return hipSuccess;
+  hipError_t e = hipMalloc(out, bytes);
+  if (e != hipSuccess && !ctx->pool.empty()) {  // out of memory: drop the cache and retry
+    (void)hipGetLastError();
+    pool_trim(ctx);
+    e = hipMalloc(out, bytes);
+  }
+  return e;
+}
+extern "C" int eofx_ctx_trim(eofx_ctx* ctx) {
+  if (!ctx) return EOFX_ERR_ARG;
+  (void)hipSetDevice(ctx->device);
+  pool_trim(ctx);
+  return EOFX_OK;
+}
+
 static int mat_alloc(eofx_ctx* ctx, int64_t n, int64_t p, eofx_mat** out) {
   eofx_mat* m = new eofx_mat();
   m->n = n;
@@ -391,8 +494,8 @@ static int mat_alloc(eofx_ctx* ctx, int64_t n, int64_t p, eofx_mat** out) {
   m->n_pad = round_up(n, ATB_BM);
   m->p_pad = round_up(p, ATB_BM);
   const size_t bytes = (size_t)m->n_pad * m->p_pad * sizeof(float);
-  hipError_t e = hipMalloc((void**)&m->X, bytes);
-  if (e == hipSuccess) e = hipMalloc((void**)&m->Xt, bytes);
+  hipError_t e = pool_malloc(ctx, (void**)&m->X, bytes);
+  if (e == hipSuccess) e = pool_malloc(ctx, (void**)&m->Xt, bytes);
   if (e != hipSuccess) {
     if (m->X) (void)hipFree(m->X);
     delete m;
@@ -406,12 +509,16 @@ static int mat_alloc(eofx_ctx* ctx, int64_t n, int64_t p, eofx_mat** out) {
 
 extern "C" int eofx_mat_destroy(eofx_ctx* ctx, eofx_mat* m) {
   if (!m) return EOFX_OK;
+  const size_t bytes = (size_t)m->n_pad * m->p_pad * sizeof(float);
   if (ctx) {
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    // same-stream reuse is ordered; nothing else touches these buffers
+    pool_give(ctx, m->X, bytes);
+    pool_give(ctx, m->Xt, bytes);
+  } else {
+    if (m->X) (void)hipFree(m->X);
+    if (m->Xt) (void)hipFree(m->Xt);
   }
-  if (m->X) (void)hipFree(m->X);
-  if (m->Xt) (void)hipFree(m->Xt);
   delete m;
   return EOFX_OK;
 }

@@ -44,6 +44,21 @@ class Context:
     def synchronize(self):
         raise_for(self.lib.eofx_ctx_synchronize(self.handle), self.handle)
 
+    def trim(self):
+        """Return cached resident-matrix buffers to the device."""
+        raise_for(self.lib.eofx_ctx_trim(self.handle), self.handle)
+
+    def profile(self, enable: bool = True):
+        raise_for(self.lib.eofx_ctx_profile(self.handle, int(enable)), self.handle)
+
+    def profile_read(self):
+        """-> dict(launches, ms, flops, bytes) of the atb_f32 launches since the last read."""
+        n = C.c_int64()
+        ms, fl, by = C.c_double(), C.c_double(), C.c_double()
+        raise_for(self.lib.eofx_ctx_profile_read(self.handle, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)),
+                  self.handle)
+        return dict(launches=n.value, ms=ms.value, flops=fl.value, bytes=by.value)
+
     def close(self):
         if getattr(self, "handle", None):
             self.lib.eofx_ctx_destroy(self.handle)
@@ -163,8 +178,9 @@ def apply(ctx: Context, X, mean, std, feature_weights, valid_feature, check_nans
 
 
 def rsvd(ctx: Context, mat: ResidentMatrix, k: int, n_oversamples: int = 10, n_iter: int | str = "auto",
-         random_state=None, flip: bool = True, omega=None):
-    """randomized SVD of the resident matrix -> (U[n,k], s[k], V[p,k]) float32 host arrays."""
+         random_state=None, flip: bool = True, omega=None, device_out: bool = False):
+    """randomized SVD of the resident matrix -> (U[n,k], s[k], V[p,k]) float32 host arrays
+    (or torch device tensors for U and V with `device_out=True`: nothing crosses PCIe)."""
     k = int(k)
     small = min(mat.n, mat.p)
     if omega is None:
@@ -172,9 +188,14 @@ def rsvd(ctx: Context, mat: ResidentMatrix, k: int, n_oversamples: int = 10, n_i
     omega = np.ascontiguousarray(omega, dtype=np.float32)
     if omega.shape != (small, k + n_oversamples):
         raise ValueError(f"omega must have shape {(small, k + n_oversamples)}")
-    U = np.empty((mat.n, k), np.float32)
+    if device_out:
+        torch = _torch()
+        U = torch.empty((mat.n, k), dtype=torch.float32, device=f"cuda:{ctx.device}")
+        V = torch.empty((mat.p, k), dtype=torch.float32, device=f"cuda:{ctx.device}")
+    else:
+        U = np.empty((mat.n, k), np.float32)
+        V = np.empty((mat.p, k), np.float32)
     s = np.empty(k, np.float32)
-    V = np.empty((mat.p, k), np.float32)
     it = -1 if n_iter == "auto" else int(n_iter)
     rc = ctx.lib.eofx_rsvd_f32(ctx.handle, mat.handle, k, int(n_oversamples), it, ptr(omega), int(flip),
                                ptr(U), ptr(s), ptr(V))
