@@ -1,0 +1,189 @@
+"""GPU tests of the drop-in model classes, mirroring the reference's own model tests
+(tests/models/single/test_eof.py, tests/models/cross/test_mca.py) on its mock fixtures
+(tests/conftest.py:225-278), plus value parity against the oracle."""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import eof_oracle as orc  # noqa: E402  (checker only)
+
+
+def mock_values():
+    rng = np.random.default_rng(7)
+    noise = rng.normal(5, 3, size=(25, 5, 4))
+    signal = 2 * np.sin(np.linspace(0, 2 * np.pi, 25))[:, None, None]
+    return signal + noise
+
+
+def mock_data_array(values=None):
+    import xeofs_amd as xe
+
+    v = mock_values() if values is None else values
+    return xe.DataArray(v, dims=("time", "lat", "lon"),
+                        coords={"time": np.arange(2001, 2026), "lat": [20.0, 30.0, 40.0, 50.0, 60.0],
+                                "lon": [-10.0, 0.0, 10.0, 20.0]}, name="t2m")
+
+
+@pytest.fixture(autouse=True)
+def _ctx(ctx):
+    return ctx
+
+
+@pytest.mark.parametrize("dim", [("time",), ("lat", "lon"), ("lon", "lat")])
+def test_eof_fit_dims(dim):  # test_eof.py:19-31, 126-181
+    import xeofs_amd as xe
+
+    X = mock_data_array()
+    m = xe.single.EOF(n_modes=3, random_state=1).fit(X, dim)
+    comps, scores = m.components(), m.scores()
+    fdims = tuple(d for d in X.dims if d not in dim)
+    assert comps.dims == ("mode",) + fdims and scores.dims == ("mode",) + tuple(dim)
+    assert comps.shape == (3,) + tuple(X.sizes[d] for d in fdims)
+    assert not np.isnan(comps.values).any() and not np.isnan(scores.values).any()
+    ev, evr = m.explained_variance(), m.explained_variance_ratio()
+    assert (ev.values > 0).all()                                   # test_eof.py:65-74
+    assert evr.values.sum() <= 1 + 1e-5                            # test_eof.py:85-100
+    assert list(m.singular_values().coords["mode"]) == [1, 2, 3]
+    assert comps.attrs["model"] == "EOF analysis" and comps.attrs["center"] == "True"
+
+
+def test_eof_values_vs_oracle():
+    import xeofs_amd as xe
+
+    X = mock_data_array()
+    m = xe.single.EOF(n_modes=4, use_coslat=True, random_state=3, solver="randomized").fit(X, "time")
+    w = np.repeat(orc.sqrt_cos_lat_weights(X.coords["lat"]), 4)
+    ref = orc.eof_fit(mock_values().reshape(25, 20), 4, feature_weights=w, random_state=3, solver="randomized")
+    s = m.singular_values().values
+    assert np.all(np.abs(s - ref["norms"]) <= 1e-5 * ref["norms"][0])
+    c = m.components().values.reshape(4, 20)
+    for j in range(4):
+        assert np.dot(c[j], ref["components"][:, j]) >= 1 - 1e-5
+    assert np.allclose(m.explained_variance_ratio().values, ref["explained_variance_ratio"], rtol=2e-5)
+    sc = m.scores().values
+    assert np.allclose(sc, ref["scores"].T, rtol=1e-3, atol=2e-4 * np.abs(ref["scores"]).max())
+    # normalized accessors (base_model_single_set.py:316-336)
+    assert np.allclose(m.scores(normalized=True).values, sc / s[:, None], rtol=1e-6)
+    assert np.allclose(m.components(normalized=False).values.reshape(4, 20), c * s[:, None], rtol=1e-6)
+
+
+def test_eof_isolated_nan_raises():  # test_eof.py:111-115
+    import xeofs_amd as xe
+
+    v = mock_values()
+    v[0, 1, 0] = np.nan
+    with pytest.raises(ValueError, match="partial NaN"):
+        xe.single.EOF().fit(mock_data_array(v), "time")
+
+
+@pytest.mark.parametrize("kind", ["full_dimensional", "boundary"])
+def test_eof_nan_fixtures(kind):  # conftest.py:265-278, test_eof.py:148-181, 267-298
+    import xeofs_amd as xe
+
+    v = mock_values()
+    v[:, 1, :] = np.nan
+    v[1 if kind == "full_dimensional" else 0] = np.nan
+    m = xe.single.EOF(n_modes=3, random_state=0).fit(mock_data_array(v), "time")
+    c, s = m.components().values, m.scores().values
+    assert c.shape == (3, 5, 4) and s.shape == (3, 25)
+    assert np.isnan(c[:, 1, :]).all() and not np.isnan(np.delete(c, 1, axis=1)).any()
+    row = 1 if kind == "full_dimensional" else 0
+    assert np.isnan(s[:, row]).all() and not np.isnan(np.delete(s, row, axis=1)).any()
+
+
+def test_eof_transform_equals_scores_and_inverse_roundtrip():  # test_eof.py:364-391, 455-488
+    import xeofs_amd as xe
+
+    X = mock_data_array()
+    m = xe.single.EOF(n_modes=20, solver="full", standardize=True).fit(X, "time")
+    sc = m.scores()
+    tr = m.transform(X)
+    assert tr.dims == sc.dims
+    assert np.allclose(tr.values, sc.values, rtol=1e-3, atol=1e-3 * np.abs(sc.values).max())
+    rec = m.inverse_transform(sc)
+    assert rec.dims == X.dims
+    assert np.allclose(rec.values, X.values, rtol=1e-4, atol=2e-4)
+    # unseen data -> no NaN (test_eof.py:393-408)
+    new = mock_data_array(mock_values()[:7] + 1.0)
+    new.coords["time"] = np.arange(7)
+    out = m.transform(new)
+    assert out.shape == (20, 7) and not np.isnan(out.values).any()
+    # NaN feature in new data -> error (test_eof.py:419-441)
+    bad = mock_values()
+    bad[:, 2, 1] = np.nan
+    with pytest.raises(ValueError, match="different locations"):
+        m.transform(mock_data_array(bad))
+
+
+def test_eof_list_input_and_weights():
+    import xeofs_amd as xe
+
+    X = mock_data_array()
+    X2 = mock_data_array(mock_values() ** 2)
+    wts = xe.DataArray(np.linspace(0.5, 1.5, 5), dims=("lat",), coords={"lat": X.coords["lat"]})
+    m = xe.single.EOF(n_modes=3, random_state=2).fit([X, X2], "time", weights=wts)
+    comps = m.components()
+    assert isinstance(comps, list) and len(comps) == 2 and comps[0].dims == ("mode", "lat", "lon")
+    M = np.concatenate([mock_values().reshape(25, 20), (mock_values() ** 2).reshape(25, 20)], axis=1)
+    w = np.tile(np.repeat(np.linspace(0.5, 1.5, 5), 4), 2)
+    ref = orc.eof_fit(M, 3, feature_weights=w, random_state=2, solver="randomized")
+    assert np.allclose(m.singular_values().values, ref["norms"], rtol=1e-5)
+
+
+def test_mca_against_oracle_and_invariants():  # test_mca.py:20-119, test_cpcca.py:152-164
+    import xeofs_amd as xe
+
+    rng = np.random.default_rng(5)
+    T = rng.standard_normal((60, 4)) * (3.0 * 0.6 ** np.arange(4))
+    A = (T @ rng.standard_normal((4, 30)) + 0.3 * rng.standard_normal((60, 30))).reshape(60, 5, 6)
+    B = (T @ rng.standard_normal((4, 28)) + 0.3 * rng.standard_normal((60, 28))).reshape(60, 4, 7)
+    X = xe.DataArray(A, dims=("time", "lat", "lon"))
+    Y = xe.DataArray(B, dims=("time", "y", "x"))
+    m = xe.cross.MCA(n_modes=3, random_state=7, solver="randomized").fit(X, Y, "time")
+    ref = orc.mca_fit(A.reshape(60, 30), B.reshape(60, 28), 3, random_state=7, solver="randomized")
+    s = m.singular_values().values
+    assert np.allclose(s, ref["singular_values"], rtol=2e-5)
+    c1, c2 = m.components()
+    assert c1.dims == ("mode", "lat", "lon") and c2.dims == ("mode", "y", "x")
+    for j in range(3):
+        assert np.dot(c1.values.reshape(3, -1)[j], ref["components1"][:, j]) >= 1 - 1e-5
+        assert np.dot(c2.values.reshape(3, -1)[j], ref["components2"][:, j]) >= 1 - 1e-5
+    s1, s2 = m.scores()
+    assert s1.dims == ("mode", "time") and np.allclose(s1.values, ref["scores1"].T, rtol=1e-3, atol=1e-3)
+    assert np.isclose(m.total_squared_covariance(), ref["total_squared_covariance"], rtol=1e-5)
+    assert m.squared_covariance_fraction().values.sum() <= 1 + 1e-5
+    t1, t2 = m.transform(X=X, Y=Y)
+    assert np.allclose(t1.values, s1.values, rtol=1e-3, atol=1e-3) and not np.isnan(t2.values).any()
+    with pytest.raises(ValueError, match="same number of samples"):
+        xe.cross.MCA(n_modes=2).fit(X, xe.DataArray(B[:50], dims=("time", "y", "x")), "time")
+
+
+def test_decomposer_mirror(ctx):  # tests/linalg/test_decomposer.py
+    import warnings
+
+    from xeofs_amd.linalg import Decomposer
+
+    X = mock_values().reshape(25, 20)
+    X = (X - X.mean(0)).astype(np.float32)
+    d = Decomposer(n_modes=5, random_state=3).fit(X)
+    assert d.U_.shape == (25, 5) and d.s_.shape == (5,) and d.V_.shape == (20, 5)
+    d2 = Decomposer(n_modes=5, random_state=3).fit(X)
+    assert np.array_equal(d.U_, d2.U_) and np.array_equal(d.V_, d2.V_)        # bitwise determinism
+    with pytest.raises(ValueError, match="rank"):
+        Decomposer(n_modes=21).fit(X)
+    with pytest.raises(ValueError, match="Unrecognized solver"):
+        Decomposer(n_modes=2, solver="nope").fit(X)
+    with pytest.raises(ValueError, match="init_rank_reduction"):
+        Decomposer(n_modes=0.5, init_rank_reduction=0.0)
+    tv = float(np.var(X.astype(np.float64), axis=0, ddof=1).sum())
+    d3 = Decomposer(n_modes=0.6, init_rank_reduction=1.0, solver="full").fit(X, total_variance=tv)
+    sv = np.linalg.svd(X.astype(np.float64), compute_uv=False)
+    assert (d3.s_.astype(np.float64) ** 2).sum() / (sv ** 2).sum() >= 0.6 and d3.s_.size < 20
+    Uo, so, Vo = orc.decomposer_fit(X.astype(np.float64), 0.6, init_rank_reduction=1.0, solver="full")
+    assert d3.s_.size == so.size and np.allclose(d3.s_, so, rtol=1e-5)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        Decomposer(n_modes=0.99, init_rank_reduction=0.1, solver="full").fit(X, total_variance=tv)
+        assert any("init_rank_reduction" in str(x.message) for x in w)

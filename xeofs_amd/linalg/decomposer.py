@@ -1,0 +1,109 @@
+"""Decomposer -- same constructor, policy, errors, warnings and outputs as the reference's
+xeofs/linalg/decomposer.py:15-226, with the solver seam (decomposer.py:141-146, the callable
+given to xr.apply_ufunc) replaced by the HIP engine call `eofx_rsvd_f32`.
+
+`fit` takes the resident (sample x feature) matrix and leaves numpy arrays
+    U_ (sample x mode), s_ (mode), V_ (feature x mode)   [V_ = conj(VT).T, decomposer.py:226]
+"""
+
+from __future__ import annotations
+
+import warnings
+
+import numpy as np
+
+from .. import engine
+
+MAX_SKETCH = 64  # widest sketch the current kernels factorise on-device
+
+
+def sanity_check_n_modes(n_modes):
+    """xeofs/utils/sanity_checks.py:105-119."""
+    if isinstance(n_modes, bool) or not isinstance(n_modes, (int, float, np.integer, np.floating)):
+        raise TypeError("n_modes must be an integer or float")
+    if isinstance(n_modes, (int, np.integer)):
+        if n_modes < 1:
+            raise ValueError("If n_modes is an integer, it must be greater than 0.")
+    elif not (0.0 < n_modes <= 1.0):
+        raise ValueError("If n_modes is a float, it must be strictly between 0 and 1.")
+
+
+class Decomposer:
+    def __init__(self, n_modes, init_rank_reduction=0.3, flip_signs=True, compute=True, solver="auto",
+                 random_state=None, component_dim_name="mode", solver_kwargs={}, ctx=None):
+        sanity_check_n_modes(n_modes)
+        self.is_based_on_variance = not isinstance(n_modes, (int, np.integer))
+        if self.is_based_on_variance and not (0 < init_rank_reduction <= 1.0):
+            raise ValueError("init_rank_reduction must be in the half open interval (0, 1].")
+        self.n_modes = n_modes
+        self.n_modes_precompute = n_modes
+        self.init_rank_reduction = init_rank_reduction
+        self.flip_signs = flip_signs
+        self.compute = compute
+        self.solver = solver
+        self.random_state = random_state
+        self.component_dim_name = component_dim_name
+        self.solver_kwargs = dict(solver_kwargs)
+        self.ctx = ctx
+
+    def fit(self, X, dims=("sample", "feature"), total_variance=None):
+        ctx = self.ctx or engine.default_context()
+        mat = X if isinstance(X, engine.ResidentMatrix) else engine.from_dense(ctx, np.asarray(X))
+        n, p = mat.shape
+        rank = min(n, p)
+        if self.is_based_on_variance:
+            self.n_modes_precompute = int(rank * self.init_rank_reduction)
+            if self.n_modes_precompute < 1:
+                warnings.warn(
+                    f"`init_rank_reduction={self.init_rank_reduction}` is too low resulting in zero components. One component will be computed instead."
+                )
+                self.n_modes_precompute = 1
+        if self.n_modes_precompute > rank:
+            raise ValueError(
+                f"n_modes must be less than or equal to the rank of the dataset (rank = {rank})."
+            )
+        is_small_data = max(n, p) < 500
+        if self.solver == "auto":
+            use_exact = bool(is_small_data and self.n_modes_precompute > int(0.8 * rank))
+        elif self.solver == "full":
+            use_exact = True
+        elif self.solver == "randomized":
+            use_exact = False
+        else:
+            raise ValueError(
+                f"Unrecognized solver '{self.solver}'. "
+                "Valid options are 'auto', 'full', and 'randomized'."
+            )
+        k = int(self.n_modes_precompute)
+        kw = dict(self.solver_kwargs)
+        for name in ("power_iteration_normalizer", "transpose", "flip_sign", "svd_lapack_driver"):
+            kw.pop(name, None)  # sklearn knobs without effect on the result here
+        if use_exact:
+            # A full-width sketch spans the whole row/column space: the same kernels then return the
+            # exact truncated SVD (no power iterations needed).
+            if rank > MAX_SKETCH:
+                raise NotImplementedError(
+                    f"solver='full' needs a sketch of width rank={rank} > {MAX_SKETCH}; use solver='randomized'.")
+            n_over, n_iter = rank - k, 0
+        else:
+            n_over = int(kw.pop("n_oversamples", 10))
+            n_iter = kw.pop("n_iter", "auto")
+            if min(k + n_over, rank) > MAX_SKETCH:
+                raise NotImplementedError(
+                    f"n_modes + n_oversamples = {k + n_over} > {MAX_SKETCH} is not supported by this build.")
+        # the per-mode sign rule (xarray_utils.py:273-301) runs on the GPU; truncating modes afterwards
+        # does not change the sign of the kept ones
+        U, s, V = engine.rsvd(ctx, mat, k, n_over, n_iter, random_state=self.random_state, flip=bool(self.flip_signs))
+        if self.is_based_on_variance:
+            if total_variance is None:
+                raise ValueError("variance-based truncation needs the total variance of the input")
+            cum = np.cumsum(s.astype(np.float64) ** 2 / (n - 1) / total_variance)
+            n_req = k - int((cum >= self.n_modes).sum()) + 1
+            if n_req > k:
+                warnings.warn(
+                    f"Dataset has {k} components, explaining {cum[-1]:.2%} of the variance. However, {self.n_modes:.2%} explained variance was requested. Please consider increasing `init_rank_reduction`."
+                )
+                n_req = k
+            U, s, V = U[:, :n_req], s[:n_req], V[:, :n_req]
+        self.U_, self.s_, self.V_ = U, s, V
+        return self
