@@ -13,8 +13,10 @@ A "step" is one whole fit of the hot path with the raw field resident in HBM:
 value = algorithmic SVD bytes (16 * n * p * 4 B, the reference's 16 GEMM passes) / step time.
 
 One JSON line on rank 0; see the task contract for the fields.  Extra objects:
-  roofline      dominant kernel atb_f32 (exact-f32 MFMA): algorithmic flops per launch
-                (2 n p_local 60) / mean launch duration from HIP events on the launch stream.
+  roofline      dominant kernel (the A^T B pass that streams the matrix): algorithmic bytes per
+                launch (n p_local 4 B; HBM-bound split-bf16 kernel) or flops (2 n p_local 60; exact-f32
+                MFMA kernel with --precision f32) / mean launch duration from HIP events on the
+                launch stream.
   cpu_baseline  the oracle's sklearn-restated randomized_svd (oracle/, "port") timed on the host
                 cores on a bounded sample (C2 shape 5000 x 259200 fp32), same algorithm.
   parity        size-independent checks at full size + singular values vs the CPU run on the
@@ -112,6 +114,8 @@ def main():
     ap.add_argument("--nlat", type=int, default=720)
     ap.add_argument("--nlon", type=int, default=1440)
     ap.add_argument("--modes", type=int, default=50)
+    ap.add_argument("--precision", choices=["mixed", "f32", "bf16x3"], default="mixed",
+                    help="mixed = bf16x3 power passes + bf16x6 final passes (default); f32 = exact-f32 MFMA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sample-parity", action="store_true",
                     help="also decompose the CPU-baseline sample on the GPU and compare singular values "
@@ -143,6 +147,7 @@ def main():
     P = args.nlat * args.nlon
     lo, hi = sharded.shard_bounds(P, world, rank)
     ctx = engine.Context(local_rank)
+    ctx.set_precision(*{"mixed": ("bf16x3", "bf16x6"), "f32": ("f32", "f32"), "bf16x3": ("bf16x3", "bf16x3")}[args.precision])
     comm = sharded.Comm()
 
     t0 = time.perf_counter()
@@ -232,15 +237,26 @@ def main():
                 pmc_traffic = tj.get("bytes_per_launch")
         except Exception:
             pmc_traffic = None
-    roofline = {
-        "kernel": "atb_f32_kernel<2> (C = A^T B, exact-f32 MFMA 32x32x2)",
-        "bound": "mfma", "achieved": round(achieved_tflops, 3), "peak": PEAK_F32_MFMA_TFLOPS,
-        "unit": "TFLOP/s", "frac": round(achieved_tflops / PEAK_F32_MFMA_TFLOPS, 4),
-        "traffic": pmc_traffic,
-        "launches_timed": prof["launches"], "mean_launch_ms": round(launch_ms, 4),
-        "alg_flops_per_launch": alg_flops_launch,
-        "hbm_alg_GBps": round(n * (hi - lo) * 4.0 / (launch_ms * 1e-3) / 1e9, 1) if launch_ms > 0 else 0.0,
-    }
+    alg_bytes_launch = n * (hi - lo) * 4.0                        # one pass streams the f32 matrix once
+    achieved_gbps = alg_bytes_launch / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+    if args.precision == "f32":
+        roofline = {
+            "kernel": "atb_f32_kernel<2> (C = A^T B, exact-f32 MFMA 32x32x2)",
+            "bound": "mfma", "achieved": round(achieved_tflops, 3), "peak": PEAK_F32_MFMA_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(achieved_tflops / PEAK_F32_MFMA_TFLOPS, 4),
+        }
+    else:
+        roofline = {
+            "kernel": "atb_bf16_kernel<2,PARTS> (C = A^T B, split-bf16 MFMA 32x32x16: 14 launches bf16x3 + "
+                      "2 launches bf16x6 per fit; mean over all 16)",
+            "bound": "hbm", "achieved": round(achieved_gbps, 1), "peak": PEAK_HBM_GBPS,
+            "unit": "GB/s", "frac": round(achieved_gbps / PEAK_HBM_GBPS, 4),
+        }
+    roofline.update({
+        "traffic": pmc_traffic, "launches_timed": prof["launches"], "mean_launch_ms": round(launch_ms, 4),
+        "alg_bytes_per_launch": alg_bytes_launch, "alg_flops_per_launch": alg_flops_launch,
+        "alg_TFLOPs": round(achieved_tflops, 2),
+    })
 
     # ---- CPU baseline + parity on a bounded sample (rank 0, N=1 only) -------------------------
     cpu_baseline = None
@@ -278,7 +294,8 @@ def main():
             "metric": "EOF randomized-SVD GB/s (algorithmic: 16 passes x n x p x 4 B per fit / fit time)",
             "value": round(alg_bytes / (ms_step * 1e-3) / 1e9, 2), "unit": "GB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32" if args.precision == "f32" else "f32 data, split-bf16 MFMA (" + "+".join(ctx.precision) + "), f32 accumulate",
             "data": "synthetic",
             "config": {"workload": f"xe.single.EOF n_modes={k} on synthetic fp32 {n}x({args.nlat}x{args.nlon}), "
                                    f"feature axis sharded over {world} GPU(s), n_iter={n_iter}, n_oversamples=10, "

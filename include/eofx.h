@@ -67,6 +67,18 @@ int eofx_ctx_trim(eofx_ctx *ctx);
  * A^T B product that streams the matrix) is bracketed by HIP events on the context
  * stream.  _read synchronises, returns and resets: the number of launches, their summed
  * duration, the flops issued (2*K*M*L on padded sizes) and the matrix bytes streamed.  */
+/* Arithmetic of the matrix passes.  Every pass reads the f32 matrix once from HBM; what
+ * differs is how the tall-skinny product is issued on the matrix cores:
+ *   EOFX_PREC_F32     exact-f32 MFMA (v_mfma_f32_32x32x2_f32), bitwise an fmaf chain
+ *   EOFX_PREC_BF16X3  operands split into 2 bf16 terms, 3 cross products  (~2^-16 per product)
+ *   EOFX_PREC_BF16X6  operands split into 3 bf16 terms, 6 cross products  (~2^-23, f32 class)
+ * power_passes applies to the 2*n_iter power-iteration products (they only have to find the
+ * subspace), final_passes to the range basis A Z, the projection A^T Q and eofx_project.
+ * Default: (BF16X3, BF16X6) -- singular values within 1e-6 of the float64 oracle. */
+#define EOFX_PREC_F32 0
+#define EOFX_PREC_BF16X3 1
+#define EOFX_PREC_BF16X6 2
+int eofx_ctx_set_precision(eofx_ctx *ctx, int power_passes, int final_passes);
 int eofx_ctx_profile(eofx_ctx *ctx, int enable);
 int eofx_ctx_profile_read(eofx_ctx *ctx, int64_t *launches, double *total_ms, double *flops,
                           double *bytes);
@@ -143,10 +155,10 @@ int eofx_crosscov_rsvd_f32(eofx_ctx *ctx, const eofx_mat *x, const eofx_mat *y, 
  * (one RCCL all-reduce of the n x L panel per pass).
  * A panel is a row-major float32 [rows_pad x L] device buffer, L a multiple of
  * 32, rows_pad = the matrix's n_pad or p_pad; pad rows/columns hold zeros.    */
-int eofx_panel_tmul_f32(eofx_ctx *ctx, const eofx_mat *m, const float *Zn, float *Yp,
-                        int L); /* Yp[p_pad x L] = X^T Zn[n_pad x L] */
-int eofx_panel_mul_f32(eofx_ctx *ctx, const eofx_mat *m, const float *Yp, float *Wn,
-                       int L); /* Wn[n_pad x L] = X Yp[p_pad x L]   */
+int eofx_panel_tmul_f32(eofx_ctx *ctx, const eofx_mat *m, const float *Zn, float *Yp, int L,
+                        int precision); /* Yp[p_pad x L] = X^T Zn[n_pad x L]; EOFX_PREC_* */
+int eofx_panel_mul_f32(eofx_ctx *ctx, const eofx_mat *m, const float *Yp, float *Wn, int L,
+                       int precision); /* Wn[n_pad x L] = X Yp[p_pad x L]   */
 /* G[L x L] (device, float64) = P^T P, accumulated in float64 with a fixed tree. */
 int eofx_panel_gram_f64(eofx_ctx *ctx, const float *P, int64_t rows_pad, int L, double *G);
 /* Cholesky-QR step from a (possibly all-reduced) Gram matrix: out = P R^-1 with

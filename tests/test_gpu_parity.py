@@ -30,8 +30,9 @@ def _gap_ok(s, j, tol=1e-3):
 
 
 # --------------------------------------------------------------------------- kernels
+@pytest.mark.parametrize("prec,tol", [("f32", 1e-5), ("bf16x6", 1e-5), ("bf16x3", 4e-5)])
 @pytest.mark.parametrize("n,p,L", [(100, 700, 32), (300, 1500, 64), (1000, 520, 64), (64, 3000, 96)])
-def test_panel_tmul_mul(ctx, n, p, L):
+def test_panel_tmul_mul(ctx, n, p, L, prec, tol):
     import torch
     from xeofs_amd import engine
 
@@ -43,8 +44,8 @@ def test_panel_tmul_mul(ctx, n, p, L):
     Y = rng.standard_normal((p, L)).astype(np.float32)
     Zp = engine.panel_import(ctx, Z, mat.n_pad, L)
     Yp = engine.panel_import(ctx, Y, mat.p_pad, L)
-    out_t = engine.panel_tmul(ctx, mat, Zp)
-    out_m = engine.panel_mul(ctx, mat, Yp)
+    out_t = engine.panel_tmul(ctx, mat, Zp, prec=prec)
+    out_m = engine.panel_mul(ctx, mat, Yp, prec=prec)
     torch.cuda.synchronize()
     got_t = out_t.cpu().numpy()
     got_m = out_m.cpu().numpy()
@@ -52,8 +53,10 @@ def test_panel_tmul_mul(ctx, n, p, L):
     ref_m = X.astype(np.float64) @ Y.astype(np.float64)
     bound_t = np.abs(X).astype(np.float64).T @ np.abs(Z)
     bound_m = np.abs(X).astype(np.float64) @ np.abs(Y)
-    assert np.all(np.abs(got_t[:p] - ref_t) <= 1e-5 * bound_t + 1e-30)
-    assert np.all(np.abs(got_m[:n] - ref_m) <= 1e-5 * bound_m + 1e-30)
+    assert np.all(np.abs(got_t[:p] - ref_t) <= tol * bound_t + 1e-30)
+    assert np.all(np.abs(got_m[:n] - ref_m) <= tol * bound_m + 1e-30)
+    if prec != "bf16x3":  # f32-class accuracy in the RMS sense as well
+        assert np.sqrt(np.mean((got_t[:p] - ref_t) ** 2)) <= 2e-6 * np.sqrt(np.mean(bound_t ** 2))
     # padding rows of the outputs must be exact zeros (they feed the next product)
     assert not got_t[p:].any() and not got_m[n:].any()
 
@@ -176,8 +179,15 @@ def _check_svd(U, s, V, Uo, so, Vo, X64, k):
     assert np.abs(V.astype(np.float64).T @ V - np.eye(k)).max() < 2e-5
 
 
+@pytest.fixture(params=[("bf16x3", "bf16x6"), ("f32", "f32"), ("bf16x3", "bf16x3")], ids=["mixed", "f32", "x3"])
+def precision(request, ctx):
+    ctx.set_precision(*request.param)
+    yield request.param
+    ctx.set_precision("bf16x3", "bf16x6")
+
+
 @pytest.mark.parametrize("n,p,k", [(512, 2048, 10), (300, 4000, 40), (2500, 700, 20), (600, 600, 5)])
-def test_rsvd_vs_oracle(ctx, n, p, k):
+def test_rsvd_vs_oracle(ctx, n, p, k, precision):
     from xeofs_amd import engine
 
     X = _field(n, p, rank=12, seed=10 + k)

@@ -39,12 +39,12 @@ class NumpyPanelOps:
         P[:src.shape[0], :src.shape[1]] = src
         return self._t(P)
 
-    def tmul(self, Zn):
+    def tmul(self, Zn, final=False):
         out = np.zeros((self.p_pad, Zn.shape[1]), np.float32)
         out[:self.p] = self.X.T @ Zn.numpy()[:self.n]
         return self._t(out)
 
-    def mul(self, Yp):
+    def mul(self, Yp, final=False):
         out = np.zeros((self.n_pad, Yp.shape[1]), np.float32)
         out[:self.n] = self.X @ Yp.numpy()[:self.p]
         return self._t(out)

@@ -13,12 +13,14 @@ mat = engine.from_dense(ctx, X)
 del X
 Z = torch.randn((mat.n_pad, L), device="cuda"); Z[n:] = 0
 Y = torch.randn((mat.p_pad, L), device="cuda"); Y[p:] = 0
-for name, fn, arg in (("tmul X^T Z", engine.panel_tmul, Z), ("mul  X Y  ", engine.panel_mul, Y)):
-    fn(ctx, mat, arg); torch.cuda.synchronize()
+precs = sys.argv[5].split(",") if len(sys.argv) > 5 else ["f32", "bf16x3", "bf16x6"]
+for prec in precs:
+  for name, fn, arg in (("tmul X^T Z", engine.panel_tmul, Z), ("mul  X Y  ", engine.panel_mul, Y)):
+    fn(ctx, mat, arg, prec=prec); torch.cuda.synchronize()
     ctx.profile(True)
     for _ in range(reps):
-        fn(ctx, mat, arg)
+        fn(ctx, mat, arg, prec=prec)
     pr = ctx.profile_read(); ctx.profile(False)
     ms = pr["ms"] / pr["launches"]
-    print(f"{name}: n={n} p={p} L={L}  {ms:.3f} ms/launch  issued {pr['flops']/pr['launches']/ms/1e9:.1f} TF/s  "
-          f"alg(l=L) {2.0*n*p*L/ms/1e9:.1f} TF/s  A-stream {n*p*4.0/ms/1e6:.0f} GB/s")
+    print(f"{prec:7s} {name}: n={n} p={p} L={L}  {ms:.3f} ms/launch  alg(l=L) {2.0*n*p*L/ms/1e9:.1f} TF/s  "
+          f"A-stream {n*p*4.0/ms/1e6:.0f} GB/s")

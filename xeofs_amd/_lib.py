@@ -32,6 +32,7 @@ SIGNATURES = {
     "eofx_ctx_synchronize": (_int, [_vp]),
     "eofx_last_error": (C.c_char_p, [_vp]),
     "eofx_ctx_trim": (_int, [_vp]),
+    "eofx_ctx_set_precision": (_int, [_vp, _int, _int]),
     "eofx_ctx_profile": (_int, [_vp, _int]),
     "eofx_ctx_profile_read": (_int, [_vp, _pi64, _pd, _pd, _pd]),
     "eofx_preprocess_f32": (_int, [_vp, _vp, _i64, _i64, _int, _int, _vp, _int, C.POINTER(_vp),
@@ -46,8 +47,8 @@ SIGNATURES = {
     "eofx_reconstruct_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _vp]),
     "eofx_crosscov_rsvd_f32": (_int, [_vp, _vp, _vp, _int, _int, _int, _vp, _int, _vp, _vp, _vp, _vp,
                                       _vp, _vp, _vp, _pd]),
-    "eofx_panel_tmul_f32": (_int, [_vp, _vp, _vp, _vp, _int]),
-    "eofx_panel_mul_f32": (_int, [_vp, _vp, _vp, _vp, _int]),
+    "eofx_panel_tmul_f32": (_int, [_vp, _vp, _vp, _vp, _int, _int]),
+    "eofx_panel_mul_f32": (_int, [_vp, _vp, _vp, _vp, _int, _int]),
     "eofx_panel_gram_f64": (_int, [_vp, _vp, _i64, _int, _vp]),
     "eofx_panel_cholqr_f32": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp]),
     "eofx_panel_matmul_f32": (_int, [_vp, _vp, _i64, _int, _vp, _int, _vp]),
@@ -56,6 +57,8 @@ SIGNATURES = {
     "eofx_panel_import_f32": (_int, [_vp, _vp, _i64, _int, _vp, _i64, _int]),
     "eofx_host_eigh_f64": (_int, [_vp, _int, _vp, _vp]),
 }
+
+PREC = {"f32": 0, "bf16x3": 1, "bf16x6": 2}
 
 _lib = None
 

@@ -26,6 +26,9 @@ struct eofx_ctx {
   size_t arena_size = 0;
   size_t arena_off = 0;
   std::string err;
+  // arithmetic of the matrix passes (EOFX_PREC_*): power iterations / final basis+projection
+  int prec_power = EOFX_PREC_BF16X3;
+  int prec_final = EOFX_PREC_BF16X6;
   // released resident-matrix buffers, kept for reuse: hipMalloc/hipFree of tens of GB cost
   // ~1 s, far more than a fit.  Bounded by pool_cap bytes; eofx_ctx_trim() empties it.
   std::vector<std::pair<void*, size_t>> pool;
@@ -284,8 +287,20 @@ static size_t atb_scratch_bytes(int64_t M, int64_t K, int L) {
 }
 
 // C[M x L] = A[K x M]^T B[K x L]; M multiple of 512, K multiple of 16, L multiple of 32.
+template <int NB>
+static void launch_atb_variant(int prec, dim3 grid, hipStream_t st, const float* A, int64_t lda,
+                               const float* B, int ldb, float* out, int L, int64_t M, int64_t K,
+                               int64_t kps, int col_base) {
+  if (prec == EOFX_PREC_BF16X3)
+    hipLaunchKernelGGL((atb_bf16_kernel<NB, 2>), grid, dim3(256), 0, st, A, lda, B, ldb, out, L, M, K, kps, col_base);
+  else if (prec == EOFX_PREC_BF16X6)
+    hipLaunchKernelGGL((atb_bf16_kernel<NB, 3>), grid, dim3(256), 0, st, A, lda, B, ldb, out, L, M, K, kps, col_base);
+  else
+    hipLaunchKernelGGL(atb_f32_kernel<NB>, grid, dim3(256), 0, st, A, lda, B, ldb, out, L, M, K, kps, col_base);
+}
+
 static int launch_atb(eofx_ctx* ctx, const float* A, int64_t lda, int64_t K, int64_t M,
-                      const float* B, int ldb, int L, float* C) {
+                      const float* B, int ldb, int L, float* C, int prec = EOFX_PREC_F32) {
   if (M % ATB_BM || K % ATB_KG || L % 32 || L <= 0)
     return set_err(ctx, EOFX_ERR_ARG, "atb: bad geometry M=%lld K=%lld L=%d", (long long)M,
                    (long long)K, L);
@@ -312,14 +327,12 @@ static int launch_atb(eofx_ctx* ctx, const float* A, int64_t lda, int64_t K, int
   }
   if (nfull > 0) {
     dim3 grid(bx, best_s, nfull);
-    hipLaunchKernelGGL(atb_f32_kernel<2>, grid, dim3(256), 0, ctx->stream, A, lda, B, ldb, out, L, M,
-                       K, best_kps, 0);
+    launch_atb_variant<2>(prec, grid, ctx->stream, A, lda, B, ldb, out, L, M, K, best_kps, 0);
     KCHK();
   }
   if (rem) {
     dim3 grid(bx, best_s, 1);
-    hipLaunchKernelGGL(atb_f32_kernel<1>, grid, dim3(256), 0, ctx->stream, A, lda, B, ldb, out, L, M,
-                       K, best_kps, nfull * 64);
+    launch_atb_variant<1>(prec, grid, ctx->stream, A, lda, B, ldb, out, L, M, K, best_kps, nfull * 64);
     KCHK();
   }
   if (ctx->profile) {
@@ -819,24 +832,34 @@ extern "C" int eofx_apply_f32(eofx_ctx* ctx, const float* X, int64_t n, int64_t 
 // ------------------------------------------------------------------------------------
 // panel-level ABI
 // ------------------------------------------------------------------------------------
-static int panel_tmul(eofx_ctx* ctx, const eofx_mat* m, const float* Zn, float* Yp, int L) {
-  return launch_atb(ctx, m->X, m->p_pad, round_up(m->n, ATB_KG), m->p_pad, Zn, L, L, Yp);
+static int panel_tmul(eofx_ctx* ctx, const eofx_mat* m, const float* Zn, float* Yp, int L, int prec) {
+  return launch_atb(ctx, m->X, m->p_pad, round_up(m->n, ATB_KG), m->p_pad, Zn, L, L, Yp, prec);
 }
-static int panel_mul(eofx_ctx* ctx, const eofx_mat* m, const float* Yp, float* Wn, int L) {
-  return launch_atb(ctx, m->Xt, m->n_pad, round_up(m->p, ATB_KG), m->n_pad, Yp, L, L, Wn);
+static int panel_mul(eofx_ctx* ctx, const eofx_mat* m, const float* Yp, float* Wn, int L, int prec) {
+  return launch_atb(ctx, m->Xt, m->n_pad, round_up(m->p, ATB_KG), m->n_pad, Yp, L, L, Wn, prec);
+}
+static bool valid_prec(int p) { return p == EOFX_PREC_F32 || p == EOFX_PREC_BF16X3 || p == EOFX_PREC_BF16X6; }
+
+extern "C" int eofx_ctx_set_precision(eofx_ctx* ctx, int power_passes, int final_passes) {
+  if (!ctx || !valid_prec(power_passes) || !valid_prec(final_passes)) return set_err(ctx, EOFX_ERR_ARG, "bad precision");
+  ctx->prec_power = power_passes;
+  ctx->prec_final = final_passes;
+  return EOFX_OK;
 }
 
-extern "C" int eofx_panel_tmul_f32(eofx_ctx* ctx, const eofx_mat* m, const float* Zn, float* Yp, int L) {
-  if (!ctx || !m || !Zn || !Yp) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+extern "C" int eofx_panel_tmul_f32(eofx_ctx* ctx, const eofx_mat* m, const float* Zn, float* Yp, int L,
+                                   int prec) {
+  if (!ctx || !m || !Zn || !Yp || !valid_prec(prec)) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
   CHK(set_device(ctx));
   CHK(arena_reserve(ctx, atb_scratch_bytes(m->p_pad, round_up(m->n, ATB_KG), L)));
-  return panel_tmul(ctx, m, Zn, Yp, L);
+  return panel_tmul(ctx, m, Zn, Yp, L, prec);
 }
-extern "C" int eofx_panel_mul_f32(eofx_ctx* ctx, const eofx_mat* m, const float* Yp, float* Wn, int L) {
-  if (!ctx || !m || !Wn || !Yp) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+extern "C" int eofx_panel_mul_f32(eofx_ctx* ctx, const eofx_mat* m, const float* Yp, float* Wn, int L,
+                                  int prec) {
+  if (!ctx || !m || !Wn || !Yp || !valid_prec(prec)) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
   CHK(set_device(ctx));
   CHK(arena_reserve(ctx, atb_scratch_bytes(m->n_pad, round_up(m->p, ATB_KG), L)));
-  return panel_mul(ctx, m, Yp, Wn, L);
+  return panel_mul(ctx, m, Yp, Wn, L, prec);
 }
 extern "C" int eofx_panel_gram_f64(eofx_ctx* ctx, const float* P, int64_t rows_pad, int L, double* G) {
   if (!ctx || !P || !G || L % 32) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
@@ -884,8 +907,8 @@ extern "C" int eofx_panel_import_f32(eofx_ctx* ctx, const float* src, int64_t ro
 // ------------------------------------------------------------------------------------
 struct LinOp {
   int64_t tall, small, tall_pad, small_pad;
-  std::function<int(const float*, float*, int)> fwd;  // tall panel  = A   * small panel
-  std::function<int(const float*, float*, int)> bwd;  // small panel = A^T * tall panel
+  std::function<int(const float*, float*, int, int)> fwd;  // tall panel  = A   * small panel (.., L, prec)
+  std::function<int(const float*, float*, int, int)> bwd;  // small panel = A^T * tall panel
 };
 
 struct RsvdOut {
@@ -917,20 +940,21 @@ static int rsvd_core(eofx_ctx* ctx, const LinOp& op, int k, int l, int n_iter, c
   CHK(import_panel(ctx, omega, op.small, l, Zs, op.small_pad, L));
   // power iterations: Z <- orth(A^T (A Z)).  Only the small-side panel is orthonormalised
   // (Cholesky-QR with a float64 Gram matrix); the tall panel is never factorised here.
+  const int pp = ctx->prec_power, pf = ctx->prec_final;
   for (int it = 0; it < n_iter; ++it) {
-    CHK(op.fwd(Zs, Yt, L));
-    CHK(op.bwd(Yt, Ws, L));
+    CHK(op.fwd(Zs, Yt, L, pp));
+    CHK(op.bwd(Yt, Ws, L, pp));
     CHK(launch_gram(ctx, Ws, op.small_pad, L, G));
     CHK(launch_cholqr(ctx, Ws, op.small_pad, L, l, G, Zs));
   }
   // range basis on the tall side: Q = orth(A Z), CholeskyQR2
-  CHK(op.fwd(Zs, Yt, L));
+  CHK(op.fwd(Zs, Yt, L, pf));
   CHK(launch_gram(ctx, Yt, op.tall_pad, L, G));
   CHK(launch_cholqr(ctx, Yt, op.tall_pad, L, l, G, Qt));
   CHK(launch_gram(ctx, Qt, op.tall_pad, L, G));
   CHK(launch_cholqr(ctx, Qt, op.tall_pad, L, l, G, Yt));  // Q now in Yt
   // B^T = A^T Q  (small x l);  B B^T = (B^T)^T (B^T)
-  CHK(op.bwd(Yt, Ws, L));
+  CHK(op.bwd(Yt, Ws, L, pf));
   CHK(launch_gram(ctx, Ws, op.small_pad, L, G));
   std::vector<double> hG((size_t)L * L);
   HIPCHK(hipMemcpyAsync(hG.data(), G, sizeof(double) * L * L, hipMemcpyDeviceToHost, ctx->stream));
@@ -1013,12 +1037,12 @@ extern "C" int eofx_rsvd_f32(eofx_ctx* ctx, const eofx_mat* m, int k, int n_over
   LinOp op;
   if (transposed) {
     op = {p, n, m->p_pad, m->n_pad,
-          [&](const float* z, float* y, int L) { return panel_tmul(ctx, m, z, y, L); },
-          [&](const float* y, float* w, int L) { return panel_mul(ctx, m, y, w, L); }};
+          [&](const float* z, float* y, int L, int pr) { return panel_tmul(ctx, m, z, y, L, pr); },
+          [&](const float* y, float* w, int L, int pr) { return panel_mul(ctx, m, y, w, L, pr); }};
   } else {
     op = {n, p, m->n_pad, m->p_pad,
-          [&](const float* z, float* y, int L) { return panel_mul(ctx, m, z, y, L); },
-          [&](const float* y, float* w, int L) { return panel_tmul(ctx, m, y, w, L); }};
+          [&](const float* z, float* y, int L, int pr) { return panel_mul(ctx, m, z, y, L, pr); },
+          [&](const float* y, float* w, int L, int pr) { return panel_tmul(ctx, m, y, w, L, pr); }};
   }
   CHK(arena_reserve(ctx, rsvd_scratch_bytes(op.tall_pad, op.small_pad, l, k)));
   ArenaScope scope(ctx);
@@ -1059,7 +1083,7 @@ extern "C" int eofx_project_f32(eofx_ctx* ctx, const eofx_mat* m, const float* V
   ARENA(float, Vp, (size_t)m->p_pad * Lo);
   ARENA(float, Sn, (size_t)m->n_pad * Lo);
   CHK(import_panel(ctx, V, m->p, k, Vp, m->p_pad, Lo));
-  CHK(panel_mul(ctx, m, Vp, Sn, Lo));
+  CHK(panel_mul(ctx, m, Vp, Sn, Lo, ctx->prec_final));
   CHK(export_panel(ctx, Sn, m->n, Lo, k, nullptr, out));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return EOFX_OK;
@@ -1118,13 +1142,13 @@ extern "C" int eofx_crosscov_rsvd_f32(eofx_ctx* ctx, const eofx_mat* x, const eo
   ArenaScope scope(ctx);
   ARENA(float, Tn, (size_t)npad * L);
   // C   Z = X^T (Y Z);   C^T W = Y^T (X W)     (scaling by 1/(n-1) is applied to s at the end)
-  auto C_mul = [&](const float* z2, float* out1, int LL) {
-    CHK(panel_mul(ctx, y, z2, Tn, LL));
-    return panel_tmul(ctx, x, Tn, out1, LL);
+  auto C_mul = [&](const float* z2, float* out1, int LL, int pr) {
+    CHK(panel_mul(ctx, y, z2, Tn, LL, pr));
+    return panel_tmul(ctx, x, Tn, out1, LL, pr);
   };
-  auto Ct_mul = [&](const float* z1, float* out2, int LL) {
-    CHK(panel_mul(ctx, x, z1, Tn, LL));
-    return panel_tmul(ctx, y, Tn, out2, LL);
+  auto Ct_mul = [&](const float* z1, float* out2, int LL, int pr) {
+    CHK(panel_mul(ctx, x, z1, Tn, LL, pr));
+    return panel_tmul(ctx, y, Tn, out2, LL, pr);
   };
   LinOp op;
   if (transposed)
@@ -1155,7 +1179,7 @@ extern "C" int eofx_crosscov_rsvd_f32(eofx_ctx* ctx, const eofx_mat* x, const eo
       float* sc = which ? scores2 : scores1;
       float* nr = which ? norm2 : norm1;
       if (!sc && !nr) continue;
-      CHK(panel_mul(ctx, mm, Qp, Sn, ro.Lo));
+      CHK(panel_mul(ctx, mm, Qp, Sn, ro.Lo, ctx->prec_final));
       CHK(export_panel(ctx, Sn, n, ro.Lo, k, sg, sc));
       if (nr) {
         CHK(launch_gram(ctx, Sn, npad, ro.Lo, Gs));
@@ -1172,8 +1196,8 @@ extern "C" int eofx_crosscov_rsvd_f32(eofx_ctx* ctx, const eofx_mat* x, const eo
   if (tsc) {
     ARENA(float, Gx, (size_t)npad * npad);
     ARENA(float, Gy, (size_t)npad * npad);
-    CHK(launch_atb(ctx, x->Xt, npad, round_up(p1, ATB_KG), npad, x->Xt, (int)npad, (int)npad, Gx));
-    CHK(launch_atb(ctx, y->Xt, npad, round_up(p2, ATB_KG), npad, y->Xt, (int)npad, (int)npad, Gy));
+    CHK(launch_atb(ctx, x->Xt, npad, round_up(p1, ATB_KG), npad, x->Xt, (int)npad, (int)npad, Gx, ctx->prec_final));
+    CHK(launch_atb(ctx, y->Xt, npad, round_up(p2, ATB_KG), npad, y->Xt, (int)npad, (int)npad, Gy, ctx->prec_final));
     const int nb = 1024;
     ARENA(double, part, nb);
     hipLaunchKernelGGL(dotprod_part_kernel, dim3(nb), dim3(256), 0, ctx->stream, Gx, Gy, npad * npad, part);

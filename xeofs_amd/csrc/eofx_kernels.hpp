@@ -133,6 +133,143 @@ __global__ __launch_bounds__(256, 2) void atb_f32_kernel(const float* __restrict
       }
 }
 
+// ---------------------------------------------------------------------------------
+// atb_bf16: the same product C = A^T B on the bf16 matrix cores, with the f32 operands split
+// on the fly into PARTS bf16 terms (x = h + m (+ l), each the RNE bf16 of the running
+// remainder) and the cross products that matter kept:
+//     PARTS = 2 ("bf16x3"):  hh + hm + mh            rel. error per product ~2^-16
+//     PARTS = 3 ("bf16x6"):  hh + hm + mh + mm + hl + lh   ~2^-23 (f32 class)
+// bf16 x bf16 products are exact in the f32 accumulator.  v_mfma_f32_32x32x16_bf16 retires
+// 16 k-rows in 32 cycles (vs 2 rows in 64 for the exact-f32 MFMA), so even six products per
+// operand pair leave the kernel HBM-bound: the matrix is still read once, as f32, straight
+// into registers -- the same coalesced 16 B/lane row reads as atb_f32.
+//
+// Fragment mapping: for the 32x32x16 MFMA lane l supplies A[i = l&31][k = 8*(l>>5) + t],
+// t = 0..7.  After the 8 row loads of a slab lane (li, lh) holds rows k0 + 2t + lh, so we
+// simply *name* MFMA-k index 8*lh + t as slab row 2t + lh; the B fragments are stored in
+// LDS under the same naming: Bs[part][kh][col][t] (16 B per (kh, col): one ds_read_b128).
+// ---------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+template <int PARTS>
+__device__ __forceinline__ void split_bf16(f32x8 r, bf16x8 (&out)[PARTS]) {
+#pragma unroll
+  for (int s = 0; s < PARTS; ++s) {
+    out[s] = __builtin_convertvector(r, bf16x8);
+    if (s + 1 < PARTS) r -= __builtin_convertvector(out[s], f32x8);
+  }
+}
+
+template <int NB, int PARTS>
+__global__ __launch_bounds__(256, 2) void atb_bf16_kernel(const float* __restrict__ A, int64_t lda,
+                                                           const float* __restrict__ B, int ldb,
+                                                           float* __restrict__ C, int ldc, int64_t M,
+                                                           int64_t K, int64_t k_per_split,
+                                                           int col_base) {
+  __shared__ __attribute__((aligned(16))) __bf16 Bs[2][PARTS][2][32 * NB][8];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int64_t m0 = (int64_t)blockIdx.x * ATB_BM + wave * ATB_WM;
+  const int64_t kb = (int64_t)blockIdx.y * k_per_split;
+  const int64_t ke = (kb + k_per_split < K) ? kb + k_per_split : K;
+  const int nchunks = (int)((ke - kb) / ATB_KC);
+  const int bcol0 = col_base + blockIdx.z * 64;
+
+  f32x16 acc[4][NB];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][b][r] = 0.f;
+
+  const float* Ap = A + (kb + lh) * lda + m0 + 4 * li;
+  constexpr int BV = 8 * NB;
+  const bool b_loader = tid < 16 * BV;
+  const int brow = tid / BV, bc4 = tid % BV;
+  const float* Bp = B + (kb + brow) * (int64_t)ldb + bcol0 + 4 * bc4;
+
+  f32x4 a0[8], a1[8];
+  f32x4 bn = {0.f, 0.f, 0.f, 0.f};
+#define EOFX_LOAD_SLAB(areg, chunk)                                                              \
+  do {                                                                                           \
+    if (b_loader) bn = *reinterpret_cast<const f32x4*>(Bp + (int64_t)(chunk) * ATB_KC * ldb);   \
+    const float* pa_ = Ap + (int64_t)(chunk) * ATB_KC * lda;                                     \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) areg[i] =                                      \
+        *reinterpret_cast<const f32x4*>(pa_ + (int64_t)(2 * i) * lda);                           \
+  } while (0)
+  // B slab -> LDS, split into bf16 parts, stored fragment-ready: row r = 2t + kh
+#define EOFX_STORE_B(buf)                                                                        \
+  do {                                                                                           \
+    if (b_loader) {                                                                              \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                            \
+        float r_ = bn[e];                                                                        \
+        _Pragma("unroll") for (int s = 0; s < PARTS; ++s) {                                      \
+          const __bf16 h_ = (__bf16)r_;                                                          \
+          Bs[buf][s][brow & 1][4 * bc4 + e][brow >> 1] = h_;                                     \
+          r_ -= (float)h_;                                                                       \
+        }                                                                                        \
+      }                                                                                          \
+    }                                                                                            \
+  } while (0)
+#define EOFX_COMPUTE_SLAB(areg, buf)                                                             \
+  do {                                                                                           \
+    bf16x8 bf_[PARTS][NB];                                                                       \
+    _Pragma("unroll") for (int s = 0; s < PARTS; ++s) _Pragma("unroll") for (int q = 0; q < NB; ++q) \
+        bf_[s][q] = *reinterpret_cast<const bf16x8*>(&Bs[buf][s][lh][32 * q + li][0]);           \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                              \
+      f32x8 x_;                                                                                  \
+      _Pragma("unroll") for (int t = 0; t < 8; ++t) x_[t] = areg[t][j];                          \
+      bf16x8 af_[PARTS];                                                                         \
+      split_bf16<PARTS>(x_, af_);                                                                \
+      _Pragma("unroll") for (int q = 0; q < NB; ++q) {                                           \
+        _Pragma("unroll") for (int sa = PARTS - 1; sa >= 0; --sa)                                \
+            _Pragma("unroll") for (int sb = PARTS - 1; sb >= 0; --sb) {                          \
+          if (sa + sb < PARTS || (PARTS == 3 && sa == 1 && sb == 1))                             \
+            acc[j][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af_[sa], bf_[sb][q], acc[j][q], 0, 0, 0); \
+        }                                                                                        \
+      }                                                                                          \
+    }                                                                                            \
+  } while (0)
+
+  if (nchunks > 0) {
+    EOFX_LOAD_SLAB(a0, 0);
+    EOFX_STORE_B(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; c += 2) {
+      EOFX_LOAD_SLAB(a1, c + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      EOFX_COMPUTE_SLAB(a0, 0);
+      EOFX_STORE_B(1);
+      __syncthreads();
+      const int c2 = (c + 2 < nchunks) ? c + 2 : c + 1;
+      EOFX_LOAD_SLAB(a0, c2);
+      __builtin_amdgcn_sched_barrier(0);
+      EOFX_COMPUTE_SLAB(a1, 1);
+      EOFX_STORE_B(0);
+      __syncthreads();
+    }
+  }
+#undef EOFX_LOAD_SLAB
+#undef EOFX_COMPUTE_SLAB
+#undef EOFX_STORE_B
+
+  float* Cs = C + (int64_t)blockIdx.y * M * ldc;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int q = 0; q < NB; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ii = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int64_t m = m0 + 4 * ii + j;
+        Cs[m * ldc + bcol0 + 32 * q + li] = acc[j][q][r];
+      }
+}
+
 // out[i] = sum_s part[s][i], fixed order, float64 accumulate.  count4 = elements / 4.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part,
                                                             float* __restrict__ out,

@@ -40,9 +40,16 @@ class Context:
                 "xeofs_amd has no CPU fallback.")
         self.handle = h
         self.device = int(device)
+        self.precision = ("bf16x3", "bf16x6")
 
     def synchronize(self):
         raise_for(self.lib.eofx_ctx_synchronize(self.handle), self.handle)
+
+    def set_precision(self, power="bf16x3", final="bf16x6"):
+        """Arithmetic of the matrix passes: "f32" (exact-f32 MFMA), "bf16x3", "bf16x6"
+        (split-bf16 MFMA, see include/eofx.h).  Default ("bf16x3", "bf16x6")."""
+        raise_for(self.lib.eofx_ctx_set_precision(self.handle, _lib.PREC[power], _lib.PREC[final]), self.handle)
+        self.precision = (power, final)
 
     def trim(self):
         """Return cached resident-matrix buffers to the device."""
@@ -285,23 +292,23 @@ def panel_export(ctx: Context, P, rows: int, k: int, sign=None) -> np.ndarray:
     return out
 
 
-def panel_tmul(ctx: Context, mat: ResidentMatrix, Zn, out=None):
+def panel_tmul(ctx: Context, mat: ResidentMatrix, Zn, out=None, prec="f32"):
     """Yp[p_pad, L] = X^T Zn[n_pad, L]"""
     torch = _torch()
     L = Zn.shape[1]
     if out is None:
         out = torch.empty((mat.p_pad, L), dtype=torch.float32, device=Zn.device)
-    raise_for(ctx.lib.eofx_panel_tmul_f32(ctx.handle, mat.handle, ptr(Zn), ptr(out), L), ctx.handle)
+    raise_for(ctx.lib.eofx_panel_tmul_f32(ctx.handle, mat.handle, ptr(Zn), ptr(out), L, _lib.PREC[prec]), ctx.handle)
     return out
 
 
-def panel_mul(ctx: Context, mat: ResidentMatrix, Yp, out=None):
+def panel_mul(ctx: Context, mat: ResidentMatrix, Yp, out=None, prec="f32"):
     """Wn[n_pad, L] = X Yp[p_pad, L]"""
     torch = _torch()
     L = Yp.shape[1]
     if out is None:
         out = torch.empty((mat.n_pad, L), dtype=torch.float32, device=Yp.device)
-    raise_for(ctx.lib.eofx_panel_mul_f32(ctx.handle, mat.handle, ptr(Yp), ptr(out), L), ctx.handle)
+    raise_for(ctx.lib.eofx_panel_mul_f32(ctx.handle, mat.handle, ptr(Yp), ptr(out), L, _lib.PREC[prec]), ctx.handle)
     return out
 
 

@@ -63,11 +63,11 @@ class HipPanelOps:
         L = self.e.panel_width(src.shape[1])
         return self.e.panel_import(self.ctx, src, rows_pad, L)
 
-    def tmul(self, Zn):   # feature panel = X_g^T Zn
-        return self.e.panel_tmul(self.ctx, self.mat, Zn)
+    def tmul(self, Zn, final=False):   # feature panel = X_g^T Zn
+        return self.e.panel_tmul(self.ctx, self.mat, Zn, prec=self.ctx.precision[1 if final else 0])
 
-    def mul(self, Yp):    # sample panel (partial sum over this rank's features) = X_g Yp
-        return self.e.panel_mul(self.ctx, self.mat, Yp)
+    def mul(self, Yp, final=False):    # sample panel (partial sum over this rank's features) = X_g Yp
+        return self.e.panel_mul(self.ctx, self.mat, Yp, prec=self.ctx.precision[1 if final else 0])
 
     def gram(self, P):
         return self.e.panel_gram(self.ctx, P)
@@ -127,11 +127,12 @@ def sharded_rsvd(ops, comm: Comm, k: int, p_total: int, p_offset: int, n_oversam
         small, tall = "p", "n"
         Z = ops.import_panel(omega[p_offset:p_offset + p_loc], "p")
 
-    def to_side(P, side):
-        """product that lands on `side` from a panel on the other side"""
+    def to_side(P, side, final=False):
+        """product that lands on `side` from a panel on the other side; `final` selects the
+        precision of the last two passes (eofx_ctx_set_precision)"""
         if side == "p":
-            return ops.tmul(P)               # local, no communication
-        return comm.sum_(ops.mul(P))         # partial sums over the feature shards
+            return ops.tmul(P, final)               # local, no communication
+        return comm.sum_(ops.mul(P, final))         # partial sums over the feature shards
 
     def gram(P, side):
         G = ops.gram(P)
@@ -141,10 +142,10 @@ def sharded_rsvd(ops, comm: Comm, k: int, p_total: int, p_offset: int, n_oversam
         Yt = to_side(Z, tall)
         W = to_side(Yt, small)
         Z = ops.cholqr(W, l, gram(W, small))
-    Yt = to_side(Z, tall)
+    Yt = to_side(Z, tall, True)
     Q = ops.cholqr(Yt, l, gram(Yt, tall))
     Q = ops.cholqr(Q, l, gram(Q, tall))          # CholeskyQR2
-    Bt = to_side(Q, small)
+    Bt = to_side(Q, small, True)
     G = gram(Bt, small)
     Gh = G.detach().cpu().numpy()[:l, :l]
     Gh = 0.5 * (Gh + Gh.T)
