@@ -292,3 +292,43 @@ def test_crosscov_sample_mismatch(ctx):
     my, _ = engine.preprocess(ctx, _field(41, 600, seed=2))
     with pytest.raises(ValueError, match="same number of samples"):
         engine.crosscov_rsvd(ctx, mx, my, 3, random_state=0)
+
+
+# --------------------------------------------------------------------------- sharded path on one GPU
+def test_sharded_world1_equals_driver_bitwise(ctx):
+    """The Python orchestration over the panel-level ABI (the multi-GPU path) must be the C++ driver's
+    step sequence: at world size 1 the results are bitwise identical.  The RCCL collectives are
+    issued for real (single-rank nccl group, Comm(force=True))."""
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    from xeofs_amd import engine, sharded
+
+    X = _field(400, 3000, seed=41)
+    X = X - X.mean(axis=0, dtype=np.float64).astype(np.float32)
+    mat = engine.from_dense(ctx, X)
+    ref = engine.rsvd(ctx, mat, 12, random_state=9)
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+        created = True
+    try:
+        comm = sharded.Comm(force=True)
+        assert comm.active
+        got = sharded.sharded_rsvd(sharded.HipPanelOps(ctx, mat), comm, 12, 3000, 0, random_state=9)
+    finally:
+        if created:
+            dist.destroy_process_group()
+    for a, b in zip(ref, got):
+        assert np.array_equal(a, b)
+    # tall orientation (n >= p): the sharded side is the small side
+    Xt = np.ascontiguousarray(X.T)
+    mat2 = engine.from_dense(ctx, Xt)
+    ref2 = engine.rsvd(ctx, mat2, 12, random_state=9)
+    got2 = sharded.sharded_rsvd(sharded.HipPanelOps(ctx, mat2), sharded.Comm(), 12, 400, 0, random_state=9)
+    for a, b in zip(ref2, got2):
+        assert np.array_equal(a, b)

@@ -567,8 +567,13 @@ static int launch_apply(eofx_ctx* ctx, const float* Xsrc, int64_t ld_src, const 
                         const int64_t* col_map, const double* shift, const double* scale, eofx_mat* m,
                         int* nan_flag) {
   dim3 grid((int)(m->p_pad / 64), (int)(m->n_pad / 64));
-  hipLaunchKernelGGL(apply_kernel, grid, dim3(256), 0, ctx->stream, Xsrc, ld_src, row_map, col_map,
-                     shift, scale, m->n, m->p, m->X, m->p_pad, m->Xt, m->n_pad, nan_flag);
+  const bool vec = !col_map && (ld_src % 4 == 0) && ((uintptr_t)Xsrc % 16 == 0);
+  if (vec)
+    hipLaunchKernelGGL(apply_kernel<true>, grid, dim3(256), 0, ctx->stream, Xsrc, ld_src, row_map, col_map,
+                       shift, scale, m->n, m->p, m->X, m->p_pad, m->Xt, m->n_pad, nan_flag);
+  else
+    hipLaunchKernelGGL(apply_kernel<false>, grid, dim3(256), 0, ctx->stream, Xsrc, ld_src, row_map, col_map,
+                       shift, scale, m->n, m->p, m->X, m->p_pad, m->Xt, m->n_pad, nan_flag);
   KCHK();
   return EOFX_OK;
 }

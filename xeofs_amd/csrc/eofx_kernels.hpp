@@ -152,12 +152,32 @@ __global__ __launch_bounds__(256, 2) void atb_f32_kernel(const float* __restrict
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// two f32 -> one dword of two RNE bf16 (lo in bits 0-15).  hipcc scalarises vector f32->bf16
+// conversions into one v_cvt_pk per element plus packing; the packed form halves the VALU work.
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+
+// x[8] -> PARTS bf16x8 terms: term s is the RNE bf16 of the remainder left by terms < s.
 template <int PARTS>
 __device__ __forceinline__ void split_bf16(f32x8 r, bf16x8 (&out)[PARTS]) {
 #pragma unroll
   for (int s = 0; s < PARTS; ++s) {
-    out[s] = __builtin_convertvector(r, bf16x8);
-    if (s + 1 < PARTS) r -= __builtin_convertvector(out[s], f32x8);
+    u32x4 pk;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) pk[h] = cvt_pk_bf16(r[2 * h], r[2 * h + 1]);
+    out[s] = __builtin_bit_cast(bf16x8, pk);
+    if (s + 1 < PARTS) {
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        r[2 * h] -= __uint_as_float(pk[h] << 16);
+        r[2 * h + 1] -= __uint_as_float(pk[h] & 0xFFFF0000u);
+      }
+    }
   }
 }
 
@@ -652,9 +672,12 @@ __global__ __launch_bounds__(256) void rowcount_kernel(const float* __restrict__
   if (threadIdx.x == 0) rowcnt[r] = red[0];
 }
 
-// grid = (p_pad/64, n_pad/64): 64x64 tile of the compacted matrix.
+// grid = (p_pad/64, n_pad/64): 64x64 tile of the compacted matrix, 16 B per lane everywhere:
+// each thread owns 4 adjacent compact columns; 16 threads cover a 256 B row segment.
 // col_map/row_map: compact index -> source index (null = identity).  shift/scale indexed by
 // SOURCE column (null = 0 / 1).  nan_flag set (atomicOr) when a NaN lands on a kept entry.
+// VEC: the source can be read with aligned 16 B loads (identity column map, ld % 4 == 0).
+template <bool VEC>
 __global__ __launch_bounds__(256) void apply_kernel(const float* __restrict__ X, int64_t ldx_src,
                                                      const int64_t* __restrict__ row_map,
                                                      const int64_t* __restrict__ col_map,
@@ -665,37 +688,61 @@ __global__ __launch_bounds__(256) void apply_kernel(const float* __restrict__ X,
                                                      int64_t n_pad, int* __restrict__ nan_flag) {
   __shared__ float T[64][65];
   const int tid = threadIdx.x;
-  const int tc = tid & 63, tr = tid >> 6;
+  const int tq = tid & 15, tr = tid >> 4;  // column quad 0..15, row 0..15 (+16 per pass)
   const int64_t c0 = (int64_t)blockIdx.x * 64, r0 = (int64_t)blockIdx.y * 64;
-  const int64_t c = c0 + tc;
-  int64_t sc = -1;
-  double sh = 0.0, sl = 1.0;
-  if (c < p) {
-    sc = col_map ? col_map[c] : c;
-    if (shift) sh = shift[sc];
-    if (scale) sl = scale[sc];
+  const int64_t cb = c0 + 4 * tq;
+  int64_t sc[4];
+  double sh[4], sl[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int64_t c = cb + e;
+    sc[e] = -1;
+    sh[e] = 0.0;
+    sl[e] = 1.0;
+    if (c < p) {
+      sc[e] = col_map ? col_map[c] : c;
+      if (shift) sh[e] = shift[sc[e]];
+      if (scale) sl[e] = scale[sc[e]];
+    }
   }
   bool bad = false;
-#pragma unroll 4
-  for (int q = 0; q < 16; ++q) {
-    const int rr = tr + 4 * q;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int rr = tr + 16 * q;
     const int64_t r = r0 + rr;
-    float v = 0.f;
-    if (sc >= 0 && r < n) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (r < n) {
       const int64_t sr = row_map ? row_map[r] : r;
-      const float x = X[sr * ldx_src + sc];
-      if (x != x) bad = true;
-      v = (float)(((double)x - sh) * sl);
+      const float* src = X + sr * ldx_src;
+      f32x4 x = {0.f, 0.f, 0.f, 0.f};
+      if (VEC && cb + 3 < p) {
+        x = *reinterpret_cast<const f32x4*>(src + cb);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (sc[e] >= 0) x[e] = src[sc[e]];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (sc[e] >= 0) {
+          if (x[e] != x[e]) bad = true;
+          v[e] = (float)(((double)x[e] - sh[e]) * sl[e]);
+        }
     }
-    T[rr][tc] = v;
-    Xc[r * p_pad + c] = v;
+    *reinterpret_cast<f32x4*>(Xc + r * p_pad + cb) = v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) T[rr][4 * tq + e] = v[e];
   }
   if (bad) atomicOr(nan_flag, 1);
   __syncthreads();
-#pragma unroll 4
-  for (int q = 0; q < 16; ++q) {
-    const int cc = tr + 4 * q;
-    Xt[(c0 + cc) * n_pad + r0 + tc] = T[tc][cc];
+  // transposed write: thread owns 4 consecutive samples of one feature column per pass
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int cc = tr + 16 * q;
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = T[4 * tq + e][cc];
+    *reinterpret_cast<f32x4*>(Xt + (c0 + cc) * n_pad + r0 + 4 * tq) = o;
   }
 }
 

@@ -21,12 +21,14 @@ import numpy as np
 class Comm:
     """Collectives over torch.distributed (nccl == RCCL on ROCm; gloo on CPU)."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, force=False):
         import torch.distributed as dist
 
         self.dist = dist
         self.group = group
-        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        init = dist.is_available() and dist.is_initialized()
+        # `force` issues the collectives even at world size 1 (exercises the RCCL calls on one GPU)
+        self.active = init and (dist.get_world_size(group) > 1 or force)
         self.rank = dist.get_rank(group) if (dist.is_available() and dist.is_initialized()) else 0
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
 
