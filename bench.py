@@ -165,15 +165,18 @@ def main():
 
     def step():
         a = time.perf_counter()
+        # the sketch (sklearn's RandomState stream, host) is drawn while the preprocess kernels run
+        omega = engine.SketchFuture(min(n, P), k + N_OVERSAMPLES, 5)
         mat, st = engine.preprocess(ctx, Xraw, center=True, standardize=False, feature_weights=None,
                                     want_stats=False)
         torch.cuda.synchronize()
         b = time.perf_counter()
         if world == 1:
-            U, s, V = engine.rsvd(ctx, mat, k, N_OVERSAMPLES, "auto", random_state=5, device_out=True)
+            U, s, V = engine.rsvd(ctx, mat, k, N_OVERSAMPLES, "auto", omega=omega.result(), device_out=True)
         else:
             ops = sharded.HipPanelOps(ctx, mat)
-            U, s, V = sharded.sharded_rsvd(ops, comm, k, P, lo, N_OVERSAMPLES, "auto", random_state=5)
+            U, s, V = sharded.sharded_rsvd(ops, comm, k, P, lo, N_OVERSAMPLES, "auto", omega=omega.result(),
+                                           device_out=True)
         torch.cuda.synchronize()
         c = time.perf_counter()
         phase["pre"] += b - a

@@ -179,7 +179,8 @@ int eofx_panel_import_f32(eofx_ctx *ctx, const float *src, int64_t rows, int l, 
                           int64_t rows_pad, int L);
 
 /* ---- small host linear algebra used by the drivers ---------------------- */
-/* symmetric eigen-decomposition (cyclic Jacobi, float64): A[n x n] row-major ->
+/* symmetric eigen-decomposition (Householder tridiagonalisation + implicit QL, float64):
+ * A[n x n] row-major ->
  * eigenvalues w[n] descending, eigenvectors as columns of Vec[n x n].          */
 int eofx_host_eigh_f64(const double *A, int n, double *w, double *Vec);
 

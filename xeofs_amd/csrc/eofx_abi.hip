@@ -204,50 +204,120 @@ static int copy_in(eofx_ctx* ctx, void* dst_dev, const void* src, size_t bytes) 
 // ------------------------------------------------------------------------------------
 // small host linear algebra
 // ------------------------------------------------------------------------------------
+// Symmetric eigen-decomposition: Householder tridiagonalisation followed by the implicit-shift
+// QL iteration, eigenvectors accumulated (the classic tred2/tql2 scheme), float64.
 extern "C" int eofx_host_eigh_f64(const double* Ain, int n, double* w, double* Vec) {
   if (!Ain || !w || !Vec || n <= 0) return EOFX_ERR_ARG;
-  std::vector<double> A(Ain, Ain + (size_t)n * n), V((size_t)n * n, 0.0);
-  for (int i = 0; i < n; ++i) V[(size_t)i * n + i] = 1.0;
-  double total = 0.0;
-  for (size_t i = 0; i < A.size(); ++i) total += A[i] * A[i];
-  for (int sweep = 0; sweep < 60; ++sweep) {
-    double off = 0.0;
-    for (int i = 0; i < n; ++i)
-      for (int j = i + 1; j < n; ++j) off += A[(size_t)i * n + j] * A[(size_t)i * n + j];
-    if (off <= 1e-32 * total || off == 0.0) break;
-    for (int p = 0; p < n - 1; ++p)
-      for (int q = p + 1; q < n; ++q) {
-        const double apq = A[(size_t)p * n + q];
-        if (apq == 0.0) continue;
-        const double app = A[(size_t)p * n + p], aqq = A[(size_t)q * n + q];
-        const double tau = (aqq - app) / (2.0 * apq);
-        const double t = (tau >= 0 ? 1.0 : -1.0) / (std::fabs(tau) + std::sqrt(1.0 + tau * tau));
-        const double c = 1.0 / std::sqrt(1.0 + t * t), s = t * c;
-        for (int k = 0; k < n; ++k) {
-          const double akp = A[(size_t)k * n + p], akq = A[(size_t)k * n + q];
-          A[(size_t)k * n + p] = c * akp - s * akq;
-          A[(size_t)k * n + q] = s * akp + c * akq;
+  std::vector<double> z((size_t)n * n), d(n), e(n);
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) z[(size_t)i * n + j] = 0.5 * (Ain[(size_t)i * n + j] + Ain[(size_t)j * n + i]);
+#define Z(i, j) z[(size_t)(i) * n + (j)]
+  // --- Householder reduction to tridiagonal form, accumulating the transformation in z
+  for (int i = n - 1; i >= 1; --i) {
+    const int l = i - 1;
+    double h = 0.0, scale = 0.0;
+    if (l > 0) {
+      for (int k = 0; k <= l; ++k) scale += std::fabs(Z(i, k));
+      if (scale == 0.0) {
+        e[i] = Z(i, l);
+      } else {
+        for (int k = 0; k <= l; ++k) {
+          Z(i, k) /= scale;
+          h += Z(i, k) * Z(i, k);
         }
-        for (int k = 0; k < n; ++k) {
-          const double apk = A[(size_t)p * n + k], aqk = A[(size_t)q * n + k];
-          A[(size_t)p * n + k] = c * apk - s * aqk;
-          A[(size_t)q * n + k] = s * apk + c * aqk;
+        double f = Z(i, l);
+        double g = (f >= 0.0) ? -std::sqrt(h) : std::sqrt(h);
+        e[i] = scale * g;
+        h -= f * g;
+        Z(i, l) = f - g;
+        f = 0.0;
+        for (int j = 0; j <= l; ++j) {
+          Z(j, i) = Z(i, j) / h;
+          g = 0.0;
+          for (int k = 0; k <= j; ++k) g += Z(j, k) * Z(i, k);
+          for (int k = j + 1; k <= l; ++k) g += Z(k, j) * Z(i, k);
+          e[j] = g / h;
+          f += e[j] * Z(i, j);
         }
-        for (int k = 0; k < n; ++k) {
-          const double vkp = V[(size_t)k * n + p], vkq = V[(size_t)k * n + q];
-          V[(size_t)k * n + p] = c * vkp - s * vkq;
-          V[(size_t)k * n + q] = s * vkp + c * vkq;
+        const double hh = f / (h + h);
+        for (int j = 0; j <= l; ++j) {
+          f = Z(i, j);
+          e[j] = g = e[j] - hh * f;
+          for (int k = 0; k <= j; ++k) Z(j, k) -= (f * e[k] + g * Z(i, k));
         }
       }
+    } else {
+      e[i] = Z(i, l);
+    }
+    d[i] = h;
   }
+  d[0] = 0.0;
+  e[0] = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const int l = i - 1;
+    if (d[i] != 0.0) {
+      for (int j = 0; j <= l; ++j) {
+        double g = 0.0;
+        for (int k = 0; k <= l; ++k) g += Z(i, k) * Z(k, j);
+        for (int k = 0; k <= l; ++k) Z(k, j) -= g * Z(k, i);
+      }
+    }
+    d[i] = Z(i, i);
+    Z(i, i) = 1.0;
+    for (int j = 0; j <= l; ++j) Z(j, i) = Z(i, j) = 0.0;
+  }
+  // --- implicit QL on the tridiagonal (d, e)
+  for (int i = 1; i < n; ++i) e[i - 1] = e[i];
+  e[n - 1] = 0.0;
+  for (int l = 0; l < n; ++l) {
+    int iter = 0, m;
+    do {
+      for (m = l; m < n - 1; ++m) {
+        const double dd = std::fabs(d[m]) + std::fabs(d[m + 1]);
+        if (std::fabs(e[m]) <= 2.220446049250313e-16 * dd) break;
+      }
+      if (m != l) {
+        if (iter++ == 200) return EOFX_ERR_LINALG;
+        double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+        double r = std::hypot(g, 1.0);
+        g = d[m] - d[l] + e[l] / (g + (g >= 0.0 ? std::fabs(r) : -std::fabs(r)));
+        double s = 1.0, c = 1.0, p = 0.0;
+        int i;
+        for (i = m - 1; i >= l; --i) {
+          double f = s * e[i];
+          const double b = c * e[i];
+          e[i + 1] = (r = std::hypot(f, g));
+          if (r == 0.0) {
+            d[i + 1] -= p;
+            e[m] = 0.0;
+            break;
+          }
+          s = f / r;
+          c = g / r;
+          g = d[i + 1] - p;
+          r = (d[i] - g) * s + 2.0 * c * b;
+          d[i + 1] = g + (p = s * r);
+          g = c * r - b;
+          for (int k = 0; k < n; ++k) {
+            f = Z(k, i + 1);
+            Z(k, i + 1) = s * Z(k, i) + c * f;
+            Z(k, i) = c * Z(k, i) - s * f;
+          }
+        }
+        if (r == 0.0 && i >= l) continue;
+        d[l] -= p;
+        e[l] = g;
+        e[m] = 0.0;
+      }
+    } while (m != l);
+  }
+#undef Z
   std::vector<int> idx(n);
   for (int i = 0; i < n; ++i) idx[i] = i;
-  std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) {
-    return A[(size_t)a * n + a] > A[(size_t)b * n + b];
-  });
+  std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return d[a] > d[b]; });
   for (int j = 0; j < n; ++j) {
-    w[j] = A[(size_t)idx[j] * n + idx[j]];
-    for (int i = 0; i < n; ++i) Vec[(size_t)i * n + j] = V[(size_t)i * n + idx[j]];
+    w[j] = d[idx[j]];
+    for (int i = 0; i < n; ++i) Vec[(size_t)i * n + j] = z[(size_t)i * n + idx[j]];
   }
   return EOFX_OK;
 }
@@ -354,7 +424,8 @@ static int launch_atb(eofx_ctx* ctx, const float* A, int64_t lda, int64_t K, int
 
 static int launch_gram(eofx_ctx* ctx, const float* P, int64_t rows, int L, double* G) {
   const int nb = (L + 63) / 64;
-  const int nbx = (int)std::min<int64_t>((rows + 31) / 32, 256);
+  // ~16 slabs of 32 rows per workgroup: few partials for the small (sample-side) panels
+  const int nbx = (int)std::max<int64_t>(1, std::min<int64_t>((rows + 511) / 512, 256));
   ArenaScope scope(ctx);
   ARENA(double, part, (size_t)nbx * L * L);
   hipLaunchKernelGGL(gram_f64_kernel, dim3(nbx, nb * nb), dim3(256), 0, ctx->stream, P, rows, L, part);
@@ -380,7 +451,7 @@ static int launch_cholqr(eofx_ctx* ctx, const float* P, int64_t rows, int L, int
   if (l > 64) return set_err(ctx, EOFX_ERR_ARG, "cholqr: sketch width %d > 64 not supported yet", l);
   ArenaScope scope(ctx);
   ARENA(double, Rinv, (size_t)L * L);
-  hipLaunchKernelGGL(chol_rinv_kernel, dim3(1), dim3(256), 0, ctx->stream, G, L, l, Rinv, 1e-13);
+  hipLaunchKernelGGL(chol_rinv_kernel, dim3(1), dim3(64), 0, ctx->stream, G, L, l, Rinv, 1e-13);
   KCHK();
   return launch_matmul(ctx, P, rows, L, Rinv, L, out);
 }

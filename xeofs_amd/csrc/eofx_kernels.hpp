@@ -381,47 +381,48 @@ __global__ __launch_bounds__(256) void f64_reduce_kernel(const double* __restric
 // tol * G[j][j] marks column j as linearly dependent: its Q column becomes exactly zero.
 // l <= 64.
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void chol_rinv_kernel(const double* __restrict__ G, int L, int l,
-                                                        double* __restrict__ Rinv, double tol) {
-  // R lives in the upper triangle of A; R^-1 (also upper triangular) is built into the
-  // unused strict lower triangle (Xi[r][c] -> A[c][r]) with its diagonal in xdiag.
+__global__ __launch_bounds__(64) void chol_rinv_kernel(const double* __restrict__ G, int L, int l,
+                                                       double* __restrict__ Rinv, double tol) {
+  // One wavefront: barriers are free and every step is latency- not throughput-bound.
+  // R lives in the upper triangle of A; R^-1 (also upper triangular) is built into the unused
+  // strict lower triangle (Xi[r][c] -> A[c][r]) with its diagonal in xdiag.
   __shared__ double A[64][65];
   __shared__ double diag0[64];
   __shared__ double xdiag[64];
   __shared__ int dead[64];
   const int tid = threadIdx.x;
-  for (int i = tid; i < 64 * 64; i += 256) {
+  for (int i = tid; i < 64 * 64; i += 64) {
     const int r = i >> 6, c = i & 63;
     A[r][c] = (r < l && c < l && c >= r) ? G[(int64_t)r * L + c] : 0.0;
   }
   __syncthreads();
-  if (tid < 64) {
-    diag0[tid] = A[tid][tid];
-    dead[tid] = 0;
-  }
+  diag0[tid] = A[tid][tid];
+  dead[tid] = 0;
   __syncthreads();
   for (int j = 0; j < l; ++j) {
+    // pivot (every lane computes it redundantly from LDS: no broadcast step needed)
+    const double d = A[j][j];
+    const bool dj = !(d > tol * diag0[j]) || !(diag0[j] > 0.0);
+    const double rjj = dj ? 1.0 : sqrt(d);
+    const double piv = dj ? 0.0 : 1.0 / rjj;
+    __syncthreads();
     if (tid == 0) {
-      const double d = A[j][j];
-      if (!(d > tol * diag0[j]) || !(diag0[j] > 0.0)) {
-        dead[j] = 1;
-        A[j][j] = 1.0;
-      } else {
-        A[j][j] = sqrt(d);
-      }
+      dead[j] = dj;
+      A[j][j] = rjj;
+    }
+    const int c = tid;
+    double rjc = 0.0;
+    if (c > j && c < l) {
+      rjc = A[j][c] * piv;
+      A[j][c] = rjc;
     }
     __syncthreads();
-    const double piv = dead[j] ? 0.0 : 1.0 / A[j][j];
-    for (int c = j + 1 + tid; c < l; c += 256) A[j][c] *= piv;
-    __syncthreads();
-    const int w = l - j - 1;
-    for (int i = tid; i < w * w; i += 256) {
-      const int r = j + 1 + i / w, c = j + 1 + i % w;
-      if (c >= r) A[r][c] -= A[j][r] * A[j][c];
-    }
+    // trailing update of column c: A[r][c] -= R[j][r] * R[j][c] for j < r <= c
+    if (c > j && c < l)
+      for (int r = j + 1; r <= c; ++r) A[r][c] -= A[j][r] * rjc;
     __syncthreads();
   }
-  // back substitution, one column per thread: R X = I
+  // back substitution, one column per lane: R X = I
   if (tid < l) {
     const int c = tid;
     if (!dead[c]) {
@@ -438,7 +439,7 @@ __global__ __launch_bounds__(256) void chol_rinv_kernel(const double* __restrict
     }
   }
   __syncthreads();
-  for (int i = tid; i < L * L; i += 256) {
+  for (int i = tid; i < L * L; i += 64) {
     const int r = i / L, c = i % L;
     double v = 0.0;
     if (r < l && c < l) v = (r == c) ? xdiag[c] : (r < c ? A[c][r] : 0.0);

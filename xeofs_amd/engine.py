@@ -135,6 +135,33 @@ def sketch_matrix(rows: int, size: int, random_state=None) -> np.ndarray:
     return np.ascontiguousarray(rs.normal(size=(rows, size)).astype(np.float32))
 
 
+class SketchFuture:
+    """Draws the sketch matrix on a worker thread so the ~10 ms of legacy-RandomState sampling
+    (600k normals at n=10000, l=60) overlap the preprocess kernels of the same fit (the ctypes
+    call into the engine releases the GIL).  `.result()` joins."""
+
+    def __init__(self, rows, size, random_state=None):
+        import threading
+
+        self._out = None
+        self._err = None
+
+        def run():
+            try:
+                self._out = sketch_matrix(rows, size, random_state)
+            except Exception as e:  # re-raised in the caller's thread
+                self._err = e
+
+        self._t = threading.Thread(target=run, daemon=True)
+        self._t.start()
+
+    def result(self):
+        self._t.join()
+        if self._err is not None:
+            raise self._err
+        return self._out
+
+
 def from_dense(ctx: Context, X) -> ResidentMatrix:
     X = _f32c(X)
     n, p = X.shape
@@ -285,8 +312,12 @@ def panel_import(ctx: Context, src, rows_pad: int, L: int):
     return P
 
 
-def panel_export(ctx: Context, P, rows: int, k: int, sign=None) -> np.ndarray:
-    out = np.empty((rows, k), np.float32)
+def panel_export(ctx: Context, P, rows: int, k: int, sign=None, device_out: bool = False):
+    if device_out:
+        torch = _torch()
+        out = torch.empty((rows, k), dtype=torch.float32, device=P.device)
+    else:
+        out = np.empty((rows, k), np.float32)
     sg = None if sign is None else np.ascontiguousarray(sign, dtype=np.float64)
     raise_for(ctx.lib.eofx_panel_export_f32(ctx.handle, ptr(P), rows, P.shape[1], k, ptr(sg), ptr(out)), ctx.handle)
     return out

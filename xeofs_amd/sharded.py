@@ -86,8 +86,8 @@ class HipPanelOps:
     def colminmax(self, P, rows):
         return self.e.panel_colminmax(self.ctx, P, rows)
 
-    def export(self, P, rows, k, sign=None):
-        return self.e.panel_export(self.ctx, P, rows, k, sign)
+    def export(self, P, rows, k, sign=None, device_out=False):
+        return self.e.panel_export(self.ctx, P, rows, k, sign, device_out)
 
     def eigh(self, G):
         return self.e.host_eigh(G)
@@ -99,7 +99,7 @@ def rsvd_auto_iters(k, n, p):
 
 
 def sharded_rsvd(ops, comm: Comm, k: int, p_total: int, p_offset: int, n_oversamples: int = 10,
-                 n_iter="auto", random_state=None, flip: bool = True, omega=None):
+                 n_iter="auto", random_state=None, flip: bool = True, omega=None, device_out: bool = False):
     """Randomized SVD of X = [X_0 | X_1 | ...] with the feature axis sharded over ranks.
 
     Returns (U[n, k] replicated, s[k] replicated, V_local[p_g, k]) as float32 numpy arrays.
@@ -172,8 +172,12 @@ def sharded_rsvd(ops, comm: Comm, k: int, p_total: int, p_offset: int, n_oversam
         mx, mn = comm.max_(mx), comm.min_(mn)
         mxh, mnh = mx.detach().cpu().numpy()[:k], mn.detach().cpu().numpy()[:k]
         sign = np.where(np.abs(mxh) >= np.abs(mnh), 1.0, -1.0)
-    U = ops.export(Up, n, k, sign)
-    V = ops.export(Vp, p_loc, k, sign)
+    if device_out:   # results stay in HBM (torch tensors); nothing crosses PCIe
+        U = ops.export(Up, n, k, sign, True)
+        V = ops.export(Vp, p_loc, k, sign, True)
+    else:
+        U = ops.export(Up, n, k, sign)
+        V = ops.export(Vp, p_loc, k, sign)
     return U, s.astype(np.float32), V
 
 
