@@ -178,6 +178,30 @@ int eofx_panel_export_f32(eofx_ctx *ctx, const float *P, int64_t rows, int L, in
 int eofx_panel_import_f32(eofx_ctx *ctx, const float *src, int64_t rows, int l, float *P,
                           int64_t rows_pad, int L);
 
+/* ---- complex / Hilbert path (ComplexEOF, HilbertEOF: single/eof.py:243-560) ----------
+ * A complex (sample x feature) matrix is held as two resident real matrices (Re, Im).
+ *
+ * eofx_hilbert_f32: analytic signal along the sample axis of every feature of `a`
+ * (utils/hilbert_transform.py:40-72): optional exponential padding to 3n around a per-feature
+ * linear fit (:75-114, padding != 0, decay_factor), batched FFT (hipFFT), zero negative / double
+ * positive frequencies, inverse FFT, middle n samples, minus the per-feature mean.
+ * out_imag receives Im; out_real (may be NULL) receives Re = a - mean(a) (equal to `a` itself
+ * when `a` is already centred).                                                              */
+int eofx_hilbert_f32(eofx_ctx *ctx, const eofx_mat *a, int padding, double decay_factor,
+                     eofx_mat **out_imag, eofx_mat **out_real);
+/* sum of squares of the resident matrix (float64, fixed reduction tree).                     */
+int eofx_mat_sumsq_f64(eofx_ctx *ctx, const eofx_mat *m, double *out);
+/* Complex panels are real panels [Re | Im] (Re in columns [0, L/2), Im in [L/2, L)).
+ * With P1 = op(A) W and P2 = op(B) W for a complex matrix Z = A + iB (A, B real resident):
+ *   conj_left = 1:  out = Z^H W :  out.re = P1.re + P2.im, out.im = P1.im - P2.re
+ *   conj_left = 0:  out = Z   W :  out.re = P1.re - P2.im, out.im = P1.im + P2.re          */
+int eofx_cpanel_combine_f32(eofx_ctx *ctx, const float *P1, const float *P2, int conj_left,
+                            int64_t rows_pad, int L, float *out);
+/* row index of the per-column max and min over the first `rows` rows (device int64[L]);
+ * used for the lexicographic complex max/min of the sign rule (xarray_utils.py:294-296).     */
+int eofx_panel_colargminmax_f32(eofx_ctx *ctx, const float *P, int64_t rows, int L, int64_t *amax,
+                                int64_t *amin);
+
 /* ---- small host linear algebra used by the drivers ---------------------- */
 /* symmetric eigen-decomposition (Householder tridiagonalisation + implicit QL, float64):
  * A[n x n] row-major ->

@@ -1,0 +1,116 @@
+"""GPU parity tests of the complex / Hilbert path against the oracle.
+
+Tolerances: Hilbert transform 2e-5 of the field scale (float32 FFT of length 3n vs the float64
+oracle); complex singular values rel 1e-5; vectors compared through |<v, v_ref>| >= 1 - 1e-5 because
+a complex singular vector is defined up to a unit phase (the reference's LOBPCG result too)."""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import eof_oracle as orc  # noqa: E402
+
+
+def _waves(n, p, seed=0, noise=0.3):
+    """travelling waves + noise: a field whose analytic signal has genuinely complex modes"""
+    rng = np.random.default_rng(seed)
+    t = np.arange(n)[:, None]
+    x = np.linspace(0, 2 * np.pi, p)[None, :]
+    X = (3.0 * np.cos(0.21 * t - 2 * x) + 1.7 * np.cos(0.37 * t + 3 * x + 0.4) + 0.9 * np.sin(0.11 * t - x)
+         + 0.01 * t + noise * rng.standard_normal((n, p)))
+    return X.astype(np.float32)
+
+
+@pytest.mark.parametrize("n,p", [(200, 700), (151, 333)])
+@pytest.mark.parametrize("padding", ["exp", None])
+def test_hilbert_stage_vs_oracle(ctx, n, p, padding):
+    from xeofs_amd import engine
+
+    X = _waves(n, p, seed=n)
+    mat, _ = engine.preprocess(ctx, X)
+    Xc = mat.download().astype(np.float64)
+    ref = orc.hilbert_transform(Xc, padding=padding, decay_factor=0.2)
+    B, A2 = engine.hilbert(ctx, mat, padding, 0.2, want_real=True)
+    scale = np.abs(ref).max()
+    assert np.abs(B.download() - ref.imag).max() <= 2e-5 * scale
+    assert np.abs(A2.download() - ref.real).max() <= 2e-5 * scale
+    assert np.isclose(B.sumsq(), (ref.imag ** 2).sum(), rtol=1e-4)
+
+
+@pytest.mark.parametrize("n,p,k", [(300, 1200, 6), (900, 250, 4)])
+def test_complex_rsvd_vs_exact(ctx, n, p, k):
+    from xeofs_amd import engine
+    from xeofs_amd.complex_svd import complex_rsvd
+
+    rng = np.random.default_rng(5)
+    r = 6
+    amp = 8.0 * 0.6 ** np.arange(r)
+    L = (rng.standard_normal((n, r)) + 1j * rng.standard_normal((n, r))) * amp
+    R = rng.standard_normal((r, p)) + 1j * rng.standard_normal((r, p))
+    Z = L @ R / np.sqrt(r) + 0.2 * (rng.standard_normal((n, p)) + 1j * rng.standard_normal((n, p)))
+    Z = Z - Z.mean(axis=0)
+    A = engine.from_dense(ctx, np.ascontiguousarray(Z.real, dtype=np.float32))
+    B = engine.from_dense(ctx, np.ascontiguousarray(Z.imag, dtype=np.float32))
+    U, s, V = complex_rsvd(ctx, A, B, k, random_state=3)
+    Ue, se, Vhe = np.linalg.svd(Z, full_matrices=False)
+    assert np.all(np.abs(s - se[:k]) <= 1e-5 * se[:k] + 2e-6 * se[0]), (s, se[:k])
+    for j in range(k):
+        assert abs(np.vdot(Vhe[j].conj(), V[:, j])) >= 1 - 1e-5, j      # V = conj(VT).T
+        assert abs(np.vdot(Ue[:, j], U[:, j])) >= 1 - 1e-5, j
+    rec = (U.astype(np.complex128) * s) @ V.astype(np.complex128).conj().T
+    best = (Ue[:, :k] * se[:k]) @ Vhe[:k]
+    assert np.linalg.norm(Z - rec) <= np.linalg.norm(Z - best) * (1 + 1e-4)
+    assert np.abs(U.conj().T @ U - np.eye(k)).max() < 2e-5 and np.abs(V.conj().T @ V - np.eye(k)).max() < 2e-5
+    # the returned vectors already satisfy the reference sign rule (xarray_utils.py:273-301)
+    assert (orc.deterministic_sign_multiplier(V.conj().T) == 1).all()
+    # against the reference's own complex solver (scipy svds lobpcg, decomposer.py:149-160)
+    Uo, so, Vo = orc.decomposer_fit(Z, k, random_state=3, solver="randomized")
+    assert np.all(np.abs(s - so) <= 1e-5 * so + 2e-6 * so[0])
+
+
+def test_hilbert_eof_model_vs_oracle(ctx):
+    import xeofs_amd as xe
+
+    n, nlat, nlon, k = 240, 6, 40, 4
+    X = _waves(n, nlat * nlon, seed=2).reshape(n, nlat, nlon)
+    da = xe.DataArray(X, dims=("time", "lat", "lon"))
+    m = xe.single.HilbertEOF(n_modes=k, padding="exp", decay_factor=0.2, random_state=1).fit(da, "time")
+    Xc = X.reshape(n, -1).astype(np.float64)
+    Xc = Xc - Xc.mean(axis=0)
+    Zo = orc.hilbert_transform(Xc, "exp", 0.2)
+    se = np.linalg.svd(Zo, compute_uv=False)[:k]
+    s = m.singular_values().values
+    assert np.all(np.abs(s - se) <= 2e-5 * se[0]), (s, se)
+    tv = orc.total_variance(Zo)
+    assert abs(m.data["total_variance"] - tv.real) <= 1e-4 * tv.real
+    assert m.explained_variance_ratio().values.sum() <= 1 + 1e-5
+    comps, scores = m.components(), m.scores()
+    assert comps.dims == ("mode", "lat", "lon") and np.iscomplexobj(comps.values)
+    assert scores.dims == ("mode", "time") and np.iscomplexobj(scores.values)
+    amp, ph = m.components_amplitude(), m.components_phase()
+    assert np.allclose(amp.values, np.abs(comps.values)) and np.allclose(ph.values, np.angle(comps.values))
+    assert (m.scores_amplitude().values >= 0).all() and np.abs(m.scores_phase().values).max() <= np.pi + 1e-6
+    # rank-k reconstruction of the analytic signal is as good as the exact truncated SVD's
+    rec = scores.values.T @ comps.values.reshape(k, -1).conj()
+    Ue, see, Vhe = np.linalg.svd(Zo, full_matrices=False)
+    best = (Ue[:, :k] * see[:k]) @ Vhe[:k]
+    assert np.linalg.norm(Zo - rec) <= np.linalg.norm(Zo - best) * (1 + 1e-3)
+
+
+def test_complex_eof_on_reference_fixture(ctx):
+    """reference tests/conftest.py:286-308 `mock_complex_data_array` (rank-2 travelling waves)"""
+    import xeofs_amd as xe
+
+    x = np.linspace(-5, 5, 128)
+    t = np.linspace(0, 4 * np.pi, 256)
+    Z = (1.0 / np.cosh(x[None, :] + 3) * np.exp(2.3j * t[:, None])
+         + 2.0 / np.cosh(x[None, :]) * np.tanh(x) * np.exp(2.8j * t[:, None]))
+    da = xe.DataArray(Z, dims=("time", "x"), coords={"time": t, "x": x})
+    m = xe.single.ComplexEOF(n_modes=2, random_state=0).fit(da, "time")
+    Zc = Z - Z.mean(axis=0)
+    se = np.linalg.svd(Zc, compute_uv=False)[:2]
+    assert np.allclose(m.singular_values().values, se, rtol=1e-5)
+    rec = m.scores().values.T @ m.components().values.conj()
+    assert np.abs(rec - Zc).max() <= 2e-4 * np.abs(Zc).max()      # two modes carry all of it
+    assert np.isclose(m.explained_variance_ratio().values.sum(), 1.0, atol=1e-4)

@@ -12,6 +12,8 @@
 #include <string>
 #include <vector>
 
+#include <hipfft/hipfft.h>
+
 #include "eofx.h"
 
 using namespace eofx;
@@ -1286,5 +1288,151 @@ extern "C" int eofx_crosscov_rsvd_f32(eofx_ctx* ctx, const eofx_mat* x, const eo
     *tsc = t / ((double)(n - 1) * (double)(n - 1));
   }
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  return EOFX_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// Hilbert transform stage (hilbert_transform.py:40-114) and complex-panel helpers
+// ------------------------------------------------------------------------------------
+#define FFTCHK(expr)                                                                            \
+  do {                                                                                          \
+    hipfftResult _r = (expr);                                                                   \
+    if (_r != HIPFFT_SUCCESS) {                                                                 \
+      rc = set_err(ctx, EOFX_ERR_HIP, "%s failed with hipfftResult %d (%s:%d)", #expr, (int)_r, \
+                   __FILE__, __LINE__);                                                         \
+      goto done;                                                                                \
+    }                                                                                           \
+  } while (0)
+
+extern "C" int eofx_hilbert_f32(eofx_ctx* ctx, const eofx_mat* a, int padding, double decay_factor,
+                                eofx_mat** out_imag, eofx_mat** out_real) {
+  if (!ctx || !a || !out_imag) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  if (padding && !(decay_factor > 0.0)) return set_err(ctx, EOFX_ERR_ARG, "decay_factor must be positive");
+  CHK(set_device(ctx));
+  const int64_t n = a->n, p = a->p, n_pad = a->n_pad, p_pad = a->p_pad;
+  const int64_t N = padding ? 3 * n : n;
+  const int64_t off = padding ? n : 0;
+  // features per FFT batch: work buffer of about 3 GB
+  int64_t Fc = std::max<int64_t>(1, std::min<int64_t>(p, (int64_t)(3.0e9 / (8.0 * (double)N))));
+  eofx_mat *mi = nullptr, *mr = nullptr;
+  CHK(mat_alloc(ctx, n, p, &mi));
+  int rc = EOFX_OK;
+  if (out_real) rc = mat_alloc(ctx, n, p, &mr);
+  cfloat* work = nullptr;
+  float* exp_tab = nullptr;
+  hipfftHandle plan = 0, plan_tail = 0;
+  bool have_plan = false, have_tail = false;
+  if (rc != EOFX_OK) goto done;
+  if (hipMalloc((void**)&work, (size_t)Fc * N * sizeof(cfloat)) != hipSuccess ||
+      hipMalloc((void**)&exp_tab, (size_t)std::max<int64_t>(n, 1) * sizeof(float)) != hipSuccess) {
+    rc = set_err(ctx, EOFX_ERR_NOMEM, "cannot allocate the FFT work buffer");
+    goto done;
+  }
+  {
+    int len = (int)N;
+    FFTCHK(hipfftPlanMany(&plan, 1, &len, nullptr, 1, len, nullptr, 1, len, HIPFFT_C2C, (int)Fc));
+    have_plan = true;
+    FFTCHK(hipfftSetStream(plan, ctx->stream));
+    const int64_t tail = p % Fc;
+    if (tail) {
+      FFTCHK(hipfftPlanMany(&plan_tail, 1, &len, nullptr, 1, len, nullptr, 1, len, HIPFFT_C2C, (int)tail));
+      have_tail = true;
+      FFTCHK(hipfftSetStream(plan_tail, ctx->stream));
+    }
+    if (padding)
+      hipLaunchKernelGGL(hilbert_exp_table_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                         exp_tab, n, decay_factor);
+    for (int64_t f0 = 0; f0 < p; f0 += Fc) {
+      const int64_t fc = std::min(Fc, p - f0);
+      hipfftHandle pl = (fc == Fc) ? plan : plan_tail;
+      hipLaunchKernelGGL(hilbert_pack_kernel, dim3((int)fc), dim3(256), 0, ctx->stream, a->Xt, n_pad, n, f0,
+                         padding, exp_tab, work, N);
+      FFTCHK(hipfftExecC2C(pl, (hipfftComplex*)work, (hipfftComplex*)work, HIPFFT_FORWARD));
+      const int64_t total = fc * N;
+      hipLaunchKernelGGL(hilbert_filter_kernel, dim3((int)std::min<int64_t>((total + 255) / 256, 16384)),
+                         dim3(256), 0, ctx->stream, work, N, total);
+      FFTCHK(hipfftExecC2C(pl, (hipfftComplex*)work, (hipfftComplex*)work, HIPFFT_BACKWARD));
+      hipLaunchKernelGGL(hilbert_unpack_kernel, dim3((int)fc), dim3(256), 0, ctx->stream, work, N, off, n, n_pad,
+                         f0, mi->Xt, mr ? mr->Xt : nullptr);
+    }
+    // zero the padding feature rows, then build the feature-contiguous layout by transposition
+    const size_t pad_bytes = (size_t)(p_pad - p) * n_pad * sizeof(float);
+    if (pad_bytes) {
+      if (hipMemsetAsync(mi->Xt + p * n_pad, 0, pad_bytes, ctx->stream) != hipSuccess ||
+          (mr && hipMemsetAsync(mr->Xt + p * n_pad, 0, pad_bytes, ctx->stream) != hipSuccess)) {
+        rc = set_err(ctx, EOFX_ERR_HIP, "memset failed");
+        goto done;
+      }
+    }
+    dim3 grid((int)(n_pad / 64), (int)(p_pad / 64));
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, ctx->stream, mi->Xt, n_pad, mi->X, p_pad);
+    if (mr) hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, ctx->stream, mr->Xt, n_pad, mr->X, p_pad);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) rc = set_err(ctx, EOFX_ERR_HIP, "hilbert stage failed: %s", hipGetErrorString(e));
+  }
+done:
+  if (have_plan) hipfftDestroy(plan);
+  if (have_tail) hipfftDestroy(plan_tail);
+  if (work) (void)hipFree(work);
+  if (exp_tab) (void)hipFree(exp_tab);
+  if (rc != EOFX_OK) {
+    if (mi) eofx_mat_destroy(ctx, mi);
+    if (mr) eofx_mat_destroy(ctx, mr);
+    return rc;
+  }
+  *out_imag = mi;
+  if (out_real) *out_real = mr;
+  return EOFX_OK;
+}
+
+extern "C" int eofx_cpanel_combine_f32(eofx_ctx* ctx, const float* P1, const float* P2, int conj_left,
+                                       int64_t rows_pad, int L, float* out) {
+  if (!ctx || !P1 || !P2 || !out || L % 2) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  CHK(set_device(ctx));
+  const int64_t total = rows_pad * (L / 2);
+  hipLaunchKernelGGL(cpanel_combine_kernel, dim3((int)std::min<int64_t>((total + 255) / 256, 8192)), dim3(256), 0,
+                     ctx->stream, P1, P2, conj_left ? 1.f : -1.f, rows_pad, L, out);
+  KCHK();
+  return EOFX_OK;
+}
+
+extern "C" int eofx_panel_colargminmax_f32(eofx_ctx* ctx, const float* P, int64_t rows, int L, int64_t* amax,
+                                           int64_t* amin) {
+  if (!ctx || !P || !amax || !amin) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  CHK(set_device(ctx));
+  const int nparts = (int)std::max<int64_t>(1, std::min<int64_t>((rows + 3) / 4, 512));
+  CHK(arena_reserve(ctx, (size_t)nparts * L * 24 + 8192));
+  ArenaScope scope(ctx);
+  ARENA(float, pmx, (size_t)nparts * L);
+  ARENA(float, pmn, (size_t)nparts * L);
+  ARENA(int64_t, imx, (size_t)nparts * L);
+  ARENA(int64_t, imn, (size_t)nparts * L);
+  hipLaunchKernelGGL(colargminmax_part_kernel, dim3(nparts, (L + 63) / 64), dim3(256), 0, ctx->stream, P, rows, L,
+                     pmx, imx, pmn, imn);
+  KCHK();
+  hipLaunchKernelGGL(colargminmax_final_kernel, dim3((L + 63) / 64), dim3(64), 0, ctx->stream, pmx, imx, pmn, imn,
+                     nparts, L, amax, amin);
+  KCHK();
+  return EOFX_OK;
+}
+
+// sum of squares of the resident matrix in float64 (fixed tree); for zero-mean columns
+// total variance = sumsq / (n - 1)
+extern "C" int eofx_mat_sumsq_f64(eofx_ctx* ctx, const eofx_mat* m, double* out) {
+  if (!ctx || !m || !out) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  CHK(set_device(ctx));
+  const int nb = 2048;
+  CHK(arena_reserve(ctx, nb * sizeof(double) + 4096));
+  ArenaScope scope(ctx);
+  ARENA(double, part, nb);
+  hipLaunchKernelGGL(dotprod_part_kernel, dim3(nb), dim3(256), 0, ctx->stream, m->X, m->X, m->n_pad * m->p_pad, part);
+  KCHK();
+  std::vector<double> hp(nb);
+  HIPCHK(hipMemcpyAsync(hp.data(), part, sizeof(double) * nb, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  double t = 0.0;
+  for (int i = 0; i < nb; ++i) t += hp[i];
+  *out = t;
   return EOFX_OK;
 }

@@ -813,4 +813,209 @@ __global__ __launch_bounds__(256) void dotprod_part_kernel(const float* __restri
   if (threadIdx.x == 0) part[blockIdx.x] = red[0];
 }
 
+// ---------------------------------------------------------------------------------
+// Hilbert transform along the sample axis (xeofs/utils/hilbert_transform.py:40-114), per feature
+// row of the sample-contiguous layout Xt.  The FFTs themselves are batched hipFFT C2C plans; the
+// kernels here build the exponentially padded series, apply the analytic-signal filter and
+// extract / re-centre the middle segment.
+// ---------------------------------------------------------------------------------
+struct cfloat {
+  float x, y;
+};
+
+__device__ __forceinline__ double block_sum_256(double v, double* red) {
+  red[threadIdx.x] = v;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  const double out = red[0];
+  __syncthreads();
+  return out;
+}
+
+// exp_tab[t] = exp(-t / n / decay), t = 0..n-1
+__global__ void hilbert_exp_table_kernel(float* __restrict__ tab, int64_t n, double decay) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) tab[t] = (float)exp(-(double)t / (double)n / decay);
+}
+
+// one workgroup per feature: ext = [amp_pre * e_rev ; y - fit ; amp_pos * e] + fit_ext (padding) or y
+__global__ __launch_bounds__(256) void hilbert_pack_kernel(const float* __restrict__ Xt, int64_t n_pad,
+                                                            int64_t n, int64_t f0, int padding,
+                                                            const float* __restrict__ exp_tab,
+                                                            cfloat* __restrict__ work, int64_t N) {
+  __shared__ double red[256];
+  const int64_t f = f0 + blockIdx.x;
+  const float* y = Xt + f * n_pad;
+  cfloat* out = work + (int64_t)blockIdx.x * N;
+  if (!padding) {
+    for (int64_t i = threadIdx.x; i < n; i += 256) out[i] = cfloat{y[i], 0.f};
+    return;
+  }
+  double sy = 0.0, sty = 0.0;
+  const double tbar = 0.5 * (double)(n - 1);
+  for (int64_t i = threadIdx.x; i < n; i += 256) {
+    const double v = (double)y[i];
+    sy += v;
+    sty += ((double)i - tbar) * v;
+  }
+  sy = block_sum_256(sy, red);
+  sty = block_sum_256(sty, red);
+  const double stt = (double)n * ((double)n * (double)n - 1.0) / 12.0;
+  const double c1 = (n > 1) ? sty / stt : 0.0;
+  const double c0 = sy / (double)n - c1 * tbar;  // fit(t) = c0 + c1 t
+  const double amp_pre = (double)y[0] - c0;
+  const double amp_pos = (double)y[n - 1] - (c0 + c1 * (double)(n - 1));
+  for (int64_t i = threadIdx.x; i < n; i += 256) {
+    const double fit_pre = c0 + c1 * (double)(i - n);
+    const double fit_pos = c0 + c1 * (double)(i + n);
+    out[i] = cfloat{(float)(amp_pre * (double)exp_tab[n - 1 - i] + fit_pre), 0.f};
+    out[n + i] = cfloat{y[i], 0.f};
+    out[2 * n + i] = cfloat{(float)(amp_pos * (double)exp_tab[i] + fit_pos), 0.f};
+  }
+}
+
+// analytic-signal filter on the spectrum, with the 1/N of the inverse transform folded in
+__global__ __launch_bounds__(256) void hilbert_filter_kernel(cfloat* __restrict__ work, int64_t N,
+                                                              int64_t total) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const float inv = 1.0f / (float)N;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t k = i % N;
+    float h;
+    if (k == 0 || (N % 2 == 0 && k == N / 2))
+      h = 1.f;
+    else if (k < (N + 1) / 2)
+      h = 2.f;
+    else
+      h = 0.f;
+    h *= inv;
+    cfloat v = work[i];
+    v.x *= h;
+    v.y *= h;
+    work[i] = v;
+  }
+}
+
+// middle segment, minus its mean: imag -> Bt row (and real -> At row if requested)
+__global__ __launch_bounds__(256) void hilbert_unpack_kernel(const cfloat* __restrict__ work, int64_t N,
+                                                              int64_t off, int64_t n, int64_t n_pad,
+                                                              int64_t f0, float* __restrict__ Bt,
+                                                              float* __restrict__ At) {
+  __shared__ double red[256];
+  const cfloat* in = work + (int64_t)blockIdx.x * N + off;
+  const int64_t f = f0 + blockIdx.x;
+  double si = 0.0, sr = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 256) {
+    si += (double)in[i].y;
+    sr += (double)in[i].x;
+  }
+  si = block_sum_256(si, red) / (double)n;
+  sr = block_sum_256(sr, red) / (double)n;
+  for (int64_t i = threadIdx.x; i < n_pad; i += 256) {
+    const bool ok = i < n;
+    Bt[f * n_pad + i] = ok ? (float)((double)in[i].y - si) : 0.f;
+    if (At) At[f * n_pad + i] = ok ? (float)((double)in[i].x - sr) : 0.f;
+  }
+}
+
+// dst[c x r] = src[r x c]^T, both dense with the given leading dimensions (multiples of 64)
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, int64_t ld_src,
+                                                         float* __restrict__ dst, int64_t ld_dst) {
+  __shared__ float T[64][65];
+  const int tid = threadIdx.x;
+  const int tq = tid & 15, tr = tid >> 4;
+  const int64_t c0 = (int64_t)blockIdx.x * 64, r0 = (int64_t)blockIdx.y * 64;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int rr = tr + 16 * q;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(src + (r0 + rr) * ld_src + c0 + 4 * tq);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) T[rr][4 * tq + e] = v[e];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int cc = tr + 16 * q;
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = T[4 * tq + e][cc];
+    *reinterpret_cast<f32x4*>(dst + (c0 + cc) * ld_dst + r0 + 4 * tq) = o;
+  }
+}
+
+// complex panel algebra on [Re | Im] panels (Re in columns [0,h), Im in [h, 2h), h = L/2):
+//   out.re = P1.re + sgn * P2.im ;  out.im = P1.im - sgn * P2.re
+// sgn = +1:  Z^H W = (A^T - i B^T)(Wr + i Wi)   with P1 = A^T [Wr|Wi], P2 = B^T [Wr|Wi]
+// sgn = -1:  Z   Y = (A + i B)(Yr + i Yi)       with P1 = A [Yr|Yi],   P2 = B [Yr|Yi]
+__global__ __launch_bounds__(256) void cpanel_combine_kernel(const float* __restrict__ P1,
+                                                              const float* __restrict__ P2, float sgn,
+                                                              int64_t rows, int L,
+                                                              float* __restrict__ out) {
+  const int h = L / 2;
+  const int64_t total = rows * h;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t r = i / h;
+    const int c = (int)(i - r * h);
+    const float p1r = P1[r * L + c], p1i = P1[r * L + h + c];
+    const float p2r = P2[r * L + c], p2i = P2[r * L + h + c];
+    out[r * L + c] = p1r + sgn * p2i;
+    out[r * L + h + c] = p1i - sgn * p2r;
+  }
+}
+
+// per-column arg max / arg min over rows [0, rows): (value, row) partials, ties -> lowest row
+__global__ __launch_bounds__(256) void colargminmax_part_kernel(const float* __restrict__ P, int64_t rows,
+                                                                 int L, float* __restrict__ pmx,
+                                                                 int64_t* __restrict__ imx,
+                                                                 float* __restrict__ pmn,
+                                                                 int64_t* __restrict__ imn) {
+  __shared__ float smx[4][64], smn[4][64];
+  __shared__ int64_t sax[4][64], san[4][64];
+  const int tid = threadIdx.x;
+  const int c = blockIdx.y * 64 + (tid & 63);
+  const int rl = tid >> 6;
+  float mx = -INFINITY, mn = INFINITY;
+  int64_t ax = -1, an = -1;
+  if (c < L)
+    for (int64_t r = (int64_t)blockIdx.x * 4 + rl; r < rows; r += (int64_t)gridDim.x * 4) {
+      const float v = P[r * L + c];
+      if (v > mx) { mx = v; ax = r; }
+      if (v < mn) { mn = v; an = r; }
+    }
+  smx[rl][tid & 63] = mx; sax[rl][tid & 63] = ax;
+  smn[rl][tid & 63] = mn; san[rl][tid & 63] = an;
+  __syncthreads();
+  if (rl == 0 && c < L) {
+    for (int q = 1; q < 4; ++q) {
+      const float a = smx[q][tid], b = smn[q][tid];
+      const int64_t ia = sax[q][tid], ib = san[q][tid];
+      if (a > mx || (a == mx && ia >= 0 && (ax < 0 || ia < ax))) { mx = a; ax = ia; }
+      if (b < mn || (b == mn && ib >= 0 && (an < 0 || ib < an))) { mn = b; an = ib; }
+    }
+    const int64_t o = (int64_t)blockIdx.x * L + c;
+    pmx[o] = mx; imx[o] = ax; pmn[o] = mn; imn[o] = an;
+  }
+}
+__global__ void colargminmax_final_kernel(const float* __restrict__ pmx, const int64_t* __restrict__ imx,
+                                          const float* __restrict__ pmn, const int64_t* __restrict__ imn,
+                                          int nparts, int L, int64_t* __restrict__ amax,
+                                          int64_t* __restrict__ amin) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= L) return;
+  float a = -INFINITY, b = INFINITY;
+  int64_t ia = -1, ib = -1;
+  for (int q = 0; q < nparts; ++q) {
+    const float va = pmx[(int64_t)q * L + c], vb = pmn[(int64_t)q * L + c];
+    const int64_t ja = imx[(int64_t)q * L + c], jb = imn[(int64_t)q * L + c];
+    if (ja >= 0 && (va > a || (va == a && (ia < 0 || ja < ia)))) { a = va; ia = ja; }
+    if (jb >= 0 && (vb < b || (vb == b && (ib < 0 || jb < ib)))) { b = vb; ib = jb; }
+  }
+  amax[c] = ia;
+  amin[c] = ib;
+}
+
 }  // namespace eofx

@@ -106,6 +106,11 @@ class ResidentMatrix:
         raise_for(self.ctx.lib.eofx_mat_download_f32(self.ctx.handle, self.handle, ptr(out)), self.ctx.handle)
         return out
 
+    def sumsq(self) -> float:
+        out = C.c_double()
+        raise_for(self.ctx.lib.eofx_mat_sumsq_f64(self.ctx.handle, self.handle, C.byref(out)), self.ctx.handle)
+        return out.value
+
     def free(self):
         if getattr(self, "handle", None) and getattr(self.ctx, "handle", None):
             self.ctx.lib.eofx_mat_destroy(self.ctx.handle, self.handle)
@@ -378,3 +383,35 @@ def panel_colminmax(ctx: Context, P, rows: int):
     mn = torch.empty(L, dtype=torch.float32, device=P.device)
     raise_for(ctx.lib.eofx_panel_colminmax_f32(ctx.handle, ptr(P), int(rows), L, ptr(mx), ptr(mn)), ctx.handle)
     return mx, mn
+
+
+# --------------------------------------------------------------------------- #
+# complex / Hilbert path                                                        #
+# --------------------------------------------------------------------------- #
+def hilbert(ctx: Context, mat: ResidentMatrix, padding="exp", decay_factor: float = 0.2, want_real: bool = False):
+    """Analytic signal along the sample axis (xeofs/utils/hilbert_transform.py:40-72).
+    Returns (imag ResidentMatrix, real ResidentMatrix | None).  As in the reference only
+    padding == "exp" pads; any other value means no padding."""
+    hi, hr = C.c_void_p(), C.c_void_p()
+    rc = ctx.lib.eofx_hilbert_f32(ctx.handle, mat.handle, int(padding == "exp"), float(decay_factor),
+                                  C.byref(hi), C.byref(hr) if want_real else None)
+    raise_for(rc, ctx.handle)
+    return ResidentMatrix(ctx, hi), (ResidentMatrix(ctx, hr) if want_real else None)
+
+
+def cpanel_combine(ctx: Context, P1, P2, conj_left: bool, out=None):
+    torch = _torch()
+    if out is None:
+        out = torch.empty_like(P1)
+    raise_for(ctx.lib.eofx_cpanel_combine_f32(ctx.handle, ptr(P1), ptr(P2), int(conj_left), P1.shape[0],
+                                              P1.shape[1], ptr(out)), ctx.handle)
+    return out
+
+
+def panel_colargminmax(ctx: Context, P, rows: int):
+    torch = _torch()
+    L = P.shape[1]
+    amax = torch.empty(L, dtype=torch.int64, device=P.device)
+    amin = torch.empty(L, dtype=torch.int64, device=P.device)
+    raise_for(ctx.lib.eofx_panel_colargminmax_f32(ctx.handle, ptr(P), int(rows), L, ptr(amax), ptr(amin)), ctx.handle)
+    return amax, amin

@@ -1,1 +1,1 @@
-from .eof import EOF  # noqa: F401
+from .eof import EOF, ComplexEOF, HilbertEOF  # noqa: F401

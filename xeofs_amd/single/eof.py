@@ -126,3 +126,102 @@ class EOF:
     def explained_variance_ratio(self):
         return self._mode_array(self.data["explained_variance"] / self.data["total_variance"],
                                 "explained_variance_ratio")
+
+
+class ComplexEOF(EOF):
+    """Drop-in for xeofs.single.ComplexEOF (xeofs/single/eof.py:243-446): EOF analysis of complex
+    data.  The complex matrix is held as two resident real matrices; the decomposition is the
+    complex randomized SVD of `xeofs_amd.complex_svd` (the reference's complex branch,
+    linalg/decomposer.py:149-160).  `standardize` is not supported for complex input."""
+
+    def __init__(self, n_modes: int = 2, padding: str = "exp", decay_factor: float = 0.2, center: bool = True,
+                 standardize: bool = False, use_coslat: bool = False, check_nans: bool = True,
+                 sample_name: str = "sample", feature_name: str = "feature", compute: bool = True,
+                 random_state: int | None = None, solver: str = "auto", solver_kwargs: dict = {}, **kwargs):
+        super().__init__(n_modes=n_modes, center=center, standardize=standardize, use_coslat=use_coslat,
+                         check_nans=check_nans, sample_name=sample_name, feature_name=feature_name,
+                         compute=compute, random_state=random_state, solver=solver, solver_kwargs=solver_kwargs,
+                         **kwargs)
+        self.attrs.update({"model": "Complex EOF analysis", "padding": padding, "decay_factor": decay_factor})
+        self._params.update({"padding": padding, "decay_factor": decay_factor})
+        self.padding, self.decay_factor = padding, decay_factor
+        self.preprocessor_imag = Preprocessor(center, False, use_coslat, check_nans)
+
+    def _complex_parts(self, X, dim, weights):
+        """preprocess Re and Im of a complex input with the same centring / weights"""
+        if self._params["standardize"]:
+            raise NotImplementedError("standardize=True is not supported for complex input")
+        vals, dims, coords, name, attrs = labelled.unpack(X)
+        re = labelled.pack(np.ascontiguousarray(vals.real), dims, coords, name, attrs, X)
+        im = labelled.pack(np.ascontiguousarray(vals.imag), dims, coords, name, attrs, X)
+        A = self.preprocessor.fit_transform(re, dim, weights)
+        self.preprocessor_imag.ctx = self.ctx
+        B = self.preprocessor_imag.fit_transform(im, dim, weights)
+        tv = self.preprocessor.total_variance + self.preprocessor_imag.total_variance
+        return A, B, tv
+
+    def fit(self, X, dim, weights=None):
+        self.ctx = self.ctx or engine.default_context()
+        self.preprocessor.ctx = self.ctx
+        A, B, tv = self._complex_parts(X, dim, weights)
+        self.sample_dims = self.preprocessor.sample_dims
+        return self._fit_complex(A, B, tv)
+
+    def _fit_complex(self, A, B, total_variance):
+        from ..complex_svd import complex_rsvd
+
+        kw = dict(self._solver_kwargs)
+        U, s, V = complex_rsvd(self.ctx, A, B, int(self.n_modes), int(kw.get("n_oversamples", 10)),
+                               kw.get("n_iter", "auto"), self._params["random_state"])
+        s64 = s.astype(np.float64)
+        self.data = dict(input_data=(A, B), components=V, scores=U * s, norms=s64,
+                         explained_variance=s64 ** 2 / (A.n - 1), total_variance=total_variance)
+        return self
+
+    def transform(self, X, normalized=False):
+        raise NotImplementedError("ComplexEOF/HilbertEOF does not support transform() (as in the reference)")
+
+    def components_amplitude(self, normalized=True):
+        c = self.components(normalized)
+        return self._map(c, np.abs, "components_amplitude")
+
+    def components_phase(self, normalized=True):
+        c = self.components(normalized)
+        return self._map(c, np.angle, "components_phase")
+
+    def scores_amplitude(self, normalized=False):
+        return self._map(self.scores(normalized), np.abs, "scores_amplitude")
+
+    def scores_phase(self, normalized=False):
+        return self._map(self.scores(normalized), np.angle, "scores_phase")
+
+    @staticmethod
+    def _map(obj, fn, name):
+        def one(a):
+            vals, dims, coords, _, attrs = labelled.unpack(a)
+            return labelled.pack(fn(vals), dims, coords, name, attrs, a)
+
+        return [one(a) for a in obj] if isinstance(obj, list) else one(obj)
+
+
+class HilbertEOF(ComplexEOF):
+    """Drop-in for xeofs.single.HilbertEOF (xeofs/single/eof.py:449-560): the real input is
+    preprocessed, Hilbert-transformed along the sample axis on the GPU (`eofx_hilbert_f32`,
+    utils/hilbert_transform.py) and decomposed as a complex matrix."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.attrs.update({"model": "Hilbert EOF analysis"})
+
+    def fit(self, X, dim, weights=None):
+        self.ctx = self.ctx or engine.default_context()
+        self.preprocessor.ctx = self.ctx
+        A = self.preprocessor.fit_transform(X, dim, weights)
+        self.sample_dims = self.preprocessor.sample_dims
+        centred = bool(self._params["center"])
+        B, A2 = engine.hilbert(self.ctx, A, self.padding, self.decay_factor, want_real=not centred)
+        if A2 is not None:          # eof.py:546-555: the analytic signal is re-centred per feature
+            A.free()
+            A = A2
+        tv = (A.sumsq() + B.sumsq()) / (A.n - 1)
+        return self._fit_complex(A, B, tv)
