@@ -157,3 +157,102 @@ def test_sharded_world1_matches_two_ranks(tmp_path):
     V2 = np.concatenate([q["V"] for q in two], axis=0)
     for j in range(k):
         assert np.dot(V[:, j], V2[:, j]) >= 1 - 1e-4
+
+
+# --------------------------------------------------------------------------- complex path, 2 ranks
+class NumpyComplexOps:
+    """numpy stand-in for complex_svd.ComplexOps ([Re|Im] float32 panels as CPU torch tensors)."""
+
+    def __init__(self, Z):
+        import torch
+
+        self.torch = torch
+        self.Z = np.asarray(Z, dtype=np.complex128)
+        self.n, self.p = Z.shape
+        self.n_pad = (self.n + 511) // 512 * 512
+        self.p_pad = (self.p + 511) // 512 * 512
+
+    def _c(self, P, rows):
+        a = P.numpy()[:rows].astype(np.float64)
+        return a[:, :32] + 1j * a[:, 32:]
+
+    def _p(self, C, rows_pad):
+        out = np.zeros((rows_pad, 64), np.float32)
+        out[:C.shape[0], :32] = C.real
+        out[:C.shape[0], 32:] = C.imag
+        return self.torch.from_numpy(out)
+
+    def import_panel(self, host, side):
+        out = np.zeros((self.n_pad if side == "n" else self.p_pad, 64), np.float32)
+        out[:host.shape[0]] = host
+        return self.torch.from_numpy(out)
+
+    def zh_mul(self, Wn, final=False):
+        return self._p(self.Z.conj().T @ self._c(Wn, self.n), self.p_pad)
+
+    def z_mul(self, Yp, final=False):
+        return self._p(self.Z @ self._c(Yp, self.p), self.n_pad)
+
+    def gram_real(self, P):
+        a = P.numpy().astype(np.float64)
+        return self.torch.from_numpy(a.T @ a)
+
+    def right_mul(self, P, M):
+        from xeofs_amd.complex_svd import _embed_right
+
+        return self.torch.from_numpy((P.numpy().astype(np.float64) @ _embed_right(M)).astype(np.float32))
+
+    def argminmax(self, P, rows):
+        a = P.numpy()[:rows]
+        return self.torch.from_numpy(a.argmax(axis=0)), self.torch.from_numpy(a.argmin(axis=0))
+
+    def export(self, P, rows, sign):
+        return P.numpy()[:rows] * np.asarray(sign, dtype=np.float32)
+
+
+def _cfield(n, p, seed):
+    rng = np.random.default_rng(seed)
+    amp = 6.0 * 0.6 ** np.arange(5)
+    L = (rng.standard_normal((n, 5)) + 1j * rng.standard_normal((n, 5))) * amp
+    R = rng.standard_normal((5, p)) + 1j * rng.standard_normal((5, p))
+    Z = L @ R + 0.3 * (rng.standard_normal((n, p)) + 1j * rng.standard_normal((n, p)))
+    return Z - Z.mean(axis=0)
+
+
+def _cworker(rank, world, port, n, p, k, out_dir):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from xeofs_amd import sharded
+    from xeofs_amd.complex_svd import complex_rsvd
+
+    Z = _cfield(n, p, 9)
+    lo, hi = sharded.shard_bounds(p, world, rank)
+    U, s, V = complex_rsvd(None, None, None, k, random_state=4, ops=NumpyComplexOps(Z[:, lo:hi]),
+                           comm=sharded.Comm(), p_total=p, p_offset=lo)
+    np.savez(os.path.join(out_dir, f"c{rank}.npz"), U=U, s=s, V=V)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,p,k", [(90, 400, 4), (420, 80, 3)])
+def test_sharded_complex_rsvd_two_ranks_gloo(tmp_path, n, p, k):
+    import torch.multiprocessing as mp
+
+    from oracle import eof_oracle as orc
+
+    mp.spawn(_cworker, args=(2, _free_port(), n, p, k, str(tmp_path)), nprocs=2, join=True)
+    parts = [np.load(tmp_path / f"c{r}.npz") for r in range(2)]
+    assert np.array_equal(parts[0]["U"], parts[1]["U"]) and np.array_equal(parts[0]["s"], parts[1]["s"])
+    V = np.concatenate([q["V"] for q in parts], axis=0)
+    U, s = parts[0]["U"], parts[0]["s"]
+    Z = _cfield(n, p, 9)
+    Ue, se, Vhe = np.linalg.svd(Z, full_matrices=False)
+    assert np.all(np.abs(s - se[:k]) <= 2e-5 * se[:k] + 2e-6 * se[0])
+    for j in range(k):
+        assert abs(np.vdot(Vhe[j].conj(), V[:, j])) >= 1 - 1e-4
+        assert abs(np.vdot(Ue[:, j], U[:, j])) >= 1 - 1e-4
+    # global (cross-rank) sign rule of the reference: already satisfied by the assembled V
+    assert (orc.deterministic_sign_multiplier(V.conj().T) == 1).all()

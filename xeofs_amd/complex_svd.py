@@ -44,7 +44,10 @@ def _hermitian_gram(G, l):
 
 
 class ComplexOps:
-    """Complex panel steps on (A, B) through the C ABI."""
+    """Complex panel steps on this rank's (A, B) through the C ABI.  With a `comm`
+    (xeofs_amd.sharded.Comm) the feature axis is sharded over ranks exactly as in the real path:
+    sample-side panels are all-reduced after every Z Y, Gram matrices of feature-side panels are
+    all-reduced before the host factorisation."""
 
     def __init__(self, ctx, A, B):
         if A.shape != B.shape:
@@ -52,40 +55,53 @@ class ComplexOps:
         self.ctx, self.A, self.B = ctx, A, B
         self.n, self.p, self.n_pad, self.p_pad = A.n, A.p, A.n_pad, A.p_pad
 
-    def zh_mul(self, Wn, final=False):      # feature-side panel = Z^H W
+    def import_panel(self, host, side):
+        return engine.panel_import(self.ctx, host, self.n_pad if side == "n" else self.p_pad, LP)
+
+    def zh_mul(self, Wn, final=False):      # feature-side panel = Z^H W   (local)
         pr = self.ctx.precision[1 if final else 0]
         P1 = engine.panel_tmul(self.ctx, self.A, Wn, prec=pr)
         P2 = engine.panel_tmul(self.ctx, self.B, Wn, prec=pr)
         return engine.cpanel_combine(self.ctx, P1, P2, True, out=P1)
 
-    def z_mul(self, Yp, final=False):       # sample-side panel = Z Y
+    def z_mul(self, Yp, final=False):       # sample-side panel = Z Y     (partial sum over features)
         pr = self.ctx.precision[1 if final else 0]
         P1 = engine.panel_mul(self.ctx, self.A, Yp, prec=pr)
         P2 = engine.panel_mul(self.ctx, self.B, Yp, prec=pr)
         return engine.cpanel_combine(self.ctx, P1, P2, False, out=P1)
 
-    def gram(self, P, l):
-        return _hermitian_gram(engine.panel_gram(self.ctx, P).cpu().numpy(), l)
+    def gram_real(self, P):                 # 64 x 64 float64 Gram of the real [Re|Im] panel (device)
+        return engine.panel_gram(self.ctx, P)
 
     def right_mul(self, P, M):
         torch = engine._torch()
         return engine.panel_matmul(self.ctx, P, torch.as_tensor(_embed_right(M), device=P.device))
 
-    def orth(self, P, l):
-        """Q = P (V diag(w^-1/2)) with P^H P = V diag(w) V^H: orthonormal columns spanning range(P);
-        numerically dependent directions are dropped (zero columns)."""
-        w, V = np.linalg.eigh(self.gram(P, l))
-        good = w > 1e-13 * max(w.max(), 0.0)
-        T = np.zeros((l, l), dtype=complex)
-        T[:, good] = V[:, good] / np.sqrt(w[good])
-        return self.right_mul(P, T)
+    def argminmax(self, P, rows):
+        return engine.panel_colargminmax(self.ctx, P, rows)
+
+    def export(self, P, rows, sign):
+        return engine.panel_export(self.ctx, P, rows, LP, sign)
 
 
-def complex_rsvd(ctx, A, B, k: int, n_oversamples: int = 10, n_iter="auto", random_state=None, flip=True):
-    """-> (U[n,k] complex64, s[k] float32, V[p,k] complex64) with Z ~ U diag(s) V^H and V = conj(VT).T."""
-    torch = engine._torch()
-    ops = ComplexOps(ctx, A, B)
-    n, p = ops.n, ops.p
+class _NoComm:
+    rank, world = 0, 1
+
+    def sum_(self, t):
+        return t
+
+
+def complex_rsvd(ctx, A, B, k: int, n_oversamples: int = 10, n_iter="auto", random_state=None, flip=True,
+                 ops=None, comm=None, p_total=None, p_offset=0):
+    """-> (U[n,k] complex64, s[k] float32, V[p_local,k] complex64) with Z ~ U diag(s) V^H, V = conj(VT).T.
+
+    Single GPU: `complex_rsvd(ctx, A, B, k, ...)`.  Feature-sharded: every rank passes its slice
+    (A, B) with `comm`, the global feature count `p_total` and its `p_offset`; U and s come back
+    replicated, V holds this rank's features."""
+    ops = ops or ComplexOps(ctx, A, B)
+    comm = comm or _NoComm()
+    n, p_loc = ops.n, ops.p
+    p = p_loc if p_total is None else int(p_total)
     r = min(n, p)
     if k > r:
         raise ValueError(f"n_modes must be less than or equal to the rank of the dataset (rank = {r}).")
@@ -96,18 +112,42 @@ def complex_rsvd(ctx, A, B, k: int, n_oversamples: int = 10, n_iter="auto", rand
     if n_iter == "auto" or n_iter is None:
         n_iter = 7 if k < 0.1 * r else 4
     omega = engine.sketch_matrix(r, k + n_oversamples, random_state)[:, :l]   # real Gaussian start
-    transposed = n < p
-    small_rows, small_pad = (n, ops.n_pad) if transposed else (p, ops.p_pad)
-    host = np.zeros((small_rows, LP), np.float32)
-    host[:, :l] = omega
-    Z = engine.panel_import(ctx, host, small_pad, LP)
-    fwd = (lambda P, f=False: ops.zh_mul(P, f)) if transposed else (lambda P, f=False: ops.z_mul(P, f))
-    bwd = (lambda P, f=False: ops.z_mul(P, f)) if transposed else (lambda P, f=False: ops.zh_mul(P, f))
+    transposed = n < p      # A_op = Z^H: tall side = features (sharded), small side = samples
+
+    def to_feature(P, f=False):
+        return ops.zh_mul(P, f)
+
+    def to_sample(P, f=False):
+        return comm.sum_(ops.z_mul(P, f))
+
+    def gram(P, side):
+        G = ops.gram_real(P)
+        if side == "p":
+            G = comm.sum_(G)
+        return _hermitian_gram(G.detach().cpu().numpy(), l)
+
+    def orth(P, side):
+        """Q = P (V diag(w^-1/2)), P^H P = V diag(w) V^H; dependent directions -> zero columns"""
+        w, V = np.linalg.eigh(gram(P, side))
+        good = w > 1e-13 * max(w.max(), 0.0)
+        T = np.zeros((l, l), dtype=complex)
+        T[:, good] = V[:, good] / np.sqrt(w[good])
+        return ops.right_mul(P, T)
+
+    if transposed:
+        small, tall, fwd, bwd = "n", "p", to_feature, to_sample
+        rows0 = omega
+    else:
+        small, tall, fwd, bwd = "p", "n", to_sample, to_feature
+        rows0 = omega[p_offset:p_offset + p_loc]
+    host = np.zeros((rows0.shape[0], LP), np.float32)
+    host[:, :l] = rows0
+    Z = ops.import_panel(host, small)
     for _ in range(int(n_iter)):
-        Z = ops.orth(bwd(fwd(Z)), l)
-    Q = ops.orth(ops.orth(fwd(Z, True), l), l)
+        Z = orth(bwd(fwd(Z)), small)
+    Q = orth(orth(fwd(Z, True), tall), tall)
     Bt = bwd(Q, True)                                   # = B^H with B = Q^H A_op
-    w, Uh = np.linalg.eigh(ops.gram(Bt, l))             # B B^H = Uh diag(w) Uh^H
+    w, Uh = np.linalg.eigh(gram(Bt, small))             # B B^H = Uh diag(w) Uh^H
     order = np.argsort(w)[::-1][:k]
     s = np.sqrt(np.maximum(w[order], 0.0))
     Uh = Uh[:, order]
@@ -115,24 +155,53 @@ def complex_rsvd(ctx, A, B, k: int, n_oversamples: int = 10, n_iter="auto", rand
         inv = np.where(s > 0, 1.0 / s, 0.0)
     Tall = ops.right_mul(Q, Uh)                         # A_op = Tall diag(s) Small^H
     Small = ops.right_mul(Bt, Uh * inv)
-    if transposed:      # A_op = Z^H  ->  Z = Small diag(s) Tall^H : U = Small, V = Tall
-        Up, Vp = Small, Tall
-    else:               # A_op = Z    ->  Z = Tall diag(s) Small^H
-        Up, Vp = Tall, Small
+    Up, Vp = (Small, Tall) if transposed else (Tall, Small)
     sign = np.ones(k)
     if flip:
-        # VT = conj(V)^T; numpy max/min of complex arrays are lexicographic (real part, then imag)
-        amax, amin = engine.panel_colargminmax(ctx, Vp, p)
-        amax, amin = amax[:k].cpu(), amin[:k].cpu()
+        # VT = conj(V)^T; numpy's max/min of complex arrays are lexicographic (real part, then imag),
+        # ties on the real part are measure-zero.  Global over the feature shards.
+        torch = engine._torch()
+        amax, amin = ops.argminmax(Vp, p_loc)
         cols = torch.arange(k)
-        vmax = (Vp[amax, cols].cpu().numpy() - 1j * Vp[amax, cols + HALF].cpu().numpy())
-        # conj flips the imaginary part; lexicographic ties on the real part are measure-zero
-        vmin = (Vp[amin, cols].cpu().numpy() - 1j * Vp[amin, cols + HALF].cpu().numpy())
-        sign = np.where(np.abs(vmax) >= np.abs(vmin), 1.0, -1.0)
+        cand = []
+        for idx in (amax[:k].cpu(), amin[:k].cpu()):
+            if p_loc > 0:
+                vr = Vp[idx, cols].detach().cpu().numpy().astype(np.float64)
+                vi = Vp[idx, cols + HALF].detach().cpu().numpy().astype(np.float64)
+            else:
+                vr, vi = np.full(k, np.nan), np.zeros(k)
+            cand.append((vr, -vi))          # conj flips the imaginary part
+        (mr, mi), (nr, ni) = cand
+        if comm.world > 1:
+            mr, mi, nr, ni = _global_lex_extrema(comm, mr, mi, nr, ni)
+        sign = np.where(np.hypot(mr, mi) >= np.hypot(nr, ni), 1.0, -1.0)
     sg = np.concatenate([sign, np.ones(HALF - k), sign, np.ones(HALF - k)])
 
     def export(P, rows):
-        full = engine.panel_export(ctx, P, rows, LP, sg)
+        full = ops.export(P, rows, sg)
         return (full[:, :k] + 1j * full[:, HALF:HALF + k]).astype(np.complex64)
 
-    return export(Up, n), s.astype(np.float32), export(Vp, p)
+    return export(Up, n), s.astype(np.float32), export(Vp, p_loc)
+
+
+def _global_lex_extrema(comm, mr, mi, nr, ni):
+    """combine per-rank lexicographic (real, imag) max / min candidates over the ranks"""
+    import torch
+    import torch.distributed as dist
+
+    k = mr.size
+    mine = torch.tensor(np.stack([mr, mi, nr, ni]), dtype=torch.float64)
+    bufs = [torch.empty_like(mine) for _ in range(comm.world)]
+    dev = None
+    if dist.get_backend(comm.group) == "nccl":
+        dev = torch.device("cuda", torch.cuda.current_device())
+        mine = mine.to(dev)
+        bufs = [b.to(dev) for b in bufs]
+    dist.all_gather(bufs, mine, group=comm.group)
+    allc = torch.stack(bufs).cpu().numpy()            # (world, 4, k)
+    out = [np.empty(k) for _ in range(4)]
+    for j in range(k):
+        mx = max(((allc[r, 0, j], allc[r, 1, j]) for r in range(comm.world) if not np.isnan(allc[r, 0, j])))
+        mn = min(((allc[r, 2, j], allc[r, 3, j]) for r in range(comm.world) if not np.isnan(allc[r, 2, j])))
+        out[0][j], out[1][j], out[2][j], out[3][j] = mx[0], mx[1], mn[0], mn[1]
+    return out
