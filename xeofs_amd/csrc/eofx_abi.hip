@@ -36,6 +36,8 @@ struct eofx_ctx {
   std::vector<std::pair<void*, size_t>> pool;
   size_t pool_bytes = 0;
   size_t pool_cap = (size_t)160 << 30;
+  // cached hipFFT plans of the Hilbert stage: key = (N, batch) -> (R2C plan, C2R plan)
+  std::vector<std::pair<std::pair<int64_t, int64_t>, std::pair<void*, void*>>> fft_plans;
   // optional per-launch timing of the dominant kernel (atb_f32) with HIP events on `stream`
   bool profile = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
@@ -152,6 +154,10 @@ extern "C" int eofx_ctx_destroy(eofx_ctx* ctx) {
     (void)hipFree(ctx->arena);
   }
   pool_trim(ctx);
+  for (auto& e : ctx->fft_plans) {
+    hipfftDestroy((hipfftHandle)e.second.first);
+    hipfftDestroy((hipfftHandle)e.second.second);
+  }
   delete ctx;
   return EOFX_OK;
 }
@@ -1312,48 +1318,71 @@ extern "C" int eofx_hilbert_f32(eofx_ctx* ctx, const eofx_mat* a, int padding, d
   const int64_t n = a->n, p = a->p, n_pad = a->n_pad, p_pad = a->p_pad;
   const int64_t N = padding ? 3 * n : n;
   const int64_t off = padding ? n : 0;
-  // features per FFT batch: work buffer of about 3 GB
-  int64_t Fc = std::max<int64_t>(1, std::min<int64_t>(p, (int64_t)(3.0e9 / (8.0 * (double)N))));
+  const int64_t nh = N / 2 + 1;          // half-spectrum bins of the real transform
+  const int64_t ldw = N + 2;             // real series row stride (floats), 8-byte aligned rows
+  // features per FFT batch: real series + half spectrum of about 3 GB together
+  int64_t Fc = std::max<int64_t>(1, std::min<int64_t>(p, (int64_t)(3.0e9 / (4.0 * (double)ldw + 8.0 * (double)nh))));
   eofx_mat *mi = nullptr, *mr = nullptr;
   CHK(mat_alloc(ctx, n, p, &mi));
   int rc = EOFX_OK;
   if (out_real) rc = mat_alloc(ctx, n, p, &mr);
-  cfloat* work = nullptr;
+  float* work = nullptr;
+  cfloat* spec = nullptr;
   float* exp_tab = nullptr;
-  hipfftHandle plan = 0, plan_tail = 0;
-  bool have_plan = false, have_tail = false;
+  hipfftHandle plan_f = 0, plan_b = 0, tail_f = 0, tail_b = 0;
+  const size_t work_bytes = (size_t)Fc * ldw * sizeof(float), spec_bytes = (size_t)Fc * nh * sizeof(cfloat);
+  const size_t tab_bytes = (size_t)std::max<int64_t>(n, 1) * sizeof(float);
   if (rc != EOFX_OK) goto done;
-  if (hipMalloc((void**)&work, (size_t)Fc * N * sizeof(cfloat)) != hipSuccess ||
-      hipMalloc((void**)&exp_tab, (size_t)std::max<int64_t>(n, 1) * sizeof(float)) != hipSuccess) {
-    rc = set_err(ctx, EOFX_ERR_NOMEM, "cannot allocate the FFT work buffer");
+  if (pool_malloc(ctx, (void**)&work, work_bytes) != hipSuccess ||
+      pool_malloc(ctx, (void**)&spec, spec_bytes) != hipSuccess ||
+      pool_malloc(ctx, (void**)&exp_tab, tab_bytes) != hipSuccess) {
+    rc = set_err(ctx, EOFX_ERR_NOMEM, "cannot allocate the FFT work buffers");
     goto done;
   }
   {
     int len = (int)N;
-    FFTCHK(hipfftPlanMany(&plan, 1, &len, nullptr, 1, len, nullptr, 1, len, HIPFFT_C2C, (int)Fc));
-    have_plan = true;
-    FFTCHK(hipfftSetStream(plan, ctx->stream));
+    int rembed = (int)ldw, cembed = (int)nh;
+    // plans are cached per (N, batch): creating them costs more than running them
+    auto get_plans = [&](int64_t batch, hipfftHandle& pf, hipfftHandle& pb) -> int {
+      for (auto& e : ctx->fft_plans)
+        if (e.first.first == N && e.first.second == batch) {
+          pf = (hipfftHandle)e.second.first;
+          pb = (hipfftHandle)e.second.second;
+          return EOFX_OK;
+        }
+      if (hipfftPlanMany(&pf, 1, &len, &rembed, 1, (int)ldw, &cembed, 1, (int)nh, HIPFFT_R2C, (int)batch) != HIPFFT_SUCCESS)
+        return set_err(ctx, EOFX_ERR_HIP, "hipfftPlanMany(R2C, N=%lld, batch=%lld) failed", (long long)N, (long long)batch);
+      if (hipfftPlanMany(&pb, 1, &len, &cembed, 1, (int)nh, &rembed, 1, (int)ldw, HIPFFT_C2R, (int)batch) != HIPFFT_SUCCESS) {
+        hipfftDestroy(pf);
+        return set_err(ctx, EOFX_ERR_HIP, "hipfftPlanMany(C2R, N=%lld, batch=%lld) failed", (long long)N, (long long)batch);
+      }
+      hipfftSetStream(pf, ctx->stream);
+      hipfftSetStream(pb, ctx->stream);
+      ctx->fft_plans.push_back({{N, batch}, {(void*)pf, (void*)pb}});
+      return EOFX_OK;
+    };
+    rc = get_plans(Fc, plan_f, plan_b);
+    if (rc != EOFX_OK) goto done;
     const int64_t tail = p % Fc;
     if (tail) {
-      FFTCHK(hipfftPlanMany(&plan_tail, 1, &len, nullptr, 1, len, nullptr, 1, len, HIPFFT_C2C, (int)tail));
-      have_tail = true;
-      FFTCHK(hipfftSetStream(plan_tail, ctx->stream));
+      rc = get_plans(tail, tail_f, tail_b);
+      if (rc != EOFX_OK) goto done;
     }
     if (padding)
       hipLaunchKernelGGL(hilbert_exp_table_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, ctx->stream,
                          exp_tab, n, decay_factor);
     for (int64_t f0 = 0; f0 < p; f0 += Fc) {
       const int64_t fc = std::min(Fc, p - f0);
-      hipfftHandle pl = (fc == Fc) ? plan : plan_tail;
+      const bool full = fc == Fc;
       hipLaunchKernelGGL(hilbert_pack_kernel, dim3((int)fc), dim3(256), 0, ctx->stream, a->Xt, n_pad, n, f0,
-                         padding, exp_tab, work, N);
-      FFTCHK(hipfftExecC2C(pl, (hipfftComplex*)work, (hipfftComplex*)work, HIPFFT_FORWARD));
-      const int64_t total = fc * N;
+                         padding, exp_tab, work, ldw);
+      FFTCHK(hipfftExecR2C(full ? plan_f : tail_f, work, (hipfftComplex*)spec));
+      const int64_t total = fc * nh;
       hipLaunchKernelGGL(hilbert_filter_kernel, dim3((int)std::min<int64_t>((total + 255) / 256, 16384)),
-                         dim3(256), 0, ctx->stream, work, N, total);
-      FFTCHK(hipfftExecC2C(pl, (hipfftComplex*)work, (hipfftComplex*)work, HIPFFT_BACKWARD));
-      hipLaunchKernelGGL(hilbert_unpack_kernel, dim3((int)fc), dim3(256), 0, ctx->stream, work, N, off, n, n_pad,
-                         f0, mi->Xt, mr ? mr->Xt : nullptr);
+                         dim3(256), 0, ctx->stream, spec, N, nh, total);
+      FFTCHK(hipfftExecC2R(full ? plan_b : tail_b, (hipfftComplex*)spec, work));
+      hipLaunchKernelGGL(hilbert_unpack_kernel, dim3((int)fc), dim3(256), 0, ctx->stream, work, ldw, off, n,
+                         n_pad, f0, a->Xt, mi->Xt, mr ? mr->Xt : nullptr);
     }
     // zero the padding feature rows, then build the feature-contiguous layout by transposition
     const size_t pad_bytes = (size_t)(p_pad - p) * n_pad * sizeof(float);
@@ -1372,10 +1401,9 @@ extern "C" int eofx_hilbert_f32(eofx_ctx* ctx, const eofx_mat* a, int padding, d
     if (e != hipSuccess) rc = set_err(ctx, EOFX_ERR_HIP, "hilbert stage failed: %s", hipGetErrorString(e));
   }
 done:
-  if (have_plan) hipfftDestroy(plan);
-  if (have_tail) hipfftDestroy(plan_tail);
-  if (work) (void)hipFree(work);
-  if (exp_tab) (void)hipFree(exp_tab);
+  pool_give(ctx, work, work_bytes);
+  pool_give(ctx, spec, spec_bytes);
+  pool_give(ctx, exp_tab, tab_bytes);
   if (rc != EOFX_OK) {
     if (mi) eofx_mat_destroy(ctx, mi);
     if (mr) eofx_mat_destroy(ctx, mr);

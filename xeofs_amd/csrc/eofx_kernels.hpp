@@ -841,17 +841,18 @@ __global__ void hilbert_exp_table_kernel(float* __restrict__ tab, int64_t n, dou
   if (t < n) tab[t] = (float)exp(-(double)t / (double)n / decay);
 }
 
-// one workgroup per feature: ext = [amp_pre * e_rev ; y - fit ; amp_pos * e] + fit_ext (padding) or y
+// one workgroup per feature: ext = [amp_pre * e_rev ; y - fit ; amp_pos * e] + fit_ext (padding) or y,
+// written as a REAL series of length N (row stride ldw floats) for the R2C transform
 __global__ __launch_bounds__(256) void hilbert_pack_kernel(const float* __restrict__ Xt, int64_t n_pad,
                                                             int64_t n, int64_t f0, int padding,
                                                             const float* __restrict__ exp_tab,
-                                                            cfloat* __restrict__ work, int64_t N) {
+                                                            float* __restrict__ work, int64_t ldw) {
   __shared__ double red[256];
   const int64_t f = f0 + blockIdx.x;
   const float* y = Xt + f * n_pad;
-  cfloat* out = work + (int64_t)blockIdx.x * N;
+  float* out = work + (int64_t)blockIdx.x * ldw;
   if (!padding) {
-    for (int64_t i = threadIdx.x; i < n; i += 256) out[i] = cfloat{y[i], 0.f};
+    for (int64_t i = threadIdx.x; i < n; i += 256) out[i] = y[i];
     return;
   }
   double sy = 0.0, sty = 0.0;
@@ -871,53 +872,53 @@ __global__ __launch_bounds__(256) void hilbert_pack_kernel(const float* __restri
   for (int64_t i = threadIdx.x; i < n; i += 256) {
     const double fit_pre = c0 + c1 * (double)(i - n);
     const double fit_pos = c0 + c1 * (double)(i + n);
-    out[i] = cfloat{(float)(amp_pre * (double)exp_tab[n - 1 - i] + fit_pre), 0.f};
-    out[n + i] = cfloat{y[i], 0.f};
-    out[2 * n + i] = cfloat{(float)(amp_pos * (double)exp_tab[i] + fit_pos), 0.f};
+    out[i] = (float)(amp_pre * (double)exp_tab[n - 1 - i] + fit_pre);
+    out[n + i] = y[i];
+    out[2 * n + i] = (float)(amp_pos * (double)exp_tab[i] + fit_pos);
   }
 }
 
-// analytic-signal filter on the spectrum, with the 1/N of the inverse transform folded in
-__global__ __launch_bounds__(256) void hilbert_filter_kernel(cfloat* __restrict__ work, int64_t N,
-                                                              int64_t total) {
+// Hilbert filter on the half spectrum of a real series: Yh(k) = -i * Y(k) for 0 < k < N/2, 0 at DC and
+// Nyquist; the 1/N of the unnormalised inverse transform is folded in.  irfft(Yh) is then the Hilbert
+// transform itself = Im(analytic signal).  `spec` holds nh = N/2 + 1 bins per feature.
+__global__ __launch_bounds__(256) void hilbert_filter_kernel(cfloat* __restrict__ spec, int64_t N,
+                                                              int64_t nh, int64_t total) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const float inv = 1.0f / (float)N;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-    const int64_t k = i % N;
-    float h;
-    if (k == 0 || (N % 2 == 0 && k == N / 2))
-      h = 1.f;
-    else if (k < (N + 1) / 2)
-      h = 2.f;
-    else
-      h = 0.f;
-    h *= inv;
-    cfloat v = work[i];
-    v.x *= h;
-    v.y *= h;
-    work[i] = v;
+    const int64_t k = i % nh;
+    const cfloat v = spec[i];
+    cfloat o = {0.f, 0.f};
+    if (k != 0 && !(N % 2 == 0 && k == N / 2)) {
+      o.x = v.y * inv;   // -i (a + i b) = b - i a
+      o.y = -v.x * inv;
+    }
+    spec[i] = o;
   }
 }
 
-// middle segment, minus its mean: imag -> Bt row (and real -> At row if requested)
-__global__ __launch_bounds__(256) void hilbert_unpack_kernel(const cfloat* __restrict__ work, int64_t N,
+// middle segment of the real Hilbert-transformed series, minus its mean -> Bt row; optionally the
+// re-centred input (Re of the analytic signal) -> At row
+__global__ __launch_bounds__(256) void hilbert_unpack_kernel(const float* __restrict__ work, int64_t ldw,
                                                               int64_t off, int64_t n, int64_t n_pad,
-                                                              int64_t f0, float* __restrict__ Bt,
+                                                              int64_t f0, const float* __restrict__ Xt,
+                                                              float* __restrict__ Bt,
                                                               float* __restrict__ At) {
   __shared__ double red[256];
-  const cfloat* in = work + (int64_t)blockIdx.x * N + off;
+  const float* in = work + (int64_t)blockIdx.x * ldw + off;
   const int64_t f = f0 + blockIdx.x;
+  const float* y = Xt + f * n_pad;
   double si = 0.0, sr = 0.0;
   for (int64_t i = threadIdx.x; i < n; i += 256) {
-    si += (double)in[i].y;
-    sr += (double)in[i].x;
+    si += (double)in[i];
+    if (At) sr += (double)y[i];
   }
   si = block_sum_256(si, red) / (double)n;
   sr = block_sum_256(sr, red) / (double)n;
   for (int64_t i = threadIdx.x; i < n_pad; i += 256) {
     const bool ok = i < n;
-    Bt[f * n_pad + i] = ok ? (float)((double)in[i].y - si) : 0.f;
-    if (At) At[f * n_pad + i] = ok ? (float)((double)in[i].x - sr) : 0.f;
+    Bt[f * n_pad + i] = ok ? (float)((double)in[i] - si) : 0.f;
+    if (At) At[f * n_pad + i] = ok ? (float)((double)y[i] - sr) : 0.f;
   }
 }
 
