@@ -202,6 +202,13 @@ int eofx_cpanel_combine_f32(eofx_ctx *ctx, const float *P1, const float *P2, int
 int eofx_panel_colargminmax_f32(eofx_ctx *ctx, const float *P, int64_t rows, int L, int64_t *amax,
                                 int64_t *amin);
 
+/* ---- the sketch matrix ------------------------------------------------------------------
+ * out[rows x cols] (host float32) = np.random.RandomState(seed).normal(size=(rows, cols))
+ * .astype(float32), bit for bit -- the Gaussian test matrix scikit-learn's randomized_svd draws
+ * (MT19937 + numpy's legacy polar method), so `random_state=seed` means what it means in the
+ * reference (decomposer.py:141-146).                                                        */
+int eofx_sketch_gaussian_f32(uint32_t seed, int64_t rows, int64_t cols, float *out);
+
 /* ---- small host linear algebra used by the drivers ---------------------- */
 /* symmetric eigen-decomposition (Householder tridiagonalisation + implicit QL, float64):
  * A[n x n] row-major ->

@@ -48,9 +48,14 @@ def test_host_eigh():
 def test_sketch_matrix_is_sklearns():
     from xeofs_amd.engine import sketch_matrix
 
-    a = sketch_matrix(50, 12, 42)
-    b = np.random.RandomState(42).normal(size=(50, 12)).astype(np.float32)
-    assert np.array_equal(a, b) and a.flags.c_contiguous
+    # native generator (eofx_sketch_gaussian_f32) vs numpy's legacy stream, bit for bit, including odd
+    # totals (cached second deviate), sizes that span MT19937 refills and the multi-threaded tail
+    for seed, shape in [(42, (50, 12)), (0, (7, 3)), (5, (3000, 60)), (2 ** 32 - 1, (1, 1)), (77, (1001, 61))]:
+        a = sketch_matrix(shape[0], shape[1], seed)
+        b = np.random.RandomState(seed).normal(size=shape).astype(np.float32)
+        assert np.array_equal(a, b) and a.flags.c_contiguous, (seed, shape)
+    rs = np.random.RandomState(9)
+    assert np.array_equal(sketch_matrix(20, 5, rs), np.random.RandomState(9).normal(size=(20, 5)).astype(np.float32))
     with pytest.raises(ValueError):
         sketch_matrix(5, 2, np.random.default_rng(0))
 

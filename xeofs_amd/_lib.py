@@ -59,6 +59,7 @@ SIGNATURES = {
     "eofx_mat_sumsq_f64": (_int, [_vp, _vp, _pd]),
     "eofx_cpanel_combine_f32": (_int, [_vp, _vp, _vp, _int, _i64, _int, _vp]),
     "eofx_panel_colargminmax_f32": (_int, [_vp, _vp, _i64, _int, _vp, _vp]),
+    "eofx_sketch_gaussian_f32": (_int, [C.c_uint32, _i64, _i64, _vp]),
     "eofx_host_eigh_f64": (_int, [_vp, _int, _vp, _vp]),
 }
 

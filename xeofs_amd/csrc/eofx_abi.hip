@@ -10,6 +10,7 @@
 #include <cstring>
 #include <functional>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <hipfft/hipfft.h>
@@ -1462,5 +1463,89 @@ extern "C" int eofx_mat_sumsq_f64(eofx_ctx* ctx, const eofx_mat* m, double* out)
   double t = 0.0;
   for (int i = 0; i < nb; ++i) t += hp[i];
   *out = t;
+  return EOFX_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// Gaussian sketch matrix, bit-identical to numpy's legacy stream
+//   np.random.RandomState(seed).normal(size=(rows, cols)).astype(np.float32)
+// which is what scikit-learn draws for randomized_svd (extmath.py _randomized_range_finder), so
+// `random_state` keeps its meaning.  MT19937 (init_genrand seeding), 53-bit doubles, Marsaglia
+// polar method with the cached second deviate (numpy legacy_gauss).  The uniform stream and the
+// accept/reject decisions are inherently sequential; the log/sqrt transforms of the accepted pairs
+// are independent and run on worker threads (same libm, same results).
+// ------------------------------------------------------------------------------------
+namespace {
+struct MT19937 {
+  uint32_t mt[624];
+  int idx;
+  explicit MT19937(uint32_t seed) {
+    mt[0] = seed;
+    for (int i = 1; i < 624; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+    idx = 624;
+  }
+  void refill() {
+    int k = 0;
+    for (; k < 624 - 397; ++k) {
+      const uint32_t y = (mt[k] & 0x80000000u) | (mt[k + 1] & 0x7fffffffu);
+      mt[k] = mt[k + 397] ^ (y >> 1) ^ (-(int32_t)(y & 1u) & 0x9908b0dfu);
+    }
+    for (; k < 623; ++k) {
+      const uint32_t y = (mt[k] & 0x80000000u) | (mt[k + 1] & 0x7fffffffu);
+      mt[k] = mt[k + (397 - 624)] ^ (y >> 1) ^ (-(int32_t)(y & 1u) & 0x9908b0dfu);
+    }
+    const uint32_t y = (mt[623] & 0x80000000u) | (mt[0] & 0x7fffffffu);
+    mt[623] = mt[396] ^ (y >> 1) ^ (-(int32_t)(y & 1u) & 0x9908b0dfu);
+    idx = 0;
+  }
+  inline uint32_t next() {
+    if (idx >= 624) refill();
+    uint32_t y = mt[idx++];
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+  }
+  inline double next_double() {
+    const uint32_t a = next() >> 5, b = next() >> 6;
+    return (a * 67108864.0 + b) / 9007199254740992.0;
+  }
+};
+}  // namespace
+
+extern "C" int eofx_sketch_gaussian_f32(uint32_t seed, int64_t rows, int64_t cols, float* out) {
+  if (!out || rows < 0 || cols < 0) return EOFX_ERR_ARG;
+  const int64_t total = rows * cols;
+  const int64_t npairs = (total + 1) / 2;
+  std::vector<double> x1(npairs), x2(npairs), r2(npairs);
+  MT19937 g(seed);
+  for (int64_t i = 0; i < npairs; ++i) {
+    double a, b, r;
+    do {
+      a = 2.0 * g.next_double() - 1.0;
+      b = 2.0 * g.next_double() - 1.0;
+      r = a * a + b * b;
+    } while (r >= 1.0 || r == 0.0);
+    x1[i] = a;
+    x2[i] = b;
+    r2[i] = r;
+  }
+  auto work = [&](int64_t lo, int64_t hi) {
+    for (int64_t i = lo; i < hi; ++i) {
+      const double f = std::sqrt(-2.0 * std::log(r2[i]) / r2[i]);
+      out[2 * i] = (float)(f * x2[i]);                          // returned first
+      if (2 * i + 1 < total) out[2 * i + 1] = (float)(f * x1[i]);  // the cached deviate
+    }
+  };
+  const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(8, npairs / 16384));
+  if (nt == 1) {
+    work(0, npairs);
+  } else {
+    std::vector<std::thread> th;
+    const int64_t step = (npairs + nt - 1) / nt;
+    for (int t = 0; t < nt; ++t) th.emplace_back(work, t * step, std::min<int64_t>(npairs, (t + 1) * step));
+    for (auto& t : th) t.join();
+  }
   return EOFX_OK;
 }

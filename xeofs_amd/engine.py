@@ -132,7 +132,14 @@ def sketch_matrix(rows: int, size: int, random_state=None) -> np.ndarray:
     if random_state is None or random_state is np.random:
         rs = np.random.mtrand._rand
     elif isinstance(random_state, numbers.Integral):
-        rs = np.random.RandomState(int(random_state))
+        seed = int(random_state)
+        if not 0 <= seed < 2 ** 32:
+            raise ValueError("Seed must be between 0 and 2**32 - 1")
+        # native generator: the same legacy MT19937 / polar-method stream as RandomState(seed).normal,
+        # bit for bit (tests/test_abi.py), ~3x faster than numpy for the 600k draws of a 10000 x 60 sketch
+        out = np.empty((rows, size), dtype=np.float32)
+        raise_for(_lib.load().eofx_sketch_gaussian_f32(seed, rows, size, ptr(out)))
+        return out
     elif isinstance(random_state, np.random.RandomState):
         rs = random_state
     else:
