@@ -106,6 +106,10 @@ def blas_threads():
 
 
 def main():
+    # Libraries (RCCL prints a version banner at communicator creation) must not pollute stdout: the
+    # contract is ONE JSON line there.  Keep the real stdout aside and point fd 1 at stderr.
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -116,6 +120,9 @@ def main():
     ap.add_argument("--modes", type=int, default=50)
     ap.add_argument("--precision", choices=["mixed", "f32", "bf16x3"], default="mixed",
                     help="mixed = bf16x3 power passes + bf16x6 final passes (default); f32 = exact-f32 MFMA")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="diagnostic: run the multi-GPU orchestration (panel-level ABI + RCCL collectives) even at "
+                         "world size 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sample-parity", action="store_true",
                     help="also decompose the CPU-baseline sample on the GPU and compare singular values "
@@ -137,7 +144,9 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (xeofs_amd has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     device = torch.device(f"cuda:{local_rank}")
-    if world > 1:
+    if world > 1 or args.force_sharded:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     if args.gpus != world:
         if rank == 0:
@@ -148,7 +157,7 @@ def main():
     lo, hi = sharded.shard_bounds(P, world, rank)
     ctx = engine.Context(local_rank)
     ctx.set_precision(*{"mixed": ("bf16x3", "bf16x6"), "f32": ("f32", "f32"), "bf16x3": ("bf16x3", "bf16x3")}[args.precision])
-    comm = sharded.Comm()
+    comm = sharded.Comm(force=args.force_sharded)
 
     t0 = time.perf_counter()
     Xraw = make_field(n, args.nlat, args.nlon, lo, hi, device)
@@ -171,7 +180,7 @@ def main():
                                     want_stats=False)
         torch.cuda.synchronize()
         b = time.perf_counter()
-        if world == 1:
+        if world == 1 and not args.force_sharded:
             U, s, V = engine.rsvd(ctx, mat, k, N_OVERSAMPLES, "auto", omega=omega.result(), device_out=True)
         else:
             ops = sharded.HipPanelOps(ctx, mat)
@@ -311,8 +320,8 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,
             "datagen_s": round(t_gen, 2),
         }
-        print(json.dumps(line), flush=True)
-    if world > 1:
+        print(json.dumps(line), file=real_stdout, flush=True)
+    if world > 1 or args.force_sharded:
         dist.barrier()
         dist.destroy_process_group()
 
