@@ -39,6 +39,7 @@ extern "C" {
 #endif
 
 #define EOFX_ABI_VERSION 1
+#define EOFX_MAX_SKETCH 256 /* widest sketch k + n_oversamples; <= 64 is factorised on the device */
 
 #define EOFX_OK 0
 #define EOFX_ERR_ARG (-1)          /* bad argument                       -> ValueError        */

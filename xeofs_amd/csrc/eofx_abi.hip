@@ -454,14 +454,60 @@ static int launch_matmul(eofx_ctx* ctx, const float* P, int64_t rows, int L, con
   return EOFX_OK;
 }
 
+// host fallback of chol_rinv for sketches wider than one wavefront's 64 columns: same algorithm,
+// same dependent-column rule, float64.  G, Rinv are L x L row-major; only the l x l block is used.
+static void host_chol_rinv(const double* G, int L, int l, double* Rinv, double tol) {
+  std::vector<double> A((size_t)l * l, 0.0), X((size_t)l * l, 0.0), d0(l);
+  std::vector<char> dead(l, 0);
+  for (int r = 0; r < l; ++r) {
+    d0[r] = G[(size_t)r * L + r];
+    for (int c = r; c < l; ++c) A[(size_t)r * l + c] = G[(size_t)r * L + c];
+  }
+  for (int j = 0; j < l; ++j) {
+    const double d = A[(size_t)j * l + j];
+    const bool dj = !(d > tol * d0[j]) || !(d0[j] > 0.0);
+    dead[j] = dj;
+    const double rjj = dj ? 1.0 : std::sqrt(d);
+    const double piv = dj ? 0.0 : 1.0 / rjj;
+    A[(size_t)j * l + j] = rjj;
+    double* rowj = &A[(size_t)j * l];
+    for (int c = j + 1; c < l; ++c) rowj[c] *= piv;
+    for (int r = j + 1; r < l; ++r) {
+      const double f = rowj[r];
+      if (f == 0.0) continue;
+      double* rowr = &A[(size_t)r * l];
+      for (int c = r; c < l; ++c) rowr[c] -= f * rowj[c];
+    }
+  }
+  for (int c = 0; c < l; ++c) {
+    if (dead[c]) continue;
+    X[(size_t)c * l + c] = 1.0 / A[(size_t)c * l + c];
+    for (int r = c - 1; r >= 0; --r) {
+      double sum = 0.0;
+      for (int t = r + 1; t <= c; ++t) sum += A[(size_t)r * l + t] * X[(size_t)t * l + c];
+      X[(size_t)r * l + c] = -sum / A[(size_t)r * l + r];
+    }
+  }
+  for (int r = 0; r < L; ++r)
+    for (int c = 0; c < L; ++c) Rinv[(size_t)r * L + c] = (r < l && c < l) ? X[(size_t)r * l + c] : 0.0;
+}
+
 // out = P R^-1 with G = R^T R (leading l x l block)
 static int launch_cholqr(eofx_ctx* ctx, const float* P, int64_t rows, int L, int l, const double* G,
                          float* out) {
-  if (l > 64) return set_err(ctx, EOFX_ERR_ARG, "cholqr: sketch width %d > 64 not supported yet", l);
   ArenaScope scope(ctx);
   ARENA(double, Rinv, (size_t)L * L);
-  hipLaunchKernelGGL(chol_rinv_kernel, dim3(1), dim3(64), 0, ctx->stream, G, L, l, Rinv, 1e-13);
-  KCHK();
+  if (l <= 64) {
+    hipLaunchKernelGGL(chol_rinv_kernel, dim3(1), dim3(64), 0, ctx->stream, G, L, l, Rinv, 1e-13);
+    KCHK();
+  } else {
+    std::vector<double> hG((size_t)L * L), hR((size_t)L * L);
+    HIPCHK(hipMemcpyAsync(hG.data(), G, sizeof(double) * L * L, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    host_chol_rinv(hG.data(), L, l, hR.data(), 1e-13);
+    HIPCHK(hipMemcpyAsync(Rinv, hR.data(), sizeof(double) * L * L, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
   return launch_matmul(ctx, P, rows, L, Rinv, L, out);
 }
 
@@ -1116,7 +1162,8 @@ extern "C" int eofx_rsvd_f32(eofx_ctx* ctx, const eofx_mat* m, int k, int n_over
                    "n_modes must be less than or equal to the rank of the dataset (rank = %lld).", (long long)r);
   const int l_req = k + n_oversamples;
   const int l = (int)std::min<int64_t>(l_req, r);
-  if (l > 64) return set_err(ctx, EOFX_ERR_ARG, "sketch width k+n_oversamples = %d > 64 not supported yet", l);
+  if (l > EOFX_MAX_SKETCH)
+    return set_err(ctx, EOFX_ERR_ARG, "sketch width k+n_oversamples = %d > %d is not supported", l, EOFX_MAX_SKETCH);
   if (n_iter < 0) n_iter = rsvd_auto_iters(k, n, p);
   const bool transposed = n < p;  // sklearn: transpose = n_samples < n_features
   LinOp op;
@@ -1214,7 +1261,7 @@ extern "C" int eofx_crosscov_rsvd_f32(eofx_ctx* ctx, const eofx_mat* x, const eo
                    "n_modes must be less than or equal to the rank of the dataset (rank = %lld).", (long long)r);
   const int l_req = k + n_oversamples;
   const int l = (int)std::min<int64_t>(l_req, r);
-  if (l > 64) return set_err(ctx, EOFX_ERR_ARG, "sketch width %d > 64 not supported yet", l);
+  if (l > EOFX_MAX_SKETCH) return set_err(ctx, EOFX_ERR_ARG, "sketch width %d > %d is not supported", l, EOFX_MAX_SKETCH);
   if (l != l_req) return set_err(ctx, EOFX_ERR_ARG, "sketch wider than rank not supported on the cross path");
   if (n_iter < 0) n_iter = rsvd_auto_iters(k, p1, p2);
   const int L = (int)round_up(l, 32);

@@ -14,7 +14,7 @@ import numpy as np
 
 from .. import engine
 
-MAX_SKETCH = 64  # widest sketch the current kernels factorise on-device
+MAX_SKETCH = 256  # EOFX_MAX_SKETCH: sketches up to 64 wide are factorised on the device, wider ones on the host
 
 
 def sanity_check_n_modes(n_modes):
