@@ -37,7 +37,16 @@ struct eofx_ctx {
   std::vector<std::pair<void*, size_t>> pool;
   size_t pool_bytes = 0;
   size_t pool_cap = (size_t)160 << 30;
-  // cached hipFFT plans of the Hilbert stage: key = (N, batch) -> (R2C plan, C2R plan)
+  // cached setups of the Hilbert stage (kernel spectrum + correction vectors per (n, padding, decay))
+  struct HilbertSetup {
+    int64_t n = 0, P = 0;
+    int padding = 0;
+    double decay = 0.0;
+    void* chat = nullptr;  // device cfloat[P/2+1]
+    float* u = nullptr;    // device float[4 n]
+  };
+  std::vector<HilbertSetup> hsetups;
+  // cached hipFFT plans of the Hilbert stage: key = (P, batch) -> (R2C plan, C2R plan)
   std::vector<std::pair<std::pair<int64_t, int64_t>, std::pair<void*, void*>>> fft_plans;
   // optional per-launch timing of the dominant kernel (atb_f32) with HIP events on `stream`
   bool profile = false;
@@ -158,6 +167,10 @@ extern "C" int eofx_ctx_destroy(eofx_ctx* ctx) {
   for (auto& e : ctx->fft_plans) {
     hipfftDestroy((hipfftHandle)e.second.first);
     hipfftDestroy((hipfftHandle)e.second.second);
+  }
+  for (auto& h : ctx->hsetups) {
+    if (h.chat) (void)hipFree(h.chat);
+    if (h.u) (void)hipFree(h.u);
   }
   delete ctx;
   return EOFX_OK;
@@ -1358,16 +1371,113 @@ extern "C" int eofx_crosscov_rsvd_f32(eofx_ctx* ctx, const eofx_mat* x, const eo
     }                                                                                           \
   } while (0)
 
+// impulse response of Im(analytic-signal filter) of period N at integer lag d (0 at d = 0 mod N):
+// N even: (2/N) cot(pi d/N) for odd d, 0 for even d;  N odd: (cot(pi d/N) - (-1)^d / sin(pi d/N)) / N
+static double hilbert_kappa(int64_t N, int64_t d) {
+  int64_t m = d % N;
+  if (m < 0) m += N;
+  if (m == 0) return 0.0;
+  const double x = M_PI * (double)d / (double)N;
+  if (N % 2 == 0) return (m % 2) ? (2.0 / (double)N) / std::tan(x) : 0.0;
+  const double sgn = (std::llabs(d) % 2) ? -1.0 : 1.0;
+  return (1.0 / std::tan(x) - sgn / std::sin(x)) / (double)N;
+}
+
+static int get_fft_plans(eofx_ctx* ctx, int64_t P, int64_t ldw, int64_t nh, int64_t batch, hipfftHandle& pf,
+                         hipfftHandle& pb) {
+  for (auto& e : ctx->fft_plans)
+    if (e.first.first == P && e.first.second == batch) {
+      pf = (hipfftHandle)e.second.first;
+      pb = (hipfftHandle)e.second.second;
+      return EOFX_OK;
+    }
+  int len = (int)P, rembed = (int)ldw, cembed = (int)nh;
+  if (hipfftPlanMany(&pf, 1, &len, &rembed, 1, (int)ldw, &cembed, 1, (int)nh, HIPFFT_R2C, (int)batch) != HIPFFT_SUCCESS)
+    return set_err(ctx, EOFX_ERR_HIP, "hipfftPlanMany(R2C, P=%lld, batch=%lld) failed", (long long)P, (long long)batch);
+  if (hipfftPlanMany(&pb, 1, &len, &cembed, 1, (int)nh, &rembed, 1, (int)ldw, HIPFFT_C2R, (int)batch) != HIPFFT_SUCCESS) {
+    hipfftDestroy(pf);
+    return set_err(ctx, EOFX_ERR_HIP, "hipfftPlanMany(C2R, P=%lld, batch=%lld) failed", (long long)P, (long long)batch);
+  }
+  hipfftSetStream(pf, ctx->stream);
+  hipfftSetStream(pb, ctx->stream);
+  ctx->fft_plans.push_back({{P, batch}, {(void*)pf, (void*)pb}});
+  return EOFX_OK;
+}
+
+// kernel spectrum and correction vectors for series length n (cached per context)
+static int get_hilbert_setup(eofx_ctx* ctx, int64_t n, int padding, double decay, int64_t P,
+                             const cfloat** chat_out, const float** u_out) {
+  for (auto& h : ctx->hsetups)
+    if (h.n == n && h.padding == padding && h.decay == decay && h.P == P) {
+      *chat_out = (const cfloat*)h.chat;
+      *u_out = h.u;
+      return EOFX_OK;
+    }
+  const int64_t N = padding ? 3 * n : n;  // period of the Hilbert kernel
+  const int64_t nh = P / 2 + 1, ldw = P + 2;
+  eofx_ctx::HilbertSetup hs;
+  hs.n = n; hs.P = P; hs.padding = padding; hs.decay = decay;
+  // circular embedding of the Toeplitz kernel, lags -(n-1) .. n-1, scaled by 1/P (unnormalised inverse)
+  std::vector<float> c((size_t)ldw, 0.f);
+  for (int64_t d = -(n - 1); d <= n - 1; ++d)
+    c[(size_t)((d % P + P) % P)] = (float)(hilbert_kappa(N, d) / (double)P);
+  float* cdev = nullptr;
+  HIPCHK(hipMalloc((void**)&cdev, sizeof(float) * ldw));
+  HIPCHK(hipMalloc(&hs.chat, sizeof(cfloat) * nh));
+  HIPCHK(hipMemcpy(cdev, c.data(), sizeof(float) * ldw, hipMemcpyHostToDevice));
+  hipfftHandle pf, pb;
+  CHK(get_fft_plans(ctx, P, ldw, nh, 1, pf, pb));
+  if (hipfftExecR2C(pf, cdev, (hipfftComplex*)hs.chat) != HIPFFT_SUCCESS)
+    return set_err(ctx, EOFX_ERR_HIP, "hipfftExecR2C failed (kernel spectrum)");
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  (void)hipFree(cdev);
+  if (padding) {
+    // u1 = K_pre e_rev, u2 = K_pos e, u3 = (K_pre + K_pos) 1, u4 = K_pre (t - n) + K_pos (t + n)
+    // with K_pre[t][s] = kappa((n + t) - s), K_pos[t][s] = kappa((n + t) - (2n + s)); float64, threaded
+    std::vector<double> e((size_t)n), kap((size_t)(4 * n + 1));
+    for (int64_t t = 0; t < n; ++t) e[t] = std::exp(-(double)t / (double)n / decay);
+    for (int64_t d = -2 * n; d <= 2 * n; ++d) kap[(size_t)(d + 2 * n)] = hilbert_kappa(N, d);
+    std::vector<float> hu((size_t)4 * n);
+    auto work = [&](int64_t lo, int64_t hi) {
+      for (int64_t t = lo; t < hi; ++t) {
+        double a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+        for (int64_t sidx = 0; sidx < n; ++sidx) {
+          const double kp = kap[(size_t)((n + t - sidx) + 2 * n)];
+          const double kq = kap[(size_t)((t - n - sidx) + 2 * n)];
+          a1 += kp * e[n - 1 - sidx];
+          a2 += kq * e[sidx];
+          a3 += kp + kq;
+          a4 += kp * (double)(sidx - n) + kq * (double)(sidx + n);
+        }
+        hu[t] = (float)a1; hu[n + t] = (float)a2; hu[2 * n + t] = (float)a3; hu[3 * n + t] = (float)a4;
+      }
+    };
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(16, n / 256));
+    std::vector<std::thread> th;
+    const int64_t step = (n + nt - 1) / nt;
+    for (int t = 0; t < nt; ++t) th.emplace_back(work, t * step, std::min<int64_t>(n, (t + 1) * step));
+    for (auto& t : th) t.join();
+    HIPCHK(hipMalloc((void**)&hs.u, sizeof(float) * 4 * n));
+    HIPCHK(hipMemcpy(hs.u, hu.data(), sizeof(float) * 4 * n, hipMemcpyHostToDevice));
+  }
+  ctx->hsetups.push_back(hs);
+  *chat_out = (const cfloat*)hs.chat;
+  *u_out = hs.u;
+  return EOFX_OK;
+}
+
 extern "C" int eofx_hilbert_f32(eofx_ctx* ctx, const eofx_mat* a, int padding, double decay_factor,
                                 eofx_mat** out_imag, eofx_mat** out_real) {
   if (!ctx || !a || !out_imag) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
   if (padding && !(decay_factor > 0.0)) return set_err(ctx, EOFX_ERR_ARG, "decay_factor must be positive");
   CHK(set_device(ctx));
   const int64_t n = a->n, p = a->p, n_pad = a->n_pad, p_pad = a->p_pad;
-  const int64_t N = padding ? 3 * n : n;
-  const int64_t off = padding ? n : 0;
-  const int64_t nh = N / 2 + 1;          // half-spectrum bins of the real transform
-  const int64_t ldw = N + 2;             // real series row stride (floats), 8-byte aligned rows
+  int64_t P = 2;
+  while (P < 2 * n) P *= 2;                 // circular length: power of two >= 2n
+  const int64_t nh = P / 2 + 1, ldw = P + 2;
+  const cfloat* chat = nullptr;
+  const float* u = nullptr;
+  CHK(get_hilbert_setup(ctx, n, padding ? 1 : 0, padding ? decay_factor : 0.0, P, &chat, &u));
   // features per FFT batch: real series + half spectrum of about 3 GB together
   int64_t Fc = std::max<int64_t>(1, std::min<int64_t>(p, (int64_t)(3.0e9 / (4.0 * (double)ldw + 8.0 * (double)nh))));
   eofx_mat *mi = nullptr, *mr = nullptr;
@@ -1376,61 +1486,37 @@ extern "C" int eofx_hilbert_f32(eofx_ctx* ctx, const eofx_mat* a, int padding, d
   if (out_real) rc = mat_alloc(ctx, n, p, &mr);
   float* work = nullptr;
   cfloat* spec = nullptr;
-  float* exp_tab = nullptr;
+  float* coef = nullptr;
   hipfftHandle plan_f = 0, plan_b = 0, tail_f = 0, tail_b = 0;
   const size_t work_bytes = (size_t)Fc * ldw * sizeof(float), spec_bytes = (size_t)Fc * nh * sizeof(cfloat);
-  const size_t tab_bytes = (size_t)std::max<int64_t>(n, 1) * sizeof(float);
+  const size_t coef_bytes = (size_t)Fc * 4 * sizeof(float);
   if (rc != EOFX_OK) goto done;
   if (pool_malloc(ctx, (void**)&work, work_bytes) != hipSuccess ||
       pool_malloc(ctx, (void**)&spec, spec_bytes) != hipSuccess ||
-      pool_malloc(ctx, (void**)&exp_tab, tab_bytes) != hipSuccess) {
+      pool_malloc(ctx, (void**)&coef, coef_bytes) != hipSuccess) {
     rc = set_err(ctx, EOFX_ERR_NOMEM, "cannot allocate the FFT work buffers");
     goto done;
   }
   {
-    int len = (int)N;
-    int rembed = (int)ldw, cembed = (int)nh;
-    // plans are cached per (N, batch): creating them costs more than running them
-    auto get_plans = [&](int64_t batch, hipfftHandle& pf, hipfftHandle& pb) -> int {
-      for (auto& e : ctx->fft_plans)
-        if (e.first.first == N && e.first.second == batch) {
-          pf = (hipfftHandle)e.second.first;
-          pb = (hipfftHandle)e.second.second;
-          return EOFX_OK;
-        }
-      if (hipfftPlanMany(&pf, 1, &len, &rembed, 1, (int)ldw, &cembed, 1, (int)nh, HIPFFT_R2C, (int)batch) != HIPFFT_SUCCESS)
-        return set_err(ctx, EOFX_ERR_HIP, "hipfftPlanMany(R2C, N=%lld, batch=%lld) failed", (long long)N, (long long)batch);
-      if (hipfftPlanMany(&pb, 1, &len, &cembed, 1, (int)nh, &rembed, 1, (int)ldw, HIPFFT_C2R, (int)batch) != HIPFFT_SUCCESS) {
-        hipfftDestroy(pf);
-        return set_err(ctx, EOFX_ERR_HIP, "hipfftPlanMany(C2R, N=%lld, batch=%lld) failed", (long long)N, (long long)batch);
-      }
-      hipfftSetStream(pf, ctx->stream);
-      hipfftSetStream(pb, ctx->stream);
-      ctx->fft_plans.push_back({{N, batch}, {(void*)pf, (void*)pb}});
-      return EOFX_OK;
-    };
-    rc = get_plans(Fc, plan_f, plan_b);
+    rc = get_fft_plans(ctx, P, ldw, nh, Fc, plan_f, plan_b);
     if (rc != EOFX_OK) goto done;
     const int64_t tail = p % Fc;
     if (tail) {
-      rc = get_plans(tail, tail_f, tail_b);
+      rc = get_fft_plans(ctx, P, ldw, nh, tail, tail_f, tail_b);
       if (rc != EOFX_OK) goto done;
     }
-    if (padding)
-      hipLaunchKernelGGL(hilbert_exp_table_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, ctx->stream,
-                         exp_tab, n, decay_factor);
     for (int64_t f0 = 0; f0 < p; f0 += Fc) {
       const int64_t fc = std::min(Fc, p - f0);
       const bool full = fc == Fc;
       hipLaunchKernelGGL(hilbert_pack_kernel, dim3((int)fc), dim3(256), 0, ctx->stream, a->Xt, n_pad, n, f0,
-                         padding, exp_tab, work, ldw);
+                         padding ? 1 : 0, work, ldw, P, coef);
       FFTCHK(hipfftExecR2C(full ? plan_f : tail_f, work, (hipfftComplex*)spec));
       const int64_t total = fc * nh;
       hipLaunchKernelGGL(hilbert_filter_kernel, dim3((int)std::min<int64_t>((total + 255) / 256, 16384)),
-                         dim3(256), 0, ctx->stream, spec, N, nh, total);
+                         dim3(256), 0, ctx->stream, spec, chat, nh, total);
       FFTCHK(hipfftExecC2R(full ? plan_b : tail_b, (hipfftComplex*)spec, work));
-      hipLaunchKernelGGL(hilbert_unpack_kernel, dim3((int)fc), dim3(256), 0, ctx->stream, work, ldw, off, n,
-                         n_pad, f0, a->Xt, mi->Xt, mr ? mr->Xt : nullptr);
+      hipLaunchKernelGGL(hilbert_unpack_kernel, dim3((int)fc), dim3(256), 0, ctx->stream, work, ldw, n, n_pad,
+                         f0, padding ? 1 : 0, coef, u, a->Xt, mi->Xt, mr ? mr->Xt : nullptr);
     }
     // zero the padding feature rows, then build the feature-contiguous layout by transposition
     const size_t pad_bytes = (size_t)(p_pad - p) * n_pad * sizeof(float);
@@ -1451,7 +1537,7 @@ extern "C" int eofx_hilbert_f32(eofx_ctx* ctx, const eofx_mat* a, int padding, d
 done:
   pool_give(ctx, work, work_bytes);
   pool_give(ctx, spec, spec_bytes);
-  pool_give(ctx, exp_tab, tab_bytes);
+  pool_give(ctx, coef, coef_bytes);
   if (rc != EOFX_OK) {
     if (mi) eofx_mat_destroy(ctx, mi);
     if (mr) eofx_mat_destroy(ctx, mr);

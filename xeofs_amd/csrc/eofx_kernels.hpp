@@ -835,89 +835,96 @@ __device__ __forceinline__ double block_sum_256(double v, double* red) {
   return out;
 }
 
-// exp_tab[t] = exp(-t / n / decay), t = 0..n-1
-__global__ void hilbert_exp_table_kernel(float* __restrict__ tab, int64_t n, double decay) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < n) tab[t] = (float)exp(-(double)t / (double)n / decay);
-}
+// The padded transform is linear in the series y (the linear fit, the pad amplitudes and the pads are
+// all linear functionals of y), so for the middle n samples
+//     Im(analytic(y_ext))[n:2n] = T y + amp_pre u1 + amp_pos u2 + c0 u3 + c1 u4
+// with T the n x n Toeplitz block of the period-3n Hilbert kernel and u1..u4 fixed vectors (host,
+// once per (n, decay)).  T y is a linear convolution with lags |d| < n: one circular convolution of
+// POWER-OF-TWO length P >= 2n (rocFFT's single-kernel territory) instead of a length-3n transform.
 
-// one workgroup per feature: ext = [amp_pre * e_rev ; y - fit ; amp_pos * e] + fit_ext (padding) or y,
-// written as a REAL series of length N (row stride ldw floats) for the R2C transform
+// one workgroup per feature: zero-padded series -> work row; fit/pad coefficients -> coef[f] (4 floats)
 __global__ __launch_bounds__(256) void hilbert_pack_kernel(const float* __restrict__ Xt, int64_t n_pad,
                                                             int64_t n, int64_t f0, int padding,
-                                                            const float* __restrict__ exp_tab,
-                                                            float* __restrict__ work, int64_t ldw) {
+                                                            float* __restrict__ work, int64_t ldw, int64_t P,
+                                                            float* __restrict__ coef) {
   __shared__ double red[256];
   const int64_t f = f0 + blockIdx.x;
   const float* y = Xt + f * n_pad;
   float* out = work + (int64_t)blockIdx.x * ldw;
-  if (!padding) {
-    for (int64_t i = threadIdx.x; i < n; i += 256) out[i] = y[i];
-    return;
-  }
   double sy = 0.0, sty = 0.0;
   const double tbar = 0.5 * (double)(n - 1);
-  for (int64_t i = threadIdx.x; i < n; i += 256) {
-    const double v = (double)y[i];
-    sy += v;
-    sty += ((double)i - tbar) * v;
+  for (int64_t i = threadIdx.x; i < P; i += 256) {
+    float v = 0.f;
+    if (i < n) {
+      v = y[i];
+      sy += (double)v;
+      sty += ((double)i - tbar) * (double)v;
+    }
+    out[i] = v;
   }
+  if (!padding) return;
   sy = block_sum_256(sy, red);
   sty = block_sum_256(sty, red);
-  const double stt = (double)n * ((double)n * (double)n - 1.0) / 12.0;
-  const double c1 = (n > 1) ? sty / stt : 0.0;
-  const double c0 = sy / (double)n - c1 * tbar;  // fit(t) = c0 + c1 t
-  const double amp_pre = (double)y[0] - c0;
-  const double amp_pos = (double)y[n - 1] - (c0 + c1 * (double)(n - 1));
-  for (int64_t i = threadIdx.x; i < n; i += 256) {
-    const double fit_pre = c0 + c1 * (double)(i - n);
-    const double fit_pos = c0 + c1 * (double)(i + n);
-    out[i] = (float)(amp_pre * (double)exp_tab[n - 1 - i] + fit_pre);
-    out[n + i] = y[i];
-    out[2 * n + i] = (float)(amp_pos * (double)exp_tab[i] + fit_pos);
+  if (threadIdx.x == 0) {
+    const double stt = (double)n * ((double)n * (double)n - 1.0) / 12.0;
+    const double c1 = (n > 1) ? sty / stt : 0.0;
+    const double c0 = sy / (double)n - c1 * tbar;  // fit(t) = c0 + c1 t  (numpy polyfit deg 1)
+    float* cf = coef + (int64_t)blockIdx.x * 4;
+    cf[0] = (float)((double)y[0] - c0);                                  // amp_pre
+    cf[1] = (float)((double)y[n - 1] - (c0 + c1 * (double)(n - 1)));     // amp_pos
+    cf[2] = (float)c0;
+    cf[3] = (float)c1;
   }
 }
 
-// Hilbert filter on the half spectrum of a real series: Yh(k) = -i * Y(k) for 0 < k < N/2, 0 at DC and
-// Nyquist; the 1/N of the unnormalised inverse transform is folded in.  irfft(Yh) is then the Hilbert
-// transform itself = Im(analytic signal).  `spec` holds nh = N/2 + 1 bins per feature.
-__global__ __launch_bounds__(256) void hilbert_filter_kernel(cfloat* __restrict__ spec, int64_t N,
-                                                              int64_t nh, int64_t total) {
+// spec[f][k] *= chat[k]   (chat = rfft of the Toeplitz kernel, 1/P of the inverse folded in)
+__global__ __launch_bounds__(256) void hilbert_filter_kernel(cfloat* __restrict__ spec,
+                                                              const cfloat* __restrict__ chat, int64_t nh,
+                                                              int64_t total) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  const float inv = 1.0f / (float)N;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-    const int64_t k = i % nh;
+    const cfloat c = chat[i % nh];
     const cfloat v = spec[i];
-    cfloat o = {0.f, 0.f};
-    if (k != 0 && !(N % 2 == 0 && k == N / 2)) {
-      o.x = v.y * inv;   // -i (a + i b) = b - i a
-      o.y = -v.x * inv;
-    }
-    spec[i] = o;
+    spec[i] = cfloat{v.x * c.x - v.y * c.y, v.x * c.y + v.y * c.x};
   }
 }
 
-// middle segment of the real Hilbert-transformed series, minus its mean -> Bt row; optionally the
+// first n samples of the convolution + the four corrections, minus the mean -> Bt row; optionally the
 // re-centred input (Re of the analytic signal) -> At row
 __global__ __launch_bounds__(256) void hilbert_unpack_kernel(const float* __restrict__ work, int64_t ldw,
-                                                              int64_t off, int64_t n, int64_t n_pad,
-                                                              int64_t f0, const float* __restrict__ Xt,
+                                                              int64_t n, int64_t n_pad, int64_t f0,
+                                                              int padding, const float* __restrict__ coef,
+                                                              const float* __restrict__ u,
+                                                              const float* __restrict__ Xt,
                                                               float* __restrict__ Bt,
                                                               float* __restrict__ At) {
   __shared__ double red[256];
-  const float* in = work + (int64_t)blockIdx.x * ldw + off;
+  const float* in = work + (int64_t)blockIdx.x * ldw;
   const int64_t f = f0 + blockIdx.x;
   const float* y = Xt + f * n_pad;
+  float a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+  if (padding) {
+    const float* cf = coef + (int64_t)blockIdx.x * 4;
+    a1 = cf[0]; a2 = cf[1]; a3 = cf[2]; a4 = cf[3];
+  }
   double si = 0.0, sr = 0.0;
   for (int64_t i = threadIdx.x; i < n; i += 256) {
-    si += (double)in[i];
+    float v = in[i];
+    if (padding) v += a1 * u[i] + a2 * u[n + i] + a3 * u[2 * n + i] + a4 * u[3 * n + i];
+    si += (double)v;
     if (At) sr += (double)y[i];
   }
   si = block_sum_256(si, red) / (double)n;
   sr = block_sum_256(sr, red) / (double)n;
   for (int64_t i = threadIdx.x; i < n_pad; i += 256) {
     const bool ok = i < n;
-    Bt[f * n_pad + i] = ok ? (float)((double)in[i] - si) : 0.f;
+    float v = 0.f;
+    if (ok) {
+      v = in[i];
+      if (padding) v += a1 * u[i] + a2 * u[n + i] + a3 * u[2 * n + i] + a4 * u[3 * n + i];
+      v = (float)((double)v - si);
+    }
+    Bt[f * n_pad + i] = v;
     if (At) At[f * n_pad + i] = ok ? (float)((double)y[i] - sr) : 0.f;
   }
 }
