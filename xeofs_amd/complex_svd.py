@@ -179,7 +179,10 @@ def complex_rsvd(ctx, A, B, k: int, n_oversamples: int = 10, n_iter="auto", rand
 
     def export(P, rows):
         full = ops.export(P, rows, sg)
-        return (full[:, :k] + 1j * full[:, HALF:HALF + k]).astype(np.complex64)
+        out = np.empty((rows, k), dtype=np.complex64)      # no complex128 temporaries on 1M-row panels
+        out.real = full[:, :k]
+        out.imag = full[:, HALF:HALF + k]
+        return out
 
     return export(Up, n), s.astype(np.float32), export(Vp, p_loc)
 
