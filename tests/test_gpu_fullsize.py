@@ -1,0 +1,105 @@
+"""GPU tests at the BASELINE.json config sizes, through size-independent properties (the oracle
+cannot run at these sizes in seconds): orthonormality, X V = U diag(s), linearity, centring,
+bitwise determinism; plus the reference's own CPU-runnable config 1
+shape against the oracle and degenerate tiny shapes."""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import eof_oracle as orc  # noqa: E402
+
+
+def _device_field(n, nlat, nlon):
+    import torch
+
+    import bench
+
+    return bench.make_field(n, nlat, nlon, 0, nlat * nlon, torch.device("cuda:0"))
+
+
+@pytest.mark.parametrize("n,nlat,nlon,k", [(5000, 360, 720, 50), (10000, 720, 1440, 50)],
+                         ids=["config2_5000x259200", "config4_10000x1036800"])
+def test_eof_properties_at_baseline_sizes(ctx, n, nlat, nlon, k):
+    import torch
+
+    from xeofs_amd import engine
+
+    X = _device_field(n, nlat, nlon)
+    mat, st = engine.preprocess(ctx, X, want_stats=False)
+    assert (st["n"], st["p"]) == (n, nlat * nlon)
+    U, s, V = engine.rsvd(ctx, mat, k, random_state=5, device_out=True)
+    Ud, Vd = U.double(), V.double()
+    sd = torch.as_tensor(s.astype(np.float64), device=Ud.device)
+    eye = torch.eye(k, dtype=torch.float64, device=Ud.device)
+    assert float((Ud.T @ Ud - eye).abs().max()) < 1e-6
+    assert float((Vd.T @ Vd - eye).abs().max()) < 1e-6
+    assert np.all(np.diff(s) <= 0) and s[-1] > 0
+    # X V = U diag(s) through the projection kernel (one more pass over the matrix)
+    XV = torch.as_tensor(engine.project(ctx, mat, V), device=Ud.device).double()
+    assert float((XV - Ud * sd).norm() / (Ud * sd).norm()) < 1e-5
+    # explained variance cannot exceed the total variance (reference tests/models/single/test_eof.py:85-100)
+    assert (s.astype(np.float64) ** 2).sum() / (n - 1) <= st["total_variance"] * (1 + 1e-5)
+    # bitwise determinism under the seed (tests/linalg/test_decomposer.py:164-192)
+    U2, s2, V2 = engine.rsvd(ctx, mat, k, random_state=5, device_out=True)
+    assert np.array_equal(s, s2) and torch.equal(U, U2) and torch.equal(V, V2)
+    # the resident matrix is centred: projecting it on V gives zero-mean scores
+    assert float(XV.mean(dim=0).abs().max()) <= 1e-6 * float(sd[0])
+    mat.free()
+    # linearity: decomposing 2 X doubles the singular values and leaves the vectors
+    mat2, _ = engine.preprocess(ctx, X * 2.0, want_stats=False)
+    U3, s3, V3 = engine.rsvd(ctx, mat2, k, random_state=5, device_out=True)
+    assert np.allclose(s3, 2.0 * s, rtol=1e-6)
+    assert float((V3.double() - Vd).abs().max()) < 1e-5
+    mat2.free()
+    ctx.trim()
+
+
+def test_config1_shape_vs_oracle(ctx):
+    """BASELINE config 1: xe.single.EOF(n_modes=10) on the air_temperature shape 2920 x (25 x 53)
+    (synthetic stand-in of the same shape), use_coslat as in the README quickstart."""
+    import xeofs_amd as xe
+
+    n, nlat, nlon, k = 2920, 25, 53, 10
+    X, lat = orc.synthetic_field(n, nlat, nlon, rank=30, seed=0)
+    lat = np.linspace(75.0, 15.0, nlat)
+    da = xe.DataArray(X.reshape(n, nlat, nlon) + 270.0, dims=("time", "lat", "lon"),
+                      coords={"lat": lat, "lon": np.linspace(200, 330, nlon)}, name="air")
+    m = xe.single.EOF(n_modes=k, use_coslat=True, random_state=5).fit(da, "time")
+    w = np.repeat(orc.sqrt_cos_lat_weights(lat), nlon)
+    ref = orc.eof_fit((X + 270.0).astype(np.float64), k, feature_weights=w, random_state=5)
+    s = m.singular_values().values
+    assert np.all(np.abs(s - ref["norms"]) <= 1e-5 * ref["norms"])
+    assert np.allclose(m.explained_variance_ratio().values, ref["explained_variance_ratio"], rtol=3e-5)
+    c = m.components().values.reshape(k, -1)
+    for j in range(k):
+        assert abs(np.dot(c[j], ref["components"][:, j])) >= 1 - 1e-5, j
+
+
+@pytest.mark.parametrize("n,p,k", [(2, 3, 1), (3, 2, 2), (2, 2, 2), (5, 1, 1), (1, 4, 1)])
+def test_tiny_shapes(ctx, n, p, k):
+    from xeofs_amd import engine
+
+    X = np.random.default_rng(n * 10 + p).standard_normal((n, p)).astype(np.float32)
+    mat = engine.from_dense(ctx, X)
+    U, s, V = engine.rsvd(ctx, mat, k, random_state=0)
+    se = np.linalg.svd(X.astype(np.float64), compute_uv=False)[:k]
+    assert np.allclose(s, se, rtol=2e-5, atol=1e-6)
+    rec = (U * s) @ V.T
+    best = np.linalg.svd(X.astype(np.float64))
+    approx = (best[0][:, :k] * best[1][:k]) @ best[2][:k]
+    assert np.abs(rec - approx).max() <= 1e-4
+
+
+def test_all_nan_and_constant_inputs(ctx):
+    from xeofs_amd import engine
+
+    X = np.full((10, 6), np.nan, dtype=np.float32)
+    with pytest.raises(ValueError, match="no valid"):
+        engine.preprocess(ctx, X)
+    X = np.ones((10, 6), dtype=np.float32)           # constant field: zero matrix after centring
+    mat, st = engine.preprocess(ctx, X, True, True)   # std clipped at float32 eps (scaler.py:106-108)
+    assert not mat.download().any() and st["total_variance"] == 0.0
+    U, s, V = engine.rsvd(ctx, mat, 2, random_state=0)
+    assert np.all(s == 0) and np.isfinite(U).all() and np.isfinite(V).all()
