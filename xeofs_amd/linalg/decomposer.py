@@ -46,7 +46,9 @@ class Decomposer:
         self.solver_kwargs = dict(solver_kwargs)
         self.ctx = ctx
 
-    def fit(self, X, dims=("sample", "feature"), total_variance=None):
+    def fit(self, X, dims=("sample", "feature"), total_variance=None, omega=None):
+        """`omega`: optional pre-drawn sketch (engine.SketchFuture / ndarray) so the host-side sampling can
+        overlap the preprocessing kernels; it must be the matrix `sketch_matrix` would draw."""
         ctx = self.ctx or engine.default_context()
         mat = X if isinstance(X, engine.ResidentMatrix) else engine.from_dense(ctx, np.asarray(X))
         n, p = mat.shape
@@ -93,7 +95,13 @@ class Decomposer:
                     f"n_modes + n_oversamples = {k + n_over} > {MAX_SKETCH} is not supported by this build.")
         # the per-mode sign rule (xarray_utils.py:273-301) runs on the GPU; truncating modes afterwards
         # does not change the sign of the kept ones
-        U, s, V = engine.rsvd(ctx, mat, k, n_over, n_iter, random_state=self.random_state, flip=bool(self.flip_signs))
+        om = None
+        if omega is not None:
+            om = omega.result() if hasattr(omega, "result") else omega
+            if om.shape != (rank, k + n_over):
+                om = None      # drawn for another policy branch: fall back to drawing it now
+        U, s, V = engine.rsvd(ctx, mat, k, n_over, n_iter, random_state=self.random_state, flip=bool(self.flip_signs),
+                              omega=om)
         if self.is_based_on_variance:
             if total_variance is None:
                 raise ValueError("variance-based truncation needs the total variance of the input")

@@ -43,15 +43,35 @@ class EOF:
     def fit(self, X, dim, weights=None):
         self.ctx = self.ctx or engine.default_context()
         self.preprocessor.ctx = self.ctx
+        omega = self._sketch_ahead(X, dim)
         mat = self.preprocessor.fit_transform(X, dim, weights)      # fused HIP preprocess
         self.sample_dims = self.preprocessor.sample_dims
-        return self._fit_algorithm(mat)
+        return self._fit_algorithm(mat, omega)
 
-    def _fit_algorithm(self, mat):
+    def _sketch_ahead(self, X, dim):
+        """Start drawing the sketch (host, sklearn's RandomState stream) on a worker thread so it
+        overlaps the upload + preprocess kernels.  Only when the shape is knowable up front
+        (integer n_modes, integer seed, single array without NaN compaction changing min(n, p))."""
+        try:
+            rs, k = self._params["random_state"], self.n_modes
+            if not isinstance(k, (int, np.integer)) or not isinstance(rs, (int, np.integer)):
+                return None
+            vals, dims, _, _, _ = labelled.unpack(X)
+            sd = (dim,) if isinstance(dim, str) else tuple(dim)
+            n = int(np.prod([vals.shape[dims.index(d)] for d in sd]))
+            p = vals.size // max(n, 1)
+            if n >= p:      # the sketch lives on the feature side: its size depends on the NaN mask
+                return None
+            n_over = int(self._solver_kwargs.get("n_oversamples", 10))
+            return engine.SketchFuture(n, int(k) + n_over, int(rs))
+        except Exception:
+            return None
+
+    def _fit_algorithm(self, mat, omega=None):
         """xeofs/single/eof.py:85-118."""
         total_variance = self.preprocessor.total_variance                     # eof.py:93
         dec = Decomposer(ctx=self.ctx, **self._decomposer_kwargs)
-        dec.fit(mat, dims=(self.sample_name, self.feature_name), total_variance=total_variance)
+        dec.fit(mat, dims=(self.sample_name, self.feature_name), total_variance=total_variance, omega=omega)
         s = dec.s_.astype(np.float64)
         n_samples = mat.n
         self.data = dict(
