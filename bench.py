@@ -114,7 +114,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=10000)
+    ap.add_argument("--nsamples", dest="n", type=int, default=10000)
     ap.add_argument("--nlat", type=int, default=720)
     ap.add_argument("--nlon", type=int, default=1440)
     ap.add_argument("--modes", type=int, default=50)
@@ -123,6 +123,9 @@ def main():
     ap.add_argument("--force-sharded", action="store_true",
                     help="diagnostic: run the multi-GPU orchestration (panel-level ABI + RCCL collectives) even at "
                          "world size 1")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for "
+                    "functional tests of the multi-rank path on a single GPU together with --same-gpu)")
+    ap.add_argument("--same-gpu", action="store_true", help="functional test: all ranks share cuda:0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sample-parity", action="store_true",
                     help="also decompose the CPU-baseline sample on the GPU and compare singular values "
@@ -136,7 +139,7 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.same_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -147,7 +150,10 @@ def main():
     if world > 1 or args.force_sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
     if args.gpus != world:
         if rank == 0:
             print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)

@@ -381,69 +381,60 @@ __global__ __launch_bounds__(256) void f64_reduce_kernel(const double* __restric
 // tol * G[j][j] marks column j as linearly dependent: its Q column becomes exactly zero.
 // l <= 64.
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void chol_rinv_kernel(const double* __restrict__ G, int L, int l,
-                                                       double* __restrict__ Rinv, double tol) {
-  // One wavefront: barriers are free and every step is latency- not throughput-bound.
-  // R lives in the upper triangle of A; R^-1 (also upper triangular) is built into the unused
-  // strict lower triangle (Xi[r][c] -> A[c][r]) with its diagonal in xdiag.
-  __shared__ double A[64][65];
-  __shared__ double diag0[64];
-  __shared__ double xdiag[64];
-  __shared__ int dead[64];
-  const int tid = threadIdx.x;
-  for (int i = tid; i < 64 * 64; i += 64) {
-    const int r = i >> 6, c = i & 63;
-    A[r][c] = (r < l && c < l && c >= r) ? G[(int64_t)r * L + c] : 0.0;
+__device__ __forceinline__ double lane_bcast(double v, int lane) {  // `lane` is a constant after unrolling
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
+// One wavefront, everything in registers: lane c owns column c of the matrix (col[r] = A[r][c]) and
+// column c of R^-1 (x[r]); all loops are fully unrolled so register indices are constants and values
+// cross lanes with v_readlane (no LDS, no barriers).  Indices >= l are padded with the identity.
+__global__ __launch_bounds__(64, 1) void chol_rinv_kernel(const double* __restrict__ G, int L, int l,
+                                                          double* __restrict__ Rinv, double tol) {
+  const int c = threadIdx.x;
+  double col[64];
+#pragma unroll
+  for (int r = 0; r < 64; ++r) {
+    double v = (r == c) ? 1.0 : 0.0;
+    if (r <= c && c < l) v = G[(int64_t)r * L + c];
+    col[r] = v;
   }
-  __syncthreads();
-  diag0[tid] = A[tid][tid];
-  dead[tid] = 0;
-  __syncthreads();
-  for (int j = 0; j < l; ++j) {
-    // pivot (every lane computes it redundantly from LDS: no broadcast step needed)
-    const double d = A[j][j];
-    const bool dj = !(d > tol * diag0[j]) || !(diag0[j] > 0.0);
+  const double dorig = (c < l) ? G[(int64_t)c * L + c] : 1.0;
+  bool dead_c = false;
+#pragma unroll
+  for (int j = 0; j < 64; ++j) {
+    const double d = lane_bcast(col[j], j);       // A[j][j] after the updates of steps < j
+    const double d0 = lane_bcast(dorig, j);
+    const bool dj = !(d > tol * d0) || !(d0 > 0.0);  // numerically dependent column (uniform)
     const double rjj = dj ? 1.0 : sqrt(d);
     const double piv = dj ? 0.0 : 1.0 / rjj;
-    __syncthreads();
-    if (tid == 0) {
-      dead[j] = dj;
-      A[j][j] = rjj;
+    if (c == j) {
+      col[j] = rjj;
+      dead_c = dj;
+    } else if (c > j) {
+      col[j] *= piv;                               // R[j][c]
     }
-    const int c = tid;
-    double rjc = 0.0;
-    if (c > j && c < l) {
-      rjc = A[j][c] * piv;
-      A[j][c] = rjc;
-    }
-    __syncthreads();
-    // trailing update of column c: A[r][c] -= R[j][r] * R[j][c] for j < r <= c
-    if (c > j && c < l)
-      for (int r = j + 1; r <= c; ++r) A[r][c] -= A[j][r] * rjc;
-    __syncthreads();
-  }
-  // back substitution, one column per lane: R X = I
-  if (tid < l) {
-    const int c = tid;
-    if (!dead[c]) {
-      const double xd = 1.0 / A[c][c];
-      xdiag[c] = xd;
-      for (int r = c - 1; r >= 0; --r) {
-        double s = A[r][c] * xd;
-        for (int t = r + 1; t < c; ++t) s += A[r][t] * A[c][t];
-        A[c][r] = -s / A[r][r];
-      }
-    } else {
-      xdiag[c] = 0.0;
-      for (int r = 0; r < c; ++r) A[c][r] = 0.0;
+    const double rjc = (c > j) ? col[j] : 0.0;
+#pragma unroll
+    for (int r = j + 1; r < 64; ++r) {
+      const double rjr = lane_bcast(col[j], r);    // R[j][r] lives in lane r
+      col[r] -= rjr * rjc;                         // only rows r <= c are ever read later
     }
   }
-  __syncthreads();
-  for (int i = tid; i < L * L; i += 64) {
-    const int r = i / L, c = i % L;
-    double v = 0.0;
-    if (r < l && c < l) v = (r == c) ? xdiag[c] : (r < c ? A[c][r] : 0.0);
-    Rinv[i] = v;
+  // back substitution for column c of X = R^-1 (R X = I), bottom row first; x[r] = 0 for r > c falls out
+  double x[64];
+#pragma unroll
+  for (int r = 63; r >= 0; --r) {
+    double s = 0.0;
+#pragma unroll
+    for (int t = r + 1; t < 64; ++t) s += lane_bcast(col[r], t) * x[t];   // R[r][t] lives in lane t
+    const double rrr = lane_bcast(col[r], r);
+    x[r] = (((r == c) ? 1.0 : 0.0) - s) / rrr;
+  }
+#pragma unroll
+  for (int r = 0; r < 64; ++r) {
+    if (r < L && c < L) Rinv[(int64_t)r * L + c] = (r < l && c < l && !dead_c) ? x[r] : 0.0;
   }
 }
 
