@@ -73,8 +73,9 @@ int eofx_ctx_trim(eofx_ctx *ctx);
  *   EOFX_PREC_F32     exact-f32 MFMA (v_mfma_f32_32x32x2_f32), bitwise an fmaf chain
  *   EOFX_PREC_BF16X3  operands split into 2 bf16 terms, 3 cross products  (~2^-16 per product)
  *   EOFX_PREC_BF16X6  operands split into 3 bf16 terms, 6 cross products  (~2^-23, f32 class)
- * power_passes applies to the 2*n_iter power-iteration products (they only have to find the
- * subspace), final_passes to the range basis A Z, the projection A^T Q and eofx_project.
+ * power_passes applies to the 2*n_iter power-iteration products and the range-basis product A Z
+ * (they only have to find a subspace), final_passes to the projection A^T Q, which decides the
+ * singular values, and to eofx_project.
  * Default: (BF16X3, BF16X6) -- singular values within 1e-6 of the float64 oracle. */
 #define EOFX_PREC_F32 0
 #define EOFX_PREC_BF16X3 1

@@ -145,7 +145,7 @@ def complex_rsvd(ctx, A, B, k: int, n_oversamples: int = 10, n_iter="auto", rand
     Z = ops.import_panel(host, small)
     for _ in range(int(n_iter)):
         Z = orth(bwd(fwd(Z)), small)
-    Q = orth(orth(fwd(Z, True), tall), tall)
+    Q = orth(orth(fwd(Z), tall), tall)                  # range basis: a subspace only, power-pass precision
     Bt = bwd(Q, True)                                   # = B^H with B = Q^H A_op
     w, Uh = np.linalg.eigh(gram(Bt, small))             # B B^H = Uh diag(w) Uh^H
     order = np.argsort(w)[::-1][:k]

@@ -1092,7 +1092,9 @@ static int rsvd_core(eofx_ctx* ctx, const LinOp& op, int k, int l, int n_iter, c
     CHK(launch_cholqr(ctx, Ws, op.small_pad, L, l, G, Zs));
   }
   // range basis on the tall side: Q = orth(A Z), CholeskyQR2
-  CHK(op.fwd(Zs, Yt, L, pf));
+  // the range-basis pass only fixes a subspace (Q is re-orthonormalised): power-pass precision is
+  // enough; the projection B^T = A^T Q below decides the singular values and uses the final one
+  CHK(op.fwd(Zs, Yt, L, pp));
   CHK(launch_gram(ctx, Yt, op.tall_pad, L, G));
   CHK(launch_cholqr(ctx, Yt, op.tall_pad, L, l, G, Qt));
   CHK(launch_gram(ctx, Qt, op.tall_pad, L, G));

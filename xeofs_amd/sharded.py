@@ -144,7 +144,7 @@ def sharded_rsvd(ops, comm: Comm, k: int, p_total: int, p_offset: int, n_oversam
         Yt = to_side(Z, tall)
         W = to_side(Yt, small)
         Z = ops.cholqr(W, l, gram(W, small))
-    Yt = to_side(Z, tall, True)
+    Yt = to_side(Z, tall)                        # range basis: a subspace only, power-pass precision
     Q = ops.cholqr(Yt, l, gram(Yt, tall))
     Q = ops.cholqr(Q, l, gram(Q, tall))          # CholeskyQR2
     Bt = to_side(Q, small, True)
