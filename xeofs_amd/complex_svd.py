@@ -111,7 +111,10 @@ def complex_rsvd(ctx, A, B, k: int, n_oversamples: int = 10, n_iter="auto", rand
                                   f"(n_modes + n_oversamples <= {HALF})")
     if n_iter == "auto" or n_iter is None:
         n_iter = 7 if k < 0.1 * r else 4
-    omega = engine.sketch_matrix(r, k + n_oversamples, random_state)[:, :l]   # real Gaussian start
+    if l == r:      # full-width sketch spans everything: identity, not an ill-conditioned square Gaussian
+        omega = np.eye(r, dtype=np.float32)
+    else:
+        omega = engine.sketch_matrix(r, k + n_oversamples, random_state)[:, :l]   # real Gaussian start
     transposed = n < p      # A_op = Z^H: tall side = features (sharded), small side = samples
 
     def to_feature(P, f=False):

@@ -1193,10 +1193,16 @@ extern "C" int eofx_rsvd_f32(eofx_ctx* ctx, const eofx_mat* m, int k, int n_over
   }
   CHK(arena_reserve(ctx, rsvd_scratch_bytes(op.tall_pad, op.small_pad, l, k)));
   ArenaScope scope(ctx);
-  // omega arrives as (small x l_req); when l was clamped only its first l columns are used
+  // omega arrives as (small x l_req).  A sketch as wide as the rank spans everything, so the identity
+  // is used instead of the Gaussian draw: a square Gaussian matrix is occasionally ill conditioned
+  // (cond ~ 1e3..1e4) and a single pass would amplify its rounding error by that factor.
   std::vector<float> om_clamped;
   const float* om = omega;
-  if (l != l_req) {
+  if (l == r) {
+    om_clamped.assign((size_t)op.small * l, 0.f);
+    for (int64_t i = 0; i < l; ++i) om_clamped[(size_t)i * l + i] = 1.f;
+    om = om_clamped.data();
+  } else if (l != l_req) {
     if (is_device_ptr(omega)) return set_err(ctx, EOFX_ERR_ARG, "omega must be a host pointer");
     om_clamped.resize((size_t)op.small * l);
     for (int64_t i = 0; i < op.small; ++i)
@@ -1302,6 +1308,12 @@ extern "C" int eofx_crosscov_rsvd_f32(eofx_ctx* ctx, const eofx_mat* x, const eo
     op = {p2, p1, y->p_pad, x->p_pad, Ct_mul, C_mul};  // A = C^T (p2 x p1)
   else
     op = {p1, p2, x->p_pad, y->p_pad, C_mul, Ct_mul};  // A = C   (p1 x p2)
+  std::vector<float> om_eye;
+  if (l == r) {   // full-width sketch: identity (see eofx_rsvd_f32)
+    om_eye.assign((size_t)op.small * l, 0.f);
+    for (int64_t i = 0; i < l; ++i) om_eye[(size_t)i * l + i] = 1.f;
+    omega = om_eye.data();
+  }
   RsvdOut ro;
   CHK(rsvd_core(ctx, op, k, l, n_iter, omega, ro));
   const float* Q1p = transposed ? ro.Svec : ro.Tvec;  // left vectors of C  (p1)

@@ -119,6 +119,8 @@ def sharded_rsvd(ops, comm: Comm, k: int, p_total: int, p_offset: int, n_oversam
     if omega is None:
         omega = sketch_matrix(r, l_req, random_state)
     omega = np.ascontiguousarray(omega[:, :l], dtype=np.float32)
+    if l == r:      # full-width sketch spans everything: identity instead of an (ill-conditioned) square Gaussian
+        omega = np.eye(r, dtype=np.float32)
     transposed = n < p_total   # A = X^T: tall side = features (sharded), small side = samples
 
     # side bookkeeping: "n" panels are replicated, "p" panels are sharded by rows
