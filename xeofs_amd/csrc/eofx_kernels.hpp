@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256, 2) void atb_f32_kernel(const float* __restrict
     if (b_loader) bn = *reinterpret_cast<const f32x4*>(Bp + (int64_t)(chunk) * ATB_KC * ldb);   \
     const float* pa_ = Ap + (int64_t)(chunk) * ATB_KC * lda;                                     \
     _Pragma("unroll") for (int i = 0; i < 8; ++i) areg[i] =                                      \
-        *reinterpret_cast<const f32x4*>(pa_ + (int64_t)(2 * i) * lda);                           \
+        __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(pa_ + (int64_t)(2 * i) * lda)); \
   } while (0)
 #define EOFX_COMPUTE_SLAB(areg, buf)                                                             \
   do {                                                                                           \
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void atb_bf16_kernel(const float* __restric
     if (b_loader) bn = *reinterpret_cast<const f32x4*>(Bp + (int64_t)(chunk) * ATB_KC * ldb);   \
     const float* pa_ = Ap + (int64_t)(chunk) * ATB_KC * lda;                                     \
     _Pragma("unroll") for (int i = 0; i < 8; ++i) areg[i] =                                      \
-        *reinterpret_cast<const f32x4*>(pa_ + (int64_t)(2 * i) * lda);                           \
+        __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(pa_ + (int64_t)(2 * i) * lda)); \
   } while (0)
   // B slab -> LDS, split into bf16 parts, stored fragment-ready: row r = 2t + kh
 #define EOFX_STORE_B(buf)                                                                        \
@@ -585,7 +585,7 @@ __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__
   for (; r + 8 <= r1; r += 8) {
     float v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)u * P];
+    for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(p + (int64_t)u * P);
     p += 8 * P;
 #pragma unroll
     for (int u = 0; u < 8; ++u)
@@ -708,7 +708,7 @@ __global__ __launch_bounds__(256) void apply_kernel(const float* __restrict__ X,
       const float* src = X + sr * ldx_src;
       f32x4 x = {0.f, 0.f, 0.f, 0.f};
       if (VEC && cb + 3 < p) {
-        x = *reinterpret_cast<const f32x4*>(src + cb);
+        x = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + cb));
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
