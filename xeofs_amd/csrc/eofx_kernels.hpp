@@ -402,16 +402,23 @@ __global__ __launch_bounds__(64, 1) void chol_rinv_kernel(const double* __restri
   }
   const double dorig = (c < l) ? G[(int64_t)c * L + c] : 1.0;
   bool dead_c = false;
+  double mypiv = 0.0;                              // 1 / R[c][c], kept by lane c
 #pragma unroll
   for (int j = 0; j < 64; ++j) {
     const double d = lane_bcast(col[j], j);       // A[j][j] after the updates of steps < j
     const double d0 = lane_bcast(dorig, j);
     const bool dj = !(d > tol * d0) || !(d0 > 0.0);  // numerically dependent column (uniform)
-    const double rjj = dj ? 1.0 : sqrt(d);
-    const double piv = dj ? 0.0 : 1.0 / rjj;
+    // 1/sqrt(d): hardware estimate + two Newton steps (full float64), no sqrt/div sequences on the
+    // critical path of the column recurrence
+    double piv = __builtin_amdgcn_rsq(dj ? 1.0 : d);
+    piv = piv * (1.5 - 0.5 * d * piv * piv);
+    piv = piv * (1.5 - 0.5 * d * piv * piv);
+    if (dj) piv = 0.0;
+    const double rjj = dj ? 1.0 : d * piv;
     if (c == j) {
       col[j] = rjj;
       dead_c = dj;
+      mypiv = dj ? 1.0 : piv;
     } else if (c > j) {
       col[j] *= piv;                               // R[j][c]
     }
@@ -429,8 +436,7 @@ __global__ __launch_bounds__(64, 1) void chol_rinv_kernel(const double* __restri
     double s = 0.0;
 #pragma unroll
     for (int t = r + 1; t < 64; ++t) s += lane_bcast(col[r], t) * x[t];   // R[r][t] lives in lane t
-    const double rrr = lane_bcast(col[r], r);
-    x[r] = (((r == c) ? 1.0 : 0.0) - s) / rrr;
+    x[r] = (((r == c) ? 1.0 : 0.0) - s) * lane_bcast(mypiv, r);           // * 1/R[r][r]
   }
 #pragma unroll
   for (int r = 0; r < 64; ++r) {
