@@ -118,8 +118,9 @@ def main():
     ap.add_argument("--nlat", type=int, default=720)
     ap.add_argument("--nlon", type=int, default=1440)
     ap.add_argument("--modes", type=int, default=50)
-    ap.add_argument("--precision", choices=["mixed", "f32", "bf16x3"], default="mixed",
-                    help="mixed = bf16x3 power passes + bf16x6 final passes (default); f32 = exact-f32 MFMA")
+    ap.add_argument("--precision", choices=["f16x3", "f32", "bf16"], default="f16x3",
+                    help="f16x3 = scaled split-fp16 MFMA on every pass (default); bf16 = bf16x3 power passes + bf16x6 "
+                         "projection pass; f32 = exact-f32 MFMA")
     ap.add_argument("--force-sharded", action="store_true",
                     help="diagnostic: run the multi-GPU orchestration (panel-level ABI + RCCL collectives) even at "
                          "world size 1")
@@ -162,7 +163,7 @@ def main():
     P = args.nlat * args.nlon
     lo, hi = sharded.shard_bounds(P, world, rank)
     ctx = engine.Context(local_rank)
-    ctx.set_precision(*{"mixed": ("bf16x3", "bf16x6"), "f32": ("f32", "f32"), "bf16x3": ("bf16x3", "bf16x3")}[args.precision])
+    ctx.set_precision(*{"f16x3": ("f16x3", "f16x3"), "f32": ("f32", "f32"), "bf16": ("bf16x3", "bf16x6")}[args.precision])
     comm = sharded.Comm(force=args.force_sharded)
 
     t0 = time.perf_counter()
@@ -265,8 +266,10 @@ def main():
         }
     else:
         roofline = {
-            "kernel": "atb_bf16_kernel<2,PARTS> (C = A^T B, split-bf16 MFMA 32x32x16: 15 launches bf16x3 + "
-                      "1 launch bf16x6 per fit; mean over all 16)",
+            "kernel": ("atb_f16_kernel<2> (C = A^T B, scaled split-fp16 MFMA 32x32x16, all 16 passes)"
+                       if args.precision == "f16x3" else
+                       "atb_bf16_kernel<2,PARTS> (C = A^T B, split-bf16 MFMA 32x32x16: 15 launches bf16x3 + 1 launch "
+                       "bf16x6 per fit; mean over all 16)"),
             "bound": "hbm", "achieved": round(achieved_gbps, 1), "peak": PEAK_HBM_GBPS,
             "unit": "GB/s", "frac": round(achieved_gbps / PEAK_HBM_GBPS, 4),
         }
@@ -313,7 +316,8 @@ def main():
             "value": round(alg_bytes / (ms_step * 1e-3) / 1e9, 2), "unit": "GB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32" if args.precision == "f32" else "f32 data, split-bf16 MFMA (" + "+".join(ctx.precision) + "), f32 accumulate",
+            "dtype": "f32" if args.precision == "f32" else "f32 data, split-" + ("fp16" if args.precision == "f16x3" else "bf16")
+                     + " MFMA (" + "+".join(ctx.precision) + "), f32 accumulate",
             "data": "synthetic",
             "config": {"workload": f"xe.single.EOF n_modes={k} on synthetic fp32 {n}x({args.nlat}x{args.nlon}), "
                                    f"feature axis sharded over {world} GPU(s), n_iter={n_iter}, n_oversamples=10, "

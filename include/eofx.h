@@ -76,10 +76,13 @@ int eofx_ctx_trim(eofx_ctx *ctx);
  * power_passes applies to the 2*n_iter power-iteration products and the range-basis product A Z
  * (they only have to find a subspace), final_passes to the projection A^T Q, which decides the
  * singular values, and to eofx_project.
- * Default: (BF16X3, BF16X6) -- singular values within 1e-6 of the float64 oracle. */
+ * Default: (F16X3, F16X3) -- every pass HBM-bound, f32-class accuracy (singular values within 1e-6
+ * of the float64 oracle on converged modes, like the exact-f32 kernel). */
 #define EOFX_PREC_F32 0
 #define EOFX_PREC_BF16X3 1
 #define EOFX_PREC_BF16X6 2
+#define EOFX_PREC_F16X3 3 /* operands scaled by exact powers of two and split into 2 fp16 terms (11+11
+                            bits), 3 cross products: ~2^-22 per product at the cost of BF16X3 */
 int eofx_ctx_set_precision(eofx_ctx *ctx, int power_passes, int final_passes);
 int eofx_ctx_profile(eofx_ctx *ctx, int enable);
 int eofx_ctx_profile_read(eofx_ctx *ctx, int64_t *launches, double *total_ms, double *flops,

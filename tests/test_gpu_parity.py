@@ -42,7 +42,7 @@ def _cos_tol(s, j):
 
 
 # --------------------------------------------------------------------------- kernels
-@pytest.mark.parametrize("prec,tol", [("f32", 1e-5), ("bf16x6", 1e-5), ("bf16x3", 4e-5)])
+@pytest.mark.parametrize("prec,tol", [("f32", 1e-5), ("bf16x6", 1e-5), ("f16x3", 1e-5), ("bf16x3", 4e-5)])
 @pytest.mark.parametrize("n,p,L", [(100, 700, 32), (300, 1500, 64), (1000, 520, 64), (64, 3000, 96)])
 def test_panel_tmul_mul(ctx, n, p, L, prec, tol):
     import torch
@@ -194,11 +194,12 @@ def _check_svd(U, s, V, Uo, so, Vo, X64, k):
     assert np.abs(V.astype(np.float64).T @ V - np.eye(k)).max() < 2e-5
 
 
-@pytest.fixture(params=[("bf16x3", "bf16x6"), ("f32", "f32"), ("bf16x3", "bf16x3")], ids=["mixed", "f32", "x3"])
+@pytest.fixture(params=[("f16x3", "f16x3"), ("f32", "f32"), ("bf16x3", "bf16x6"), ("bf16x3", "bf16x3")],
+                ids=["f16x3", "f32", "bf16mixed", "bf16x3"])
 def precision(request, ctx):
     ctx.set_precision(*request.param)
     yield request.param
-    ctx.set_precision("bf16x3", "bf16x6")
+    ctx.set_precision("f16x3", "f16x3")
 
 
 @pytest.mark.parametrize("n,p,k", [(512, 2048, 10), (300, 4000, 40), (2500, 700, 20), (600, 600, 5),

@@ -63,7 +63,7 @@ SIGNATURES = {
     "eofx_host_eigh_f64": (_int, [_vp, _int, _vp, _vp]),
 }
 
-PREC = {"f32": 0, "bf16x3": 1, "bf16x6": 2}
+PREC = {"f32": 0, "bf16x3": 1, "bf16x6": 2, "f16x3": 3}
 
 _lib = None
 

@@ -30,8 +30,8 @@ struct eofx_ctx {
   size_t arena_off = 0;
   std::string err;
   // arithmetic of the matrix passes (EOFX_PREC_*): power iterations / final basis+projection
-  int prec_power = EOFX_PREC_BF16X3;
-  int prec_final = EOFX_PREC_BF16X6;
+  int prec_power = EOFX_PREC_F16X3;
+  int prec_final = EOFX_PREC_F16X3;
   // released resident-matrix buffers, kept for reuse: hipMalloc/hipFree of tens of GB cost
   // ~1 s, far more than a fit.  Bounded by pool_cap bytes; eofx_ctx_trim() empties it.
   std::vector<std::pair<void*, size_t>> pool;
@@ -59,6 +59,8 @@ struct eofx_mat {
   int64_t n = 0, p = 0, n_pad = 0, p_pad = 0;
   float* X = nullptr;   // [n_pad x p_pad]
   float* Xt = nullptr;  // [p_pad x n_pad]
+  unsigned* absmax_dev = nullptr;  // float bits of max |x| (device scalar, for the fp16-split scaling)
+  float absmax = 0.f;              // host copy, valid once the matrix is built
 };
 
 static int set_err(eofx_ctx* ctx, int code, const char* fmt, ...) {
@@ -382,8 +384,11 @@ static size_t atb_scratch_bytes(int64_t M, int64_t K, int L) {
 template <int NB>
 static void launch_atb_variant(int prec, dim3 grid, hipStream_t st, const float* A, int64_t lda,
                                const float* B, int ldb, float* out, int L, int64_t M, int64_t K,
-                               int64_t kps, int col_base) {
-  if (prec == EOFX_PREC_BF16X3)
+                               int64_t kps, int col_base, float a_scale, const float* b_absmax) {
+  if (prec == EOFX_PREC_F16X3)
+    hipLaunchKernelGGL(atb_f16_kernel<NB>, grid, dim3(256), 0, st, A, lda, B, ldb, out, L, M, K, kps, col_base,
+                       a_scale, b_absmax);
+  else if (prec == EOFX_PREC_BF16X3)
     hipLaunchKernelGGL((atb_bf16_kernel<NB, 2>), grid, dim3(256), 0, st, A, lda, B, ldb, out, L, M, K, kps, col_base);
   else if (prec == EOFX_PREC_BF16X6)
     hipLaunchKernelGGL((atb_bf16_kernel<NB, 3>), grid, dim3(256), 0, st, A, lda, B, ldb, out, L, M, K, kps, col_base);
@@ -391,8 +396,11 @@ static void launch_atb_variant(int prec, dim3 grid, hipStream_t st, const float*
     hipLaunchKernelGGL(atb_f32_kernel<NB>, grid, dim3(256), 0, st, A, lda, B, ldb, out, L, M, K, kps, col_base);
 }
 
+// a_absmax: max |a| over A (host); b_absmax_dev: device scalar with max |b| (nullptr: measured here).
+// Both are only used by the fp16-split variant.
 static int launch_atb(eofx_ctx* ctx, const float* A, int64_t lda, int64_t K, int64_t M,
-                      const float* B, int ldb, int L, float* C, int prec = EOFX_PREC_F32) {
+                      const float* B, int ldb, int L, float* C, int prec = EOFX_PREC_F32,
+                      float a_absmax = 0.f, const float* b_absmax_dev = nullptr) {
   if (M % ATB_BM || K % ATB_KG || L % 32 || L <= 0)
     return set_err(ctx, EOFX_ERR_ARG, "atb: bad geometry M=%lld K=%lld L=%d", (long long)M,
                    (long long)K, L);
@@ -411,6 +419,24 @@ static int launch_atb(eofx_ctx* ctx, const float* A, int64_t lda, int64_t K, int
       out = C;
     }
   }
+  float a_scale = 1.f;
+  if (prec == EOFX_PREC_F16X3) {
+    if (a_absmax > 0.f && std::isfinite(a_absmax)) {
+      int e;
+      (void)std::frexp(a_absmax, &e);
+      a_scale = std::ldexp(1.f, 14 - e);
+    }
+    if (!b_absmax_dev) {
+      unsigned* bm = arena_alloc<unsigned>(ctx, 1);
+      if (!bm) return set_err(ctx, EOFX_ERR_NOMEM, "arena exhausted (panel max)");
+      HIPCHK(hipMemsetAsync(bm, 0, sizeof(unsigned), ctx->stream));
+      const int64_t total4 = K * (L / 4);
+      hipLaunchKernelGGL(panel_absmax_kernel, dim3((int)std::max<int64_t>(1, std::min<int64_t>((total4 + 255) / 256, 2048))),
+                         dim3(256), 0, ctx->stream, B, K, L, (int64_t)ldb, bm);
+      KCHK();
+      b_absmax_dev = reinterpret_cast<const float*>(bm);
+    }
+  }
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (ctx->profile) {
     HIPCHK(hipEventCreate(&ev0));
@@ -419,12 +445,12 @@ static int launch_atb(eofx_ctx* ctx, const float* A, int64_t lda, int64_t K, int
   }
   if (nfull > 0) {
     dim3 grid(bx, best_s, nfull);
-    launch_atb_variant<2>(prec, grid, ctx->stream, A, lda, B, ldb, out, L, M, K, best_kps, 0);
+    launch_atb_variant<2>(prec, grid, ctx->stream, A, lda, B, ldb, out, L, M, K, best_kps, 0, a_scale, b_absmax_dev);
     KCHK();
   }
   if (rem) {
     dim3 grid(bx, best_s, 1);
-    launch_atb_variant<1>(prec, grid, ctx->stream, A, lda, B, ldb, out, L, M, K, best_kps, nfull * 64);
+    launch_atb_variant<1>(prec, grid, ctx->stream, A, lda, B, ldb, out, L, M, K, best_kps, nfull * 64, a_scale, b_absmax_dev);
     KCHK();
   }
   if (ctx->profile) {
@@ -648,8 +674,11 @@ static int mat_alloc(eofx_ctx* ctx, int64_t n, int64_t p, eofx_mat** out) {
   const size_t bytes = (size_t)m->n_pad * m->p_pad * sizeof(float);
   hipError_t e = pool_malloc(ctx, (void**)&m->X, bytes);
   if (e == hipSuccess) e = pool_malloc(ctx, (void**)&m->Xt, bytes);
+  if (e == hipSuccess) e = pool_malloc(ctx, (void**)&m->absmax_dev, 256);
+  if (e == hipSuccess) e = hipMemsetAsync(m->absmax_dev, 0, 256, ctx->stream);
   if (e != hipSuccess) {
     if (m->X) (void)hipFree(m->X);
+    if (m->Xt) (void)hipFree(m->Xt);
     delete m;
     (void)hipGetLastError();
     return set_err(ctx, EOFX_ERR_NOMEM, "cannot allocate resident matrix %lld x %lld (2 x %.2f GB): %s",
@@ -667,6 +696,7 @@ extern "C" int eofx_mat_destroy(eofx_ctx* ctx, eofx_mat* m) {
     // same-stream reuse is ordered; nothing else touches these buffers
     pool_give(ctx, m->X, bytes);
     pool_give(ctx, m->Xt, bytes);
+    pool_give(ctx, m->absmax_dev, 256);
   } else {
     if (m->X) (void)hipFree(m->X);
     if (m->Xt) (void)hipFree(m->Xt);
@@ -702,18 +732,30 @@ static int stage_input(eofx_ctx* ctx, const float* X, size_t count, Staged& st) 
   return EOFX_OK;
 }
 
+// absmax_src: device scalar holding max |transformed value| when the column statistics already know it
+// (preprocess path); nullptr -> measured with one extra read of the written matrix.
 static int launch_apply(eofx_ctx* ctx, const float* Xsrc, int64_t ld_src, const int64_t* row_map,
                         const int64_t* col_map, const double* shift, const double* scale, eofx_mat* m,
-                        int* nan_flag) {
+                        int* nan_flag, const unsigned* absmax_src = nullptr) {
   dim3 grid((int)(m->p_pad / 64), (int)(m->n_pad / 64));
   const bool vec = !col_map && (ld_src % 4 == 0) && ((uintptr_t)Xsrc % 16 == 0);
   if (vec)
     hipLaunchKernelGGL(apply_kernel<true>, grid, dim3(256), 0, ctx->stream, Xsrc, ld_src, row_map, col_map,
-                       shift, scale, m->n, m->p, m->X, m->p_pad, m->Xt, m->n_pad, nan_flag);
+                       shift, scale, m->n, m->p, m->X, m->p_pad, m->Xt, m->n_pad, nan_flag, m->absmax_dev);
   else
     hipLaunchKernelGGL(apply_kernel<false>, grid, dim3(256), 0, ctx->stream, Xsrc, ld_src, row_map, col_map,
-                       shift, scale, m->n, m->p, m->X, m->p_pad, m->Xt, m->n_pad, nan_flag);
+                       shift, scale, m->n, m->p, m->X, m->p_pad, m->Xt, m->n_pad, nan_flag, m->absmax_dev);
   KCHK();
+  if (absmax_src) {
+    HIPCHK(hipMemcpyAsync(m->absmax_dev, absmax_src, sizeof(unsigned), hipMemcpyDeviceToDevice, ctx->stream));
+  } else {
+    const int64_t total4 = m->n_pad * (m->p_pad / 4);
+    hipLaunchKernelGGL(panel_absmax_kernel, dim3((int)std::min<int64_t>((total4 + 255) / 256, 2048)), dim3(256), 0,
+                       ctx->stream, m->X, m->n_pad, (int)m->p_pad, m->p_pad, m->absmax_dev);
+    KCHK();
+  }
+  // host copy of max |x| (callers synchronise the stream before using the matrix)
+  HIPCHK(hipMemcpyAsync(&m->absmax, m->absmax_dev, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   return EOFX_OK;
 }
 
@@ -763,6 +805,7 @@ extern "C" int eofx_mat_download_f32(eofx_ctx* ctx, const eofx_mat* m, float* ds
 struct PreState {  // device arrays of length P
   int* cnt;
   double *mean, *stdv, *shift, *scale, *m2;
+  unsigned* absmax;  // device scalar: max |transformed value| (float bits)
 };
 
 static int run_colstats(eofx_ctx* ctx, const float* Xd, int64_t n, int64_t P, int center, int standardize,
@@ -776,12 +819,15 @@ static int run_colstats(eofx_ctx* ctx, const float* Xd, int64_t n, int64_t P, in
   ARENA(int, cnt_p, (size_t)RS * P);
   ARENA(double, sum_p, (size_t)RS * P);
   ARENA(double, sq_p, (size_t)RS * P);
+  ARENA(float, mn_p, (size_t)RS * P);
+  ARENA(float, mx_p, (size_t)RS * P);
   hipLaunchKernelGGL(colstats_kernel, dim3(gx, (int)RS), dim3(256), 0, ctx->stream, Xd, n, P, rps, cnt_p,
-                     sum_p, sq_p);
+                     sum_p, sq_p, mn_p, mx_p);
   KCHK();
-  hipLaunchKernelGGL(colstats_finalize_kernel, dim3(gx), dim3(256), 0, ctx->stream, cnt_p, sum_p, sq_p,
+  HIPCHK(hipMemsetAsync(ps.absmax, 0, sizeof(unsigned), ctx->stream));
+  hipLaunchKernelGGL(colstats_finalize_kernel, dim3(gx), dim3(256), 0, ctx->stream, cnt_p, sum_p, sq_p, mn_p, mx_p,
                      (int)RS, P, center, standardize, w_dev, (double)1.1920928955078125e-07, ps.cnt,
-                     ps.mean, ps.stdv, ps.shift, ps.scale, ps.m2);
+                     ps.mean, ps.stdv, ps.shift, ps.scale, ps.m2, ps.absmax);
   KCHK();
   return EOFX_OK;
 }
@@ -790,12 +836,12 @@ static size_t colstats_scratch(int64_t n, int64_t P) {
   const int64_t gx = (P + 255) / 256;
   int64_t RS = std::max<int64_t>(1, (2048 + gx - 1) / gx);
   RS = std::min<int64_t>(RS, std::max<int64_t>(1, n / 64));
-  return (size_t)(RS + 1) * P * 24 + (size_t)P * 64 + (size_t)n * 16 + (1 << 20);
+  return (size_t)(RS + 1) * P * 32 + (size_t)P * 64 + (size_t)n * 16 + (1 << 20);
 }
 
 // shared tail of preprocess/apply: NaN policy, maps, allocation, apply kernel
 static int sanitize_and_apply(eofx_ctx* ctx, const float* Xd, int64_t n, int64_t P, PreState& ps,
-                              const uint8_t* expect_valid, int check_nans, eofx_mat** out,
+                              bool stats_absmax, const uint8_t* expect_valid, int check_nans, eofx_mat** out,
                               uint8_t* valid_feature, uint8_t* valid_sample, int64_t* n_out,
                               int64_t* p_out, std::vector<int>& hcnt) {
   hcnt.resize(P);
@@ -873,7 +919,8 @@ static int sanitize_and_apply(eofx_ctx* ctx, const float* Xd, int64_t n, int64_t
     }
     if (!flag || (pv < P && !dcol) || (ns < n && !drow)) rc = set_err(ctx, EOFX_ERR_NOMEM, "arena exhausted (maps)");
     if (rc == EOFX_OK && hipMemsetAsync(flag, 0, sizeof(int), ctx->stream) != hipSuccess) rc = EOFX_ERR_HIP;
-    if (rc == EOFX_OK) rc = launch_apply(ctx, Xd, P, drow, dcol, ps.shift, ps.scale, m, flag);
+    if (rc == EOFX_OK)
+      rc = launch_apply(ctx, Xd, P, drow, dcol, ps.shift, ps.scale, m, flag, stats_absmax ? ps.absmax : nullptr);
     if (rc == EOFX_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = EOFX_ERR_HIP;
   }
   if (rc != EOFX_OK) {
@@ -903,7 +950,8 @@ extern "C" int eofx_preprocess_f32(eofx_ctx* ctx, const float* X, int64_t n, int
   ARENA(double, dshift, P);
   ARENA(double, dscale, P);
   ARENA(double, dm2, P);
-  ps = {cnt, dmean, dstd, dshift, dscale, dm2};
+  ARENA(unsigned, dabsmax, 1);
+  ps = {cnt, dmean, dstd, dshift, dscale, dm2, dabsmax};
   double* wdev = nullptr;
   if (feat_weights) {
     wdev = arena_alloc<double>(ctx, P);
@@ -913,7 +961,7 @@ extern "C" int eofx_preprocess_f32(eofx_ctx* ctx, const float* X, int64_t n, int
   CHK(run_colstats(ctx, st.dev, n, P, center, standardize, wdev, ps));
   std::vector<int> hcnt;
   int64_t ns = 0, pv = 0;
-  CHK(sanitize_and_apply(ctx, st.dev, n, P, ps, nullptr, check_nans, out, valid_feature, valid_sample, &ns,
+  CHK(sanitize_and_apply(ctx, st.dev, n, P, ps, true, nullptr, check_nans, out, valid_feature, valid_sample, &ns,
                          &pv, hcnt));
   if (n_out) *n_out = ns;
   if (p_out) *p_out = pv;
@@ -949,7 +997,8 @@ extern "C" int eofx_apply_f32(eofx_ctx* ctx, const float* X, int64_t n, int64_t 
   ARENA(double, dshift, P);
   ARENA(double, dscale, P);
   ARENA(double, dm2, P);
-  ps = {cnt, dmean, dstd, dshift, dscale, dm2};
+  ARENA(unsigned, dabsmax, 1);
+  ps = {cnt, dmean, dstd, dshift, dscale, dm2, dabsmax};
   CHK(run_colstats(ctx, st.dev, n, P, 0, 0, nullptr, ps));
   // overwrite shift/scale with the fitted state
   std::vector<double> hshift(P, 0.0), hscale(P, 1.0);
@@ -967,7 +1016,7 @@ extern "C" int eofx_apply_f32(eofx_ctx* ctx, const float* X, int64_t n, int64_t 
   HIPCHK(hipStreamSynchronize(ctx->stream));
   std::vector<int> hcnt;
   int64_t ns = 0, pv = 0;
-  CHK(sanitize_and_apply(ctx, st.dev, n, P, ps, valid_feature, check_nans, out, nullptr, valid_sample, &ns,
+  CHK(sanitize_and_apply(ctx, st.dev, n, P, ps, false, valid_feature, check_nans, out, nullptr, valid_sample, &ns,
                          &pv, hcnt));
   if (n_out) *n_out = ns;
   return EOFX_OK;
@@ -977,12 +1026,14 @@ extern "C" int eofx_apply_f32(eofx_ctx* ctx, const float* X, int64_t n, int64_t 
 // panel-level ABI
 // ------------------------------------------------------------------------------------
 static int panel_tmul(eofx_ctx* ctx, const eofx_mat* m, const float* Zn, float* Yp, int L, int prec) {
-  return launch_atb(ctx, m->X, m->p_pad, round_up(m->n, ATB_KG), m->p_pad, Zn, L, L, Yp, prec);
+  return launch_atb(ctx, m->X, m->p_pad, round_up(m->n, ATB_KG), m->p_pad, Zn, L, L, Yp, prec, m->absmax);
 }
 static int panel_mul(eofx_ctx* ctx, const eofx_mat* m, const float* Yp, float* Wn, int L, int prec) {
-  return launch_atb(ctx, m->Xt, m->n_pad, round_up(m->p, ATB_KG), m->n_pad, Yp, L, L, Wn, prec);
+  return launch_atb(ctx, m->Xt, m->n_pad, round_up(m->p, ATB_KG), m->n_pad, Yp, L, L, Wn, prec, m->absmax);
 }
-static bool valid_prec(int p) { return p == EOFX_PREC_F32 || p == EOFX_PREC_BF16X3 || p == EOFX_PREC_BF16X6; }
+static bool valid_prec(int p) {
+  return p == EOFX_PREC_F32 || p == EOFX_PREC_BF16X3 || p == EOFX_PREC_BF16X6 || p == EOFX_PREC_F16X3;
+}
 
 extern "C" int eofx_ctx_set_precision(eofx_ctx* ctx, int power_passes, int final_passes) {
   if (!ctx || !valid_prec(power_passes) || !valid_prec(final_passes)) return set_err(ctx, EOFX_ERR_ARG, "bad precision");
@@ -1355,8 +1406,10 @@ extern "C" int eofx_crosscov_rsvd_f32(eofx_ctx* ctx, const eofx_mat* x, const eo
   if (tsc) {
     ARENA(float, Gx, (size_t)npad * npad);
     ARENA(float, Gy, (size_t)npad * npad);
-    CHK(launch_atb(ctx, x->Xt, npad, round_up(p1, ATB_KG), npad, x->Xt, (int)npad, (int)npad, Gx, ctx->prec_final));
-    CHK(launch_atb(ctx, y->Xt, npad, round_up(p2, ATB_KG), npad, y->Xt, (int)npad, (int)npad, Gy, ctx->prec_final));
+    CHK(launch_atb(ctx, x->Xt, npad, round_up(p1, ATB_KG), npad, x->Xt, (int)npad, (int)npad, Gx, ctx->prec_final, x->absmax,
+                   reinterpret_cast<const float*>(x->absmax_dev)));
+    CHK(launch_atb(ctx, y->Xt, npad, round_up(p2, ATB_KG), npad, y->Xt, (int)npad, (int)npad, Gy, ctx->prec_final, y->absmax,
+                   reinterpret_cast<const float*>(y->absmax_dev)));
     const int nb = 1024;
     ARENA(double, part, nb);
     hipLaunchKernelGGL(dotprod_part_kernel, dim3(nb), dim3(256), 0, ctx->stream, Gx, Gy, npad * npad, part);
@@ -1530,7 +1583,8 @@ extern "C" int eofx_hilbert_f32(eofx_ctx* ctx, const eofx_mat* a, int padding, d
                          dim3(256), 0, ctx->stream, spec, chat, nh, total);
       FFTCHK(hipfftExecC2R(full ? plan_b : tail_b, (hipfftComplex*)spec, work));
       hipLaunchKernelGGL(hilbert_unpack_kernel, dim3((int)fc), dim3(256), 0, ctx->stream, work, ldw, n, n_pad,
-                         f0, padding ? 1 : 0, coef, u, a->Xt, mi->Xt, mr ? mr->Xt : nullptr);
+                         f0, padding ? 1 : 0, coef, u, a->Xt, mi->Xt, mr ? mr->Xt : nullptr, mi->absmax_dev,
+                         mr ? mr->absmax_dev : nullptr);
     }
     // zero the padding feature rows, then build the feature-contiguous layout by transposition
     const size_t pad_bytes = (size_t)(p_pad - p) * n_pad * sizeof(float);
@@ -1545,6 +1599,9 @@ extern "C" int eofx_hilbert_f32(eofx_ctx* ctx, const eofx_mat* a, int padding, d
     hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, ctx->stream, mi->Xt, n_pad, mi->X, p_pad);
     if (mr) hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, ctx->stream, mr->Xt, n_pad, mr->X, p_pad);
     hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(&mi->absmax, mi->absmax_dev, sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && mr)
+      e = hipMemcpyAsync(&mr->absmax, mr->absmax_dev, sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) rc = set_err(ctx, EOFX_ERR_HIP, "hilbert stage failed: %s", hipGetErrorString(e));
   }

@@ -290,6 +290,172 @@ __global__ __launch_bounds__(256, 2) void atb_bf16_kernel(const float* __restric
       }
 }
 
+// ---------------------------------------------------------------------------------
+// atb_f16: the same product with the operands split into TWO fp16 terms (hi: round-toward-zero
+// fp16 of the scaled value, lo: fp16 of the exact remainder) and the three cross products
+// hh + hm + mh on v_mfma_f32_32x32x16_f16.  fp16 carries 11 significant bits, so two terms hold 22:
+// f32-class accuracy (~2^-22 per product) at the cost of bf16x3.  fp16's narrow exponent range is
+// handled by exact power-of-two scaling: A is multiplied by a_scale (from the matrix' max |x|,
+// host), B by b_scale (from the panel's max |b|, read from a device scalar written by
+// panel_absmax_kernel) so that |scaled| <= 2^14; the epilogue multiplies by the exact inverse.
+// Elements far below the maximum fall into fp16 subnormals in their lo term only: an ABSOLUTE
+// error of 2^-25 * max, irrelevant against the f32 accumulation.
+// ---------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split_f16(f32x8 r, f16x8 (&out)[2]) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    u32x4 pk;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const fp16x2_t p = __builtin_amdgcn_cvt_pkrtz(r[2 * h], r[2 * h + 1]);
+      pk[h] = __builtin_bit_cast(unsigned, p);
+      if (s == 0) {
+        r[2 * h] -= (float)p[0];
+        r[2 * h + 1] -= (float)p[1];
+      }
+    }
+    out[s] = __builtin_bit_cast(f16x8, pk);
+  }
+}
+
+// scale = 2^(14 - e) with |m| <= 2^e (m = max |value|); 1 for an all-zero operand
+__device__ __forceinline__ float f16_scale_for(float m) {
+  if (!(m > 0.f) || !(m < INFINITY)) return 1.f;
+  int e;
+  (void)frexpf(m, &e);
+  return ldexpf(1.f, 14 - e);
+}
+
+template <int NB>
+__global__ __launch_bounds__(256, 2) void atb_f16_kernel(const float* __restrict__ A, int64_t lda,
+                                                          const float* __restrict__ B, int ldb,
+                                                          float* __restrict__ C, int ldc, int64_t M,
+                                                          int64_t K, int64_t k_per_split, int col_base,
+                                                          float a_scale,
+                                                          const float* __restrict__ b_absmax) {
+  __shared__ __attribute__((aligned(16))) _Float16 Bs[2][2][2][32 * NB][8];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int64_t m0 = (int64_t)blockIdx.x * ATB_BM + wave * ATB_WM;
+  const int64_t kb = (int64_t)blockIdx.y * k_per_split;
+  const int64_t ke = (kb + k_per_split < K) ? kb + k_per_split : K;
+  const int nchunks = (int)((ke - kb) / ATB_KC);
+  const int bcol0 = col_base + blockIdx.z * 64;
+  const float b_scale = f16_scale_for(*b_absmax);
+  const float out_scale = 1.f / (a_scale * b_scale);   // exact: both are powers of two
+
+  f32x16 acc[4][NB];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][b][r] = 0.f;
+
+  const float* Ap = A + (kb + lh) * lda + m0 + 4 * li;
+  constexpr int BV = 8 * NB;
+  const bool b_loader = tid < 16 * BV;
+  const int brow = tid / BV, bc4 = tid % BV;
+  const float* Bp = B + (kb + brow) * (int64_t)ldb + bcol0 + 4 * bc4;
+
+  f32x4 a0[8], a1[8];
+  f32x4 bn = {0.f, 0.f, 0.f, 0.f};
+#define EOFX_LOAD_SLAB(areg, chunk)                                                              \
+  do {                                                                                           \
+    if (b_loader) bn = *reinterpret_cast<const f32x4*>(Bp + (int64_t)(chunk) * ATB_KC * ldb);   \
+    const float* pa_ = Ap + (int64_t)(chunk) * ATB_KC * lda;                                     \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) areg[i] =                                      \
+        __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(pa_ + (int64_t)(2 * i) * lda)); \
+  } while (0)
+#define EOFX_STORE_B(buf)                                                                        \
+  do {                                                                                           \
+    if (b_loader) {                                                                              \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                            \
+        const float r_ = bn[e] * b_scale;                                                        \
+        const fp16x2_t h_ = __builtin_amdgcn_cvt_pkrtz(r_, 0.f);                                 \
+        const _Float16 m_ = (_Float16)(r_ - (float)h_[0]);                                       \
+        Bs[buf][0][brow & 1][4 * bc4 + e][brow >> 1] = (_Float16)h_[0];                          \
+        Bs[buf][1][brow & 1][4 * bc4 + e][brow >> 1] = m_;                                       \
+      }                                                                                          \
+    }                                                                                            \
+  } while (0)
+#define EOFX_COMPUTE_SLAB(areg, buf)                                                             \
+  do {                                                                                           \
+    f16x8 bf_[2][NB];                                                                            \
+    _Pragma("unroll") for (int s = 0; s < 2; ++s) _Pragma("unroll") for (int q = 0; q < NB; ++q) \
+        bf_[s][q] = *reinterpret_cast<const f16x8*>(&Bs[buf][s][lh][32 * q + li][0]);            \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                              \
+      f32x8 x_;                                                                                  \
+      _Pragma("unroll") for (int t = 0; t < 8; ++t) x_[t] = areg[t][j] * a_scale;                \
+      f16x8 af_[2];                                                                              \
+      split_f16(x_, af_);                                                                        \
+      _Pragma("unroll") for (int q = 0; q < NB; ++q) {                                           \
+        acc[j][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af_[1], bf_[0][q], acc[j][q], 0, 0, 0); \
+        acc[j][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af_[0], bf_[1][q], acc[j][q], 0, 0, 0); \
+        acc[j][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af_[0], bf_[0][q], acc[j][q], 0, 0, 0); \
+      }                                                                                          \
+    }                                                                                            \
+  } while (0)
+
+  if (nchunks > 0) {
+    EOFX_LOAD_SLAB(a0, 0);
+    EOFX_STORE_B(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; c += 2) {
+      EOFX_LOAD_SLAB(a1, c + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      EOFX_COMPUTE_SLAB(a0, 0);
+      EOFX_STORE_B(1);
+      __syncthreads();
+      const int c2 = (c + 2 < nchunks) ? c + 2 : c + 1;
+      EOFX_LOAD_SLAB(a0, c2);
+      __builtin_amdgcn_sched_barrier(0);
+      EOFX_COMPUTE_SLAB(a1, 1);
+      EOFX_STORE_B(0);
+      __syncthreads();
+    }
+  }
+#undef EOFX_LOAD_SLAB
+#undef EOFX_COMPUTE_SLAB
+#undef EOFX_STORE_B
+
+  float* Cs = C + (int64_t)blockIdx.y * M * ldc;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int q = 0; q < NB; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ii = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int64_t m = m0 + 4 * ii + j;
+        Cs[m * ldc + bcol0 + 32 * q + li] = acc[j][q][r] * out_scale;
+      }
+}
+
+// max |v| over a (rows x cols) block with leading dimension ld -> *out (float bits, atomicMax on the
+// unsigned view: order-independent, hence deterministic).  *out must be zeroed first.
+__global__ __launch_bounds__(256) void panel_absmax_kernel(const float* __restrict__ P, int64_t rows,
+                                                            int cols, int64_t ld,
+                                                            unsigned* __restrict__ out) {
+  const int64_t total = rows * (cols / 4);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t r = i / (cols / 4);
+    const int c4 = (int)(i - r * (cols / 4));
+    const f32x4 v = *reinterpret_cast<const f32x4*>(P + r * ld + 4 * c4);
+    m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+}
+
 // out[i] = sum_s part[s][i], fixed order, float64 accumulate.  count4 = elements / 4.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part,
                                                             float* __restrict__ out,
@@ -579,13 +745,16 @@ __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__
                                                         int64_t P, int64_t rows_per_split,
                                                         int* __restrict__ cnt,
                                                         double* __restrict__ sum,
-                                                        double* __restrict__ sumsq) {
+                                                        double* __restrict__ sumsq,
+                                                        float* __restrict__ vmin,
+                                                        float* __restrict__ vmax) {
   const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (c >= P) return;
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_split;
   const int64_t r1 = (r0 + rows_per_split < n) ? r0 + rows_per_split : n;
   int k = 0;
   double s = 0.0, q = 0.0;
+  float lo = INFINITY, hi = -INFINITY;   // fminf/fmaxf skip NaN
   const float* p = X + r0 * P + c;
   int64_t r = r0;
   for (; r + 8 <= r1; r += 8) {
@@ -594,16 +763,21 @@ __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__
     for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(p + (int64_t)u * P);
     p += 8 * P;
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
+    for (int u = 0; u < 8; ++u) {
+      lo = fminf(lo, v[u]);
+      hi = fmaxf(hi, v[u]);
       if (v[u] == v[u]) {
         const double d = (double)v[u];
         ++k;
         s += d;
         q += d * d;
       }
+    }
   }
   for (; r < r1; ++r, p += P) {
     const float v = *p;
+    lo = fminf(lo, v);
+    hi = fmaxf(hi, v);
     if (v == v) {
       const double d = (double)v;
       ++k;
@@ -615,23 +789,30 @@ __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__
   cnt[o] = k;
   sum[o] = s;
   sumsq[o] = q;
+  vmin[o] = lo;
+  vmax[o] = hi;
 }
 
 // One thread per feature.  weights may be null (ones).  Outputs per (uncompacted) feature.
 __global__ __launch_bounds__(256) void colstats_finalize_kernel(
     const int* __restrict__ cnt_p, const double* __restrict__ sum_p,
-    const double* __restrict__ sumsq_p, int splits, int64_t P, int center, int standardize,
+    const double* __restrict__ sumsq_p, const float* __restrict__ vmin_p,
+    const float* __restrict__ vmax_p, int splits, int64_t P, int center, int standardize,
     const double* __restrict__ weights, double eps, int* __restrict__ cnt, double* __restrict__ mean,
     double* __restrict__ stdv, double* __restrict__ shift, double* __restrict__ scale,
-    double* __restrict__ m2) {
+    double* __restrict__ m2, unsigned* __restrict__ absmax) {
   const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (c >= P) return;
+  float amax = 0.f;
+  if (c < P) {
   int k = 0;
   double s = 0.0, q = 0.0;
+  float lo = INFINITY, hi = -INFINITY;
   for (int sp = 0; sp < splits; ++sp) {
     k += cnt_p[(int64_t)sp * P + c];
     s += sum_p[(int64_t)sp * P + c];
     q += sumsq_p[(int64_t)sp * P + c];
+    lo = fminf(lo, vmin_p[(int64_t)sp * P + c]);
+    hi = fmaxf(hi, vmax_p[(int64_t)sp * P + c]);
   }
   cnt[c] = k;
   double mu = NAN, sd = NAN, M2 = 0.0;
@@ -645,9 +826,16 @@ __global__ __launch_bounds__(256) void colstats_finalize_kernel(
   mean[c] = mu;
   stdv[c] = sd;
   const double w = weights ? weights[c] : 1.0;
-  shift[c] = center ? mu : 0.0;
-  scale[c] = (standardize ? 1.0 / sd : 1.0) * w;
+  const double sh = center ? mu : 0.0, sc = (standardize ? 1.0 / sd : 1.0) * w;
+  shift[c] = sh;
+  scale[c] = sc;
   m2[c] = M2;
+  // max |(x - shift) * scale| of this feature after the transform (1 ulp headroom for the float cast)
+  if (k > 0) amax = (float)(fmax(fabs((double)hi - sh), fabs((double)lo - sh)) * fabs(sc) * 1.000001);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+  if ((threadIdx.x & 63) == 0 && amax > 0.f && amax < INFINITY) atomicMax(absmax, __float_as_uint(amax));
 }
 
 // count of non-NaN entries per row restricted to valid feature columns
@@ -683,10 +871,12 @@ __global__ __launch_bounds__(256) void apply_kernel(const float* __restrict__ X,
                                                      const double* __restrict__ scale, int64_t n,
                                                      int64_t p, float* __restrict__ Xc,
                                                      int64_t p_pad, float* __restrict__ Xt,
-                                                     int64_t n_pad, int* __restrict__ nan_flag) {
+                                                     int64_t n_pad, int* __restrict__ nan_flag,
+                                                     unsigned* __restrict__ absmax) {
   __shared__ float T[64][65];
   const int tid = threadIdx.x;
   const int tq = tid & 15, tr = tid >> 4;  // column quad 0..15, row 0..15 (+16 per pass)
+  float vmax = 0.f;
   const int64_t c0 = (int64_t)blockIdx.x * 64, r0 = (int64_t)blockIdx.y * 64;
   const int64_t cb = c0 + 4 * tq;
   int64_t sc[4];
@@ -729,9 +919,15 @@ __global__ __launch_bounds__(256) void apply_kernel(const float* __restrict__ X,
     }
     *reinterpret_cast<f32x4*>(Xc + r * p_pad + cb) = v;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) T[rr][4 * tq + e] = v[e];
+    for (int e = 0; e < 4; ++e) {
+      T[rr][4 * tq + e] = v[e];
+      vmax = fmaxf(vmax, fabsf(v[e]));
+    }
   }
   if (bad) atomicOr(nan_flag, 1);
+  (void)vmax;
+  (void)absmax;  // the maximum comes from the column statistics (or panel_absmax_kernel): one atomic per
+                 // wave here would serialise 10^7 updates of a single word
   __syncthreads();
   // transposed write: thread owns 4 consecutive samples of one feature column per pass
 #pragma unroll
@@ -894,7 +1090,9 @@ __global__ __launch_bounds__(256) void hilbert_unpack_kernel(const float* __rest
                                                               const float* __restrict__ u,
                                                               const float* __restrict__ Xt,
                                                               float* __restrict__ Bt,
-                                                              float* __restrict__ At) {
+                                                              float* __restrict__ At,
+                                                              unsigned* __restrict__ bmax,
+                                                              unsigned* __restrict__ amax) {
   __shared__ double red[256];
   const float* in = work + (int64_t)blockIdx.x * ldw;
   const int64_t f = f0 + blockIdx.x;
@@ -913,6 +1111,7 @@ __global__ __launch_bounds__(256) void hilbert_unpack_kernel(const float* __rest
   }
   si = block_sum_256(si, red) / (double)n;
   sr = block_sum_256(sr, red) / (double)n;
+  float mb = 0.f, ma = 0.f;
   for (int64_t i = threadIdx.x; i < n_pad; i += 256) {
     const bool ok = i < n;
     float v = 0.f;
@@ -922,7 +1121,21 @@ __global__ __launch_bounds__(256) void hilbert_unpack_kernel(const float* __rest
       v = (float)((double)v - si);
     }
     Bt[f * n_pad + i] = v;
-    if (At) At[f * n_pad + i] = ok ? (float)((double)y[i] - sr) : 0.f;
+    mb = fmaxf(mb, fabsf(v));
+    if (At) {
+      const float a = ok ? (float)((double)y[i] - sr) : 0.f;
+      At[f * n_pad + i] = a;
+      ma = fmaxf(ma, fabsf(a));
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mb = fmaxf(mb, __shfl_xor(mb, o));
+    ma = fmaxf(ma, __shfl_xor(ma, o));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (mb > 0.f) atomicMax(bmax, __float_as_uint(mb));
+    if (At && ma > 0.f) atomicMax(amax, __float_as_uint(ma));
   }
 }
 

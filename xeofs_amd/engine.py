@@ -40,14 +40,14 @@ class Context:
                 "xeofs_amd has no CPU fallback.")
         self.handle = h
         self.device = int(device)
-        self.precision = ("bf16x3", "bf16x6")
+        self.precision = ("f16x3", "f16x3")
 
     def synchronize(self):
         raise_for(self.lib.eofx_ctx_synchronize(self.handle), self.handle)
 
-    def set_precision(self, power="bf16x3", final="bf16x6"):
-        """Arithmetic of the matrix passes: "f32" (exact-f32 MFMA), "bf16x3", "bf16x6"
-        (split-bf16 MFMA, see include/eofx.h).  Default ("bf16x3", "bf16x6")."""
+    def set_precision(self, power="f16x3", final="f16x3"):
+        """Arithmetic of the matrix passes: "f16x3" (scaled split-fp16 MFMA, default), "f32" (exact-f32
+        MFMA), "bf16x3", "bf16x6" (split-bf16 MFMA); see include/eofx.h."""
         raise_for(self.lib.eofx_ctx_set_precision(self.handle, _lib.PREC[power], _lib.PREC[final]), self.handle)
         self.precision = (power, final)
 
