@@ -207,6 +207,17 @@ int eofx_cpanel_combine_f32(eofx_ctx *ctx, const float *P1, const float *P2, int
 int eofx_panel_colargminmax_f32(eofx_ctx *ctx, const float *P, int64_t rows, int L, int64_t *amax,
                                 int64_t *amin);
 
+/* ---- rotation of loadings (EOFRotator: linalg/_numpy/_rotation.py:6-187), up to 64 modes ------
+ * eofx_panel_row_normalize_f32: Kaiser normalisation out[r,:] = P[r,:] / (||P[r,:]|| + eps).
+ * eofx_panel_rot_step_f64: one pass over the normalised loadings X (rows_pad x L):
+ *   per row b = x R (float64); mode 0 (one Varimax iteration, _rotation.py:166-176):
+ *   G = X^T (b * (b^2 - aux)), aux[j] = alpha * sum_r b_rj^2;  mode 1 (Promax regression terms,
+ *   _rotation.py:62-69): G = B^T ((b/aux) |b/aux|^(power-1)), aux[j] = max_r |b_rj|.
+ *   R, aux, G are device float64 (L x L, L, L x L).                                            */
+int eofx_panel_row_normalize_f32(eofx_ctx *ctx, const float *P, int64_t rows_pad, int L, float *out);
+int eofx_panel_rot_step_f64(eofx_ctx *ctx, const float *X, int64_t rows_pad, int L, const double *R,
+                            const double *aux, int mode, double power, double *G);
+
 /* ---- the sketch matrix ------------------------------------------------------------------
  * out[rows x cols] (host float32) = np.random.RandomState(seed).normal(size=(rows, cols))
  * .astype(float32), bit for bit -- the Gaussian test matrix scikit-learn's randomized_svd draws

@@ -459,3 +459,79 @@ def synthetic_field(n, n_lat, n_lon, rank=100, seed=0, dtype=np.float32, nan_fra
         mask = np.random.default_rng(seed + 77).random(p) < nan_frac
         X[:, mask] = np.nan
     return X, lat
+
+
+# --------------------------------------------------------------------------- #
+# N2  Varimax / Promax rotation + EOFRotator                                    #
+# --------------------------------------------------------------------------- #
+def varimax(X, gamma=1.0, max_iter=1000, rtol=1e-8):
+    """xeofs/linalg/_numpy/_rotation.py:95-187 `_varimax` (eager, numpy branch)."""
+    X = np.array(X, dtype=np.result_type(X, np.float64), copy=True)
+    n_samples, n_modes = X.shape
+    if n_modes < 2:
+        raise ValueError("Cannot rotate {:} modes (columns), but must be 2 or more.".format(n_modes))
+    R = np.eye(n_modes)
+    h = np.sqrt(np.sum(X * X.conj(), axis=1))
+    eps = np.finfo(X.dtype).eps
+    X = (1.0 / (h + eps))[:, np.newaxis] * X
+    delta = 0.0
+    XH = X.conj().T
+    alpha = gamma / n_samples
+    for _ in range(max_iter):
+        delta_old = delta
+        basis = X @ R
+        basis2 = basis * basis.conj()
+        W = np.sum(basis2, axis=0)
+        transformed = XH @ (basis * (basis2 - (alpha * W)))
+        U, svals, VT = np.linalg.svd(transformed)
+        R = U @ VT
+        delta = np.sum(svals)
+        if (abs(delta - delta_old) / delta) < rtol:
+            break
+    if (abs(delta - delta_old) / delta) > rtol:
+        raise RuntimeError("Rotation process did not converge.")
+    X = h[:, np.newaxis] * X
+    return X @ R, R
+
+
+def promax(X, power=1, max_iter=1000, rtol=1e-8):
+    """xeofs/linalg/_numpy/_rotation.py:6-92 `_promax`."""
+    X, rot_mat = varimax(X, max_iter=max_iter, rtol=rtol)
+    h = np.sqrt(np.sum(X * X.conj(), axis=1))
+    eps = np.finfo(X.dtype).eps
+    X = (1.0 / (h + eps))[:, np.newaxis] * X
+    Xnorm = X / np.max(abs(X), axis=0)
+    P = Xnorm * np.abs(Xnorm) ** (power - 1)
+    L = np.linalg.inv(X.conj().T @ X) @ X.conj().T @ P
+    try:
+        sigma_inv = np.diag(np.diag(np.linalg.inv(L.conj().T @ L)))
+    except np.linalg.LinAlgError:
+        sigma_inv = np.diag(np.diag(np.linalg.pinv(L.conj().T @ L)))
+    L = L @ np.sqrt(sigma_inv)
+    Xrot = h[:, np.newaxis] * (X @ L)
+    rot_mat = rot_mat @ L
+    L_inv = np.linalg.inv(L)
+    return Xrot, rot_mat, L_inv @ L_inv.conj().T
+
+
+def eof_rotator_fit(eof, n_modes, power=1, max_iter=1000, rtol=1e-8):
+    """xeofs/single/eof_rotator.py:119-205 on the dict returned by `eof_fit`
+    (sorted by explained variance as `_sort_by_variance` does after compute, :207-218)."""
+    comps = eof["components"][:, :n_modes]
+    expvar = eof["explained_variance"][:n_modes]
+    loadings = comps * np.sqrt(expvar)
+    rot_loadings, rot_matrix, phi = promax(loadings, power=power, max_iter=max_iter, rtol=rtol)
+    expvar_r = (np.abs(rot_loadings) ** 2).sum(axis=0)
+    idx = np.argsort(expvar_r)[::-1]
+    rot_components = rot_loadings / np.sqrt(expvar_r)
+    n_samples = eof["input_data"].shape[0]
+    norms = (expvar_r * (n_samples - 1)) ** 0.5
+    scores = eof["scores"][:, :n_modes] / eof["norms"][:n_modes]
+    RinvT = rot_matrix if power == 1 else np.linalg.inv(rot_matrix).conj().T
+    scores = scores @ RinvT * norms
+    sign = deterministic_sign_multiplier(rot_components.T)
+    rot_components = rot_components * sign
+    scores = scores * sign
+    return dict(components=rot_components[:, idx], scores=scores[:, idx], norms=norms[idx],
+                explained_variance=expvar_r[idx], total_variance=eof["total_variance"], idx_modes_sorted=idx,
+                rotation_matrix=rot_matrix, phi_matrix=phi, modes_sign=sign[idx])

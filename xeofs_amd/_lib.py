@@ -59,6 +59,8 @@ SIGNATURES = {
     "eofx_mat_sumsq_f64": (_int, [_vp, _vp, _pd]),
     "eofx_cpanel_combine_f32": (_int, [_vp, _vp, _vp, _int, _i64, _int, _vp]),
     "eofx_panel_colargminmax_f32": (_int, [_vp, _vp, _i64, _int, _vp, _vp]),
+    "eofx_panel_row_normalize_f32": (_int, [_vp, _vp, _i64, _int, _vp]),
+    "eofx_panel_rot_step_f64": (_int, [_vp, _vp, _i64, _int, _vp, _vp, _int, C.c_double, _vp]),
     "eofx_sketch_gaussian_f32": (_int, [C.c_uint32, _i64, _i64, _vp]),
     "eofx_host_eigh_f64": (_int, [_vp, _int, _vp, _vp]),
 }
@@ -78,6 +80,10 @@ def load() -> C.CDLL:
             f"{LIB_PATH} not found: build it with `make -C xeofs_amd/csrc` "
             "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
             "xeofs_amd has no CPU fallback.")
+    # torch ships its own HIP runtime: it has to be the one the process binds first, otherwise
+    # torch later reports "No HIP GPUs are available" (two libamdhip64 copies in one process).
+    import torch  # noqa: F401
+
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing

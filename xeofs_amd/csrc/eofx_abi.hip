@@ -1816,3 +1816,31 @@ extern "C" int eofx_sketch_gaussian_f32(uint32_t seed, int64_t rows, int64_t col
   }
   return EOFX_OK;
 }
+
+// ------------------------------------------------------------------------------------
+// rotation of loadings (Varimax / Promax), panel-level steps
+// ------------------------------------------------------------------------------------
+extern "C" int eofx_panel_row_normalize_f32(eofx_ctx* ctx, const float* P, int64_t rows_pad, int L, float* out) {
+  if (!ctx || !P || !out) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  CHK(set_device(ctx));
+  hipLaunchKernelGGL(row_normalize_kernel, dim3((int)((rows_pad + 3) / 4)), dim3(256), 0, ctx->stream, P, rows_pad, L,
+                     2.220446049250313e-16, out);
+  KCHK();
+  return EOFX_OK;
+}
+
+extern "C" int eofx_panel_rot_step_f64(eofx_ctx* ctx, const float* X, int64_t rows_pad, int L, const double* R,
+                                       const double* aux, int mode, double power, double* G) {
+  if (!ctx || !X || !R || !aux || !G || L > 64 || L % 32) return set_err(ctx, EOFX_ERR_ARG, "bad argument (L <= 64)");
+  CHK(set_device(ctx));
+  const int nbx = (int)std::max<int64_t>(1, std::min<int64_t>((rows_pad + 31) / 32, 512));
+  CHK(arena_reserve(ctx, (size_t)(nbx + 1) * L * L * sizeof(double) + 4096));
+  ArenaScope scope(ctx);
+  ARENA(double, part, (size_t)nbx * L * L);
+  hipLaunchKernelGGL(rot_step_kernel, dim3(nbx), dim3(256), 0, ctx->stream, X, rows_pad, L, R, aux, mode, power, part);
+  KCHK();
+  const int64_t count = (int64_t)L * L;
+  hipLaunchKernelGGL(f64_reduce_kernel, dim3((int)((count + 255) / 256)), dim3(256), 0, ctx->stream, part, G, count, nbx);
+  KCHK();
+  return EOFX_OK;
+}

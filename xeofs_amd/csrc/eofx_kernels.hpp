@@ -1236,4 +1236,107 @@ __global__ void colargminmax_final_kernel(const float* __restrict__ pmx, const i
   amin[c] = ib;
 }
 
+// ---------------------------------------------------------------------------------
+// Varimax / Promax rotation of loadings (xeofs/linalg/_numpy/_rotation.py:6-187), modes <= 64.
+// The loadings panel X (rows = features, L = 64 columns) stays resident; one iteration of the
+// reference loop  basis = X R;  T = basis * (|basis|^2 - alpha W);  G = X^T T  is ONE pass over X:
+// per row  b = x R (float64),  t = f(b),  G += left^T t  with everything but the final m x m SVD on
+// the device.  mode 0 (varimax step):  left = x, t_j = b_j (b_j^2 - aw_j)
+//              mode 1 (promax fit)  :  left = b, t_j = (b_j / mx_j) |b_j / mx_j|^(power-1)
+// grid = (nblocks); each workgroup owns a strided set of 32-row tiles; partials reduced in fixed order.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rot_step_kernel(const float* __restrict__ X, int64_t rows, int L,
+                                                       const double* __restrict__ R,
+                                                       const double* __restrict__ aux, int mode,
+                                                       double power, double* __restrict__ Gpart) {
+  __shared__ float Xs[32][64];
+  __shared__ double Rs[64][64];
+  __shared__ double Ts[32][64];
+  __shared__ double Ls[32][64];   // left factor (mode 1 only)
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 64 * 64; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    Rs[r][c] = (r < L && c < L) ? R[(int64_t)r * L + c] : 0.0;
+  }
+  const int ti = tid >> 4, tj = tid & 15;
+  const int brow = tid >> 3, bc0 = (tid & 7) * 8;   // b entries: row brow, columns bc0..bc0+7
+  double acc[4][4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) acc[x][y] = 0.0;
+  double auxr[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) auxr[e] = (bc0 + e < L) ? aux[bc0 + e] : (mode ? 1.0 : 0.0);
+  __syncthreads();
+  for (int64_t r0 = (int64_t)blockIdx.x * 32; r0 < rows; r0 += (int64_t)gridDim.x * 32) {
+    for (int i = tid; i < 32 * 16; i += 256) {
+      const int rr = i >> 4, c4 = (i & 15) * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (r0 + rr < rows && c4 < L) v = *reinterpret_cast<const f32x4*>(X + (r0 + rr) * L + c4);
+      *reinterpret_cast<f32x4*>(&Xs[rr][c4]) = v;
+    }
+    __syncthreads();
+    double b[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) b[e] = 0.0;
+    for (int k = 0; k < 64; ++k) {
+      const double xv = (double)Xs[brow][k];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) b[e] += xv * Rs[k][bc0 + e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      double t;
+      if (mode == 0) {
+        t = b[e] * (b[e] * b[e] - auxr[e]);
+      } else {
+        const double z = b[e] / auxr[e];
+        t = (power == 1.0) ? z : z * pow(fabs(z), power - 1.0);
+        Ls[brow][bc0 + e] = b[e];
+      }
+      Ts[brow][bc0 + e] = t;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int r = 0; r < 32; ++r) {
+      double a[4], c[4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) a[x] = mode ? Ls[r][4 * ti + x] : (double)Xs[r][4 * ti + x];
+#pragma unroll
+      for (int y = 0; y < 4; ++y) c[y] = Ts[r][4 * tj + y];
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) acc[x][y] += a[x] * c[y];
+    }
+    __syncthreads();
+  }
+  double* G = Gpart + (int64_t)blockIdx.x * L * L;
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) {
+      const int gi = 4 * ti + x, gj = 4 * tj + y;
+      if (gi < L && gj < L) G[(int64_t)gi * L + gj] = acc[x][y];
+    }
+}
+
+// Kaiser normalisation: out[r,:] = P[r,:] / (||P[r,:]|| + eps)   (one wave per row quad)
+__global__ __launch_bounds__(256) void row_normalize_kernel(const float* __restrict__ P, int64_t rows, int L,
+                                                            double eps, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  double s = 0.0;
+  for (int c = lane; c < L; c += 64) {
+    const double v = (double)P[r * L + c];
+    s += v * v;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const double inv = 1.0 / (sqrt(s) + eps);
+  for (int c = lane; c < L; c += 64) out[r * L + c] = (float)((double)P[r * L + c] * inv);
+}
+
 }  // namespace eofx

@@ -422,3 +422,24 @@ def panel_colargminmax(ctx: Context, P, rows: int):
     amin = torch.empty(L, dtype=torch.int64, device=P.device)
     raise_for(ctx.lib.eofx_panel_colargminmax_f32(ctx.handle, ptr(P), int(rows), L, ptr(amax), ptr(amin)), ctx.handle)
     return amax, amin
+
+
+# --------------------------------------------------------------------------- #
+# rotation steps                                                                #
+# --------------------------------------------------------------------------- #
+def panel_row_normalize(ctx: Context, P, out=None):
+    torch = _torch()
+    if out is None:
+        out = torch.empty_like(P)
+    raise_for(ctx.lib.eofx_panel_row_normalize_f32(ctx.handle, ptr(P), P.shape[0], P.shape[1], ptr(out)), ctx.handle)
+    return out
+
+
+def panel_rot_step(ctx: Context, X, R, aux, mode: int, power: float = 1.0):
+    """one pass over the normalised loadings panel -> L x L float64 (device) ; see include/eofx.h"""
+    torch = _torch()
+    L = X.shape[1]
+    G = torch.empty((L, L), dtype=torch.float64, device=X.device)
+    raise_for(ctx.lib.eofx_panel_rot_step_f64(ctx.handle, ptr(X), X.shape[0], L, ptr(R), ptr(aux), int(mode),
+                                              float(power), ptr(G)), ctx.handle)
+    return G

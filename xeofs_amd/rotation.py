@@ -1,0 +1,82 @@
+"""Varimax / Promax rotation of resident loadings (xeofs/linalg/_numpy/_rotation.py:6-187).
+
+The p x m loadings stay on the GPU as a 64-wide panel.  Each iteration of the reference loop
+(`basis = X R; transformed = X^H (basis * (|basis|^2 - alpha W)); U, s, VT = svd(transformed);
+R = U VT`) is one fused pass over the panel (`eofx_panel_rot_step_f64`, float64 row arithmetic) plus an
+m x m SVD on the host; `W = diag(R^T (X^T X) R)` comes from the m x m Gram matrix computed once.
+Convergence test, error and outputs are the reference's.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from . import engine
+
+MAX_ROT_MODES = 64
+
+
+def _dev(a, like):
+    torch = engine._torch()
+    return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=like.device)
+
+
+def _pad(M, L):
+    out = np.zeros((L, L))
+    m = M.shape[0]
+    out[:m, :m] = M
+    return out
+
+
+def promax(ctx, loadings: np.ndarray, power: int = 1, max_iter: int = 1000, rtol: float = 1e-8):
+    """-> (rotated loadings [p, m] float32, rotation matrix [m, m], phi [m, m]) like `_promax`."""
+    loadings = np.ascontiguousarray(loadings, dtype=np.float32)
+    p, m = loadings.shape
+    if m < 2:
+        raise ValueError("Cannot rotate {:} modes (columns), but must be 2 or more.".format(m))
+    if m > MAX_ROT_MODES:
+        raise NotImplementedError(f"rotation of more than {MAX_ROT_MODES} modes is not supported by this build")
+    L = engine.panel_width(m)
+    rows_pad = (p + 511) // 512 * 512
+    Lp = engine.panel_import(ctx, loadings, rows_pad, L)           # loadings
+    Xn = engine.panel_row_normalize(ctx, Lp)                       # Kaiser-normalised rows
+    S = engine.panel_gram(ctx, Xn).cpu().numpy()[:m, :m]           # X^T X
+    S = 0.5 * (S + S.T)
+    R = np.eye(m)
+    alpha = 1.0 / p
+    delta = 0.0
+    for _ in range(int(max_iter)):
+        delta_old = delta
+        W = np.einsum("ij,ik,kj->j", R, S, R)                      # column sums of (X R)^2
+        aux = np.zeros(L)
+        aux[:m] = alpha * W
+        G = engine.panel_rot_step(ctx, Xn, _dev(_pad(R, L), Xn), _dev(aux, Xn), 0).cpu().numpy()[:m, :m]
+        U, svals, VT = np.linalg.svd(G)
+        R = U @ VT
+        delta = float(np.sum(svals))
+        if abs(delta - delta_old) / delta < rtol:
+            break
+    if abs(delta - delta_old) / delta > rtol:
+        raise RuntimeError("Rotation process did not converge.")
+    rot_mat = R
+    phi = np.eye(m)
+    if power != 1:
+        # Promax: regress the powered, max-normalised varimax solution on itself (_rotation.py:57-84)
+        B = engine.panel_matmul(ctx, Xn, _dev(_pad(R, L), Xn))     # X R (normalised, rotated)
+        mx, mn = engine.panel_colminmax(ctx, B, p)
+        cmax = np.maximum(np.abs(mx.cpu().numpy()), np.abs(mn.cpu().numpy()))[:m].astype(np.float64)
+        aux = np.ones(L)
+        aux[:m] = cmax
+        XtP = engine.panel_rot_step(ctx, Xn, _dev(_pad(R, L), Xn), _dev(aux, Xn), 1, float(power)).cpu().numpy()[:m, :m]
+        XtX = R.T @ S @ R
+        Lm = np.linalg.inv(XtX) @ XtP
+        try:
+            sigma_inv = np.diag(np.diag(np.linalg.inv(Lm.T @ Lm)))
+        except np.linalg.LinAlgError:
+            sigma_inv = np.diag(np.diag(np.linalg.pinv(Lm.T @ Lm)))
+        Lm = Lm @ np.sqrt(sigma_inv)
+        rot_mat = R @ Lm
+        L_inv = np.linalg.inv(Lm)
+        phi = L_inv @ L_inv.T
+    Xrot = engine.panel_matmul(ctx, Lp, _dev(_pad(rot_mat, L), Lp))   # (h Xn) rot_mat = loadings rot_mat
+    return engine.panel_export(ctx, Xrot, p, m), rot_mat, phi
