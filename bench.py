@@ -183,8 +183,12 @@ def main():
         a = time.perf_counter()
         # the sketch (sklearn's RandomState stream, host) is drawn while the preprocess kernels run
         omega = engine.SketchFuture(min(n, P), k + N_OVERSAMPLES, 5)
-        mat, st = engine.preprocess(ctx, Xraw, center=True, standardize=False, feature_weights=None,
-                                    want_stats=False)
+        if world == 1 and not args.force_sharded:
+            mat, st = engine.preprocess(ctx, Xraw, center=True, standardize=False, feature_weights=None,
+                                        want_stats=False)
+        else:   # + the global facts: valid-sample mask / isolated-NaN check, feature offsets, total variance
+            mat, st = sharded.sharded_preprocess(ctx, Xraw, comm, center=True, standardize=False,
+                                                 feature_weights=None, want_stats=False)
         torch.cuda.synchronize()
         b = time.perf_counter()
         if world == 1 and not args.force_sharded:

@@ -196,6 +196,11 @@ int eofx_hilbert_f32(eofx_ctx *ctx, const eofx_mat *a, int padding, double decay
                      eofx_mat **out_imag, eofx_mat **out_real);
 /* sum of squares of the resident matrix (float64, fixed reduction tree).                     */
 int eofx_mat_sumsq_f64(eofx_ctx *ctx, const eofx_mat *m, double *out);
+/* Sample-space Gram matrix G[n_pad x n_pad] = X X^T (float32, device) of a resident matrix and the
+ * float64 dot product of two device float arrays: the two pieces of the total squared covariance
+ * sum(|X^T Y|^2) = <X X^T, Y Y^T> (cross/cpcca.py:991-1000) when X and Y are sharded over GPUs.  */
+int eofx_mat_sample_gram_f32(eofx_ctx *ctx, const eofx_mat *m, float *G);
+int eofx_vec_dot_f64(eofx_ctx *ctx, const float *a, const float *b, int64_t count, double *out);
 /* Complex panels are real panels [Re | Im] (Re in columns [0, L/2), Im in [L/2, L)).
  * With P1 = op(A) W and P2 = op(B) W for a complex matrix Z = A + iB (A, B real resident):
  *   conj_left = 1:  out = Z^H W :  out.re = P1.re + P2.im, out.im = P1.im - P2.re

@@ -133,3 +133,30 @@ def test_two_rank_sharded_path_on_one_gpu(ctx):
     assert len(two.stdout.strip().splitlines()) == 1 and len(one.stdout.strip().splitlines()) == 1  # ONE JSON line
     assert np.allclose(d2["parity"]["s_head"], d1["parity"]["s_head"], rtol=2e-6)
     assert d2["parity"]["XV_eq_Us_relerr"] < 1e-5 and d2["parity"]["orth_V_maxabs"] < 1e-6
+
+
+@pytest.mark.parametrize("nan", [False, True])
+def test_two_rank_sharded_mca_and_eof_on_one_gpu(ctx, nan):
+    """SURVEY.md §8e (rows C3 + preprocess facts): two processes share cuda:0, each holds half of each
+    field's space axis; `sharded_mca_fit` / `sharded_eof_fit` (HIP kernels + gloo all-reduces) against the
+    single-GPU drivers on the whole fields.  Tolerances: float32 summation-order differences only."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29519", os.path.join(root, "tools", "sharded_mca_worker.py"),
+           "--backend", "gloo", "--same-gpu"] + (["--nan"] if nan else [])
+    run = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    assert run.returncode == 0, run.stderr[-3000:]
+    d = json.loads([ln for ln in run.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert d["world"] == 2 and d["p_total"] == [d["p1"], d["p2"]]
+    if nan:
+        assert d["n_valid"] == 699 and d["p1"] < 5000 and d["p2"] < 3600
+    assert d["mca_s"] < 2e-5 and d["eof_s"] < 2e-5
+    assert d["mca_q1_cos"] > 1 - 1e-5 and d["mca_q2_cos"] > 1 - 1e-5 and d["eof_v_cos"] > 1 - 1e-5
+    assert d["mca_scores1"] < 1e-4 and d["mca_scores2"] < 1e-4 and d["eof_scores"] < 1e-4
+    assert d["mca_norm1"] < 1e-4 and d["mca_tsc"] < 1e-5 and d["eof_tv"] < 1e-6

@@ -80,6 +80,14 @@ class NumpyPanelOps:
         w, V = np.linalg.eigh(G)
         return w[::-1], V[:, ::-1]
 
+    def sample_gram(self):
+        G = np.zeros((self.n_pad, self.n_pad), np.float32)
+        G[:self.n, :self.n] = self.X.astype(np.float64) @ self.X.T.astype(np.float64)
+        return self._t(G)
+
+    def dot(self, a, b):
+        return float(np.dot(a.numpy().ravel().astype(np.float64), b.numpy().ravel().astype(np.float64)))
+
 
 def _field(n, p, seed):
     rng = np.random.default_rng(seed)
@@ -256,3 +264,100 @@ def test_sharded_complex_rsvd_two_ranks_gloo(tmp_path, n, p, k):
         assert abs(np.vdot(Ue[:, j], U[:, j])) >= 1 - 1e-4
     # global (cross-rank) sign rule of the reference: already satisfied by the assembled V
     assert (orc.deterministic_sign_multiplier(V.conj().T) == 1).all()
+
+
+# --------------------------------------------------------------------------- cross-covariance path, 2 ranks
+def _xy(n, p1, p2):
+    rng = np.random.default_rng(9)
+    t = rng.standard_normal((n, 6)) * (5.0 * 0.7 ** np.arange(6))
+    X = t @ rng.standard_normal((6, p1)) + 0.5 * rng.standard_normal((n, p1))
+    Y = t @ rng.standard_normal((6, p2)) + 0.5 * rng.standard_normal((n, p2))
+    return (X - X.mean(0)).astype(np.float32), (Y - Y.mean(0)).astype(np.float32)
+
+
+def _cross_worker(rank, world, port, n, p1, p2, k, seed, out_dir):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from xeofs_amd import sharded
+
+    X, Y = _xy(n, p1, p2)
+    lo1, hi1 = sharded.shard_bounds(p1, world, rank)
+    lo2, hi2 = sharded.shard_bounds(p2, world, rank)
+    out = sharded.sharded_crosscov_rsvd(NumpyPanelOps(X[:, lo1:hi1]), NumpyPanelOps(Y[:, lo2:hi2]), sharded.Comm(),
+                                        k, p1, lo1, p2, lo2, random_state=seed)
+    np.savez(os.path.join(out_dir, f"c{rank}.npz"), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,p1,p2,k", [(80, 300, 420, 4), (80, 420, 300, 4)])
+def test_sharded_crosscov_two_ranks_gloo(tmp_path, n, p1, p2, k):
+    """X and Y sharded on their own feature axes; result = the oracle's MCA."""
+    import torch.multiprocessing as mp
+
+    from oracle import eof_oracle as orc
+
+    seed = 4
+    mp.spawn(_cross_worker, args=(2, _free_port(), n, p1, p2, k, seed, str(tmp_path)), nprocs=2, join=True)
+    parts = [np.load(tmp_path / f"c{r}.npz") for r in range(2)]
+    for key in ("s", "scores1", "scores2", "norm1", "norm2", "total_squared_covariance"):
+        assert np.array_equal(parts[0][key], parts[1][key]), key        # replicated bitwise
+    Q1 = np.concatenate([q["Q1"] for q in parts], axis=0)
+    Q2 = np.concatenate([q["Q2"] for q in parts], axis=0)
+    X, Y = _xy(n, p1, p2)
+    ref = orc.mca_fit(X.astype(np.float64), Y.astype(np.float64), k, random_state=seed, solver="randomized")
+    so = ref["singular_values"]
+    assert np.all(np.abs(parts[0]["s"] - so) <= 5e-5 * so[0])
+    tsc = float(parts[0]["total_squared_covariance"])
+    assert abs(tsc - ref["total_squared_covariance"]) <= 1e-4 * ref["total_squared_covariance"]
+    for j in range(k):
+        assert np.dot(Q1[:, j].astype(np.float64), ref["components1"][:, j]) >= 1 - 1e-4, j
+        assert np.dot(Q2[:, j].astype(np.float64), ref["components2"][:, j]) >= 1 - 1e-4, j
+    assert np.allclose(parts[0]["scores1"], ref["scores1"], atol=2e-3 * np.abs(ref["scores1"]).max())
+    assert np.allclose(parts[0]["scores2"], ref["scores2"], atol=2e-3 * np.abs(ref["scores2"]).max())
+    assert np.allclose(parts[0]["norm1"], ref["norm1"], rtol=1e-3)
+    assert np.allclose(parts[0]["norm2"], ref["norm2"], rtol=1e-3)
+
+
+def _mask_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from xeofs_amd import sharded
+
+    comm = sharded.Comm()
+    res = {}
+    base = np.array([True, True, False, True])
+    res["same"] = sharded.combine_sample_masks(comm, base, 5)
+    # rank 1 owns only all-NaN features: it does not vote
+    res["empty_shard"] = sharded.combine_sample_masks(comm, base if rank == 0 else np.zeros(4, bool),
+                                                      5 if rank == 0 else 0)
+    other = base.copy()
+    if rank == 1:
+        other[1] = False        # sample 1 is all-NaN in rank 1's features only -> isolated NaNs globally
+    try:
+        sharded.combine_sample_masks(comm, other, 5)
+        res["partial"] = "no error"
+    except ValueError as e:
+        res["partial"] = str(e)
+    res["partial_unchecked"] = sharded.combine_sample_masks(comm, other, 5, check_nans=False)
+    np.savez(os.path.join(out_dir, f"m{rank}.npz"), **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_combine_sample_masks_two_ranks_gloo(tmp_path):
+    import torch.multiprocessing as mp
+
+    mp.spawn(_mask_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        m = np.load(tmp_path / f"m{r}.npz")
+        assert m["same"].tolist() == [True, True, False, True]
+        assert m["empty_shard"].tolist() == [True, True, False, True]
+        assert "partial NaN entries" in str(m["partial"])
+        assert m["partial_unchecked"].tolist() == [True, True, False, True]

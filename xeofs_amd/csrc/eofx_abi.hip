@@ -1314,6 +1314,43 @@ extern "C" int eofx_reconstruct_f32(eofx_ctx* ctx, const float* S, const float* 
   return EOFX_OK;
 }
 
+// n_pad x n_pad sample-space Gram matrix X X^T of a resident matrix (float32, through the atb kernel)
+static int sample_gram(eofx_ctx* ctx, const eofx_mat* m, float* G) {
+  const int64_t npad = m->n_pad;
+  return launch_atb(ctx, m->Xt, npad, round_up(m->p, ATB_KG), npad, m->Xt, (int)npad, (int)npad, G, ctx->prec_final,
+                    m->absmax, reinterpret_cast<const float*>(m->absmax_dev));
+}
+
+// <a, b> over `count` floats, float64 accumulation, fixed reduction tree
+static int device_dot(eofx_ctx* ctx, const float* a, const float* b, int64_t count, double* out) {
+  const int nb = 1024;
+  CHK(arena_reserve(ctx, nb * sizeof(double) + 4096));
+  ArenaScope scope(ctx);
+  ARENA(double, part, nb);
+  hipLaunchKernelGGL(dotprod_part_kernel, dim3(nb), dim3(256), 0, ctx->stream, a, b, count, part);
+  KCHK();
+  std::vector<double> hp(nb);
+  HIPCHK(hipMemcpyAsync(hp.data(), part, sizeof(double) * nb, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  double t = 0.0;
+  for (int i = 0; i < nb; ++i) t += hp[i];
+  *out = t;
+  return EOFX_OK;
+}
+
+extern "C" int eofx_mat_sample_gram_f32(eofx_ctx* ctx, const eofx_mat* m, float* G) {
+  if (!ctx || !m || !G) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  CHK(set_device(ctx));
+  CHK(arena_reserve(ctx, atb_scratch_bytes(m->n_pad, m->p_pad, (int)m->n_pad) + (1 << 20)));
+  return sample_gram(ctx, m, G);
+}
+
+extern "C" int eofx_vec_dot_f64(eofx_ctx* ctx, const float* a, const float* b, int64_t count, double* out) {
+  if (!ctx || !a || !b || !out || count < 0) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  CHK(set_device(ctx));
+  return device_dot(ctx, a, b, count, out);
+}
+
 // ------------------------------------------------------------------------------------
 // cross-covariance path (MCA): matrix-free rSVD of C = X^T Y / (n-1)
 // ------------------------------------------------------------------------------------
@@ -1406,19 +1443,10 @@ extern "C" int eofx_crosscov_rsvd_f32(eofx_ctx* ctx, const eofx_mat* x, const eo
   if (tsc) {
     ARENA(float, Gx, (size_t)npad * npad);
     ARENA(float, Gy, (size_t)npad * npad);
-    CHK(launch_atb(ctx, x->Xt, npad, round_up(p1, ATB_KG), npad, x->Xt, (int)npad, (int)npad, Gx, ctx->prec_final, x->absmax,
-                   reinterpret_cast<const float*>(x->absmax_dev)));
-    CHK(launch_atb(ctx, y->Xt, npad, round_up(p2, ATB_KG), npad, y->Xt, (int)npad, (int)npad, Gy, ctx->prec_final, y->absmax,
-                   reinterpret_cast<const float*>(y->absmax_dev)));
-    const int nb = 1024;
-    ARENA(double, part, nb);
-    hipLaunchKernelGGL(dotprod_part_kernel, dim3(nb), dim3(256), 0, ctx->stream, Gx, Gy, npad * npad, part);
-    KCHK();
-    std::vector<double> hp(nb);
-    HIPCHK(hipMemcpyAsync(hp.data(), part, sizeof(double) * nb, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    CHK(sample_gram(ctx, x, Gx));
+    CHK(sample_gram(ctx, y, Gy));
     double t = 0.0;
-    for (int i = 0; i < nb; ++i) t += hp[i];
+    CHK(device_dot(ctx, Gx, Gy, npad * npad, &t));
     *tsc = t / ((double)(n - 1) * (double)(n - 1));
   }
   HIPCHK(hipStreamSynchronize(ctx->stream));

@@ -111,6 +111,13 @@ class ResidentMatrix:
         raise_for(self.ctx.lib.eofx_mat_sumsq_f64(self.ctx.handle, self.handle, C.byref(out)), self.ctx.handle)
         return out.value
 
+    def sample_gram(self):
+        """X X^T as an [n_pad, n_pad] float32 device tensor (rows/columns beyond n are zero)."""
+        torch = _torch()
+        G = torch.empty((self.n_pad, self.n_pad), dtype=torch.float32, device=f"cuda:{self.ctx.device}")
+        raise_for(self.ctx.lib.eofx_mat_sample_gram_f32(self.ctx.handle, self.handle, ptr(G)), self.ctx.handle)
+        return G
+
     def free(self):
         if getattr(self, "handle", None) and getattr(self.ctx, "handle", None):
             self.ctx.lib.eofx_mat_destroy(self.ctx.handle, self.handle)
@@ -443,3 +450,10 @@ def panel_rot_step(ctx: Context, X, R, aux, mode: int, power: float = 1.0):
     raise_for(ctx.lib.eofx_panel_rot_step_f64(ctx.handle, ptr(X), X.shape[0], L, ptr(R), ptr(aux), int(mode),
                                               float(power), ptr(G)), ctx.handle)
     return G
+
+
+def vec_dot(ctx: Context, a, b) -> float:
+    """float64 dot product of two equally sized float32 device tensors (fixed reduction tree)"""
+    out = C.c_double()
+    raise_for(ctx.lib.eofx_vec_dot_f64(ctx.handle, ptr(a), ptr(b), a.numel(), C.byref(out)), ctx.handle)
+    return out.value

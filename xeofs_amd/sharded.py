@@ -92,10 +92,77 @@ class HipPanelOps:
     def eigh(self, G):
         return self.e.host_eigh(G)
 
+    def sample_gram(self):             # X_g X_g^T, [n_pad, n_pad] float32 on the device
+        return self.mat.sample_gram()
+
+    def dot(self, a, b):
+        return self.e.vec_dot(self.ctx, a, b)
+
 
 def rsvd_auto_iters(k, n, p):
     """sklearn extmath._randomized_svd: 7 if n_components < 0.1 * min(M.shape) else 4."""
     return 7 if k < 0.1 * min(n, p) else 4
+
+
+def _resolve_sketch(k, r, n_oversamples, omega, random_state):
+    """sketch width policy shared by the drivers: l = min(k + n_oversamples, rank); a full-width sketch
+    spans everything, so the identity replaces an (occasionally ill-conditioned) square Gaussian"""
+    from .engine import sketch_matrix
+
+    if k > r:
+        raise ValueError(f"n_modes must be less than or equal to the rank of the dataset (rank = {r}).")
+    l_req = k + n_oversamples
+    l = min(l_req, r)
+    if omega is None:
+        omega = sketch_matrix(r, l_req, random_state)
+    omega = np.ascontiguousarray(omega[:, :l], dtype=np.float32)
+    if l == r:
+        omega = np.eye(r, dtype=np.float32)
+    return omega, l
+
+
+def _rsvd_panels(la, to_tall, to_small, gram_small, gram_tall, Z, l, k, n_iter):
+    """The pass sequence of `rsvd_core` (csrc/eofx_abi.hip) on abstract products.
+
+    `to_tall(P, final)` / `to_small(P, final)` apply A / A^T to a panel (including whatever reduction
+    the sharding needs), `gram_*` return the globally reduced L x L float64 Gram matrix of a panel on
+    that side, `la` supplies the matrix-independent steps (cholqr, matmul, eigh).  Returns the
+    singular-vector panels (tall side, small side) and the k singular values (float64).
+    """
+    for _ in range(int(n_iter)):
+        Yt = to_tall(Z, False)
+        W = to_small(Yt, False)
+        Z = la.cholqr(W, l, gram_small(W))
+    Yt = to_tall(Z, False)                       # range basis: a subspace only, power-pass precision
+    Q = la.cholqr(Yt, l, gram_tall(Yt))
+    Q = la.cholqr(Q, l, gram_tall(Q))            # CholeskyQR2
+    Bt = to_small(Q, True)
+    G = gram_small(Bt)
+    Gh = G.detach().cpu().numpy()[:l, :l]
+    Gh = 0.5 * (Gh + Gh.T)
+    if not np.isfinite(Gh).all():
+        raise np.linalg.LinAlgError("SVD failed. This may be due to isolated NaN values in the data.")
+    w, Uh = la.eigh(Gh)
+    s = np.sqrt(np.maximum(w[:k], 0.0))
+    L = Z.shape[1]
+    Lo = (k + 31) // 32 * 32
+    M1 = np.zeros((L, Lo))
+    M2 = np.zeros((L, Lo))
+    M1[:l, :k] = Uh[:, :k]
+    with np.errstate(divide="ignore"):
+        inv = np.where(s > 0, 1.0 / s, 0.0)
+    M2[:l, :k] = Uh[:, :k] * inv
+    Tv = la.matmul(Q, M1)       # singular vectors on the tall side
+    Sv = la.matmul(Bt, M2)      # singular vectors on the small side
+    return Tv, Sv, s
+
+
+def _sign_from_extrema(comm, ops, Vp, rows, k):
+    """xeofs sign rule (utils/xarray_utils.py:273-301): global per-mode max / min over all shards"""
+    mx, mn = ops.colminmax(Vp, rows)
+    mx, mn = comm.max_(mx), comm.min_(mn)
+    mxh, mnh = mx.detach().cpu().numpy()[:k], mn.detach().cpu().numpy()[:k]
+    return np.where(np.abs(mxh) >= np.abs(mnh), 1.0, -1.0)
 
 
 def sharded_rsvd(ops, comm: Comm, k: int, p_total: int, p_offset: int, n_oversamples: int = 10,
@@ -106,21 +173,10 @@ def sharded_rsvd(ops, comm: Comm, k: int, p_total: int, p_offset: int, n_oversam
     `omega` is the global sketch matrix (min(n, p_total) x (k + n_oversamples)), identical
     on every rank (same seed), drawn as scikit-learn does.
     """
-    from .engine import sketch_matrix
-
     n, p_loc = ops.n, ops.p
-    r = min(n, p_total)
-    if k > r:
-        raise ValueError(f"n_modes must be less than or equal to the rank of the dataset (rank = {r}).")
-    l_req = k + n_oversamples
-    l = min(l_req, r)
+    omega, l = _resolve_sketch(k, min(n, p_total), n_oversamples, omega, random_state)
     if n_iter == "auto" or n_iter is None or (isinstance(n_iter, int) and n_iter < 0):
         n_iter = rsvd_auto_iters(k, n, p_total)
-    if omega is None:
-        omega = sketch_matrix(r, l_req, random_state)
-    omega = np.ascontiguousarray(omega[:, :l], dtype=np.float32)
-    if l == r:      # full-width sketch spans everything: identity instead of an (ill-conditioned) square Gaussian
-        omega = np.eye(r, dtype=np.float32)
     transposed = n < p_total   # A = X^T: tall side = features (sharded), small side = samples
 
     # side bookkeeping: "n" panels are replicated, "p" panels are sharded by rows
@@ -131,7 +187,7 @@ def sharded_rsvd(ops, comm: Comm, k: int, p_total: int, p_offset: int, n_oversam
         small, tall = "p", "n"
         Z = ops.import_panel(omega[p_offset:p_offset + p_loc], "p")
 
-    def to_side(P, side, final=False):
+    def to_side(P, side, final):
         """product that lands on `side` from a panel on the other side; `final` selects the
         precision of the last two passes (eofx_ctx_set_precision)"""
         if side == "p":
@@ -142,38 +198,10 @@ def sharded_rsvd(ops, comm: Comm, k: int, p_total: int, p_offset: int, n_oversam
         G = ops.gram(P)
         return comm.sum_(G) if side == "p" else G
 
-    for _ in range(int(n_iter)):
-        Yt = to_side(Z, tall)
-        W = to_side(Yt, small)
-        Z = ops.cholqr(W, l, gram(W, small))
-    Yt = to_side(Z, tall)                        # range basis: a subspace only, power-pass precision
-    Q = ops.cholqr(Yt, l, gram(Yt, tall))
-    Q = ops.cholqr(Q, l, gram(Q, tall))          # CholeskyQR2
-    Bt = to_side(Q, small, True)
-    G = gram(Bt, small)
-    Gh = G.detach().cpu().numpy()[:l, :l]
-    Gh = 0.5 * (Gh + Gh.T)
-    if not np.isfinite(Gh).all():
-        raise np.linalg.LinAlgError("SVD failed. This may be due to isolated NaN values in the data.")
-    w, Uh = ops.eigh(Gh)
-    s = np.sqrt(np.maximum(w[:k], 0.0))
-    L = Z.shape[1]
-    Lo = (k + 31) // 32 * 32
-    M1 = np.zeros((L, Lo))
-    M2 = np.zeros((L, Lo))
-    M1[:l, :k] = Uh[:, :k]
-    with np.errstate(divide="ignore"):
-        inv = np.where(s > 0, 1.0 / s, 0.0)
-    M2[:l, :k] = Uh[:, :k] * inv
-    Tv = ops.matmul(Q, M1)      # singular vectors on the tall side
-    Sv = ops.matmul(Bt, M2)     # singular vectors on the small side
+    Tv, Sv, s = _rsvd_panels(ops, lambda P, f: to_side(P, tall, f), lambda P, f: to_side(P, small, f),
+                             lambda P: gram(P, small), lambda P: gram(P, tall), Z, l, k, n_iter)
     Vp, Up = (Tv, Sv) if transposed else (Sv, Tv)
-    sign = None
-    if flip:  # xeofs sign rule on VT: global per-mode max / min over all features
-        mx, mn = ops.colminmax(Vp, p_loc)
-        mx, mn = comm.max_(mx), comm.min_(mn)
-        mxh, mnh = mx.detach().cpu().numpy()[:k], mn.detach().cpu().numpy()[:k]
-        sign = np.where(np.abs(mxh) >= np.abs(mnh), 1.0, -1.0)
+    sign = _sign_from_extrema(comm, ops, Vp, p_loc, k) if flip else None
     if device_out:   # results stay in HBM (torch tensors); nothing crosses PCIe
         U = ops.export(Up, n, k, sign, True)
         V = ops.export(Vp, p_loc, k, sign, True)
@@ -181,6 +209,165 @@ def sharded_rsvd(ops, comm: Comm, k: int, p_total: int, p_offset: int, n_oversam
         U = ops.export(Up, n, k, sign)
         V = ops.export(Vp, p_loc, k, sign)
     return U, s.astype(np.float32), V
+
+
+def sharded_crosscov_rsvd(opsx, opsy, comm: Comm, k: int, p1_total: int, p1_offset: int, p2_total: int,
+                          p2_offset: int, n_oversamples: int = 10, n_iter="auto", random_state=None,
+                          flip: bool = True, omega=None, want_tsc: bool = True):
+    """Matrix-free randomized SVD of C = X^T Y / (n - 1) (cross/cpcca.py:168-225, `eofx_crosscov_rsvd_f32`)
+    with X and Y each sharded along their own feature axis.
+
+    Rank g holds X_g (n x p1_g) and Y_g (n x p2_g).  C Z = X^T (Y Z): the inner product Y Z is a sum
+    over Y's shards (all-reduce of the n x L panel), the outer product is local to X's shards; the
+    same for C^T.  Both sides of C are sharded, so every Gram matrix is all-reduced (L x L float64).
+    Returns a dict like `engine.crosscov_rsvd`: Q1 / Q2 are this rank's rows, everything else is
+    replicated.
+    """
+    n = opsx.n
+    if opsy.n != n:
+        raise ValueError("Both data matrices must have the same number of samples but found "
+                         f"{n} in the first and {opsy.n} in the second.")
+    omega, l = _resolve_sketch(k, min(p1_total, p2_total), n_oversamples, omega, random_state)
+    if n_iter == "auto" or n_iter is None or (isinstance(n_iter, int) and n_iter < 0):
+        n_iter = rsvd_auto_iters(k, p1_total, p2_total)
+    transposed = p1_total < p2_total            # C is p1 x p2: sklearn works on C^T when rows < cols
+
+    def c_mul(Z2, final):                        # C Z2 -> p1 side
+        return opsx.tmul(comm.sum_(opsy.mul(Z2, final)), final)
+
+    def ct_mul(Z1, final):                       # C^T Z1 -> p2 side
+        return opsy.tmul(comm.sum_(opsx.mul(Z1, final)), final)
+
+    def gram(P):
+        return comm.sum_(opsx.gram(P))
+
+    if transposed:       # A = C^T (p2 x p1): small side = p1 (X's features)
+        Z = opsx.import_panel(omega[p1_offset:p1_offset + opsx.p], "p")
+        Tv, Sv, s = _rsvd_panels(opsx, ct_mul, c_mul, gram, gram, Z, l, k, n_iter)
+        Q1p, Q2p = Sv, Tv
+    else:                # A = C (p1 x p2): small side = p2 (Y's features)
+        Z = opsy.import_panel(omega[p2_offset:p2_offset + opsy.p], "p")
+        Tv, Sv, s = _rsvd_panels(opsx, c_mul, ct_mul, gram, gram, Z, l, k, n_iter)
+        Q1p, Q2p = Tv, Sv
+    sign = _sign_from_extrema(comm, opsy, Q2p, opsy.p, k) if flip else None
+    out = dict(s=(s / (n - 1)).astype(np.float32), Q1=opsx.export(Q1p, opsx.p, k, sign),
+               Q2=opsy.export(Q2p, opsy.p, k, sign))
+    # scores = X Q1, Y Q2 (sum over the feature shards) and their norms (cpcca.py:204-208)
+    for name, ops, Qp in (("1", opsx, Q1p), ("2", opsy, Q2p)):
+        Sn = comm.sum_(ops.mul(Qp, True))
+        out["scores" + name] = ops.export(Sn, n, k, sign)
+        g = ops.gram(Sn).detach().cpu().numpy()
+        out["norm" + name] = np.sqrt(np.diag(g)[:k]).astype(np.float32)
+    if want_tsc:
+        # sum |C|^2 = <X X^T, Y Y^T> / (n-1)^2 ; X X^T = sum_g X_g X_g^T: one n x n all-reduce,
+        # then <G_x, G_y,g> locally and a scalar all-reduce (cpcca.py:991-1000)
+        import torch
+
+        Gx = comm.sum_(opsx.sample_gram())
+        t = torch.tensor([opsy.dot(Gx, opsy.sample_gram())], dtype=torch.float64, device=Gx.device)
+        out["total_squared_covariance"] = float(comm.sum_(t).cpu()[0]) / float(n - 1) ** 2
+    return out
+
+
+def combine_sample_masks(comm: Comm, valid_sample, n_valid_features: int, check_nans: bool = True):
+    """Global NaN bookkeeping of the Sanitizer (preprocessing/sanitizer.py:58-126) when the feature
+    axis is sharded: a sample is valid if it is valid in any shard; with `check_nans` a sample that is
+    all-NaN in one shard's valid features but not in another's has isolated NaNs globally, which the
+    reference rejects.  `valid_sample` is this rank's boolean mask (from `eofx_preprocess_f32` with
+    check_nans=0 semantics: any valid feature non-NaN).  Returns the global mask (numpy bool)."""
+    import torch
+
+    vs = np.asarray(valid_sample, dtype=bool)
+    dev = "cpu"
+    if comm.active and comm.dist.get_backend(comm.group) == "nccl":
+        dev = f"cuda:{torch.cuda.current_device()}"
+    cnt = torch.zeros(vs.size + 1, dtype=torch.int32, device=dev)
+    has = n_valid_features > 0
+    cnt[:-1] = torch.from_numpy((vs & has).astype(np.int32)).to(dev)
+    cnt[-1] = int(has)
+    comm.sum_(cnt)
+    cnt = cnt.cpu().numpy()
+    shards, votes = int(cnt[-1]), cnt[:-1]
+    if check_nans and np.any((votes != 0) & (votes != shards)):
+        raise ValueError("Input data contains partial NaN entries, which will cause the the SVD to fail.")
+    return votes > 0
+
+
+def _gather_counts(comm: Comm, value: int):
+    """all-gather of one integer per rank (as an all-reduce of a one-hot vector)"""
+    import torch
+
+    dev = "cpu"
+    if comm.active and comm.dist.get_backend(comm.group) == "nccl":
+        dev = f"cuda:{torch.cuda.current_device()}"
+    v = torch.zeros(max(comm.world, 1), dtype=torch.int64, device=dev)
+    v[comm.rank] = int(value)
+    return comm.sum_(v).cpu().numpy()
+
+
+def _sum_scalar(comm: Comm, value: float) -> float:
+    import torch
+
+    dev = "cpu"
+    if comm.active and comm.dist.get_backend(comm.group) == "nccl":
+        dev = f"cuda:{torch.cuda.current_device()}"
+    return float(comm.sum_(torch.tensor([value], dtype=torch.float64, device=dev)).cpu()[0])
+
+
+def sharded_preprocess(ctx, X_local, comm: Comm, center=True, standardize=False, feature_weights=None,
+                       check_nans=True, want_stats=True):
+    """Scaler + Sanitizer + total variance (rows R1-R6) of this rank's slice of the stacked feature axis.
+
+    Per-feature statistics, masks and the compaction are local (`eofx_preprocess_f32`); the global
+    facts are combined here: the valid-sample mask / isolated-NaN check
+    (`combine_sample_masks`), the number of valid features of every rank (-> this rank's offset on the
+    global valid-feature axis) and the total variance.  Returns (ResidentMatrix, stats) like
+    `engine.preprocess`, with `p_total`, `p_offset` and the global `total_variance` added.
+    """
+    from . import engine
+
+    mat, st = engine.preprocess(ctx, X_local, center=center, standardize=standardize, feature_weights=feature_weights,
+                                check_nans=check_nans, want_stats=want_stats)
+    counts = _gather_counts(comm, mat.p)
+    st["p_total"] = int(counts.sum())
+    st["p_offset"] = int(counts[:comm.rank].sum())
+    st["valid_sample"] = combine_sample_masks(comm, st["valid_sample"], mat.p, check_nans)
+    st["total_variance_local"] = st["total_variance"]
+    st["total_variance"] = _sum_scalar(comm, st["total_variance"])
+    return mat, st
+
+
+def sharded_eof_fit(ctx, X_local, comm: Comm, n_modes: int, center=True, standardize=False, feature_weights=None,
+                    check_nans=True, random_state=None, n_oversamples: int = 10, n_iter="auto", omega=None,
+                    device_out: bool = False):
+    """`EOF.fit` (single/eof.py:85-118) with the space axis sharded: X_local is this rank's
+    (n, P_g) slice of the stacked raw field.  Returns the DataContainer entries as a dict; `components`
+    holds this rank's rows, everything else is replicated."""
+    mat, st = sharded_preprocess(ctx, X_local, comm, center, standardize, feature_weights, check_nans)
+    ops = HipPanelOps(ctx, mat)
+    U, s, V = sharded_rsvd(ops, comm, n_modes, st["p_total"], st["p_offset"], n_oversamples, n_iter,
+                           random_state=random_state, omega=omega, device_out=device_out)
+    s64 = np.asarray(s, dtype=np.float64)
+    return dict(input_data=mat, components=V, scores=U * (s if not device_out else ops.e._torch().as_tensor(s, device=U.device)),
+                norms=s64, explained_variance=s64 ** 2 / (mat.n - 1), total_variance=st["total_variance"],
+                U=U, stats=st)
+
+
+def sharded_mca_fit(ctx, X_local, Y_local, comm: Comm, n_modes: int, standardize=(False, False),
+                    feature_weights=(None, None), check_nans=(True, True), random_state=None,
+                    n_oversamples: int = 10, n_iter="auto", omega=None, want_tsc: bool = True):
+    """`MCA.fit` (cross/base_model_cross_set.py:269-321 + cross/cpcca.py:168-225, use_pca=False) with
+    both fields sharded along their own space axes."""
+    mx, sx = sharded_preprocess(ctx, X_local, comm, True, standardize[0], feature_weights[0], check_nans[0])
+    my, sy = sharded_preprocess(ctx, Y_local, comm, True, standardize[1], feature_weights[1], check_nans[1])
+    out = sharded_crosscov_rsvd(HipPanelOps(ctx, mx), HipPanelOps(ctx, my), comm, n_modes, sx["p_total"],
+                                sx["p_offset"], sy["p_total"], sy["p_offset"], n_oversamples, n_iter,
+                                random_state=random_state, omega=omega, want_tsc=want_tsc)
+    s = out["s"].astype(np.float64)
+    return dict(input_data1=mx, input_data2=my, components1=out["Q1"], components2=out["Q2"],
+                scores1=out["scores1"], scores2=out["scores2"], singular_values=s, squared_covariance=s ** 2,
+                total_squared_covariance=out.get("total_squared_covariance"), norm1=out["norm1"], norm2=out["norm2"],
+                stats1=sx, stats2=sy)
 
 
 def shard_bounds(p_total: int, world: int, rank: int):
