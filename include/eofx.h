@@ -196,10 +196,12 @@ int eofx_hilbert_f32(eofx_ctx *ctx, const eofx_mat *a, int padding, double decay
                      eofx_mat **out_imag, eofx_mat **out_real);
 /* sum of squares of the resident matrix (float64, fixed reduction tree).                     */
 int eofx_mat_sumsq_f64(eofx_ctx *ctx, const eofx_mat *m, double *out);
-/* Sample-space Gram matrix G[n_pad x n_pad] = X X^T (float32, device) of a resident matrix and the
- * float64 dot product of two device float arrays: the two pieces of the total squared covariance
- * sum(|X^T Y|^2) = <X X^T, Y Y^T> (cross/cpcca.py:991-1000) when X and Y are sharded over GPUs.  */
-int eofx_mat_sample_gram_f32(eofx_ctx *ctx, const eofx_mat *m, float *G);
+/* Gram matrix of a resident matrix (float32, device): side 0 = sample space G[n_pad x n_pad] = X X^T,
+ * side 1 = feature space G[p_pad x p_pad] = X^T X (rows/columns beyond n / p are zero).  Used for
+ * (a) the total squared covariance sum(|X^T Y|^2) = <X X^T, Y Y^T> (cross/cpcca.py:991-1000) when X and
+ * Y are sharded over GPUs (with eofx_vec_dot_f64), (b) the exact PCA pre-reduction of the cross models
+ * (preprocessing/pca.py:94-123): eigenvectors of the small-side Gram matrix span the PCA subspace.   */
+int eofx_mat_gram_f32(eofx_ctx *ctx, const eofx_mat *m, int side, float *G);
 int eofx_vec_dot_f64(eofx_ctx *ctx, const float *a, const float *b, int64_t count, double *out);
 /* Complex panels are real panels [Re | Im] (Re in columns [0, L/2), Im in [L/2, L)).
  * With P1 = op(A) W and P2 = op(B) W for a complex matrix Z = A + iB (A, B real resident):

@@ -358,14 +358,34 @@ def cross_covariance(X, Y):
     return X.conj().T @ Y / (X.shape[0] - 1)
 
 
+def pca_fit(Xc, n_modes=0.999, init_rank_reduction=0.3, random_state=None):
+    """xeofs/preprocessing/pca.py:94-123: `SVD(n_modes, init_rank_reduction, random_state).fit_transform`
+    (xeofs/linalg/_numpy/_svd.py:108-241 -- the same solver policy, sign rule and variance truncation as
+    the Decomposer, restated in `decomposer_fit`).  The cross models build their PCA without a
+    random_state (cross/base_model_cross_set.py:165-179), i.e. the reference's own result is only
+    reproducible to the convergence of the randomized solver.  Returns (scores = X V, V, s)."""
+    if isinstance(n_modes, str):
+        if n_modes != "all":
+            raise ValueError("`n_modes` must be an integer, float or 'all'")
+        n_modes = min(Xc.shape)
+    U, s, V = decomposer_fit(Xc, n_modes, init_rank_reduction=init_rank_reduction, random_state=random_state)
+    return Xc @ V, V, s
+
+
 def mca_fit(X, Y, n_modes, standardize=False, feature_weights_x=None, feature_weights_y=None,
-            random_state=None, solver="auto", solver_kwargs=None, check_nans=True):
-    """xeofs/cross/base_model_cross_set.py:269-321 with use_pca=False, alpha=1
-    (MCA, cross/mca.py:107) + xeofs/cross/cpcca.py:168-225.  CPCCA always
-    centres (cpcca.py:145)."""
+            random_state=None, solver="auto", solver_kwargs=None, check_nans=True, use_pca=False,
+            n_pca_modes=0.999, pca_init_rank_reduction=0.3, pca_random_state=None):
+    """xeofs/cross/base_model_cross_set.py:269-321 with alpha=1 (MCA, cross/mca.py:107) +
+    xeofs/cross/cpcca.py:168-225.  CPCCA always centres (cpcca.py:145).  With `use_pca` the
+    analysis runs on the PC scores and the singular vectors are projected back
+    (preprocessing/pca.py:125-168)."""
     px = preprocess(X, True, standardize, feature_weights_x, check_nans)
     py = preprocess(Y, True, standardize, feature_weights_y, check_nans)
     Xc, Yc = px["X"], py["X"]
+    V1 = V2 = None
+    if use_pca:
+        Xc, V1, _ = pca_fit(Xc, n_pca_modes, pca_init_rank_reduction, pca_random_state)
+        Yc, V2, _ = pca_fit(Yc, n_pca_modes, pca_init_rank_reduction, pca_random_state)
     C = cross_covariance(Xc, Yc)
     Q1, s, Q2 = decomposer_fit(C, n_modes, random_state=random_state, solver=solver,
                                solver_kwargs=solver_kwargs)
@@ -375,10 +395,11 @@ def mca_fit(X, Y, n_modes, standardize=False, feature_weights_x=None, feature_we
     norm1 = np.sqrt((scores1.conj() * scores1).sum(axis=0)).real
     norm2 = np.sqrt((scores2.conj() * scores2).sum(axis=0)).real
     return dict(
-        input_data1=Xc, input_data2=Yc, components1=Q1, components2=Q2,
+        input_data1=Xc, input_data2=Yc, components1=Q1 if V1 is None else V1 @ Q1,
+        components2=Q2 if V2 is None else V2 @ Q2,
         scores1=scores1, scores2=scores2, singular_values=s, squared_covariance=s ** 2,
         total_squared_covariance=tsc, idx_modes_sorted=np.argsort(s)[::-1],
-        norm1=norm1, norm2=norm2, C=C, pre_x=px, pre_y=py,
+        norm1=norm1, norm2=norm2, C=C, pre_x=px, pre_y=py, pca_modes=(Xc.shape[1], Yc.shape[1]),
     )
 
 

@@ -1,0 +1,155 @@
+"""GPU parity of the PCA pre-reduction path: `eofx_mat_gram_f32`,
+`xeofs_amd.pca.ResidentPCA`, `MCA(use_pca=True)` against the oracle restatement of
+xeofs/preprocessing/pca.py + xeofs/linalg/_numpy/_svd.py (exact SVD here: the reference's PCA is an unseeded
+randomized SVD, so its own output is only defined to that solver's convergence)."""
+
+import warnings
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import eof_oracle as orc  # noqa: E402  (checker only)
+
+
+def _field(n, p, seed, rank=12, noise=0.3):
+    rng = np.random.default_rng(seed)
+    T = rng.standard_normal((n, rank)) * (5.0 * 0.8 ** np.arange(rank))
+    X = T @ rng.standard_normal((rank, p)) + noise * rng.standard_normal((n, p))
+    return (X - X.mean(0)).astype(np.float32)
+
+
+@pytest.mark.parametrize("n,p", [(300, 2000), (700, 5200), (900, 260)])
+def test_mat_gram_both_sides(ctx, n, p):
+    from xeofs_amd import engine
+
+    X = _field(n, p, 0)
+    mat = engine.from_dense(ctx, X)
+    X64 = X.astype(np.float64)
+    for side, ref in ((0, X64 @ X64.T), (1, X64.T @ X64)):
+        G = mat.gram(side).cpu().numpy()
+        d = ref.shape[0]
+        assert np.abs(G[:d, :d] - ref).max() <= 2e-6 * np.abs(ref).max()     # float32-class products
+        assert not G[d:].any() and not G[:, d:].any()
+    mat.free()
+
+
+@pytest.mark.parametrize("n,p,n_modes", [(400, 3000, 0.999), (400, 3000, 0.9), (400, 3000, 25), (1000, 300, 0.99),
+                                         (120, 900, "all")])
+def test_resident_pca_vs_exact_svd(ctx, n, p, n_modes):
+    from xeofs_amd import engine
+    from xeofs_amd.pca import ResidentPCA
+
+    X = _field(n, p, 1)
+    mat = engine.from_dense(ctx, X)
+    X64 = X.astype(np.float64)
+    tv = orc.total_variance(X64)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        pca = ResidentPCA(ctx, n_modes).fit(mat, tv)
+        # the reference's policy with an exact solver: same n_modes_precompute, same truncation rule
+        nm = min(n, p) if n_modes == "all" else n_modes
+        U, s, V = orc.decomposer_fit(X64, nm, solver="full")
+    m = len(s)
+    assert pca.m == m
+    keep = s > 1e-3 * s[0]          # ("all" reaches the numerically zero tail of centred data)
+    assert np.allclose(pca.s[keep], s[keep], rtol=2e-5)
+    Vg = pca.components().astype(np.float64)
+    assert np.abs(Vg[:, keep].T @ Vg[:, keep] - np.eye(keep.sum())).max() < 2e-5
+    gaps = np.minimum(np.abs(np.diff(s, prepend=np.inf)), np.abs(np.diff(s, append=0.0))) / s[0]
+    for j in np.nonzero(keep & (gaps > 1e-3))[0]:
+        assert np.dot(Vg[:, j], V[:, j]) > 1 - 1e-4, j                       # same sign convention too
+    sc = pca.scores()
+    assert np.allclose(sc[:, keep], (X64 @ Vg)[:, keep], atol=2e-4 * s[0])
+    # transform on the training matrix reproduces the scores; back-projection is V Q
+    assert np.allclose(pca.transform(mat)[:, keep], sc[:, keep], atol=2e-4 * s[0])
+    Q = np.linalg.qr(np.random.default_rng(3).standard_normal((m, 3)))[0]
+    assert np.allclose(pca.back_project(Q), Vg @ Q, atol=1e-5)
+    mat.free()
+
+
+def test_pca_variance_warning_and_errors(ctx):
+    from xeofs_amd import engine
+    from xeofs_amd.pca import ResidentPCA
+
+    X = _field(200, 1500, 2, rank=150, noise=1.0)
+    mat = engine.from_dense(ctx, X)
+    with pytest.warns(UserWarning, match="Please consider increasing `init_rank_reduction`"):
+        p = ResidentPCA(ctx, 0.9999, init_rank_reduction=0.05).fit(mat)
+    assert p.m == int(200 * 0.05)
+    with pytest.raises(ValueError, match="rank of the dataset"):
+        ResidentPCA(ctx, 201).fit(mat)
+    with pytest.raises(ValueError, match="init_rank_reduction"):
+        ResidentPCA(ctx, 0.9, init_rank_reduction=0.0)
+    mat.free()
+
+
+@pytest.mark.parametrize("use_pca", [True, [True, False]])
+def test_mca_default_pca_route_vs_oracle(ctx, use_pca):
+    """`xe.cross.MCA()` with the reference's default arguments (use_pca=True, n_pca_modes=0.999)."""
+    import xeofs_amd as xe
+
+    rng = np.random.default_rng(5)
+    T = rng.standard_normal((150, 6)) * (3.0 * 0.7 ** np.arange(6))
+    A = (T @ rng.standard_normal((6, 24 * 30)) + 0.05 * rng.standard_normal((150, 720))).reshape(150, 24, 30)
+    B = (T @ rng.standard_normal((6, 20 * 28)) + 0.05 * rng.standard_normal((150, 560))).reshape(150, 20, 28)
+    X = xe.DataArray(A, dims=("time", "lat", "lon"))
+    Y = xe.DataArray(B, dims=("time", "y", "x"))
+    m = xe.cross.MCA(n_modes=4, random_state=7, use_pca=use_pca).fit(X, Y, "time")
+    ref = orc.mca_fit(A.reshape(150, -1), B.reshape(150, -1), 4, random_state=7, use_pca=True, pca_random_state=0)
+    if use_pca is True:
+        assert (m.pca[0].m, m.pca[1].m) == ref["pca_modes"]
+        tol = 2e-4
+    else:
+        ref = orc.mca_fit(A.reshape(150, -1), B.reshape(150, -1), 4, random_state=7, use_pca=False)
+        assert m.pca[1] is None
+        tol = 2e-3        # one field truncated at 99.9 % of its variance, the other not
+    assert np.allclose(m.singular_values().values, ref["singular_values"], rtol=tol)
+    c1, c2 = m.components()
+    C1, C2 = c1.values.reshape(4, -1).T, c2.values.reshape(4, -1).T
+    assert np.abs(C1.T @ C1 - np.eye(4)).max() < 1e-4
+    for j in range(4):
+        assert abs(np.dot(C1[:, j], ref["components1"][:, j])) > 1 - 10 * tol
+        assert abs(np.dot(C2[:, j], ref["components2"][:, j])) > 1 - 10 * tol
+    s1, s2 = m.scores()
+    t1, t2 = m.transform(X=X, Y=Y)
+    assert np.allclose(t1.values, s1.values, atol=2e-3 * np.abs(s1.values).max())
+    assert np.allclose(t2.values, s2.values, atol=2e-3 * np.abs(s2.values).max())
+    if use_pca is True:
+        sgn = np.sign(np.sum(C1 * ref["components1"], axis=0))
+        assert np.allclose(s1.values.T * sgn, ref["scores1"], atol=5e-3 * np.abs(ref["scores1"]).max())
+        assert np.isclose(m.total_squared_covariance(), ref["total_squared_covariance"], rtol=1e-4)
+
+
+@pytest.mark.parametrize("n_modes,solver", [(0.95, "auto"), (300, "randomized"), (40, "full")])
+def test_decomposer_wide_route(ctx, n_modes, solver):
+    """Decomposer requests beyond the sketch kernels' width (float n_modes -> int(0.3 * rank) modes,
+    hundreds of modes, solver='full' at rank > 256) take the exact Gram route; policy, truncation and
+    sign rule are the reference's (linalg/decomposer.py:76-226)."""
+    from xeofs_amd.linalg import Decomposer
+
+    X = _field(1000, 4000, 7, rank=30, noise=0.2)
+    X64 = X.astype(np.float64)
+    tv = orc.total_variance(X64)
+    d = Decomposer(n_modes=n_modes, solver=solver, ctx=ctx).fit(X, total_variance=tv)
+    U, s, V = orc.decomposer_fit(X64, n_modes, solver="full")
+    assert d.s_.shape == s.shape and d.V_.shape == V.shape and d.U_.shape == U.shape
+    assert np.allclose(d.s_, s, rtol=2e-5)
+    for j in range(min(20, len(s))):
+        assert np.dot(d.V_[:, j].astype(np.float64), V[:, j]) > 1 - 1e-4
+        assert np.dot(d.U_[:, j].astype(np.float64), U[:, j]) > 1 - 1e-4
+
+
+def test_eof_many_modes(ctx):
+    import xeofs_amd as xe
+
+    vals = _field(600, 40 * 50, 8, rank=20, noise=0.2).reshape(600, 40, 50)
+    X = xe.DataArray(vals, dims=("time", "lat", "lon"))
+    m = xe.single.EOF(n_modes=400, random_state=1).fit(X, "time")
+    ref = orc.eof_fit(vals.reshape(600, -1).astype(np.float64), 400, solver="full")
+    assert np.allclose(m.singular_values().values, ref["norms"], rtol=2e-5)
+    assert m.explained_variance_ratio().values.sum() <= 1 + 1e-6
+    rec = m.inverse_transform(m.scores()).values
+    full = ref["scores"] @ ref["components"].T + vals.reshape(600, -1).mean(0)
+    assert np.allclose(rec.reshape(600, -1), full, atol=2e-4 * np.abs(full).max())

@@ -5,10 +5,10 @@ xeofs/cross/cpcca.py:168-225).
 The cross-covariance matrix C = X^T Y/(n-1) is never materialised: the engine applies it as a
 matrix-free operator X^T (Y .) inside the randomized SVD (`eofx_crosscov_rsvd_f32`).
 
-`use_pca` / `n_pca_modes` / `pca_init_rank_reduction` are accepted for signature compatibility.
-The reference's default PCA pre-reduction (keep 99.9 % of each field's variance) exists to make
-C small enough to form; it is unnecessary here, and the result corresponds to `use_pca=False`
-(i.e. without the <= 0.1 % variance truncation).
+With `use_pca=True` (the reference default, base_model_cross_set.py:165-179, 307-308) each field is
+first reduced to the principal components that explain `n_pca_modes` (99.9 %) of its variance
+(`xeofs_amd.pca.ResidentPCA`: exact, two wide passes over the resident matrix); the cross-covariance
+analysis then runs on the n x m score matrices and the singular vectors are projected back (V Q).
 """
 
 from __future__ import annotations
@@ -18,6 +18,7 @@ import datetime
 import numpy as np
 
 from .. import __version__, engine, labelled
+from ..pca import ResidentPCA
 from ..linalg.decomposer import MAX_SKETCH, sanity_check_n_modes
 from ..preprocessing import Preprocessor
 
@@ -57,18 +58,35 @@ class MCA:
         k = int(self.n_modes)
         kw = dict(self.solver_kwargs)
         n_over, n_iter = int(kw.pop("n_oversamples", 10)), kw.pop("n_iter", "auto")
-        rank = min(mx.p, my.p)
+        # PCA pre-reduction (base_model_cross_set.py:307-308): the analysis runs on the PC scores
+        self.pca = [None, None]
+        work = [mx, my]
+        for i, (mat, pre) in enumerate(((mx, self.preprocessor1), (my, self.preprocessor2))):
+            if self._params["use_pca"][i]:
+                pca = ResidentPCA(self.ctx, self._params["n_pca_modes"][i], self._params["pca_init_rank_reduction"][i])
+                pca.fit(mat, pre.total_variance)
+                self.pca[i] = pca
+                work[i] = engine.from_dense(self.ctx, pca.scores().astype(np.float32))
+        wx, wy = work
+        rank = min(wx.p, wy.p)
         if k > rank:
             raise ValueError(f"n_modes must be less than or equal to the rank of the dataset (rank = {rank}).")
-        small = max(mx.p, my.p) < 500
+        small = max(wx.p, wy.p) < 500
         if self.solver == "full" or (self.solver == "auto" and small and k > int(0.8 * rank)):
             if rank > MAX_SKETCH:
-                raise NotImplementedError("solver='full' on the cross path needs rank <= 64; use 'randomized'")
+                raise NotImplementedError(f"solver='full' on the cross path needs rank <= {MAX_SKETCH}; use 'randomized'")
             n_over, n_iter = rank - k, 0
-        out = engine.crosscov_rsvd(self.ctx, mx, my, k, n_over, n_iter, random_state=self.random_state)
+        n_over = min(n_over, rank - k)         # a sketch as wide as the rank is already exact
+        out = engine.crosscov_rsvd(self.ctx, wx, wy, k, n_over, n_iter, random_state=self.random_state)
         s = out["s"].astype(np.float64)
+        self._q = [out["Q1"].astype(np.float64), out["Q2"].astype(np.float64)]     # singular vectors in PC space
+        comps = [self.pca[i].back_project(self._q[i]) if self.pca[i] is not None else out[f"Q{i + 1}"]
+                 for i in range(2)]
+        for i in range(2):
+            if self.pca[i] is not None:
+                work[i].free()
         self.data = dict(
-            input_data1=mx, input_data2=my, components1=out["Q1"], components2=out["Q2"],
+            input_data1=mx, input_data2=my, components1=comps[0], components2=comps[1],
             scores1=out["scores1"], scores2=out["scores2"], singular_values=s, squared_covariance=s ** 2,
             total_squared_covariance=out["total_squared_covariance"], idx_modes_sorted=np.argsort(s)[::-1],
             norm1=out["norm1"].astype(np.float64), norm2=out["norm2"].astype(np.float64),
@@ -100,7 +118,11 @@ class MCA:
                 continue
             pre = self.preprocessor1 if which == 1 else self.preprocessor2
             mat, fields, vs = pre.transform(Z)
-            proj = engine.project(self.ctx, mat, self.data[f"components{which}"])
+            pca = self.pca[which - 1]
+            if pca is not None:     # pca.transform -> X V (pca.py:125-134), then the PC-space singular vectors
+                proj = (pca.transform(mat) @ self._q[which - 1]).astype(np.float32)
+            else:
+                proj = engine.project(self.ctx, mat, self.data[f"components{which}"])
             mat.free()
             if normalized:
                 proj = proj / self.data[f"norm{which}"].astype(proj.dtype)

@@ -470,10 +470,18 @@ static int launch_atb(eofx_ctx* ctx, const float* A, int64_t lda, int64_t K, int
 }
 
 
+// number of row-strided partial Gram matrices: ~16 slabs of 32 rows per workgroup for the narrow
+// (sketch-width) panels; wide panels already expose (L/64)^2 sub-blocks, so fewer partials (<= 64 MB)
+static int gram_parts(int64_t rows, int L) {
+  const int64_t by_rows = std::min<int64_t>((rows + 511) / 512, 256);
+  const int64_t by_mem = ((int64_t)64 << 20) / ((int64_t)L * L * 8);
+  return (int)std::max<int64_t>(1, std::min(by_rows, std::max<int64_t>(by_mem, 1)));
+}
+
 static int launch_gram(eofx_ctx* ctx, const float* P, int64_t rows, int L, double* G) {
   const int nb = (L + 63) / 64;
   // ~16 slabs of 32 rows per workgroup: few partials for the small (sample-side) panels
-  const int nbx = (int)std::max<int64_t>(1, std::min<int64_t>((rows + 511) / 512, 256));
+  const int nbx = gram_parts(rows, L);
   ArenaScope scope(ctx);
   ARENA(double, part, (size_t)nbx * L * L);
   hipLaunchKernelGGL(gram_f64_kernel, dim3(nbx, nb * nb), dim3(256), 0, ctx->stream, P, rows, L, part);
@@ -1059,7 +1067,7 @@ extern "C" int eofx_panel_mul_f32(eofx_ctx* ctx, const eofx_mat* m, const float*
 extern "C" int eofx_panel_gram_f64(eofx_ctx* ctx, const float* P, int64_t rows_pad, int L, double* G) {
   if (!ctx || !P || !G || L % 32) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
   CHK(set_device(ctx));
-  CHK(arena_reserve(ctx, (size_t)257 * L * L * sizeof(double)));
+  CHK(arena_reserve(ctx, (size_t)(gram_parts(rows_pad, L) + 1) * L * L * sizeof(double)));
   return launch_gram(ctx, P, rows_pad, L, G);
 }
 extern "C" int eofx_panel_cholqr_f32(eofx_ctx* ctx, const float* P, int64_t rows_pad, int L, int l,
@@ -1314,12 +1322,19 @@ extern "C" int eofx_reconstruct_f32(eofx_ctx* ctx, const float* S, const float* 
   return EOFX_OK;
 }
 
-// n_pad x n_pad sample-space Gram matrix X X^T of a resident matrix (float32, through the atb kernel)
-static int sample_gram(eofx_ctx* ctx, const eofx_mat* m, float* G) {
-  const int64_t npad = m->n_pad;
-  return launch_atb(ctx, m->Xt, npad, round_up(m->p, ATB_KG), npad, m->Xt, (int)npad, (int)npad, G, ctx->prec_final,
+// Gram matrix of a resident matrix through the atb kernel (float32 result):
+// side 0: sample space, G[n_pad x n_pad] = X X^T;  side 1: feature space, G[p_pad x p_pad] = X^T X
+static int mat_gram(eofx_ctx* ctx, const eofx_mat* m, int side, float* G) {
+  if (side == 0) {
+    const int64_t npad = m->n_pad;
+    return launch_atb(ctx, m->Xt, npad, round_up(m->p, ATB_KG), npad, m->Xt, (int)npad, (int)npad, G, ctx->prec_final,
+                      m->absmax, reinterpret_cast<const float*>(m->absmax_dev));
+  }
+  const int64_t ppad = m->p_pad;
+  return launch_atb(ctx, m->X, ppad, round_up(m->n, ATB_KG), ppad, m->X, (int)ppad, (int)ppad, G, ctx->prec_final,
                     m->absmax, reinterpret_cast<const float*>(m->absmax_dev));
 }
+static int sample_gram(eofx_ctx* ctx, const eofx_mat* m, float* G) { return mat_gram(ctx, m, 0, G); }
 
 // <a, b> over `count` floats, float64 accumulation, fixed reduction tree
 static int device_dot(eofx_ctx* ctx, const float* a, const float* b, int64_t count, double* out) {
@@ -1338,11 +1353,13 @@ static int device_dot(eofx_ctx* ctx, const float* a, const float* b, int64_t cou
   return EOFX_OK;
 }
 
-extern "C" int eofx_mat_sample_gram_f32(eofx_ctx* ctx, const eofx_mat* m, float* G) {
-  if (!ctx || !m || !G) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+extern "C" int eofx_mat_gram_f32(eofx_ctx* ctx, const eofx_mat* m, int side, float* G) {
+  if (!ctx || !m || !G || (side != 0 && side != 1)) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
   CHK(set_device(ctx));
-  CHK(arena_reserve(ctx, atb_scratch_bytes(m->n_pad, m->p_pad, (int)m->n_pad) + (1 << 20)));
-  return sample_gram(ctx, m, G);
+  const int64_t d = side ? m->p_pad : m->n_pad, o = side ? m->n_pad : m->p_pad;
+  if (d > (1 << 16)) return set_err(ctx, EOFX_ERR_ARG, "Gram side of %lld is too large", (long long)d);
+  CHK(arena_reserve(ctx, atb_scratch_bytes(d, o, (int)d) + (1 << 20)));
+  return mat_gram(ctx, m, side, G);
 }
 
 extern "C" int eofx_vec_dot_f64(eofx_ctx* ctx, const float* a, const float* b, int64_t count, double* out) {

@@ -111,12 +111,17 @@ class ResidentMatrix:
         raise_for(self.ctx.lib.eofx_mat_sumsq_f64(self.ctx.handle, self.handle, C.byref(out)), self.ctx.handle)
         return out.value
 
-    def sample_gram(self):
-        """X X^T as an [n_pad, n_pad] float32 device tensor (rows/columns beyond n are zero)."""
+    def gram(self, side: int = 0):
+        """side 0: X X^T as an [n_pad, n_pad] float32 device tensor; side 1: X^T X [p_pad, p_pad]
+        (rows/columns beyond n / p are zero)."""
         torch = _torch()
-        G = torch.empty((self.n_pad, self.n_pad), dtype=torch.float32, device=f"cuda:{self.ctx.device}")
-        raise_for(self.ctx.lib.eofx_mat_sample_gram_f32(self.ctx.handle, self.handle, ptr(G)), self.ctx.handle)
+        d = self.p_pad if side else self.n_pad
+        G = torch.empty((d, d), dtype=torch.float32, device=f"cuda:{self.ctx.device}")
+        raise_for(self.ctx.lib.eofx_mat_gram_f32(self.ctx.handle, self.handle, int(side), ptr(G)), self.ctx.handle)
         return G
+
+    def sample_gram(self):
+        return self.gram(0)
 
     def free(self):
         if getattr(self, "handle", None) and getattr(self.ctx, "handle", None):

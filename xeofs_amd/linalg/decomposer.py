@@ -14,7 +14,8 @@ import numpy as np
 
 from .. import engine
 
-MAX_SKETCH = 256  # EOFX_MAX_SKETCH: sketches up to 64 wide are factorised on the device, wider ones on the host
+MAX_SKETCH = 256  # EOFX_MAX_SKETCH: sketches up to 64 wide are factorised on the device, wider ones on the host;
+                  # beyond it the Decomposer switches to the exact small-side Gram route (xeofs_amd/pca.py)
 
 
 def sanity_check_n_modes(n_modes):
@@ -80,19 +81,24 @@ class Decomposer:
         kw = dict(self.solver_kwargs)
         for name in ("power_iteration_normalizer", "transpose", "flip_sign", "svd_lapack_driver"):
             kw.pop(name, None)  # sklearn knobs without effect on the result here
+        wide = False
         if use_exact:
             # A full-width sketch spans the whole row/column space: the same kernels then return the
             # exact truncated SVD (no power iterations needed).
-            if rank > MAX_SKETCH:
-                raise NotImplementedError(
-                    f"solver='full' needs a sketch of width rank={rank} > {MAX_SKETCH}; use solver='randomized'.")
             n_over, n_iter = rank - k, 0
+            wide = rank > MAX_SKETCH
         else:
             n_over = int(kw.pop("n_oversamples", 10))
             n_iter = kw.pop("n_iter", "auto")
-            if min(k + n_over, rank) > MAX_SKETCH:
-                raise NotImplementedError(
-                    f"n_modes + n_oversamples = {k + n_over} > {MAX_SKETCH} is not supported by this build.")
+            wide = min(k + n_over, rank) > MAX_SKETCH
+        if wide:
+            # more modes than the sketch kernels hold (e.g. float n_modes -> int(0.3 * rank) modes): at that
+            # width the exact small-side Gram route is cheaper than the randomized passes (xeofs_amd/pca.py)
+            from ..pca import ResidentPCA
+
+            pca = ResidentPCA(ctx, k, flip_signs=bool(self.flip_signs)).fit(mat, total_variance)
+            U, s, V = pca.U.astype(np.float32), pca.s.astype(np.float32), pca.components()
+            return self._finish(U, s, V, n, k, total_variance)
         # the per-mode sign rule (xarray_utils.py:273-301) runs on the GPU; truncating modes afterwards
         # does not change the sign of the kept ones
         om = None
@@ -102,6 +108,10 @@ class Decomposer:
                 om = None      # drawn for another policy branch: fall back to drawing it now
         U, s, V = engine.rsvd(ctx, mat, k, n_over, n_iter, random_state=self.random_state, flip=bool(self.flip_signs),
                               omega=om)
+        return self._finish(U, s, V, n, k, total_variance)
+
+    def _finish(self, U, s, V, n, k, total_variance):
+        """variance-fraction truncation, decomposer.py:179-212"""
         if self.is_based_on_variance:
             if total_variance is None:
                 raise ValueError("variance-based truncation needs the total variance of the input")

@@ -1,0 +1,150 @@
+"""PCA pre-reduction of a resident matrix: xeofs/preprocessing/pca.py:94-171 on top of
+xeofs/linalg/_numpy/_svd.py:89-106,108-241 (`n_modes` float = explained-variance target inside the first
+int(rank * init_rank_reduction) modes).
+
+The reference computes those int(0.3 * rank) modes with an *unseeded* randomized SVD (sketch width ~0.3 n,
+10 passes over X).  At that width the MI355X-first route is the exact one, in two wide passes over X:
+
+  1. G = X X^T (sample space, n x n; or X^T X when p < n) through the streaming `atb` kernel
+     (`eofx_mat_gram_f32`, one launch, the matrix read n_pad/64 times from HBM),
+  2. symmetric eigendecomposition of G (float64, rocSOLVER through torch.linalg.eigh; 0.2 s at n = 5000) ->
+     the whole spectrum, hence the reference's truncation rule evaluated exactly, and the basis U_m,
+  3. B = X^T U_m (wide panel product, the same kernel) and a Rayleigh-Ritz step on B^T B (float64 Gram, m x m
+     eigh): singular values / vectors accurate to float32 rounding independent of their size (the Gram matrix
+     of step 1 only has to deliver the subspace).
+
+V stays resident in HBM as a [p_pad, Lm] panel: `transform` (X_new V) and the back-projection of the cross
+model's singular vectors (V Q) are panel products.
+"""
+
+from __future__ import annotations
+
+import warnings
+
+import numpy as np
+
+from . import engine
+
+
+def _round32(m):
+    return (int(m) + 31) // 32 * 32
+
+
+class ResidentPCA:
+    def __init__(self, ctx, n_modes=0.999, init_rank_reduction: float = 0.3, flip_signs: bool = True):
+        self.ctx = ctx
+        self.flip_signs = flip_signs
+        self.n_modes = n_modes
+        self.init_rank_reduction = init_rank_reduction
+        self.is_based_on_variance = not isinstance(n_modes, (int, np.integer, str))
+        if self.is_based_on_variance and not (0 < init_rank_reduction <= 1.0):
+            raise ValueError("init_rank_reduction must be in the half open interval (0, 1].")
+
+    # ------------------------------------------------------------------ policy (_svd.py:89-106)
+    def _n_modes_precompute(self, rank: int) -> int:
+        if self.is_based_on_variance:
+            n_pre = int(rank * self.init_rank_reduction)
+            if n_pre < 1:
+                warnings.warn(f"`init_rank_reduction={self.init_rank_reduction}` is too low resulting in zero "
+                              "components. One component will be computed instead.")
+                n_pre = 1
+            return n_pre
+        if isinstance(self.n_modes, str):
+            if self.n_modes != "all":
+                raise ValueError("`n_modes` must be an integer, float or 'all'")
+            return rank
+        if self.n_modes > rank:
+            raise ValueError(f"n_modes must be less than or equal to the rank of the dataset (rank = {rank}).")
+        return int(self.n_modes)
+
+    # ------------------------------------------------------------------ fit
+    def fit(self, mat, total_variance: float | None = None):
+        torch = engine._torch()
+        ctx = self.ctx
+        n, p = mat.n, mat.p
+        rank = min(n, p)
+        n_pre = self._n_modes_precompute(rank)
+        side = 0 if n <= p else 1                       # Gram matrix on the small side
+        r = n if side == 0 else p
+        G = mat.gram(side)[:r, :r].double()
+        G = 0.5 * (G + G.T)
+        if not bool(torch.isfinite(G).all()):
+            raise np.linalg.LinAlgError("SVD failed. This may be due to isolated NaN values in the data.")
+        lam, E = torch.linalg.eigh(G)                   # ascending
+        lam = torch.flip(lam, (0,)).clamp_min(0.0)
+        E = torch.flip(E, (1,))
+        lam_h = lam.cpu().numpy()
+        if total_variance is None:
+            total_variance = float(lam_h.sum()) / (n - 1)
+        m = n_pre
+        if self.is_based_on_variance:                   # _svd.py:215-241
+            cum = np.cumsum(lam_h[:n_pre] / (n - 1) / total_variance)
+            m = n_pre - int((cum >= self.n_modes).sum()) + 1
+            if m > n_pre:
+                warnings.warn(f"Dataset has {n_pre} components, explaining {cum[-1]:.2%} of the variance. However, "
+                              f"{self.n_modes:.2%} explained variance was requested. Please consider increasing "
+                              "`init_rank_reduction`.")
+                m = n_pre
+        Lm = _round32(m)
+        rows_small = mat.n_pad if side == 0 else mat.p_pad
+        Es = torch.zeros((rows_small, Lm), dtype=torch.float32, device=G.device)
+        Es[:r, :m] = E[:, :m].float()
+        # tall-side panel B = A^T E (A = X for side 0): columns ~ s_j v_j
+        B = engine.panel_tmul(ctx, mat, Es, prec=ctx.precision[1]) if side == 0 else \
+            engine.panel_mul(ctx, mat, Es, prec=ctx.precision[1])
+        M = engine.panel_gram(ctx, B)[:m, :m]
+        M = 0.5 * (M + M.T)
+        th, W = torch.linalg.eigh(M)
+        th = torch.flip(th, (0,)).clamp_min(0.0)
+        W = torch.flip(W, (1,))
+        s = torch.sqrt(th)
+        tiny = float(th[0]) * 1e-14 if m else 0.0
+        inv = torch.where(th > tiny, 1.0 / torch.sqrt(th.clamp_min(1e-300)), torch.zeros_like(th))
+        Wt = torch.zeros((Lm, Lm), dtype=torch.float64, device=G.device)
+        Wt[:m, :m] = W * inv                            # B W theta^-1/2 : orthonormal tall-side vectors
+        Tall = engine.panel_matmul(ctx, B, Wt)
+        del B
+        Small = (E[:, :m] @ W)                          # r x m float64, orthonormal small-side vectors
+        if side == 0:
+            self.Vp, U = Tall, Small                    # V: p_pad x Lm panel (device), U: n x m
+        else:                                           # features are the small side: V = E W, U = tall side
+            Vp = torch.zeros((mat.p_pad, Lm), dtype=torch.float32, device=G.device)
+            Vp[:p, :m] = Small.float()
+            self.Vp, U = Vp, Tall[:n, :m].double()
+        # deterministic sign (utils/xarray_utils.py:273-301 on V), applied before the truncation in _svd.py:208-213
+        mx, mn = engine.panel_colminmax(ctx, self.Vp, p)
+        mx, mn = mx.double()[:m], mn.double()[:m]
+        sign = torch.where(mx.abs() >= mn.abs(), torch.ones_like(mx), -torch.ones_like(mx))
+        if not self.flip_signs:
+            sign = torch.ones_like(sign)
+        self.sign = sign.cpu().numpy()
+        self.m, self.Lm, self.n, self.p, self.p_pad = m, Lm, n, p, mat.p_pad
+        self.s = s.cpu().numpy()
+        self.U = (U * sign).cpu().numpy()               # n x m float64
+        self.singular_values_all = np.sqrt(lam_h)
+        self.total_variance = total_variance
+        return self
+
+    # ------------------------------------------------------------------ PC-space views
+    def scores(self):
+        """X V = U s  (n x m), what `PCA.transform` returns for the training data (pca.py:125-134)."""
+        return self.U * self.s
+
+    def transform(self, mat_new):
+        """X_new V (n' x m) for a resident matrix preprocessed with the fitted state."""
+        out = engine.panel_mul(self.ctx, mat_new, self.Vp, prec=self.ctx.precision[1])
+        return out[:mat_new.n, :self.m].double().cpu().numpy() * self.sign
+
+    def back_project(self, Q):
+        """V Q (p x k): components from PC space back to feature space (pca.py:158-168)."""
+        torch = engine._torch()
+        Q = np.asarray(Q, dtype=np.float64)
+        k = Q.shape[1]
+        M = np.zeros((self.Lm, _round32(k)))
+        M[:self.m, :k] = Q * self.sign[:, None]
+        out = engine.panel_matmul(self.ctx, self.Vp, torch.as_tensor(M, device=self.Vp.device))
+        return engine.panel_export(self.ctx, out, self.p, k)
+
+    def components(self):
+        """V (p x m) float32 on the host."""
+        return engine.panel_export(self.ctx, self.Vp, self.p, self.m, self.sign)
