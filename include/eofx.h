@@ -196,6 +196,12 @@ int eofx_hilbert_f32(eofx_ctx *ctx, const eofx_mat *a, int padding, double decay
                      eofx_mat **out_imag, eofx_mat **out_real);
 /* sum of squares of the resident matrix (float64, fixed reduction tree).                     */
 int eofx_mat_sumsq_f64(eofx_ctx *ctx, const eofx_mat *m, double *out);
+/* Bootstrap resampling (validation/bootstrapper.py:78-91): out = rows `rows[0..n_rows)` (host indices
+ * into src, drawn with replacement) of the resident matrix, re-centred per feature when `center`
+ * (the bootstrap model is `EOF(n_modes)` with its default center=True).  mean (host, [p], may be NULL)
+ * receives the per-feature mean that was removed, total_variance the ddof=1 variance sum.          */
+int eofx_resample_f32(eofx_ctx *ctx, const eofx_mat *src, const int64_t *rows, int64_t n_rows, int center,
+                      eofx_mat **out, double *mean, double *total_variance);
 /* Gram matrix of a resident matrix (float32, device): side 0 = sample space G[n_pad x n_pad] = X X^T,
  * side 1 = feature space G[p_pad x p_pad] = X^T X (rows/columns beyond n / p are zero).  Used for
  * (a) the total squared covariance sum(|X^T Y|^2) = <X X^T, Y Y^T> (cross/cpcca.py:991-1000) when X and

@@ -556,3 +556,31 @@ def eof_rotator_fit(eof, n_modes, power=1, max_iter=1000, rtol=1e-8):
     return dict(components=rot_components[:, idx], scores=scores[:, idx], norms=norms[idx],
                 explained_variance=expvar_r[idx], total_variance=eof["total_variance"], idx_modes_sorted=idx,
                 rotation_matrix=rot_matrix, phi_matrix=phi, modes_sign=sign[idx])
+
+
+# --------------------------------------------------------------------------- #
+# N3  EOFBootstrapper                                                           #
+# --------------------------------------------------------------------------- #
+def eof_bootstrap(eof, n_modes, n_bootstraps=20, seed=None, random_state=None):
+    """xeofs/validation/bootstrapper.py:54-135 on the dict returned by `eof_fit` (+ "input_data" = the
+    preprocessed matrix).  Each member: rows drawn with `default_rng(seed).choice(n, n, replace=True)`
+    (:79), `EOF(n_modes, standardize=False, use_coslat=False).fit` (centre again, :88-89), scores =
+    member.transform(input_data) (:95); afterwards the per-mode sign from the correlation with the
+    model's scores (:112-121).  `random_state` seeds the members' solvers (unseeded in the reference)."""
+    X = eof["input_data"]
+    n = X.shape[0]
+    rng = np.random.default_rng(seed)
+    expvar, totvar, comps, scores = [], [], [], []
+    for b in range(n_bootstraps):
+        idx = rng.choice(n, n, replace=True)
+        member = eof_fit(X[idx], n_modes, random_state=None if random_state is None else random_state + b)
+        expvar.append(member["explained_variance"])
+        totvar.append(member["total_variance"])
+        comps.append(member["components"])
+        scores.append(eof_transform(X - member["mean"], member["components"]))
+    expvar, totvar, comps, scores = map(np.asarray, (expvar, totvar, comps, scores))
+    ms = eof["scores"][:, :n_modes]
+    corr = (scores * ms).mean(axis=1) / scores.std(axis=1) / ms.std(axis=0)
+    signs = np.sign(corr)
+    return dict(components=comps * signs[:, None, :], scores=scores * signs[:, None, :], norms=eof["norms"],
+                explained_variance=expvar, total_variance=totvar)

@@ -817,7 +817,8 @@ struct PreState {  // device arrays of length P
 };
 
 static int run_colstats(eofx_ctx* ctx, const float* Xd, int64_t n, int64_t P, int center, int standardize,
-                        const double* w_dev, PreState& ps) {
+                        const double* w_dev, PreState& ps, int64_t ld = 0, const int64_t* row_map = nullptr) {
+  if (ld == 0) ld = P;
   const int gx = (int)((P + 255) / 256);
   int64_t RS = std::max<int64_t>(1, (2048 + gx - 1) / gx);
   RS = std::min<int64_t>(RS, std::max<int64_t>(1, n / 64));
@@ -829,8 +830,8 @@ static int run_colstats(eofx_ctx* ctx, const float* Xd, int64_t n, int64_t P, in
   ARENA(double, sq_p, (size_t)RS * P);
   ARENA(float, mn_p, (size_t)RS * P);
   ARENA(float, mx_p, (size_t)RS * P);
-  hipLaunchKernelGGL(colstats_kernel, dim3(gx, (int)RS), dim3(256), 0, ctx->stream, Xd, n, P, rps, cnt_p,
-                     sum_p, sq_p, mn_p, mx_p);
+  hipLaunchKernelGGL(colstats_kernel, dim3(gx, (int)RS), dim3(256), 0, ctx->stream, Xd, n, P, ld, row_map, rps,
+                     cnt_p, sum_p, sq_p, mn_p, mx_p);
   KCHK();
   HIPCHK(hipMemsetAsync(ps.absmax, 0, sizeof(unsigned), ctx->stream));
   hipLaunchKernelGGL(colstats_finalize_kernel, dim3(gx), dim3(256), 0, ctx->stream, cnt_p, sum_p, sq_p, mn_p, mx_p,
@@ -1027,6 +1028,60 @@ extern "C" int eofx_apply_f32(eofx_ctx* ctx, const float* X, int64_t n, int64_t 
   CHK(sanitize_and_apply(ctx, st.dev, n, P, ps, false, valid_feature, check_nans, out, nullptr, valid_sample, &ns,
                          &pv, hcnt));
   if (n_out) *n_out = ns;
+  return EOFX_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// bootstrap resampling (validation/bootstrapper.py:78-91): rows of a resident matrix drawn with
+// replacement, re-centred, as a new resident matrix -- a row gather inside the statistics and apply
+// kernels instead of a host round trip.
+// ------------------------------------------------------------------------------------
+extern "C" int eofx_resample_f32(eofx_ctx* ctx, const eofx_mat* src, const int64_t* rows, int64_t n_rows,
+                                 int center, eofx_mat** out, double* mean, double* total_variance) {
+  if (!ctx || !src || !rows || !out || n_rows <= 0) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  CHK(set_device(ctx));
+  for (int64_t i = 0; i < n_rows; ++i)
+    if (rows[i] < 0 || rows[i] >= src->n)
+      return set_err(ctx, EOFX_ERR_ARG, "row index %lld out of range [0, %lld)", (long long)rows[i], (long long)src->n);
+  const int64_t P = src->p;
+  CHK(arena_reserve(ctx, colstats_scratch(n_rows, P)));
+  ArenaScope scope(ctx);
+  PreState ps;
+  ARENA(int, cnt, P);
+  ARENA(double, dmean, P);
+  ARENA(double, dstd, P);
+  ARENA(double, dshift, P);
+  ARENA(double, dscale, P);
+  ARENA(double, dm2, P);
+  ARENA(unsigned, dabsmax, 1);
+  ARENA(int64_t, drows, n_rows);
+  ps = {cnt, dmean, dstd, dshift, dscale, dm2, dabsmax};
+  CHK(copy_in(ctx, drows, rows, sizeof(int64_t) * n_rows));
+  CHK(run_colstats(ctx, src->X, n_rows, P, center, 0, nullptr, ps, src->p_pad, drows));
+  eofx_mat* m = nullptr;
+  CHK(mat_alloc(ctx, n_rows, P, &m));
+  ARENA(int, flag, 1);
+  HIPCHK(hipMemsetAsync(flag, 0, sizeof(int), ctx->stream));
+  int rc = launch_apply(ctx, src->X, src->p_pad, drows, nullptr, ps.shift, ps.scale, m, flag, ps.absmax);
+  if (rc == EOFX_OK && mean)
+    if (hipMemcpyAsync(mean, ps.mean, sizeof(double) * P, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = EOFX_ERR_HIP;
+  if (rc == EOFX_OK && total_variance) {
+    std::vector<double> hm2(P);
+    if (hipMemcpyAsync(hm2.data(), ps.m2, sizeof(double) * P, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) {
+      rc = EOFX_ERR_HIP;
+    } else {
+      double tv = 0.0;
+      for (int64_t c = 0; c < P; ++c) tv += hm2[c] / (double)(n_rows - 1);
+      *total_variance = tv;
+    }
+  }
+  if (rc == EOFX_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = EOFX_ERR_HIP;
+  if (rc != EOFX_OK) {
+    eofx_mat_destroy(ctx, m);
+    return rc == EOFX_ERR_HIP ? set_err(ctx, EOFX_ERR_HIP, "resample: HIP failure") : rc;
+  }
+  *out = m;
   return EOFX_OK;
 }
 

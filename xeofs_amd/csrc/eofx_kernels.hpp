@@ -742,7 +742,9 @@ __global__ __launch_bounds__(256) void panel_import_kernel(const float* __restri
 //   apply    : gather valid rows/cols, (x - shift) * scale, write X and X^T zero padded.
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__ X, int64_t n,
-                                                        int64_t P, int64_t rows_per_split,
+                                                        int64_t P, int64_t ld,
+                                                        const int64_t* __restrict__ row_map,
+                                                        int64_t rows_per_split,
                                                         int* __restrict__ cnt,
                                                         double* __restrict__ sum,
                                                         double* __restrict__ sumsq,
@@ -755,13 +757,15 @@ __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__
   int k = 0;
   double s = 0.0, q = 0.0;
   float lo = INFINITY, hi = -INFINITY;   // fminf/fmaxf skip NaN
-  const float* p = X + r0 * P + c;
+  // row_map (bootstrap resampling: source row of every logical row) is wave-uniform -> scalar loads
   int64_t r = r0;
   for (; r + 8 <= r1; r += 8) {
     float v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(p + (int64_t)u * P);
-    p += 8 * P;
+    for (int u = 0; u < 8; ++u) {
+      const int64_t rr = row_map ? row_map[r + u] : r + u;
+      v[u] = __builtin_nontemporal_load(X + rr * ld + c);
+    }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       lo = fminf(lo, v[u]);
@@ -774,8 +778,9 @@ __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__
       }
     }
   }
-  for (; r < r1; ++r, p += P) {
-    const float v = *p;
+  for (; r < r1; ++r) {
+    const int64_t rr = row_map ? row_map[r] : r;
+    const float v = X[rr * ld + c];
     lo = fminf(lo, v);
     hi = fmaxf(hi, v);
     if (v == v) {

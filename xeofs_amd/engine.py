@@ -462,3 +462,15 @@ def vec_dot(ctx: Context, a, b) -> float:
     out = C.c_double()
     raise_for(ctx.lib.eofx_vec_dot_f64(ctx.handle, ptr(a), ptr(b), a.numel(), C.byref(out)), ctx.handle)
     return out.value
+
+
+def resample(ctx: Context, mat: ResidentMatrix, rows, center: bool = True):
+    """Bootstrap member of a resident matrix: rows drawn with replacement, re-centred.
+    -> (ResidentMatrix, mean[p] float64, total_variance)"""
+    rows = np.ascontiguousarray(rows, dtype=np.int64)
+    mean = np.empty(mat.p, np.float64)
+    tv = C.c_double()
+    h = C.c_void_p()
+    raise_for(ctx.lib.eofx_resample_f32(ctx.handle, mat.handle, ptr(rows), rows.size, int(center), C.byref(h), ptr(mean),
+                                        C.byref(tv)), ctx.handle)
+    return ResidentMatrix(ctx, h), mean, tv.value

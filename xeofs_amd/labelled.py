@@ -107,3 +107,17 @@ def pack(values, dims, coords, name, attrs, like):
     if _xr is not None and isinstance(like, _xr.DataArray):
         return _xr.DataArray(values, dims=dims, coords=coords, name=name, attrs=attrs)
     return DataArray(values, dims, coords, name, attrs)
+
+
+def concat(objs, dim, coord):
+    """Stack equally shaped arrays along a new leading dimension `dim` (xr.concat(..., dim=dim) +
+    assign_coords); a list of lists (multi-field outputs) is stacked field by field."""
+    if isinstance(objs[0], (list, tuple)):
+        return [concat([o[i] for o in objs], dim, coord) for i in range(len(objs[0]))]
+    if _xr is not None and isinstance(objs[0], _xr.DataArray):
+        return _xr.concat(objs, dim=dim).assign_coords({dim: np.asarray(coord)})
+    vals, dims, coords, name, attrs = unpack(objs[0])
+    stacked = np.stack([unpack(o)[0] for o in objs], axis=0)
+    coords = dict(coords)
+    coords[dim] = np.asarray(coord)
+    return DataArray(stacked, (dim,) + tuple(dims), coords, name, attrs)
