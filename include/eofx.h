@@ -196,6 +196,11 @@ int eofx_hilbert_f32(eofx_ctx *ctx, const eofx_mat *a, int padding, double decay
                      eofx_mat **out_imag, eofx_mat **out_real);
 /* sum of squares of the resident matrix (float64, fixed reduction tree).                     */
 int eofx_mat_sumsq_f64(eofx_ctx *ctx, const eofx_mat *m, double *out);
+/* Euclidean row norms (float64, host|device out[rows]) of a panel, and the per-feature norms
+ * sqrt(sum_t X[t,j]^2) of a resident matrix (out[p]): the standard deviations the correlation patterns of
+ * the cross models divide by (utils/optional/statistics.py:50-54, cross/cpcca.py:642-845).            */
+int eofx_panel_rownorm_f64(eofx_ctx *ctx, const float *P, int64_t rows, int L, double *out);
+int eofx_mat_feature_norms_f64(eofx_ctx *ctx, const eofx_mat *m, double *out);
 /* Bootstrap resampling (validation/bootstrapper.py:78-91): out = rows `rows[0..n_rows)` (host indices
  * into src, drawn with replacement) of the resident matrix, re-centred per feature when `center`
  * (the bootstrap model is `EOF(n_modes)` with its default center=True).  mean (host, [p], may be NULL)

@@ -584,3 +584,158 @@ def eof_bootstrap(eof, n_modes, n_bootstraps=20, seed=None, random_state=None):
     signs = np.sign(corr)
     return dict(components=comps * signs[:, None, :], scores=scores * signs[:, None, :], norms=eof["norms"],
                 explained_variance=expvar, total_variance=totvar)
+
+
+# --------------------------------------------------------------------------- #
+# N4  Whitener + CPCCA family (CCA alpha=0, RDA alpha=[0,1], MCA alpha=1)       #
+# --------------------------------------------------------------------------- #
+def fractional_matrix_power(C, power):
+    """xeofs/linalg/_numpy/_utils.py:6-33: SVD of the symmetric matrix (solver 'full' here,
+    whitener.py:125), singular values <= eps dropped, V s^power V^H."""
+    U, s, VT = np.linalg.svd(C)
+    sgn = deterministic_sign_multiplier(VT)
+    V = (VT * sgn[:, None]).conj().T
+    keep = s > np.finfo(s.dtype).eps
+    V, s = V[:, keep], s[keep]
+    out = V @ np.diag(s ** power) @ V.conj().T
+    return out if np.iscomplexobj(C) else out.real
+
+
+def whitener_fit(X, alpha):
+    """xeofs/preprocessing/whitener.py:86-133: T = (X^H X / n)^((alpha-1)/2), Tinv = inv(T) (pinv fallback);
+    identity when alpha == 1 (:46-60)."""
+    if np.isclose(alpha, 1.0):
+        return None, None
+    C = X.conj().T @ X / X.shape[0]
+    T = fractional_matrix_power(C, (alpha - 1) / 2)
+    try:
+        Tinv = np.linalg.inv(T)
+    except np.linalg.LinAlgError:
+        Tinv = np.linalg.pinv(T)
+    return T, Tinv
+
+
+def cpcca_fit(X, Y, n_modes, alpha=(0.2, 0.2), standardize=False, random_state=None, solver="auto", use_pca=True,
+              n_pca_modes=0.999, pca_init_rank_reduction=0.3, pca_random_state=None, pca_solver="auto"):
+    """xeofs/cross/base_model_cross_set.py:269-321 + xeofs/cross/cpcca.py:168-225 for general alpha.
+    Returns the DataContainer entries plus the fitted transforms (V_i, T_i, Tinv_i)."""
+    alpha = [alpha, alpha] if np.isscalar(alpha) else list(alpha)
+    px = preprocess(X, True, standardize)
+    py = preprocess(Y, True, standardize)
+    data, Vs, Ts, Tinvs = [], [], [], []
+    for Z, a in ((px["X"], alpha[0]), (py["X"], alpha[1])):
+        V = None
+        if use_pca:
+            nm = min(Z.shape) if n_pca_modes == "all" else n_pca_modes
+            _, _, V = decomposer_fit(Z, nm, init_rank_reduction=pca_init_rank_reduction,
+                                     random_state=pca_random_state, solver=pca_solver)
+            Z = Z @ V
+        T, Tinv = whitener_fit(Z, a)
+        if T is not None:
+            Z = Z @ T
+        data.append(Z); Vs.append(V); Ts.append(T); Tinvs.append(Tinv)
+    Xw, Yw = data
+    C = cross_covariance(Xw, Yw)
+    Q1, s, Q2 = decomposer_fit(C, n_modes, random_state=random_state, solver=solver)
+    Cu = C if Tinvs[1] is None else C @ Tinvs[1]                     # cpcca.py:991-1000
+    Cu = Cu.conj().T if Tinvs[0] is None else Cu.conj().T @ Tinvs[0]
+    tsc = (np.abs(Cu) ** 2).sum()
+    scores1, scores2 = Xw @ Q1, Yw @ Q2
+    norm1 = np.sqrt((scores1.conj() * scores1).sum(axis=0)).real
+    norm2 = np.sqrt((scores2.conj() * scores2).sum(axis=0)).real
+
+    def back(Q, i):      # whitener.inverse_transform_components, pca.inverse_transform_components
+        Q = Q if Tinvs[i] is None else Tinvs[i].conj().T @ Q
+        return Q if Vs[i] is None else Vs[i] @ Q
+    return dict(input_data1=Xw, input_data2=Yw, Q1=Q1, Q2=Q2, components1=back(Q1, 0), components2=back(Q2, 1),
+                scores1=scores1, scores2=scores2, singular_values=s, squared_covariance=s ** 2,
+                total_squared_covariance=tsc, norm1=norm1, norm2=norm2, V=Vs, T=Ts, Tinv=Tinvs,
+                pre_x=px, pre_y=py)
+
+
+def _unwhiten(Z, Tinv):
+    return Z if Tinv is None else Z @ Tinv
+
+
+def cpcca_transform(m, Xc=None, Yc=None, normalized=False):
+    """base_model_cross_set.py:323-374 + cpcca.py:227-252 on preprocessed (centred) new data."""
+    out = []
+    for i, Z in enumerate((Xc, Yc)):
+        if Z is None:
+            continue
+        if m["V"][i] is not None:
+            Z = Z @ m["V"][i]
+        if m["T"][i] is not None:
+            Z = Z @ m["T"][i]
+        S = Z @ m[f"Q{i + 1}"]
+        out.append(S / m[f"norm{i + 1}"] if normalized else S)
+    return out[0] if len(out) == 1 else out
+
+
+def cpcca_predict(m, Xc):
+    """cpcca.py:273-302: pseudo scores of Y from new X."""
+    Z = Xc if m["V"][0] is None else Xc @ m["V"][0]
+    Z = Z if m["T"][0] is None else Z @ m["T"][0]
+    Rx, Ry = m["scores1"], m["scores2"]
+    G = Rx.conj().T @ Ry / np.linalg.norm(Rx, axis=0) ** 2
+    return Z @ m["Q1"] @ G
+
+
+def cpcca_inverse_transform(m, scores, which):
+    """cpcca.py:254-271 + base_model_cross_set.py:376-425: back to the preprocessed feature space."""
+    i = which - 1
+    Z = scores @ m[f"Q{which}"][:, :scores.shape[1]].conj().T
+    Z = _unwhiten(Z, m["Tinv"][i])
+    return Z if m["V"][i] is None else Z @ m["V"][i].conj().T
+
+
+def cpcca_diagnostics(m):
+    """cpcca.py:330-640: cross / auto correlation coefficients of the scores, squared covariance
+    fraction and the three fractions of variance explained (Swenson 2015, eq. 15)."""
+    Rx, Ry = m["scores1"], m["scores2"]
+    k = Rx.shape[1]
+    nrm = lambda Z: Z / Z.std(axis=0)
+    n = Rx.shape[0]
+    out = dict(cross_correlation_coefficients=np.diag(nrm(Rx).conj().T @ nrm(Ry) / (n - 1)).real,
+               correlation_coefficients_X=nrm(Rx).conj().T @ nrm(Rx) / (n - 1),
+               correlation_coefficients_Y=nrm(Ry).conj().T @ nrm(Ry) / (n - 1))
+    X1, X2 = _unwhiten(m["input_data1"], m["Tinv"][0]), _unwhiten(m["input_data2"], m["Tinv"][1])
+    scf, fxx, fyy, fyx = [], [], [], []
+    tvx, tvy = (np.abs(X1) ** 2).sum() / (n - 1), (np.abs(X2) ** 2).sum() / (n - 1)
+    Cx = X1.conj().T @ X1 / (n - 1)
+    Tm = fractional_matrix_power(Cx, -0.5)
+    tv_yx = np.linalg.norm(Tm @ X1.conj().T @ X2 / (n - 1)) ** 2
+    for j in range(k):
+        X1r = _unwhiten(Rx[:, [j]] @ m["Q1"][:, [j]].conj().T, m["Tinv"][0])
+        X2r = _unwhiten(Ry[:, [j]] @ m["Q2"][:, [j]].conj().T, m["Tinv"][1])
+        dX, dY = X1 - X1r, X2 - X2r
+        scf.append(1 - np.linalg.norm(dX.conj().T @ dY / (n - 1)) ** 2 / m["total_squared_covariance"])
+        fxx.append(1 - ((np.abs(dX) ** 2).sum() / (n - 1)) / tvx)
+        fyy.append(1 - ((np.abs(dY) ** 2).sum() / (n - 1)) / tvy)
+        fyx.append(1 - np.linalg.norm(Tm @ dX.conj().T @ dY / (n - 1)) ** 2 / tv_yx)
+    scf = np.asarray(scf)
+    out.update(squared_covariance_fraction=np.where(scf < 0, 0, scf), fraction_variance_X_explained_by_X=np.asarray(fxx),
+               fraction_variance_Y_explained_by_Y=np.asarray(fyy), fraction_variance_Y_explained_by_X=np.asarray(fyx))
+    return out
+
+
+def pearson_patterns(data, scores):
+    """xeofs/utils/optional/statistics.py:9-104 without multiple-test correction: correlation of every
+    feature with every score series (centred data assumed, population std) and two-sided p-values from the
+    beta distribution (scipy.stats.pearsonr reference)."""
+    import scipy.stats as st
+
+    n = data.shape[0]
+    corr = (data / data.std(0)).conj().T @ (scores / scores.std(0)) / n
+    a = n / 2 - 1
+    return corr, 2 * st.beta(a, a, loc=-1, scale=2).cdf(-np.abs(corr))
+
+
+def cpcca_patterns(m, kind="homogeneous"):
+    """cpcca.py:642-845: data are taken back through whitener and PCA (i.e. the PCA-truncated fields)."""
+    fields = []
+    for i in range(2):
+        Z = _unwhiten(m[f"input_data{i + 1}"], m["Tinv"][i])
+        fields.append(Z if m["V"][i] is None else Z @ m["V"][i].conj().T)
+    s1, s2 = (m["scores1"], m["scores2"]) if kind == "homogeneous" else (m["scores2"], m["scores1"])
+    return pearson_patterns(fields[0], s1), pearson_patterns(fields[1], s2)

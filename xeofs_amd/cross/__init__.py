@@ -1,1 +1,1 @@
-from .mca import MCA  # noqa: F401
+from .cpcca import CCA, CPCCA, MCA, RDA  # noqa: F401

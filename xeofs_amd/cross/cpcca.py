@@ -1,0 +1,503 @@
+"""xeofs_amd.cross.CPCCA / MCA / CCA / RDA -- drop-ins for xeofs.cross.CPCCA (xeofs/cross/cpcca.py:23-1020),
+MCA (cross/mca.py:20-123, alpha = 1), CCA (cross/cca.py, alpha = 0) and RDA (cross/rda.py, alpha = [0, 1]);
+fit / transform / inverse_transform / predict as in xeofs/cross/base_model_cross_set.py:269-460.
+
+Pipeline per field: fused HIP preprocess -> resident matrix -> PCA pre-reduction (`xeofs_amd.pca.ResidentPCA`,
+default on) -> fractional whitening T = (Z^T Z / n)^((alpha-1)/2) in PC space (m x m, host algebra as in
+preprocessing/whitener.py:115-133) -> matrix-free randomized SVD of the cross-covariance of the two analysis
+matrices (`eofx_crosscov_rsvd_f32`; C is never formed) -> singular vectors taken back through whitener and PCA
+(V (Tinv^H Q), a panel product on the resident V).
+
+With alpha = 1 and use_pca = False the analysis runs directly on the resident feature-space matrices
+(the SURVEY.md §8 hot path, row R14/R15).  The diagnostics of Swenson (2015) are evaluated through rank-one
+algebra on panel products (A B, A^T R) instead of per-mode reconstructions of the full fields.
+"""
+
+from __future__ import annotations
+
+import datetime
+import warnings
+
+import numpy as np
+
+from .. import __version__, engine, labelled
+from ..linalg.decomposer import MAX_SKETCH, sanity_check_n_modes
+from ..pca import ResidentPCA
+from ..preprocessing import Preprocessor
+
+MAX_DENSE_WHITEN = 8192     # whitening without PCA forms the p x p covariance (as the reference does)
+
+
+def _pair(v):
+    return list(v) if isinstance(v, (list, tuple)) else [v, v]
+
+
+def fractional_matrix_power(C, power):
+    """linalg/_numpy/_utils.py:6-33 for a real symmetric PSD matrix: V s^power V^T, s <= eps dropped."""
+    w, V = np.linalg.eigh(0.5 * (C + C.T))
+    keep = w > np.finfo(w.dtype).eps
+    return (V[:, keep] * w[keep] ** power) @ V[:, keep].T
+
+
+class _Side:
+    """One field of the cross model: resident matrix, optional PCA, optional whitener, analysis matrix."""
+
+    def __init__(self, ctx, mat, pca, alpha):
+        self.ctx, self.mat, self.pca, self.alpha = ctx, mat, pca, alpha
+        self.T = self.Tinv = None
+        self.Z = None if pca is None else pca.scores()          # analysis matrix on the host (n x m), or None
+        if not np.isclose(alpha, 1.0):                          # whitener.py:46-60: identity when alpha == 1
+            if self.Z is None:
+                if mat.p > MAX_DENSE_WHITEN:
+                    raise NotImplementedError(
+                        f"alpha < 1 without PCA needs the {mat.p} x {mat.p} feature covariance; use use_pca=True")
+                self.Z = mat.download().astype(np.float64)
+            n, m = self.Z.shape
+            if n < m:                                           # whitener.py:101-104
+                warnings.warn(f"The number of samples ({n}) is smaller than the number of features ({m}), leading to "
+                              "an ill-conditioned problem. This may cause unstable results. Consider using PCA to "
+                              "reduce dimensionality and stabilize the problem by setting `use_pca=True`.")
+            Cm = self.Z.T @ self.Z / n
+            self.T = fractional_matrix_power(Cm, (alpha - 1) / 2)
+            try:
+                self.Tinv = np.linalg.inv(self.T)
+            except np.linalg.LinAlgError:
+                self.Tinv = np.linalg.pinv(self.T)
+            self.Z = self.Z @ self.T
+        self.work = mat if self.Z is None else engine.from_dense(ctx, self.Z.astype(np.float32))
+        self.n, self.m = mat.n, (mat.p if self.Z is None else self.Z.shape[1])
+
+    # --- analysis-space <-> feature-space maps ------------------------------------------------
+    def to_analysis(self, mat_new):
+        """preprocessed new data (resident) -> analysis space: pca.transform, whitener.transform"""
+        if self.Z is None:
+            return None                                          # stays resident
+        Z = self.pca.transform(mat_new) if self.pca is not None else mat_new.download().astype(np.float64)
+        return Z if self.T is None else Z @ self.T
+
+    def components_back(self, Q):
+        """whitener.inverse_transform_components, pca.inverse_transform_components: V (Tinv^H Q)"""
+        Q = np.asarray(Q, dtype=np.float64)
+        if self.Tinv is not None:
+            Q = self.Tinv.T @ Q
+        if self.pca is not None:
+            return self.pca.back_project(Q)
+        return Q.astype(np.float32)
+
+    def data_back(self, Z):
+        """analysis-space rows -> preprocessed feature space: whitener / pca inverse_transform_data"""
+        if self.Tinv is not None:
+            Z = Z @ self.Tinv
+        if self.pca is not None:
+            return engine.reconstruct(self.ctx, Z.astype(np.float32), self.pca.components())
+        return Z.astype(np.float32)
+
+    # --- unwhitened analysis matrix A (= input_data after whitener.inverse_transform_data) ------
+    def A_host(self):
+        if self.Z is None:
+            return None
+        return self.Z if self.Tinv is None else self.Z @ self.Tinv
+
+    def A_mul(self, B):
+        """A B for B (m x k)"""
+        A = self.A_host()
+        if A is not None:
+            return A @ B
+        return engine.project(self.ctx, self.mat, np.ascontiguousarray(B, dtype=np.float32)).astype(np.float64)
+
+    def A_tmul(self, R):
+        """A^T R for R (n x k)"""
+        A = self.A_host()
+        if A is not None:
+            return A.T @ R
+        torch = engine._torch()
+        k = R.shape[1]
+        L = engine.panel_width(k)
+        Rp = engine.panel_import(self.ctx, np.ascontiguousarray(R, dtype=np.float32), self.mat.n_pad, L)
+        out = engine.panel_tmul(self.ctx, self.mat, Rp, prec=self.ctx.precision[1])
+        return engine.panel_export(self.ctx, out, self.mat.p, k).astype(np.float64)
+
+    def A_sumsq(self):
+        A = self.A_host()
+        return float((A * A).sum()) if A is not None else self.mat.sumsq()
+
+    def feature_std_and_cov(self, R):
+        """for the correlation patterns: per-feature population std of the (PCA-truncated) field and
+        field^T R in feature space (p x k)"""
+        n = self.n
+        if self.pca is not None:
+            A = self.A_host()
+            num = self.pca.back_project(A.T @ R).astype(np.float64)
+            S = A.T @ A
+            w, E = np.linalg.eigh(0.5 * (S + S.T))
+            half = (E * np.sqrt(np.clip(w, 0, None))) @ E.T
+            std = self.pca.row_norms(half) / np.sqrt(n)
+        elif self.Z is not None:
+            A = self.A_host()
+            num, std = A.T @ R, np.sqrt((A * A).sum(axis=0) / n)
+        else:
+            num, std = self.A_tmul(R), engine.feature_norms(self.ctx, self.mat) / np.sqrt(n)
+        return num, std
+
+    def free(self):
+        if self.Z is not None and self.work is not None:
+            self.work.free()
+        self.work = None
+
+
+class CPCCA:
+    _model_name = "Continuum Power CCA"
+
+    def __init__(self, n_modes: int = 2, alpha=0.2, standardize=False, use_coslat=False, use_pca=True,
+                 n_pca_modes=0.999, pca_init_rank_reduction=0.3, check_nans=True, compute: bool = True,
+                 sample_name: str = "sample", feature_name="feature", solver: str = "auto", random_state=None,
+                 solver_kwargs: dict = {}, **kwargs):
+        sanity_check_n_modes(n_modes)
+        if solver not in ("auto", "full", "randomized"):
+            raise ValueError(f"Unrecognized solver '{solver}'. Valid options are 'auto', 'full', and 'randomized'.")
+        self.n_modes = n_modes
+        std, cos, chk = _pair(standardize), _pair(use_coslat), _pair(check_nans)
+        self._params = dict(n_modes=n_modes, alpha=[float(a) for a in _pair(alpha)], standardize=std, use_coslat=cos,
+                            check_nans=chk, use_pca=_pair(use_pca), n_pca_modes=_pair(n_pca_modes),
+                            pca_init_rank_reduction=_pair(pca_init_rank_reduction), sample_name=sample_name,
+                            feature_name=_pair(feature_name), random_state=random_state, compute=compute, solver=solver)
+        self.alpha = self._params["alpha"]
+        self.solver, self.random_state, self.solver_kwargs = solver, random_state, dict(solver_kwargs)
+        self.sample_name = sample_name
+        # CPCCA always centres (cpcca.py:145)
+        self.preprocessor1 = Preprocessor(True, std[0], cos[0], chk[0])
+        self.preprocessor2 = Preprocessor(True, std[1], cos[1], chk[1])
+        self.attrs = {"model": self._model_name, "software": "xeofs_amd", "version": __version__,
+                      "date": datetime.datetime.now().strftime("%Y-%m-%d %H:%M:%S")}
+        self.ctx = None
+        self.data = {}
+        self.pca = [None, None]
+        self.side = [None, None]
+
+    def get_params(self):
+        return dict(self._params)
+
+    # ------------------------------------------------------------------ fit
+    def fit(self, X, Y, dim, weights_X=None, weights_Y=None):
+        self.ctx = self.ctx or engine.default_context()
+        self.preprocessor1.ctx = self.preprocessor2.ctx = self.ctx
+        mx = self.preprocessor1.fit_transform(X, dim, weights_X)
+        my = self.preprocessor2.fit_transform(Y, dim, weights_Y)
+        self.sample_dims = self.preprocessor1.sample_dims
+        if mx.n != my.n:
+            raise ValueError("Both data matrices must have the same number of samples but found "
+                             f"{mx.n} in the first and {my.n} in the second.")
+        k = int(self.n_modes)
+        kw = dict(self.solver_kwargs)
+        n_over, n_iter = int(kw.pop("n_oversamples", 10)), kw.pop("n_iter", "auto")
+        # PCA pre-reduction and whitening (base_model_cross_set.py:307-313)
+        for i, (mat, pre) in enumerate(((mx, self.preprocessor1), (my, self.preprocessor2))):
+            pca = None
+            if self._params["use_pca"][i]:
+                pca = ResidentPCA(self.ctx, self._params["n_pca_modes"][i], self._params["pca_init_rank_reduction"][i])
+                pca.fit(mat, pre.total_variance)
+            self.pca[i] = pca
+            self.side[i] = _Side(self.ctx, mat, pca, self.alpha[i])
+        sx, sy = self.side
+        rank = min(sx.m, sy.m)
+        if k > rank:
+            raise ValueError(f"n_modes must be less than or equal to the rank of the dataset (rank = {rank}).")
+        small = max(sx.m, sy.m) < 500
+        if self.solver == "full" or (self.solver == "auto" and small and k > int(0.8 * rank)):
+            if rank > MAX_SKETCH:
+                raise NotImplementedError(f"solver='full' on the cross path needs rank <= {MAX_SKETCH}; use 'randomized'")
+            n_over, n_iter = rank - k, 0
+        n_over = min(n_over, rank - k)         # a sketch as wide as the rank is already exact
+        identity = sx.Tinv is None and sy.Tinv is None
+        out = engine.crosscov_rsvd(self.ctx, sx.work, sy.work, k, n_over, n_iter, random_state=self.random_state,
+                                   want_tsc=identity)
+        s = out["s"].astype(np.float64)
+        self._q = [out["Q1"].astype(np.float64), out["Q2"].astype(np.float64)]     # in the analysis space
+        tsc = out["total_squared_covariance"] if identity else self._unwhitened_tsc()
+        comps = [self.side[i].components_back(self._q[i]) for i in range(2)]
+        for sd in self.side:
+            sd.free()
+        self.data = dict(
+            input_data1=mx, input_data2=my, components1=comps[0], components2=comps[1],
+            scores1=out["scores1"], scores2=out["scores2"], singular_values=s, squared_covariance=s ** 2,
+            total_squared_covariance=tsc, idx_modes_sorted=np.argsort(s)[::-1],
+            norm1=out["norm1"].astype(np.float64), norm2=out["norm2"].astype(np.float64),
+        )
+        return self
+
+    def _unwhitened_tsc(self):
+        """cpcca.py:991-1000: sum |Tinv1^T C Tinv2|^2 = || A1^T A2 ||_F^2 / (n-1)^2 on the unwhitened matrices"""
+        sx, sy = self.side
+        n = sx.n
+        A1, A2 = sx.A_host(), sy.A_host()
+        if A1 is not None and A2 is not None:
+            return float(((A1.T @ A2) ** 2).sum()) / (n - 1) ** 2
+        mats, tmp = [], []
+        for sd, A in ((sx, A1), (sy, A2)):
+            if A is None:
+                mats.append(sd.mat)
+            else:
+                mats.append(engine.from_dense(self.ctx, A.astype(np.float32)))
+                tmp.append(mats[-1])
+        t = engine.vec_dot(self.ctx, mats[0].gram(0), mats[1].gram(0)) / (n - 1) ** 2
+        for m in tmp:
+            m.free()
+        return t
+
+    # ------------------------------------------------------------------ accessors (base_model_cross_set.py:465-523)
+    def components(self, normalized: bool = True):
+        q1, q2 = self.data["components1"], self.data["components2"]
+        if not normalized:
+            q1, q2 = q1 * self.data["norm1"].astype(q1.dtype), q2 * self.data["norm2"].astype(q2.dtype)
+        return (self.preprocessor1.inverse_transform_components(q1, "components1", self.attrs),
+                self.preprocessor2.inverse_transform_components(q2, "components2", self.attrs))
+
+    def scores(self, normalized: bool = False):
+        s1, s2 = self.data["scores1"], self.data["scores2"]
+        if normalized:
+            s1, s2 = s1 / self.data["norm1"].astype(s1.dtype), s2 / self.data["norm2"].astype(s2.dtype)
+        return (self.preprocessor1.inverse_transform_scores(s1, "scores1", self.attrs),
+                self.preprocessor2.inverse_transform_scores(s2, "scores2", self.attrs))
+
+    def _project(self, which, Z):
+        """preprocess -> pca -> whitener -> singular vectors; returns (scores n' x k, fields, valid samples)"""
+        pre = self.preprocessor1 if which == 1 else self.preprocessor2
+        sd = self.side[which - 1]
+        mat, fields, vs = pre.transform(Z)
+        Za = sd.to_analysis(mat)
+        if Za is None:
+            proj = engine.project(self.ctx, mat, self._q[which - 1].astype(np.float32)).astype(np.float64)
+        else:
+            proj = Za @ self._q[which - 1]
+        mat.free()
+        return proj, fields, vs
+
+    def transform(self, X=None, Y=None, normalized: bool = False):
+        """base_model_cross_set.py:323-374 + cpcca.py:227-252."""
+        if X is None and Y is None:
+            raise ValueError("Either X or Y must be provided.")
+        outs = []
+        for which, Z in ((1, X), (2, Y)):
+            if Z is None:
+                continue
+            pre = self.preprocessor1 if which == 1 else self.preprocessor2
+            proj, fields, vs = self._project(which, Z)
+            if normalized:
+                proj = proj / self.data[f"norm{which}"]
+            outs.append(pre.inverse_transform_scores(proj.astype(np.float32), f"scores{which}", self.attrs, fields, vs))
+        return outs[0] if len(outs) == 1 else tuple(outs)
+
+    def predict(self, X):
+        """base_model_cross_set.py:427-449 + cpcca.py:273-302: pseudo scores of Y from new X."""
+        proj, fields, vs = self._project(1, X)
+        Rx, Ry = self.data["scores1"].astype(np.float64), self.data["scores2"].astype(np.float64)
+        G = Rx.T @ Ry / np.linalg.norm(Rx, axis=0) ** 2
+        return self.preprocessor2.inverse_transform_scores((proj @ G).astype(np.float32), "pseudo_scores_Y", self.attrs,
+                                                           fields, vs)
+
+    def inverse_transform(self, X=None, Y=None):
+        """base_model_cross_set.py:376-425 + cpcca.py:254-271: scores (with a 'mode' dimension) back to the fields."""
+        if X is None and Y is None:
+            raise ValueError("Either X or Y must be provided.")
+        outs = []
+        for which, S in ((1, X), (2, Y)):
+            if S is None:
+                continue
+            pre = self.preprocessor1 if which == 1 else self.preprocessor2
+            vals, dims, coords, _, _ = labelled.unpack(S)
+            if "mode" not in dims:
+                vals, dims = vals[None], ("mode",) + tuple(dims)
+                coords = dict(coords, mode=np.array([1]))
+            modes = np.asarray(coords["mode"]).astype(int)
+            order = [dims.index("mode")] + [i for i, d in enumerate(dims) if d != "mode"]
+            Sm = np.transpose(vals, order).reshape(len(modes), -1).T.astype(np.float64)     # (n', k')
+            vs = ~np.isnan(Sm).all(axis=1)
+            Za = Sm[vs] @ self._q[which - 1][:, modes - 1].T                                  # analysis space
+            rec = self.side[which - 1].data_back(Za)
+            f0 = pre.fields[0]
+            sample_shape = tuple(vals.shape[dims.index(d)] for d in f0.sample_dims)
+            fields = []
+            for f in pre.fields:
+                g = object.__new__(type(f))
+                g.__dict__.update(f.__dict__)
+                g.sample_shape = sample_shape
+                g.coords = dict(f.coords, **{d: coords[d] for d in f.sample_dims if d in coords})
+                fields.append(g)
+            outs.append(pre.inverse_transform_data(rec, "reconstructed_data", fields, vs))
+        return outs[0] if len(outs) == 1 else outs
+
+    def _mode_array(self, values, name):
+        k = len(values)
+        return labelled.pack(np.asarray(values), ("mode",), {"mode": np.arange(1, k + 1)}, name, dict(self.attrs),
+                             self.preprocessor1.fields[0].like)
+
+    def singular_values(self):
+        return self._mode_array(self.data["singular_values"], "singular_values")
+
+    def squared_covariance(self):
+        return self._mode_array(self.data["squared_covariance"], "squared_covariance")
+
+    def total_squared_covariance(self):
+        return self.data["total_squared_covariance"]
+
+    # ------------------------------------------------------------------ diagnostics (cpcca.py:330-640)
+    @staticmethod
+    def _corr(A, B):
+        """cpcca.py:910-985 method='correlation': columns scaled by their population std, cross-products / (n-1)"""
+        A, B = A.astype(np.float64), B.astype(np.float64)
+        return (A / A.std(axis=0)).T @ (B / B.std(axis=0)) / (A.shape[0] - 1)
+
+    def cross_correlation_coefficients(self):
+        return self._mode_array(np.diag(self._corr(self.data["scores1"], self.data["scores2"])),
+                                "cross_correlation_coefficients")
+
+    def _mode_matrix(self, M, name):
+        k = M.shape[0]
+        return labelled.pack(M, ("mode_x", "mode_y"), {"mode_x": np.arange(1, k + 1), "mode_y": np.arange(1, k + 1)}, name,
+                             dict(self.attrs), self.preprocessor1.fields[0].like)
+
+    def correlation_coefficients_X(self):
+        return self._mode_matrix(self._corr(self.data["scores1"], self.data["scores1"]), "correlation_coefficients_X")
+
+    def correlation_coefficients_Y(self):
+        return self._mode_matrix(self._corr(self.data["scores2"], self.data["scores2"]), "correlation_coefficients_Y")
+
+    def _rank_one_terms(self):
+        """per-mode pieces of the residuals d_i = A_i - r_i b_i^T (b_i = Tinv_i^T q_i), all modes batched into
+        panel products: g1 = A1^T R2, g2 = A2^T R1, a_i = A_i b_i, ..."""
+        R1, R2 = self.data["scores1"].astype(np.float64), self.data["scores2"].astype(np.float64)
+        B = []
+        for i in range(2):
+            Q = self._q[i]
+            B.append(Q if self.side[i].Tinv is None else self.side[i].Tinv.T @ Q)
+        return R1, R2, B[0], B[1]
+
+    def squared_covariance_fraction(self):
+        """cpcca.py:418-497: 1 - ||d_X^T d_Y||_F^2 / ||X^T Y||_F^2 per mode (clipped at 0).
+
+        D = M - b1 g2^T - g1 b2^T + c b1 b2^T with M = A1^T A2; ||D||^2 is expanded into inner products of
+        n-vectors A_i x so that M (and any per-mode reconstruction of the fields) is never formed."""
+        sx, sy = self.side
+        n = sx.n
+        R1, R2, B1, B2 = self._rank_one_terms()
+        G1, G2 = sx.A_tmul(R2), sy.A_tmul(R1)                        # (m1 x k), (m2 x k)
+        a1, a2b = sx.A_mul(B1), sy.A_mul(B2)                         # A1 b1, A2 b2   (n x k)
+        a2g, a1g = sy.A_mul(G2), sx.A_mul(G1)                        # A2 g2, A1 g1   (n x k)
+        c = (R1 * R2).sum(axis=0)
+        nb1, nb2 = (B1 * B1).sum(0), (B2 * B2).sum(0)
+        ng1, ng2 = (G1 * G1).sum(0), (G2 * G2).sum(0)
+        M2 = self.data["total_squared_covariance"] * (n - 1) ** 2
+        b1g1, g2b2 = (B1 * G1).sum(0), (G2 * B2).sum(0)
+        D2 = (M2 + nb1 * ng2 + ng1 * nb2 + c ** 2 * nb1 * nb2 - 2 * (a1 * a2g).sum(0) - 2 * (a1g * a2b).sum(0)
+              + 2 * c * (a1 * a2b).sum(0) + 2 * b1g1 * g2b2 - 2 * c * nb1 * g2b2 - 2 * c * b1g1 * nb2)
+        scf = 1 - D2 / M2
+        return self._mode_array(np.where(scf < 0, 0, scf), "squared_covariance_fraction")
+
+    def _fve_self(self, i):
+        sd = self.side[i]
+        R = self.data[f"scores{i + 1}"].astype(np.float64)
+        B = self._rank_one_terms()[2 + i]
+        tot = sd.A_sumsq()
+        res = tot - 2 * (R * sd.A_mul(B)).sum(0) + (R * R).sum(0) * (B * B).sum(0)
+        return 1 - res / tot
+
+    def fraction_variance_X_explained_by_X(self):
+        return self._mode_array(self._fve_self(0), "fraction_variance_X_explained_by_X")
+
+    def fraction_variance_Y_explained_by_Y(self):
+        return self._mode_array(self._fve_self(1), "fraction_variance_Y_explained_by_Y")
+
+    def fraction_variance_Y_explained_by_X(self):
+        """cpcca.py:563-640: like the SCF but with (X^T X)^(-1/2) in front (needs X in a reduced space)."""
+        sx, sy = self.side
+        A1, A2 = sx.A_host(), sy.A_host()
+        if A1 is None or A2 is None:
+            raise NotImplementedError("fraction_variance_Y_explained_by_X needs the whitening of the X covariance: "
+                                      "fit with use_pca=True")
+        n = sx.n
+        R1, R2, B1, B2 = self._rank_one_terms()
+        Tm = fractional_matrix_power(A1.T @ A1 / (n - 1), -0.5)
+        M = A1.T @ A2
+        TM = Tm @ M
+        tot = (TM ** 2).sum()
+        G1, G2 = A1.T @ R2, A2.T @ R1
+        c = (R1 * R2).sum(axis=0)
+        out = np.empty(R1.shape[1])
+        for j in range(R1.shape[1]):
+            D = (TM - np.outer(Tm @ B1[:, j], G2[:, j]) - np.outer(Tm @ G1[:, j], B2[:, j])
+                 + c[j] * np.outer(Tm @ B1[:, j], B2[:, j]))
+            out[j] = 1 - (D ** 2).sum() / tot
+        return self._mode_array(out, "fraction_variance_Y_explained_by_X")
+
+    # ------------------------------------------------------------------ correlation patterns (cpcca.py:642-845)
+    def _patterns(self, kind, correction, alpha):
+        if correction is not None:
+            raise NotImplementedError("multiple-test corrections need statsmodels (an optional dependency of the "
+                                      "reference as well); only correction=None is available")
+        from scipy.special import betainc
+
+        n = self.side[0].n
+        S1, S2 = self.data["scores1"].astype(np.float64), self.data["scores2"].astype(np.float64)
+        pairs = ((0, S1), (1, S2)) if kind == "homogeneous" else ((0, S2), (1, S1))
+        pats, pvals = [], []
+        for i, S in pairs:
+            Sn = (S - S.mean(0)) / S.std(0)                       # statistics.py:50-54 (population std)
+            num, std = self.side[i].feature_std_and_cov(Sn)
+            with np.errstate(invalid="ignore", divide="ignore"):
+                corr = num / std[:, None] / n
+            a = n / 2 - 1                                         # statistics.py:85-101: beta(a, a) on [-1, 1]
+            pv = 2 * betainc(a, a, np.clip((1 - np.abs(corr)) / 2, 0, 1))
+            pre = self.preprocessor1 if i == 0 else self.preprocessor2
+            side = "left" if i == 0 else "right"
+            pats.append(pre.inverse_transform_components(corr.astype(np.float32), f"{side}_{kind}_patterns", self.attrs))
+            pvals.append(pre.inverse_transform_components(pv.astype(np.float32), f"pvalues_of_{side}_{kind}_patterns",
+                                                          self.attrs))
+        return tuple(pats), tuple(pvals)
+
+    def homogeneous_patterns(self, correction=None, alpha=0.05):
+        return self._patterns("homogeneous", correction, alpha)
+
+    def heterogeneous_patterns(self, correction=None, alpha=0.05):
+        return self._patterns("heterogeneous", correction, alpha)
+
+
+class MCA(CPCCA):
+    """cross/mca.py:20-123: CPCCA with alpha = [1, 1]."""
+    _model_name = "Maximum Covariance Analysis"
+
+    def __init__(self, n_modes: int = 2, standardize=False, use_coslat=False, check_nans=True, use_pca=True,
+                 n_pca_modes=0.999, pca_init_rank_reduction=0.3, compute: bool = True, sample_name: str = "sample",
+                 feature_name="feature", solver: str = "auto", random_state=None, solver_kwargs: dict = {}):
+        super().__init__(n_modes=n_modes, alpha=[1.0, 1.0], standardize=standardize, use_coslat=use_coslat,
+                         use_pca=use_pca, n_pca_modes=n_pca_modes, pca_init_rank_reduction=pca_init_rank_reduction,
+                         check_nans=check_nans, compute=compute, sample_name=sample_name, feature_name=feature_name,
+                         solver=solver, random_state=random_state, solver_kwargs=solver_kwargs)
+        self._params.pop("alpha")
+
+
+class CCA(CPCCA):
+    """cross/cca.py: CPCCA with alpha = [0, 0]."""
+    _model_name = "Canonical Correlation Analysis"
+
+    def __init__(self, n_modes: int = 2, standardize=False, use_coslat=False, check_nans=True, use_pca=True,
+                 n_pca_modes=0.999, pca_init_rank_reduction=0.3, compute: bool = True, sample_name: str = "sample",
+                 feature_name="feature", solver: str = "auto", random_state=None, solver_kwargs: dict = {}):
+        super().__init__(n_modes=n_modes, alpha=[0.0, 0.0], standardize=standardize, use_coslat=use_coslat,
+                         use_pca=use_pca, n_pca_modes=n_pca_modes, pca_init_rank_reduction=pca_init_rank_reduction,
+                         check_nans=check_nans, compute=compute, sample_name=sample_name, feature_name=feature_name,
+                         solver=solver, random_state=random_state, solver_kwargs=solver_kwargs)
+        self._params.pop("alpha")
+
+
+class RDA(CPCCA):
+    """cross/rda.py: CPCCA with alpha = [0, 1]."""
+    _model_name = "Redundancy Analysis"
+
+    def __init__(self, n_modes: int = 2, standardize=False, use_coslat=False, check_nans=True, use_pca=True,
+                 n_pca_modes=0.999, pca_init_rank_reduction=0.3, compute: bool = True, sample_name: str = "sample",
+                 feature_name="feature", solver: str = "auto", random_state=None, solver_kwargs: dict = {}):
+        super().__init__(n_modes=n_modes, alpha=[0.0, 1.0], standardize=standardize, use_coslat=use_coslat,
+                         use_pca=use_pca, n_pca_modes=n_pca_modes, pca_init_rank_reduction=pca_init_rank_reduction,
+                         check_nans=check_nans, compute=compute, sample_name=sample_name, feature_name=feature_name,
+                         solver=solver, random_state=random_state, solver_kwargs=solver_kwargs)
+        self._params.pop("alpha")

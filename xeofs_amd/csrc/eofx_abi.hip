@@ -1920,6 +1920,29 @@ extern "C" int eofx_sketch_gaussian_f32(uint32_t seed, int64_t rows, int64_t col
 // ------------------------------------------------------------------------------------
 // rotation of loadings (Varimax / Promax), panel-level steps
 // ------------------------------------------------------------------------------------
+// row norms of a panel (host|device float64 output of `rows` entries)
+static int launch_rownorm(eofx_ctx* ctx, const float* P, int64_t rows, int64_t L, int64_t ld, double* out) {
+  ArenaScope scope(ctx);
+  ARENA(double, tmp, rows);
+  hipLaunchKernelGGL(rownorm_kernel, dim3((int)((rows + 3) / 4)), dim3(256), 0, ctx->stream, P, rows, L, ld, tmp);
+  KCHK();
+  HIPCHK(hipMemcpyAsync(out, tmp, sizeof(double) * rows, hipMemcpyDefault, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return EOFX_OK;
+}
+extern "C" int eofx_panel_rownorm_f64(eofx_ctx* ctx, const float* P, int64_t rows, int L, double* out) {
+  if (!ctx || !P || !out || rows <= 0 || L <= 0) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  CHK(set_device(ctx));
+  CHK(arena_reserve(ctx, (size_t)rows * sizeof(double) + 4096));
+  return launch_rownorm(ctx, P, rows, L, L, out);
+}
+extern "C" int eofx_mat_feature_norms_f64(eofx_ctx* ctx, const eofx_mat* m, double* out) {
+  if (!ctx || !m || !out) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  CHK(set_device(ctx));
+  CHK(arena_reserve(ctx, (size_t)m->p * sizeof(double) + 4096));
+  return launch_rownorm(ctx, m->Xt, m->p, m->n, m->n_pad, out);   // rows of X^T = features
+}
+
 extern "C" int eofx_panel_row_normalize_f32(eofx_ctx* ctx, const float* P, int64_t rows_pad, int L, float* out) {
   if (!ctx || !P || !out) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
   CHK(set_device(ctx));

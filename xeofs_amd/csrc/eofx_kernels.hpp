@@ -1344,4 +1344,21 @@ __global__ __launch_bounds__(256) void row_normalize_kernel(const float* __restr
   for (int c = lane; c < L; c += 64) out[r * L + c] = (float)((double)P[r * L + c] * inv);
 }
 
+// Euclidean norm of every row of a row-major [rows x L] array with leading dimension ld (one wave per
+// row, float64 accumulation).  Used for the per-feature standard deviations of the correlation patterns.
+__global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ P, int64_t rows, int64_t L,
+                                                      int64_t ld, double* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  double s = 0.0;
+  for (int64_t c = lane; c < L; c += 64) {
+    const double v = (double)P[r * ld + c];
+    s += v * v;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) out[r] = sqrt(s);
+}
+
 }  // namespace eofx

@@ -474,3 +474,16 @@ def resample(ctx: Context, mat: ResidentMatrix, rows, center: bool = True):
     raise_for(ctx.lib.eofx_resample_f32(ctx.handle, mat.handle, ptr(rows), rows.size, int(center), C.byref(h), ptr(mean),
                                         C.byref(tv)), ctx.handle)
     return ResidentMatrix(ctx, h), mean, tv.value
+
+
+def panel_rownorm(ctx: Context, P, rows: int) -> np.ndarray:
+    out = np.empty(rows, np.float64)
+    raise_for(ctx.lib.eofx_panel_rownorm_f64(ctx.handle, ptr(P), rows, P.shape[1], ptr(out)), ctx.handle)
+    return out
+
+
+def feature_norms(ctx: Context, mat: ResidentMatrix) -> np.ndarray:
+    """sqrt(sum over samples of x^2) per feature of the resident matrix"""
+    out = np.empty(mat.p, np.float64)
+    raise_for(ctx.lib.eofx_mat_feature_norms_f64(ctx.handle, mat.handle, ptr(out)), ctx.handle)
+    return out

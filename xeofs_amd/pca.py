@@ -148,3 +148,12 @@ class ResidentPCA:
     def components(self):
         """V (p x m) float32 on the host."""
         return engine.panel_export(self.ctx, self.Vp, self.p, self.m, self.sign)
+
+    def row_norms(self, M):
+        """Euclidean norms of the rows of V diag(sign) M (p,), M: m x m -- the per-feature standard deviations
+        of the PCA-truncated field when M = (A^T A)^(1/2)."""
+        torch = engine._torch()
+        Mp = np.zeros((self.Lm, self.Lm))
+        Mp[:self.m, :self.m] = np.asarray(M, dtype=np.float64) * self.sign[:, None]
+        out = engine.panel_matmul(self.ctx, self.Vp, torch.as_tensor(Mp, device=self.Vp.device))
+        return engine.panel_rownorm(self.ctx, out, self.p)
