@@ -1,5 +1,5 @@
 import time, numpy as np, torch, sys
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
 rng = np.random.default_rng(0)
 A = rng.standard_normal((n, 2 * n)).astype(np.float32)

@@ -1,7 +1,7 @@
 """Time Varimax / Promax on C4-sized loadings (p = 1,036,800 features, m modes): HIP path vs the oracle."""
 import sys, time
 import numpy as np
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from xeofs_amd import engine, rotation
 from oracle import eof_oracle as orc
 
