@@ -739,3 +739,51 @@ def cpcca_patterns(m, kind="homogeneous"):
         fields.append(Z if m["V"][i] is None else Z @ m["V"][i].conj().T)
     s1, s2 = (m["scores1"], m["scores2"]) if kind == "homogeneous" else (m["scores2"], m["scores1"])
     return pearson_patterns(fields[0], s1), pearson_patterns(fields[1], s2)
+
+
+def cpcca_rotator_fit(m, n_modes, power=1, max_iter=1000, rtol=1e-8):
+    """xeofs/cross/cpcca_rotator.py:122-263 on the dict returned by `cpcca_fit`: Varimax/Promax of the
+    stacked feature-space loadings [Qx; Qy] sqrt(s), taken back to the analysis space (pca / whitener
+    transform_components), sorted by squared covariance (:265-280, after compute)."""
+    k = n_modes
+    s = m["singular_values"][:k]
+    scaling = np.sqrt(s)
+    Qx, Qy = m["components1"][:, :k], m["components2"][:, :k]            # already whitener^-1, pca^-1
+    p1 = Qx.shape[0]
+    loadings = np.concatenate([Qx, Qy], axis=0) * scaling
+    rot_loadings, rot_matrix, phi = promax(loadings, power=power, max_iter=max_iter, rtol=rtol)
+    out = []
+    for i, blk in enumerate((rot_loadings[:p1], rot_loadings[p1:])):
+        Q = blk if m["V"][i] is None else m["V"][i].conj().T @ blk       # pca.transform_components
+        Q = Q if m["T"][i] is None else m["T"][i].conj().T @ Q           # whitener.transform_components
+        out.append(Q)
+    norm1, norm2 = np.linalg.norm(out[0], axis=0), np.linalg.norm(out[1], axis=0)
+    Q1r, Q2r = out[0] / norm1, out[1] / norm2
+    sqcov = (norm1 * norm2) ** 2
+    idx = np.argsort(sqcov)[::-1]
+    RinvT = rot_matrix if power == 1 else np.linalg.inv(rot_matrix).conj().T
+    sc1 = (m["scores1"][:, :k] / scaling) @ RinvT * norm1
+    sc2 = (m["scores2"][:, :k] / scaling) @ RinvT * norm2
+    sign = deterministic_sign_multiplier(rot_loadings.T)
+
+    def back(Q, i):
+        Q = Q if m["Tinv"][i] is None else m["Tinv"][i].conj().T @ Q
+        return Q if m["V"][i] is None else m["V"][i] @ Q
+    return dict(Q1=(Q1r * sign)[:, idx], Q2=(Q2r * sign)[:, idx], components1=back(Q1r * sign, 0)[:, idx],
+                components2=back(Q2r * sign, 1)[:, idx], scores1=(sc1 * sign)[:, idx], scores2=(sc2 * sign)[:, idx],
+                squared_covariance=sqcov[idx], norm1=norm1[idx], norm2=norm2[idx], idx_modes_sorted=idx,
+                rotation_matrix=rot_matrix, phi_matrix=phi, modes_sign=sign[idx],
+                total_squared_covariance=m["total_squared_covariance"])
+
+
+def cpcca_rotator_transform(m, rr, Zc, which, n_modes, power=1, normalized=False):
+    """cpcca_rotator.py:282-372 on preprocessed new data `Zc`: projection on the *back-projected* model
+    components (whitener^-1, pca^-1), / sqrt(s), rotation, sort, sign, norm.  (For alpha != 1 this is not
+    the map that produced the fitted scores -- the reference projects on Tinv^H Q, not T Q.)"""
+    k = n_modes
+    scaling = np.sqrt(m["singular_values"][:k])
+    R = rr["rotation_matrix"]
+    RinvT = R if power == 1 else np.linalg.inv(R).conj().T
+    proj = (Zc @ m[f"components{which}"][:, :k] / scaling) @ RinvT
+    proj = proj[:, rr["idx_modes_sorted"]] * rr["modes_sign"]
+    return proj if normalized else proj * rr[f"norm{which}"]
