@@ -431,7 +431,7 @@ static int launch_atb(eofx_ctx* ctx, const float* A, int64_t lda, int64_t K, int
       if (!bm) return set_err(ctx, EOFX_ERR_NOMEM, "arena exhausted (panel max)");
       HIPCHK(hipMemsetAsync(bm, 0, sizeof(unsigned), ctx->stream));
       const int64_t total4 = K * (L / 4);
-      hipLaunchKernelGGL(panel_absmax_kernel, dim3((int)std::max<int64_t>(1, std::min<int64_t>((total4 + 255) / 256, 2048))),
+      hipLaunchKernelGGL(panel_absmax_kernel, dim3((int)std::max<int64_t>(1, std::min<int64_t>((total4 + 1023) / 1024, 1024))),
                          dim3(256), 0, ctx->stream, B, K, L, (int64_t)ldb, bm);
       KCHK();
       b_absmax_dev = reinterpret_cast<const float*>(bm);
@@ -470,10 +470,10 @@ static int launch_atb(eofx_ctx* ctx, const float* A, int64_t lda, int64_t K, int
 }
 
 
-// number of row-strided partial Gram matrices: ~16 slabs of 32 rows per workgroup for the narrow
+// number of row-strided partial Gram matrices: >= 4 slabs of 32 rows per workgroup for the narrow
 // (sketch-width) panels; wide panels already expose (L/64)^2 sub-blocks, so fewer partials (<= 64 MB)
 static int gram_parts(int64_t rows, int L) {
-  const int64_t by_rows = std::min<int64_t>((rows + 511) / 512, 256);
+  const int64_t by_rows = std::min<int64_t>((rows + 127) / 128, 256);
   const int64_t by_mem = ((int64_t)64 << 20) / ((int64_t)L * L * 8);
   return (int)std::max<int64_t>(1, std::min(by_rows, std::max<int64_t>(by_mem, 1)));
 }
@@ -545,7 +545,7 @@ static int launch_cholqr(eofx_ctx* ctx, const float* P, int64_t rows, int L, int
   ArenaScope scope(ctx);
   ARENA(double, Rinv, (size_t)L * L);
   if (l <= 64) {
-    hipLaunchKernelGGL(chol_rinv_kernel, dim3(1), dim3(64), 0, ctx->stream, G, L, l, Rinv, 1e-13);
+    hipLaunchKernelGGL(chol_rinv_kernel, dim3(1), dim3(256), 0, ctx->stream, G, L, l, Rinv, 1e-13);
     KCHK();
   } else {
     std::vector<double> hG((size_t)L * L), hR((size_t)L * L);
@@ -758,7 +758,7 @@ static int launch_apply(eofx_ctx* ctx, const float* Xsrc, int64_t ld_src, const 
     HIPCHK(hipMemcpyAsync(m->absmax_dev, absmax_src, sizeof(unsigned), hipMemcpyDeviceToDevice, ctx->stream));
   } else {
     const int64_t total4 = m->n_pad * (m->p_pad / 4);
-    hipLaunchKernelGGL(panel_absmax_kernel, dim3((int)std::min<int64_t>((total4 + 255) / 256, 2048)), dim3(256), 0,
+    hipLaunchKernelGGL(panel_absmax_kernel, dim3((int)std::max<int64_t>(1, std::min<int64_t>((total4 + 1023) / 1024, 1024))), dim3(256), 0,
                        ctx->stream, m->X, m->n_pad, (int)m->p_pad, m->p_pad, m->absmax_dev);
     KCHK();
   }

@@ -442,18 +442,31 @@ __global__ __launch_bounds__(256, 2) void atb_f16_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void panel_absmax_kernel(const float* __restrict__ P, int64_t rows,
                                                             int cols, int64_t ld,
                                                             unsigned* __restrict__ out) {
-  const int64_t total = rows * (cols / 4);
+  __shared__ float red[4];
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   float m = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-    const int64_t r = i / (cols / 4);
-    const int c4 = (int)(i - r * (cols / 4));
-    const f32x4 v = *reinterpret_cast<const f32x4*>(P + r * ld + 4 * c4);
-    m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+  if (ld == cols) {   // contiguous block (every panel): plain linear sweep, no index arithmetic
+    const int64_t total = rows * (cols / 4);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+      const f32x4 v = reinterpret_cast<const f32x4*>(P)[i];
+      m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    }
+  } else {
+    const int c4n = cols / 4;
+    for (int64_t r = blockIdx.x; r < rows; r += gridDim.x)
+      for (int c4 = threadIdx.x; c4 < c4n; c4 += blockDim.x) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(P + r * ld + 4 * c4);
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+      }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {   // one atomic per workgroup
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (m > 0.f) atomicMax(out, __float_as_uint(m));
+  }
 }
 
 // out[i] = sum_s part[s][i], fixed order, float64 accumulate.  count4 = elements / 4.
@@ -547,66 +560,74 @@ __global__ __launch_bounds__(256) void f64_reduce_kernel(const double* __restric
 // tol * G[j][j] marks column j as linearly dependent: its Q column becomes exactly zero.
 // l <= 64.
 // ---------------------------------------------------------------------------------
-__device__ __forceinline__ double lane_bcast(double v, int lane) {  // `lane` is a constant after unrolling
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-  return __hiloint2double(hi, lo);
-}
-
-// One wavefront, everything in registers: lane c owns column c of the matrix (col[r] = A[r][c]) and
-// column c of R^-1 (x[r]); all loops are fully unrolled so register indices are constants and values
-// cross lanes with v_readlane (no LDS, no barriers).  Indices >= l are padded with the identity.
-__global__ __launch_bounds__(64, 1) void chol_rinv_kernel(const double* __restrict__ G, int L, int l,
-                                                          double* __restrict__ Rinv, double tol) {
-  const int c = threadIdx.x;
-  double col[64];
-#pragma unroll
-  for (int r = 0; r < 64; ++r) {
+// One workgroup, matrix in LDS, plain loops (a fully unrolled register-resident variant is ~300 KB of
+// straight-line code and runs out of the instruction cache: 390 us instead of ~100).
+//   phase 1: right-looking Cholesky, two barriers per column, trailing update spread over 256 threads;
+//   phase 2: back substitution for X = R^-1 (R X = I), bottom row first, column c by the four threads (c, q).
+// Rows / columns >= l are padded with the identity.
+__global__ __launch_bounds__(256) void chol_rinv_kernel(const double* __restrict__ G, int L, int l,
+                                                         double* __restrict__ Rinv, double tol) {
+  __shared__ double A[64][65];     // upper triangle: R[r][c], r < c (the diagonal is kept as 1/R[j][j] in pivs)
+  __shared__ double X[64][65];     // R^-1 (upper triangle)
+  __shared__ double d0s[64], pivs[64];
+  __shared__ double Ps[4][64];
+  __shared__ int dead[64];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 64 * 64; i += 256) {
+    const int r = i >> 6, c = i & 63;
     double v = (r == c) ? 1.0 : 0.0;
     if (r <= c && c < l) v = G[(int64_t)r * L + c];
-    col[r] = v;
+    A[r][c] = v;
   }
-  const double dorig = (c < l) ? G[(int64_t)c * L + c] : 1.0;
-  bool dead_c = false;
-  double mypiv = 0.0;                              // 1 / R[c][c], kept by lane c
-#pragma unroll
-  for (int j = 0; j < 64; ++j) {
-    const double d = lane_bcast(col[j], j);       // A[j][j] after the updates of steps < j
-    const double d0 = lane_bcast(dorig, j);
+  if (tid < 64) {
+    d0s[tid] = (tid < l) ? G[(int64_t)tid * L + tid] : 1.0;
+    pivs[tid] = 1.0;
+    dead[tid] = 0;
+  }
+  __syncthreads();
+  for (int j = 0; j < l; ++j) {
+    const double d = A[j][j];                       // after the updates of steps < j
+    const double d0 = d0s[j];
     const bool dj = !(d > tol * d0) || !(d0 > 0.0);  // numerically dependent column (uniform)
-    // 1/sqrt(d): hardware estimate + two Newton steps (full float64), no sqrt/div sequences on the
-    // critical path of the column recurrence
-    double piv = __builtin_amdgcn_rsq(dj ? 1.0 : d);
+    double piv = __builtin_amdgcn_rsq(dj ? 1.0 : d); // 1/sqrt(d): estimate + two Newton steps (full float64)
     piv = piv * (1.5 - 0.5 * d * piv * piv);
     piv = piv * (1.5 - 0.5 * d * piv * piv);
     if (dj) piv = 0.0;
-    const double rjj = dj ? 1.0 : d * piv;
-    if (c == j) {
-      col[j] = rjj;
-      dead_c = dj;
-      mypiv = dj ? 1.0 : piv;
-    } else if (c > j) {
-      col[j] *= piv;                               // R[j][c]
+    if (tid == j) {                                  // the diagonal R[j][j] = d * piv is only needed as 1/R[j][j]
+      dead[j] = dj;
+      pivs[j] = dj ? 1.0 : piv;
+    } else if (tid > j && tid < 64) {
+      A[j][tid] *= piv;                              // R[j][c]
     }
-    const double rjc = (c > j) ? col[j] : 0.0;
-#pragma unroll
-    for (int r = j + 1; r < 64; ++r) {
-      const double rjr = lane_bcast(col[j], r);    // R[j][r] lives in lane r
-      col[r] -= rjr * rjc;                         // only rows r <= c are ever read later
+    __syncthreads();
+    const int c = tid & 63;
+    if (c > j) {
+      const double rjc = A[j][c];
+#pragma unroll 4
+      for (int r = j + 1 + (tid >> 6); r <= c; r += 4) A[r][c] -= A[j][r] * rjc;
+    }
+    __syncthreads();                                 // A[j+1][j+1] is final before the next column reads it
+  }
+  // each of the four threads (c, q) sums every fourth term of sum_{t > r} R[r][t] X[t][c]; the partials
+  // are combined in a fixed order (deterministic)
+  {
+    const int c = tid & 63, q = tid >> 6;
+    for (int r = 63; r >= 0; --r) {
+      double s = 0.0;
+#pragma unroll 4
+      for (int t = r + 1 + q; t <= c; t += 4) s += A[r][t] * X[t][c];
+      Ps[q][c] = s;
+      __syncthreads();
+      if (q == 0) {
+        const double tot = ((Ps[0][c] + Ps[1][c]) + Ps[2][c]) + Ps[3][c];
+        X[r][c] = (r <= c) ? (((r == c) ? 1.0 : 0.0) - tot) * pivs[r] : 0.0;
+      }
+      __syncthreads();
     }
   }
-  // back substitution for column c of X = R^-1 (R X = I), bottom row first; x[r] = 0 for r > c falls out
-  double x[64];
-#pragma unroll
-  for (int r = 63; r >= 0; --r) {
-    double s = 0.0;
-#pragma unroll
-    for (int t = r + 1; t < 64; ++t) s += lane_bcast(col[r], t) * x[t];   // R[r][t] lives in lane t
-    x[r] = (((r == c) ? 1.0 : 0.0) - s) * lane_bcast(mypiv, r);           // * 1/R[r][r]
-  }
-#pragma unroll
-  for (int r = 0; r < 64; ++r) {
-    if (r < L && c < L) Rinv[(int64_t)r * L + c] = (r < l && c < l && !dead_c) ? x[r] : 0.0;
+  for (int i = tid; i < 64 * 64; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    if (r < L && c < L) Rinv[(int64_t)r * L + c] = (r < l && c < l && !dead[c]) ? X[r][c] : 0.0;
   }
 }
 

@@ -135,6 +135,18 @@ class ResidentMatrix:
             pass
 
 
+def _host_staging(shape):
+    """float32 host array the engine will upload: page-locked when a GPU is present (the upload of the
+    sketch then is a plain DMA instead of a staged pageable copy; torch caches the pinned blocks)"""
+    try:
+        torch = _torch()
+        if torch.cuda.is_available():
+            return torch.empty(shape, dtype=torch.float32, pin_memory=True).numpy()
+    except Exception:
+        pass
+    return np.empty(shape, dtype=np.float32)
+
+
 def sketch_matrix(rows: int, size: int, random_state=None) -> np.ndarray:
     """The Gaussian test matrix exactly as scikit-learn draws it for
     randomized_svd (sklearn/utils/extmath.py `_randomized_range_finder`):
@@ -149,7 +161,7 @@ def sketch_matrix(rows: int, size: int, random_state=None) -> np.ndarray:
             raise ValueError("Seed must be between 0 and 2**32 - 1")
         # native generator: the same legacy MT19937 / polar-method stream as RandomState(seed).normal,
         # bit for bit (tests/test_abi.py), ~3x faster than numpy for the 600k draws of a 10000 x 60 sketch
-        out = np.empty((rows, size), dtype=np.float32)
+        out = _host_staging((rows, size))
         raise_for(_lib.load().eofx_sketch_gaussian_f32(seed, rows, size, ptr(out)))
         return out
     elif isinstance(random_state, np.random.RandomState):
