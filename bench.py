@@ -39,6 +39,7 @@ sys.path.insert(0, ROOT)
 N_OVERSAMPLES = 10
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBPS = 8000.0
+READ_CEILING_GBPS = 6835.0   # measured: 16 B non-temporal streaming read of 41.5 GB, 16384 workgroups
 
 
 def ar1_series(n, r):
@@ -276,6 +277,9 @@ def main():
                        "bf16x6 per fit; mean over all 16)"),
             "bound": "hbm", "achieved": round(achieved_gbps, 1), "peak": PEAK_HBM_GBPS,
             "unit": "GB/s", "frac": round(achieved_gbps / PEAK_HBM_GBPS, 4),
+            # plain streaming read of the same 41.5 GB on this box (tools/probes/read_bw_probe.hip): 6835 GB/s
+            "practical_read_ceiling": READ_CEILING_GBPS,
+            "frac_of_read_ceiling": round(achieved_gbps / READ_CEILING_GBPS, 4),
         }
     roofline.update({
         "traffic": pmc_traffic, "launches_timed": prof["launches"], "mean_launch_ms": round(launch_ms, 4),
