@@ -135,8 +135,8 @@ def test_two_rank_sharded_path_on_one_gpu(ctx):
     assert d2["parity"]["XV_eq_Us_relerr"] < 1e-5 and d2["parity"]["orth_V_maxabs"] < 1e-6
 
 
-@pytest.mark.parametrize("nan", [False, True])
-def test_two_rank_sharded_mca_and_eof_on_one_gpu(ctx, nan):
+@pytest.mark.parametrize("nan,pca", [(False, False), (True, False), (False, True)])
+def test_two_rank_sharded_mca_and_eof_on_one_gpu(ctx, nan, pca):
     """SURVEY.md §8e (rows C3 + preprocess facts): two processes share cuda:0, each holds half of each
     field's space axis; `sharded_mca_fit` / `sharded_eof_fit` (HIP kernels + gloo all-reduces) against the
     single-GPU drivers on the whole fields.  Tolerances: float32 summation-order differences only."""
@@ -149,7 +149,7 @@ def test_two_rank_sharded_mca_and_eof_on_one_gpu(ctx, nan):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", "29519", os.path.join(root, "tools", "sharded_mca_worker.py"),
-           "--backend", "gloo", "--same-gpu"] + (["--nan"] if nan else [])
+           "--backend", "gloo", "--same-gpu"] + (["--nan"] if nan else []) + (["--pca"] if pca else [])
     run = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=root)
     assert run.returncode == 0, run.stderr[-3000:]
     d = json.loads([ln for ln in run.stdout.strip().splitlines() if ln.startswith("{")][-1])

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--p2", type=int, default=3600)
     ap.add_argument("--modes", type=int, default=8)
     ap.add_argument("--nan", action="store_true", help="mask some grid points / time steps with NaN")
+    ap.add_argument("--pca", action="store_true", help="MCA with the PCA pre-reduction (reference default)")
     a = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -49,7 +50,8 @@ def main():
     lo1, hi1 = sharded.shard_bounds(a.p1, world, rank)
     lo2, hi2 = sharded.shard_bounds(a.p2, world, rank)
     k, seed = a.modes, 5
-    mca = sharded.sharded_mca_fit(ctx, X[:, lo1:hi1], Y[:, lo2:hi2], comm, k, random_state=seed)
+    mca = sharded.sharded_mca_fit(ctx, X[:, lo1:hi1], Y[:, lo2:hi2], comm, k, random_state=seed, use_pca=a.pca,
+                                  n_pca_modes=0.98)
     eof = sharded.sharded_eof_fit(ctx, X[:, lo1:hi1], comm, k, random_state=seed)
 
     def gather_rows(local):
@@ -62,7 +64,16 @@ def main():
     if rank == 0:
         mx, stx = engine.preprocess(ctx, X)
         my, sty = engine.preprocess(ctx, Y)
-        ref = engine.crosscov_rsvd(ctx, mx, my, k, 10, "auto", random_state=seed)
+        if a.pca:
+            from xeofs_amd.pca import ResidentPCA
+
+            p1 = ResidentPCA(ctx, 0.98).fit(mx, stx["total_variance"])
+            p2 = ResidentPCA(ctx, 0.98).fit(my, sty["total_variance"])
+            w1, w2 = engine.from_dense(ctx, p1.scores().astype(np.float32)), engine.from_dense(ctx, p2.scores().astype(np.float32))
+            ref = engine.crosscov_rsvd(ctx, w1, w2, k, min(10, min(w1.p, w2.p) - k), "auto", random_state=seed)
+            ref["Q1"], ref["Q2"] = p1.back_project(ref["Q1"]), p2.back_project(ref["Q2"])
+        else:
+            ref = engine.crosscov_rsvd(ctx, mx, my, k, 10, "auto", random_state=seed)
         U1, s1, V1 = engine.rsvd(ctx, mx, k, 10, "auto", random_state=seed)
         rel = lambda x, y: float(np.abs(np.asarray(x, np.float64) - np.asarray(y, np.float64)).max() / np.abs(np.asarray(y, np.float64)).max())
         cosmin = lambda A, B: float(np.min(np.sum(A.astype(np.float64) * B.astype(np.float64), axis=0)))

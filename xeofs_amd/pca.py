@@ -58,15 +58,27 @@ class ResidentPCA:
         return int(self.n_modes)
 
     # ------------------------------------------------------------------ fit
-    def fit(self, mat, total_variance: float | None = None):
+    def fit(self, mat, total_variance: float | None = None, comm=None, p_total: int | None = None):
+        """`comm` (xeofs_amd.sharded.Comm): `mat` is this rank's slice of the feature axis (p_total features
+        in all); the n x n Gram matrix and the m x m Rayleigh-Ritz Gram matrix are all-reduced, V stays
+        sharded by rows, scores / singular values are replicated.  `total_variance` must then be the global
+        one."""
         torch = engine._torch()
         ctx = self.ctx
         n, p = mat.n, mat.p
-        rank = min(n, p)
+        sharded = comm is not None and getattr(comm, "active", False)
+        p_all = int(p_total) if (sharded and p_total is not None) else p
+        rank = min(n, p_all)
         n_pre = self._n_modes_precompute(rank)
-        side = 0 if n <= p else 1                       # Gram matrix on the small side
+        side = 0 if n <= p_all else 1                   # Gram matrix on the small side
+        if sharded and side == 1:
+            raise NotImplementedError("feature-sharded PCA needs n <= p (the Gram matrix lives on the sample side)")
         r = n if side == 0 else p
-        G = mat.gram(side)[:r, :r].double()
+        Gf = mat.gram(side)
+        if sharded:
+            Gf = comm.sum_(Gf)                          # X X^T = sum over the feature shards
+        G = Gf[:r, :r].double()
+        del Gf
         G = 0.5 * (G + G.T)
         if not bool(torch.isfinite(G).all()):
             raise np.linalg.LinAlgError("SVD failed. This may be due to isolated NaN values in the data.")
@@ -92,7 +104,10 @@ class ResidentPCA:
         # tall-side panel B = A^T E (A = X for side 0): columns ~ s_j v_j
         B = engine.panel_tmul(ctx, mat, Es, prec=ctx.precision[1]) if side == 0 else \
             engine.panel_mul(ctx, mat, Es, prec=ctx.precision[1])
-        M = engine.panel_gram(ctx, B)[:m, :m]
+        M = engine.panel_gram(ctx, B)
+        if sharded:
+            M = comm.sum_(M)
+        M = M[:m, :m]
         M = 0.5 * (M + M.T)
         th, W = torch.linalg.eigh(M)
         th = torch.flip(th, (0,)).clamp_min(0.0)
@@ -113,6 +128,8 @@ class ResidentPCA:
             self.Vp, U = Vp, Tall[:n, :m].double()
         # deterministic sign (utils/xarray_utils.py:273-301 on V), applied before the truncation in _svd.py:208-213
         mx, mn = engine.panel_colminmax(ctx, self.Vp, p)
+        if sharded:
+            mx, mn = comm.max_(mx), comm.min_(mn)
         mx, mn = mx.double()[:m], mn.double()[:m]
         sign = torch.where(mx.abs() >= mn.abs(), torch.ones_like(mx), -torch.ones_like(mx))
         if not self.flip_signs:

@@ -355,11 +355,38 @@ def sharded_eof_fit(ctx, X_local, comm: Comm, n_modes: int, center=True, standar
 
 def sharded_mca_fit(ctx, X_local, Y_local, comm: Comm, n_modes: int, standardize=(False, False),
                     feature_weights=(None, None), check_nans=(True, True), random_state=None,
-                    n_oversamples: int = 10, n_iter="auto", omega=None, want_tsc: bool = True):
-    """`MCA.fit` (cross/base_model_cross_set.py:269-321 + cross/cpcca.py:168-225, use_pca=False) with
-    both fields sharded along their own space axes."""
+                    n_oversamples: int = 10, n_iter="auto", omega=None, want_tsc: bool = True, use_pca: bool = False,
+                    n_pca_modes=0.999, pca_init_rank_reduction=0.3):
+    """`MCA.fit` (cross/base_model_cross_set.py:269-321 + cross/cpcca.py:168-225) with both fields sharded
+    along their own space axes.  With `use_pca` (the reference default) each field is first reduced by a
+    feature-sharded `ResidentPCA` (all-reduced n x n Gram matrix); the analysis on the replicated PC scores
+    needs no further communication and the components come back as this rank's rows of V Q."""
     mx, sx = sharded_preprocess(ctx, X_local, comm, True, standardize[0], feature_weights[0], check_nans[0])
     my, sy = sharded_preprocess(ctx, Y_local, comm, True, standardize[1], feature_weights[1], check_nans[1])
+    if use_pca:
+        from . import engine
+        from .pca import ResidentPCA
+
+        pcas, work = [], []
+        for mat, st in ((mx, sx), (my, sy)):
+            pca = ResidentPCA(ctx, n_pca_modes, pca_init_rank_reduction).fit(mat, st["total_variance"], comm=comm,
+                                                                                p_total=st["p_total"])
+            pcas.append(pca)
+            work.append(engine.from_dense(ctx, pca.scores().astype(np.float32)))
+        k = int(n_modes)
+        rank = min(work[0].p, work[1].p)
+        if k > rank:
+            raise ValueError(f"n_modes must be less than or equal to the rank of the dataset (rank = {rank}).")
+        out = engine.crosscov_rsvd(ctx, work[0], work[1], k, min(n_oversamples, rank - k), n_iter,
+                                   random_state=random_state, omega=omega, want_tsc=want_tsc)
+        for w in work:
+            w.free()
+        s = out["s"].astype(np.float64)
+        return dict(input_data1=mx, input_data2=my, components1=pcas[0].back_project(out["Q1"]),
+                    components2=pcas[1].back_project(out["Q2"]), scores1=out["scores1"], scores2=out["scores2"],
+                    singular_values=s, squared_covariance=s ** 2,
+                    total_squared_covariance=out.get("total_squared_covariance"), norm1=out["norm1"],
+                    norm2=out["norm2"], stats1=sx, stats2=sy, pca=pcas)
     out = sharded_crosscov_rsvd(HipPanelOps(ctx, mx), HipPanelOps(ctx, my), comm, n_modes, sx["p_total"],
                                 sx["p_offset"], sy["p_total"], sy["p_offset"], n_oversamples, n_iter,
                                 random_state=random_state, omega=omega, want_tsc=want_tsc)
