@@ -487,7 +487,7 @@ static int launch_gram(eofx_ctx* ctx, const float* P, int64_t rows, int L, doubl
   hipLaunchKernelGGL(gram_f64_kernel, dim3(nbx, nb * nb), dim3(256), 0, ctx->stream, P, rows, L, part);
   KCHK();
   const int64_t count = (int64_t)L * L;
-  hipLaunchKernelGGL(f64_reduce_kernel, dim3((int)((count + 255) / 256)), dim3(256), 0, ctx->stream,
+  hipLaunchKernelGGL(f64_reduce_kernel, dim3((int)((count + 63) / 64)), dim3(256), 0, ctx->stream,
                      part, G, count, nbx);
   KCHK();
   return EOFX_OK;
@@ -1963,7 +1963,7 @@ extern "C" int eofx_panel_rot_step_f64(eofx_ctx* ctx, const float* X, int64_t ro
   hipLaunchKernelGGL(rot_step_kernel, dim3(nbx), dim3(256), 0, ctx->stream, X, rows_pad, L, R, aux, mode, power, part);
   KCHK();
   const int64_t count = (int64_t)L * L;
-  hipLaunchKernelGGL(f64_reduce_kernel, dim3((int)((count + 255) / 256)), dim3(256), 0, ctx->stream, part, G, count, nbx);
+  hipLaunchKernelGGL(f64_reduce_kernel, dim3((int)((count + 63) / 64)), dim3(256), 0, ctx->stream, part, G, count, nbx);
   KCHK();
   return EOFX_OK;
 }

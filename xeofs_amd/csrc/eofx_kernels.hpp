@@ -547,11 +547,19 @@ __global__ __launch_bounds__(256) void gram_f64_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void f64_reduce_kernel(const double* __restrict__ part,
                                                          double* __restrict__ out, int64_t count,
                                                          int nparts) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= count) return;
+  // 64 outputs per workgroup, four threads per output: thread (i, q) sums the partials b = q, q+4, ...;
+  // the four sums are combined in a fixed order (deterministic)
+  __shared__ double red[4][64];
+  const int li = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + li;
   double s = 0;
-  for (int b = 0; b < nparts; ++b) s += part[(int64_t)b * count + i];
-  out[i] = s;
+  if (i < count) {
+#pragma unroll 4
+    for (int b = q; b < nparts; b += 4) s += part[(int64_t)b * count + i];
+  }
+  red[q][li] = s;
+  __syncthreads();
+  if (q == 0 && i < count) out[i] = ((red[0][li] + red[1][li]) + red[2][li]) + red[3][li];
 }
 
 // ---------------------------------------------------------------------------------
@@ -561,16 +569,18 @@ __global__ __launch_bounds__(256) void f64_reduce_kernel(const double* __restric
 // l <= 64.
 // ---------------------------------------------------------------------------------
 // One workgroup, matrix in LDS, plain loops (a fully unrolled register-resident variant is ~300 KB of
-// straight-line code and runs out of the instruction cache: 390 us instead of ~100).
-//   phase 1: right-looking Cholesky, two barriers per column, trailing update spread over 256 threads;
-//   phase 2: back substitution for X = R^-1 (R X = I), bottom row first, column c by the four threads (c, q).
-// Rows / columns >= l are padded with the identity.
+// straight-line code and runs out of the instruction cache: 390 us).
+//   phase 1: blocked right-looking Cholesky (upper form A = R^T R), 8 rows per block: wave 0 factors the
+//            8-row panel wave-synchronously (no barriers), then all four waves apply the rank-8 update to
+//            the trailing rows -- two barriers per block instead of two per column;
+//   phase 2: back substitution for X = R^-1 (R X = I), bottom row first; each wave owns 16 columns, lane
+//            (c, q) sums every fourth term, partials meet through quad shuffles -- no barriers at all.
+// Rows / columns >= l are padded with the identity.  All sums run in a fixed order (deterministic).
 __global__ __launch_bounds__(256) void chol_rinv_kernel(const double* __restrict__ G, int L, int l,
                                                          double* __restrict__ Rinv, double tol) {
   __shared__ double A[64][65];     // upper triangle: R[r][c], r < c (the diagonal is kept as 1/R[j][j] in pivs)
   __shared__ double X[64][65];     // R^-1 (upper triangle)
   __shared__ double d0s[64], pivs[64];
-  __shared__ double Ps[4][64];
   __shared__ int dead[64];
   const int tid = threadIdx.x;
   for (int i = tid; i < 64 * 64; i += 256) {
@@ -585,46 +595,66 @@ __global__ __launch_bounds__(256) void chol_rinv_kernel(const double* __restrict
     dead[tid] = 0;
   }
   __syncthreads();
-  for (int j = 0; j < l; ++j) {
-    const double d = A[j][j];                       // after the updates of steps < j
-    const double d0 = d0s[j];
-    const bool dj = !(d > tol * d0) || !(d0 > 0.0);  // numerically dependent column (uniform)
-    double piv = __builtin_amdgcn_rsq(dj ? 1.0 : d); // 1/sqrt(d): estimate + two Newton steps (full float64)
-    piv = piv * (1.5 - 0.5 * d * piv * piv);
-    piv = piv * (1.5 - 0.5 * d * piv * piv);
-    if (dj) piv = 0.0;
-    if (tid == j) {                                  // the diagonal R[j][j] = d * piv is only needed as 1/R[j][j]
-      dead[j] = dj;
-      pivs[j] = dj ? 1.0 : piv;
-    } else if (tid > j && tid < 64) {
-      A[j][tid] *= piv;                              // R[j][c]
+  for (int jb = 0; jb < l; jb += 8) {
+    const int je = (jb + 8 < l) ? jb + 8 : l;
+    if (tid < 64) {                                    // wave 0: rows jb .. je-1 of R, wave-synchronous
+      const int c = tid;
+      for (int j = jb; j < je; ++j) {
+        const double d = A[j][j];                      // after the updates of all earlier rows
+        const double d0 = d0s[j];
+        const bool dj = !(d > tol * d0) || !(d0 > 0.0);   // numerically dependent column (uniform)
+        double piv = __builtin_amdgcn_rsq(dj ? 1.0 : d);  // 1/sqrt(d): estimate + two Newton steps
+        piv = piv * (1.5 - 0.5 * d * piv * piv);
+        piv = piv * (1.5 - 0.5 * d * piv * piv);
+        if (dj) piv = 0.0;
+        if (c == j) {
+          dead[j] = dj;
+          pivs[j] = dj ? 1.0 : piv;
+        }
+        double rjc = 0.0;
+        if (c > j) {
+          rjc = A[j][c] * piv;                         // R[j][c]
+          A[j][c] = rjc;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (c > j)
+          for (int r = j + 1; r < je && r <= c; ++r) A[r][c] -= A[j][r] * rjc;   // rows of this panel only
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
     }
     __syncthreads();
-    const int c = tid & 63;
-    if (c > j) {
-      const double rjc = A[j][c];
-#pragma unroll 4
-      for (int r = j + 1 + (tid >> 6); r <= c; r += 4) A[r][c] -= A[j][r] * rjc;
+    {                                                  // rank-(je-jb) update of the trailing rows r >= je
+      const int c = tid & 63;
+      if (c >= je) {
+        double rc[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) rc[u] = (jb + u < je) ? A[jb + u][c] : 0.0;
+        for (int r = je + (tid >> 6); r <= c; r += 4) {
+          double s = 0.0;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) s += ((jb + u < je) ? A[jb + u][r] : 0.0) * rc[u];
+          A[r][c] -= s;
+        }
+      }
     }
-    __syncthreads();                                 // A[j+1][j+1] is final before the next column reads it
+    __syncthreads();
   }
-  // each of the four threads (c, q) sums every fourth term of sum_{t > r} R[r][t] X[t][c]; the partials
-  // are combined in a fixed order (deterministic)
   {
-    const int c = tid & 63, q = tid >> 6;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int c = wave * 16 + (lane >> 2), q = lane & 3;
     for (int r = 63; r >= 0; --r) {
       double s = 0.0;
-#pragma unroll 4
       for (int t = r + 1 + q; t <= c; t += 4) s += A[r][t] * X[t][c];
-      Ps[q][c] = s;
-      __syncthreads();
-      if (q == 0) {
-        const double tot = ((Ps[0][c] + Ps[1][c]) + Ps[2][c]) + Ps[3][c];
-        X[r][c] = (r <= c) ? (((r == c) ? 1.0 : 0.0) - tot) * pivs[r] : 0.0;
-      }
-      __syncthreads();
+      const double s1 = s + __shfl_xor(s, 1);          // (q0 + q1), (q2 + q3)
+      const double tot = s1 + __shfl_xor(s1, 2);       // ((q0 + q1) + (q2 + q3)) in every lane of the quad
+      if (q == 0) X[r][c] = (r <= c) ? (((r == c) ? 1.0 : 0.0) - tot) * pivs[r] : 0.0;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
   }
+  __syncthreads();
   for (int i = tid; i < 64 * 64; i += 256) {
     const int r = i >> 6, c = i & 63;
     if (r < L && c < L) Rinv[(int64_t)r * L + c] = (r < l && c < l && !dead[c]) ? X[r][c] : 0.0;
