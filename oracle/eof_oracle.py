@@ -787,3 +787,28 @@ def cpcca_rotator_transform(m, rr, Zc, which, n_modes, power=1, normalized=False
     proj = (Zc @ m[f"components{which}"][:, :k] / scaling) @ RinvT
     proj = proj[:, rr["idx_modes_sorted"]] * rr["modes_sign"]
     return proj if normalized else proj * rr[f"norm{which}"]
+
+
+# --------------------------------------------------------------------------- #
+# R10  dask branch: dask.array.linalg.svd_compressed                            #
+# --------------------------------------------------------------------------- #
+def svd_compressed(X, k, seed=None, n_power_iter=4, n_oversamples=10, min_subspace_size=20):
+    """The algorithm of `dask.array.linalg.svd_compressed` (dask is an un-vendored dependency, pinned
+    `dask>=2023.0.1` in pyproject.toml; called at xeofs/linalg/decomposer.py:163-171 with
+    `n_power_iter=4`), restated from its published implementation (Halko et al. 2009, alg. 4.3/5.1):
+    comp_level = min(max(min_subspace_size, k + n_oversamples), min(m, n)); Omega ~ N(0,1) (n x comp_level);
+    Y = X Omega; n_power_iter times Y = X (X^T Y) (iterator="power": no re-normalisation); q = tsqr(Y);
+    B = q^T X; SVD of B; u = q u_B; truncate to k; svd_flip.  Only the random stream differs from dask's
+    chunked generator (any Gaussian sketch spans the same subspace to the solver's tolerance)."""
+    X = np.asarray(X, dtype=np.float64)
+    m, n = X.shape
+    comp = min(max(min_subspace_size, k + n_oversamples), min(m, n))
+    Y = X @ np.random.RandomState(seed).standard_normal(size=(n, comp))
+    for _ in range(n_power_iter):
+        Y = X @ (X.T @ Y)
+    q, _ = np.linalg.qr(Y)
+    u, s, vt = np.linalg.svd(q.T @ X, full_matrices=False)
+    u = q @ u
+    u, s, vt = u[:, :k], s[:k], vt[:k]
+    u, vt = svd_flip(u, vt)
+    return u, s, vt

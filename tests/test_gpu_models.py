@@ -187,3 +187,30 @@ def test_decomposer_mirror(ctx):  # tests/linalg/test_decomposer.py
         warnings.simplefilter("always")
         Decomposer(n_modes=0.99, init_rank_reduction=0.1, solver="full").fit(X, total_variance=tv)
         assert any("init_rank_reduction" in str(x.message) for x in w)
+
+
+def test_eof_dask_branch_policy(ctx):
+    """a chunked (dask-backed) input selects the reference's dask branch
+    (linalg/decomposer.py:104, 163-171: svd_compressed(k, seed, n_power_iter=4), sketch width
+    max(20, k + 10)).  The engine materialises the data but keeps the branch's parameters; the result
+    matches the oracle's restatement of svd_compressed (and the exact SVD) on a gap-separated spectrum."""
+    import xeofs_amd as xe
+    from xeofs_amd.linalg import Decomposer
+
+    rng = np.random.default_rng(1)
+    vals = ((rng.standard_normal((300, 7)) * (9.0 * 0.65 ** np.arange(7))) @ rng.standard_normal((7, 40 * 30))
+            + 0.05 * rng.standard_normal((300, 1200))).reshape(300, 40, 30).astype(np.float32)
+    X = xe.DataArray(vals, dims=("time", "lat", "lon"), chunks=((100, 100, 100), (40,), (30,)))
+    assert xe.labelled.is_lazy(X) and not xe.labelled.is_lazy(xe.DataArray(vals, dims=("time", "lat", "lon")))
+    m = xe.single.EOF(n_modes=5, random_state=3).fit(X, "time")
+    Xc = vals.reshape(300, -1).astype(np.float64)
+    Xc -= Xc.mean(0)
+    u, s, vt = orc.svd_compressed(Xc, 5, seed=3)
+    assert np.allclose(m.singular_values().values, s, rtol=2e-5)
+    comps = m.components().values.reshape(5, -1)
+    for j in range(5):
+        assert abs(np.dot(comps[j], vt[j])) > 1 - 1e-5
+    # policy: width max(20, k + 10) and 4 power passes; never the exact solver for lazy input
+    d = Decomposer(n_modes=3, lazy_input=True, ctx=ctx, solver_kwargs={"n_power_iter": 2, "compute": False})
+    d.fit(Xc.astype(np.float32))
+    assert np.allclose(d.s_, s[:3], rtol=2e-5)

@@ -20,8 +20,9 @@ class DataArray:
     """Minimal labelled n-d array (dims, coords, name, attrs) mirroring the xarray names used
     by the reference's accessors."""
 
-    def __init__(self, data, dims=None, coords=None, name=None, attrs=None):
+    def __init__(self, data, dims=None, coords=None, name=None, attrs=None, chunks=None):
         self.values = np.asarray(data)
+        self.chunks = chunks          # like xarray: None for an in-memory array, chunk sizes for a dask-backed one
         if dims is None:
             dims = tuple(f"dim_{i}" for i in range(self.values.ndim))
         self.dims = tuple(dims)
@@ -121,3 +122,11 @@ def concat(objs, dim, coord):
     coords = dict(coords)
     coords[dim] = np.asarray(coord)
     return DataArray(stacked, (dim,) + tuple(dims), coords, name, attrs)
+
+
+def is_lazy(obj) -> bool:
+    """True for a dask-backed (chunked) array: `xarray.DataArray.chunks is not None` -- the reference then
+    takes its dask branch (linalg/decomposer.py:104, 163-171)."""
+    if isinstance(obj, (list, tuple)):
+        return any(is_lazy(o) for o in obj)
+    return getattr(obj, "chunks", None) is not None

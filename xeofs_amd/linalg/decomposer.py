@@ -31,7 +31,7 @@ def sanity_check_n_modes(n_modes):
 
 class Decomposer:
     def __init__(self, n_modes, init_rank_reduction=0.3, flip_signs=True, compute=True, solver="auto",
-                 random_state=None, component_dim_name="mode", solver_kwargs={}, ctx=None):
+                 random_state=None, component_dim_name="mode", solver_kwargs={}, ctx=None, lazy_input=False):
         sanity_check_n_modes(n_modes)
         self.is_based_on_variance = not isinstance(n_modes, (int, np.integer))
         if self.is_based_on_variance and not (0 < init_rank_reduction <= 1.0):
@@ -46,6 +46,10 @@ class Decomposer:
         self.component_dim_name = component_dim_name
         self.solver_kwargs = dict(solver_kwargs)
         self.ctx = ctx
+        # the input was a dask-backed array: the reference then calls dask.array.linalg.svd_compressed
+        # (decomposer.py:104, 163-171).  The engine is eager and resident, so the data are materialised, but the
+        # branch keeps its parameters: sketch width max(20, k + 10), n_power_iter (default 4) power passes.
+        self.lazy_input = bool(lazy_input)
 
     def fit(self, X, dims=("sample", "feature"), total_variance=None, omega=None):
         """`omega`: optional pre-drawn sketch (engine.SketchFuture / ndarray) so the host-side sampling can
@@ -67,7 +71,7 @@ class Decomposer:
             )
         is_small_data = max(n, p) < 500
         if self.solver == "auto":
-            use_exact = bool(is_small_data and self.n_modes_precompute > int(0.8 * rank))
+            use_exact = bool(is_small_data and self.n_modes_precompute > int(0.8 * rank) and not self.lazy_input)
         elif self.solver == "full":
             use_exact = True
         elif self.solver == "randomized":
@@ -87,6 +91,13 @@ class Decomposer:
             # exact truncated SVD (no power iterations needed).
             n_over, n_iter = rank - k, 0
             wide = rank > MAX_SKETCH
+        elif self.lazy_input:
+            # svd_compressed: comp_level = min(max(20, k + n_oversamples), rank), `n_power_iter` passes
+            # (re-orthonormalised here; dask's default iterator="power" does not, which float32 could not afford)
+            kw.pop("compute", None)
+            n_over = min(max(20, k + int(kw.pop("n_oversamples", 10))), rank) - k
+            n_iter = int(kw.pop("n_power_iter", 4))
+            wide = k + n_over > MAX_SKETCH
         else:
             n_over = int(kw.pop("n_oversamples", 10))
             n_iter = kw.pop("n_iter", "auto")

@@ -43,7 +43,8 @@ class EOF:
     def fit(self, X, dim, weights=None):
         self.ctx = self.ctx or engine.default_context()
         self.preprocessor.ctx = self.ctx
-        omega = self._sketch_ahead(X, dim)
+        self._decomposer_kwargs["lazy_input"] = labelled.is_lazy(X)
+        omega = None if self._decomposer_kwargs["lazy_input"] else self._sketch_ahead(X, dim)
         mat = self.preprocessor.fit_transform(X, dim, weights)      # fused HIP preprocess
         self.sample_dims = self.preprocessor.sample_dims
         return self._fit_algorithm(mat, omega)
