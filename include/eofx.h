@@ -163,7 +163,10 @@ int eofx_crosscov_rsvd_f32(eofx_ctx *ctx, const eofx_mat *x, const eofx_mat *y, 
 int eofx_panel_tmul_f32(eofx_ctx *ctx, const eofx_mat *m, const float *Zn, float *Yp, int L,
                         int precision); /* Yp[p_pad x L] = X^T Zn[n_pad x L]; EOFX_PREC_* */
 int eofx_panel_mul_f32(eofx_ctx *ctx, const eofx_mat *m, const float *Yp, float *Wn, int L,
-                       int precision); /* Wn[n_pad x L] = X Yp[p_pad x L]   */
+                       int precision);
+/* EXPERIMENTAL: Wn = X (X^T Zn) -- both products of a power iteration in one pass over the matrix
+ * (persistent cooperative kernel, L must be 64, n_pad a multiple of 1024 and <= 12288, 256-CU part).      */
+int eofx_panel_fused_f32(eofx_ctx *ctx, const eofx_mat *m, const float *Zn, float *Wn, int L); /* Wn[n_pad x L] = X Yp[p_pad x L]   */
 /* G[L x L] (device, float64) = P^T P, accumulated in float64 with a fixed tree. */
 int eofx_panel_gram_f64(eofx_ctx *ctx, const float *P, int64_t rows_pad, int L, double *G);
 /* Cholesky-QR step from a (possibly all-reduced) Gram matrix: out = P R^-1 with

@@ -357,3 +357,27 @@ def test_sharded_world1_equals_driver_bitwise(ctx):
     got2 = sharded.sharded_rsvd(sharded.HipPanelOps(ctx, mat2), sharded.Comm(), 12, 400, 0, random_state=9)
     for a, b in zip(ref2, got2):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("n,p", [(5000, 6000), (3000, 9000)])
+def test_experimental_fused_power_product(ctx, n, p):
+    """`eofx_panel_fused_f32` (W = X (X^T Z) in one pass over X^T, persistent cooperative kernel with an
+    in-L2 exchange between the 32 CUs of an XCD; experimental) against the two-pass product.
+    Tolerance: float32-class (both paths use split-fp16 / exact-f32 MFMA products, different summation order)."""
+    import torch
+    from xeofs_amd import engine
+
+    X = torch.randn((n, p), device="cuda", dtype=torch.float32)
+    mat = engine.from_dense(ctx, X)
+    if mat.n_pad % 1024:
+        pytest.skip("fused product needs n_pad % 1024 == 0")
+    Z = torch.randn((mat.n_pad, 64), device="cuda")
+    Z[n:] = 0
+    Z = Z / Z.norm(dim=0)
+    ref = engine.panel_mul(ctx, mat, engine.panel_tmul(ctx, mat, Z, prec="f32"), prec="f32")
+    got = engine.panel_fused(ctx, mat, Z)
+    got2 = engine.panel_fused(ctx, mat, Z)
+    assert torch.equal(got, got2)                                         # fixed-order exchange: bitwise reproducible
+    assert float((got - ref).abs().max()) <= 5e-6 * float(ref.abs().max())
+    assert not bool(got[n:].any())                                        # padded samples stay zero
+    mat.free()

@@ -2,6 +2,7 @@
 // launch logic, the randomized-SVD drivers and the small host-side linear algebra.
 // Kernels live in eofx_kernels.hpp.  gfx950 only.
 #include "eofx_kernels.hpp"
+#include "eofx_fused.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -1111,6 +1112,88 @@ extern "C" int eofx_panel_tmul_f32(eofx_ctx* ctx, const eofx_mat* m, const float
   CHK(set_device(ctx));
   CHK(arena_reserve(ctx, atb_scratch_bytes(m->p_pad, round_up(m->n, ATB_KG), L)));
   return panel_tmul(ctx, m, Zn, Yp, L, prec);
+}
+// W = X (X^T Z) in one pass over X^T (experimental fused power-iteration product, eofx_fused.hpp).
+// Needs the 8-XCD / 256-CU part, a 64-wide panel and n_pad a multiple of 1024 with n_pad / 32 <= 384.
+static bool fused_supported(const eofx_ctx* ctx, const eofx_mat* m, int L) {
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) return false;
+  return prop.multiProcessorCount == FX_GROUPS * FX_MEMBERS && prop.cooperativeLaunch && L == 64 && m->n_pad % 1024 == 0 &&
+         m->n_pad / FX_MEMBERS <= 4 * FX_MAXT * 32 && m->n_pad / FX_MEMBERS <= 4 * FX_MAXK * 16;
+}
+static int panel_fused(eofx_ctx* ctx, const eofx_mat* m, const float* Zn, float* Wn) {
+  const int64_t npad = m->n_pad;
+  int rows_per_cu = (int)(npad / FX_MEMBERS);
+  ArenaScope scope(ctx);
+  ARENA(float, scrP, (size_t)FX_GROUPS * FX_SLOTS * FX_MEMBERS * 2048);
+  ARENA(float, scrR, (size_t)FX_GROUPS * FX_SLOTS * 2048);
+  ARENA(int, flags, FX_GROUPS * FX_SLOTS * 2 + 64);
+  ARENA(unsigned, zmax, 1);
+  ARENA(float, Wpart, (size_t)FX_GROUPS * npad * 64);
+  int* err = flags + FX_GROUPS * FX_SLOTS * 2;
+  HIPCHK(hipMemsetAsync(flags, 0, sizeof(int) * (FX_GROUPS * FX_SLOTS * 2 + 64), ctx->stream));
+  HIPCHK(hipMemsetAsync(zmax, 0, sizeof(unsigned), ctx->stream));
+  const int64_t total4 = npad * 16;
+  hipLaunchKernelGGL(panel_absmax_kernel, dim3((int)std::max<int64_t>(1, std::min<int64_t>((total4 + 1023) / 1024, 1024))),
+                     dim3(256), 0, ctx->stream, Zn, npad, 64, (int64_t)64, zmax);
+  KCHK();
+  float a_scale = 1.f;
+  if (m->absmax > 0.f && std::isfinite(m->absmax)) {
+    int e;
+    (void)std::frexp(m->absmax, &e);
+    a_scale = std::ldexp(1.f, 14 - e);
+  }
+  const float* Xt = m->Xt;
+  int64_t ldx = npad, ppad = m->p_pad;
+  const float* zmaxf = reinterpret_cast<const float*>(zmax);
+  void* args[] = {(void*)&Xt, (void*)&ldx, (void*)&ppad, (void*)&rows_per_cu, (void*)&Zn, (void*)&Wpart, (void*)&scrP,
+                  (void*)&scrR, (void*)&flags, (void*)&a_scale, (void*)&zmaxf, (void*)&err};
+  const size_t smem = (size_t)(32 * (rows_per_cu + 4) + 5 * 2048) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_xxt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               160 * 1024));
+    attr_set = true;
+  }
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (ctx->profile) {
+    HIPCHK(hipEventCreate(&ev0));
+    HIPCHK(hipEventCreate(&ev1));
+    HIPCHK(hipEventRecord(ev0, ctx->stream));
+  }
+  HIPCHK(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(fused_xxt_kernel), dim3(FX_GROUPS * FX_MEMBERS), dim3(256),
+                                    args, smem, ctx->stream));
+  if (ctx->profile) {
+    HIPCHK(hipEventRecord(ev1, ctx->stream));
+    ctx->prof_events.emplace_back(ev0, ev1);
+    ctx->prof_flops += 4.0 * (double)npad * (double)m->p_pad * 64.0;
+    ctx->prof_bytes += (double)npad * (double)m->p_pad * 4.0;
+  }
+  const int64_t count4 = npad * 64 / 4;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)std::min<int64_t>((count4 + 255) / 256, 4096)), dim3(256), 0, ctx->stream,
+                     Wpart, Wn, count4, FX_GROUPS);
+  KCHK();
+  int herr = 0;
+  HIPCHK(hipMemcpyAsync(&herr, err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (std::getenv("EOFX_FUSED_TIMING")) {
+    long long ts[7];
+    HIPCHK(hipMemcpy(ts, err + 2, sizeof(ts), hipMemcpyDeviceToHost));
+    const double f = 1e-2 / (double)std::max<long long>(ts[6], 1);   // wall_clock64 ticks at 100 MHz -> us per slab
+    fprintf(stderr, "[fused] per slab (us): load %.2f  phase1 %.2f  post+barrier %.2f  reduce+barrier %.2f  readY %.2f  phase2 %.2f  (%lld slabs)\n",
+            ts[0] * f, ts[1] * f, ts[2] * f, ts[3] * f, ts[4] * f, ts[5] * f, ts[6]);
+  }
+  if (herr == 2) return set_err(ctx, EOFX_ERR_HIP, "fused product: workgroups are not dispatched round robin over the XCDs");
+  if (herr) return set_err(ctx, EOFX_ERR_HIP, "fused product: a workgroup timed out waiting for its group");
+  return EOFX_OK;
+}
+extern "C" int eofx_panel_fused_f32(eofx_ctx* ctx, const eofx_mat* m, const float* Zn, float* Wn, int L) {
+  if (!ctx || !m || !Zn || !Wn) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  CHK(set_device(ctx));
+  if (!fused_supported(ctx, m, L))
+    return set_err(ctx, EOFX_ERR_ARG, "fused product needs a 256-CU device, L = 64 and n_pad %% 1024 == 0 (n_pad <= 12288)");
+  CHK(arena_reserve(ctx, (size_t)FX_GROUPS * FX_SLOTS * (FX_MEMBERS + 1) * 2048 * 4 + (size_t)FX_GROUPS * m->n_pad * 64 * 4 + (1 << 20)));
+  return panel_fused(ctx, m, Zn, Wn);
 }
 extern "C" int eofx_panel_mul_f32(eofx_ctx* ctx, const eofx_mat* m, const float* Yp, float* Wn, int L,
                                   int prec) {

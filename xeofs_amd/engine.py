@@ -499,3 +499,12 @@ def feature_norms(ctx: Context, mat: ResidentMatrix) -> np.ndarray:
     out = np.empty(mat.p, np.float64)
     raise_for(ctx.lib.eofx_mat_feature_norms_f64(ctx.handle, mat.handle, ptr(out)), ctx.handle)
     return out
+
+
+def panel_fused(ctx: Context, mat: ResidentMatrix, Zn, out=None):
+    """Wn[n_pad, 64] = X (X^T Zn) in one pass over the matrix (experimental)"""
+    torch = _torch()
+    if out is None:
+        out = torch.empty((mat.n_pad, Zn.shape[1]), dtype=torch.float32, device=Zn.device)
+    raise_for(ctx.lib.eofx_panel_fused_f32(ctx.handle, mat.handle, ptr(Zn), ptr(out), Zn.shape[1]), ctx.handle)
+    return out
