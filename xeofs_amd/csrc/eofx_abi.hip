@@ -560,14 +560,14 @@ static int launch_cholqr(eofx_ctx* ctx, const float* P, int64_t rows, int L, int
 }
 
 static int launch_colminmax(eofx_ctx* ctx, const float* P, int64_t rows, int L, float* mx, float* mn) {
-  const int nparts = (int)std::min<int64_t>((rows + 3) / 4, 512);
+  const int nparts = (int)std::min<int64_t>((rows + 3) / 4, 256);
   ArenaScope scope(ctx);
   ARENA(float, pmx, (size_t)nparts * L);
   ARENA(float, pmn, (size_t)nparts * L);
   hipLaunchKernelGGL(colminmax_part_kernel, dim3(nparts, (L + 63) / 64), dim3(256), 0, ctx->stream, P,
                      rows, L, pmx, pmn);
   KCHK();
-  hipLaunchKernelGGL(colminmax_final_kernel, dim3((L + 63) / 64), dim3(64), 0, ctx->stream, pmx, pmn,
+  hipLaunchKernelGGL(colminmax_final_kernel, dim3((L + 63) / 64), dim3(256), 0, ctx->stream, pmx, pmn,
                      nparts, L, mx, mn);
   KCHK();
   return EOFX_OK;

@@ -568,10 +568,16 @@ __global__ __launch_bounds__(256) void f64_reduce_kernel(const double* __restric
 // tol * G[j][j] marks column j as linearly dependent: its Q column becomes exactly zero.
 // l <= 64.
 // ---------------------------------------------------------------------------------
+__device__ __forceinline__ double rl_f64(double v, int lane) {   // broadcast of lane `lane` (uniform index)
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
 // One workgroup, matrix in LDS, plain loops (a fully unrolled register-resident variant is ~300 KB of
 // straight-line code and runs out of the instruction cache: 390 us).
 //   phase 1: blocked right-looking Cholesky (upper form A = R^T R), 8 rows per block: wave 0 factors the
-//            8-row panel wave-synchronously (no barriers), then all four waves apply the rank-8 update to
+//            8-row panel in registers (v_readlane broadcasts, no barriers), then all four waves apply the rank-8 update to
 //            the trailing rows -- two barriers per block instead of two per column;
 //   phase 2: back substitution for X = R^-1 (R X = I), bottom row first; each wave owns 16 columns, lane
 //            (c, q) sums every fourth term, partials meet through quad shuffles -- no barriers at all.
@@ -597,32 +603,42 @@ __global__ __launch_bounds__(256) void chol_rinv_kernel(const double* __restrict
   __syncthreads();
   for (int jb = 0; jb < l; jb += 8) {
     const int je = (jb + 8 < l) ? jb + 8 : l;
-    if (tid < 64) {                                    // wave 0: rows jb .. je-1 of R, wave-synchronous
+    if (tid < 64) {   // wave 0 factors rows jb .. je-1 of R in registers: lane c holds a[u] = A[jb+u][c];
+                      // values cross lanes with v_readlane (uniform lane index), no LDS round trips
       const int c = tid;
-      for (int j = jb; j < je; ++j) {
-        const double d = A[j][j];                      // after the updates of all earlier rows
-        const double d0 = d0s[j];
-        const bool dj = !(d > tol * d0) || !(d0 > 0.0);   // numerically dependent column (uniform)
-        double piv = __builtin_amdgcn_rsq(dj ? 1.0 : d);  // 1/sqrt(d): estimate + two Newton steps
-        piv = piv * (1.5 - 0.5 * d * piv * piv);
-        piv = piv * (1.5 - 0.5 * d * piv * piv);
-        if (dj) piv = 0.0;
-        if (c == j) {
-          dead[j] = dj;
-          pivs[j] = dj ? 1.0 : piv;
+      double a[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] = (jb + u < je) ? A[jb + u][c] : 0.0;
+      const double d0c = d0s[c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int j = jb + u;
+        if (j < je) {                                   // uniform
+          const double d = rl_f64(a[u], j);             // A[j][j] after the updates of all earlier rows
+          const double d0 = rl_f64(d0c, j);
+          const bool dj = !(d > tol * d0) || !(d0 > 0.0);   // numerically dependent column
+          double piv = __builtin_amdgcn_rsq(dj ? 1.0 : d);  // 1/sqrt(d): estimate + two Newton steps
+          piv = piv * (1.5 - 0.5 * d * piv * piv);
+          piv = piv * (1.5 - 0.5 * d * piv * piv);
+          if (dj) piv = 0.0;
+          if (c == j) {
+            dead[j] = dj;
+            pivs[j] = dj ? 1.0 : piv;
+          }
+          a[u] = (c > j) ? a[u] * piv : 0.0;            // R[j][c]
+#pragma unroll
+          for (int u2 = u + 1; u2 < 8; ++u2) {
+            const int r = jb + u2;
+            if (r < je) {
+              const double rjr = rl_f64(a[u], r);       // R[j][r] lives in lane r
+              if (c >= r) a[u2] -= rjr * a[u];
+            }
+          }
         }
-        double rjc = 0.0;
-        if (c > j) {
-          rjc = A[j][c] * piv;                         // R[j][c]
-          A[j][c] = rjc;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (c > j)
-          for (int r = j + 1; r < je && r <= c; ++r) A[r][c] -= A[j][r] * rjc;   // rows of this panel only
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
       }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (jb + u < je && c > jb + u) A[jb + u][c] = a[u];
     }
     __syncthreads();
     {                                                  // rank-(je-jb) update of the trailing rows r >= je
@@ -646,6 +662,7 @@ __global__ __launch_bounds__(256) void chol_rinv_kernel(const double* __restrict
     const int c = wave * 16 + (lane >> 2), q = lane & 3;
     for (int r = 63; r >= 0; --r) {
       double s = 0.0;
+#pragma unroll 4
       for (int t = r + 1 + q; t <= c; t += 4) s += A[r][t] * X[t][c];
       const double s1 = s + __shfl_xor(s, 1);          // (q0 + q1), (q2 + q3)
       const double tot = s1 + __shfl_xor(s1, 2);       // ((q0 + q1) + (q2 + q3)) in every lane of the quad
@@ -741,18 +758,28 @@ __global__ __launch_bounds__(256) void colminmax_part_kernel(const float* __rest
     pmn[(int64_t)blockIdx.x * L + c] = mn;
   }
 }
-__global__ void colminmax_final_kernel(const float* __restrict__ pmx, const float* __restrict__ pmn,
-                                       int nparts, int L, float* __restrict__ mx,
-                                       float* __restrict__ mn) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= L) return;
+// 64 columns per workgroup, four threads per column (max / min are order independent)
+__global__ __launch_bounds__(256) void colminmax_final_kernel(const float* __restrict__ pmx,
+                                                              const float* __restrict__ pmn, int nparts, int L,
+                                                              float* __restrict__ mx, float* __restrict__ mn) {
+  __shared__ float sa[4][64], sb[4][64];
+  const int li = threadIdx.x & 63, qq = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + li;
   float a = -INFINITY, b = INFINITY;
-  for (int q = 0; q < nparts; ++q) {
-    a = fmaxf(a, pmx[(int64_t)q * L + c]);
-    b = fminf(b, pmn[(int64_t)q * L + c]);
+  if (c < L) {
+#pragma unroll 8
+    for (int q = qq; q < nparts; q += 4) {
+      a = fmaxf(a, pmx[(int64_t)q * L + c]);
+      b = fminf(b, pmn[(int64_t)q * L + c]);
+    }
   }
-  mx[c] = a;
-  mn[c] = b;
+  sa[qq][li] = a;
+  sb[qq][li] = b;
+  __syncthreads();
+  if (qq == 0 && c < L) {
+    mx[c] = fmaxf(fmaxf(sa[0][li], sa[1][li]), fmaxf(sa[2][li], sa[3][li]));
+    mn[c] = fminf(fminf(sb[0][li], sb[1][li]), fminf(sb[2][li], sb[3][li]));
+  }
 }
 
 // dst[r*k + c] = P[r*L + c] * sign[c]   (dense export, drops padding)
