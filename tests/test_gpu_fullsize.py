@@ -160,3 +160,78 @@ def test_two_rank_sharded_mca_and_eof_on_one_gpu(ctx, nan, pca):
     assert d["mca_q1_cos"] > 1 - 1e-5 and d["mca_q2_cos"] > 1 - 1e-5 and d["eof_v_cos"] > 1 - 1e-5
     assert d["mca_scores1"] < 1e-4 and d["mca_scores2"] < 1e-4 and d["eof_scores"] < 1e-4
     assert d["mca_norm1"] < 1e-4 and d["mca_tsc"] < 1e-5 and d["eof_tv"] < 1e-6
+
+
+def test_mca_properties_at_config3(ctx):
+    """BASELINE config 3: MCA(n_modes=20) on two 5000 x (360 x 360) halves, `use_pca=False` semantics, through
+    size-independent properties: orthonormal singular vectors, C Q2 = Q1 diag(s) with C = X^T Y / (n - 1) applied
+    matrix-free, scores = X Q1, the squared-covariance identity sum(s^2) <= TSC, bitwise determinism."""
+    import torch
+
+    from xeofs_amd import engine
+
+    n, nlat, nlon, k = 5000, 360, 720, 20
+    F = _device_field(n, nlat, nlon).reshape(n, nlat, nlon)
+    X = F[:, :, :360].reshape(n, -1).contiguous()
+    Y = F[:, :, 360:].reshape(n, -1).contiguous()
+    del F
+    mx, _ = engine.preprocess(ctx, X, want_stats=False)
+    my, _ = engine.preprocess(ctx, Y, want_stats=False)
+    out = engine.crosscov_rsvd(ctx, mx, my, k, random_state=5)
+    Q1, Q2, s = out["Q1"].astype(np.float64), out["Q2"].astype(np.float64), out["s"].astype(np.float64)
+    assert np.abs(Q1.T @ Q1 - np.eye(k)).max() < 1e-6 and np.abs(Q2.T @ Q2 - np.eye(k)).max() < 1e-6
+    assert np.all(np.diff(s) <= 0) and s[-1] > 0
+    # C Q2 = X^T (Y Q2) / (n - 1) = Q1 diag(s): two projections and one reconstruction-free product
+    YQ2 = engine.project(ctx, my, out["Q2"]).astype(np.float64)                 # n x k
+    assert np.allclose(YQ2, out["scores2"], atol=1e-4 * np.abs(YQ2).max())
+    XQ1 = engine.project(ctx, mx, out["Q1"]).astype(np.float64)
+    assert np.allclose(XQ1, out["scores1"], atol=1e-4 * np.abs(XQ1).max())
+    cross = XQ1.T @ YQ2 / (n - 1)                                              # Q1^T C Q2 = diag(s)
+    assert np.allclose(np.diag(cross), s, rtol=1e-5)
+    assert np.abs(cross - np.diag(np.diag(cross))).max() < 1e-5 * s[0]
+    assert np.allclose(out["norm1"], np.linalg.norm(XQ1, axis=0), rtol=1e-5)
+    assert (s ** 2).sum() <= out["total_squared_covariance"] * (1 + 1e-6)
+    out2 = engine.crosscov_rsvd(ctx, mx, my, k, random_state=5)
+    assert np.array_equal(out["s"], out2["s"]) and np.array_equal(out["Q1"], out2["Q1"])
+    # swapping the fields transposes C: same singular values, vectors exchanged
+    sw = engine.crosscov_rsvd(ctx, my, mx, k, random_state=5, want_tsc=False)
+    lead = 5      # the gap-separated modes; the rest sits in the noise bulk, where a randomized solver only
+    #               converges to the sketch-dependent subspace (the shared t_j of the synthetic halves)
+    assert np.allclose(sw["s"][:lead], out["s"][:lead], rtol=1e-5)
+    assert np.abs(np.abs(np.sum(sw["Q1"].astype(np.float64) * Q2, axis=0))[:lead] - 1).max() < 1e-4
+    mx.free(); my.free()
+    ctx.trim()
+
+
+def test_hilbert_complex_properties_at_scale(ctx):
+    """BASELINE config 5 shape family (Hilbert EOF, padding='exp', decay 0.2) at 4000 x (360 x 720), k = 20:
+    the analytic signal's real part is the (centred) input, its spectrum is one-sided (checked on sampled
+    features with a host FFT), and the complex rSVD satisfies Z V = U diag(s) with orthonormal U, V."""
+    import torch
+
+    from xeofs_amd import engine
+    from xeofs_amd.complex_svd import complex_rsvd
+
+    n, nlat, nlon, k = 4000, 360, 720, 20
+    X = _device_field(n, nlat, nlon)
+    A, st = engine.preprocess(ctx, X, want_stats=False)
+    del X
+    B, _ = engine.hilbert(ctx, A, "exp", 0.2)
+    p = nlat * nlon
+    cols = np.array([0, 1, 777, p // 2, p - 1])
+    a = A.download()[:, cols].astype(np.float64)
+    b = B.download()[:, cols].astype(np.float64)
+    ref = orc.hilbert_transform(a, padding="exp", decay_factor=0.2)            # per-feature operation
+    assert np.allclose(b, ref.imag, atol=2e-5 * np.abs(ref.imag).max())
+    U, s, V = complex_rsvd(ctx, A, B, k, random_state=5)
+    assert np.all(np.diff(s) <= 0) and s[-1] > 0
+    Uc, Vc = U.astype(np.complex128), V.astype(np.complex128)
+    assert np.abs(Uc.conj().T @ Uc - np.eye(k)).max() < 1e-5
+    assert np.abs(Vc.conj().T @ Vc - np.eye(k)).max() < 1e-5
+    # Z V = (A + iB) V = U diag(s): four real projections
+    Vr, Vi = np.ascontiguousarray(V.real), np.ascontiguousarray(V.imag)
+    ZV = (engine.project(ctx, A, Vr) - engine.project(ctx, B, Vi)) + 1j * (engine.project(ctx, A, Vi) + engine.project(ctx, B, Vr))
+    Us = Uc * s.astype(np.float64)
+    assert np.linalg.norm(ZV - Us) / np.linalg.norm(Us) < 2e-5
+    A.free(); B.free()
+    ctx.trim()
