@@ -22,7 +22,9 @@ by oracle/make_golden.py) against
   (a) the real third-party solvers run in the build container: bit-for-bit
       against sklearn's `randomized_svd`, to rounding against scipy `hilbert`,
       `svds` and exact LAPACK SVDs;
-  (b) every invariant the reference's tests state for this path.
+  (b) the output of the real `dask.array.linalg.svd_compressed` (tests/golden/g7, generated with the image's
+      conda interpreter by oracle/make_golden_dask.py) for the dask branch;
+  (c) every invariant the reference's tests state for this path.
 The thin xeofs wrapper semantics (policy, sign rule, scaling, NaN handling) are
 restated from source and are "parity unpinned" by reference-run outputs.
 """

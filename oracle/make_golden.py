@@ -86,6 +86,46 @@ def main():
     y2 = np.random.default_rng(4).standard_normal((51, 4))
     np.savez_compressed(os.path.join(OUT, "g6_hilbert.npz"), y_even=y1, h_even=hilbert(y1, axis=0), y_odd=y2,
                         h_odd=hilbert(y2, axis=0), **VERS)
+    # G2: the reference's NaN fixtures (tests/conftest.py:265-278: "isolated" / "boundary" / full-dimensional
+    # masks on mock_data_array) through numpy's own nan-aware reductions: what Scaler + Sanitizer must produce
+    base = mock_data_array()
+    full = base.copy()
+    full[:, 0, 0] = np.nan          # a grid point missing at all times (full-dimensional along time)
+    full[3, :, :] = np.nan          # a time step missing everywhere
+    fl = full.reshape(25, 20)
+    vf, vs = ~np.isnan(fl).all(axis=0), ~np.isnan(fl).all(axis=1)
+    mean = np.nanmean(fl, axis=0)
+    std = np.nanstd(fl, axis=0)
+    comp = (fl - mean)[np.ix_(vs, vf)]
+    isolated = base.copy()
+    isolated[5, 2, 1] = np.nan      # a single missing value: the reference raises (sanitizer.py:115-122)
+    np.savez_compressed(os.path.join(OUT, "g2_nan_patterns.npz"), full=full, valid_feature=vf, valid_sample=vs,
+                        mean=mean, std=std, compact_centered=comp, total_variance=np.var(comp, axis=0, ddof=1).sum(),
+                        s_exact=np.linalg.svd(comp, compute_uv=False), isolated=isolated, **VERS)
+    # G3: config-1 shape 2920 x (25 x 53), decaying spectrum, k = 10, seeds {0, 5, 42}: scikit-learn outputs in
+    # float64 and float32 (only s and a few rows/columns of U / Vt are stored to keep the fixture small)
+    X3 = lowrank(2920, 25 * 53, 20, 9, np.float64)
+    g3 = dict(n=2920, p=1325, rank=20, data_seed=9, k=10)
+    for seed in (0, 5, 42):
+        for dt, tag in ((np.float64, "f64"), (np.float32, "f32")):
+            U, s, Vt = randomized_svd(X3.astype(dt), n_components=10, random_state=seed)
+            g3[f"s_{tag}_{seed}"] = s
+            g3[f"U_head_{tag}_{seed}"] = U[:8]
+            g3[f"Vt_head_{tag}_{seed}"] = Vt[:, :16]
+    g3["s_exact"] = np.linalg.svd(X3, compute_uv=False)[:10]
+    np.savez_compressed(os.path.join(OUT, "g3_config1_shape.npz"), **g3, **VERS)
+    # G5b: the cross models' default route (use_pca=True, n_pca_modes=0.999, init_rank_reduction=0.3):
+    # `_SVD` = scikit-learn randomized_svd with int(0.3 * rank) components, then the variance truncation
+    # (linalg/_numpy/_svd.py:89-106, 215-241), here with the real solver on the G5 fields
+    g5 = {}
+    for nm, Zc in (("x", Xc), ("y", Yc)):
+        n_pre = int(min(Zc.shape) * 0.3)
+        U, s, Vt = randomized_svd(Zc, n_components=n_pre, random_state=3)
+        cum = np.cumsum(s ** 2 / (Zc.shape[0] - 1) / np.var(Zc, axis=0, ddof=1).sum())
+        g5[f"n_pre_{nm}"], g5[f"s_{nm}"], g5[f"cum_{nm}"] = n_pre, s, cum
+        g5[f"n_keep_{nm}"] = min(n_pre, n_pre - int((cum >= 0.999).sum()) + 1)
+        g5[f"absVt_{nm}"] = np.abs(Vt)
+    np.savez_compressed(os.path.join(OUT, "g5_pca_route.npz"), pca_seed=3, **g5, **VERS)
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("wrote", sorted(os.listdir(OUT)), f"{tot/1024:.0f} kB")
 
