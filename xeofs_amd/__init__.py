@@ -8,4 +8,4 @@ include/eofx.h).  There is no CPU fallback.
 __version__ = "0.1.0"
 
 from . import cross, single, validation  # noqa: E402,F401
-from .labelled import DataArray  # noqa: E402,F401
+from .labelled import DataArray, Dataset  # noqa: E402,F401

@@ -88,6 +88,43 @@ class DataArray:
         return f"<xeofs_amd.DataArray {self.name!r} {dict(self.sizes)}>"
 
 
+class Dataset:
+    """Minimal stand-in for `xarray.Dataset`: named DataArrays sharing their dimensions.  The reference accepts
+    Datasets (its README quickstart feeds one) and returns Datasets with the same data_vars
+    (preprocessing/stacker.py:203-206, 271-275)."""
+
+    def __init__(self, data_vars, attrs=None):
+        self.data_vars = {}
+        for k, v in dict(data_vars).items():
+            if not isinstance(v, DataArray):
+                raise TypeError("Dataset variables must be DataArrays")
+            self.data_vars[k] = DataArray(v.values, v.dims, v.coords, k, v.attrs, v.chunks)
+        self.attrs = dict(attrs or {})
+
+    def __getitem__(self, k):
+        return self.data_vars[k]
+
+    def __iter__(self):
+        return iter(self.data_vars)
+
+    def keys(self):
+        return self.data_vars.keys()
+
+    def __repr__(self):
+        return f"<xeofs_amd.Dataset {list(self.data_vars)}>"
+
+
+def is_dataset(obj) -> bool:
+    return isinstance(obj, Dataset) or (_xr is not None and isinstance(obj, _xr.Dataset))
+
+
+def make_dataset(like, data_vars):
+    """a Dataset of the same flavour as `like`"""
+    if _xr is not None and isinstance(like, _xr.Dataset):
+        return _xr.Dataset(data_vars)
+    return Dataset(data_vars)
+
+
 def is_xarray(obj) -> bool:
     return _xr is not None and isinstance(obj, (_xr.DataArray, _xr.Dataset))
 
@@ -129,4 +166,6 @@ def is_lazy(obj) -> bool:
     takes its dask branch (linalg/decomposer.py:104, 163-171)."""
     if isinstance(obj, (list, tuple)):
         return any(is_lazy(o) for o in obj)
-    return getattr(obj, "chunks", None) is not None
+    if isinstance(obj, Dataset):
+        return any(is_lazy(v) for v in obj.data_vars.values())
+    return bool(getattr(obj, "chunks", None))

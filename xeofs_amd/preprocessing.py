@@ -70,7 +70,7 @@ class Preprocessor:
     def _fields(self, X, sample_dims):
         self.is_list = isinstance(X, (list, tuple))
         self.is_dataset = False
-        if labelled._xr is not None and isinstance(X, labelled._xr.Dataset):
+        if labelled.is_dataset(X):
             self.is_dataset, self._ds_like = True, X
             X = [X[v] for v in X.data_vars]
         xs = list(X) if isinstance(X, (list, tuple)) else [X]
@@ -115,7 +115,7 @@ class Preprocessor:
         return mat, fields, vs
 
     def _fields_like(self, X):
-        if labelled._xr is not None and isinstance(X, labelled._xr.Dataset):
+        if labelled.is_dataset(X):
             X = [X[v] for v in X.data_vars]
         xs = list(X) if isinstance(X, (list, tuple)) else [X]
         fields = [_Field(x, self.sample_dims) for x in xs]
@@ -126,7 +126,7 @@ class Preprocessor:
     # ------------------------------------------------------------------ backward
     def _wrap(self, outs):
         if self.is_dataset:
-            return labelled._xr.Dataset({f.name: o for f, o in zip(self.fields, outs)})
+            return labelled.make_dataset(self._ds_like, {f.name: o for f, o in zip(self.fields, outs)})
         return outs if self.is_list else outs[0]
 
     def inverse_transform_components(self, V, name="components", attrs=None):
