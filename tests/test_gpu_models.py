@@ -243,3 +243,16 @@ def test_dataset_in_dataset_out(ctx):
     assert isinstance(rec, xe.Dataset) and rec["sq"].dims == ("time", "y", "x")
     tr = m.transform(ds)
     assert np.allclose(tr.values, sc.values, atol=1e-3 * np.abs(sc.values).max())
+
+
+def test_lazy_input_error_conventions(ctx):
+    """linalg/decomposer.py:172-177 and :191-193 (tests/linalg/test_decomposer.py:255-268): complex + dask is
+    not implemented; a variance-based number of modes cannot be combined with a dask-backed input."""
+    import xeofs_amd as xe
+
+    v = mock_values().astype(np.float32)
+    lazy = xe.DataArray(v, dims=("time", "lat", "lon"), chunks=((25,), (5,), (4,)))
+    with pytest.raises(NotImplementedError, match="Complex data together with dask"):
+        xe.single.HilbertEOF(n_modes=2).fit(lazy, "time")
+    with pytest.raises(ValueError, match="not supported with dask arrays"):
+        xe.single.EOF(n_modes=0.9).fit(lazy, "time")

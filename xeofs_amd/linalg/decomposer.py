@@ -124,6 +124,10 @@ class Decomposer:
     def _finish(self, U, s, V, n, k, total_variance):
         """variance-fraction truncation, decomposer.py:179-212"""
         if self.is_based_on_variance:
+            if self.lazy_input:      # decomposer.py:191-193
+                raise ValueError("Estimating the number of modes to keep based on variance is not supported with dask "
+                                 "arrays. Please explicitly specifiy the number of modes to keep by using an integer for "
+                                 "the number of modes.")
             if total_variance is None:
                 raise ValueError("variance-based truncation needs the total variance of the input")
             cum = np.cumsum(s.astype(np.float64) ** 2 / (n - 1) / total_variance)

@@ -182,11 +182,18 @@ class ComplexEOF(EOF):
         return A, B, tv
 
     def fit(self, X, dim, weights=None):
+        self._reject_lazy(X)
         self.ctx = self.ctx or engine.default_context()
         self.preprocessor.ctx = self.ctx
         A, B, tv = self._complex_parts(X, dim, weights)
         self.sample_dims = self.preprocessor.sample_dims
         return self._fit_complex(A, B, tv)
+
+    @staticmethod
+    def _reject_lazy(X):
+        if labelled.is_lazy(X):     # linalg/decomposer.py:172-177
+            raise NotImplementedError("Complex data together with dask is currently not implemented. See dask issue 7639 "
+                                      "https://github.com/dask/dask/issues/7639")
 
     def _fit_complex(self, A, B, total_variance):
         from ..complex_svd import complex_rsvd
@@ -235,6 +242,7 @@ class HilbertEOF(ComplexEOF):
         self.attrs.update({"model": "Hilbert EOF analysis"})
 
     def fit(self, X, dim, weights=None):
+        self._reject_lazy(X)
         self.ctx = self.ctx or engine.default_context()
         self.preprocessor.ctx = self.ctx
         A = self.preprocessor.fit_transform(X, dim, weights)
