@@ -1,0 +1,62 @@
+"""Randomised parity sweep of the cross models (CPCCA family) against the oracle: random shapes, NaN masks,
+standardisation, alpha, PCA on/off.  Prints failures."""
+import sys, os, warnings
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import xeofs_amd as xe
+from oracle import eof_oracle as orc
+
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+ncase = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+bad = 0
+warnings.simplefilter("ignore")
+for case in range(ncase):
+    n = int(rng.integers(40, 400))
+    s1 = (int(rng.integers(3, 12)), int(rng.integers(3, 14)))
+    s2 = (int(rng.integers(3, 12)), int(rng.integers(3, 14)))
+    p1, p2 = s1[0] * s1[1], s2[0] * s2[1]
+    r = int(rng.integers(3, 7))
+    T = rng.standard_normal((n, r)) * (4.0 * rng.uniform(0.55, 0.8) ** np.arange(r))
+    A = T @ rng.standard_normal((r, p1)) + rng.uniform(0.05, 0.4) * rng.standard_normal((n, p1)) + rng.uniform(-50, 50)
+    B = T @ rng.standard_normal((r, p2)) + rng.uniform(0.05, 0.4) * rng.standard_normal((n, p2)) + rng.uniform(-50, 50)
+    if rng.random() < 0.5:
+        A[:, rng.choice(p1, size=max(1, p1 // 8), replace=False)] = np.nan
+    if rng.random() < 0.4:
+        B[:, rng.choice(p2, size=max(1, p2 // 8), replace=False)] = np.nan
+    std = bool(rng.integers(0, 2))
+    use_pca = bool(rng.integers(0, 2))
+    alpha = float(rng.choice([1.0, 1.0, 0.5, 0.0])) if (use_pca or min(n, n) > max(p1, p2)) else 1.0
+    k = int(rng.integers(1, min(r, 4) + 1))
+    npm = int(rng.integers(r + 1, r + 6)) if use_pca else 0.999
+    seed = int(rng.integers(0, 1000))
+    try:
+        X = xe.DataArray(A.reshape((n,) + s1), dims=("time", "lat", "lon"))
+        Y = xe.DataArray(B.reshape((n,) + s2), dims=("time", "y", "x"))
+        m = xe.cross.CPCCA(n_modes=k, alpha=alpha, standardize=std, use_pca=use_pca, n_pca_modes=npm, random_state=seed)
+        m.fit(X, Y, "time")
+        ref = orc.cpcca_fit(A, B, k, alpha=alpha, standardize=std, use_pca=use_pca, n_pca_modes=npm, pca_solver="full",
+                            random_state=seed)
+        s, so = m.singular_values().values, ref["singular_values"]
+        ok = np.allclose(s, so, rtol=5e-4)
+        c1 = m.components()[0].values.reshape(k, -1).T
+        c1 = c1[~np.isnan(c1).any(axis=1)]
+        r1 = ref["components1"]
+        for j in range(k):
+            cosv = abs(np.dot(c1[:, j], r1[:, j])) / np.linalg.norm(c1[:, j]) / np.linalg.norm(r1[:, j])
+            gap = min(abs(so[j] - so[j - 1]) if j else np.inf, abs(so[j] - so[j + 1]) if j + 1 < k else so[j]) / so[0]
+            if gap > 0.05 and cosv < 1 - 5e-3:
+                ok = False
+        t1 = m.transform(X=X)
+        s1v = m.scores()[0]
+        if not np.allclose(t1.values, s1v.values, atol=5e-3 * np.abs(s1v.values).max()):
+            ok = False
+        scf = m.squared_covariance_fraction().values
+        if not ((scf >= -1e-9).all() and (scf <= 1 + 1e-4).all()):
+            ok = False
+    except Exception as e:
+        ok = False
+        print("  exception:", type(e).__name__, str(e)[:200])
+    if not ok:
+        bad += 1
+        print(f"case {case}: n={n} p1={p1} p2={p2} k={k} alpha={alpha} std={std} pca={use_pca} npm={npm} seed={seed} FAILED")
+print("cases", ncase, "bad", bad)
