@@ -474,22 +474,23 @@ static int launch_atb(eofx_ctx* ctx, const float* A, int64_t lda, int64_t K, int
 // number of row-strided partial Gram matrices: >= 4 slabs of 32 rows per workgroup for the narrow
 // (sketch-width) panels; wide panels already expose (L/64)^2 sub-blocks, so fewer partials (<= 64 MB)
 static int gram_parts(int64_t rows, int L) {
-  const int64_t by_rows = std::min<int64_t>((rows + 127) / 128, 256);
-  const int64_t by_mem = ((int64_t)64 << 20) / ((int64_t)L * L * 8);
+  // workgroups along the rows; every wave writes its own partial (4 per workgroup, each L x L float64):
+  // >= 8 k-steps (32 rows) per wave, <= 64 MB of partials
+  const int64_t by_rows = std::min<int64_t>((rows + 127) / 128, 512);
+  const int64_t by_mem = ((int64_t)64 << 20) / ((int64_t)L * L * 8 * 4);
   return (int)std::max<int64_t>(1, std::min(by_rows, std::max<int64_t>(by_mem, 1)));
 }
 
 static int launch_gram(eofx_ctx* ctx, const float* P, int64_t rows, int L, double* G) {
   const int nb = (L + 63) / 64;
-  // ~16 slabs of 32 rows per workgroup: few partials for the small (sample-side) panels
   const int nbx = gram_parts(rows, L);
   ArenaScope scope(ctx);
-  ARENA(double, part, (size_t)nbx * L * L);
-  hipLaunchKernelGGL(gram_f64_kernel, dim3(nbx, nb * nb), dim3(256), 0, ctx->stream, P, rows, L, part);
+  ARENA(double, part, (size_t)nbx * 4 * L * L);
+  hipLaunchKernelGGL(gram_mfma_kernel, dim3(nbx, nb * nb), dim3(256), 0, ctx->stream, P, rows, L, part);
   KCHK();
   const int64_t count = (int64_t)L * L;
   hipLaunchKernelGGL(f64_reduce_kernel, dim3((int)((count + 63) / 64)), dim3(256), 0, ctx->stream,
-                     part, G, count, nbx);
+                     part, G, count, nbx * 4);
   KCHK();
   return EOFX_OK;
 }
@@ -1205,7 +1206,7 @@ extern "C" int eofx_panel_mul_f32(eofx_ctx* ctx, const eofx_mat* m, const float*
 extern "C" int eofx_panel_gram_f64(eofx_ctx* ctx, const float* P, int64_t rows_pad, int L, double* G) {
   if (!ctx || !P || !G || L % 32) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
   CHK(set_device(ctx));
-  CHK(arena_reserve(ctx, (size_t)(gram_parts(rows_pad, L) + 1) * L * L * sizeof(double)));
+  CHK(arena_reserve(ctx, (size_t)(4 * gram_parts(rows_pad, L) + 1) * L * L * sizeof(double)));
   return launch_gram(ctx, P, rows_pad, L, G);
 }
 extern "C" int eofx_panel_cholqr_f32(eofx_ctx* ctx, const float* P, int64_t rows_pad, int L, int l,
@@ -1342,7 +1343,7 @@ static size_t rsvd_scratch_bytes(int64_t tall_pad, int64_t small_pad, int l, int
   b += atb_scratch_bytes(small_pad, tall_pad, (int)L);        // split-K partials (small side)
   b += atb_scratch_bytes(tall_pad, small_pad, (int)L);        // split-K partials (tall side)
   b += atb_scratch_bytes(small_pad, tall_pad, (int)Lo);
-  b += 260 * L * L * 8 + L * Lo * 8;                          // gram partials, Rinv, M
+  b += (size_t)(4 * gram_parts(std::max(tall_pad, small_pad), (int)L) + 4) * L * L * 8 + L * Lo * 8;  // gram partials, Rinv, M
   b += (size_t)std::max(tall_pad, small_pad) * (Lo + L) * 4;  // export / import staging
   b += 4 << 20;
   return b;

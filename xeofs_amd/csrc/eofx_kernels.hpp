@@ -544,6 +544,69 @@ __global__ __launch_bounds__(256) void gram_f64_kernel(const float* __restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------
+// gram_mfma: the same float64 Gram matrix on the fp64 matrix cores (v_mfma_f64_16x16x4_f64).
+//   grid = (nbx, nb*nb); every WAVE writes its own partial (4 * nbx partials per 64x64 sub-block) so no
+//   cross-wave reduction is needed; the partials are summed in a fixed order by f64_reduce_kernel.
+//   Per k-step a wave reads 4 rows x 64 columns (lane (c = l % 16, k = l / 16) loads the float4 at
+//   P[row + k][64 b + 4 c ..]: one full 256 B row per 16 lanes), converts to float64 and issues the 16
+//   products a[qa] x b[qb]: lane c of "column group" q stands for column 4 c + q, so tile (qa, qb) holds
+//   G[64 bi + 4 i + qa][64 bj + 4 j + qb].  Products and sums are exact float64 (inputs are float32).
+// ---------------------------------------------------------------------------------
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void gram_mfma_kernel(const float* __restrict__ P, int64_t rows, int L,
+                                                         double* __restrict__ Gpart) {
+  const int nb = (L + 63) / 64;
+  const int bi = blockIdx.y / nb, bj = blockIdx.y % nb;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lc = lane & 15, lk = lane >> 4;
+  const int ca = 64 * bi + 4 * lc, cb = 64 * bj + 4 * lc;
+  const bool same = (bi == bj);
+  f64x4 acc[4][4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) acc[x][y] = f64x4{0.0, 0.0, 0.0, 0.0};
+  const int64_t wstride = (int64_t)gridDim.x * 4 * 4;        // rows covered by one sweep of all waves
+  // software pipeline: the loads of the next k-step are in flight while the 16 products of this one issue
+  auto fetch = [&](int64_t r0, f32x4& va, f32x4& vb) {
+    const int64_t r = r0 + lk;
+    va = f32x4{0.f, 0.f, 0.f, 0.f};
+    vb = va;
+    if (r < rows) {
+      if (ca < L) va = *reinterpret_cast<const f32x4*>(P + r * L + ca);
+      if (!same && cb < L) vb = *reinterpret_cast<const f32x4*>(P + r * L + cb);
+    }
+    if (same) vb = va;
+  };
+  int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * 4;
+  f32x4 va, vb, na, nb_;
+  fetch(r0, va, vb);
+  for (; r0 < rows; r0 += wstride) {
+    fetch(r0 + wstride, na, nb_);                           // rows >= `rows` load zeros
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+      for (int y = 0; y < 4; ++y)
+        acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)va[x], (double)vb[y], acc[x][y], 0, 0, 0);
+    va = na;
+    vb = nb_;
+  }
+  double* G = Gpart + ((int64_t)blockIdx.x * 4 + wave) * (int64_t)L * L;
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = lk + 4 * q, j = lc;                       // D[lane / 16 + 4 reg][lane % 16] (measured layout)
+        const int gi = 64 * bi + 4 * i + x, gj = 64 * bj + 4 * j + y;
+        if (gi < L && gj < L) G[(int64_t)gi * L + gj] = acc[x][y][q];
+      }
+}
+
 __global__ __launch_bounds__(256) void f64_reduce_kernel(const double* __restrict__ part,
                                                          double* __restrict__ out, int64_t count,
                                                          int nparts) {
