@@ -110,7 +110,6 @@ class _Side:
         A = self.A_host()
         if A is not None:
             return A.T @ R
-        torch = engine._torch()
         k = R.shape[1]
         L = engine.panel_width(k)
         Rp = engine.panel_import(self.ctx, np.ascontiguousarray(R, dtype=np.float32), self.mat.n_pad, L)
