@@ -843,6 +843,34 @@ static int run_colstats(eofx_ctx* ctx, const float* Xd, int64_t n, int64_t P, in
   return EOFX_OK;
 }
 
+struct FeatSummary {
+  int64_t pv = 0;      // features with at least one non-NaN value
+  int cmin = 0, cmax = 0;
+  double tv = 0.0;     // total variance of the transformed valid features (ddof = 1)
+};
+static int run_feature_summary(eofx_ctx* ctx, const PreState& ps, int64_t P, FeatSummary& fs) {
+  const int nb = (int)std::max<int64_t>(1, std::min<int64_t>((P + 4095) / 4096, 256));
+  ArenaScope scope(ctx);
+  ARENA(double, tvp, nb);
+  ARENA(int, ip, 3 * nb);
+  hipLaunchKernelGGL(feature_summary_kernel, dim3(nb), dim3(256), 0, ctx->stream, ps.cnt, ps.m2, ps.scale, P, tvp, ip);
+  KCHK();
+  std::vector<double> htv(nb);
+  std::vector<int> hip_(3 * nb);
+  HIPCHK(hipMemcpyAsync(htv.data(), tvp, sizeof(double) * nb, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(hip_.data(), ip, sizeof(int) * 3 * nb, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  fs = FeatSummary();
+  fs.cmin = INT32_MAX;
+  for (int b = 0; b < nb; ++b) {   // fixed order
+    fs.tv += htv[b];
+    fs.pv += hip_[3 * b];
+    fs.cmin = std::min(fs.cmin, hip_[3 * b + 1]);
+    fs.cmax = std::max(fs.cmax, hip_[3 * b + 2]);
+  }
+  return EOFX_OK;
+}
+
 static size_t colstats_scratch(int64_t n, int64_t P) {
   const int64_t gx = (P + 255) / 256;
   int64_t RS = std::max<int64_t>(1, (2048 + gx - 1) / gx);
@@ -854,23 +882,31 @@ static size_t colstats_scratch(int64_t n, int64_t P) {
 static int sanitize_and_apply(eofx_ctx* ctx, const float* Xd, int64_t n, int64_t P, PreState& ps,
                               bool stats_absmax, const uint8_t* expect_valid, int check_nans, eofx_mat** out,
                               uint8_t* valid_feature, uint8_t* valid_sample, int64_t* n_out,
-                              int64_t* p_out, std::vector<int>& hcnt) {
-  hcnt.resize(P);
-  HIPCHK(hipMemcpyAsync(hcnt.data(), ps.cnt, sizeof(int) * P, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  int64_t pv = 0;
-  int cmax = 0, cmin = INT32_MAX;
-  for (int64_t c = 0; c < P; ++c) {
-    const int k = hcnt[c];
-    if (k > 0) {
-      ++pv;
-      cmax = std::max(cmax, k);
-      cmin = std::min(cmin, k);
+                              int64_t* p_out, std::vector<int>& hcnt, FeatSummary* summary = nullptr) {
+  FeatSummary fs;
+  CHK(run_feature_summary(ctx, ps, P, fs));
+  if (summary) *summary = fs;
+  int64_t pv = fs.pv;
+  int cmax = fs.cmax, cmin = fs.cmin;
+  hcnt.clear();
+  if (pv == P) {   // every feature has data (the common case): no need for the P-sized count array on the host
+    if (valid_feature) std::memset(valid_feature, 1, (size_t)P);
+    if (expect_valid && check_nans)
+      for (int64_t c = 0; c < P; ++c)
+        if (!expect_valid[c])
+          return set_err(ctx, EOFX_ERR_NAN_MISMATCH,
+                         "Input data had NaN features in different locations than the original data.");
+  } else {
+    hcnt.resize(P);
+    HIPCHK(hipMemcpyAsync(hcnt.data(), ps.cnt, sizeof(int) * P, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (int64_t c = 0; c < P; ++c) {
+      const int k = hcnt[c];
+      if (valid_feature) valid_feature[c] = k > 0;
+      if (expect_valid && check_nans && (expect_valid[c] != 0) != (k > 0))
+        return set_err(ctx, EOFX_ERR_NAN_MISMATCH,
+                       "Input data had NaN features in different locations than the original data.");
     }
-    if (valid_feature) valid_feature[c] = k > 0;
-    if (expect_valid && check_nans && (expect_valid[c] != 0) != (k > 0))
-      return set_err(ctx, EOFX_ERR_NAN_MISMATCH,
-                     "Input data had NaN features in different locations than the original data.");
   }
   if (pv == 0) return set_err(ctx, EOFX_ERR_ARG, "input has no valid (non-NaN) feature");
   static const char* kPartial =
@@ -972,22 +1008,14 @@ extern "C" int eofx_preprocess_f32(eofx_ctx* ctx, const float* X, int64_t n, int
   CHK(run_colstats(ctx, st.dev, n, P, center, standardize, wdev, ps));
   std::vector<int> hcnt;
   int64_t ns = 0, pv = 0;
+  FeatSummary fs;
   CHK(sanitize_and_apply(ctx, st.dev, n, P, ps, true, nullptr, check_nans, out, valid_feature, valid_sample, &ns,
-                         &pv, hcnt));
+                         &pv, hcnt, &fs));
   if (n_out) *n_out = ns;
   if (p_out) *p_out = pv;
   if (mean) HIPCHK(hipMemcpyAsync(mean, ps.mean, sizeof(double) * P, hipMemcpyDeviceToHost, ctx->stream));
   if (std_) HIPCHK(hipMemcpyAsync(std_, ps.stdv, sizeof(double) * P, hipMemcpyDeviceToHost, ctx->stream));
-  if (total_variance) {
-    std::vector<double> hm2(P), hsc(P);
-    HIPCHK(hipMemcpyAsync(hm2.data(), ps.m2, sizeof(double) * P, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(hsc.data(), ps.scale, sizeof(double) * P, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    double tv = 0.0;
-    for (int64_t c = 0; c < P; ++c)
-      if (hcnt[c] > 0) tv += hsc[c] * hsc[c] * hm2[c] / (double)(hcnt[c] - 1);
-    *total_variance = tv;
-  }
+  if (total_variance) *total_variance = fs.tv;   // summed on the device (feature_summary_kernel)
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return EOFX_OK;
 }
@@ -1067,16 +1095,10 @@ extern "C" int eofx_resample_f32(eofx_ctx* ctx, const eofx_mat* src, const int64
   int rc = launch_apply(ctx, src->X, src->p_pad, drows, nullptr, ps.shift, ps.scale, m, flag, ps.absmax);
   if (rc == EOFX_OK && mean)
     if (hipMemcpyAsync(mean, ps.mean, sizeof(double) * P, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = EOFX_ERR_HIP;
-  if (rc == EOFX_OK && total_variance) {
-    std::vector<double> hm2(P);
-    if (hipMemcpyAsync(hm2.data(), ps.m2, sizeof(double) * P, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-        hipStreamSynchronize(ctx->stream) != hipSuccess) {
-      rc = EOFX_ERR_HIP;
-    } else {
-      double tv = 0.0;
-      for (int64_t c = 0; c < P; ++c) tv += hm2[c] / (double)(n_rows - 1);
-      *total_variance = tv;
-    }
+  if (rc == EOFX_OK && total_variance) {   // sum_c M2_c / (n_rows - 1), summed on the device
+    FeatSummary fs;
+    rc = run_feature_summary(ctx, ps, P, fs);
+    if (rc == EOFX_OK) *total_variance = fs.tv;
   }
   if (rc == EOFX_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = EOFX_ERR_HIP;
   if (rc != EOFX_OK) {

@@ -984,6 +984,52 @@ __global__ __launch_bounds__(256) void colstats_finalize_kernel(
   if ((threadIdx.x & 63) == 0 && amax > 0.f && amax < INFINITY) atomicMax(absmax, __float_as_uint(amax));
 }
 
+// Per-workgroup summary of the column statistics (fixed-order tree): number of valid features, min / max of
+// their non-NaN counts, and the total variance sum_c scale_c^2 M2_c / (cnt_c - 1) -- so that the common
+// NaN-free case needs a few hundred bytes from the device instead of P-sized arrays.
+__global__ __launch_bounds__(256) void feature_summary_kernel(const int* __restrict__ cnt,
+                                                              const double* __restrict__ m2,
+                                                              const double* __restrict__ scale, int64_t P,
+                                                              double* __restrict__ tv_part,
+                                                              int* __restrict__ ipart) {
+  __shared__ double st[256];
+  __shared__ int sp[256], smin[256], smax[256];
+  const int tid = threadIdx.x;
+  double tv = 0.0;
+  int pv = 0, cmin = INT32_MAX, cmax = 0;
+  const int64_t per = (P + gridDim.x - 1) / gridDim.x;
+  const int64_t c0 = (int64_t)blockIdx.x * per, c1 = (c0 + per < P) ? c0 + per : P;
+  for (int64_t c = c0 + tid; c < c1; c += 256) {
+    const int k = cnt[c];
+    if (k > 0) {
+      ++pv;
+      cmin = k < cmin ? k : cmin;
+      cmax = k > cmax ? k : cmax;
+      tv += scale[c] * scale[c] * m2[c] / (double)(k - 1);
+    }
+  }
+  st[tid] = tv;
+  sp[tid] = pv;
+  smin[tid] = cmin;
+  smax[tid] = cmax;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) {
+      st[tid] += st[tid + s];
+      sp[tid] += sp[tid + s];
+      smin[tid] = smin[tid + s] < smin[tid] ? smin[tid + s] : smin[tid];
+      smax[tid] = smax[tid + s] > smax[tid] ? smax[tid + s] : smax[tid];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    tv_part[blockIdx.x] = st[0];
+    ipart[3 * blockIdx.x] = sp[0];
+    ipart[3 * blockIdx.x + 1] = smin[0];
+    ipart[3 * blockIdx.x + 2] = smax[0];
+  }
+}
+
 // count of non-NaN entries per row restricted to valid feature columns
 __global__ __launch_bounds__(256) void rowcount_kernel(const float* __restrict__ X, int64_t n,
                                                         int64_t P, const int* __restrict__ colcnt,
