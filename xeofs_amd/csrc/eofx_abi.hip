@@ -561,7 +561,7 @@ static int launch_cholqr(eofx_ctx* ctx, const float* P, int64_t rows, int L, int
 }
 
 static int launch_colminmax(eofx_ctx* ctx, const float* P, int64_t rows, int L, float* mx, float* mn) {
-  const int nparts = (int)std::min<int64_t>((rows + 3) / 4, 256);
+  const int nparts = (int)std::max<int64_t>(1, std::min<int64_t>((rows + 127) / 128, 1024));
   ArenaScope scope(ctx);
   ARENA(float, pmx, (size_t)nparts * L);
   ARENA(float, pmn, (size_t)nparts * L);
@@ -1248,7 +1248,7 @@ extern "C" int eofx_panel_colminmax_f32(eofx_ctx* ctx, const float* P, int64_t r
                                         float* mn) {
   if (!ctx || !P || !mx || !mn) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
   CHK(set_device(ctx));
-  CHK(arena_reserve(ctx, (size_t)2 * 512 * L * sizeof(float) + 4096));
+  CHK(arena_reserve(ctx, (size_t)2 * 1024 * L * sizeof(float) + 4096));
   return launch_colminmax(ctx, P, rows, L, mx, mn);
 }
 extern "C" int eofx_panel_export_f32(eofx_ctx* ctx, const float* P, int64_t rows, int L, int k,

@@ -794,31 +794,55 @@ __global__ __launch_bounds__(256) void panel_matmul_kernel(const float* __restri
 }
 
 // per-column max/min over rows [0, rows): partial per block, then a second tiny pass.
+// thread (cq, rl): float4 of columns 64 by + 4 cq .., rows rl, rl + 16, ... (one 256 B row per 16 lanes);
+// eight independent loads in flight per thread
 __global__ __launch_bounds__(256) void colminmax_part_kernel(const float* __restrict__ P,
                                                              int64_t rows, int L,
                                                              float* __restrict__ pmx,
                                                              float* __restrict__ pmn) {
-  __shared__ float smx[4][64], smn[4][64];
+  __shared__ float smx[16][64], smn[16][64];
   const int tid = threadIdx.x;
-  const int c = blockIdx.y * 64 + (tid & 63);
-  const int rl = tid >> 6;
-  float mx = -INFINITY, mn = INFINITY;
-  if (c < L)
-    for (int64_t r = (int64_t)blockIdx.x * 4 + rl; r < rows; r += (int64_t)gridDim.x * 4) {
-      const float v = P[r * L + c];
-      mx = fmaxf(mx, v);
-      mn = fminf(mn, v);
+  const int cq = tid & 15, rl = tid >> 4;
+  const int c = blockIdx.y * 64 + 4 * cq;
+  f32x4 mx = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, mn = {INFINITY, INFINITY, INFINITY, INFINITY};
+  if (c < L) {
+    const int64_t step = (int64_t)gridDim.x * 16;
+    int64_t r = (int64_t)blockIdx.x * 16 + rl;
+    for (; r + 7 * step < rows; r += 8 * step) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(P + (r + u * step) * L + c);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          mx[e] = fmaxf(mx[e], v[u][e]);
+          mn[e] = fminf(mn[e], v[u][e]);
+        }
     }
-  smx[rl][tid & 63] = mx;
-  smn[rl][tid & 63] = mn;
+    for (; r < rows; r += step) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(P + r * L + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        mx[e] = fmaxf(mx[e], v[e]);
+        mn[e] = fminf(mn[e], v[e]);
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    smx[rl][4 * cq + e] = mx[e];
+    smn[rl][4 * cq + e] = mn[e];
+  }
   __syncthreads();
-  if (rl == 0 && c < L) {
-    for (int q = 1; q < 4; ++q) {
-      mx = fmaxf(mx, smx[q][tid]);
-      mn = fminf(mn, smn[q][tid]);
+  if (tid < 64 && blockIdx.y * 64 + tid < L) {
+    float a = smx[0][tid], b = smn[0][tid];
+    for (int q = 1; q < 16; ++q) {
+      a = fmaxf(a, smx[q][tid]);
+      b = fminf(b, smn[q][tid]);
     }
-    pmx[(int64_t)blockIdx.x * L + c] = mx;
-    pmn[(int64_t)blockIdx.x * L + c] = mn;
+    pmx[(int64_t)blockIdx.x * L + blockIdx.y * 64 + tid] = a;
+    pmn[(int64_t)blockIdx.x * L + blockIdx.y * 64 + tid] = b;
   }
 }
 // 64 columns per workgroup, four threads per column (max / min are order independent)
