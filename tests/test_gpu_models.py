@@ -256,3 +256,24 @@ def test_lazy_input_error_conventions(ctx):
         xe.single.HilbertEOF(n_modes=2).fit(lazy, "time")
     with pytest.raises(ValueError, match="not supported with dask arrays"):
         xe.single.EOF(n_modes=0.9).fit(lazy, "time")
+
+
+def test_resident_torch_input(ctx):
+    """A field that already lives in HBM (torch CUDA tensor inside a DataArray) is read in place: same result,
+    bit for bit, as the same values handed over as a numpy array."""
+    import torch
+    import xeofs_amd as xe
+
+    v = mock_values().astype(np.float32)
+    a = xe.DataArray(v, dims=("time", "lat", "lon"), coords={"lat": [20.0, 30.0, 40.0, 50.0, 60.0]})
+    b = xe.DataArray(torch.as_tensor(v, device="cuda"), dims=("time", "lat", "lon"), coords={"lat": [20.0, 30.0, 40.0, 50.0, 60.0]})
+    ma = xe.single.EOF(n_modes=3, use_coslat=True, random_state=4).fit(a, ("time",))
+    mb = xe.single.EOF(n_modes=3, use_coslat=True, random_state=4).fit(b, ("time",))
+    assert np.array_equal(ma.components().values, mb.components().values)
+    assert np.array_equal(ma.scores().values, mb.scores().values)
+    # non-leading sample dimension: the permuted view is materialised on the device
+    mc = xe.single.EOF(n_modes=2, random_state=1).fit(b, ("lat", "lon"))
+    md = xe.single.EOF(n_modes=2, random_state=1).fit(a, ("lat", "lon"))
+    assert np.array_equal(mc.singular_values().values, md.singular_values().values)
+    c1, c2 = xe.cross.MCA(n_modes=2, random_state=3, use_pca=False).fit(b, b, "time").components()
+    assert c1.dims == ("mode", "lat", "lon") and not np.isnan(c2.values).any()

@@ -16,12 +16,18 @@ except Exception:  # xarray absent
     _xr = None
 
 
+def _is_torch(a) -> bool:
+    return type(a).__module__.startswith("torch") and hasattr(a, "device")
+
+
 class DataArray:
     """Minimal labelled n-d array (dims, coords, name, attrs) mirroring the xarray names used
     by the reference's accessors."""
 
     def __init__(self, data, dims=None, coords=None, name=None, attrs=None, chunks=None):
-        self.values = np.asarray(data)
+        # a torch tensor (e.g. a field that already lives in HBM) is kept as it is: the preprocessing kernels
+        # read it in place, nothing crosses PCIe
+        self.values = data if _is_torch(data) else np.asarray(data)
         self.chunks = chunks          # like xarray: None for an in-memory array, chunk sizes for a dask-backed one
         if dims is None:
             dims = tuple(f"dim_{i}" for i in range(self.values.ndim))
@@ -37,7 +43,7 @@ class DataArray:
         self.attrs = dict(attrs or {})
 
     data = property(lambda self: self.values)
-    shape = property(lambda self: self.values.shape)
+    shape = property(lambda self: tuple(self.values.shape))
     ndim = property(lambda self: self.values.ndim)
     dtype = property(lambda self: self.values.dtype)
 

@@ -36,9 +36,9 @@ class _Field:
         self.sample_dims = tuple(sample_dims)
         self.feature_dims = tuple(d for d in dims if d not in sample_dims)  # order of X.dims (stacker.py:192-193)
         order = [dims.index(d) for d in self.sample_dims + self.feature_dims]
-        v = np.transpose(vals, order)
-        self.sample_shape = v.shape[:len(self.sample_dims)]
-        self.feature_shape = v.shape[len(self.sample_dims):]
+        v = vals.permute(order) if labelled._is_torch(vals) else np.transpose(vals, order)   # device tensors stay on the device
+        self.sample_shape = tuple(v.shape[:len(self.sample_dims)])
+        self.feature_shape = tuple(v.shape[len(self.sample_dims):])
         self.n = int(np.prod(self.sample_shape, dtype=np.int64))
         self.P = int(np.prod(self.feature_shape, dtype=np.int64))
         self.matrix = v.reshape(self.n, self.P)
@@ -92,6 +92,14 @@ class Preprocessor:
                     v = v * f.feature_vector(w)
                 ws.append(v)
             ws = np.concatenate(ws)
+        if any(labelled._is_torch(f.matrix) for f in fields):      # resident input: concatenate on the device
+            import torch
+
+            dev = next(f.matrix.device for f in fields if labelled._is_torch(f.matrix))
+            mats = [(f.matrix if labelled._is_torch(f.matrix) else torch.as_tensor(np.asarray(f.matrix))).to(dev, torch.float32)
+                    for f in fields]
+            M = mats[0] if len(mats) == 1 else torch.cat(mats, dim=1)
+            return M.contiguous(), ws
         mats = [np.asarray(f.matrix, dtype=np.float32) for f in fields]
         M = mats[0] if len(mats) == 1 else np.concatenate(mats, axis=1)
         return np.ascontiguousarray(M), ws

@@ -60,7 +60,7 @@ class EOF:
             vals, dims, _, _, _ = labelled.unpack(X)
             sd = (dim,) if isinstance(dim, str) else tuple(dim)
             n = int(np.prod([vals.shape[dims.index(d)] for d in sd]))
-            p = vals.size // max(n, 1)
+            p = int(np.prod(tuple(vals.shape), dtype=np.int64)) // max(n, 1)
             if n >= p:      # the sketch lives on the feature side: its size depends on the NaN mask
                 return None
             n_over = int(self._solver_kwargs.get("n_oversamples", 10))
