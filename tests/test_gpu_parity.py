@@ -381,3 +381,24 @@ def test_experimental_fused_power_product(ctx, n, p):
     assert float((got - ref).abs().max()) <= 5e-6 * float(ref.abs().max())
     assert not bool(got[n:].any())                                        # padded samples stay zero
     mat.free()
+
+
+def test_documented_size_limits_fail_loudly(ctx):
+    """The limits DESIGN.md §13 lists raise instead of degrading silently."""
+    import torch
+    from xeofs_amd import engine, rotation
+    from xeofs_amd.complex_svd import complex_rsvd
+
+    with pytest.raises(NotImplementedError, match="more than 64 modes"):
+        rotation.promax(ctx, np.ones((200, 65), np.float32))
+    rng = np.random.default_rng(0)
+    A = engine.from_dense(ctx, rng.standard_normal((300, 400)).astype(np.float32))
+    B = engine.from_dense(ctx, rng.standard_normal((300, 400)).astype(np.float32))
+    with pytest.raises(NotImplementedError, match="complex sketch width"):
+        complex_rsvd(ctx, A, B, 30)                      # 30 + 10 oversamples > 32
+    Z = torch.zeros((A.n_pad, 32), device="cuda")
+    with pytest.raises(ValueError, match="fused product needs"):
+        engine.panel_fused(ctx, A, Z)                    # L != 64
+    with pytest.raises(ValueError, match="rank of the dataset"):
+        engine.rsvd(ctx, A, 301)
+    A.free(); B.free()
