@@ -4,8 +4,8 @@ import numpy as np
 from oracle import eof_oracle as orc
 from xeofs_amd import engine
 ctx = engine.Context(0)
-rng = np.random.default_rng(1)
-for case in range(41):
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+for case in range((int(sys.argv[2]) if len(sys.argv) > 2 else 40) + 1):
     n = int(rng.integers(12, 700)); p = int(rng.integers(12, 3000)); r = min(n, p)
     k = int(rng.integers(1, max(2, min(r - 1, 40)))); rank = int(rng.integers(2, 12))
     amp = 5.0 * rng.uniform(0.5, 0.95) ** np.arange(rank)
