@@ -27,11 +27,8 @@ for case in range(ncase):
         U, s, V = engine.rsvd(ctx, mat, k, random_state=seed)
         mat.free()
         so = ref["norms"]
-        # modes the randomized solver has not converged on (oracle vs exact SVD differ by delta_j, typically the
-        # noise bulk with few samples) amplify rounding-level differences between mathematically equivalent
-        # normalisations: allow 5e-3 of that convergence gap on top of the 1e-5 of the converged modes
         se = np.linalg.svd(ref["input_data"], compute_uv=False)[:k]
-        ok = np.all(np.abs(s - so) <= 1e-5 * so + 3e-6 * so[0] + 5e-3 * np.abs(so - se))
+        ok = np.all(np.abs(s - so) <= 1e-5 * so + 3e-6 * so[0])
         ok &= abs(st["total_variance"] - ref["total_variance"]) <= 1e-5 * ref["total_variance"]
         ok &= V.shape == ref["components"].shape and U.shape == ref["U"].shape
         for j in range(k):

@@ -1288,6 +1288,8 @@ static int rsvd_auto_iters(int k, int64_t n, int64_t p) {
 }
 
 // All panels are carved from the arena by the caller-visible drivers (reserve first).
+constexpr size_t EOFX_ORTH_TALL_BYTES = (size_t)16 << 20;   // keep in sync with xeofs_amd/sharded.py
+
 static int rsvd_core(eofx_ctx* ctx, const LinOp& op, int k, int l, int n_iter, const float* omega,
                      RsvdOut& out) {
   const int L = (int)round_up(l, 32);
@@ -1305,9 +1307,22 @@ static int rsvd_core(eofx_ctx* ctx, const LinOp& op, int k, int l, int n_iter, c
   // power iterations: Z <- orth(A^T (A Z)).  Only the small-side panel is orthonormalised
   // (Cholesky-QR with a float64 Gram matrix); the tall panel is never factorised here.
   const int pp = ctx->prec_power, pf = ctx->prec_final;
+  // scikit-learn re-normalises after EVERY product (LU).  Leaving the tall panel as it is between the two
+  // products of an iteration is exact in exact arithmetic, but in float32 the unconverged noise-bulk modes of
+  // small problems (k ~ n/3 on ~100 samples) then drift 1e-4 from the float64 reference instead of 2e-6.
+  // Where the tall panel is small (<= EOFX_ORTH_TALL_BYTES) the extra Cholesky-QR costs microseconds and is
+  // done; at config-2/4 sizes (where it would cost 6 % of a fit, and where the sample-parity check of bench.py
+  // shows 1e-6 without it) it is skipped.
+  const bool orth_tall = (size_t)op.tall_pad * L * sizeof(float) <= EOFX_ORTH_TALL_BYTES;
   for (int it = 0; it < n_iter; ++it) {
     CHK(op.fwd(Zs, Yt, L, pp));
-    CHK(op.bwd(Yt, Ws, L, pp));
+    if (orth_tall) {
+      CHK(launch_gram(ctx, Yt, op.tall_pad, L, G));
+      CHK(launch_cholqr(ctx, Yt, op.tall_pad, L, l, G, Qt));
+      CHK(op.bwd(Qt, Ws, L, pp));
+    } else {
+      CHK(op.bwd(Yt, Ws, L, pp));
+    }
     CHK(launch_gram(ctx, Ws, op.small_pad, L, G));
     CHK(launch_cholqr(ctx, Ws, op.small_pad, L, l, G, Zs));
   }

@@ -121,7 +121,15 @@ def _resolve_sketch(k, r, n_oversamples, omega, random_state):
     return omega, l
 
 
-def _rsvd_panels(la, to_tall, to_small, gram_small, gram_tall, Z, l, k, n_iter):
+ORTH_TALL_BYTES = 16 << 20     # EOFX_ORTH_TALL_BYTES of csrc/eofx_abi.hip
+
+
+def _orth_tall(tall_total: int, L: int) -> bool:
+    """the rule of `rsvd_core`: re-normalise the tall panel inside the power iterations while that is cheap"""
+    return ((int(tall_total) + 511) // 512 * 512) * L * 4 <= ORTH_TALL_BYTES
+
+
+def _rsvd_panels(la, to_tall, to_small, gram_small, gram_tall, Z, l, k, n_iter, orth_tall=False):
     """The pass sequence of `rsvd_core` (csrc/eofx_abi.hip) on abstract products.
 
     `to_tall(P, final)` / `to_small(P, final)` apply A / A^T to a panel (including whatever reduction
@@ -131,6 +139,8 @@ def _rsvd_panels(la, to_tall, to_small, gram_small, gram_tall, Z, l, k, n_iter):
     """
     for _ in range(int(n_iter)):
         Yt = to_tall(Z, False)
+        if orth_tall:
+            Yt = la.cholqr(Yt, l, gram_tall(Yt))
         W = to_small(Yt, False)
         Z = la.cholqr(W, l, gram_small(W))
     Yt = to_tall(Z, False)                       # range basis: a subspace only, power-pass precision
@@ -199,7 +209,8 @@ def sharded_rsvd(ops, comm: Comm, k: int, p_total: int, p_offset: int, n_oversam
         return comm.sum_(G) if side == "p" else G
 
     Tv, Sv, s = _rsvd_panels(ops, lambda P, f: to_side(P, tall, f), lambda P, f: to_side(P, small, f),
-                             lambda P: gram(P, small), lambda P: gram(P, tall), Z, l, k, n_iter)
+                             lambda P: gram(P, small), lambda P: gram(P, tall), Z, l, k, n_iter,
+                             _orth_tall(n if tall == "n" else p_total, Z.shape[1]))
     Vp, Up = (Tv, Sv) if transposed else (Sv, Tv)
     sign = _sign_from_extrema(comm, ops, Vp, p_loc, k) if flip else None
     if device_out:   # results stay in HBM (torch tensors); nothing crosses PCIe
@@ -243,11 +254,11 @@ def sharded_crosscov_rsvd(opsx, opsy, comm: Comm, k: int, p1_total: int, p1_offs
 
     if transposed:       # A = C^T (p2 x p1): small side = p1 (X's features)
         Z = opsx.import_panel(omega[p1_offset:p1_offset + opsx.p], "p")
-        Tv, Sv, s = _rsvd_panels(opsx, ct_mul, c_mul, gram, gram, Z, l, k, n_iter)
+        Tv, Sv, s = _rsvd_panels(opsx, ct_mul, c_mul, gram, gram, Z, l, k, n_iter, _orth_tall(p2_total, Z.shape[1]))
         Q1p, Q2p = Sv, Tv
     else:                # A = C (p1 x p2): small side = p2 (Y's features)
         Z = opsy.import_panel(omega[p2_offset:p2_offset + opsy.p], "p")
-        Tv, Sv, s = _rsvd_panels(opsx, c_mul, ct_mul, gram, gram, Z, l, k, n_iter)
+        Tv, Sv, s = _rsvd_panels(opsx, c_mul, ct_mul, gram, gram, Z, l, k, n_iter, _orth_tall(p1_total, Z.shape[1]))
         Q1p, Q2p = Tv, Sv
     sign = _sign_from_extrema(comm, opsy, Q2p, opsy.p, k) if flip else None
     out = dict(s=(s / (n - 1)).astype(np.float32), Q1=opsx.export(Q1p, opsx.p, k, sign),
