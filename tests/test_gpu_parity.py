@@ -402,3 +402,34 @@ def test_documented_size_limits_fail_loudly(ctx):
     with pytest.raises(ValueError, match="rank of the dataset"):
         engine.rsvd(ctx, A, 301)
     A.free(); B.free()
+
+
+def test_peaked_spectrum_on_a_large_tall_panel(ctx):
+    """A strongly peaked spectrum (sigma_1 / sigma_l ~ 60) with many unconverged noise-bulk modes on a tall panel
+    above the 16 MB size rule: the data-driven rule of `rsvd_core` (pivots of the first small-side Cholesky
+    factor) switches the per-iteration re-normalisation of the tall panel on, and the result matches the float64
+    oracle to the strict tolerance; the sharded driver takes the same decision (bitwise equal at world size 1)."""
+    from xeofs_amd import engine, sharded
+
+    rng = np.random.default_rng(3)
+    n, p, k = 160, 70000, 36
+    amp = 60.0 * 0.45 ** np.arange(5)
+    X = ((rng.standard_normal((n, 5)) * amp) @ rng.standard_normal((5, p)) / np.sqrt(p) * 40 + rng.standard_normal((n, p))).astype(np.float32)
+    X -= X.mean(0)
+    mat = engine.from_dense(ctx, X)
+    assert mat.p_pad * 64 * 4 > sharded.ORTH_TALL_BYTES
+    U, s, V = engine.rsvd(ctx, mat, k, random_state=9)
+    Uo, so, Vo = orc.decomposer_fit(X.astype(np.float64), k, random_state=9, solver="randomized")
+    assert so[0] / so[-1] > 5
+    assert np.all(np.abs(s - so) <= 1e-5 * so + 3e-6 * so[0])
+    ops = sharded.HipPanelOps(ctx, mat)
+
+    class NoComm:
+        active = False
+        def sum_(self, t): return t
+        def max_(self, t): return t
+        def min_(self, t): return t
+
+    U2, s2, V2 = sharded.sharded_rsvd(ops, NoComm(), k, p, 0, random_state=9)
+    assert np.array_equal(s, s2) and np.array_equal(U, U2) and np.array_equal(V, V2)
+    mat.free()
