@@ -146,8 +146,14 @@ def complex_rsvd(ctx, A, B, k: int, n_oversamples: int = 10, n_iter="auto", rand
     host = np.zeros((rows0.shape[0], LP), np.float32)
     host[:, :l] = rows0
     Z = ops.import_panel(host, small)
+    # like the real driver: re-normalise the tall panel inside the iteration while it is small (sharded.py)
+    tall_total = n if tall == "n" else p
+    orth_tall = ((tall_total + 511) // 512 * 512) * LP * 4 <= (16 << 20)
     for _ in range(int(n_iter)):
-        Z = orth(bwd(fwd(Z)), small)
+        Yt = fwd(Z)
+        if orth_tall:
+            Yt = orth(Yt, tall)
+        Z = orth(bwd(Yt), small)
     Q = orth(orth(fwd(Z), tall), tall)                  # range basis: a subspace only, power-pass precision
     Bt = bwd(Q, True)                                   # = B^H with B = Q^H A_op
     w, Uh = np.linalg.eigh(gram(Bt, small))             # B B^H = Uh diag(w) Uh^H
