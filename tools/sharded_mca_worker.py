@@ -18,7 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--same-gpu", action="store_true")
-    ap.add_argument("--n", type=int, default=700)
+    ap.add_argument("--nsamples", dest="n", type=int, default=700)
     ap.add_argument("--p1", type=int, default=5000)
     ap.add_argument("--p2", type=int, default=3600)
     ap.add_argument("--modes", type=int, default=8)
