@@ -13,6 +13,12 @@
  *                 + sign rule xeofs/utils/xarray_utils.py:273-301
  *   project     : xr.dot(X, components)     xeofs/single/eof.py:129, cross/cpcca.py:204-205
  *   cross-cov   : X^H Y/(n-1) + its rSVD    xeofs/cross/cpcca.py:168-225,1007-1015
+ *   hilbert     : analytic signal + padding xeofs/utils/hilbert_transform.py:40-114
+ *   and, for the callers either side of the path (panel-level building blocks):
+ *   rotation    : Varimax / Promax step     xeofs/linalg/_numpy/_rotation.py:6-187
+ *   PCA         : small-side Gram matrix    xeofs/preprocessing/pca.py:94-171
+ *   bootstrap   : row resampling + centring xeofs/validation/bootstrapper.py:78-91
+ *   patterns    : per-feature norms         xeofs/utils/optional/statistics.py:50-54
  *
  * Conventions
  *   - plain pointers and sizes only; no torch / xarray types.
