@@ -51,9 +51,10 @@ class CPCCARotator:
         C1 = np.asarray(model.data["components1"])[:, :k]
         C2 = np.asarray(model.data["components2"])[:, :k]
         p1 = C1.shape[0]
-        loadings = np.concatenate([C1, C2], axis=0) * scaling.astype(np.float32)
-        rot_loadings, rot_matrix, phi = rotation.promax(self.ctx, loadings, power=self._params["power"],
-                                                        max_iter=self._params["max_iter"], rtol=self._params["rtol"])
+        # stacked loadings [Qx; Qy] sqrt(s): scaled, rotated, normalised, signed and ordered on the resident panel
+        Xrot, ptot, k, rot_matrix, phi = rotation.promax_panel(self.ctx, np.concatenate([C1, C2], axis=0),
+                                                               power=self._params["power"], max_iter=self._params["max_iter"],
+                                                               rtol=self._params["rtol"], col_scale=scaling)
         # analysis-space images of the rotated loadings: Q sqrt(s) rotation_matrix
         Qr = [model._q[i][:, :k] * scaling @ rot_matrix for i in range(2)]
         norm1, norm2 = np.linalg.norm(Qr[0], axis=0), np.linalg.norm(Qr[1], axis=0)
@@ -62,15 +63,22 @@ class CPCCARotator:
         RinvT = self._rot_mat_inv_trans(rot_matrix)
         sc1 = (np.asarray(model.data["scores1"], dtype=np.float64)[:, :k] / scaling) @ RinvT * norm1
         sc2 = (np.asarray(model.data["scores2"], dtype=np.float64)[:, :k] / scaling) @ RinvT * norm2
-        mx, mn = rot_loadings.max(axis=0), rot_loadings.min(axis=0)        # xarray_utils.py:273-301
+        mx, mn = engine.panel_colminmax(self.ctx, Xrot, ptot)                 # xarray_utils.py:273-301
+        mx, mn = mx.cpu().numpy()[:k].astype(np.float64), mn.cpu().numpy()[:k].astype(np.float64)
         sign = np.where(np.abs(mx) >= np.abs(mn), 1.0, -1.0)
-        # feature-space components (what `components()` back-projects to): rotated loadings / norm
-        F1 = rot_loadings[:p1] / norm1.astype(np.float32) * sign.astype(np.float32)
-        F2 = rot_loadings[p1:] / norm2.astype(np.float32) * sign.astype(np.float32)
+        # feature-space components (what `components()` back-projects to): rotated loadings / norm, signed, sorted
+        L = Xrot.shape[1]
+        F = []
+        for norm, lo, hi in ((norm1, 0, p1), (norm2, p1, ptot)):
+            M = np.zeros((L, L))
+            M[idx, np.arange(k)] = sign[idx] / norm[idx]
+            blk = engine.panel_matmul(self.ctx, Xrot[lo:], rotation._dev(M, Xrot))
+            F.append(engine.panel_export(self.ctx, blk, hi - lo, k))
+        del Xrot
         self.model_data = dict(singular_values=np.asarray(model.data["singular_values"]), components1=C1, components2=C2)
         self.data = dict(
             input_data1=model.data["input_data1"], input_data2=model.data["input_data2"],
-            components1=np.ascontiguousarray(F1[:, idx]), components2=np.ascontiguousarray(F2[:, idx]),
+            components1=F[0], components2=F[1],
             scores1=(sc1 * sign)[:, idx].astype(np.float32), scores2=(sc2 * sign)[:, idx].astype(np.float32),
             squared_covariance=sqcov[idx], total_squared_covariance=model.data["total_squared_covariance"],
             idx_modes_sorted=idx, norm1=norm1[idx], norm2=norm2[idx], rotation_matrix=rot_matrix, phi_matrix=phi,

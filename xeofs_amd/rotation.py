@@ -30,6 +30,14 @@ def _pad(M, L):
 
 def promax(ctx, loadings: np.ndarray, power: int = 1, max_iter: int = 1000, rtol: float = 1e-8):
     """-> (rotated loadings [p, m] float32, rotation matrix [m, m], phi [m, m]) like `_promax`."""
+    Xrot, p, m, rot_mat, phi = promax_panel(ctx, loadings, power=power, max_iter=max_iter, rtol=rtol)
+    return engine.panel_export(ctx, Xrot, p, m), rot_mat, phi
+
+
+def promax_panel(ctx, loadings: np.ndarray, power: int = 1, max_iter: int = 1000, rtol: float = 1e-8, col_scale=None):
+    """Like `promax`, but the rotated loadings stay in HBM: -> (panel [rows_pad, L] on the device, p, m, rotation
+    matrix, phi).  `col_scale` (m values) multiplies the columns of `loadings` on the device first (components ->
+    loadings = components * sqrt(explained variance) without a host pass)."""
     loadings = np.ascontiguousarray(loadings, dtype=np.float32)
     p, m = loadings.shape
     if m < 2:
@@ -39,6 +47,10 @@ def promax(ctx, loadings: np.ndarray, power: int = 1, max_iter: int = 1000, rtol
     L = engine.panel_width(m)
     rows_pad = (p + 511) // 512 * 512
     Lp = engine.panel_import(ctx, loadings, rows_pad, L)           # loadings
+    if col_scale is not None:
+        D = np.zeros((L, L))
+        D[np.arange(m), np.arange(m)] = np.asarray(col_scale, dtype=np.float64)
+        Lp = engine.panel_matmul(ctx, Lp, _dev(D, Lp))
     Xn = engine.panel_row_normalize(ctx, Lp)                       # Kaiser-normalised rows
     S = engine.panel_gram(ctx, Xn).cpu().numpy()[:m, :m]           # X^T X
     S = 0.5 * (S + S.T)
@@ -79,4 +91,21 @@ def promax(ctx, loadings: np.ndarray, power: int = 1, max_iter: int = 1000, rtol
         L_inv = np.linalg.inv(Lm)
         phi = L_inv @ L_inv.T
     Xrot = engine.panel_matmul(ctx, Lp, _dev(_pad(rot_mat, L), Lp))   # (h Xn) rot_mat = loadings rot_mat
-    return engine.panel_export(ctx, Xrot, p, m), rot_mat, phi
+    return Xrot, p, m, rot_mat, phi
+
+
+def finish_on_device(ctx, Xrot, p, m):
+    """Post-processing of the rotated loadings panel without host passes (eof_rotator.py:150-190): explained
+    variance = column sums of squares (float64 Gram diagonal), order by it, unit-norm components, deterministic sign
+    (utils/xarray_utils.py:273-301).  -> (components [p, m] float32 host, sorted / normalised / signed;
+    expvar (unsorted), idx, sign (unsorted))."""
+    L = Xrot.shape[1]
+    expvar = np.diag(engine.panel_gram(ctx, Xrot).cpu().numpy())[:m].copy()
+    idx = np.argsort(expvar)[::-1]
+    mx, mn = engine.panel_colminmax(ctx, Xrot, p)
+    mx, mn = mx.cpu().numpy()[:m].astype(np.float64), mn.cpu().numpy()[:m].astype(np.float64)
+    sign = np.where(np.abs(mx) >= np.abs(mn), 1.0, -1.0)
+    M = np.zeros((L, L))                              # column j of the output = column idx[j], scaled and signed
+    M[idx, np.arange(m)] = sign[idx] / np.sqrt(expvar[idx])
+    comps = engine.panel_export(ctx, engine.panel_matmul(ctx, Xrot, _dev(M, Xrot)), p, m)
+    return comps, expvar, idx, sign

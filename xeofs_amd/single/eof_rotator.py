@@ -43,27 +43,23 @@ class EOFRotator(EOF):
         comps = np.asarray(model.data["components"])[:, :m]
         m = comps.shape[1]
         expvar = np.asarray(model.data["explained_variance"], dtype=np.float64)[:m]
-        loadings = comps * np.sqrt(expvar).astype(comps.dtype)
-        rot_loadings, rot_matrix, phi = rotation.promax(self.ctx, loadings, power=power,
-                                                        max_iter=self._params["max_iter"], rtol=self._params["rtol"])
-        expvar_r = np.sum(rot_loadings.astype(np.float64) ** 2, axis=0)
-        idx = np.argsort(expvar_r)[::-1]
-        rot_components = rot_loadings / np.sqrt(expvar_r).astype(rot_loadings.dtype)
+        # loadings = components * sqrt(expvar); rotation, explained variance, normalisation, sign and ordering all
+        # happen on the resident panel -- the host sees the finished components once
+        Xrot, p, m, rot_matrix, phi = rotation.promax_panel(self.ctx, comps, power=power, max_iter=self._params["max_iter"],
+                                                            rtol=self._params["rtol"], col_scale=np.sqrt(expvar))
+        rot_sorted, expvar_r, idx, sign = rotation.finish_on_device(self.ctx, Xrot, p, m)
+        del Xrot
         n_samples = model.data["input_data"].n
         norms = (expvar_r * (n_samples - 1)) ** 0.5
         svals = np.asarray(model.data["norms"], dtype=np.float64)[:m]
         scores = np.asarray(model.data["scores"])[:, :m].astype(np.float64) / svals
         RinvT = self._rot_mat_inv_trans(rot_matrix)
         scores = scores @ RinvT * norms
-        # xeofs/utils/xarray_utils.py:273-301 on the rotated components
-        mx, mn = rot_components.max(axis=0), rot_components.min(axis=0)
-        sign = np.where(np.abs(mx) >= np.abs(mn), 1.0, -1.0)
-        rot_components = rot_components * sign.astype(rot_components.dtype)
         scores = scores * sign
         self.model_data = dict(singular_values=np.asarray(model.data["norms"]), components=np.asarray(model.data["components"]))
         self.data = dict(
             input_data=model.data["input_data"],
-            components=np.ascontiguousarray(rot_components[:, idx]),
+            components=rot_sorted,
             scores=np.ascontiguousarray(scores[:, idx].astype(np.float32)),
             norms=norms[idx], explained_variance=expvar_r[idx], total_variance=model.data["total_variance"],
             idx_modes_sorted=idx, rotation_matrix=rot_matrix, phi_matrix=phi, modes_sign=sign[idx],
