@@ -559,6 +559,7 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(const float* __restrict_
                                                          double* __restrict__ Gpart) {
   const int nb = (L + 63) / 64;
   const int bi = blockIdx.y / nb, bj = blockIdx.y % nb;
+  if (bi > bj) return;             // G is symmetric: the sub-block (bj, bi) writes this one as well
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lc = lane & 15, lk = lane >> 4;
   const int ca = 64 * bi + 4 * lc, cb = 64 * bj + 4 * lc;
@@ -603,7 +604,10 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(const float* __restrict_
       for (int q = 0; q < 4; ++q) {
         const int i = lk + 4 * q, j = lc;                       // D[lane / 16 + 4 reg][lane % 16] (measured layout)
         const int gi = 64 * bi + 4 * i + x, gj = 64 * bj + 4 * j + y;
-        if (gi < L && gj < L) G[(int64_t)gi * L + gj] = acc[x][y][q];
+        if (gi < L && gj < L) {
+          G[(int64_t)gi * L + gj] = acc[x][y][q];
+          if (!same) G[(int64_t)gj * L + gi] = acc[x][y][q];
+        }
       }
 }
 
