@@ -23,7 +23,7 @@ constexpr int FX_GROUPS = 8;     // XCDs
 constexpr int FX_SLOTS = 4;      // exchange slots per group (generation counted)
 constexpr int FX_MAXT = 3;       // 32-sample tiles per wave   (rows per CU <= 4 * 3 * 32 = 384)
 constexpr int FX_MAXK = 6;       // 16-sample k-steps per wave (rows per CU <= 4 * 6 * 16 = 384)
-constexpr long FX_SPIN_LIMIT = 40000000;
+constexpr long FX_SPIN_LIMIT = 4000000;   // ~2 s; after the first time-out every wait returns at once
 
 // Exchange traffic stays inside the XCD: stores are written through to the L2 and loads bypass the CU's
 // vector L1 (scope bit sc0 = "group"), nothing goes out to the fabric (agent-scope sc1 accesses cost ~10 us
@@ -42,11 +42,14 @@ __device__ __forceinline__ void fx_signal_and_wait(int* flag, int target, int* e
   if (threadIdx.x == 0) {
     __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     long spins = 0;
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target)
-      if (++spins > FX_SPIN_LIMIT) {
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      ++spins;
+      if (spins > FX_SPIN_LIMIT) {      // a member never arrived: flag the failure, everybody winds down fast
         __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         break;
       }
+      if ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+    }
   }
   __syncthreads();
 }
@@ -116,6 +119,10 @@ __global__ __launch_bounds__(256, 1) void fused_xxt_kernel(const float* __restri
   } while (0)
   int it = 0;
   for (int64_t slab = g; slab < nslabs; slab += FX_GROUPS, ++it) {
+    if ((it & 15) == 0) {          // wind down after a time-out anywhere (decision made uniform by the barrier)
+      const int e = (tid == 0) ? (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1) : 0;
+      if (__syncthreads_or(e)) break;
+    }
     const int slot = it % FX_SLOTS, gen = it / FX_SLOTS;
     // 1. sub-slab -> LDS
     {
