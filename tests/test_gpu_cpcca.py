@@ -87,9 +87,8 @@ def test_cpcca_diagnostics_vs_oracle(ctx, alpha, use_pca):
     m, ref, X, Y, A, B = _models(alpha, use_pca)
     d = orc.cpcca_diagnostics(ref)
     tol = dict(rtol=2e-3, atol=2e-4)
-    assert np.allclose(m.cross_correlation_coefficients().values * np.sign(d["cross_correlation_coefficients"]),
-                       np.abs(d["cross_correlation_coefficients"]), **tol) or \
-        np.allclose(np.abs(m.cross_correlation_coefficients().values), np.abs(d["cross_correlation_coefficients"]), **tol)
+    # (the sign of a mode pair is a free choice of the SVD: compare magnitudes)
+    assert np.allclose(np.abs(m.cross_correlation_coefficients().values), np.abs(d["cross_correlation_coefficients"]), **tol)
     assert np.allclose(np.abs(m.correlation_coefficients_X().values), np.abs(d["correlation_coefficients_X"]), **tol)
     assert np.allclose(np.abs(m.correlation_coefficients_Y().values), np.abs(d["correlation_coefficients_Y"]), **tol)
     assert np.allclose(m.squared_covariance_fraction().values, d["squared_covariance_fraction"], **tol)
