@@ -405,10 +405,9 @@ def test_documented_size_limits_fail_loudly(ctx):
 
 
 def test_peaked_spectrum_on_a_large_tall_panel(ctx):
-    """A strongly peaked spectrum (sigma_1 / sigma_l ~ 60) with many unconverged noise-bulk modes on a tall panel
-    above the 16 MB size rule: the data-driven rule of `rsvd_core` (pivots of the first small-side Cholesky
-    factor) switches the per-iteration re-normalisation of the tall panel on, and the result matches the float64
-    oracle to the strict tolerance; the sharded driver takes the same decision (bitwise equal at world size 1)."""
+    """A peaked spectrum (sigma_1 / sigma_k ~ 6) with many unconverged noise-bulk modes on a tall panel above the
+    16 MB size rule (no re-normalisation of the tall panel inside the iterations): the result matches the float64
+    oracle to the strict tolerance, and the sharded driver is bitwise equal at world size 1."""
     from xeofs_amd import engine, sharded
 
     rng = np.random.default_rng(3)

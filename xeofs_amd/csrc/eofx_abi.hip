@@ -541,32 +541,6 @@ static void host_chol_rinv(const double* G, int L, int l, double* Rinv, double t
     for (int c = 0; c < L; ++c) Rinv[(size_t)r * L + c] = (r < l && c < l) ? X[(size_t)r * l + c] : 0.0;
 }
 
-// max / min diagonal entry of the Cholesky factor of the leading l x l block of G (numerically dependent
-// columns skipped): an estimate of the condition number of the panel behind G.  Plain unpivoted float64 loop,
-// restated one-to-one in xeofs_amd/sharded.py::_chol_pivot_ratio so that both drivers take the same decision.
-static double chol_pivot_ratio(const double* G, int L, int l, double tol) {
-  std::vector<double> A((size_t)l * l, 0.0);
-  for (int r = 0; r < l; ++r)
-    for (int c = r; c < l; ++c) A[(size_t)r * l + c] = G[(size_t)r * L + c];
-  double rmax = 0.0, rmin = INFINITY;
-  for (int j = 0; j < l; ++j) {
-    const double d = A[(size_t)j * l + j], d0 = G[(size_t)j * L + j];
-    if (!(d > tol * d0) || !(d0 > 0.0)) {           // dependent column: contributes nothing
-      for (int c = j + 1; c < l; ++c) A[(size_t)j * l + c] = 0.0;
-      continue;
-    }
-    const double rjj = std::sqrt(d);
-    rmax = std::max(rmax, rjj);
-    rmin = std::min(rmin, rjj);
-    for (int c = j + 1; c < l; ++c) A[(size_t)j * l + c] /= rjj;
-    for (int r = j + 1; r < l; ++r) {
-      const double f = A[(size_t)j * l + r];
-      for (int c = r; c < l; ++c) A[(size_t)r * l + c] -= f * A[(size_t)j * l + c];
-    }
-  }
-  return (rmin > 0.0 && std::isfinite(rmin)) ? rmax / rmin : INFINITY;
-}
-
 // out = P R^-1 with G = R^T R (leading l x l block)
 static int launch_cholqr(eofx_ctx* ctx, const float* P, int64_t rows, int L, int l, const double* G,
                          float* out) {
@@ -1198,11 +1172,11 @@ static int panel_fused(eofx_ctx* ctx, const eofx_mat* m, const float* Zn, float*
   void* args[] = {(void*)&Xt, (void*)&ldx, (void*)&ppad, (void*)&rows_per_cu, (void*)&Zn, (void*)&Wpart, (void*)&scrP,
                   (void*)&scrR, (void*)&flags, (void*)&a_scale, (void*)&zmaxf, (void*)&err};
   const size_t smem = (size_t)(32 * (rows_per_cu + 4) + 5 * 2048) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static size_t attr_bytes = 0;    // opt in to more than 64 KB of dynamic LDS (exactly what this launch needs)
+  if (smem > attr_bytes) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_xxt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               160 * 1024));
-    attr_set = true;
+                               (int)smem));
+    attr_bytes = smem;
   }
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (ctx->profile) {
@@ -1315,7 +1289,6 @@ static int rsvd_auto_iters(int k, int64_t n, int64_t p) {
 
 // All panels are carved from the arena by the caller-visible drivers (reserve first).
 constexpr size_t EOFX_ORTH_TALL_BYTES = (size_t)16 << 20;   // keep in sync with xeofs_amd/sharded.py
-constexpr double EOFX_ORTH_COND = 50.0;                     // (same)
 
 static int rsvd_core(eofx_ctx* ctx, const LinOp& op, int k, int l, int n_iter, const float* omega,
                      RsvdOut& out) {
@@ -1338,12 +1311,9 @@ static int rsvd_core(eofx_ctx* ctx, const LinOp& op, int k, int l, int n_iter, c
   // products of an iteration is exact in exact arithmetic, but in float32 the unconverged noise-bulk modes of
   // small problems (k ~ n/3 on ~100 samples) then drift 1e-4 from the float64 reference instead of 2e-6.
   // Where the tall panel is small (<= EOFX_ORTH_TALL_BYTES) the extra Cholesky-QR costs microseconds and is
-  // done; at config-2/4 sizes (where it would cost 6 % of a fit, and where the sample-parity check of bench.py
-  // shows 1e-6 without it) it is skipped.
-  // For large tall panels the decision is taken from the data after the first iteration: the pivots of the
-  // small-side Cholesky factor estimate the condition number of W = A^T A Z ~ (sigma_1 / sigma_l)^2; below
-  // EOFX_ORTH_COND (flat spectra such as the benchmark field: 2.3) nothing is lost and the step is skipped.
-  bool orth_tall = (size_t)op.tall_pad * L * sizeof(float) <= EOFX_ORTH_TALL_BYTES;
+  // done; for large panels it made no measurable difference (tools/cond_study.py) and would cost 6 % of a
+  // config-4 fit, so it is skipped there.
+  const bool orth_tall = (size_t)op.tall_pad * L * sizeof(float) <= EOFX_ORTH_TALL_BYTES;
   for (int it = 0; it < n_iter; ++it) {
     CHK(op.fwd(Zs, Yt, L, pp));
     if (orth_tall) {
@@ -1352,15 +1322,6 @@ static int rsvd_core(eofx_ctx* ctx, const LinOp& op, int k, int l, int n_iter, c
       CHK(op.bwd(Qt, Ws, L, pp));
     } else {
       CHK(op.bwd(Yt, Ws, L, pp));
-    }
-    if (it == 0 && !orth_tall && n_iter > 1) {
-      CHK(launch_gram(ctx, Ws, op.small_pad, L, G));
-      std::vector<double> hG0((size_t)L * L);
-      HIPCHK(hipMemcpyAsync(hG0.data(), G, sizeof(double) * L * L, hipMemcpyDeviceToHost, ctx->stream));
-      HIPCHK(hipStreamSynchronize(ctx->stream));
-      orth_tall = chol_pivot_ratio(hG0.data(), L, l, 1e-13) > EOFX_ORTH_COND;
-      CHK(launch_cholqr(ctx, Ws, op.small_pad, L, l, G, Zs));
-      continue;
     }
     CHK(launch_gram(ctx, Ws, op.small_pad, L, G));
     CHK(launch_cholqr(ctx, Ws, op.small_pad, L, l, G, Zs));

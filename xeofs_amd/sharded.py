@@ -129,28 +129,6 @@ def _orth_tall(tall_total: int, L: int) -> bool:
     return ((int(tall_total) + 511) // 512 * 512) * L * 4 <= ORTH_TALL_BYTES
 
 
-ORTH_COND = 50.0               # EOFX_ORTH_COND
-
-
-def _chol_pivot_ratio(G, l, tol=1e-13):
-    """`chol_pivot_ratio` of csrc/eofx_abi.hip, restated one-to-one (max / min diagonal of the unpivoted
-    Cholesky factor of G[:l, :l], dependent columns skipped)"""
-    A = np.triu(np.array(G[:l, :l], dtype=np.float64))
-    d0 = np.diag(G)[:l].astype(np.float64)
-    rmax, rmin = 0.0, np.inf
-    for j in range(l):
-        d = A[j, j]
-        if not (d > tol * d0[j]) or not (d0[j] > 0.0):
-            A[j, j + 1:] = 0.0
-            continue
-        rjj = np.sqrt(d)
-        rmax, rmin = max(rmax, rjj), min(rmin, rjj)
-        A[j, j + 1:] /= rjj
-        row = A[j, j + 1:]
-        A[j + 1:, j + 1:] -= np.triu(np.outer(row, row))
-    return rmax / rmin if (rmin > 0.0 and np.isfinite(rmin)) else np.inf
-
-
 def _rsvd_panels(la, to_tall, to_small, gram_small, gram_tall, Z, l, k, n_iter, orth_tall=False):
     """The pass sequence of `rsvd_core` (csrc/eofx_abi.hip) on abstract products.
 
@@ -159,15 +137,12 @@ def _rsvd_panels(la, to_tall, to_small, gram_small, gram_tall, Z, l, k, n_iter, 
     that side, `la` supplies the matrix-independent steps (cholqr, matmul, eigh).  Returns the
     singular-vector panels (tall side, small side) and the k singular values (float64).
     """
-    for it in range(int(n_iter)):
+    for _ in range(int(n_iter)):
         Yt = to_tall(Z, False)
         if orth_tall:
             Yt = la.cholqr(Yt, l, gram_tall(Yt))
         W = to_small(Yt, False)
-        Gs = gram_small(W)
-        if it == 0 and not orth_tall and n_iter > 1:     # data-driven decision of `rsvd_core` (same on every rank)
-            orth_tall = _chol_pivot_ratio(Gs.detach().cpu().numpy(), l) > ORTH_COND
-        Z = la.cholqr(W, l, Gs)
+        Z = la.cholqr(W, l, gram_small(W))
     Yt = to_tall(Z, False)                       # range basis: a subspace only, power-pass precision
     Q = la.cholqr(Yt, l, gram_tall(Yt))
     Q = la.cholqr(Q, l, gram_tall(Q))            # CholeskyQR2
