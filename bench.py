@@ -109,8 +109,6 @@ def blas_threads():
 def main():
     # Libraries (RCCL prints a version banner at communicator creation) must not pollute stdout: the
     # contract is ONE JSON line there.  Keep the real stdout aside and point fd 1 at stderr.
-    real_stdout = os.fdopen(os.dup(1), "w")
-    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -133,6 +131,23 @@ def main():
                     help="also decompose the CPU-baseline sample on the GPU and compare singular values "
                          "(adds smaller launches of the dominant kernel; tests/test_gpu_parity.py covers it)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Started without a launcher: become `torch.distributed.run` with one rank per GPU (the driver's own
+        # command line), same arguments.  Rank 0 of the child job prints the JSON line on this stdout.
+        import socket
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execvpe(sys.executable, cmd, env)
+
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist

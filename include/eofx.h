@@ -170,9 +170,11 @@ int eofx_panel_tmul_f32(eofx_ctx *ctx, const eofx_mat *m, const float *Zn, float
                         int precision); /* Yp[p_pad x L] = X^T Zn[n_pad x L]; EOFX_PREC_* */
 int eofx_panel_mul_f32(eofx_ctx *ctx, const eofx_mat *m, const float *Yp, float *Wn, int L,
                        int precision);
-/* EXPERIMENTAL: Wn = X (X^T Zn) -- both products of a power iteration in one pass over the matrix
- * (persistent cooperative kernel, L must be 64, n_pad a multiple of 1024 and <= 12288, 256-CU part).      */
-int eofx_panel_fused_f32(eofx_ctx *ctx, const eofx_mat *m, const float *Zn, float *Wn, int L); /* Wn[n_pad x L] = X Yp[p_pad x L]   */
+/* Wn = X (X^T Zn), optionally also Yp = X^T Zn (Yp may be NULL) -- both products of a power iteration in one pass
+ * over the sample-contiguous layout (persistent cooperative kernel, xeofs_amd/csrc/eofx_fused.hpp; split-fp16 MFMA).
+ * L must be 64, n_pad one of 3072 / 5120 / 8192 / 10240, 256-CU part; EOFX_ERR_ARG otherwise (callers fall back to
+ * eofx_panel_tmul_f32 + eofx_panel_mul_f32, which the rSVD drivers do on their own).                                  */
+int eofx_panel_fused_f32(eofx_ctx *ctx, const eofx_mat *m, const float *Zn, float *Wn, float *Yp, int L);
 /* G[L x L] (device, float64) = P^T P, accumulated in float64 with a fixed tree. */
 int eofx_panel_gram_f64(eofx_ctx *ctx, const float *P, int64_t rows_pad, int L, double *G);
 /* Cholesky-QR step from a (possibly all-reduced) Gram matrix: out = P R^-1 with

@@ -133,6 +133,13 @@ def test_two_rank_sharded_path_on_one_gpu(ctx):
     assert len(two.stdout.strip().splitlines()) == 1 and len(one.stdout.strip().splitlines()) == 1  # ONE JSON line
     assert np.allclose(d2["parity"]["s_head"], d1["parity"]["s_head"], rtol=2e-6)
     assert d2["parity"]["XV_eq_Us_relerr"] < 1e-5 and d2["parity"]["orth_V_maxabs"] < 1e-6
+    # the same job without an external launcher: `bench.py --gpus 2` starts its own two ranks
+    env_nl = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    self2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                            "--same-gpu"] + common, capture_output=True, text=True, env=env_nl, timeout=600, cwd=root)
+    assert self2.returncode == 0, self2.stderr[-2000:]
+    ds = json.loads([ln for ln in self2.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert ds["n_gpus"] == 2 and np.allclose(ds["parity"]["s_head"], d2["parity"]["s_head"], rtol=1e-7)
 
 
 @pytest.mark.parametrize("nan,pca", [(False, False), (True, False), (False, True)])

@@ -359,27 +359,32 @@ def test_sharded_world1_equals_driver_bitwise(ctx):
         assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("n,p", [(5000, 6000), (3000, 9000)])
-def test_experimental_fused_power_product(ctx, n, p):
-    """`eofx_panel_fused_f32` (W = X (X^T Z) in one pass over X^T, persistent cooperative kernel with an
-    in-L2 exchange between the 32 CUs of an XCD; experimental) against the two-pass product.
-    Tolerance: float32-class (both paths use split-fp16 / exact-f32 MFMA products, different summation order)."""
+@pytest.mark.parametrize("n,p", [(5000, 6000), (3000, 9000), (8100, 20000), (10000, 33000)])
+def test_fused_power_product(ctx, n, p):
+    """`eofx_panel_fused_f32` (W = X (X^T Z) and Y = X^T Z in one pass over X^T: persistent cooperative kernel with an
+    in-L2 exchange between the 32 CUs of an XCD) against the two-pass exact-f32 products.
+    Tolerance: float32-class (split-fp16 MFMA products, different summation order); bitwise reproducible."""
     import torch
     from xeofs_amd import engine
 
-    X = torch.randn((n, p), device="cuda", dtype=torch.float32)
+    g = torch.Generator(device="cuda").manual_seed(n + p)
+    X = torch.randn((n, p), device="cuda", dtype=torch.float32, generator=g)
+    X *= torch.logspace(-2, 1, p, device="cuda")           # features of very different scales
     mat = engine.from_dense(ctx, X)
-    if mat.n_pad % 1024:
-        pytest.skip("fused product needs n_pad % 1024 == 0")
-    Z = torch.randn((mat.n_pad, 64), device="cuda")
+    if mat.n_pad not in (3072, 5120, 8192, 10240):
+        pytest.skip("fused product: n_pad not instantiated")
+    Z = torch.randn((mat.n_pad, 64), device="cuda", generator=g)
     Z[n:] = 0
     Z = Z / Z.norm(dim=0)
-    ref = engine.panel_mul(ctx, mat, engine.panel_tmul(ctx, mat, Z, prec="f32"), prec="f32")
-    got = engine.panel_fused(ctx, mat, Z)
+    Yref = engine.panel_tmul(ctx, mat, Z, prec="f32")
+    ref = engine.panel_mul(ctx, mat, Yref, prec="f32")
+    got, Y = engine.panel_fused(ctx, mat, Z, want_y=True)
     got2 = engine.panel_fused(ctx, mat, Z)
     assert torch.equal(got, got2)                                         # fixed-order exchange: bitwise reproducible
+    assert float((Y - Yref).abs().max()) <= 2e-6 * float(Yref.abs().max())
     assert float((got - ref).abs().max()) <= 5e-6 * float(ref.abs().max())
     assert not bool(got[n:].any())                                        # padded samples stay zero
+    assert not bool(Y[p:].any())                                          # padded features too
     mat.free()
 
 

@@ -70,6 +70,22 @@ def test_promax_matches_oracle(ctx, p, m, power):
         assert np.abs(R.T @ R - np.eye(m)).max() < 1e-10
 
 
+@pytest.mark.parametrize("case", ["real_a", "real_b"])
+@pytest.mark.parametrize("power", [1, 2, 4])
+def test_promax_matches_reference_golden(ctx, case, power):
+    """HIP rotation path vs outputs of the reference's own `_promax` (tests/golden/g8_rotation.npz,
+    oracle/make_golden_rotation.py).  Tolerance: float32 loadings storage, 2e-5 of the largest loading."""
+    import os
+    from xeofs_amd import rotation
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g8_rotation.npz"))
+    X = g[f"{case}_X"]
+    Xr, R, phi = rotation.promax(ctx, X.astype(np.float32), power=power)
+    assert np.abs(R - g[f"{case}_p{power}_R"]).max() < 2e-5 * max(1.0, np.abs(g[f"{case}_p{power}_R"]).max())
+    assert np.abs(phi - g[f"{case}_p{power}_phi"]).max() < 2e-5
+    assert np.abs(Xr - g[f"{case}_p{power}_Xrot"]).max() < 2e-5 * np.abs(X).max()
+
+
 def test_promax_errors(ctx):
     from xeofs_amd import rotation
 

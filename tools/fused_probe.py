@@ -14,7 +14,9 @@ Z = torch.randn((mat.n_pad, 64), device="cuda"); Z[n:] = 0
 Z = Z / Z.norm(dim=0)
 ref = engine.panel_mul(ctx, mat, engine.panel_tmul(ctx, mat, Z, prec="f32"), prec="f32")
 two = engine.panel_mul(ctx, mat, engine.panel_tmul(ctx, mat, Z, prec="f16x3"), prec="f16x3")
-got = engine.panel_fused(ctx, mat, Z)
+got, Yg = engine.panel_fused(ctx, mat, Z, want_y=True)
+Yr = engine.panel_tmul(ctx, mat, Z, prec="f32")
+print(f"max |Y fused - Y ref| / max = {float((Yg - Yr).abs().max()) / float(Yr.abs().max()):.3e}")
 torch.cuda.synchronize()
 sc = float(ref.abs().max())
 print(f"max |fused - f32 ref| / max = {float((got - ref).abs().max()) / sc:.3e};  two-pass f16x3 vs ref = {float((two - ref).abs().max()) / sc:.3e}")

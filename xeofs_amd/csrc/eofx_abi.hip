@@ -1136,25 +1136,54 @@ extern "C" int eofx_panel_tmul_f32(eofx_ctx* ctx, const eofx_mat* m, const float
   CHK(arena_reserve(ctx, atb_scratch_bytes(m->p_pad, round_up(m->n, ATB_KG), L)));
   return panel_tmul(ctx, m, Zn, Yp, L, prec);
 }
-// W = X (X^T Z) in one pass over X^T (experimental fused power-iteration product, eofx_fused.hpp).
-// Needs the 8-XCD / 256-CU part, a 64-wide panel and n_pad a multiple of 1024 with n_pad / 32 <= 384.
-static bool fused_supported(const eofx_ctx* ctx, const eofx_mat* m, int L) {
-  hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) return false;
-  return prop.multiProcessorCount == FX_GROUPS * FX_MEMBERS && prop.cooperativeLaunch && L == 64 && m->n_pad % 1024 == 0 &&
-         m->n_pad / FX_MEMBERS <= 4 * FX_MAXT * 32 && m->n_pad / FX_MEMBERS <= 4 * FX_MAXK * 16;
+// W = X (X^T Z) in one pass over X^T (fused power-iteration product, eofx_fused.hpp); optionally Y = X^T Z too.
+// Needs the 8-XCD / 256-CU part, a 64-wide panel and n_pad = 1024 KS with an instantiated KS.
+static bool fused_ks_ok(int64_t n_pad) {
+  if (n_pad % 1024) return false;
+  const int64_t ks = n_pad / 1024;
+  return ks == 3 || ks == 5 || ks == 8 || ks == 10;
 }
-static int panel_fused(eofx_ctx* ctx, const eofx_mat* m, const float* Zn, float* Wn) {
+static bool fused_supported(const eofx_ctx* ctx, const eofx_mat* m, int L) {
+  static int cu_count = -1, coop = 0;
+  if (cu_count < 0) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) return false;
+    cu_count = prop.multiProcessorCount;
+    coop = prop.cooperativeLaunch;
+  }
+  return cu_count == FX_GROUPS * FX_MEMBERS && coop && L == 64 && fused_ks_ok(m->n_pad) && m->p_pad % 512 == 0;
+}
+static size_t fused_arena_bytes(const eofx_mat* m) {
+  return (size_t)FX_GROUPS * FX_SLOTS * (FX_MEMBERS + 1) * FX_TILE_GRAN * 16 + (size_t)FX_GROUPS * m->n_pad * 64 * 4 + (1 << 20);
+}
+template <int KS, int DBG = 0>
+static hipError_t fused_launch(const FxParams& prm, hipStream_t st) {
+  constexpr int R = 32 * KS;
+  const size_t smem = (size_t)2 * 32 * (R + 16) * 2 + (size_t)32 * (R + 4) * 4 + 256 * 4 + 64 * 4 + 8192;
+  static bool attr_set = false;    // opt in to more than 64 KB of dynamic LDS (exactly what this launch needs)
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused2_kernel<KS, DBG>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  FxParams p = prm;
+  void* args[] = {(void*)&p};
+  return hipLaunchCooperativeKernel(reinterpret_cast<const void*>(fused2_kernel<KS, DBG>), dim3(FX_GROUPS * FX_MEMBERS), dim3(512),
+                                    args, smem, st);
+}
+// Yp may be null.  Both outputs are complete when the call returns (it reads the kernel's status word).
+static int panel_fused(eofx_ctx* ctx, const eofx_mat* m, const float* Zn, float* Wn, float* Yp) {
   const int64_t npad = m->n_pad;
-  int rows_per_cu = (int)(npad / FX_MEMBERS);
   ArenaScope scope(ctx);
-  ARENA(float, scrP, (size_t)FX_GROUPS * FX_SLOTS * FX_MEMBERS * 2048);
-  ARENA(float, scrR, (size_t)FX_GROUPS * FX_SLOTS * 2048);
-  ARENA(int, flags, FX_GROUPS * FX_SLOTS * 2 + 64);
+  const size_t e1_gran = (size_t)FX_GROUPS * FX_SLOTS * FX_MEMBERS * FX_TILE_GRAN;
+  const size_t e2_gran = (size_t)FX_GROUPS * FX_SLOTS * FX_TILE_GRAN;
+  ARENA(u32x4, exch, e1_gran + e2_gran);
+  ARENA(int, ctl, 64);
   ARENA(unsigned, zmax, 1);
   ARENA(float, Wpart, (size_t)FX_GROUPS * npad * 64);
-  int* err = flags + FX_GROUPS * FX_SLOTS * 2;
-  HIPCHK(hipMemsetAsync(flags, 0, sizeof(int) * (FX_GROUPS * FX_SLOTS * 2 + 64), ctx->stream));
+  HIPCHK(hipMemsetAsync(exch, 0, (e1_gran + e2_gran) * 16, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctl, 0, sizeof(int) * 64, ctx->stream));
   HIPCHK(hipMemsetAsync(zmax, 0, sizeof(unsigned), ctx->stream));
   const int64_t total4 = npad * 16;
   hipLaunchKernelGGL(panel_absmax_kernel, dim3((int)std::max<int64_t>(1, std::min<int64_t>((total4 + 1023) / 1024, 1024))),
@@ -1166,26 +1195,49 @@ static int panel_fused(eofx_ctx* ctx, const eofx_mat* m, const float* Zn, float*
     (void)std::frexp(m->absmax, &e);
     a_scale = std::ldexp(1.f, 14 - e);
   }
-  const float* Xt = m->Xt;
-  int64_t ldx = npad, ppad = m->p_pad;
-  const float* zmaxf = reinterpret_cast<const float*>(zmax);
-  void* args[] = {(void*)&Xt, (void*)&ldx, (void*)&ppad, (void*)&rows_per_cu, (void*)&Zn, (void*)&Wpart, (void*)&scrP,
-                  (void*)&scrR, (void*)&flags, (void*)&a_scale, (void*)&zmaxf, (void*)&err};
-  const size_t smem = (size_t)(32 * (rows_per_cu + 4) + 5 * 2048) * sizeof(float);
-  static size_t attr_bytes = 0;    // opt in to more than 64 KB of dynamic LDS (exactly what this launch needs)
-  if (smem > attr_bytes) {
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_xxt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)smem));
-    attr_bytes = smem;
-  }
+  int lg = 0;
+  while (((int64_t)1 << lg) < npad) ++lg;
+  FxParams prm;
+  prm.Xt = m->Xt;
+  prm.ldx = npad;
+  prm.niter = m->p_pad / 32 / FX_GROUPS;
+  prm.Z = Zn;
+  prm.Wpart = Wpart;
+  prm.E1 = exch;
+  prm.E2 = exch + e1_gran;
+  prm.Yout = Yp;
+  prm.z_absmax = reinterpret_cast<const float*>(zmax);
+  prm.a_scale = a_scale;
+  prm.s1 = std::ldexp(1.f, -(13 + lg));
+  prm.ctl = ctl;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (ctx->profile) {
     HIPCHK(hipEventCreate(&ev0));
     HIPCHK(hipEventCreate(&ev1));
     HIPCHK(hipEventRecord(ev0, ctx->stream));
   }
-  HIPCHK(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(fused_xxt_kernel), dim3(FX_GROUPS * FX_MEMBERS), dim3(256),
-                                    args, smem, ctx->stream));
+  hipError_t le = hipErrorInvalidValue;
+  switch (npad / 1024) {
+    case 3: le = fused_launch<3>(prm, ctx->stream); break;
+    case 5: le = fused_launch<5>(prm, ctx->stream); break;
+    case 8: le = fused_launch<8>(prm, ctx->stream); break;
+    case 10: {
+      const char* dbg = std::getenv("EOFX_FUSED_TIMING");   // probe builds of the C4 shape: see DBG in eofx_fused.hpp
+      switch (dbg ? std::atoi(dbg) : 0) {
+        case 1: le = fused_launch<10, 1>(prm, ctx->stream); break;
+        case 3: le = fused_launch<10, 3>(prm, ctx->stream); break;
+        case 5: le = fused_launch<10, 5>(prm, ctx->stream); break;
+        case 9: le = fused_launch<10, 9>(prm, ctx->stream); break;
+        case 17: le = fused_launch<10, 17>(prm, ctx->stream); break;
+        case 33: le = fused_launch<10, 33>(prm, ctx->stream); break;
+        case 67: le = fused_launch<10, 67>(prm, ctx->stream); break;
+        case 31: le = fused_launch<10, 31>(prm, ctx->stream); break;
+        default: le = fused_launch<10>(prm, ctx->stream); break;
+      }
+    } break;
+    default: break;
+  }
+  HIPCHK(le);
   if (ctx->profile) {
     HIPCHK(hipEventRecord(ev1, ctx->stream));
     ctx->prof_events.emplace_back(ev0, ev1);
@@ -1197,26 +1249,27 @@ static int panel_fused(eofx_ctx* ctx, const eofx_mat* m, const float* Zn, float*
                      Wpart, Wn, count4, FX_GROUPS);
   KCHK();
   int herr = 0;
-  HIPCHK(hipMemcpyAsync(&herr, err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(&herr, ctl, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  if (std::getenv("EOFX_FUSED_TIMING")) {
-    long long ts[7];
-    HIPCHK(hipMemcpy(ts, err + 2, sizeof(ts), hipMemcpyDeviceToHost));
-    const double f = 1e-2 / (double)std::max<long long>(ts[6], 1);   // wall_clock64 ticks at 100 MHz -> us per slab
-    fprintf(stderr, "[fused] per slab (us): load %.2f  phase1 %.2f  post+barrier %.2f  reduce+barrier %.2f  readY %.2f  phase2 %.2f  (%lld slabs)\n",
-            ts[0] * f, ts[1] * f, ts[2] * f, ts[3] * f, ts[4] * f, ts[5] * f, ts[6]);
+  if (std::getenv("EOFX_FUSED_TIMING") && npad == 10240) {
+    long long ts[17];
+    HIPCHK(hipMemcpy(ts, ctl + 2, sizeof(ts), hipMemcpyDeviceToHost));
+    const double f = 1e-2 / (double)std::max<long long>(ts[16], 1);   // wall_clock64 ticks at 100 MHz -> us per slab
+    fprintf(stderr, "[fused] per slab (us)  A: stage %.2f  issue %.2f  barrier %.2f  phase1+post %.2f  barrier %.2f |  B: consume+stage %.2f  "
+            "issue %.2f  barrier %.2f  reduce %.2f  phase2 %.2f  barrier %.2f  (%lld iterations)\n", ts[0] * f, ts[1] * f, ts[2] * f,
+            ts[3] * f, ts[4] * f, ts[8] * f, ts[9] * f, ts[10] * f, ts[11] * f, ts[12] * f, ts[13] * f, ts[16]);
   }
   if (herr == 2) return set_err(ctx, EOFX_ERR_HIP, "fused product: workgroups are not dispatched round robin over the XCDs");
   if (herr) return set_err(ctx, EOFX_ERR_HIP, "fused product: a workgroup timed out waiting for its group");
   return EOFX_OK;
 }
-extern "C" int eofx_panel_fused_f32(eofx_ctx* ctx, const eofx_mat* m, const float* Zn, float* Wn, int L) {
+extern "C" int eofx_panel_fused_f32(eofx_ctx* ctx, const eofx_mat* m, const float* Zn, float* Wn, float* Yp, int L) {
   if (!ctx || !m || !Zn || !Wn) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
   CHK(set_device(ctx));
   if (!fused_supported(ctx, m, L))
-    return set_err(ctx, EOFX_ERR_ARG, "fused product needs a 256-CU device, L = 64 and n_pad %% 1024 == 0 (n_pad <= 12288)");
-  CHK(arena_reserve(ctx, (size_t)FX_GROUPS * FX_SLOTS * (FX_MEMBERS + 1) * 2048 * 4 + (size_t)FX_GROUPS * m->n_pad * 64 * 4 + (1 << 20)));
-  return panel_fused(ctx, m, Zn, Wn);
+    return set_err(ctx, EOFX_ERR_ARG, "fused product needs a 256-CU device, L = 64 and n_pad in {3072, 5120, 8192, 10240}");
+  CHK(arena_reserve(ctx, fused_arena_bytes(m)));
+  return panel_fused(ctx, m, Zn, Wn, Yp);
 }
 extern "C" int eofx_panel_mul_f32(eofx_ctx* ctx, const eofx_mat* m, const float* Yp, float* Wn, int L,
                                   int prec) {

@@ -501,10 +501,12 @@ def feature_norms(ctx: Context, mat: ResidentMatrix) -> np.ndarray:
     return out
 
 
-def panel_fused(ctx: Context, mat: ResidentMatrix, Zn, out=None):
-    """Wn[n_pad, 64] = X (X^T Zn) in one pass over the matrix (experimental)"""
+def panel_fused(ctx: Context, mat: ResidentMatrix, Zn, out=None, want_y=False):
+    """Wn[n_pad, 64] = X (X^T Zn) in one pass over the matrix; with want_y also Yp[p_pad, 64] = X^T Zn"""
     torch = _torch()
     if out is None:
         out = torch.empty((mat.n_pad, Zn.shape[1]), dtype=torch.float32, device=Zn.device)
-    raise_for(ctx.lib.eofx_panel_fused_f32(ctx.handle, mat.handle, ptr(Zn), ptr(out), Zn.shape[1]), ctx.handle)
-    return out
+    Y = torch.empty((mat.p_pad, Zn.shape[1]), dtype=torch.float32, device=Zn.device) if want_y else None
+    raise_for(ctx.lib.eofx_panel_fused_f32(ctx.handle, mat.handle, ptr(Zn), ptr(out), ptr(Y) if want_y else None,
+                                           Zn.shape[1]), ctx.handle)
+    return (out, Y) if want_y else out
