@@ -1232,6 +1232,7 @@ static int panel_fused(eofx_ctx* ctx, const eofx_mat* m, const float* Zn, float*
         case 33: le = fused_launch<10, 33>(prm, ctx->stream); break;
         case 67: le = fused_launch<10, 67>(prm, ctx->stream); break;
         case 31: le = fused_launch<10, 31>(prm, ctx->stream); break;
+        case 133: le = fused_launch<10, 133>(prm, ctx->stream); break;
         default: le = fused_launch<10>(prm, ctx->stream); break;
       }
     } break;

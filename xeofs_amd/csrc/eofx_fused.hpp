@@ -69,10 +69,11 @@ __device__ __forceinline__ void fx_split4(f32x4 v, unsigned (&hi)[2], unsigned (
 }
 
 // DBG (probe builds only): bit 0 in-kernel phase timers, 1 no re-read loads, 2 no exchange loads, 3 no phase-2 MFMAs,
-// 4 no phase-1 MFMAs, 5 stream with nt loads, 6 no staging of the re-read
+// 4 no phase-1 MFMAs, 5 stream with nt loads, 6 no staging of the re-read, 7 phase 2 only two iterations behind (with bit 2)
 template <int KS, int DBG = 0>
 __global__ __launch_bounds__(512) void fused2_kernel(FxParams P) {
   constexpr bool TIMING = (DBG & 1) != 0;
+  constexpr int LAG = (DBG & 128) ? 2 : FX_LAG, LRS = (DBG & 128) ? 1 : FX_LRS;   // bit 7: timing probe of a short lag
   constexpr int R = 32 * KS;              // samples per member
   constexpr int NT = 2 * KS;              // 16-sample tiles per member
   constexpr int MT = (NT + 3) / 4;        // tiles per wave (role B)
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(512) void fused2_kernel(FxParams P) {
   const int64_t ldx = P.ldx, niter = P.niter;
   const float a_scale = P.a_scale, s1 = P.s1;
   const float b_scale = f16_scale_for(*P.z_absmax);
-  const int64_t total = (niter + FX_LAG + 1) & ~(int64_t)1;      // iterations (even), the same for both roles
+  const int64_t total = (niter + LAG + 1) & ~(int64_t)1;      // iterations (even), the same for both roles
 
   if (threadIdx.x == 0) {   // every member of group g has to run on XCD g: the exchange relies on a shared L2
     unsigned xcc = 0;
@@ -152,21 +153,12 @@ __global__ __launch_bounds__(512) void fused2_kernel(FxParams P) {
         *reinterpret_cast<uint2*>(Alo + loff0 + 32 * u) = make_uint2(lo[0], lo[1]);
       }
       tick(0);
-      // (2) stream: the sub-slab two iterations ahead (plain loads: the lines stay in the L2 for phase 2), issued as
-      //     soon as its registers are free
-      {
-        const float* s1p = slab_ptr(it + 2);
-#pragma unroll
-        for (int u = 0; u < KS; ++u)
-          xa[par][u] = (DBG & 32) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(s1p + goff0 + 32 * u))
-                                  : *reinterpret_cast<const f32x4*>(s1p + goff0 + 32 * u);
-      }
-      __builtin_amdgcn_sched_barrier(0);
       tick(1);
       __syncthreads();
       tick(2);
       // (3) phase 1 of slab `it`, post the partial tile
       {
+        const float* s1p = slab_ptr(it + 2);
         f32x4 a1[2][2];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
@@ -190,6 +182,13 @@ __global__ __launch_bounds__(512) void fused2_kernel(FxParams P) {
 #pragma unroll
           for (int mt = 0; mt < 2; ++mt)
             a1[mt][ks & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], zb[ks][0], a1[mt][ks & 1], 0, 0, 0);
+          // the stream, two iterations ahead (plain loads: the lines stay in the L2 for phase 2): one 16-byte chunk per
+          // k-step, so the address unit is fed evenly instead of in one burst per iteration
+          xa[par][ks] = (DBG & 32) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(s1p + goff0 + 32 * ks))
+                                   : *reinterpret_cast<const f32x4*>(s1p + goff0 + 32 * ks);
+          __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // 4 LDS reads
+          __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);   // 6 MFMAs
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 global load
         }
         const f32x4 v0 = a1[0][0] + a1[0][1], v1 = a1[1][0] + a1[1][1];
         const unsigned tag = (unsigned)(it + 1);
@@ -259,7 +258,7 @@ __global__ __launch_bounds__(512) void fused2_kernel(FxParams P) {
     };
 
     auto body = [&](int64_t it) {
-      const int64_t s_rs = it - FX_LRS, s_ag = it - FX_LAG;
+      const int64_t s_rs = it - LRS, s_ag = it - LAG;
       // (1) consume what the previous iteration issued.  The re-read sub-slab goes to LDS first: its registers are
       //     reloaded below, after the exchange work has given the LDS writes time to drain.
 #pragma unroll
@@ -311,14 +310,8 @@ __global__ __launch_bounds__(512) void fused2_kernel(FxParams P) {
       tick(0);
       // (2) issue the loads of the next iteration: exchange first, the re-read of the sub-slab last
       if (!(DBG & 4)) {
-        load_rs(it + 1 - FX_LRS);
-        load_ag(it + 1 - FX_LAG);
-      }
-      {
-        const float* s2 = slab_ptr(it + 1 - FX_LAG);
-#pragma unroll
-        for (int u = 0; u < KS; ++u)
-          if (!(DBG & 2)) xb[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(s2 + goff0 + 32 * u));
+        load_rs(it + 1 - LRS);
+        load_ag(it + 1 - LAG);
       }
       __builtin_amdgcn_sched_barrier(0);
       tick(1);
@@ -346,6 +339,7 @@ __global__ __launch_bounds__(512) void fused2_kernel(FxParams P) {
       tick(3);
       // (3b) phase 2 of slab it - LAG
       {
+        const float* s2 = slab_ptr(it + 1 - LAG);
         f16x8 yb[4][2];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -369,6 +363,10 @@ __global__ __launch_bounds__(512) void fused2_kernel(FxParams P) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) accW[tl][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0], yb[q][0], accW[tl][q], 0, 0, 0);
           }
+          // the re-read of the next phase-2 sub-slab, spread over the tiles
+#pragma unroll
+          for (int u = tl * KS / MT; u < (tl + 1) * KS / MT; ++u)
+            if (!(DBG & 2)) xb[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(s2 + goff0 + 32 * u));
         }
       }
       tick(4);
