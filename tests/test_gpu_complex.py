@@ -114,3 +114,41 @@ def test_complex_eof_on_reference_fixture(ctx):
     rec = m.scores().values.T @ m.components().values.conj()
     assert np.abs(rec - Zc).max() <= 2e-4 * np.abs(Zc).max()      # two modes carry all of it
     assert np.isclose(m.explained_variance_ratio().values.sum(), 1.0, atol=1e-4)
+
+
+def test_complex_inverse_transform_roundtrip(ctx):
+    """eof.py:134-156 with complex scores / components: inverse_transform(scores) = scores . conj(V)^T un-scaled with the
+    (complex) mean -- the rank-2 fixture is reproduced exactly; HilbertEOF returns the real part (eof.py:564-567);
+    a scalar mode is expanded (base_model_single_set.py:276-277); EOFRotator refuses complex models."""
+    import xeofs_amd as xe
+
+    x = np.linspace(-5, 5, 128)
+    t = np.linspace(0, 4 * np.pi, 256)
+    Z = (1.0 / np.cosh(x[None, :] + 3) * np.exp(2.3j * t[:, None])
+         + 2.0 / np.cosh(x[None, :]) * np.tanh(x) * np.exp(2.8j * t[:, None])) + (0.3 - 0.2j)
+    da = xe.DataArray(Z, dims=("time", "x"), coords={"time": t, "x": x})
+    m = xe.single.ComplexEOF(n_modes=2, random_state=0).fit(da, "time")
+    rec = m.inverse_transform(m.scores())
+    assert rec.dims == ("time", "x") and np.iscomplexobj(rec.values)
+    assert np.abs(rec.values - Z).max() <= 3e-4 * np.abs(Z).max()
+    # oracle of the formula itself, mode by mode: Re(S) Re(V)^T + Im(S) Im(V)^T etc.
+    S, V = m.scores().values.T, m.components().values.T          # (n, k), (p, k)
+    want = S @ V.conj().T + Z.mean(axis=0)
+    assert np.abs(rec.values - want).max() <= 2e-5 * np.abs(want).max()
+    sc = m.scores()
+    one = xe.DataArray(sc.values[1], dims=("time",), coords={"time": t, "mode": 2})
+    r1 = m.inverse_transform(one)
+    want1 = np.outer(S[:, 1], V[:, 1].conj()) + Z.mean(axis=0)
+    assert np.abs(r1.values - want1).max() <= 2e-5 * np.abs(want1).max()
+
+    n, nlat, nlon, k = 240, 6, 40, 4
+    X = _waves(n, nlat * nlon, seed=2).reshape(n, nlat, nlon)
+    dh = xe.DataArray(X, dims=("time", "lat", "lon"))
+    h = xe.single.HilbertEOF(n_modes=k, random_state=1).fit(dh, "time")
+    rh = h.inverse_transform(h.scores())
+    assert rh.dims == ("time", "lat", "lon") and not np.iscomplexobj(rh.values)
+    Sh, Vh = h.scores().values.T, h.components().values.reshape(k, -1).T
+    wanth = (Sh @ Vh.conj().T).real + X.reshape(n, -1).mean(axis=0)
+    assert np.abs(rh.values.reshape(n, -1) - wanth).max() <= 2e-5 * np.abs(wanth).max()
+    with pytest.raises(NotImplementedError, match="real models only"):
+        xe.single.EOFRotator(n_modes=2).fit(m)

@@ -138,7 +138,7 @@ def is_xarray(obj) -> bool:
 def unpack(obj):
     """-> (values ndarray, dims tuple, coords dict, name, attrs) from either array flavour."""
     if _xr is not None and isinstance(obj, _xr.DataArray):
-        coords = {k: np.asarray(v.values) for k, v in obj.coords.items() if k in obj.dims}
+        coords = {k: np.asarray(v.values) for k, v in obj.coords.items() if k in obj.dims or v.ndim == 0}   # + scalar coords
         return np.asarray(obj.values), tuple(obj.dims), coords, obj.name, dict(obj.attrs)
     if isinstance(obj, DataArray):
         return obj.values, obj.dims, dict(obj.coords), obj.name, dict(obj.attrs)

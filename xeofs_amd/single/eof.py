@@ -95,20 +95,22 @@ class EOF:
     def fit_transform(self, X, dim, weights=None, **kwargs):
         return self.fit(X, dim, weights).transform(X, **kwargs)
 
-    def inverse_transform(self, scores, normalized: bool = False):
-        """base_model_single_set.py:205-286 + eof.py:134-156: Xhat = scores . conj(V)^T, then un-scale."""
+    def _parse_scores(self, scores, normalized, dtype):
+        """base_model_single_set.py:205-286: scores with a (possibly scalar) 'mode' coordinate -> (S [n', k'] of the valid
+        samples, mode numbers, valid-sample mask, the fields relabelled with the scores' sample coordinates)."""
         vals, dims, coords, _, _ = labelled.unpack(scores)
-        if "mode" not in dims:
-            raise ValueError("scores must have a 'mode' dimension")
-        modes = np.asarray(coords["mode"]).astype(int)
+        dims = tuple(dims)
+        if "mode" not in dims:          # a single selected mode: "Handle scalar mode in xr.dot" (line 276)
+            m = np.asarray(coords.get("mode", 1)).reshape(-1)[:1]
+            vals, dims = np.asarray(vals)[None], ("mode",) + dims
+            coords = dict(coords, mode=m)
+        modes = np.asarray(coords["mode"]).astype(int).reshape(-1)
         order = [dims.index("mode")] + [i for i, d in enumerate(dims) if d != "mode"]
         S = np.transpose(vals, order).reshape(len(modes), -1).T            # (n_samples, k')
         vs = ~np.isnan(S).all(axis=1)
-        S = np.ascontiguousarray(S[vs], dtype=np.float32)
+        S = np.ascontiguousarray(S[vs], dtype=dtype)
         if normalized:
-            S = S * self.data["norms"][modes - 1].astype(np.float32)
-        V = np.ascontiguousarray(self.data["components"][:, modes - 1])
-        rec = engine.reconstruct(self.ctx, S, V)
+            S = S * self.data["norms"][modes - 1].astype(S.real.dtype)
         f0 = self.preprocessor.fields[0]
         sample_shape = tuple(vals.shape[dims.index(d)] for d in f0.sample_dims)
         fields = []
@@ -118,6 +120,13 @@ class EOF:
             g.sample_shape = sample_shape
             g.coords = dict(f.coords, **{d: coords[d] for d in f.sample_dims if d in coords})
             fields.append(g)
+        return S, modes, vs, fields
+
+    def inverse_transform(self, scores, normalized: bool = False):
+        """base_model_single_set.py:205-286 + eof.py:134-156: Xhat = scores . conj(V)^T, then un-scale."""
+        S, modes, vs, fields = self._parse_scores(scores, normalized, np.float32)
+        V = np.ascontiguousarray(self.data["components"][:, modes - 1])
+        rec = engine.reconstruct(self.ctx, S, V)
         return self.preprocessor.inverse_transform_data(rec, "reconstructed_data", fields, vs)
 
     # ------------------------------------------------------------------ accessors
@@ -209,6 +218,28 @@ class ComplexEOF(EOF):
     def transform(self, X, normalized=False):
         raise NotImplementedError("ComplexEOF/HilbertEOF does not support transform() (as in the reference)")
 
+    _real_reconstruction = False      # HilbertEOF: eof.py:564-567 keeps the real part only
+
+    def inverse_transform(self, scores, normalized: bool = False):
+        """eof.py:134-156 with complex scores and components: Xhat = S conj(V)^T, i.e.
+        Re = Sr Vr^T + Si Vi^T and Im = Si Vr^T - Sr Vi^T -- two real products of width 2 k' on the GPU; each part is
+        un-scaled with the centring of its own part (the reference's Scaler holds one complex mean)."""
+        S, modes, vs, fields = self._parse_scores(scores, normalized, np.complex64)
+        V = self.data["components"][:, modes - 1]
+        Vri = np.ascontiguousarray(np.concatenate([V.real, V.imag], axis=1), dtype=np.float32)
+        Sre = np.ascontiguousarray(np.concatenate([S.real, S.imag], axis=1), dtype=np.float32)
+        re = self.preprocessor.inverse_transform_data(engine.reconstruct(self.ctx, Sre, Vri), "reconstructed_data", fields, vs)
+        if self._real_reconstruction:
+            return re
+        Sim = np.ascontiguousarray(np.concatenate([S.imag, -S.real], axis=1), dtype=np.float32)
+        im = self.preprocessor_imag.inverse_transform_data(engine.reconstruct(self.ctx, Sim, Vri), "reconstructed_data", fields, vs)
+
+        def join(a, b):
+            va, dims, coords, name, attrs = labelled.unpack(a)
+            return labelled.pack(va + 1j * labelled.unpack(b)[0], dims, coords, name, attrs, a)
+
+        return [join(a, b) for a, b in zip(re, im)] if isinstance(re, list) else join(re, im)
+
     def components_amplitude(self, normalized=True):
         c = self.components(normalized)
         return self._map(c, np.abs, "components_amplitude")
@@ -236,6 +267,8 @@ class HilbertEOF(ComplexEOF):
     """Drop-in for xeofs.single.HilbertEOF (xeofs/single/eof.py:449-560): the real input is
     preprocessed, Hilbert-transformed along the sample axis on the GPU (`eofx_hilbert_f32`,
     utils/hilbert_transform.py) and decomposed as a complex matrix."""
+
+    _real_reconstruction = True
 
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)

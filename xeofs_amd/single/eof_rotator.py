@@ -41,6 +41,9 @@ class EOFRotator(EOF):
         m = int(self._params["n_modes"])
         power = self._params["power"]
         comps = np.asarray(model.data["components"])[:, :m]
+        if np.iscomplexobj(comps):     # ComplexEOFRotator / HilbertEOFRotator (eof_rotator.py:294-400) are not built yet
+            raise NotImplementedError("EOFRotator rotates real models only; rotation of ComplexEOF / HilbertEOF models "
+                                      "(the reference's ComplexEOFRotator / HilbertEOFRotator) is not supported")
         m = comps.shape[1]
         expvar = np.asarray(model.data["explained_variance"], dtype=np.float64)[:m]
         # loadings = components * sqrt(expvar); rotation, explained variance, normalisation, sign and ordering all
