@@ -126,6 +126,9 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for "
                     "functional tests of the multi-rank path on a single GPU together with --same-gpu)")
     ap.add_argument("--same-gpu", action="store_true", help="functional test: all ranks share cuda:0")
+    ap.add_argument("--two-layouts", action="store_true",
+                    help="write both layouts of the preprocessed matrix (round-1 behaviour) instead of streaming the raw "
+                         "field through the Scaler map in the X^T Z passes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sample-parity", action="store_true",
                     help="also decompose the CPU-baseline sample on the GPU and compare singular values "
@@ -201,10 +204,10 @@ def main():
         omega = engine.SketchFuture(min(n, P), k + N_OVERSAMPLES, 5)
         if world == 1 and not args.force_sharded:
             mat, st = engine.preprocess(ctx, Xraw, center=True, standardize=False, feature_weights=None,
-                                        want_stats=False)
+                                        want_stats=False, keep_raw=not args.two_layouts)
         else:   # + the global facts: valid-sample mask / isolated-NaN check, feature offsets, total variance
             mat, st = sharded.sharded_preprocess(ctx, Xraw, comm, center=True, standardize=False,
-                                                 feature_weights=None, want_stats=False)
+                                                 feature_weights=None, want_stats=False, keep_raw=not args.two_layouts)
         torch.cuda.synchronize()
         b = time.perf_counter()
         if world == 1 and not args.force_sharded:

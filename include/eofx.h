@@ -133,6 +133,20 @@ int eofx_mat_shape(const eofx_mat *m, int64_t *n, int64_t *p, int64_t *n_pad, in
 /* copy the resident matrix back (host|device dst, n x p dense).                */
 int eofx_mat_download_f32(eofx_ctx *ctx, const eofx_mat *m, float *dst);
 
+/* ---- layout policy -------------------------------------------------------
+ * A resident matrix normally holds the preprocessed field twice (feature- and sample-contiguous).  With keep_raw = 1
+ * eofx_preprocess_f32 / eofx_apply_f32 write the sample-contiguous layout only whenever nothing is dropped (no all-NaN
+ * feature or sample) and the raw field is 16-byte aligned with P % 4 == 0: the products that stream the
+ * feature-contiguous layout (X^T Z) then read the RAW field and apply the Scaler map
+ * (xeofs/preprocessing/scaler.py:153, (x - mean) / std * weights) on the fly -- one third less traffic in the
+ * preprocessor, one layout less in HBM.  A DEVICE field handed to the preprocessor must stay alive and unmodified
+ * until eofx_mat_release_raw or eofx_mat_destroy (a host field is staged and owned by the matrix).  After the release --
+ * or for passes in another precision than EOFX_PREC_F16X3 -- the feature-contiguous layout is rebuilt on demand
+ * from the sample-contiguous one.                                                                              */
+int eofx_ctx_set_layout(eofx_ctx *ctx, int keep_raw);
+int eofx_mat_release_raw(eofx_ctx *ctx, eofx_mat *m);
+int eofx_mat_layout(const eofx_mat *m, int *has_feature_contiguous, int *has_raw);
+
 /* ---- randomized SVD (the decomposer seam) ------------------------------
  * Replaces randomized_svd(X, n_components=k, random_state) at decomposer.py:146.
  *   omega   host, (min(n,p) x (k+n_oversamples)) float32 Gaussian test matrix, drawn

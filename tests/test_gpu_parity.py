@@ -437,3 +437,47 @@ def test_peaked_spectrum_on_a_large_tall_panel(ctx):
     U2, s2, V2 = sharded.sharded_rsvd(ops, NoComm(), k, p, 0, random_state=9)
     assert np.array_equal(s, s2) and np.array_equal(U, U2) and np.array_equal(V, V2)
     mat.free()
+
+
+@pytest.mark.parametrize("n,P,std,wts", [(300, 1024, False, False), (517, 2500, True, True), (1000, 7300, False, True),
+                                         (96, 516, True, False)])
+def test_raw_mode_equals_two_layout_mode(ctx, n, P, std, wts):
+    """eofx_ctx_set_layout(1): the feature-contiguous layout is never written, X^T Z streams the raw field through the
+    Scaler map (atb_f16_kernel<NB, true>).  The map is the expression the apply kernel writes, so the panel product, the
+    randomized SVD and everything downstream are BITWISE those of the two-layout mode -- for row counts that are not a
+    multiple of 32 and column counts that are not a multiple of 512 (clamped reads) as well."""
+    import torch
+    from xeofs_amd import engine
+
+    g = torch.Generator(device="cuda").manual_seed(n * 7 + P)
+    X = torch.randn((n, P), device="cuda", generator=g) * 3 + torch.linspace(-40, 250, P, device="cuda")
+    w = np.linspace(0.2, 1.7, P) if wts else None
+    m2, st2 = engine.preprocess(ctx, X, True, std, w)
+    m1, st1 = engine.preprocess(ctx, X, True, std, w, keep_raw=True)
+    assert m2.layout() == (True, False) and m1.layout() == (False, True)
+    assert st1["total_variance"] == st2["total_variance"] and np.array_equal(st1["mean"], st2["mean"])
+    Z = torch.randn((m1.n_pad, 64), device="cuda", generator=g)
+    Z[n:] = 0
+    assert torch.equal(engine.panel_tmul(ctx, m1, Z), engine.panel_tmul(ctx, m2, Z))
+    k = 7
+    for a, b in zip(engine.rsvd(ctx, m1, k, random_state=3), engine.rsvd(ctx, m2, k, random_state=3)):
+        assert np.array_equal(a, b)
+    # other precisions, the Gram matrix and the download need the layout itself: rebuilt from the sample-contiguous one
+    assert torch.equal(engine.panel_tmul(ctx, m1, Z, prec="f32"), engine.panel_tmul(ctx, m2, Z, prec="f32"))
+    assert m1.layout()[0]
+    assert np.array_equal(m1.download(), m2.download())
+    m1.release_raw()
+    assert m1.layout() == (True, False)
+    assert torch.equal(engine.panel_tmul(ctx, m1, Z), engine.panel_tmul(ctx, m2, Z))
+    # a host field: the staged copy is owned by the matrix
+    Xh = X.cpu().numpy()
+    m3, _ = engine.preprocess(ctx, Xh, True, std, w, keep_raw=True)
+    assert m3.layout() == (False, True)
+    assert torch.equal(engine.panel_tmul(ctx, m3, Z), engine.panel_tmul(ctx, m2, Z))
+    # anything that drops features or samples falls back to the two-layout mode
+    Xn = X.clone()
+    Xn[:, 5] = float("nan")
+    m4, st4 = engine.preprocess(ctx, Xn, True, std, w, keep_raw=True)
+    assert m4.layout() == (True, False) and st4["p"] == P - 1
+    for m in (m1, m2, m3, m4):
+        m.free()

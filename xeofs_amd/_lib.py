@@ -58,6 +58,9 @@ SIGNATURES = {
     "eofx_hilbert_f32": (_int, [_vp, _vp, _int, C.c_double, C.POINTER(_vp), C.POINTER(_vp)]),
     "eofx_mat_sumsq_f64": (_int, [_vp, _vp, _pd]),
     "eofx_panel_fused_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _int]),
+    "eofx_ctx_set_layout": (_int, [_vp, _int]),
+    "eofx_mat_release_raw": (_int, [_vp, _vp]),
+    "eofx_mat_layout": (_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "eofx_panel_rownorm_f64": (_int, [_vp, _vp, _i64, _int, _vp]),
     "eofx_mat_feature_norms_f64": (_int, [_vp, _vp, _vp]),
     "eofx_resample_f32": (_int, [_vp, _vp, _vp, _i64, _int, C.POINTER(_vp), _vp, _pd]),

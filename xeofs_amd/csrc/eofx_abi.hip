@@ -49,6 +49,8 @@ struct eofx_ctx {
   std::vector<HilbertSetup> hsetups;
   // cached hipFFT plans of the Hilbert stage: key = (P, batch) -> (R2C plan, C2R plan)
   std::vector<std::pair<std::pair<int64_t, int64_t>, std::pair<void*, void*>>> fft_plans;
+  // 1: preprocessing keeps a reference to the raw field instead of writing the feature-contiguous layout
+  int keep_raw = 0;
   // optional per-launch timing of the dominant kernel (atb_f32) with HIP events on `stream`
   bool profile = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
@@ -58,8 +60,15 @@ struct eofx_ctx {
 
 struct eofx_mat {
   int64_t n = 0, p = 0, n_pad = 0, p_pad = 0;
-  float* X = nullptr;   // [n_pad x p_pad]
+  float* X = nullptr;   // [n_pad x p_pad]; absent in raw mode until something needs it (ensure_X)
   float* Xt = nullptr;  // [p_pad x n_pad]
+  // raw mode (eofx_ctx_set_layout): the feature-contiguous layout is the caller's RAW field [n x p] (or the staged copy
+  // of a host field, owned here) read through the affine preprocessing map aff = {shift[p_pad], scale[p_pad]}
+  const float* raw = nullptr;
+  float* raw_owned = nullptr;
+  size_t raw_owned_bytes = 0;
+  int64_t raw_ld = 0;
+  float* aff = nullptr;      // [3][p_pad]: shift hi, shift lo, scale (aff_pack_kernel)
   unsigned* absmax_dev = nullptr;  // float bits of max |x| (device scalar, for the fp16-split scaling)
   float absmax = 0.f;              // host copy, valid once the matrix is built
 };
@@ -382,13 +391,24 @@ static size_t atb_scratch_bytes(int64_t M, int64_t K, int L) {
 }
 
 // C[M x L] = A[K x M]^T B[K x L]; M multiple of 512, K multiple of 16, L multiple of 32.
+// raw view of A (atb_f16_kernel<NB, true>): the raw field with the affine preprocessing map applied on the fly
+struct AffView {
+  const float* aff = nullptr;   // {shift hi, shift lo, scale}[ld]
+  int64_t ld = 0;
+  int rows = 0;        // valid rows of the raw field
+  int64_t cols = 0;    // valid columns
+};
 template <int NB>
 static void launch_atb_variant(int prec, dim3 grid, hipStream_t st, const float* A, int64_t lda,
                                const float* B, int ldb, float* out, int L, int64_t M, int64_t K,
-                               int64_t kps, int col_base, float a_scale, const float* b_absmax) {
-  if (prec == EOFX_PREC_F16X3)
+                               int64_t kps, int col_base, float a_scale, const float* b_absmax,
+                               const AffView* aff = nullptr) {
+  if (prec == EOFX_PREC_F16X3 && aff)
+    hipLaunchKernelGGL((atb_f16_kernel<NB, true>), grid, dim3(256), 0, st, A, lda, B, ldb, out, L, M, K, kps, col_base,
+                       a_scale, b_absmax, aff->aff, aff->ld, aff->rows, aff->cols);
+  else if (prec == EOFX_PREC_F16X3)
     hipLaunchKernelGGL(atb_f16_kernel<NB>, grid, dim3(256), 0, st, A, lda, B, ldb, out, L, M, K, kps, col_base,
-                       a_scale, b_absmax);
+                       a_scale, b_absmax, (const float*)nullptr, (int64_t)0, 0, (int64_t)0);
   else if (prec == EOFX_PREC_BF16X3)
     hipLaunchKernelGGL((atb_bf16_kernel<NB, 2>), grid, dim3(256), 0, st, A, lda, B, ldb, out, L, M, K, kps, col_base);
   else if (prec == EOFX_PREC_BF16X6)
@@ -401,7 +421,8 @@ static void launch_atb_variant(int prec, dim3 grid, hipStream_t st, const float*
 // Both are only used by the fp16-split variant.
 static int launch_atb(eofx_ctx* ctx, const float* A, int64_t lda, int64_t K, int64_t M,
                       const float* B, int ldb, int L, float* C, int prec = EOFX_PREC_F32,
-                      float a_absmax = 0.f, const float* b_absmax_dev = nullptr) {
+                      float a_absmax = 0.f, const float* b_absmax_dev = nullptr, const AffView* aff = nullptr) {
+  if (aff && prec != EOFX_PREC_F16X3) return set_err(ctx, EOFX_ERR_ARG, "atb: the raw view needs the f16x3 kernel");
   if (M % ATB_BM || K % ATB_KG || L % 32 || L <= 0)
     return set_err(ctx, EOFX_ERR_ARG, "atb: bad geometry M=%lld K=%lld L=%d", (long long)M,
                    (long long)K, L);
@@ -446,12 +467,12 @@ static int launch_atb(eofx_ctx* ctx, const float* A, int64_t lda, int64_t K, int
   }
   if (nfull > 0) {
     dim3 grid(bx, best_s, nfull);
-    launch_atb_variant<2>(prec, grid, ctx->stream, A, lda, B, ldb, out, L, M, K, best_kps, 0, a_scale, b_absmax_dev);
+    launch_atb_variant<2>(prec, grid, ctx->stream, A, lda, B, ldb, out, L, M, K, best_kps, 0, a_scale, b_absmax_dev, aff);
     KCHK();
   }
   if (rem) {
     dim3 grid(bx, best_s, 1);
-    launch_atb_variant<1>(prec, grid, ctx->stream, A, lda, B, ldb, out, L, M, K, best_kps, nfull * 64, a_scale, b_absmax_dev);
+    launch_atb_variant<1>(prec, grid, ctx->stream, A, lda, B, ldb, out, L, M, K, best_kps, nfull * 64, a_scale, b_absmax_dev, aff);
     KCHK();
   }
   if (ctx->profile) {
@@ -675,14 +696,14 @@ extern "C" int eofx_ctx_trim(eofx_ctx* ctx) {
   return EOFX_OK;
 }
 
-static int mat_alloc(eofx_ctx* ctx, int64_t n, int64_t p, eofx_mat** out) {
+static int mat_alloc(eofx_ctx* ctx, int64_t n, int64_t p, eofx_mat** out, bool want_x = true) {
   eofx_mat* m = new eofx_mat();
   m->n = n;
   m->p = p;
   m->n_pad = round_up(n, ATB_BM);
   m->p_pad = round_up(p, ATB_BM);
   const size_t bytes = (size_t)m->n_pad * m->p_pad * sizeof(float);
-  hipError_t e = pool_malloc(ctx, (void**)&m->X, bytes);
+  hipError_t e = want_x ? pool_malloc(ctx, (void**)&m->X, bytes) : hipSuccess;
   if (e == hipSuccess) e = pool_malloc(ctx, (void**)&m->Xt, bytes);
   if (e == hipSuccess) e = pool_malloc(ctx, (void**)&m->absmax_dev, 256);
   if (e == hipSuccess) e = hipMemsetAsync(m->absmax_dev, 0, 256, ctx->stream);
@@ -704,13 +725,16 @@ extern "C" int eofx_mat_destroy(eofx_ctx* ctx, eofx_mat* m) {
   if (ctx) {
     (void)hipSetDevice(ctx->device);
     // same-stream reuse is ordered; nothing else touches these buffers
-    pool_give(ctx, m->X, bytes);
+    if (m->X) pool_give(ctx, m->X, bytes);
     pool_give(ctx, m->Xt, bytes);
     pool_give(ctx, m->absmax_dev, 256);
+    if (m->raw_owned) pool_give(ctx, m->raw_owned, m->raw_owned_bytes);
   } else {
     if (m->X) (void)hipFree(m->X);
     if (m->Xt) (void)hipFree(m->Xt);
+    if (m->raw_owned) (void)hipFree(m->raw_owned);
   }
+  if (m->aff) (void)hipFree(m->aff);
   delete m;
   return EOFX_OK;
 }
@@ -742,6 +766,15 @@ static int stage_input(eofx_ctx* ctx, const float* X, size_t count, Staged& st) 
   return EOFX_OK;
 }
 
+// raw mode over a host field: the staged device copy lives as long as the matrix that reads it
+static void adopt_staged(eofx_mat** out, Staged& st, size_t bytes) {
+  if (out && *out && (*out)->raw && (*out)->raw == st.owned) {
+    (*out)->raw_owned = st.owned;
+    (*out)->raw_owned_bytes = bytes;
+    st.owned = nullptr;
+  }
+}
+
 // absmax_src: device scalar holding max |transformed value| when the column statistics already know it
 // (preprocess path); nullptr -> measured with one extra read of the written matrix.
 static int launch_apply(eofx_ctx* ctx, const float* Xsrc, int64_t ld_src, const int64_t* row_map,
@@ -759,13 +792,50 @@ static int launch_apply(eofx_ctx* ctx, const float* Xsrc, int64_t ld_src, const 
   if (absmax_src) {
     HIPCHK(hipMemcpyAsync(m->absmax_dev, absmax_src, sizeof(unsigned), hipMemcpyDeviceToDevice, ctx->stream));
   } else {
-    const int64_t total4 = m->n_pad * (m->p_pad / 4);
+    const int64_t total4 = m->n_pad * (m->p_pad / 4);   // same elements in either layout
     hipLaunchKernelGGL(panel_absmax_kernel, dim3((int)std::max<int64_t>(1, std::min<int64_t>((total4 + 1023) / 1024, 1024))), dim3(256), 0,
-                       ctx->stream, m->X, m->n_pad, (int)m->p_pad, m->p_pad, m->absmax_dev);
+                       ctx->stream, m->Xt, m->p_pad, (int)m->n_pad, m->n_pad, m->absmax_dev);
     KCHK();
   }
   // host copy of max |x| (callers synchronise the stream before using the matrix)
   HIPCHK(hipMemcpyAsync(&m->absmax, m->absmax_dev, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  return EOFX_OK;
+}
+
+// The feature-contiguous layout of a raw-mode matrix, built on demand from the sample-contiguous one (tiled transpose).
+static int ensure_X(eofx_ctx* ctx, const eofx_mat* cm) {
+  eofx_mat* m = const_cast<eofx_mat*>(cm);
+  if (m->X) return EOFX_OK;
+  const size_t bytes = (size_t)m->n_pad * m->p_pad * sizeof(float);
+  if (pool_malloc(ctx, (void**)&m->X, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    m->X = nullptr;
+    return set_err(ctx, EOFX_ERR_NOMEM, "cannot allocate the feature-contiguous layout (%.2f GB)", bytes / 1e9);
+  }
+  hipLaunchKernelGGL(transpose_kernel, dim3((int)(m->n_pad / 64), (int)(m->p_pad / 64)), dim3(256), 0, ctx->stream, m->Xt,
+                     m->n_pad, m->X, m->p_pad);
+  KCHK();
+  return EOFX_OK;
+}
+extern "C" int eofx_ctx_set_layout(eofx_ctx* ctx, int keep_raw) {
+  if (!ctx) return EOFX_ERR_ARG;
+  ctx->keep_raw = keep_raw ? 1 : 0;
+  return EOFX_OK;
+}
+extern "C" int eofx_mat_release_raw(eofx_ctx* ctx, eofx_mat* m) {
+  if (!ctx || !m) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  CHK(set_device(ctx));
+  HIPCHK(hipStreamSynchronize(ctx->stream));   // passes still reading the raw field
+  if (m->raw_owned) pool_give(ctx, m->raw_owned, m->raw_owned_bytes);
+  m->raw_owned = nullptr;
+  m->raw_owned_bytes = 0;
+  m->raw = nullptr;
+  return EOFX_OK;
+}
+extern "C" int eofx_mat_layout(const eofx_mat* m, int* has_x, int* has_raw) {
+  if (!m) return EOFX_ERR_ARG;
+  if (has_x) *has_x = m->X != nullptr;
+  if (has_raw) *has_raw = m->raw != nullptr;
   return EOFX_OK;
 }
 
@@ -799,6 +869,7 @@ extern "C" int eofx_mat_download_f32(eofx_ctx* ctx, const eofx_mat* m, float* ds
   float* tmp = dst;
   if (!dev) HIPCHK(hipMalloc((void**)&tmp, total * sizeof(float)));
   const int blocks = (int)std::min<int64_t>((total + 255) / 256, 16384);
+  CHK(ensure_X(ctx, m));
   hipLaunchKernelGGL(mat_download_kernel, dim3(blocks), dim3(256), 0, ctx->stream, m->X, m->p_pad, m->n,
                      m->p, tmp);
   hipError_t e = hipGetLastError();
@@ -938,9 +1009,29 @@ static int sanitize_and_apply(eofx_ctx* ctx, const float* Xd, int64_t n, int64_t
   if (p_out) *p_out = pv;
   if (!out) return EOFX_OK;
 
+  // raw mode (eofx_ctx_set_layout): nothing is dropped or reordered, so the raw field itself -- read through the
+  // affine map -- is the feature-contiguous layout; only the sample-contiguous one is written.  P < 2^31 rows: int.
+  const bool raw_mode = ctx->keep_raw && pv == P && ns == n && P % 4 == 0 && ((uintptr_t)Xd % 16) == 0 && n < ((int64_t)1 << 31);
   eofx_mat* m = nullptr;
-  CHK(mat_alloc(ctx, ns, pv, &m));
+  CHK(mat_alloc(ctx, ns, pv, &m, !raw_mode));
   int rc = EOFX_OK;
+  if (raw_mode) {
+    const size_t abytes = sizeof(float) * 3 * (size_t)m->p_pad;
+    if (hipMalloc((void**)&m->aff, abytes) != hipSuccess) {
+      (void)hipGetLastError();
+      m->aff = nullptr;
+      eofx_mat_destroy(ctx, m);
+      return set_err(ctx, EOFX_ERR_NOMEM, "cannot allocate the affine map (%zu bytes)", abytes);
+    }
+    hipLaunchKernelGGL(aff_pack_kernel, dim3((int)((m->p_pad + 255) / 256)), dim3(256), 0, ctx->stream, ps.shift, ps.scale, P,
+                       m->p_pad, m->aff);
+    if (hipGetLastError() != hipSuccess) {
+      eofx_mat_destroy(ctx, m);
+      return set_err(ctx, EOFX_ERR_HIP, "raw mode: affine map kernel failed");
+    }
+    m->raw = Xd;
+    m->raw_ld = P;
+  }
   {
     ArenaScope scope(ctx);
     int64_t* dcol = nullptr;
@@ -1011,6 +1102,7 @@ extern "C" int eofx_preprocess_f32(eofx_ctx* ctx, const float* X, int64_t n, int
   FeatSummary fs;
   CHK(sanitize_and_apply(ctx, st.dev, n, P, ps, true, nullptr, check_nans, out, valid_feature, valid_sample, &ns,
                          &pv, hcnt, &fs));
+  adopt_staged(out, st, (size_t)n * P * sizeof(float));
   if (n_out) *n_out = ns;
   if (p_out) *p_out = pv;
   if (mean) HIPCHK(hipMemcpyAsync(mean, ps.mean, sizeof(double) * P, hipMemcpyDeviceToHost, ctx->stream));
@@ -1057,6 +1149,7 @@ extern "C" int eofx_apply_f32(eofx_ctx* ctx, const float* X, int64_t n, int64_t 
   int64_t ns = 0, pv = 0;
   CHK(sanitize_and_apply(ctx, st.dev, n, P, ps, false, valid_feature, check_nans, out, nullptr, valid_sample, &ns,
                          &pv, hcnt));
+  adopt_staged(out, st, (size_t)n * P * sizeof(float));
   if (n_out) *n_out = ns;
   return EOFX_OK;
 }
@@ -1087,6 +1180,7 @@ extern "C" int eofx_resample_f32(eofx_ctx* ctx, const eofx_mat* src, const int64
   ARENA(int64_t, drows, n_rows);
   ps = {cnt, dmean, dstd, dshift, dscale, dm2, dabsmax};
   CHK(copy_in(ctx, drows, rows, sizeof(int64_t) * n_rows));
+  CHK(ensure_X(ctx, src));
   CHK(run_colstats(ctx, src->X, n_rows, P, center, 0, nullptr, ps, src->p_pad, drows));
   eofx_mat* m = nullptr;
   CHK(mat_alloc(ctx, n_rows, P, &m));
@@ -1113,6 +1207,15 @@ extern "C" int eofx_resample_f32(eofx_ctx* ctx, const eofx_mat* src, const int64
 // panel-level ABI
 // ------------------------------------------------------------------------------------
 static int panel_tmul(eofx_ctx* ctx, const eofx_mat* m, const float* Zn, float* Yp, int L, int prec) {
+  if (!m->X && m->raw && prec == EOFX_PREC_F16X3) {   // raw mode: stream the raw field through the affine map
+    AffView av;
+    av.aff = m->aff;
+    av.ld = m->p_pad;
+    av.rows = (int)m->n;
+    av.cols = m->p;
+    return launch_atb(ctx, m->raw, m->raw_ld, round_up(m->n, ATB_KG), m->p_pad, Zn, L, L, Yp, prec, m->absmax, nullptr, &av);
+  }
+  CHK(ensure_X(ctx, m));
   return launch_atb(ctx, m->X, m->p_pad, round_up(m->n, ATB_KG), m->p_pad, Zn, L, L, Yp, prec, m->absmax);
 }
 static int panel_mul(eofx_ctx* ctx, const eofx_mat* m, const float* Yp, float* Wn, int L, int prec) {
@@ -1561,6 +1664,7 @@ static int mat_gram(eofx_ctx* ctx, const eofx_mat* m, int side, float* G) {
                       m->absmax, reinterpret_cast<const float*>(m->absmax_dev));
   }
   const int64_t ppad = m->p_pad;
+  CHK(ensure_X(ctx, m));
   return launch_atb(ctx, m->X, ppad, round_up(m->n, ATB_KG), ppad, m->X, (int)ppad, (int)ppad, G, ctx->prec_final,
                     m->absmax, reinterpret_cast<const float*>(m->absmax_dev));
 }
@@ -1934,7 +2038,8 @@ extern "C" int eofx_mat_sumsq_f64(eofx_ctx* ctx, const eofx_mat* m, double* out)
   CHK(arena_reserve(ctx, nb * sizeof(double) + 4096));
   ArenaScope scope(ctx);
   ARENA(double, part, nb);
-  hipLaunchKernelGGL(dotprod_part_kernel, dim3(nb), dim3(256), 0, ctx->stream, m->X, m->X, m->n_pad * m->p_pad, part);
+  const float* base = m->X ? m->X : m->Xt;   // the same elements (raw mode holds the sample-contiguous layout only)
+  hipLaunchKernelGGL(dotprod_part_kernel, dim3(nb), dim3(256), 0, ctx->stream, base, base, m->n_pad * m->p_pad, part);
   KCHK();
   std::vector<double> hp(nb);
   HIPCHK(hipMemcpyAsync(hp.data(), part, sizeof(double) * nb, hipMemcpyDeviceToHost, ctx->stream));

@@ -13,6 +13,19 @@ namespace eofx {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// The Scaler map (xeofs/preprocessing/scaler.py:153) in float32 arithmetic: (x - mean) * scale with the float64 mean
+// carried as a float pair, so the subtraction is exact whenever x and the mean are within a factor of two of each other
+// (Sterbenz) and otherwise rounds like any float subtraction; about one ulp from the float64 formula.  ONE definition,
+// used by apply_kernel (which writes the sample-contiguous layout) and by the raw view of atb_f16_kernel (which streams
+// the raw field): both see the same float32 matrix.
+__device__ __forceinline__ void aff_split(double sh, float& hi, float& lo) {
+  hi = (float)sh;
+  lo = (float)(sh - (double)hi);
+}
+__device__ __forceinline__ float aff_map(float x, float sh_hi, float sh_lo, float scale) {
+  return ((x - sh_hi) - sh_lo) * scale;
+}
+
 // ---------------------------------------------------------------------------------
 // atb_f32: C[M x L] = A[K x M]^T * B[K x L]        (the dominant kernel)
 //
@@ -329,13 +342,20 @@ __device__ __forceinline__ float f16_scale_for(float m) {
   return ldexpf(1.f, 14 - e);
 }
 
-template <int NB>
+// AFF: A is the RAW field [a_rows x a_cols] (lda); the preprocessing map aff_map(x, shift hi, shift lo, scale) -- the
+// expression apply_kernel writes into the sample-contiguous layout, so both layouts hold the same float32 matrix -- is
+// applied on the fly (the exact power-of-two a_scale folded into the scale), and the feature-contiguous copy of the
+// matrix never exists.  Rows >= a_rows are read from the last row (their B rows are zero), 16-byte column chunks
+// >= a_cols from chunk 0 with scale 0.  aff = {hi[aff_ld], lo[aff_ld], scale[aff_ld]} from aff_pack_kernel.
+template <int NB, bool AFF = false>
 __global__ __launch_bounds__(256, 2) void atb_f16_kernel(const float* __restrict__ A, int64_t lda,
                                                           const float* __restrict__ B, int ldb,
                                                           float* __restrict__ C, int ldc, int64_t M,
                                                           int64_t K, int64_t k_per_split, int col_base,
                                                           float a_scale,
-                                                          const float* __restrict__ b_absmax) {
+                                                          const float* __restrict__ b_absmax,
+                                                          const float* __restrict__ aff = nullptr,
+                                                          int64_t aff_ld = 0, int a_rows = 0, int64_t a_cols = 0) {
   __shared__ __attribute__((aligned(16))) _Float16 Bs[2][2][2][32 * NB][8];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -357,7 +377,15 @@ __global__ __launch_bounds__(256, 2) void atb_f16_kernel(const float* __restrict
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][b][r] = 0.f;
 
-  const float* Ap = A + (kb + lh) * lda + m0 + 4 * li;
+  const bool colok = !AFF || m0 + 4 * li < a_cols;
+  const float* Ap = A + (AFF ? (colok ? m0 + 4 * li : 0) : (kb + lh) * lda + m0 + 4 * li);
+  // {shift hi, shift lo, scale} of this lane's four columns (aff_pack_kernel; scale 0 beyond a_cols)
+  f32x4 shh_ = {0.f, 0.f, 0.f, 0.f}, shl_ = {0.f, 0.f, 0.f, 0.f}, sla_ = {0.f, 0.f, 0.f, 0.f};
+  if (AFF && colok) {
+    shh_ = *reinterpret_cast<const f32x4*>(aff + m0 + 4 * li);
+    shl_ = *reinterpret_cast<const f32x4*>(aff + aff_ld + m0 + 4 * li);
+    sla_ = *reinterpret_cast<const f32x4*>(aff + 2 * aff_ld + m0 + 4 * li) * a_scale;   // exact: a power of two
+  }
   constexpr int BV = 8 * NB;
   const bool b_loader = tid < 16 * BV;
   const int brow = tid / BV, bc4 = tid % BV;
@@ -368,9 +396,23 @@ __global__ __launch_bounds__(256, 2) void atb_f16_kernel(const float* __restrict
 #define EOFX_LOAD_SLAB(areg, chunk)                                                              \
   do {                                                                                           \
     if (b_loader) bn = *reinterpret_cast<const f32x4*>(Bp + (int64_t)(chunk) * ATB_KC * ldb);   \
-    const float* pa_ = Ap + (int64_t)(chunk) * ATB_KC * lda;                                     \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i) areg[i] =                                      \
-        __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(pa_ + (int64_t)(2 * i) * lda)); \
+    if (AFF) {                                                                                   \
+      const int r0_ = (int)kb + (chunk) * ATB_KC + lh;                                           \
+      if ((int)kb + (chunk) * ATB_KC + ATB_KC <= a_rows) {   /* whole slab inside the field */    \
+        const float* pa_ = Ap + (int64_t)r0_ * lda;                                              \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) areg[i] =                                  \
+            __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(pa_ + (int64_t)(2 * i) * lda)); \
+      } else {                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                          \
+          const int r_ = r0_ + 2 * i < a_rows ? r0_ + 2 * i : a_rows - 1;                        \
+          areg[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Ap + (int64_t)r_ * lda)); \
+        }                                                                                        \
+      }                                                                                          \
+    } else {                                                                                     \
+      const float* pa_ = Ap + (int64_t)(chunk) * ATB_KC * lda;                                   \
+      _Pragma("unroll") for (int i = 0; i < 8; ++i) areg[i] =                                    \
+          __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(pa_ + (int64_t)(2 * i) * lda)); \
+    }                                                                                            \
   } while (0)
 #define EOFX_STORE_B(buf)                                                                        \
   do {                                                                                           \
@@ -391,7 +433,8 @@ __global__ __launch_bounds__(256, 2) void atb_f16_kernel(const float* __restrict
         bf_[s][q] = *reinterpret_cast<const f16x8*>(&Bs[buf][s][lh][32 * q + li][0]);            \
     _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                              \
       f32x8 x_;                                                                                  \
-      _Pragma("unroll") for (int t = 0; t < 8; ++t) x_[t] = areg[t][j] * a_scale;                \
+      _Pragma("unroll") for (int t = 0; t < 8; ++t)                                              \
+          x_[t] = AFF ? aff_map(areg[t][j], shh_[j], shl_[j], sla_[j]) : areg[t][j] * a_scale;     \
       f16x8 af_[2];                                                                              \
       split_f16(x_, af_);                                                                        \
       _Pragma("unroll") for (int q = 0; q < NB; ++q) {                                           \
@@ -1078,6 +1121,21 @@ __global__ __launch_bounds__(256) void rowcount_kernel(const float* __restrict__
   if (threadIdx.x == 0) rowcnt[r] = red[0];
 }
 
+// shift / scale (float64, per source column) -> {hi, lo, scale} float triples of the raw view; columns >= p: zeros
+__global__ __launch_bounds__(256) void aff_pack_kernel(const double* __restrict__ shift, const double* __restrict__ scale,
+                                                        int64_t p, int64_t p_pad, float* __restrict__ out) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= p_pad) return;
+  float hi = 0.f, lo = 0.f, sl = 0.f;
+  if (c < p) {
+    aff_split(shift ? shift[c] : 0.0, hi, lo);
+    sl = scale ? (float)scale[c] : 1.f;
+  }
+  out[c] = hi;
+  out[p_pad + c] = lo;
+  out[2 * p_pad + c] = sl;
+}
+
 // grid = (p_pad/64, n_pad/64): 64x64 tile of the compacted matrix, 16 B per lane everywhere:
 // each thread owns 4 adjacent compact columns; 16 threads cover a 256 B row segment.
 // col_map/row_map: compact index -> source index (null = identity).  shift/scale indexed by
@@ -1100,17 +1158,17 @@ __global__ __launch_bounds__(256) void apply_kernel(const float* __restrict__ X,
   const int64_t c0 = (int64_t)blockIdx.x * 64, r0 = (int64_t)blockIdx.y * 64;
   const int64_t cb = c0 + 4 * tq;
   int64_t sc[4];
-  double sh[4], sl[4];
+  float shh[4], shl[4], slf[4];   // shift as a float pair (hi + lo carries the float64 mean), scale in float
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int64_t c = cb + e;
     sc[e] = -1;
-    sh[e] = 0.0;
-    sl[e] = 1.0;
+    shh[e] = shl[e] = 0.f;
+    slf[e] = 1.f;
     if (c < p) {
       sc[e] = col_map ? col_map[c] : c;
-      if (shift) sh[e] = shift[sc[e]];
-      if (scale) sl[e] = scale[sc[e]];
+      if (shift) aff_split(shift[sc[e]], shh[e], shl[e]);
+      if (scale) slf[e] = (float)scale[sc[e]];
     }
   }
   bool bad = false;
@@ -1134,10 +1192,10 @@ __global__ __launch_bounds__(256) void apply_kernel(const float* __restrict__ X,
       for (int e = 0; e < 4; ++e)
         if (sc[e] >= 0) {
           if (x[e] != x[e]) bad = true;
-          v[e] = (float)(((double)x[e] - sh[e]) * sl[e]);
+          v[e] = aff_map(x[e], shh[e], shl[e], slf[e]);
         }
     }
-    *reinterpret_cast<f32x4*>(Xc + r * p_pad + cb) = v;
+    if (Xc) *reinterpret_cast<f32x4*>(Xc + r * p_pad + cb) = v;   // absent in raw mode (eofx_ctx_set_layout)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       T[rr][4 * tq + e] = v[e];

@@ -96,6 +96,7 @@ class ResidentMatrix:
         n, p, npad, ppad = (C.c_int64() for _ in range(4))
         ctx.lib.eofx_mat_shape(handle, C.byref(n), C.byref(p), C.byref(npad), C.byref(ppad))
         self.n, self.p, self.n_pad, self.p_pad = n.value, p.value, npad.value, ppad.value
+        self._keepalive = None     # the device field a raw-mode matrix reads (must outlive it)
 
     @property
     def shape(self):
@@ -123,10 +124,22 @@ class ResidentMatrix:
     def sample_gram(self):
         return self.gram(0)
 
+    def layout(self):
+        """-> (has the feature-contiguous layout, reads the raw field instead): see eofx_ctx_set_layout"""
+        hx, hr = C.c_int(), C.c_int()
+        self.ctx.lib.eofx_mat_layout(self.handle, C.byref(hx), C.byref(hr))
+        return bool(hx.value), bool(hr.value)
+
+    def release_raw(self):
+        """Drop the reference to the raw field (raw mode); the feature-contiguous layout is rebuilt on demand."""
+        raise_for(self.ctx.lib.eofx_mat_release_raw(self.ctx.handle, self.handle), self.ctx.handle)
+        self._keepalive = None
+
     def free(self):
         if getattr(self, "handle", None) and getattr(self.ctx, "handle", None):
             self.ctx.lib.eofx_mat_destroy(self.ctx.handle, self.handle)
         self.handle = None
+        self._keepalive = None
 
     def __del__(self):
         try:
@@ -207,9 +220,11 @@ def from_dense(ctx: Context, X) -> ResidentMatrix:
 
 
 def preprocess(ctx: Context, X, center=True, standardize=False, feature_weights=None,
-               check_nans=True, want_stats=True, build=True):
+               check_nans=True, want_stats=True, build=True, keep_raw=False):
     """Scaler + Sanitizer + total variance on the stacked raw (n, P) field.
-    Returns (ResidentMatrix | None, stats dict)."""
+    Returns (ResidentMatrix | None, stats dict).  keep_raw: raw mode (include/eofx.h, eofx_ctx_set_layout) -- the
+    feature-contiguous layout is not written, the products read the raw field through the Scaler map; a device
+    field must then stay unmodified until `release_raw()` / `free()` (the matrix holds a reference to it)."""
     X = _f32c(X)
     n, P = X.shape
     w = None if feature_weights is None else np.ascontiguousarray(feature_weights, dtype=np.float64)
@@ -222,13 +237,20 @@ def preprocess(ctx: Context, X, center=True, standardize=False, feature_weights=
     n_out, p_out = C.c_int64(), C.c_int64()
     tv = C.c_double()
     h = C.c_void_p()
-    rc = ctx.lib.eofx_preprocess_f32(ctx.handle, ptr(X), n, P, int(center), int(standardize), ptr(w),
-                                     int(check_nans), C.byref(h) if build else None, ptr(mean), ptr(std),
-                                     ptr(vf), ptr(vs), C.byref(n_out), C.byref(p_out), C.byref(tv))
+    ctx.lib.eofx_ctx_set_layout(ctx.handle, int(bool(keep_raw)))
+    try:
+        rc = ctx.lib.eofx_preprocess_f32(ctx.handle, ptr(X), n, P, int(center), int(standardize), ptr(w),
+                                         int(check_nans), C.byref(h) if build else None, ptr(mean), ptr(std),
+                                         ptr(vf), ptr(vs), C.byref(n_out), C.byref(p_out), C.byref(tv))
+    finally:
+        ctx.lib.eofx_ctx_set_layout(ctx.handle, 0)
     raise_for(rc, ctx.handle)
     stats = dict(mean=mean, std=std, valid_feature=vf.astype(bool), valid_sample=vs.astype(bool),
                  n=n_out.value, p=p_out.value, total_variance=tv.value)
-    return (ResidentMatrix(ctx, h) if build else None), stats
+    mat = ResidentMatrix(ctx, h) if build else None
+    if mat is not None and keep_raw and hasattr(X, "data_ptr"):
+        mat._keepalive = X
+    return mat, stats
 
 
 def apply(ctx: Context, X, mean, std, feature_weights, valid_feature, check_nans=True):
