@@ -17,10 +17,11 @@ One JSON line on rank 0; see the task contract for the fields.  Extra objects:
                 launch (n p_local 4 B; HBM-bound split-bf16 kernel) or flops (2 n p_local 60; exact-f32
                 MFMA kernel with --precision f32) / mean launch duration from HIP events on the
                 launch stream.
-  cpu_baseline  the oracle's sklearn-restated randomized_svd (oracle/, "port") timed on the host
-                cores on a bounded sample (C2 shape 5000 x 259200 fp32), same algorithm.
-  parity        size-independent checks at full size + singular values vs the CPU run on the
-                sample.
+  cpu_baseline  the oracle's sklearn-restated randomized_svd (oracle/, "port") timed on the host cores on a
+                bounded sample (the workload's n and k on half of its grid, fp32); "f64": the same kernel in
+                float64 and the whole oracle fit on the config-2 shape (what xeofs itself computes in).
+  parity        size-independent checks at full size + singular values of both samples vs the CPU runs;
+                the float64 comparison is a gate: above 1e-5 the run exits non-zero.
 """
 
 from __future__ import annotations
@@ -130,9 +131,8 @@ def main():
                     help="write both layouts of the preprocessed matrix (round-1 behaviour) instead of streaming the raw "
                          "field through the Scaler map in the X^T Z passes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sample-parity", action="store_true",
-                    help="also decompose the CPU-baseline sample on the GPU and compare singular values "
-                         "(adds smaller launches of the dominant kernel; tests/test_gpu_parity.py covers it)")
+    ap.add_argument("--no-f64-baseline", action="store_true",
+                    help="skip the float64 CPU leg (config-2 shape: kernel level + whole oracle fit) and its 1e-5 parity gate")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -305,8 +305,16 @@ def main():
         "alg_TFLOPs": round(achieved_tflops, 2),
     })
 
-    # ---- CPU baseline + parity on a bounded sample (rank 0, N=1 only) -------------------------
+    # ---- CPU baseline + parity gate on bounded samples (rank 0, N=1 only) ---------------------
+    # After the timed region and after profile_read, so the launch statistics above are those of the workload only.
+    #   sample A: the workload's n and k on half of its grid, float32, kernel level (oracle randomized_svd) -> `value`
+    #   sample B: BASELINE config-2 shape 5000 x (360 x 720): the reference promotes to float64
+    #             (xeofs/utils/xarray_utils.py:78-100), so this is what xeofs itself would run: float64 kernel level and
+    #             the whole oracle fit (Scaler + Sanitizer + randomized SVD + sign rule + scores).  The GPU decomposes the
+    #             same field and its singular values must match the float64 oracle to 1e-5 (the gate
+    #             "beside every timing"); the run FAILS otherwise.
     cpu_baseline = None
+    gate_failed = None
     if world == 1 and not args.no_cpu_baseline:
         from oracle import eof_oracle as orc   # checker / baseline only
 
@@ -316,16 +324,16 @@ def main():
         ns, nlat_s, nlon_s, ks = 10000, 720, 720, 50      # the workload's n and k on half of its grid: 10-15 s of CPU work
         Xs = make_field(ns, nlat_s, nlon_s, 0, nlat_s * nlon_s, device)
         mat_s, _ = engine.preprocess(ctx, Xs, want_stats=False)
-        sg = None
-        if args.sample_parity:
-            Ug, sg, Vg = engine.rsvd(ctx, mat_s, ks, N_OVERSAMPLES, "auto", random_state=5)
+        Ug, sg, Vg = engine.rsvd(ctx, mat_s, ks, N_OVERSAMPLES, "auto", random_state=5)
         Xc = mat_s.download()           # the centred float32 matrix the GPU decomposed
         mat_s.free()
-        del Xs
+        del Xs, Ug, Vg
         t0 = time.perf_counter()
         Uc, sc, Vtc = orc.randomized_svd(Xc, ks, random_state=5)
         t_cpu = time.perf_counter() - t0
+        del Xc, Uc, Vtc
         bytes_s = (2 * sharded.rsvd_auto_iters(ks, ns, nlat_s * nlon_s) + 2) * ns * nlat_s * nlon_s * 4.0
+        parity["sample_sv_relerr_vs_cpu_f32_max"] = float(np.max(np.abs(sg - sc) / sc))
         cpu_baseline = {
             "value": round(bytes_s / t_cpu / 1e9, 3), "unit": "GB/s", "cores": blas_threads(),
             "kind": "port",
@@ -333,8 +341,35 @@ def main():
                       f"n and k on half of its grid, {t_cpu:.2f} s wall, {ks / t_cpu:.2f} modes/s",
             "host_cpus": os.cpu_count(),
         }
-        if sg is not None:
-            parity["sample_sv_relerr_vs_cpu_max"] = float(np.max(np.abs(sg - sc) / sc))
+        if not args.no_f64_baseline:
+            nb, nlat_b, nlon_b, kb = 5000, 360, 720, 50
+            Xb = make_field(nb, nlat_b, nlon_b, 0, nlat_b * nlon_b, device)
+            mat_b, _ = engine.preprocess(ctx, Xb, want_stats=False, keep_raw=not args.two_layouts)
+            Ub, sb, Vb = engine.rsvd(ctx, mat_b, kb, N_OVERSAMPLES, "auto", random_state=5)
+            mat_b.free()
+            Xb64 = Xb.cpu().numpy().astype(np.float64)
+            del Xb, Ub, Vb
+            t0 = time.perf_counter()
+            ref = orc.eof_fit(Xb64, kb, random_state=5)                    # the reference's whole fit, float64
+            t_fit = time.perf_counter() - t0
+            Xc64 = Xb64 - Xb64.mean(axis=0)
+            del Xb64
+            t0 = time.perf_counter()
+            orc.randomized_svd(Xc64, kb, random_state=5)
+            t_k64 = time.perf_counter() - t0
+            del Xc64
+            bytes_b = (2 * sharded.rsvd_auto_iters(kb, nb, nlat_b * nlon_b) + 2) * nb * nlat_b * nlon_b
+            rel = float(np.max(np.abs(sb - ref["norms"]) / ref["norms"]))
+            parity["sample_sv_relerr_vs_cpu_f64_max"] = rel
+            parity["sample_sv_gate"] = 1e-5
+            cpu_baseline["f64"] = {
+                "sample": f"config-2 shape {nb}x({nlat_b}x{nlon_b}), k={kb}, float64 (what xeofs runs: it promotes the field)",
+                "kernel_GBps": round(bytes_b * 8.0 / t_k64 / 1e9, 3), "kernel_GBps_f32_equiv": round(bytes_b * 4.0 / t_k64 / 1e9, 3),
+                "kernel_s": round(t_k64, 2), "fit_s": round(t_fit, 2), "fit_modes_per_s": round(kb / t_fit, 3),
+                "fit": "oracle eof_fit: Scaler + Sanitizer + randomized_svd + sign rule + scores (xeofs/single/eof.py:85-118)",
+            }
+            if not (rel <= 1e-5):
+                gate_failed = f"singular values of the config-2 sample differ from the float64 oracle by {rel:.3e} > 1e-5"
 
     if rank == 0:
         line = {
@@ -360,6 +395,8 @@ def main():
     if world > 1 or args.force_sharded:
         dist.barrier()
         dist.destroy_process_group()
+    if gate_failed:
+        raise SystemExit("bench.py: PARITY GATE FAILED -- " + gate_failed)
 
 
 if __name__ == "__main__":

@@ -242,3 +242,43 @@ def test_hilbert_complex_properties_at_scale(ctx):
     assert np.linalg.norm(ZV - Us) / np.linalg.norm(Us) < 2e-5
     A.free(); B.free()
     ctx.trim()
+
+
+def test_config5_hilbert_complex_full_size(ctx):
+    """BASELINE config 5 at its own size: 8000 x (720 x 1440), Hilbert transform with padding='exp' (decay 0.2), complex
+    randomized SVD with n_modes = 20 on ONE GPU.  Size-independent properties: the imaginary part of sampled features is
+    the oracle's Hilbert transform of their (centred) real part, U and V are orthonormal, (A + iB) V = U diag(s), the
+    spectrum is sorted, and the fit is bitwise reproducible.  Single columns are fetched with one-hot projections
+    (nothing of the 33 GB parts crosses PCIe)."""
+    import torch
+
+    from xeofs_amd import engine
+    from xeofs_amd.complex_svd import complex_rsvd
+
+    n, nlat, nlon, k = 8000, 720, 1440, 20
+    p = nlat * nlon
+    X = _device_field(n, nlat, nlon)
+    A, st = engine.preprocess(ctx, X, want_stats=False)
+    del X
+    torch.cuda.empty_cache()
+    B, _ = engine.hilbert(ctx, A, "exp", 0.2)
+    cols = np.array([0, 1, 4097, p // 2, p - 1])
+    E = np.zeros((p, len(cols)), np.float32)
+    E[cols, np.arange(len(cols))] = 1.0
+    a = engine.project(ctx, A, E).astype(np.float64)
+    b = engine.project(ctx, B, E).astype(np.float64)
+    ref = orc.hilbert_transform(a, padding="exp", decay_factor=0.2)            # per-feature operation
+    assert np.allclose(b, ref.imag, atol=2e-5 * np.abs(ref.imag).max())
+    U, s, V = complex_rsvd(ctx, A, B, k, random_state=5)
+    assert np.all(np.diff(s) <= 0) and s[-1] > 0
+    Uc, Vc = U.astype(np.complex128), V.astype(np.complex128)
+    assert np.abs(Uc.conj().T @ Uc - np.eye(k)).max() < 1e-5
+    assert np.abs(Vc.conj().T @ Vc - np.eye(k)).max() < 1e-5
+    Vr, Vi = np.ascontiguousarray(V.real), np.ascontiguousarray(V.imag)
+    ZV = (engine.project(ctx, A, Vr) - engine.project(ctx, B, Vi)) + 1j * (engine.project(ctx, A, Vi) + engine.project(ctx, B, Vr))
+    Us = Uc * s.astype(np.float64)
+    assert np.linalg.norm(ZV - Us) / np.linalg.norm(Us) < 2e-5
+    U2, s2, V2 = complex_rsvd(ctx, A, B, k, random_state=5)
+    assert np.array_equal(s, s2) and np.array_equal(V, V2)
+    A.free(); B.free()
+    ctx.trim()
