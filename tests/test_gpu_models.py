@@ -216,6 +216,35 @@ def test_eof_dask_branch_policy(ctx):
     assert np.allclose(d.s_, s[:3], rtol=2e-5)
 
 
+def test_compute_false_defers_the_fit(ctx):
+    """Row R10, `compute=False` (base_model.py:57-82, base_model_single_set.py:157-159): with a chunked input the fit is
+    deferred -- `fit` returns without touching the data, `compute()` (or the first read of a fitted quantity, like
+    touching a lazy DataArray in the reference) runs it; results equal the eager fit bitwise.  An in-memory input is
+    fitted at once whatever `compute` says (the reference's numpy branch has nothing lazy)."""
+    import xeofs_amd as xe
+
+    rng = np.random.default_rng(1)
+    vals = ((rng.standard_normal((300, 7)) * (9.0 * 0.65 ** np.arange(7))) @ rng.standard_normal((7, 40 * 30))
+            + 0.05 * rng.standard_normal((300, 1200))).reshape(300, 40, 30).astype(np.float32)
+    lazy = xe.DataArray(vals, dims=("time", "lat", "lon"), chunks=((100, 100, 100), (40,), (30,)))
+    eager = xe.single.EOF(n_modes=5, random_state=3).fit(lazy, "time")
+    assert not eager.is_deferred
+    m = xe.single.EOF(n_modes=5, random_state=3, compute=False).fit(lazy, "time")
+    assert m.is_deferred and m._data == {}
+    assert m.compute() is m and not m.is_deferred
+    assert np.array_equal(m.singular_values().values, eager.singular_values().values)
+    m2 = xe.single.EOF(n_modes=5, random_state=3, compute=False).fit(lazy, "time")
+    assert m2.is_deferred
+    assert np.array_equal(m2.components().values, eager.components().values) and not m2.is_deferred   # first read computes
+    m3 = xe.single.EOF(n_modes=5, random_state=3, compute=False).fit(xe.DataArray(vals, dims=("time", "lat", "lon")), "time")
+    assert not m3.is_deferred
+    lz2 = xe.DataArray(vals[:, :20], dims=("time", "lat", "lon"), chunks=((300,), (20,), (30,)))
+    c = xe.cross.MCA(n_modes=3, random_state=1, compute=False).fit(lazy, lz2, "time")
+    assert c.is_deferred
+    ce = xe.cross.MCA(n_modes=3, random_state=1).fit(lazy, lz2, "time")
+    assert np.allclose(c.singular_values().values, ce.singular_values().values, rtol=1e-6) and not c.is_deferred
+
+
 def test_dataset_in_dataset_out(ctx):
     """Dataset in -> Dataset out with the same data_vars (preprocessing/stacker.py:203-206,
     271-275); the README quickstart (config 1) feeds a Dataset.  Two variables on different grids are

@@ -21,6 +21,7 @@ import warnings
 import numpy as np
 
 from .. import __version__, engine, labelled
+from .._deferred import Deferred
 from ..linalg.decomposer import MAX_SKETCH, sanity_check_n_modes
 from ..pca import ResidentPCA
 from ..preprocessing import Preprocessor
@@ -144,7 +145,7 @@ class _Side:
         self.work = None
 
 
-class CPCCA:
+class CPCCA(Deferred):
     _model_name = "Continuum Power CCA"
 
     def __init__(self, n_modes: int = 2, alpha=0.2, standardize=False, use_coslat=False, use_pca=True,
@@ -178,6 +179,11 @@ class CPCCA:
 
     # ------------------------------------------------------------------ fit
     def fit(self, X, Y, dim, weights_X=None, weights_Y=None):
+        if (labelled.is_lazy(X) or labelled.is_lazy(Y)) and not self._params["compute"]:   # base_model_cross_set.py: defer
+            return self._defer(lambda: self._fit_now(X, Y, dim, weights_X, weights_Y))
+        return self._fit_now(X, Y, dim, weights_X, weights_Y)
+
+    def _fit_now(self, X, Y, dim, weights_X=None, weights_Y=None):
         self.ctx = self.ctx or engine.default_context()
         self.preprocessor1.ctx = self.preprocessor2.ctx = self.ctx
         mx = self.preprocessor1.fit_transform(X, dim, weights_X)

@@ -12,11 +12,12 @@ import datetime
 import numpy as np
 
 from .. import __version__, engine, labelled
+from .._deferred import Deferred
 from ..linalg.decomposer import Decomposer
 from ..preprocessing import Preprocessor
 
 
-class EOF:
+class EOF(Deferred):
     def __init__(self, n_modes: int = 2, center: bool = True, standardize: bool = False, use_coslat: bool = False,
                  check_nans=True, sample_name: str = "sample", feature_name: str = "feature", compute: bool = True,
                  random_state: int | None = None, solver: str = "auto", solver_kwargs: dict = {}, **kwargs):
@@ -41,6 +42,11 @@ class EOF:
 
     # ------------------------------------------------------------------ fit
     def fit(self, X, dim, weights=None):
+        if labelled.is_lazy(X) and not self._params["compute"]:     # base_model_single_set.py:157-159: defer
+            return self._defer(lambda: self._fit_now(X, dim, weights))
+        return self._fit_now(X, dim, weights)
+
+    def _fit_now(self, X, dim, weights=None):
         self.ctx = self.ctx or engine.default_context()
         self.preprocessor.ctx = self.ctx
         self._decomposer_kwargs["lazy_input"] = labelled.is_lazy(X)
@@ -190,7 +196,7 @@ class ComplexEOF(EOF):
         tv = self.preprocessor.total_variance + self.preprocessor_imag.total_variance
         return A, B, tv
 
-    def fit(self, X, dim, weights=None):
+    def _fit_now(self, X, dim, weights=None):
         self._reject_lazy(X)
         self.ctx = self.ctx or engine.default_context()
         self.preprocessor.ctx = self.ctx
@@ -274,7 +280,7 @@ class HilbertEOF(ComplexEOF):
         super().__init__(*args, **kwargs)
         self.attrs.update({"model": "Hilbert EOF analysis"})
 
-    def fit(self, X, dim, weights=None):
+    def _fit_now(self, X, dim, weights=None):
         self._reject_lazy(X)
         self.ctx = self.ctx or engine.default_context()
         self.preprocessor.ctx = self.ctx
