@@ -239,6 +239,18 @@ int eofx_resample_f32(eofx_ctx *ctx, const eofx_mat *src, const int64_t *rows, i
  * (preprocessing/pca.py:94-123): eigenvectors of the small-side Gram matrix span the PCA subspace.   */
 int eofx_mat_gram_f32(eofx_ctx *ctx, const eofx_mat *m, int side, float *G);
 int eofx_vec_dot_f64(eofx_ctx *ctx, const float *a, const float *b, int64_t count, double *out);
+/* ---- complex randomized SVD (the decomposer's complex branch) -----------------------------------------------
+ * Z = A + iB (two resident real matrices of equal shape) ~ U diag(s) V^H.  Replaces
+ * scipy.sparse.linalg.svds(X, k, solver="lobpcg") at xeofs/linalg/decomposer.py:149-160 (+ the sign rule,
+ * xarray_utils.py:273-301, with numpy's lexicographic complex max / min).  A pass over the data is one launch of the
+ * streaming kernel in its two-matrix form; the l x l Hermitian factorisations run on the host in float64.
+ * omega: host [min(n,p) x (k + n_oversamples)] REAL start matrix (the Gaussian numpy's RandomState draws; the
+ * identity when k + n_oversamples >= min(n, p)); n_iter < 0 = scikit-learn's "auto".  U [n x k], V [p x k]:
+ * complex64, row-major, interleaved (re, im), host|device; s [k] float32.  k + n_oversamples <= 64
+ * (EOFX_ERR_ARG beyond); vectors are defined up to a unit phase per mode, as in the reference.                   */
+int eofx_rsvd_c64(eofx_ctx *ctx, const eofx_mat *A, const eofx_mat *B, int k, int n_oversamples, int n_iter,
+                  const float *omega, int flip_signs, float *U, float *s, float *V);
+
 /* Complex panels are real panels [Re | Im] (Re in columns [0, L/2), Im in [L/2, L)).
  * With P1 = op(A) W and P2 = op(B) W for a complex matrix Z = A + iB (A, B real resident):
  *   conj_left = 1:  out = Z^H W :  out.re = P1.re + P2.im, out.im = P1.im - P2.re

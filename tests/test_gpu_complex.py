@@ -152,3 +152,66 @@ def test_complex_inverse_transform_roundtrip(ctx):
     assert np.abs(rh.values.reshape(n, -1) - wanth).max() <= 2e-5 * np.abs(wanth).max()
     with pytest.raises(NotImplementedError, match="real models only"):
         xe.single.EOFRotator(n_modes=2).fit(m)
+
+
+@pytest.mark.parametrize("n,p,k,prec", [(300, 1200, 6, "f16x3"), (900, 250, 4, "f16x3"), (700, 3000, 40, "f16x3"),
+                                        (2100, 600, 33, "f16x3"), (300, 1200, 6, "f32"), (64, 5000, 30, "f16x3")])
+def test_engine_complex_rsvd_vs_exact(ctx, n, p, k, prec):
+    """`eofx_rsvd_c64` (the complex decomposer entry: one two-matrix launch per pass, Hermitian Cholesky-QR on the host)
+    against the exact complex SVD: singular values 1e-5, vectors up to a unit phase, reconstruction, orthonormality,
+    the reference's sign rule; sketches up to 64 complex columns (k = 40 with 10 oversamples = 50); the exact-f32
+    passes go through two launches + recombination; bitwise reproducible."""
+    from xeofs_amd import engine
+
+    rng = np.random.default_rng(5)
+    r = max(6, k)
+    amp = 8.0 * 0.85 ** np.arange(r)
+    L = (rng.standard_normal((n, r)) + 1j * rng.standard_normal((n, r))) * amp
+    R = rng.standard_normal((r, p)) + 1j * rng.standard_normal((r, p))
+    Z = L @ R / np.sqrt(r) + 0.02 * (rng.standard_normal((n, p)) + 1j * rng.standard_normal((n, p)))
+    Z = Z - Z.mean(axis=0)
+    A = engine.from_dense(ctx, np.ascontiguousarray(Z.real, dtype=np.float32))
+    B = engine.from_dense(ctx, np.ascontiguousarray(Z.imag, dtype=np.float32))
+    ctx.set_precision(prec, prec)
+    try:
+        U, s, V = engine.rsvd_c64(ctx, A, B, k, random_state=3)
+        U2, s2, V2 = engine.rsvd_c64(ctx, A, B, k, random_state=3)
+    finally:
+        ctx.set_precision("f16x3", "f16x3")
+    assert np.array_equal(s, s2) and np.array_equal(U, U2) and np.array_equal(V, V2)
+    Ue, se, Vhe = np.linalg.svd(Z, full_matrices=False)
+    assert np.all(np.abs(s - se[:k]) <= 1e-5 * se[:k] + 2e-6 * se[0]), (s, se[:k])
+    gaps = np.minimum(np.abs(np.diff(se[:k + 1])), np.r_[np.inf, np.abs(np.diff(se[:k]))]) / se[:k]
+    for j in range(k):
+        if gaps[j] > 1e-2:
+            assert abs(np.vdot(Vhe[j].conj(), V[:, j])) >= 1 - 1e-5, j      # V = conj(VT).T
+            assert abs(np.vdot(Ue[:, j], U[:, j])) >= 1 - 1e-5, j
+    rec = (U.astype(np.complex128) * s) @ V.astype(np.complex128).conj().T
+    best = (Ue[:, :k] * se[:k]) @ Vhe[:k]
+    assert np.linalg.norm(Z - rec) <= np.linalg.norm(Z - best) * (1 + 1e-4)
+    assert np.abs(U.conj().T @ U - np.eye(k)).max() < 2e-5 and np.abs(V.conj().T @ V - np.eye(k)).max() < 2e-5
+    assert (orc.deterministic_sign_multiplier(V.conj().T) == 1).all()
+    A.free(); B.free()
+
+
+def test_complex_eof_standardize(ctx):
+    """`ComplexEOF(standardize=True)` -- the reference's own docstring example (xeofs/single/eof.py:298): the Scaler
+    divides the complex field by numpy's (real) std of a complex array, sqrt(var Re + var Im) (scaler.py:105-108)."""
+    import xeofs_amd as xe
+
+    rng = np.random.default_rng(3)
+    n, p, k = 200, 90, 3
+    amp = np.array([6.0, 3.0, 1.5])
+    Z = ((rng.standard_normal((n, 3)) + 1j * rng.standard_normal((n, 3))) * amp) @ (
+        rng.standard_normal((3, p)) + 1j * rng.standard_normal((3, p)))
+    Z = Z * np.linspace(0.5, 4.0, p) + 0.1 * (rng.standard_normal((n, p)) + 1j * rng.standard_normal((n, p))) + (2 - 1j)
+    da = xe.DataArray(Z, dims=("time", "x"))
+    m = xe.single.ComplexEOF(n_modes=k, standardize=True, random_state=0).fit(da, "time")
+    Zs = (Z - Z.mean(axis=0)) / Z.std(axis=0)
+    se = np.linalg.svd(Zs, compute_uv=False)[:k]
+    assert np.allclose(m.singular_values().values, se, rtol=2e-5)
+    assert abs(m.data["total_variance"] - (np.abs(Zs) ** 2).sum() / (n - 1)) <= 1e-5 * p
+    rec = m.inverse_transform(m.scores())             # back in the original units: un-scaled with the same deviation
+    Ue, see, Vhe = np.linalg.svd(Zs, full_matrices=False)
+    best = ((Ue[:, :k] * see[:k]) @ Vhe[:k]) * Z.std(axis=0) + Z.mean(axis=0)
+    assert np.abs(rec.values - best).max() <= 5e-4 * np.abs(Z).max()

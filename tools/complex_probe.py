@@ -16,13 +16,18 @@ for rep in range(2):
     torch.cuda.synchronize(); t1 = time.perf_counter()
     B, _ = engine.hilbert(ctx, A, "exp", 0.2)
     torch.cuda.synchronize(); t2 = time.perf_counter()
-    ctx.profile(True)
-    U, s, V = complex_rsvd(ctx, A, B, k, random_state=5)
-    torch.cuda.synchronize(); t3 = time.perf_counter()
-    pr = ctx.profile_read(); ctx.profile(False)
     p = nlat * nlon
     passes = 16
-    print(f"rep{rep} n={n} p={p} k={k}: preprocess {1e3*(t1-t0):.1f} ms  hilbert {1e3*(t2-t1):.1f} ms  "
-          f"complex rsvd {1e3*(t3-t2):.1f} ms  (atb launches {pr['launches']}, {pr['ms']:.1f} ms in atb)  "
-          f"alg complex64 GB/s {passes*n*p*8.0/(t3-t2)/1e9:.0f}  s[:3]={s[:3]}")
+    for name, fn in (("engine eofx_rsvd_c64", lambda: engine.rsvd_c64(ctx, A, B, k, random_state=5)),
+                     ("panel-level (python) driver", lambda: complex_rsvd(ctx, A, B, k, random_state=5))):
+        if name.startswith("panel") and k + 10 > 32:
+            continue
+        torch.cuda.synchronize(); t2b = time.perf_counter()
+        ctx.profile(True)
+        U, s, V = fn()
+        torch.cuda.synchronize(); t3 = time.perf_counter()
+        pr = ctx.profile_read(); ctx.profile(False)
+        print(f"rep{rep} n={n} p={p} k={k} [{name}]: preprocess {1e3*(t1-t0):.1f} ms  hilbert {1e3*(t2-t1):.1f} ms  "
+              f"complex rsvd {1e3*(t3-t2b):.1f} ms  (atb launches {pr['launches']}, {pr['ms']:.1f} ms in atb)  "
+              f"alg complex64 GB/s {passes*n*p*8.0/(t3-t2b)/1e9:.0f}  s[:3]={s[:3]}")
     A.free(); B.free()

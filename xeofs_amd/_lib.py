@@ -58,6 +58,7 @@ SIGNATURES = {
     "eofx_hilbert_f32": (_int, [_vp, _vp, _int, C.c_double, C.POINTER(_vp), C.POINTER(_vp)]),
     "eofx_mat_sumsq_f64": (_int, [_vp, _vp, _pd]),
     "eofx_panel_fused_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _int]),
+    "eofx_rsvd_c64": (_int, [_vp, _vp, _vp, _int, _int, _int, _vp, _int, _vp, _vp, _vp]),
     "eofx_ctx_set_layout": (_int, [_vp, _int]),
     "eofx_mat_release_raw": (_int, [_vp, _vp]),
     "eofx_mat_layout": (_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),

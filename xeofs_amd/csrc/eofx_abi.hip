@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <complex>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -402,13 +403,17 @@ template <int NB>
 static void launch_atb_variant(int prec, dim3 grid, hipStream_t st, const float* A, int64_t lda,
                                const float* B, int ldb, float* out, int L, int64_t M, int64_t K,
                                int64_t kps, int col_base, float a_scale, const float* b_absmax,
-                               const AffView* aff = nullptr) {
-  if (prec == EOFX_PREC_F16X3 && aff)
+                               const AffView* aff = nullptr, const float* A2 = nullptr, const float* B2 = nullptr,
+                               int s_half = 0) {
+  if (prec == EOFX_PREC_F16X3 && A2)
+    hipLaunchKernelGGL(atb_f16_kernel<NB>, grid, dim3(256), 0, st, A, lda, B, ldb, out, L, M, K, kps, col_base,
+                       a_scale, b_absmax, (const float*)nullptr, (int64_t)0, 0, (int64_t)0, A2, B2, s_half);
+  else if (prec == EOFX_PREC_F16X3 && aff)
     hipLaunchKernelGGL((atb_f16_kernel<NB, true>), grid, dim3(256), 0, st, A, lda, B, ldb, out, L, M, K, kps, col_base,
-                       a_scale, b_absmax, aff->aff, aff->ld, aff->rows, aff->cols);
+                       a_scale, b_absmax, aff->aff, aff->ld, aff->rows, aff->cols, (const float*)nullptr, (const float*)nullptr, 0);
   else if (prec == EOFX_PREC_F16X3)
     hipLaunchKernelGGL(atb_f16_kernel<NB>, grid, dim3(256), 0, st, A, lda, B, ldb, out, L, M, K, kps, col_base,
-                       a_scale, b_absmax, (const float*)nullptr, (int64_t)0, 0, (int64_t)0);
+                       a_scale, b_absmax, (const float*)nullptr, (int64_t)0, 0, (int64_t)0, (const float*)nullptr, (const float*)nullptr, 0);
   else if (prec == EOFX_PREC_BF16X3)
     hipLaunchKernelGGL((atb_bf16_kernel<NB, 2>), grid, dim3(256), 0, st, A, lda, B, ldb, out, L, M, K, kps, col_base);
   else if (prec == EOFX_PREC_BF16X6)
@@ -421,8 +426,10 @@ static void launch_atb_variant(int prec, dim3 grid, hipStream_t st, const float*
 // Both are only used by the fp16-split variant.
 static int launch_atb(eofx_ctx* ctx, const float* A, int64_t lda, int64_t K, int64_t M,
                       const float* B, int ldb, int L, float* C, int prec = EOFX_PREC_F32,
-                      float a_absmax = 0.f, const float* b_absmax_dev = nullptr, const AffView* aff = nullptr) {
+                      float a_absmax = 0.f, const float* b_absmax_dev = nullptr, const AffView* aff = nullptr,
+                      const float* A2 = nullptr, const float* B2 = nullptr) {
   if (aff && prec != EOFX_PREC_F16X3) return set_err(ctx, EOFX_ERR_ARG, "atb: the raw view needs the f16x3 kernel");
+  if (A2 && (prec != EOFX_PREC_F16X3 || aff || !B2)) return set_err(ctx, EOFX_ERR_ARG, "atb: the two-matrix form needs the f16x3 kernel");
   if (M % ATB_BM || K % ATB_KG || L % 32 || L <= 0)
     return set_err(ctx, EOFX_ERR_ARG, "atb: bad geometry M=%lld K=%lld L=%d", (long long)M,
                    (long long)K, L);
@@ -433,8 +440,11 @@ static int launch_atb(eofx_ctx* ctx, const float* A, int64_t lda, int64_t K, int
   int64_t best_kps = plan.kps;
   ArenaScope scope(ctx);
   float* out = C;
+  const int s_half = best_s;            // two-matrix form: splits [0, s_half) stream A, [s_half, 2 s_half) stream A2
+  if (A2) best_s *= 2;
   if (best_s > 1) {
     out = arena_alloc<float>(ctx, (size_t)best_s * M * L);
+    if (!out && A2) return set_err(ctx, EOFX_ERR_NOMEM, "arena exhausted (two-matrix partials)");
     if (!out) {  // no room for partials: fall back to a single split (still correct)
       best_s = 1;
       best_kps = K;
@@ -467,19 +477,19 @@ static int launch_atb(eofx_ctx* ctx, const float* A, int64_t lda, int64_t K, int
   }
   if (nfull > 0) {
     dim3 grid(bx, best_s, nfull);
-    launch_atb_variant<2>(prec, grid, ctx->stream, A, lda, B, ldb, out, L, M, K, best_kps, 0, a_scale, b_absmax_dev, aff);
+    launch_atb_variant<2>(prec, grid, ctx->stream, A, lda, B, ldb, out, L, M, K, best_kps, 0, a_scale, b_absmax_dev, aff, A2, B2, s_half);
     KCHK();
   }
   if (rem) {
     dim3 grid(bx, best_s, 1);
-    launch_atb_variant<1>(prec, grid, ctx->stream, A, lda, B, ldb, out, L, M, K, best_kps, nfull * 64, a_scale, b_absmax_dev, aff);
+    launch_atb_variant<1>(prec, grid, ctx->stream, A, lda, B, ldb, out, L, M, K, best_kps, nfull * 64, a_scale, b_absmax_dev, aff, A2, B2, s_half);
     KCHK();
   }
   if (ctx->profile) {
     HIPCHK(hipEventRecord(ev1, ctx->stream));
     ctx->prof_events.emplace_back(ev0, ev1);
-    ctx->prof_flops += 2.0 * (double)K * (double)M * (double)L;
-    ctx->prof_bytes += (double)K * (double)M * 4.0 * (nfull + (rem ? 1 : 0));
+    ctx->prof_flops += 2.0 * (double)K * (double)M * (double)L * (A2 ? 2 : 1);
+    ctx->prof_bytes += (double)K * (double)M * 4.0 * (nfull + (rem ? 1 : 0)) * (A2 ? 2 : 1);
   }
   if (best_s > 1) {
     const int64_t count4 = M * L / 4;
@@ -2026,6 +2036,315 @@ extern "C" int eofx_panel_colargminmax_f32(eofx_ctx* ctx, const float* P, int64_
   hipLaunchKernelGGL(colargminmax_final_kernel, dim3((L + 63) / 64), dim3(64), 0, ctx->stream, pmx, imx, pmn, imn,
                      nparts, L, amax, amin);
   KCHK();
+  return EOFX_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// complex randomized SVD (rows R9 of SURVEY.md §8a): Z = A + iB as two resident real matrices.
+// Replaces scipy.sparse.linalg.svds(lobpcg) at xeofs/linalg/decomposer.py:149-160.  A complex panel of h columns is
+// a real panel [Re | Im] of 2 h columns; a pass over the data is ONE launch of the streaming kernel in its two-matrix
+// form (Z^H W = A^T [Wr|Wi] + B^T [Wi|-Wr],  Z Y = A [Yr|Yi] + B [-Yi|Yr]); orthonormalisation is a complex
+// Cholesky-QR on the Hermitian Gram matrix assembled from one real float64 Gram of the panel (host, l <= 64).
+// ------------------------------------------------------------------------------------
+namespace {
+typedef std::complex<double> zdouble;
+
+// Hermitian l x l Gram P^H P from the real LP x LP Gram of [Pr | Pi] (h = LP / 2)
+static void hermitian_from_real(const std::vector<double>& G, int LP, int l, std::vector<zdouble>& H) {
+  const int h = LP / 2;
+  H.assign((size_t)l * l, zdouble(0.0, 0.0));
+  for (int i = 0; i < l; ++i)
+    for (int j = 0; j < l; ++j) {
+      const double rr = G[(size_t)i * LP + j], ii = G[(size_t)(h + i) * LP + h + j];
+      const double ri = G[(size_t)i * LP + h + j], ir = G[(size_t)(h + i) * LP + j];
+      H[(size_t)i * l + j] = zdouble(rr + ii, ri - ir);
+    }
+  for (int i = 0; i < l; ++i)
+    for (int j = i; j < l; ++j) {
+      const zdouble v = 0.5 * (H[(size_t)i * l + j] + std::conj(H[(size_t)j * l + i]));
+      H[(size_t)i * l + j] = v;
+      H[(size_t)j * l + i] = std::conj(v);
+    }
+}
+// T (l x l upper triangular) with (P T)^H (P T) = I for H = P^H P; dependent columns -> zero columns (same rule as the
+// real driver's chol_rinv: pivot below tol * original diagonal)
+static void host_zchol_rinv(const std::vector<zdouble>& Hin, int l, std::vector<zdouble>& T, double tol) {
+  std::vector<zdouble> A(Hin);
+  std::vector<double> d0(l);
+  std::vector<char> dead(l, 0);
+  for (int j = 0; j < l; ++j) d0[j] = Hin[(size_t)j * l + j].real();
+  for (int j = 0; j < l; ++j) {        // H = R^H R, R upper triangular, stored in the upper part of A
+    const double d = A[(size_t)j * l + j].real();
+    const bool dj = !(d > tol * d0[j]) || !(d0[j] > 0.0);
+    dead[j] = dj;
+    const double rjj = dj ? 1.0 : std::sqrt(d);
+    const double piv = dj ? 0.0 : 1.0 / rjj;
+    A[(size_t)j * l + j] = rjj;
+    for (int c = j + 1; c < l; ++c) A[(size_t)j * l + c] *= piv;
+    for (int r = j + 1; r < l; ++r) {
+      const zdouble f = std::conj(A[(size_t)j * l + r]);
+      if (f == zdouble(0.0, 0.0)) continue;
+      for (int c = r; c < l; ++c) A[(size_t)r * l + c] -= f * A[(size_t)j * l + c];
+    }
+  }
+  T.assign((size_t)l * l, zdouble(0.0, 0.0));
+  for (int c = 0; c < l; ++c) {        // T = R^-1 column by column
+    if (dead[c]) continue;
+    T[(size_t)c * l + c] = 1.0 / A[(size_t)c * l + c];
+    for (int r = c - 1; r >= 0; --r) {
+      zdouble sum(0.0, 0.0);
+      for (int t = r + 1; t <= c; ++t) sum += A[(size_t)r * l + t] * T[(size_t)t * l + c];
+      T[(size_t)r * l + c] = -sum / A[(size_t)r * l + r];
+    }
+  }
+}
+// Hermitian eigen-decomposition through the real symmetric embedding [[Hr, -Hi], [Hi, Hr]] (every eigenvalue twice,
+// eigenvectors (x; y) <-> x + i y) and the real tridiagonal QL solver; complex Gram-Schmidt inside clusters removes the
+// duplicates.  -> w descending, V columns (row-major l x l).
+static int host_heigh(const std::vector<zdouble>& H, int l, std::vector<double>& w, std::vector<zdouble>& V) {
+  const int m = 2 * l;
+  std::vector<double> E((size_t)m * m), ew(m), ev((size_t)m * m);
+  for (int i = 0; i < l; ++i)
+    for (int j = 0; j < l; ++j) {
+      const zdouble v = H[(size_t)i * l + j];
+      E[(size_t)i * m + j] = v.real();
+      E[(size_t)(l + i) * m + l + j] = v.real();
+      E[(size_t)i * m + l + j] = -v.imag();
+      E[(size_t)(l + i) * m + j] = v.imag();
+    }
+  const int rc = eofx_host_eigh_f64(E.data(), m, ew.data(), ev.data());   // descending eigenvalues, columns
+  if (rc != EOFX_OK) return rc;
+  w.assign(l, 0.0);
+  V.assign((size_t)l * l, zdouble(0.0, 0.0));
+  int got = 0;
+  const double scale = std::max(std::fabs(ew[0]), std::fabs(ew[m - 1]));
+  for (int c = 0; c < m && got < l; ++c) {
+    std::vector<zdouble> v(l);
+    for (int i = 0; i < l; ++i) v[i] = zdouble(ev[(size_t)i * m + c], ev[(size_t)(l + i) * m + c]);
+    for (int pass = 0; pass < 2; ++pass)
+      for (int g = 0; g < got; ++g) {
+        if (std::fabs(w[g] - ew[c]) > 1e-6 * scale + 1e-300) continue;    // other clusters are orthogonal already
+        zdouble dot(0.0, 0.0);
+        for (int i = 0; i < l; ++i) dot += std::conj(V[(size_t)i * l + g]) * v[i];
+        for (int i = 0; i < l; ++i) v[i] -= dot * V[(size_t)i * l + g];
+      }
+    double nrm = 0.0;
+    for (int i = 0; i < l; ++i) nrm += std::norm(v[i]);
+    nrm = std::sqrt(nrm);
+    if (nrm < 0.5) continue;             // the partner (i v) of an accepted vector
+    for (int i = 0; i < l; ++i) V[(size_t)i * l + got] = v[i] / nrm;
+    w[got] = ew[c];
+    ++got;
+  }
+  return got == l ? EOFX_OK : EOFX_ERR_LINALG;
+}
+// real LP x Lo matrix E with [Pr|Pi] E = [Re(P M) | Im(P M)] for complex M (l x m), h = LP/2, ho = Lo/2
+static void embed_right(const std::vector<zdouble>& M, int l, int mcols, int LP, int Lo, std::vector<double>& E) {
+  const int h = LP / 2, ho = Lo / 2;
+  E.assign((size_t)LP * Lo, 0.0);
+  for (int i = 0; i < l; ++i)
+    for (int j = 0; j < mcols; ++j) {
+      const zdouble v = M[(size_t)i * mcols + j];
+      E[(size_t)i * Lo + j] = v.real();
+      E[(size_t)(h + i) * Lo + j] = -v.imag();
+      E[(size_t)i * Lo + ho + j] = v.imag();
+      E[(size_t)(h + i) * Lo + ho + j] = v.real();
+    }
+}
+}  // namespace
+
+struct CplxOps {
+  eofx_ctx* ctx;
+  const eofx_mat *A, *B;
+  int LP;
+  float* rot;    // companion panel [max(n_pad, p_pad) x LP]
+  float* tmp;    // second product of the two-launch path (other precisions than f16x3)
+  float absmax;
+  int rot_panel(const float* P, float sgn, int64_t rows) {
+    const int64_t total = rows * (LP / 2);
+    hipLaunchKernelGGL(cpanel_rot_kernel, dim3((int)std::min<int64_t>((total + 255) / 256, 8192)), dim3(256), 0, ctx->stream, P, sgn,
+                       rows, LP, rot);
+    return hipGetLastError() == hipSuccess ? EOFX_OK : EOFX_ERR_HIP;
+  }
+  int combine(const float* P1, const float* P2, float sgn, int64_t rows, float* out) {
+    const int64_t total = rows * (LP / 2);
+    hipLaunchKernelGGL(cpanel_combine_kernel, dim3((int)std::min<int64_t>((total + 255) / 256, 8192)), dim3(256), 0, ctx->stream,
+                       P1, P2, sgn, rows, LP, out);
+    return hipGetLastError() == hipSuccess ? EOFX_OK : EOFX_ERR_HIP;
+  }
+  // feature-side panel = Z^H W
+  int zh_mul(const float* Wn, float* Yp, int prec) {
+    const int64_t K = round_up(A->n, ATB_KG), M = A->p_pad;
+    if (prec == EOFX_PREC_F16X3) {
+      CHK(rot_panel(Wn, 1.f, A->n_pad));
+      return launch_atb(ctx, A->X, M, K, M, Wn, LP, LP, Yp, prec, absmax, nullptr, nullptr, B->X, rot);
+    }
+    CHK(launch_atb(ctx, A->X, M, K, M, Wn, LP, LP, Yp, prec, absmax));
+    CHK(launch_atb(ctx, B->X, M, K, M, Wn, LP, LP, tmp, prec, absmax));
+    return combine(Yp, tmp, 1.f, A->p_pad, Yp);
+  }
+  // sample-side panel = Z Y
+  int z_mul(const float* Yp, float* Wn, int prec) {
+    const int64_t K = round_up(A->p, ATB_KG), M = A->n_pad;
+    if (prec == EOFX_PREC_F16X3) {
+      CHK(rot_panel(Yp, -1.f, A->p_pad));
+      return launch_atb(ctx, A->Xt, M, K, M, Yp, LP, LP, Wn, prec, absmax, nullptr, nullptr, B->Xt, rot);
+    }
+    CHK(launch_atb(ctx, A->Xt, M, K, M, Yp, LP, LP, Wn, prec, absmax));
+    CHK(launch_atb(ctx, B->Xt, M, K, M, Yp, LP, LP, tmp, prec, absmax));
+    return combine(Wn, tmp, -1.f, A->n_pad, Wn);
+  }
+};
+
+// U [n x k] and V [p x k] are complex64, row-major, interleaved (re, im); s [k] float32; all host|device.
+// omega: [min(n, p) x (k + n_oversamples)] REAL Gaussian start (host), as the reference's random_state would draw.
+extern "C" int eofx_rsvd_c64(eofx_ctx* ctx, const eofx_mat* A, const eofx_mat* B, int k, int n_oversamples, int n_iter,
+                             const float* omega, int flip_signs, float* U, float* s, float* V) {
+  if (!ctx || !A || !B || !omega || !s || k <= 0 || n_oversamples < 0)
+    return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  if (A->n != B->n || A->p != B->p) return set_err(ctx, EOFX_ERR_SHAPE, "real and imaginary parts must have the same shape");
+  CHK(set_device(ctx));
+  const int64_t n = A->n, p = A->p, r = std::min(n, p);
+  if (k > r) return set_err(ctx, EOFX_ERR_RANK, "n_modes must be less than or equal to the rank of the dataset (rank = %lld).", (long long)r);
+  const int l = (int)std::min<int64_t>(k + n_oversamples, r);
+  if (l > 64) return set_err(ctx, EOFX_ERR_ARG, "complex sketch width %d > 64 is not supported (n_modes + n_oversamples <= 64)", l);
+  if (n_iter < 0) n_iter = k < 0.1 * (double)r ? 7 : 4;
+  const int h = l <= 32 ? 32 : 64, LP = 2 * h;
+  const int ko = (int)round_up(k, 16), Lo = 2 * ko;       // output panels [Re(ko) | Im(ko)]
+  CHK(ensure_X(ctx, A));
+  CHK(ensure_X(ctx, B));
+  const bool transposed = n < p;     // A_op = Z^H: tall side = features
+  const int64_t small = transposed ? n : p;
+  const int64_t small_pad = transposed ? A->n_pad : A->p_pad, tall_pad = transposed ? A->p_pad : A->n_pad;
+  const int64_t big = std::max(A->n_pad, A->p_pad);
+  size_t need = (size_t)(2 * small_pad + 2 * tall_pad + 2 * big) * LP * 4 + (size_t)(small_pad + tall_pad) * Lo * 4;
+  need += 2 * atb_scratch_bytes(A->p_pad, round_up(n, ATB_KG), LP) + 2 * atb_scratch_bytes(A->n_pad, round_up(p, ATB_KG), LP);
+  need += (size_t)(4 * gram_parts(big, LP) + 8) * LP * LP * 8 + (size_t)big * (Lo + LP) * 4 + (8 << 20);
+  CHK(arena_reserve(ctx, need));
+  ArenaScope scope(ctx);
+  ARENA(float, Zs, (size_t)small_pad * LP);
+  ARENA(float, Ws, (size_t)small_pad * LP);
+  ARENA(float, Yt, (size_t)tall_pad * LP);
+  ARENA(float, Qt, (size_t)tall_pad * LP);
+  ARENA(float, rot, (size_t)big * LP);
+  ARENA(float, tmp, (size_t)big * LP);
+  ARENA(float, Tv, (size_t)tall_pad * Lo);
+  ARENA(float, Sv, (size_t)small_pad * Lo);
+  ARENA(double, G, (size_t)LP * LP);
+  ARENA(double, Ed, (size_t)LP * LP);
+  CplxOps ops{ctx, A, B, LP, rot, tmp, std::max(A->absmax, B->absmax)};
+  const int pp = ctx->prec_power, pf = ctx->prec_final;
+  auto fwd = [&](const float* in, float* out, int prec) { return transposed ? ops.zh_mul(in, out, prec) : ops.z_mul(in, out, prec); };
+  auto bwd = [&](const float* in, float* out, int prec) { return transposed ? ops.z_mul(in, out, prec) : ops.zh_mul(in, out, prec); };
+  std::vector<double> hG((size_t)LP * LP), hE;
+  std::vector<zdouble> H, T;
+  auto gram_h = [&](const float* P, int64_t rows_pad) -> int {
+    CHK(launch_gram(ctx, P, rows_pad, LP, G));
+    HIPCHK(hipMemcpyAsync(hG.data(), G, sizeof(double) * LP * LP, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    hermitian_from_real(hG, LP, l, H);
+    for (const zdouble& v : H)
+      if (!std::isfinite(v.real()) || !std::isfinite(v.imag()))
+        return set_err(ctx, EOFX_ERR_LINALG, "SVD failed. This may be due to isolated NaN values in the data.");
+    return EOFX_OK;
+  };
+  auto right_mul = [&](const float* P, int64_t rows_pad, const std::vector<zdouble>& M, int mcols, int Lout, float* out) -> int {
+    embed_right(M, l, mcols, LP, Lout, hE);
+    HIPCHK(hipMemcpyAsync(Ed, hE.data(), sizeof(double) * LP * Lout, hipMemcpyHostToDevice, ctx->stream));
+    CHK(launch_matmul(ctx, P, rows_pad, LP, Ed, Lout, out));
+    HIPCHK(hipStreamSynchronize(ctx->stream));    // hE / Ed are reused
+    return EOFX_OK;
+  };
+  auto orth = [&](const float* P, int64_t rows_pad, float* out) -> int {
+    CHK(gram_h(P, rows_pad));
+    host_zchol_rinv(H, l, T, 1e-13);
+    return right_mul(P, rows_pad, T, l, LP, out);
+  };
+  // start panel [Omega | 0]: a real Gaussian (or the identity for a full-width sketch, which the caller passes as omega)
+  {
+    std::vector<float> host((size_t)small * LP, 0.f);
+    for (int64_t i = 0; i < small; ++i)
+      for (int j = 0; j < l; ++j) host[(size_t)i * LP + j] = omega[(size_t)i * (k + n_oversamples) + j];
+    CHK(import_panel(ctx, host.data(), small, LP, Zs, small_pad, LP));
+  }
+  const bool orth_tall = (size_t)tall_pad * LP * sizeof(float) <= EOFX_ORTH_TALL_BYTES;
+  for (int it = 0; it < n_iter; ++it) {
+    CHK(fwd(Zs, Yt, pp));
+    if (orth_tall) {
+      CHK(orth(Yt, tall_pad, Qt));
+      CHK(bwd(Qt, Ws, pp));
+    } else {
+      CHK(bwd(Yt, Ws, pp));
+    }
+    CHK(orth(Ws, small_pad, Zs));
+  }
+  CHK(fwd(Zs, Yt, pp));
+  CHK(orth(Yt, tall_pad, Qt));
+  CHK(orth(Qt, tall_pad, Yt));                     // Q in Yt (CholeskyQR2)
+  CHK(bwd(Yt, Ws, pf));                            // B^H, B = Q^H A_op
+  CHK(gram_h(Ws, small_pad));                      // B B^H
+  std::vector<double> w;
+  std::vector<zdouble> Uh;
+  if (host_heigh(H, l, w, Uh) != EOFX_OK) return set_err(ctx, EOFX_ERR_LINALG, "complex SVD: Hermitian eigen-solver failed");
+  std::vector<zdouble> M1((size_t)l * k), M2((size_t)l * k);
+  std::vector<float> hs(k);
+  for (int j = 0; j < k; ++j) {
+    const double sv = std::sqrt(std::max(w[j], 0.0));
+    hs[j] = (float)sv;
+    const double inv = sv > 0.0 ? 1.0 / sv : 0.0;
+    for (int i = 0; i < l; ++i) {
+      M1[(size_t)i * k + j] = Uh[(size_t)i * l + j];
+      M2[(size_t)i * k + j] = Uh[(size_t)i * l + j] * inv;
+    }
+  }
+  CHK(right_mul(Yt, tall_pad, M1, k, Lo, Tv));     // A_op = Tall diag(s) Small^H
+  CHK(right_mul(Ws, small_pad, M2, k, Lo, Sv));
+  const float* Vp = transposed ? Tv : Sv;
+  const float* Up = transposed ? Sv : Tv;
+  std::vector<double> sign(k, 1.0);
+  if (flip_signs) {
+    // VT = conj(V)^T; numpy's max / min of complex numbers are lexicographic (real part, then imaginary part)
+    ARENA(int64_t, amax, Lo);
+    ARENA(int64_t, amin, Lo);
+    CHK(eofx_panel_colargminmax_f32(ctx, Vp, p, Lo, amax, amin));
+    std::vector<int64_t> hmx(Lo), hmn(Lo);
+    HIPCHK(hipMemcpyAsync(hmx.data(), amax, sizeof(int64_t) * Lo, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(hmn.data(), amin, sizeof(int64_t) * Lo, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (int j = 0; j < k; ++j) {
+      float c[4];   // (re, im) at the arg max and the arg min of the real part
+      HIPCHK(hipMemcpy(&c[0], Vp + hmx[j] * Lo + j, sizeof(float), hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(&c[1], Vp + hmx[j] * Lo + ko + j, sizeof(float), hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(&c[2], Vp + hmn[j] * Lo + j, sizeof(float), hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(&c[3], Vp + hmn[j] * Lo + ko + j, sizeof(float), hipMemcpyDeviceToHost));
+      sign[j] = std::hypot((double)c[0], (double)c[1]) >= std::hypot((double)c[2], (double)c[3]) ? 1.0 : -1.0;
+    }
+  }
+  // interleaved complex64 exports
+  auto export_c = [&](const float* P, int64_t rows, float* dst) -> int {
+    if (!dst) return EOFX_OK;
+    ArenaScope sc(ctx);
+    double* dsign = arena_alloc<double>(ctx, k);
+    if (!dsign) return set_err(ctx, EOFX_ERR_NOMEM, "arena exhausted (export sign)");
+    CHK(copy_in(ctx, dsign, sign.data(), sizeof(double) * k));
+    float* t = dst;
+    const bool dev = is_device_ptr(dst);
+    if (!dev) {
+      t = arena_alloc<float>(ctx, (size_t)rows * k * 2);
+      if (!t) return set_err(ctx, EOFX_ERR_NOMEM, "arena exhausted (export staging)");
+    }
+    const int64_t total = rows * k;
+    hipLaunchKernelGGL(cpanel_export_kernel, dim3((int)std::min<int64_t>((total + 255) / 256, 8192)), dim3(256), 0, ctx->stream, P,
+                       rows, Lo, k, dsign, t);
+    KCHK();
+    if (!dev) CHK(copy_out(ctx, dst, t, sizeof(float) * total * 2));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return EOFX_OK;
+  };
+  CHK(export_c(Up, n, U));
+  CHK(export_c(Vp, p, V));
+  if (is_device_ptr(s)) HIPCHK(hipMemcpy(s, hs.data(), sizeof(float) * k, hipMemcpyHostToDevice));
+  else std::memcpy(s, hs.data(), sizeof(float) * k);
   return EOFX_OK;
 }
 

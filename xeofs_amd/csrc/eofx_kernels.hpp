@@ -355,14 +355,24 @@ __global__ __launch_bounds__(256, 2) void atb_f16_kernel(const float* __restrict
                                                           float a_scale,
                                                           const float* __restrict__ b_absmax,
                                                           const float* __restrict__ aff = nullptr,
-                                                          int64_t aff_ld = 0, int a_rows = 0, int64_t a_cols = 0) {
+                                                          int64_t aff_ld = 0, int a_rows = 0, int64_t a_cols = 0,
+                                                          const float* A2 = nullptr, const float* B2 = nullptr,
+                                                          int s_half = 0) {
+  // Two-matrix form (complex passes, eofx_rsvd_c64): splits [s_half, 2 s_half) stream a second matrix A2 (same shape)
+  // against its own panel B2 -- C = A^T B + A2^T B2 in one launch, summed by the split-K reduction.
   __shared__ __attribute__((aligned(16))) _Float16 Bs[2][2][2][32 * NB][8];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int64_t m0 = (int64_t)blockIdx.x * ATB_BM + wave * ATB_WM;
-  const int64_t kb = (int64_t)blockIdx.y * k_per_split;
+  int sy_ = blockIdx.y;
+  if (A2 != nullptr && sy_ >= s_half) {
+    A = A2;
+    B = B2;
+    sy_ -= s_half;
+  }
+  const int64_t kb = (int64_t)sy_ * k_per_split;
   const int64_t ke = (kb + k_per_split < K) ? kb + k_per_split : K;
   const int nchunks = (int)((ke - kb) / ATB_KC);
   const int bcol0 = col_base + blockIdx.z * 64;
@@ -1460,6 +1470,36 @@ __global__ __launch_bounds__(256) void cpanel_combine_kernel(const float* __rest
     const float p2r = P2[r * L + c], p2i = P2[r * L + h + c];
     out[r * L + c] = p1r + sgn * p2i;
     out[r * L + h + c] = p1i - sgn * p2r;
+  }
+}
+
+// companion panel of a complex pass: out = sgn * [Pi | -Pr]  (so that A^T [Pr|Pi] + B^T out = [Re | Im] of Z^H P for
+// sgn = +1, and A [Pr|Pi] + B out = Z P for sgn = -1)
+__global__ __launch_bounds__(256) void cpanel_rot_kernel(const float* __restrict__ P, float sgn, int64_t rows, int L,
+                                                          float* __restrict__ out) {
+  const int h = L / 2;
+  const int64_t total = rows * h;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t r = i / h;
+    const int c = (int)(i - r * h);
+    out[r * L + c] = sgn * P[r * L + h + c];
+    out[r * L + h + c] = -sgn * P[r * L + c];
+  }
+}
+
+// [Re(ko) | Im(ko)] panel -> dense [rows x k] interleaved complex64, optional column signs
+__global__ __launch_bounds__(256) void cpanel_export_kernel(const float* __restrict__ P, int64_t rows, int L, int k,
+                                                             const double* __restrict__ sign, float* __restrict__ dst) {
+  const int h = L / 2;
+  const int64_t total = rows * k;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t r = i / k;
+    const int c = (int)(i - r * k);
+    const float sg = sign ? (float)sign[c] : 1.f;
+    dst[2 * i] = sg * P[r * L + c];
+    dst[2 * i + 1] = sg * P[r * L + h + c];
   }
 }
 

@@ -523,6 +523,28 @@ def feature_norms(ctx: Context, mat: ResidentMatrix) -> np.ndarray:
     return out
 
 
+def rsvd_c64(ctx: Context, A: ResidentMatrix, B: ResidentMatrix, k: int, n_oversamples: int = 10, n_iter="auto",
+             random_state=None, flip: bool = True):
+    """complex randomized SVD of Z = A + iB (eofx_rsvd_c64) -> (U[n,k] complex64, s[k] float32, V[p,k] complex64)"""
+    k = int(k)
+    r = min(A.n, A.p)
+    if k > r:
+        raise ValueError(f"n_modes must be less than or equal to the rank of the dataset (rank = {r}).")
+    l = min(k + n_oversamples, r)
+    if l == r:      # full-width sketch spans everything: identity, not an ill-conditioned square Gaussian
+        omega = np.zeros((r, k + n_oversamples), np.float32)
+        omega[np.arange(l), np.arange(l)] = 1.0
+    else:
+        omega = np.ascontiguousarray(sketch_matrix(r, k + n_oversamples, random_state), dtype=np.float32)
+    it = -1 if n_iter in ("auto", None) else int(n_iter)
+    U = np.empty((A.n, k), np.complex64)
+    V = np.empty((A.p, k), np.complex64)
+    s = np.empty(k, np.float32)
+    raise_for(ctx.lib.eofx_rsvd_c64(ctx.handle, A.handle, B.handle, k, int(n_oversamples), it, ptr(omega), int(flip),
+                                    ptr(U), ptr(s), ptr(V)), ctx.handle)
+    return U, s, V
+
+
 def panel_fused(ctx: Context, mat: ResidentMatrix, Zn, out=None, want_y=False):
     """Wn[n_pad, 64] = X (X^T Zn) in one pass over the matrix; with want_y also Yp[p_pad, 64] = X^T Zn"""
     torch = _torch()

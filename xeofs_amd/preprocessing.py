@@ -104,11 +104,28 @@ class Preprocessor:
         M = mats[0] if len(mats) == 1 else np.concatenate(mats, axis=1)
         return np.ascontiguousarray(M), ws
 
-    def fit_transform(self, X, sample_dims, weights=None):
+    def peek_std(self, X, sample_dims):
+        """per-feature standard deviation (ddof = 0, clipped at float32 eps: scaler.py:105-108) of the stacked field,
+        without building the matrix -- the complex models combine the deviations of the two parts"""
+        ctx = self.ctx or engine.default_context()
+        M, _ = self._stack(self._fields(X, _as_tuple(sample_dims)), None)
+        _, st = engine.preprocess(ctx, M, True, True, None, self.check_nans, build=False)
+        return st["std"]
+
+    def fit_transform(self, X, sample_dims, weights=None, std_override=None):
+        """std_override: per-feature deviations to scale with instead of this field's own (complex input: one real
+        deviation sqrt(var Re + var Im) for both parts, numpy's std of a complex array)."""
         self.sample_dims = _as_tuple(sample_dims)
         ctx = self.ctx or engine.default_context()
         self.fields = self._fields(X, self.sample_dims)
         M, self.feature_weights = self._stack(self.fields, weights)
+        if std_override is not None:
+            _, st = engine.preprocess(ctx, M, self.center, False, self.feature_weights, self.check_nans, build=False)
+            self.mean_, self.std_ = (st["mean"] if self.center else None), np.asarray(std_override, dtype=np.float64)
+            self.valid_feature, self.valid_sample = st["valid_feature"], st["valid_sample"]
+            mat, _ = engine.apply(ctx, M, self.mean_, self.std_, self.feature_weights, self.valid_feature, self.check_nans)
+            self.total_variance = mat.sumsq() / (mat.n - 1)
+            return mat
         mat, st = engine.preprocess(ctx, M, self.center, self.standardize, self.feature_weights, self.check_nans)
         self.mean_, self.std_ = (st["mean"] if self.center else None), (st["std"] if self.standardize else None)
         self.valid_feature, self.valid_sample = st["valid_feature"], st["valid_sample"]

@@ -168,7 +168,7 @@ class ComplexEOF(EOF):
     """Drop-in for xeofs.single.ComplexEOF (xeofs/single/eof.py:243-446): EOF analysis of complex
     data.  The complex matrix is held as two resident real matrices; the decomposition is the
     complex randomized SVD of `xeofs_amd.complex_svd` (the reference's complex branch,
-    linalg/decomposer.py:149-160).  `standardize` is not supported for complex input."""
+    linalg/decomposer.py:149-160)."""
 
     def __init__(self, n_modes: int = 2, padding: str = "exp", decay_factor: float = 0.2, center: bool = True,
                  standardize: bool = False, use_coslat: bool = False, check_nans: bool = True,
@@ -185,14 +185,19 @@ class ComplexEOF(EOF):
 
     def _complex_parts(self, X, dim, weights):
         """preprocess Re and Im of a complex input with the same centring / weights"""
-        if self._params["standardize"]:
-            raise NotImplementedError("standardize=True is not supported for complex input")
         vals, dims, coords, name, attrs = labelled.unpack(X)
         re = labelled.pack(np.ascontiguousarray(vals.real), dims, coords, name, attrs, X)
         im = labelled.pack(np.ascontiguousarray(vals.imag), dims, coords, name, attrs, X)
-        A = self.preprocessor.fit_transform(re, dim, weights)
         self.preprocessor_imag.ctx = self.ctx
-        B = self.preprocessor_imag.fit_transform(im, dim, weights)
+        std_c = None
+        if self._params["standardize"]:
+            # scaler.py:105-108 on complex data: numpy's std of a complex array is the real
+            # sqrt(mean |z - mean|^2) = sqrt(var Re + var Im); both parts are divided by it
+            self.preprocessor.standardize = False
+            s_re, s_im = self.preprocessor.peek_std(re, dim), self.preprocessor_imag.peek_std(im, dim)
+            std_c = np.maximum(np.sqrt(s_re ** 2 + s_im ** 2), np.finfo(np.float32).eps)
+        A = self.preprocessor.fit_transform(re, dim, weights, std_override=std_c)
+        B = self.preprocessor_imag.fit_transform(im, dim, weights, std_override=std_c)
         tv = self.preprocessor.total_variance + self.preprocessor_imag.total_variance
         return A, B, tv
 
@@ -211,11 +216,9 @@ class ComplexEOF(EOF):
                                       "https://github.com/dask/dask/issues/7639")
 
     def _fit_complex(self, A, B, total_variance):
-        from ..complex_svd import complex_rsvd
-
         kw = dict(self._solver_kwargs)
-        U, s, V = complex_rsvd(self.ctx, A, B, int(self.n_modes), int(kw.get("n_oversamples", 10)),
-                               kw.get("n_iter", "auto"), self._params["random_state"])
+        U, s, V = engine.rsvd_c64(self.ctx, A, B, int(self.n_modes), int(kw.get("n_oversamples", 10)),
+                                  kw.get("n_iter", "auto"), self._params["random_state"])
         s64 = s.astype(np.float64)
         self.data = dict(input_data=(A, B), components=V, scores=U * s, norms=s64,
                          explained_variance=s64 ** 2 / (A.n - 1), total_variance=total_variance)
