@@ -18,7 +18,8 @@ for rep in range(2):
     torch.cuda.synchronize(); t2 = time.perf_counter()
     p = nlat * nlon
     passes = 16
-    for name, fn in (("engine eofx_rsvd_c64", lambda: engine.rsvd_c64(ctx, A, B, k, random_state=5)),
+    om = engine.sketch_matrix(min(n, p), k + 10, 5)
+    for name, fn in (("engine eofx_rsvd_c64", lambda: engine.rsvd_c64(ctx, A, B, k, random_state=5, omega=om)),
                      ("panel-level (python) driver", lambda: complex_rsvd(ctx, A, B, k, random_state=5))):
         if name.startswith("panel") and k + 10 > 32:
             continue

@@ -2307,18 +2307,14 @@ extern "C" int eofx_rsvd_c64(eofx_ctx* ctx, const eofx_mat* A, const eofx_mat* B
     ARENA(int64_t, amax, Lo);
     ARENA(int64_t, amin, Lo);
     CHK(eofx_panel_colargminmax_f32(ctx, Vp, p, Lo, amax, amin));
-    std::vector<int64_t> hmx(Lo), hmn(Lo);
-    HIPCHK(hipMemcpyAsync(hmx.data(), amax, sizeof(int64_t) * Lo, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(hmn.data(), amin, sizeof(int64_t) * Lo, hipMemcpyDeviceToHost, ctx->stream));
+    ARENA(float, picks, 4 * (size_t)k);
+    hipLaunchKernelGGL(cpanel_pick_kernel, dim3((k + 63) / 64), dim3(64), 0, ctx->stream, Vp, Lo, k, amax, amin, picks);
+    KCHK();
+    std::vector<float> c(4 * (size_t)k);
+    HIPCHK(hipMemcpyAsync(c.data(), picks, sizeof(float) * 4 * k, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    for (int j = 0; j < k; ++j) {
-      float c[4];   // (re, im) at the arg max and the arg min of the real part
-      HIPCHK(hipMemcpy(&c[0], Vp + hmx[j] * Lo + j, sizeof(float), hipMemcpyDeviceToHost));
-      HIPCHK(hipMemcpy(&c[1], Vp + hmx[j] * Lo + ko + j, sizeof(float), hipMemcpyDeviceToHost));
-      HIPCHK(hipMemcpy(&c[2], Vp + hmn[j] * Lo + j, sizeof(float), hipMemcpyDeviceToHost));
-      HIPCHK(hipMemcpy(&c[3], Vp + hmn[j] * Lo + ko + j, sizeof(float), hipMemcpyDeviceToHost));
-      sign[j] = std::hypot((double)c[0], (double)c[1]) >= std::hypot((double)c[2], (double)c[3]) ? 1.0 : -1.0;
-    }
+    for (int j = 0; j < k; ++j)   // |max| >= |min| in numpy's lexicographic complex order (real part decides)
+      sign[j] = std::hypot((double)c[4 * j], (double)c[4 * j + 1]) >= std::hypot((double)c[4 * j + 2], (double)c[4 * j + 3]) ? 1.0 : -1.0;
   }
   // interleaved complex64 exports
   auto export_c = [&](const float* P, int64_t rows, float* dst) -> int {

@@ -1488,6 +1488,18 @@ __global__ __launch_bounds__(256) void cpanel_rot_kernel(const float* __restrict
   }
 }
 
+// (re, im) of column j at the rows amax[j] and amin[j]: out[4 j .. 4 j + 3]  (complex sign rule)
+__global__ void cpanel_pick_kernel(const float* __restrict__ P, int L, int k, const int64_t* __restrict__ amax,
+                                   const int64_t* __restrict__ amin, float* __restrict__ out) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= k) return;
+  const int h = L / 2;
+  out[4 * j + 0] = P[amax[j] * L + j];
+  out[4 * j + 1] = P[amax[j] * L + h + j];
+  out[4 * j + 2] = P[amin[j] * L + j];
+  out[4 * j + 3] = P[amin[j] * L + h + j];
+}
+
 // [Re(ko) | Im(ko)] panel -> dense [rows x k] interleaved complex64, optional column signs
 __global__ __launch_bounds__(256) void cpanel_export_kernel(const float* __restrict__ P, int64_t rows, int L, int k,
                                                              const double* __restrict__ sign, float* __restrict__ dst) {

@@ -524,7 +524,7 @@ def feature_norms(ctx: Context, mat: ResidentMatrix) -> np.ndarray:
 
 
 def rsvd_c64(ctx: Context, A: ResidentMatrix, B: ResidentMatrix, k: int, n_oversamples: int = 10, n_iter="auto",
-             random_state=None, flip: bool = True):
+             random_state=None, flip: bool = True, omega=None):
     """complex randomized SVD of Z = A + iB (eofx_rsvd_c64) -> (U[n,k] complex64, s[k] float32, V[p,k] complex64)"""
     k = int(k)
     r = min(A.n, A.p)
@@ -534,8 +534,12 @@ def rsvd_c64(ctx: Context, A: ResidentMatrix, B: ResidentMatrix, k: int, n_overs
     if l == r:      # full-width sketch spans everything: identity, not an ill-conditioned square Gaussian
         omega = np.zeros((r, k + n_oversamples), np.float32)
         omega[np.arange(l), np.arange(l)] = 1.0
-    else:
+    elif omega is None:
         omega = np.ascontiguousarray(sketch_matrix(r, k + n_oversamples, random_state), dtype=np.float32)
+    else:
+        omega = np.ascontiguousarray(omega, dtype=np.float32)
+        if omega.shape != (r, k + n_oversamples):
+            raise ValueError(f"omega must have shape {(r, k + n_oversamples)}")
     it = -1 if n_iter in ("auto", None) else int(n_iter)
     U = np.empty((A.n, k), np.complex64)
     V = np.empty((A.p, k), np.complex64)

@@ -215,10 +215,13 @@ class ComplexEOF(EOF):
             raise NotImplementedError("Complex data together with dask is currently not implemented. See dask issue 7639 "
                                       "https://github.com/dask/dask/issues/7639")
 
-    def _fit_complex(self, A, B, total_variance):
+    def _fit_complex(self, A, B, total_variance, omega=None):
         kw = dict(self._solver_kwargs)
+        om = None if omega is None else omega.result()
+        if om is not None and om.shape[0] != min(A.n, A.p):     # samples or features were dropped: draw again
+            om = None
         U, s, V = engine.rsvd_c64(self.ctx, A, B, int(self.n_modes), int(kw.get("n_oversamples", 10)),
-                                  kw.get("n_iter", "auto"), self._params["random_state"])
+                                  kw.get("n_iter", "auto"), self._params["random_state"], omega=om)
         s64 = s.astype(np.float64)
         self.data = dict(input_data=(A, B), components=V, scores=U * s, norms=s64,
                          explained_variance=s64 ** 2 / (A.n - 1), total_variance=total_variance)
@@ -287,6 +290,7 @@ class HilbertEOF(ComplexEOF):
         self._reject_lazy(X)
         self.ctx = self.ctx or engine.default_context()
         self.preprocessor.ctx = self.ctx
+        omega = self._sketch_ahead(X, dim)          # drawn on a worker thread while the Hilbert stage runs
         A = self.preprocessor.fit_transform(X, dim, weights)
         self.sample_dims = self.preprocessor.sample_dims
         centred = bool(self._params["center"])
@@ -295,4 +299,4 @@ class HilbertEOF(ComplexEOF):
             A.free()
             A = A2
         tv = (A.sumsq() + B.sumsq()) / (A.n - 1)
-        return self._fit_complex(A, B, tv)
+        return self._fit_complex(A, B, tv, omega)
