@@ -89,7 +89,19 @@ int eofx_ctx_trim(eofx_ctx *ctx);
 #define EOFX_PREC_BF16X6 2
 #define EOFX_PREC_F16X3 3 /* operands scaled by exact powers of two and split into 2 fp16 terms (11+11
                             bits), 3 cross products: ~2^-22 per product at the cost of BF16X3 */
+#define EOFX_PREC_F64 4   /* float64 multiply-accumulate on the fp64 matrix cores (v_mfma_f64_16x16x4_f64): exact products
+                           * of the float32 data and panel, float64 sums -- the reference's arithmetic after it promotes
+                           * the field; MFMA-bound, about 3x the time of the split-fp16 pass.  For spectra whose wanted
+                           * modes lie more than ~500x below the leading one.                       */
 int eofx_ctx_set_precision(eofx_ctx *ctx, int power_passes, int final_passes);
+/* 1 when the drivers re-normalise the tall (rows_pad x L) panel between the two products of EVERY power iteration:
+ * small panels (<= 16 MiB) and the float64 mode (the first iteration always does).  Exported so that panel-level
+ * drivers follow the same rule.                                                                                  */
+int eofx_orth_tall_rule(int64_t tall_rows_pad, int L, int precision_power);
+/* 1 when the spectrum is peaked enough (sqrt of the ratio of the extreme eigenvalues of the small-side Gram matrix of
+ * the first power iteration > 30) for the drivers to keep that step in the remaining iterations as well.  G: host,
+ * leading l x l block, row stride ld.                                                                           */
+int eofx_peaked_spectrum(const double *G, int ld, int l);
 int eofx_ctx_profile(eofx_ctx *ctx, int enable);
 int eofx_ctx_profile_read(eofx_ctx *ctx, int64_t *launches, double *total_ms, double *flops,
                           double *bytes);

@@ -59,6 +59,8 @@ SIGNATURES = {
     "eofx_mat_sumsq_f64": (_int, [_vp, _vp, _pd]),
     "eofx_panel_fused_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _int]),
     "eofx_rsvd_c64": (_int, [_vp, _vp, _vp, _int, _int, _int, _vp, _int, _vp, _vp, _vp]),
+    "eofx_orth_tall_rule": (_int, [_i64, _int, _int]),
+    "eofx_peaked_spectrum": (_int, [_vp, _int, _int]),
     "eofx_ctx_set_layout": (_int, [_vp, _int]),
     "eofx_mat_release_raw": (_int, [_vp, _vp]),
     "eofx_mat_layout": (_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
@@ -75,7 +77,7 @@ SIGNATURES = {
     "eofx_host_eigh_f64": (_int, [_vp, _int, _vp, _vp]),
 }
 
-PREC = {"f32": 0, "bf16x3": 1, "bf16x6": 2, "f16x3": 3}
+PREC = {"f32": 0, "bf16x3": 1, "bf16x6": 2, "f16x3": 3, "f64": 4}
 
 _lib = None
 

@@ -148,12 +148,19 @@ def complex_rsvd(ctx, A, B, k: int, n_oversamples: int = 10, n_iter="auto", rand
     Z = ops.import_panel(host, small)
     # like the real driver: re-normalise the tall panel inside the iteration while it is small (sharded.py)
     tall_total = n if tall == "n" else p
-    orth_tall = ((tall_total + 511) // 512 * 512) * LP * 4 <= (16 << 20)
-    for _ in range(int(n_iter)):
+    from .sharded import _orth_tall
+
+    orth_tall = _orth_tall(tall_total, LP, getattr(ctx, "precision", ("f16x3",))[0])
+    orth_rest = orth_tall
+    for it in range(int(n_iter)):
         Yt = fwd(Z)
-        if orth_tall:
+        if it == 0 or orth_rest:           # the first iteration always re-normalises the tall panel (rsvd_core)
             Yt = orth(Yt, tall)
-        Z = orth(bwd(Yt), small)
+        Wp = bwd(Yt)
+        if it == 0 and not orth_tall and int(n_iter) > 1:      # peaked spectrum: keep the step (eofx_peaked_spectrum's rule)
+            wv = np.linalg.eigvalsh(gram(Wp, small))
+            orth_rest = not (wv[0] > 0.0) or np.sqrt(wv[-1] / wv[0]) > 30.0
+        Z = orth(Wp, small)
     Q = orth(orth(fwd(Z), tall), tall)                  # range basis: a subspace only, power-pass precision
     Bt = bwd(Q, True)                                   # = B^H with B = Q^H A_op
     w, Uh = np.linalg.eigh(gram(Bt, small))             # B B^H = Uh diag(w) Uh^H

@@ -388,7 +388,7 @@ static AtbPlan atb_plan(int64_t M, int64_t K, int L) {
 }
 static size_t atb_scratch_bytes(int64_t M, int64_t K, int L) {
   const AtbPlan pl = atb_plan(M, K, L);
-  return pl.S > 1 ? (size_t)pl.S * M * L * sizeof(float) + 4096 : 4096;
+  return pl.S > 1 ? (size_t)pl.S * M * L * (sizeof(float) + sizeof(double)) + 4096 : 4096;   // f32 or f64 partials
 }
 
 // C[M x L] = A[K x M]^T B[K x L]; M multiple of 512, K multiple of 16, L multiple of 32.
@@ -474,6 +474,36 @@ static int launch_atb(eofx_ctx* ctx, const float* A, int64_t lda, int64_t K, int
     HIPCHK(hipEventCreate(&ev0));
     HIPCHK(hipEventCreate(&ev1));
     HIPCHK(hipEventRecord(ev0, ctx->stream));
+  }
+  if (prec == EOFX_PREC_F64) {   // float64 partials (the float32 ones above are not used)
+    double* outd = nullptr;
+    if (best_s > 1) {
+      outd = arena_alloc<double>(ctx, (size_t)best_s * M * L);
+      if (!outd) return set_err(ctx, EOFX_ERR_NOMEM, "arena exhausted (float64 partials)");
+    }
+    if (nfull > 0) {
+      hipLaunchKernelGGL(atb_f64_kernel<2>, dim3(bx, best_s, nfull), dim3(512), 0, ctx->stream, A, lda, B, ldb, C, outd, L, M, K,
+                         best_kps, 0);
+      KCHK();
+    }
+    if (rem) {
+      hipLaunchKernelGGL(atb_f64_kernel<1>, dim3(bx, best_s, 1), dim3(512), 0, ctx->stream, A, lda, B, ldb, C, outd, L, M, K,
+                         best_kps, nfull * 64);
+      KCHK();
+    }
+    if (ctx->profile) {
+      HIPCHK(hipEventRecord(ev1, ctx->stream));
+      ctx->prof_events.emplace_back(ev0, ev1);
+      ctx->prof_flops += 2.0 * (double)K * (double)M * (double)L;
+      ctx->prof_bytes += (double)K * (double)M * 4.0 * (nfull + (rem ? 1 : 0));
+    }
+    if (outd) {
+      const int64_t count = M * L;
+      hipLaunchKernelGGL(splitk_reduce_f64_kernel, dim3((int)std::min<int64_t>((count + 255) / 256, 8192)), dim3(256), 0, ctx->stream,
+                         outd, C, count, best_s);
+      KCHK();
+    }
+    return EOFX_OK;
   }
   if (nfull > 0) {
     dim3 grid(bx, best_s, nfull);
@@ -1232,7 +1262,7 @@ static int panel_mul(eofx_ctx* ctx, const eofx_mat* m, const float* Yp, float* W
   return launch_atb(ctx, m->Xt, m->n_pad, round_up(m->p, ATB_KG), m->n_pad, Yp, L, L, Wn, prec, m->absmax);
 }
 static bool valid_prec(int p) {
-  return p == EOFX_PREC_F32 || p == EOFX_PREC_BF16X3 || p == EOFX_PREC_BF16X6 || p == EOFX_PREC_F16X3;
+  return p == EOFX_PREC_F32 || p == EOFX_PREC_BF16X3 || p == EOFX_PREC_BF16X6 || p == EOFX_PREC_F16X3 || p == EOFX_PREC_F64;
 }
 
 extern "C" int eofx_ctx_set_precision(eofx_ctx* ctx, int power_passes, int final_passes) {
@@ -1455,7 +1485,39 @@ static int rsvd_auto_iters(int k, int64_t n, int64_t p) {
 }
 
 // All panels are carved from the arena by the caller-visible drivers (reserve first).
-constexpr size_t EOFX_ORTH_TALL_BYTES = (size_t)16 << 20;   // keep in sync with xeofs_amd/sharded.py
+constexpr size_t EOFX_ORTH_TALL_BYTES = (size_t)16 << 20;
+constexpr double EOFX_PEAKED_RATIO = 30.0;
+// Is the tall panel re-normalised between the two products of a power iteration?  scikit-learn normalises after EVERY
+// product; leaving that step out is exact in exact arithmetic, but one iteration then squares sigma_1 / sigma_l inside
+// the float32 panel and the Cholesky-QR that follows squares it again: modes more than ~500x below the leading one
+// drift from the float64 reference (6e-5 at 1370x, lost beyond 4000x; with the step 8e-6 at 41000x, tests
+// test_peaked_spectrum_*).  The step costs 0.85 ms per iteration at config 4 (4 % of a fit), so:
+//   * always: small tall panels (<= 16 MiB: microseconds), the float64 mode, and the FIRST iteration of every fit;
+//   * afterwards only where it matters: after the first iteration the small-side Gram matrix W^T W is a Rayleigh
+//     quotient of X X^T on an orthonormal basis; if the square root of the ratio of its extreme eigenvalues
+//     (~ sigma_1 / sigma_l) exceeds EOFX_PEAKED_RATIO the remaining iterations keep the step.
+// ONE rule (eofx_orth_tall_rule / eofx_peaked_spectrum) for the C++ drivers and the panel-level (sharded) driver.
+static bool orth_tall_rule(int64_t tall_pad, int L, int prec_power) {
+  if (std::getenv("EOFX_FORCE_ORTH_TALL")) return true;    // experiments (tools/cond_study.py)
+  return prec_power == EOFX_PREC_F64 || (size_t)tall_pad * L * sizeof(float) <= EOFX_ORTH_TALL_BYTES;
+}
+extern "C" int eofx_orth_tall_rule(int64_t tall_rows_pad, int L, int prec_power) {
+  return orth_tall_rule(tall_rows_pad, L, prec_power) ? 1 : 0;
+}
+// G: leading l x l block (row stride ld) of the small-side float64 Gram matrix after the first iteration (host)
+extern "C" int eofx_peaked_spectrum(const double* G, int ld, int l) {
+  if (!G || l <= 0) return 0;
+  std::vector<double> A((size_t)l * l), w(l), V((size_t)l * l);
+  for (int i = 0; i < l; ++i)
+    for (int j = 0; j < l; ++j) A[(size_t)i * l + j] = 0.5 * (G[(size_t)i * ld + j] + G[(size_t)j * ld + i]);
+  for (double v : A)
+    if (!std::isfinite(v)) return 0;
+  if (eofx_host_eigh_f64(A.data(), l, w.data(), V.data()) != EOFX_OK) return 1;
+  const double hi = w[0], lo = w[l - 1];                 // descending
+  if (!(hi > 0.0)) return 0;
+  if (!(lo > 0.0)) return 1;
+  return std::sqrt(hi / lo) > EOFX_PEAKED_RATIO ? 1 : 0;
+}
 
 static int rsvd_core(eofx_ctx* ctx, const LinOp& op, int k, int l, int n_iter, const float* omega,
                      RsvdOut& out) {
@@ -1480,10 +1542,11 @@ static int rsvd_core(eofx_ctx* ctx, const LinOp& op, int k, int l, int n_iter, c
   // Where the tall panel is small (<= EOFX_ORTH_TALL_BYTES) the extra Cholesky-QR costs microseconds and is
   // done; for large panels it made no measurable difference (tools/cond_study.py) and would cost 6 % of a
   // config-4 fit, so it is skipped there.
-  const bool orth_tall = (size_t)op.tall_pad * L * sizeof(float) <= EOFX_ORTH_TALL_BYTES;
+  const bool orth_always = orth_tall_rule(op.tall_pad, L, pp);
+  bool orth_rest = orth_always;
   for (int it = 0; it < n_iter; ++it) {
     CHK(op.fwd(Zs, Yt, L, pp));
-    if (orth_tall) {
+    if (it == 0 || orth_rest) {
       CHK(launch_gram(ctx, Yt, op.tall_pad, L, G));
       CHK(launch_cholqr(ctx, Yt, op.tall_pad, L, l, G, Qt));
       CHK(op.bwd(Qt, Ws, L, pp));
@@ -1491,6 +1554,12 @@ static int rsvd_core(eofx_ctx* ctx, const LinOp& op, int k, int l, int n_iter, c
       CHK(op.bwd(Yt, Ws, L, pp));
     }
     CHK(launch_gram(ctx, Ws, op.small_pad, L, G));
+    if (it == 0 && !orth_always && n_iter > 1) {   // peaked spectrum?  (one small download per fit)
+      std::vector<double> hG0((size_t)L * L);
+      HIPCHK(hipMemcpyAsync(hG0.data(), G, sizeof(double) * L * L, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      orth_rest = eofx_peaked_spectrum(hG0.data(), L, l) != 0;
+    }
     CHK(launch_cholqr(ctx, Ws, op.small_pad, L, l, G, Zs));
   }
   // range basis on the tall side: Q = orth(A Z), CholeskyQR2
@@ -2267,16 +2336,24 @@ extern "C" int eofx_rsvd_c64(eofx_ctx* ctx, const eofx_mat* A, const eofx_mat* B
       for (int j = 0; j < l; ++j) host[(size_t)i * LP + j] = omega[(size_t)i * (k + n_oversamples) + j];
     CHK(import_panel(ctx, host.data(), small, LP, Zs, small_pad, LP));
   }
-  const bool orth_tall = (size_t)tall_pad * LP * sizeof(float) <= EOFX_ORTH_TALL_BYTES;
+  const bool orth_always = orth_tall_rule(tall_pad, LP, pp);
+  bool orth_rest = orth_always;
   for (int it = 0; it < n_iter; ++it) {
     CHK(fwd(Zs, Yt, pp));
-    if (orth_tall) {
+    if (it == 0 || orth_rest) {
       CHK(orth(Yt, tall_pad, Qt));
       CHK(bwd(Qt, Ws, pp));
     } else {
       CHK(bwd(Yt, Ws, pp));
     }
-    CHK(orth(Ws, small_pad, Zs));
+    CHK(gram_h(Ws, small_pad));
+    if (it == 0 && !orth_always && n_iter > 1) {   // peaked spectrum?  the Hermitian Gram matrix is on the host already
+      std::vector<zdouble> V0;
+      std::vector<double> w0;
+      orth_rest = host_heigh(H, l, w0, V0) != EOFX_OK || !(w0[l - 1] > 0.0) || std::sqrt(w0[0] / w0[l - 1]) > EOFX_PEAKED_RATIO;
+    }
+    host_zchol_rinv(H, l, T, 1e-13);
+    CHK(right_mul(Ws, small_pad, T, l, LP, Zs));
   }
   CHK(fwd(Zs, Yt, pp));
   CHK(orth(Yt, tall_pad, Qt));

@@ -522,6 +522,125 @@ __global__ __launch_bounds__(256) void panel_absmax_kernel(const float* __restri
   }
 }
 
+// ---------------------------------------------------------------------------------
+// atb_f64: the same product with float64 multiply-accumulate on the fp64 matrix cores (v_mfma_f64_16x16x4_f64):
+// operands are the float32 data and panel converted exactly, every product is exact (24 + 24 bits) and the sums are
+// float64 -- the arithmetic the reference does after promoting the field (xeofs/utils/xarray_utils.py:78-100).
+// MFMA-bound: 2 K M L flop at the 78.6 TFLOP/s float64 peak, about 3x the time of the HBM-bound split-fp16 pass.
+//   block = 512 threads = 8 waves x 64 columns of A; lane (c = l % 16, kq = l / 16) loads 16 B (columns 4c..4c+3) of
+//   row k0 + kq: the four floats are element (i = c, k = kq) of FOUR A fragments (sub-tile t holds columns 4 i + t).
+//   Split-K partials are float64 (Cd), reduced by splitk_reduce_f64_kernel; a single split writes float32 directly.
+// ---------------------------------------------------------------------------------
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+template <int NB>
+__global__ __launch_bounds__(512) void atb_f64_kernel(const float* __restrict__ A, int64_t lda,
+                                                       const float* __restrict__ B, int ldb,
+                                                       float* __restrict__ C, double* __restrict__ Cd, int ldc,
+                                                       int64_t M, int64_t K, int64_t k_per_split, int col_base) {
+  __shared__ __attribute__((aligned(16))) double Bs[2][ATB_KC][32 * NB];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int c16 = lane & 15, kq = lane >> 4;
+  const int64_t m0 = (int64_t)blockIdx.x * ATB_BM + wave * 64;
+  const int64_t kb = (int64_t)blockIdx.y * k_per_split;
+  const int64_t ke = (kb + k_per_split < K) ? kb + k_per_split : K;
+  const int nchunks = (int)((ke - kb) / ATB_KC);
+  const int bcol0 = col_base + blockIdx.z * 64;
+  constexpr int NT = 2 * NB;          // 16-column tiles of the panel
+
+  f64x4 acc[4][NT];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int q = 0; q < NT; ++q) acc[t][q] = f64x4{0.0, 0.0, 0.0, 0.0};
+
+  const float* Ap = A + (kb + kq) * lda + m0 + 4 * c16;
+  constexpr int BV = 8 * NB;                      // float4 per panel row
+  const bool b_loader = tid < 16 * BV;
+  const int brow = tid / BV, bc4 = tid % BV;
+  const float* Bp = B + (kb + brow) * (int64_t)ldb + bcol0 + 4 * bc4;
+
+  f32x4 a0[4], a1[4];
+  f32x4 bn = {0.f, 0.f, 0.f, 0.f};
+#define EOFX_LOAD_SLAB(areg, chunk)                                                              \
+  do {                                                                                           \
+    if (b_loader) bn = *reinterpret_cast<const f32x4*>(Bp + (int64_t)(chunk) * ATB_KC * ldb);   \
+    const float* pa_ = Ap + (int64_t)(chunk) * ATB_KC * lda;                                     \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) areg[s] =                                      \
+        __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(pa_ + (int64_t)(4 * s) * lda)); \
+  } while (0)
+#define EOFX_STORE_B(buf)                                                                        \
+  do {                                                                                           \
+    if (b_loader) {                                                                              \
+      double* d_ = &Bs[buf][brow][4 * bc4];                                                      \
+      d_[0] = (double)bn[0]; d_[1] = (double)bn[1]; d_[2] = (double)bn[2]; d_[3] = (double)bn[3]; \
+    }                                                                                            \
+  } while (0)
+#define EOFX_COMPUTE_SLAB(areg, buf)                                                             \
+  do {                                                                                           \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                              \
+      double b_[NT];                                                                             \
+      _Pragma("unroll") for (int q = 0; q < NT; ++q) b_[q] = Bs[buf][4 * s + kq][16 * q + c16];  \
+      _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                            \
+        const double a_ = (double)areg[s][t];                                                    \
+        _Pragma("unroll") for (int q = 0; q < NT; ++q)                                           \
+            acc[t][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, b_[q], acc[t][q], 0, 0, 0);     \
+      }                                                                                          \
+    }                                                                                            \
+  } while (0)
+
+  if (nchunks > 0) {
+    EOFX_LOAD_SLAB(a0, 0);
+    EOFX_STORE_B(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; c += 2) {
+      EOFX_LOAD_SLAB(a1, c + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      EOFX_COMPUTE_SLAB(a0, 0);
+      EOFX_STORE_B(1);
+      __syncthreads();
+      const int c2 = (c + 2 < nchunks) ? c + 2 : c + 1;
+      EOFX_LOAD_SLAB(a0, c2);
+      __builtin_amdgcn_sched_barrier(0);
+      EOFX_COMPUTE_SLAB(a1, 1);
+      EOFX_STORE_B(0);
+      __syncthreads();
+    }
+  }
+#undef EOFX_LOAD_SLAB
+#undef EOFX_COMPUTE_SLAB
+#undef EOFX_STORE_B
+
+  // D layout of the f64 16x16 MFMA: col = lane % 16, row = lane / 16 + 4 * reg; A row i of sub-tile t is column 4 i + t
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int q = 0; q < NT; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = kq + 4 * r;
+        const int64_t m = m0 + 4 * i + t;
+        const int64_t o = m * ldc + bcol0 + 16 * q + c16;
+        if (Cd)
+          Cd[(int64_t)blockIdx.y * M * ldc + o] = acc[t][q][r];
+        else
+          C[o] = (float)acc[t][q][r];
+      }
+}
+
+// out[i] = (float) sum_s part[s][i] over float64 partials, fixed order
+__global__ __launch_bounds__(256) void splitk_reduce_f64_kernel(const double* __restrict__ part, float* __restrict__ out,
+                                                                int64_t count, int splits) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+    double s = 0.0;
+    for (int k = 0; k < splits; ++k) s += part[(int64_t)k * count + i];
+    out[i] = (float)s;
+  }
+}
+
 // out[i] = sum_s part[s][i], fixed order, float64 accumulate.  count4 = elements / 4.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part,
                                                             float* __restrict__ out,
@@ -606,7 +725,6 @@ __global__ __launch_bounds__(256) void gram_f64_kernel(const float* __restrict__
 //   products a[qa] x b[qb]: lane c of "column group" q stands for column 4 c + q, so tile (qa, qb) holds
 //   G[64 bi + 4 i + qa][64 bj + 4 j + qb].  Products and sums are exact float64 (inputs are float32).
 // ---------------------------------------------------------------------------------
-typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256) void gram_mfma_kernel(const float* __restrict__ P, int64_t rows, int L,
                                                          double* __restrict__ Gpart) {

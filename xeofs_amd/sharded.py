@@ -121,12 +121,26 @@ def _resolve_sketch(k, r, n_oversamples, omega, random_state):
     return omega, l
 
 
-ORTH_TALL_BYTES = 16 << 20     # EOFX_ORTH_TALL_BYTES of csrc/eofx_abi.hip
+def _orth_tall(tall_total: int, L: int, prec_power: str = "f16x3") -> bool:
+    """the rule of `rsvd_core` (eofx_orth_tall_rule, one definition in the C library): re-normalise the tall panel
+    inside the power iterations while that is cheap, and always in the float64 mode"""
+    from . import _lib
+
+    rows_pad = (int(tall_total) + 511) // 512 * 512
+    return bool(_lib.load().eofx_orth_tall_rule(rows_pad, int(L), _lib.PREC[prec_power]))
 
 
-def _orth_tall(tall_total: int, L: int) -> bool:
-    """the rule of `rsvd_core`: re-normalise the tall panel inside the power iterations while that is cheap"""
-    return ((int(tall_total) + 511) // 512 * 512) * L * 4 <= ORTH_TALL_BYTES
+def _peaked(G, l: int) -> bool:
+    """eofx_peaked_spectrum on the (globally reduced) small-side Gram matrix of the first iteration"""
+    from . import _lib
+
+    Gh = np.ascontiguousarray(G.detach().cpu().numpy() if hasattr(G, "detach") else np.asarray(G), dtype=np.float64)
+    return bool(_lib.load().eofx_peaked_spectrum(_lib.ptr(Gh), int(Gh.shape[1]), int(l)))
+
+
+def _prec_power(ops) -> str:
+    ctx = getattr(ops, "ctx", None)
+    return getattr(ctx, "precision", ("f16x3", "f16x3"))[0]
 
 
 def _rsvd_panels(la, to_tall, to_small, gram_small, gram_tall, Z, l, k, n_iter, orth_tall=False):
@@ -137,12 +151,16 @@ def _rsvd_panels(la, to_tall, to_small, gram_small, gram_tall, Z, l, k, n_iter, 
     that side, `la` supplies the matrix-independent steps (cholqr, matmul, eigh).  Returns the
     singular-vector panels (tall side, small side) and the k singular values (float64).
     """
-    for _ in range(int(n_iter)):
+    orth_rest = bool(orth_tall)
+    for it in range(int(n_iter)):
         Yt = to_tall(Z, False)
-        if orth_tall:
+        if it == 0 or orth_rest:       # the first iteration always re-normalises the tall panel (rsvd_core)
             Yt = la.cholqr(Yt, l, gram_tall(Yt))
         W = to_small(Yt, False)
-        Z = la.cholqr(W, l, gram_small(W))
+        Gs = gram_small(W)
+        if it == 0 and not orth_tall and int(n_iter) > 1:   # peaked spectrum?  same rule, same code as the C++ driver
+            orth_rest = _peaked(Gs, l)
+        Z = la.cholqr(W, l, Gs)
     Yt = to_tall(Z, False)                       # range basis: a subspace only, power-pass precision
     Q = la.cholqr(Yt, l, gram_tall(Yt))
     Q = la.cholqr(Q, l, gram_tall(Q))            # CholeskyQR2
@@ -210,7 +228,7 @@ def sharded_rsvd(ops, comm: Comm, k: int, p_total: int, p_offset: int, n_oversam
 
     Tv, Sv, s = _rsvd_panels(ops, lambda P, f: to_side(P, tall, f), lambda P, f: to_side(P, small, f),
                              lambda P: gram(P, small), lambda P: gram(P, tall), Z, l, k, n_iter,
-                             _orth_tall(n if tall == "n" else p_total, Z.shape[1]))
+                             _orth_tall(n if tall == "n" else p_total, Z.shape[1], _prec_power(ops)))
     Vp, Up = (Tv, Sv) if transposed else (Sv, Tv)
     sign = _sign_from_extrema(comm, ops, Vp, p_loc, k) if flip else None
     if device_out:   # results stay in HBM (torch tensors); nothing crosses PCIe
@@ -254,11 +272,11 @@ def sharded_crosscov_rsvd(opsx, opsy, comm: Comm, k: int, p1_total: int, p1_offs
 
     if transposed:       # A = C^T (p2 x p1): small side = p1 (X's features)
         Z = opsx.import_panel(omega[p1_offset:p1_offset + opsx.p], "p")
-        Tv, Sv, s = _rsvd_panels(opsx, ct_mul, c_mul, gram, gram, Z, l, k, n_iter, _orth_tall(p2_total, Z.shape[1]))
+        Tv, Sv, s = _rsvd_panels(opsx, ct_mul, c_mul, gram, gram, Z, l, k, n_iter, _orth_tall(p2_total, Z.shape[1], _prec_power(opsx)))
         Q1p, Q2p = Sv, Tv
     else:                # A = C (p1 x p2): small side = p2 (Y's features)
         Z = opsy.import_panel(omega[p2_offset:p2_offset + opsy.p], "p")
-        Tv, Sv, s = _rsvd_panels(opsx, c_mul, ct_mul, gram, gram, Z, l, k, n_iter, _orth_tall(p1_total, Z.shape[1]))
+        Tv, Sv, s = _rsvd_panels(opsx, c_mul, ct_mul, gram, gram, Z, l, k, n_iter, _orth_tall(p1_total, Z.shape[1], _prec_power(opsx)))
         Q1p, Q2p = Tv, Sv
     sign = _sign_from_extrema(comm, opsy, Q2p, opsy.p, k) if flip else None
     out = dict(s=(s / (n - 1)).astype(np.float32), Q1=opsx.export(Q1p, opsx.p, k, sign),
