@@ -39,6 +39,7 @@ sys.path.insert(0, ROOT)
 
 N_OVERSAMPLES = 10
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_F64_MFMA_TFLOPS = 78.6    # v_mfma_f64_16x16x4_f64 dense peak
 PEAK_HBM_GBPS = 8000.0
 READ_CEILING_GBPS = 6835.0   # measured: 16 B non-temporal streaming read of 41.5 GB, 16384 workgroups
 
@@ -118,9 +119,10 @@ def main():
     ap.add_argument("--nlat", type=int, default=720)
     ap.add_argument("--nlon", type=int, default=1440)
     ap.add_argument("--modes", type=int, default=50)
-    ap.add_argument("--precision", choices=["f16x3", "f32", "bf16"], default="f16x3",
+    ap.add_argument("--precision", choices=["f16x3", "f32", "bf16", "f64"], default="f16x3",
                     help="f16x3 = scaled split-fp16 MFMA on every pass (default); bf16 = bf16x3 power passes + bf16x6 "
-                         "projection pass; f32 = exact-f32 MFMA")
+                         "projection pass; f32 = exact-f32 MFMA; f64 = float64 multiply-accumulate on the fp64 matrix cores "
+                         "(the accuracy mode for peaked spectra)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="diagnostic: run the multi-GPU orchestration (panel-level ABI + RCCL collectives) even at "
                          "world size 1")
@@ -182,7 +184,7 @@ def main():
     P = args.nlat * args.nlon
     lo, hi = sharded.shard_bounds(P, world, rank)
     ctx = engine.Context(local_rank)
-    ctx.set_precision(*{"f16x3": ("f16x3", "f16x3"), "f32": ("f32", "f32"), "bf16": ("bf16x3", "bf16x6")}[args.precision])
+    ctx.set_precision(*{"f16x3": ("f16x3", "f16x3"), "f32": ("f32", "f32"), "bf16": ("bf16x3", "bf16x6"), "f64": ("f64", "f64")}[args.precision])
     comm = sharded.Comm(force=args.force_sharded)
 
     t0 = time.perf_counter()
@@ -281,11 +283,13 @@ def main():
             pmc_traffic = None
     alg_bytes_launch = n * (hi - lo) * 4.0                        # one pass streams the f32 matrix once
     achieved_gbps = alg_bytes_launch / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
-    if args.precision == "f32":
+    if args.precision in ("f32", "f64"):
+        pk = PEAK_F32_MFMA_TFLOPS if args.precision == "f32" else PEAK_F64_MFMA_TFLOPS
         roofline = {
-            "kernel": "atb_f32_kernel<2> (C = A^T B, exact-f32 MFMA 32x32x2)",
-            "bound": "mfma", "achieved": round(achieved_tflops, 3), "peak": PEAK_F32_MFMA_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(achieved_tflops / PEAK_F32_MFMA_TFLOPS, 4),
+            "kernel": ("atb_f32_kernel<2> (C = A^T B, exact-f32 MFMA 32x32x2)" if args.precision == "f32" else
+                       "atb_f64_kernel<2> (C = A^T B, float64 MFMA 16x16x4 on the float32 data and panel)"),
+            "bound": "mfma", "achieved": round(achieved_tflops, 3), "peak": pk,
+            "unit": "TFLOP/s", "frac": round(achieved_tflops / pk, 4),
         }
     else:
         roofline = {
@@ -377,7 +381,7 @@ def main():
             "value": round(alg_bytes / (ms_step * 1e-3) / 1e9, 2), "unit": "GB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32" if args.precision == "f32" else "f32 data, split-" + ("fp16" if args.precision == "f16x3" else "bf16")
+            "dtype": "f32" if args.precision == "f32" else "f32 data, f64 multiply-accumulate" if args.precision == "f64" else "f32 data, split-" + ("fp16" if args.precision == "f16x3" else "bf16")
                      + " MFMA (" + "+".join(ctx.precision) + "), f32 accumulate",
             "data": "synthetic",
             "config": {"workload": f"xe.single.EOF n_modes={k} on synthetic fp32 {n}x({args.nlat}x{args.nlon}), "

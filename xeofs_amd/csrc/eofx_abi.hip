@@ -764,6 +764,8 @@ extern "C" int eofx_mat_destroy(eofx_ctx* ctx, eofx_mat* m) {
   const size_t bytes = (size_t)m->n_pad * m->p_pad * sizeof(float);
   if (ctx) {
     (void)hipSetDevice(ctx->device);
+    // launch_apply queues a copy INTO this struct (m->absmax): nothing may still be in flight when it goes away
+    (void)hipStreamSynchronize(ctx->stream);
     // same-stream reuse is ordered; nothing else touches these buffers
     if (m->X) pool_give(ctx, m->X, bytes);
     pool_give(ctx, m->Xt, bytes);

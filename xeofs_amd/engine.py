@@ -297,6 +297,9 @@ def rsvd(ctx: Context, mat: ResidentMatrix, k: int, n_oversamples: int = 10, n_i
 
 def project(ctx: Context, mat: ResidentMatrix, V) -> np.ndarray:
     V = _f32c(V)
+    if V.ndim != 2 or V.shape[0] != mat.p:
+        raise ValueError(f"components have {V.shape[0] if V.ndim == 2 else V.shape} features, the matrix has {mat.p} "
+                         "(a different NaN pattern in the new data?)")
     k = V.shape[1]
     out = np.empty((mat.n, k), np.float32)
     raise_for(ctx.lib.eofx_project_f32(ctx.handle, mat.handle, ptr(V), k, ptr(out)), ctx.handle)
@@ -305,6 +308,8 @@ def project(ctx: Context, mat: ResidentMatrix, V) -> np.ndarray:
 
 def reconstruct(ctx: Context, S, V) -> np.ndarray:
     S, V = _f32c(S), _f32c(V)
+    if S.ndim != 2 or V.ndim != 2 or S.shape[1] != V.shape[1]:
+        raise ValueError(f"scores {S.shape} and components {V.shape} do not have the same number of modes")
     n, k = S.shape
     p = V.shape[0]
     out = np.empty((n, p), np.float32)
@@ -321,6 +326,11 @@ def crosscov_rsvd(ctx: Context, x: ResidentMatrix, y: ResidentMatrix, k: int, n_
     if omega is None:
         omega = sketch_matrix(small, k + n_oversamples, random_state)
     omega = np.ascontiguousarray(omega, dtype=np.float32)
+    if omega.shape != (small, k + n_oversamples):
+        raise ValueError(f"omega must have shape {(small, k + n_oversamples)}")
+    if x.n != y.n:
+        raise ValueError(f"Both data matrices must have the same number of samples but found {x.n} in the first and "
+                         f"{y.n} in the second.")
     n = x.n
     Q1 = np.empty((x.p, k), np.float32)
     Q2 = np.empty((y.p, k), np.float32)

@@ -42,7 +42,7 @@ class EOFBootstrapper(EOF):
         self.sample_dims = getattr(model, "sample_dims", None)
         mat = model.data["input_data"]
         n, p = mat.n, mat.p
-        k = int(model.get_params()["n_modes"])
+        k = int(np.asarray(model.data["components"]).shape[1])     # the fitted number of modes (n_modes may be a variance target)
         n_boot = int(self._params["n_bootstraps"])
         rng = np.random.default_rng(self._params["seed"])
         expvar = np.empty((n_boot, k))
