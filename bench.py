@@ -272,7 +272,7 @@ def main():
     launch_ms = prof["ms"] / max(prof["launches"], 1)
     achieved_tflops = alg_flops_launch / (launch_ms * 1e-3) / 1e12 if launch_ms > 0 else 0.0
     pmc_traffic = None
-    tfile = os.path.join(ROOT, "profiles", "r01_atb_hbm_traffic.json")
+    tfile = os.path.join(ROOT, "profiles", "r02_atb_hbm_traffic.json")
     if os.path.exists(tfile):
         try:
             with open(tfile) as f:
@@ -293,7 +293,8 @@ def main():
         }
     else:
         roofline = {
-            "kernel": ("atb_f16_kernel<2> (C = A^T B, scaled split-fp16 MFMA 32x32x16, all 16 passes)"
+            "kernel": ("atb_f16_kernel<2, true|false> (C = A^T B, scaled split-fp16 MFMA 32x32x16, all 16 passes: 8 over the raw field "
+                       "through the Scaler map, 8 over the sample-contiguous layout; mean over all)"
                        if args.precision == "f16x3" else
                        "atb_bf16_kernel<2,PARTS> (C = A^T B, split-bf16 MFMA 32x32x16: 15 launches bf16x3 + 1 launch "
                        "bf16x6 per fit; mean over all 16)"),
