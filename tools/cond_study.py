@@ -1,8 +1,11 @@
-"""The float32 limit of the engine as a function of the spectrum's peakedness: GPU singular values (k = 40 modes,
-36 of them in the unconverged noise bulk) against the float64 oracle for growing leading-mode amplitudes.  The error
-follows eps_f32 * sigma_1 / sigma_k whatever the normalisation inside the iterations (re-normalising the tall
-panel, eigen-aligned "SVQB" bases: no change) -- panels are stored and accumulated in float32, the reference works
-in float64."""
+"""Accuracy of the engine as a function of the spectrum's peakedness: GPU singular values (k = 40 modes, 36 of them
+in the unconverged noise bulk) against the float64 oracle for growing leading-mode amplitudes.
+
+Round-2 finding (replaces the round-1 reading of this sweep): without re-normalising the tall panel inside the
+iteration the error follows eps_f32 * sigma_1 / sigma_k; with it (EOFX_FORCE_ORTH_TALL=1, or the adaptive rule the
+drivers now apply: eofx_orth_tall_rule + eofx_peaked_spectrum) the default passes stay within 1e-5 up to
+sigma_1 / sigma_k = 4e4.  Run with EOFX_FORCE_ORTH_TALL=0 / 1 / unset to see the three curves; a test-side study,
+like the fuzz_* sweeps it uses the oracle as the checker."""
 import sys, os, subprocess, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
