@@ -129,9 +129,11 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for "
                     "functional tests of the multi-rank path on a single GPU together with --same-gpu)")
     ap.add_argument("--same-gpu", action="store_true", help="functional test: all ranks share cuda:0")
-    ap.add_argument("--two-layouts", action="store_true",
-                    help="write both layouts of the preprocessed matrix (round-1 behaviour) instead of streaming the raw "
-                         "field through the Scaler map in the X^T Z passes")
+    ap.add_argument("--layout", choices=("inplace", "raw", "copy"), default="inplace",
+                    help="inplace: the preprocessor writes nothing, both products stream the field where it lies through "
+                         "the Scaler map; raw: only the sample-contiguous layout is written (X^T Z streams the field); "
+                         "copy: both layouts of the preprocessed matrix are written (round-1 behaviour)")
+    ap.add_argument("--two-layouts", action="store_true", help="same as --layout copy")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f64-baseline", action="store_true",
                     help="skip the float64 CPU leg (config-2 shape: kernel level + whole oracle fit) and its 1e-5 parity gate")
@@ -199,6 +201,11 @@ def main():
         torch.cuda.synchronize()
 
     phase = {"pre": 0.0, "svd": 0.0}
+    if args.two_layouts:
+        args.layout = "copy"
+    if args.precision != "f16x3":
+        args.layout = "copy"     # the in-place / raw views exist for the split-fp16 passes only
+    layout_kw = {"keep_raw": args.layout == "raw", "in_place": args.layout == "inplace"}
 
     def step():
         a = time.perf_counter()
@@ -206,10 +213,10 @@ def main():
         omega = engine.SketchFuture(min(n, P), k + N_OVERSAMPLES, 5)
         if world == 1 and not args.force_sharded:
             mat, st = engine.preprocess(ctx, Xraw, center=True, standardize=False, feature_weights=None,
-                                        want_stats=False, keep_raw=not args.two_layouts)
+                                        want_stats=False, **layout_kw)
         else:   # + the global facts: valid-sample mask / isolated-NaN check, feature offsets, total variance
             mat, st = sharded.sharded_preprocess(ctx, Xraw, comm, center=True, standardize=False,
-                                                 feature_weights=None, want_stats=False, keep_raw=not args.two_layouts)
+                                                 feature_weights=None, want_stats=False, **layout_kw)
         torch.cuda.synchronize()
         b = time.perf_counter()
         if world == 1 and not args.force_sharded:
@@ -349,7 +356,7 @@ def main():
         if not args.no_f64_baseline:
             nb, nlat_b, nlon_b, kb = 5000, 360, 720, 50
             Xb = make_field(nb, nlat_b, nlon_b, 0, nlat_b * nlon_b, device)
-            mat_b, _ = engine.preprocess(ctx, Xb, want_stats=False, keep_raw=not args.two_layouts)
+            mat_b, _ = engine.preprocess(ctx, Xb, want_stats=False, **layout_kw)
             Ub, sb, Vb = engine.rsvd(ctx, mat_b, kb, N_OVERSAMPLES, "auto", random_state=5)
             mat_b.free()
             Xb64 = Xb.cpu().numpy().astype(np.float64)

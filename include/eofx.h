@@ -146,18 +146,24 @@ int eofx_mat_shape(const eofx_mat *m, int64_t *n, int64_t *p, int64_t *n_pad, in
 int eofx_mat_download_f32(eofx_ctx *ctx, const eofx_mat *m, float *dst);
 
 /* ---- layout policy -------------------------------------------------------
- * A resident matrix normally holds the preprocessed field twice (feature- and sample-contiguous).  With keep_raw = 1
- * eofx_preprocess_f32 / eofx_apply_f32 write the sample-contiguous layout only whenever nothing is dropped (no all-NaN
- * feature or sample) and the raw field is 16-byte aligned with P % 4 == 0: the products that stream the
- * feature-contiguous layout (X^T Z) then read the RAW field and apply the Scaler map
- * (xeofs/preprocessing/scaler.py:153, (x - mean) / std * weights) on the fly -- one third less traffic in the
- * preprocessor, one layout less in HBM.  A DEVICE field handed to the preprocessor must stay alive and unmodified
- * until eofx_mat_release_raw or eofx_mat_destroy (a host field is staged and owned by the matrix).  After the release --
- * or for passes in another precision than EOFX_PREC_F16X3 -- the feature-contiguous layout is rebuilt on demand
- * from the sample-contiguous one.                                                                              */
-int eofx_ctx_set_layout(eofx_ctx *ctx, int keep_raw);
+ * mode 0  a resident matrix holds the preprocessed field twice (feature- and sample-contiguous): every pass streams a
+ *         plain float32 matrix.
+ * mode 1  ("raw") eofx_preprocess_f32 / eofx_apply_f32 write the sample-contiguous layout only: the products that stream
+ *         the feature-contiguous layout (X^T Z) read the RAW field and apply the Scaler map
+ *         (xeofs/preprocessing/scaler.py:153, (x - mean) / std * weights) on the fly -- one third less traffic in the
+ *         preprocessor, one layout less in HBM.
+ * mode 2  ("in place") nothing is written: the preprocessor is the statistics pass alone, X^T Z streams the field as in
+ *         mode 1 and X Y streams it along its rows (axb_f16_kernel) -- the field is read where it lies, 1x its size in
+ *         HBM instead of 3x.  Entry points that need a layout (other precisions than EOFX_PREC_F16X3, the Hilbert
+ *         transform, Gram matrices, download, resampling) build it on demand from the field through the same map.
+ * Modes 1 and 2 apply whenever nothing is dropped (no all-NaN feature or sample) and the raw field is 16-byte aligned
+ * with P % 4 == 0; otherwise mode 0 is used silently.  A DEVICE field handed to the preprocessor must stay alive and
+ * unmodified until eofx_mat_release_raw (which first builds what only the field could provide) or eofx_mat_destroy; a
+ * host field is staged and owned by the matrix.  eofx_mat_layout: bit 0 / bit 1 of *layouts = feature- /
+ * sample-contiguous layout present.                                                                              */
+int eofx_ctx_set_layout(eofx_ctx *ctx, int mode);
 int eofx_mat_release_raw(eofx_ctx *ctx, eofx_mat *m);
-int eofx_mat_layout(const eofx_mat *m, int *has_feature_contiguous, int *has_raw);
+int eofx_mat_layout(const eofx_mat *m, int *layouts, int *has_raw);
 
 /* ---- randomized SVD (the decomposer seam) ------------------------------
  * Replaces randomized_svd(X, n_components=k, random_state) at decomposer.py:146.

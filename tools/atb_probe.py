@@ -9,8 +9,11 @@ n, p, L = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 5
 ctx = engine.Context(0)
 X = torch.randn((n, p), device="cuda", dtype=torch.float32)
-mat = engine.from_dense(ctx, X)
-del X
+if os.environ.get("PROBE_LAYOUT", "") in ("raw", "inplace"):   # the raw view / in-place kernels (f16x3 only)
+    mat, _ = engine.preprocess(ctx, X, center=True, want_stats=False, keep_raw=True, in_place=os.environ["PROBE_LAYOUT"] == "inplace")
+else:
+    mat = engine.from_dense(ctx, X)
+    del X
 Z = torch.randn((mat.n_pad, L), device="cuda"); Z[n:] = 0
 Y = torch.randn((mat.p_pad, L), device="cuda"); Y[p:] = 0
 precs = sys.argv[5].split(",") if len(sys.argv) > 5 else ["f32", "bf16x3", "bf16x6"]

@@ -50,7 +50,8 @@ struct eofx_ctx {
   std::vector<HilbertSetup> hsetups;
   // cached hipFFT plans of the Hilbert stage: key = (P, batch) -> (R2C plan, C2R plan)
   std::vector<std::pair<std::pair<int64_t, int64_t>, std::pair<void*, void*>>> fft_plans;
-  // 1: preprocessing keeps a reference to the raw field instead of writing the feature-contiguous layout
+  // layout policy of the next preprocess / apply (eofx_ctx_set_layout): 0 = write both layouts, 1 = keep a reference to
+  // the raw field instead of the feature-contiguous layout, 2 = in place: write nothing, both products stream the field
   int keep_raw = 0;
   // optional per-launch timing of the dominant kernel (atb_f32) with HIP events on `stream`
   bool profile = false;
@@ -62,7 +63,7 @@ struct eofx_ctx {
 struct eofx_mat {
   int64_t n = 0, p = 0, n_pad = 0, p_pad = 0;
   float* X = nullptr;   // [n_pad x p_pad]; absent in raw mode until something needs it (ensure_X)
-  float* Xt = nullptr;  // [p_pad x n_pad]
+  float* Xt = nullptr;  // [p_pad x n_pad]; absent in in-place mode until something needs it (ensure_Xt)
   // raw mode (eofx_ctx_set_layout): the feature-contiguous layout is the caller's RAW field [n x p] (or the staged copy
   // of a host field, owned here) read through the affine preprocessing map aff = {shift[p_pad], scale[p_pad]}
   const float* raw = nullptr;
@@ -386,9 +387,40 @@ static AtbPlan atb_plan(int64_t M, int64_t K, int L) {
   }
   return best;
 }
+// axb_f16_kernel (the in-place sample-side product): rows_pad / 256 row tiles x S feature splits.  S = 1 when the row
+// tiles alone fill the chip, otherwise a multiple of 8 (one split per XCD at a time) from the same kind of cost model.
+static AtbPlan axb_plan(int64_t rows_pad, int64_t K) {
+  const int64_t rt = rows_pad / AXB_BM;
+  const int64_t units = K / AXB_KG;
+  if (rt >= 1024 || units < 16) return {1, K};
+  if (const char* ev = std::getenv("EOFX_AXB_SPLITS")) {   // tuning hook (tools/atb_probe.py)
+    const int want = std::max(8, atoi(ev) / 8 * 8);
+    const int64_t kps = round_up((units + want - 1) / want, 1) * AXB_KG;
+    return {(int)((K + kps - 1) / kps), kps};
+  }
+  AtbPlan best{1, K};
+  double best_t = 1e30;
+  for (int s8 = 1; s8 <= 32 && 8 * s8 <= units; ++s8) {
+    const int S = 8 * s8;
+    const int64_t kps = (units + S - 1) / S * AXB_KG;
+    const int s_eff = (int)((K + kps - 1) / kps);
+    if (s_eff > S || s_eff <= S - 8) continue;
+    const double rounds = std::ceil((double)rt * s8 / 64.0);          // 64 resident workgroups per XCD
+    double t = rounds * (double)kps * 1024.0 / 1.25e10;               // 256 rows x 4 B per feature, ~12.5 GB/s per slot
+    t += (2.0 * s_eff + 1.0) * (double)rows_pad * 64.0 * 4.0 / 4.0e12;
+    if (t < best_t * 0.98) {
+      best_t = t;
+      best = {s_eff, kps};
+    }
+  }
+  return best;
+}
 static size_t atb_scratch_bytes(int64_t M, int64_t K, int L) {
   const AtbPlan pl = atb_plan(M, K, L);
-  return pl.S > 1 ? (size_t)pl.S * M * L * (sizeof(float) + sizeof(double)) + 4096 : 4096;   // f32 or f64 partials
+  size_t b = pl.S > 1 ? (size_t)pl.S * M * L * (sizeof(float) + sizeof(double)) + 4096 : 4096;   // f32 or f64 partials
+  const AtbPlan px = axb_plan(M, round_up(K, AXB_KG));      // in case M is the sample side of an in-place matrix
+  if (px.S > 1) b = std::max(b, (size_t)px.S * M * round_up(L, 64) * sizeof(float) + 4096);
+  return b;
 }
 
 // C[M x L] = A[K x M]^T B[K x L]; M multiple of 512, K multiple of 16, L multiple of 32.
@@ -531,6 +563,68 @@ static int launch_atb(eofx_ctx* ctx, const float* A, int64_t lda, int64_t K, int
   return EOFX_OK;
 }
 
+
+// W[n_pad x L] = X' Y with X' = the raw field [rows x cols] (ld) through the affine map, read in place (axb_f16_kernel).
+// Y: [>= round_up(cols, 64) x L] panel whose rows >= cols are zero.  L a multiple of 32.
+static int launch_axb(eofx_ctx* ctx, const float* raw, int64_t ld, int64_t rows, int64_t cols, int64_t rows_pad,
+                      const float* aff, int64_t aff_ld, float a_absmax, const float* Y, int L, float* W) {
+  const int64_t K = round_up(cols, AXB_KG);
+  if (L % 32 || L <= 0 || rows_pad % AXB_BM || rows >= ((int64_t)1 << 31) || K * L >= ((int64_t)1 << 31) ||
+      64 * ld + K >= ((int64_t)1 << 30))     // the kernel's 32-bit offsets
+    return set_err(ctx, EOFX_ERR_ARG, "axb: bad geometry rows=%lld cols=%lld L=%d", (long long)rows, (long long)cols, L);
+  const AtbPlan plan = axb_plan(rows_pad, K);
+  const int rt = (int)(rows_pad / AXB_BM);
+  const int nfull = L / 64, rem = L % 64;
+  ArenaScope scope(ctx);
+  float* out = W;
+  if (plan.S > 1) {
+    out = arena_alloc<float>(ctx, (size_t)plan.S * rows_pad * L);
+    if (!out) return set_err(ctx, EOFX_ERR_NOMEM, "arena exhausted (in-place product partials)");
+  }
+  float a_scale = 1.f;
+  if (a_absmax > 0.f && std::isfinite(a_absmax)) {
+    int e;
+    (void)std::frexp(a_absmax, &e);
+    a_scale = std::ldexp(1.f, 14 - e);
+  }
+  unsigned* bm = arena_alloc<unsigned>(ctx, 1);
+  if (!bm) return set_err(ctx, EOFX_ERR_NOMEM, "arena exhausted (panel max)");
+  HIPCHK(hipMemsetAsync(bm, 0, sizeof(unsigned), ctx->stream));
+  const int64_t total4 = K * (L / 4);
+  hipLaunchKernelGGL(panel_absmax_kernel, dim3((int)std::max<int64_t>(1, std::min<int64_t>((total4 + 1023) / 1024, 1024))),
+                     dim3(256), 0, ctx->stream, Y, K, L, (int64_t)L, bm);
+  KCHK();
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (ctx->profile) {
+    HIPCHK(hipEventCreate(&ev0));
+    HIPCHK(hipEventCreate(&ev1));
+    HIPCHK(hipEventRecord(ev0, ctx->stream));
+  }
+  const int gx = plan.S > 1 ? 8 * rt * ((plan.S + 7) / 8) : rt;
+  if (nfull > 0) {
+    hipLaunchKernelGGL(axb_f16_kernel<4>, dim3(gx, nfull), dim3(256), 0, ctx->stream, raw, ld, (int)rows, cols, aff, aff_ld, Y, L, out,
+                       L, rows_pad, K, plan.kps, plan.S, rt, 0, a_scale, reinterpret_cast<const float*>(bm));
+    KCHK();
+  }
+  if (rem) {
+    hipLaunchKernelGGL(axb_f16_kernel<2>, dim3(gx, 1), dim3(256), 0, ctx->stream, raw, ld, (int)rows, cols, aff, aff_ld, Y, L, out,
+                       L, rows_pad, K, plan.kps, plan.S, rt, nfull * 64, a_scale, reinterpret_cast<const float*>(bm));
+    KCHK();
+  }
+  if (ctx->profile) {
+    HIPCHK(hipEventRecord(ev1, ctx->stream));
+    ctx->prof_events.emplace_back(ev0, ev1);
+    ctx->prof_flops += 2.0 * (double)K * (double)rows_pad * (double)L;
+    ctx->prof_bytes += (double)K * (double)rows * 4.0 * (nfull + (rem ? 1 : 0));
+  }
+  if (plan.S > 1) {
+    const int64_t count4 = rows_pad * L / 4;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)std::min<int64_t>((count4 + 255) / 256, 4096)), dim3(256), 0, ctx->stream,
+                       out, W, count4, plan.S);
+    KCHK();
+  }
+  return EOFX_OK;
+}
 
 // number of row-strided partial Gram matrices: >= 4 slabs of 32 rows per workgroup for the narrow
 // (sketch-width) panels; wide panels already expose (L/64)^2 sub-blocks, so fewer partials (<= 64 MB)
@@ -736,7 +830,7 @@ extern "C" int eofx_ctx_trim(eofx_ctx* ctx) {
   return EOFX_OK;
 }
 
-static int mat_alloc(eofx_ctx* ctx, int64_t n, int64_t p, eofx_mat** out, bool want_x = true) {
+static int mat_alloc(eofx_ctx* ctx, int64_t n, int64_t p, eofx_mat** out, bool want_x = true, bool want_xt = true) {
   eofx_mat* m = new eofx_mat();
   m->n = n;
   m->p = p;
@@ -744,7 +838,7 @@ static int mat_alloc(eofx_ctx* ctx, int64_t n, int64_t p, eofx_mat** out, bool w
   m->p_pad = round_up(p, ATB_BM);
   const size_t bytes = (size_t)m->n_pad * m->p_pad * sizeof(float);
   hipError_t e = want_x ? pool_malloc(ctx, (void**)&m->X, bytes) : hipSuccess;
-  if (e == hipSuccess) e = pool_malloc(ctx, (void**)&m->Xt, bytes);
+  if (e == hipSuccess && want_xt) e = pool_malloc(ctx, (void**)&m->Xt, bytes);
   if (e == hipSuccess) e = pool_malloc(ctx, (void**)&m->absmax_dev, 256);
   if (e == hipSuccess) e = hipMemsetAsync(m->absmax_dev, 0, 256, ctx->stream);
   if (e != hipSuccess) {
@@ -768,7 +862,7 @@ extern "C" int eofx_mat_destroy(eofx_ctx* ctx, eofx_mat* m) {
     (void)hipStreamSynchronize(ctx->stream);
     // same-stream reuse is ordered; nothing else touches these buffers
     if (m->X) pool_give(ctx, m->X, bytes);
-    pool_give(ctx, m->Xt, bytes);
+    if (m->Xt) pool_give(ctx, m->Xt, bytes);
     pool_give(ctx, m->absmax_dev, 256);
     if (m->raw_owned) pool_give(ctx, m->raw_owned, m->raw_owned_bytes);
   } else {
@@ -826,10 +920,10 @@ static int launch_apply(eofx_ctx* ctx, const float* Xsrc, int64_t ld_src, const 
   const bool vec = !col_map && (ld_src % 4 == 0) && ((uintptr_t)Xsrc % 16 == 0);
   if (vec)
     hipLaunchKernelGGL(apply_kernel<true>, grid, dim3(256), 0, ctx->stream, Xsrc, ld_src, row_map, col_map,
-                       shift, scale, m->n, m->p, m->X, m->p_pad, m->Xt, m->n_pad, nan_flag, m->absmax_dev);
+                       shift, scale, m->n, m->p, m->X, m->p_pad, m->Xt, m->n_pad, nan_flag, (const float*)nullptr, (int64_t)0);
   else
     hipLaunchKernelGGL(apply_kernel<false>, grid, dim3(256), 0, ctx->stream, Xsrc, ld_src, row_map, col_map,
-                       shift, scale, m->n, m->p, m->X, m->p_pad, m->Xt, m->n_pad, nan_flag, m->absmax_dev);
+                       shift, scale, m->n, m->p, m->X, m->p_pad, m->Xt, m->n_pad, nan_flag, (const float*)nullptr, (int64_t)0);
   KCHK();
   if (absmax_src) {
     HIPCHK(hipMemcpyAsync(m->absmax_dev, absmax_src, sizeof(unsigned), hipMemcpyDeviceToDevice, ctx->stream));
@@ -844,10 +938,34 @@ static int launch_apply(eofx_ctx* ctx, const float* Xsrc, int64_t ld_src, const 
   return EOFX_OK;
 }
 
+// The sample-contiguous layout of an in-place matrix, built on demand: the raw field through the same affine map the
+// streaming kernels apply (apply_kernel with the packed float triples), or a tiled transpose of X.
+static int ensure_Xt(eofx_ctx* ctx, const eofx_mat* cm) {
+  eofx_mat* m = const_cast<eofx_mat*>(cm);
+  if (m->Xt) return EOFX_OK;
+  if (!m->X && !(m->raw && m->aff)) return set_err(ctx, EOFX_ERR_ARG, "matrix holds no data (raw field released?)");
+  const size_t bytes = (size_t)m->n_pad * m->p_pad * sizeof(float);
+  if (pool_malloc(ctx, (void**)&m->Xt, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    m->Xt = nullptr;
+    return set_err(ctx, EOFX_ERR_NOMEM, "cannot allocate the sample-contiguous layout (%.2f GB)", bytes / 1e9);
+  }
+  if (m->X) {
+    hipLaunchKernelGGL(transpose_kernel, dim3((int)(m->p_pad / 64), (int)(m->n_pad / 64)), dim3(256), 0, ctx->stream, m->X,
+                       m->p_pad, m->Xt, m->n_pad);
+  } else {
+    hipLaunchKernelGGL(apply_kernel<true>, dim3((int)(m->p_pad / 64), (int)(m->n_pad / 64)), dim3(256), 0, ctx->stream, m->raw,
+                       m->raw_ld, (const int64_t*)nullptr, (const int64_t*)nullptr, (const double*)nullptr, (const double*)nullptr,
+                       m->n, m->p, (float*)nullptr, m->p_pad, m->Xt, m->n_pad, (int*)nullptr, (const float*)m->aff, m->p_pad);
+  }
+  KCHK();
+  return EOFX_OK;
+}
 // The feature-contiguous layout of a raw-mode matrix, built on demand from the sample-contiguous one (tiled transpose).
 static int ensure_X(eofx_ctx* ctx, const eofx_mat* cm) {
   eofx_mat* m = const_cast<eofx_mat*>(cm);
   if (m->X) return EOFX_OK;
+  CHK(ensure_Xt(ctx, m));
   const size_t bytes = (size_t)m->n_pad * m->p_pad * sizeof(float);
   if (pool_malloc(ctx, (void**)&m->X, bytes) != hipSuccess) {
     (void)hipGetLastError();
@@ -860,13 +978,14 @@ static int ensure_X(eofx_ctx* ctx, const eofx_mat* cm) {
   return EOFX_OK;
 }
 extern "C" int eofx_ctx_set_layout(eofx_ctx* ctx, int keep_raw) {
-  if (!ctx) return EOFX_ERR_ARG;
-  ctx->keep_raw = keep_raw ? 1 : 0;
+  if (!ctx || keep_raw < 0 || keep_raw > 2) return EOFX_ERR_ARG;
+  ctx->keep_raw = keep_raw;
   return EOFX_OK;
 }
 extern "C" int eofx_mat_release_raw(eofx_ctx* ctx, eofx_mat* m) {
   if (!ctx || !m) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
   CHK(set_device(ctx));
+  if (m->raw && !m->Xt && !m->X) CHK(ensure_Xt(ctx, m));   // in place: the field is the only copy -- materialise first
   HIPCHK(hipStreamSynchronize(ctx->stream));   // passes still reading the raw field
   if (m->raw_owned) pool_give(ctx, m->raw_owned, m->raw_owned_bytes);
   m->raw_owned = nullptr;
@@ -876,7 +995,7 @@ extern "C" int eofx_mat_release_raw(eofx_ctx* ctx, eofx_mat* m) {
 }
 extern "C" int eofx_mat_layout(const eofx_mat* m, int* has_x, int* has_raw) {
   if (!m) return EOFX_ERR_ARG;
-  if (has_x) *has_x = m->X != nullptr;
+  if (has_x) *has_x = (m->X != nullptr ? 1 : 0) | (m->Xt != nullptr ? 2 : 0);   // bit 0: feature-contiguous, bit 1: sample-contiguous
   if (has_raw) *has_raw = m->raw != nullptr;
   return EOFX_OK;
 }
@@ -1055,7 +1174,8 @@ static int sanitize_and_apply(eofx_ctx* ctx, const float* Xd, int64_t n, int64_t
   // affine map -- is the feature-contiguous layout; only the sample-contiguous one is written.  P < 2^31 rows: int.
   const bool raw_mode = ctx->keep_raw && pv == P && ns == n && P % 4 == 0 && ((uintptr_t)Xd % 16) == 0 && n < ((int64_t)1 << 31);
   eofx_mat* m = nullptr;
-  CHK(mat_alloc(ctx, ns, pv, &m, !raw_mode));
+  const bool in_place = raw_mode && ctx->keep_raw == 2;
+  CHK(mat_alloc(ctx, ns, pv, &m, !raw_mode, !in_place));
   int rc = EOFX_OK;
   if (raw_mode) {
     const size_t abytes = sizeof(float) * 3 * (size_t)m->p_pad;
@@ -1099,7 +1219,12 @@ static int sanitize_and_apply(eofx_ctx* ctx, const float* Xd, int64_t n, int64_t
     }
     if (!flag || (pv < P && !dcol) || (ns < n && !drow)) rc = set_err(ctx, EOFX_ERR_NOMEM, "arena exhausted (maps)");
     if (rc == EOFX_OK && hipMemsetAsync(flag, 0, sizeof(int), ctx->stream) != hipSuccess) rc = EOFX_ERR_HIP;
-    if (rc == EOFX_OK)
+    if (rc == EOFX_OK && in_place && !stats_absmax) rc = set_err(ctx, EOFX_ERR_ARG, "in-place layout needs the column statistics");
+    if (rc == EOFX_OK && in_place) {   // nothing to write: max |x'| comes from the column statistics
+      if (hipMemcpyAsync(m->absmax_dev, ps.absmax, sizeof(unsigned), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
+          hipMemcpyAsync(&m->absmax, m->absmax_dev, sizeof(float), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+        rc = EOFX_ERR_HIP;
+    } else if (rc == EOFX_OK)
       rc = launch_apply(ctx, Xd, P, drow, dcol, ps.shift, ps.scale, m, flag, stats_absmax ? ps.absmax : nullptr);
     if (rc == EOFX_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = EOFX_ERR_HIP;
   }
@@ -1261,6 +1386,11 @@ static int panel_tmul(eofx_ctx* ctx, const eofx_mat* m, const float* Zn, float* 
   return launch_atb(ctx, m->X, m->p_pad, round_up(m->n, ATB_KG), m->p_pad, Zn, L, L, Yp, prec, m->absmax);
 }
 static int panel_mul(eofx_ctx* ctx, const eofx_mat* m, const float* Yp, float* Wn, int L, int prec) {
+  if (!m->Xt && m->raw && m->aff && prec == EOFX_PREC_F16X3 &&
+      round_up(m->p, AXB_KG) * (int64_t)L < ((int64_t)1 << 31) &&
+      64 * m->raw_ld + round_up(m->p, AXB_KG) < ((int64_t)1 << 30))   // in place: stream the raw field along its rows
+    return launch_axb(ctx, m->raw, m->raw_ld, m->n, m->p, m->n_pad, m->aff, m->p_pad, m->absmax, Yp, L, Wn);
+  CHK(ensure_Xt(ctx, m));
   return launch_atb(ctx, m->Xt, m->n_pad, round_up(m->p, ATB_KG), m->n_pad, Yp, L, L, Wn, prec, m->absmax);
 }
 static bool valid_prec(int p) {
@@ -1320,6 +1450,7 @@ static hipError_t fused_launch(const FxParams& prm, hipStream_t st) {
 // Yp may be null.  Both outputs are complete when the call returns (it reads the kernel's status word).
 static int panel_fused(eofx_ctx* ctx, const eofx_mat* m, const float* Zn, float* Wn, float* Yp) {
   const int64_t npad = m->n_pad;
+  CHK(ensure_Xt(ctx, m));
   ArenaScope scope(ctx);
   const size_t e1_gran = (size_t)FX_GROUPS * FX_SLOTS * FX_MEMBERS * FX_TILE_GRAN;
   const size_t e2_gran = (size_t)FX_GROUPS * FX_SLOTS * FX_TILE_GRAN;
@@ -1741,6 +1872,7 @@ extern "C" int eofx_reconstruct_f32(eofx_ctx* ctx, const float* S, const float* 
 static int mat_gram(eofx_ctx* ctx, const eofx_mat* m, int side, float* G) {
   if (side == 0) {
     const int64_t npad = m->n_pad;
+    CHK(ensure_Xt(ctx, m));
     return launch_atb(ctx, m->Xt, npad, round_up(m->p, ATB_KG), npad, m->Xt, (int)npad, (int)npad, G, ctx->prec_final,
                       m->absmax, reinterpret_cast<const float*>(m->absmax_dev));
   }
@@ -2005,6 +2137,7 @@ extern "C" int eofx_hilbert_f32(eofx_ctx* ctx, const eofx_mat* a, int padding, d
   const cfloat* chat = nullptr;
   const float* u = nullptr;
   CHK(get_hilbert_setup(ctx, n, padding ? 1 : 0, padding ? decay_factor : 0.0, P, &chat, &u));
+  CHK(ensure_Xt(ctx, a));
   // features per FFT batch: real series + half spectrum of about 3 GB together
   int64_t Fc = std::max<int64_t>(1, std::min<int64_t>(p, (int64_t)(3.0e9 / (4.0 * (double)ldw + 8.0 * (double)nh))));
   eofx_mat *mi = nullptr, *mr = nullptr;
@@ -2282,7 +2415,7 @@ extern "C" int eofx_rsvd_c64(eofx_ctx* ctx, const eofx_mat* A, const eofx_mat* B
   if (n_iter < 0) n_iter = k < 0.1 * (double)r ? 7 : 4;
   const int h = l <= 32 ? 32 : 64, LP = 2 * h;
   const int ko = (int)round_up(k, 16), Lo = 2 * ko;       // output panels [Re(ko) | Im(ko)]
-  CHK(ensure_X(ctx, A));
+  CHK(ensure_X(ctx, A));   // (ensure_X builds the sample-contiguous layout first where that is missing too)
   CHK(ensure_X(ctx, B));
   const bool transposed = n < p;     // A_op = Z^H: tall side = features
   const int64_t small = transposed ? n : p;
@@ -2432,6 +2565,7 @@ extern "C" int eofx_mat_sumsq_f64(eofx_ctx* ctx, const eofx_mat* m, double* out)
   CHK(arena_reserve(ctx, nb * sizeof(double) + 4096));
   ArenaScope scope(ctx);
   ARENA(double, part, nb);
+  if (!m->X) CHK(ensure_Xt(ctx, m));
   const float* base = m->X ? m->X : m->Xt;   // the same elements (raw mode holds the sample-contiguous layout only)
   hipLaunchKernelGGL(dotprod_part_kernel, dim3(nb), dim3(256), 0, ctx->stream, base, base, m->n_pad * m->p_pad, part);
   KCHK();
@@ -2614,6 +2748,7 @@ extern "C" int eofx_mat_feature_norms_f64(eofx_ctx* ctx, const eofx_mat* m, doub
   if (!ctx || !m || !out) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
   CHK(set_device(ctx));
   CHK(arena_reserve(ctx, (size_t)m->p * sizeof(double) + 4096));
+  CHK(ensure_Xt(ctx, m));
   return launch_rownorm(ctx, m->Xt, m->p, m->n, m->n_pad, out);   // rows of X^T = features
 }
 

@@ -12,6 +12,7 @@ namespace eofx {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // The Scaler map (xeofs/preprocessing/scaler.py:153) in float32 arithmetic: (x - mean) * scale with the float64 mean
 // carried as a float pair, so the subtraction is exact whenever x and the mean are within a factor of two of each other
@@ -166,6 +167,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 // two f32 -> one dword of two RNE bf16 (lo in bits 0-15).  hipcc scalarises vector f32->bf16
 // conversions into one v_cvt_pk per element plus packing; the packed form halves the VALU work.
@@ -488,6 +490,254 @@ __global__ __launch_bounds__(256, 2) void atb_f16_kernel(const float* __restrict
         const int64_t m = m0 + 4 * ii + j;
         Cs[m * ldc + bcol0 + 32 * q + li] = acc[j][q][r] * out_scale;
       }
+}
+
+// ---------------------------------------------------------------------------------
+// axb_f16: C[M x 64] = A'[M x K] B[K x 64] with A the RAW field read IN PLACE (row-major: rows = samples,
+// the K = feature axis contiguous) and A' = aff_map(A) applied on the fly -- the sample-side product X Y of the power
+// iteration without a sample-contiguous copy of the matrix.  Same scaled split-fp16 scheme as atb_f16 (hh + hl + lh).
+//
+//   A  a wave owns 64 rows.  It streams them with fully coalesced non-temporal 16-byte loads (one instruction = 8 rows
+//      x one 128-byte line each: every line is touched exactly once and does not settle in L2, which stays free for
+//      the B slabs), maps + splits its 4 features per lane in registers -- a lane keeps the same 4 features of the slab
+//      for all 8 row groups, so its {shift hi, shift lo, scale} triples are three 16-byte loads per slab -- and
+//      transposes through a PRIVATE LDS region ([plane][row][32 halves], rows padded to 80 bytes: conflict-free
+//      16-byte reads in the operand layout of v_mfma_f32_16x16x32_f16).  Wave-private, so no workgroup barrier guards
+//      it.  (Loading in the operand layout directly -- one row per lane -- needs cached loads, the second touch of every
+//      line then relies on L1 and the stream evicts the B slabs from L2: 17 % more HBM traffic, measured.)
+//   B  32 x 64 slab through LDS as two fp16 planes [k-group][column][8], XOR-swizzled columns, written as packed
+//      pairs, shared by the 4 waves, double buffered.
+//   C  split-K partials [split][c_rows][ldc], reduced in fixed order by splitk_reduce_kernel.
+//
+//   grid = (8 * row_tiles * ceil(splits / 8), L/64); block = 256 = 4 waves x 64 rows.  Workgroup ids are dealt to the 8
+//   XCDs round-robin, so id -> (xcd = id % 8, slot = id / 8), split = xcd + 8 (slot / row_tiles), row tile = slot %
+//   row_tiles: all row tiles of one split run on ONE XCD and share its B slabs through that XCD's L2.
+//   Rows >= a_rows read the last row and write zeros; 16-byte feature chunks >= a_cols read chunk 0 (their scale is 0).
+// ---------------------------------------------------------------------------------
+constexpr int AXB_KC = 32;    // features per slab
+constexpr int AXB_KG = 64;    // K granularity: slabs are consumed in pairs
+constexpr int AXB_BM = 256;   // rows per workgroup
+constexpr int AXB_LDA = 40;   // halves per staged row (32 + 8 of padding)
+
+// DBG (tools/probes/axb_probe.hip only): 1 no MFMA, 2 no conversion either, 4 no B / map loads, 8 cached A loads
+template <int NQ, int DBG = 0>   // 16-column tiles per workgroup column block: 4 (64 columns) or 2 (a 32-column remainder)
+__global__ __launch_bounds__(256, 2) void axb_f16_kernel(const float* __restrict__ A, int64_t lda, int a_rows,
+                                                          int64_t a_cols, const float* __restrict__ aff, int64_t aff_ld,
+                                                          const float* __restrict__ B, int ldb, float* __restrict__ C,
+                                                          int ldc, int64_t c_rows, int64_t K, int64_t k_per_split,
+                                                          int splits, int row_tiles, int col_base, float a_scale,
+                                                          const float* __restrict__ b_absmax) {
+  __shared__ __attribute__((aligned(16))) _Float16 Bs[2][2][4][64][8];
+  __shared__ __attribute__((aligned(16))) _Float16 As[4][2][64][AXB_LDA];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: scalar branches below
+  const int ln = lane & 15, g = lane >> 4;
+  const int lr = lane >> 3, lc = lane & 7;   // loader view: row inside a group of 8, 16-byte chunk of the 128-byte line
+  const int slot_ = splits > 1 ? (int)blockIdx.x >> 3 : (int)blockIdx.x;
+  const int split = splits > 1 ? ((int)blockIdx.x & 7) + 8 * (slot_ / row_tiles) : 0;
+  if (split >= splits) return;
+  const int r0 = (slot_ % row_tiles) * AXB_BM + wave * 64;
+  const bool live = r0 < a_rows;
+  const bool full = r0 + 64 <= a_rows;
+  const unsigned ldab = (unsigned)lda * 4u;   // row pitch in bytes
+  const int64_t kb = (int64_t)split * k_per_split;
+  const int64_t ke = (kb + k_per_split < K) ? kb + k_per_split : K;
+  const int nslab = (int)((ke - kb) / AXB_KC);
+  const int bcol0 = col_base + blockIdx.y * 64;
+  const float b_scale = f16_scale_for(*b_absmax);
+  const float out_scale = 1.f / (a_scale * b_scale);   // exact: both are powers of two
+
+  f32x4 acc[4][NQ];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc[j][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // A: uniform base of the wave's row block + 32-bit byte offsets (the launcher guarantees 64 lda + K < 2^30 elements)
+  const char* const Ab = reinterpret_cast<const char*>(A + (int64_t)(live ? r0 : 0) * lda);
+  const int arow0 = live ? r0 : 0;     // dead waves stream the first rows (their results are discarded)
+  // 32-bit offsets from uniform bases for the small streams (the launcher guarantees K * ldb < 2^31)
+  const float* const aff1 = aff + aff_ld;
+  const float* const aff2 = aff + 2 * aff_ld;
+  const int fo = (int)kb + 4 * lc;
+  // B loader: two adjacent k rows, four columns: k = 2 kp, kp = (lane >> 4) | (wave << 2) -> k-group = wave
+  const int bc4 = tid & 15;
+  const int bk = 2 * ((lane >> 4) | (wave << 2));
+  const int bt = bk & 7;
+  const bool b_loader = bc4 < 4 * NQ;
+  const int bo = ((int)kb + bk) * ldb + bcol0 + 4 * (bc4 % (4 * NQ));
+
+  f32x4 a0[8], a1[8], f0[3], f1[3];
+  float m1 = -1.f;   // opaque to the optimiser: x - (float)h stays ONE v_fma_mix_f32 instead of a conversion and a subtraction
+  asm volatile("" : "+v"(m1));
+  f32x4 bn0 = {0.f, 0.f, 0.f, 0.f}, bn1 = bn0;
+#define EOFX_AXB_LD(p_) ((DBG & 8) ? *reinterpret_cast<const f32x4*>(p_) : __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p_)))
+  // Every thread issues the same loads on every path (the partial-tile branch issues as many as the full one): the
+  // compiler's vmcnt bookkeeping stays exact, and a wait for an older load leaves the younger ones in flight.
+#define EOFX_LOAD_B(chunk)                                                                             \
+  do {                                                                                                 \
+    if (!(DBG & 4)) {                                                                                  \
+      bn0 = *reinterpret_cast<const f32x4*>(B + (bo + (chunk) * AXB_KC * ldb));                        \
+      bn1 = *reinterpret_cast<const f32x4*>(B + (bo + (chunk) * AXB_KC * ldb + ldb));                  \
+    }                                                                                                  \
+  } while (0)
+#define EOFX_LOAD_F(freg, chunk)                                                                       \
+  do {                                                                                                 \
+    if (!(DBG & 4)) {                                                                                  \
+      freg[0] = *reinterpret_cast<const f32x4*>(aff + (fo + (chunk) * AXB_KC));                        \
+      freg[1] = *reinterpret_cast<const f32x4*>(aff1 + (fo + (chunk) * AXB_KC));                       \
+      freg[2] = *reinterpret_cast<const f32x4*>(aff2 + (fo + (chunk) * AXB_KC));                       \
+    }                                                                                                  \
+  } while (0)
+  // row groups u0 .. u0+3 (32 rows) of slab `chunk`
+#define EOFX_LOAD_A(areg, chunk, u0)                                                                   \
+  do {                                                                                                 \
+    const int ko_ = (chunk) * AXB_KC;                                                                  \
+    const bool kin_ = fo + ko_ < a_cols;                                                               \
+    const unsigned kof_ = kin_ ? (unsigned)(fo + ko_) * 4u : 0u;                                       \
+    if (full) {                                                                                        \
+      _Pragma("unroll") for (int u = (u0); u < (u0) + 4; ++u)                                          \
+          areg[u] = EOFX_AXB_LD(Ab + ((unsigned)(8 * u + lr) * ldab + kof_));                          \
+    } else {                                                                                           \
+      int lr_ = lr;   /* the one partial wave per split: recomputed per slab, nothing kept live */      \
+      asm volatile("" : "+v"(lr_));                                                                    \
+      _Pragma("unroll") for (int u = (u0); u < (u0) + 4; ++u) {                                        \
+        const int r_ = arow0 + lr_ + 8 * u < a_rows ? lr_ + 8 * u : a_rows - 1 - arow0;                \
+        areg[u] = EOFX_AXB_LD(Ab + ((unsigned)r_ * ldab + kof_));                                      \
+      }                                                                                                \
+    }                                                                                                  \
+  } while (0)
+#define EOFX_STORE_B(buf)                                                                              \
+  do {                                                                                                 \
+    if (b_loader) _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                      \
+      const int col_ = 4 * bc4 + e;                                                                    \
+      const int sl_ = col_ ^ ((col_ >> 3) & 7);                                                        \
+      const float v0_ = bn0[e] * b_scale, v1_ = bn1[e] * b_scale;                                      \
+      const fp16x2_t h_ = __builtin_amdgcn_cvt_pkrtz(v0_, v1_);                                        \
+      fp16x2_t l_;                                                                                     \
+      l_[0] = (__fp16)__builtin_fmaf((float)h_[0], m1, v0_);                                           \
+      l_[1] = (__fp16)__builtin_fmaf((float)h_[1], m1, v1_);                                           \
+      *reinterpret_cast<unsigned*>(&Bs[buf][0][wave][sl_][bt]) = __builtin_bit_cast(unsigned, h_);     \
+      *reinterpret_cast<unsigned*>(&Bs[buf][1][wave][sl_][bt]) = __builtin_bit_cast(unsigned, l_);     \
+    }                                                                                                  \
+  } while (0)
+  // map + split this lane's 4 features of row groups u0 .. u0+3 into the wave's LDS region
+#define EOFX_AXB_CONVERT(areg, u0)                                                                     \
+  _Pragma("unroll") for (int u = (u0); u < (u0) + 4; ++u) {                                            \
+    u32x2 hi_, lo_;                                                                                    \
+    if (DBG & 2) {                                                                                     \
+      hi_[0] = __float_as_uint(areg[u][0]); hi_[1] = __float_as_uint(areg[u][1]);                      \
+      lo_[0] = __float_as_uint(areg[u][2]); lo_[1] = __float_as_uint(areg[u][3]);                      \
+    } else {                                                                                           \
+      _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                  \
+        /* aff_map on a pair (packed float32 arithmetic: the same three roundings per element) */       \
+        const f32x2 x_ = {areg[u][2 * h], areg[u][2 * h + 1]};                                         \
+        const f32x2 v_ = ((x_ + fh_[h]) + fl_[h]) * fs_[h];   /* fh_, fl_ hold the NEGATED shift pair */ \
+        const fp16x2_t p_ = __builtin_amdgcn_cvt_pkrtz(v_[0], v_[1]);                                  \
+        const fp16x2_t q_ = __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf((float)p_[0], m1, v_[0]),        \
+                                                       __builtin_fmaf((float)p_[1], m1, v_[1]));        \
+        hi_[h] = __builtin_bit_cast(unsigned, p_);                                                     \
+        lo_[h] = __builtin_bit_cast(unsigned, q_);                                                     \
+      }                                                                                                \
+    }                                                                                                  \
+    *reinterpret_cast<u32x2*>(&As[wave][0][8 * u + lr][4 * lc]) = hi_;                                 \
+    *reinterpret_cast<u32x2*>(&As[wave][1][8 * u + lr][4 * lc]) = lo_;                                 \
+  }
+  // 32 rows (two 16-row tiles) x NQ column tiles: the three products ordered so that dependent MFMAs are 2 NQ apart
+#define EOFX_AXB_MFMA(jh, buf)                                                                         \
+  do {                                                                                                 \
+    f16x8 af_[2][2], bf_[2][NQ];                                                                       \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int s = 0; s < 2; ++s)        \
+        af_[j][s] = *reinterpret_cast<const f16x8*>(&As[wave][s][16 * (2 * (jh) + j) + ln][8 * g]);    \
+    _Pragma("unroll") for (int q = 0; q < NQ; ++q) {                                                   \
+      const int col_ = 16 * q + ln;                                                                    \
+      const int sl_ = col_ ^ ((col_ >> 3) & 7);                                                        \
+      bf_[0][q] = *reinterpret_cast<const f16x8*>(&Bs[buf][0][g][sl_][0]);                             \
+      bf_[1][q] = *reinterpret_cast<const f16x8*>(&Bs[buf][1][g][sl_][0]);                             \
+    }                                                                                                  \
+    if (DBG & 1) {                                                                                     \
+      _Pragma("unroll") for (int q = 0; q < NQ; ++q) _Pragma("unroll") for (int j = 0; j < 2; ++j)     \
+          _Pragma("unroll") for (int r = 0; r < 4; ++r) acc[2 * (jh) + j][q][r] +=                     \
+              (float)af_[j][0][r] + (float)af_[j][1][r + 4] + (float)bf_[0][q][r] + (float)bf_[1][q][r]; \
+    } else {                                                                                           \
+      _Pragma("unroll") for (int q = 0; q < NQ; ++q) _Pragma("unroll") for (int j = 0; j < 2; ++j)     \
+          acc[2 * (jh) + j][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af_[j][1], bf_[0][q], acc[2 * (jh) + j][q], 0, 0, 0); \
+      _Pragma("unroll") for (int q = 0; q < NQ; ++q) _Pragma("unroll") for (int j = 0; j < 2; ++j)     \
+          acc[2 * (jh) + j][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af_[j][0], bf_[1][q], acc[2 * (jh) + j][q], 0, 0, 0); \
+      _Pragma("unroll") for (int q = 0; q < NQ; ++q) _Pragma("unroll") for (int j = 0; j < 2; ++j)     \
+          acc[2 * (jh) + j][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af_[j][0], bf_[0][q], acc[2 * (jh) + j][q], 0, 0, 0); \
+    }                                                                                                  \
+  } while (0)
+  // One slab: the B rows fetched during the previous slab go to the other LDS buffer and the next ones are requested;
+  // rows 0..31 are converted, their registers immediately take the loads of the slab AFTER the next (two slabs of A stay
+  // in flight per wave through the matrix work and the barrier), their MFMAs run under the conversion of rows 32..63.
+#define EOFX_SLAB(areg, freg, buf, next_b, next_a)                                                     \
+  do {                                                                                                 \
+    EOFX_STORE_B(1 - (buf));                                                                           \
+    EOFX_LOAD_B(next_b);                                                                               \
+    if (live) {                                                                                        \
+      f32x2 fh_[2], fl_[2], fs_[2];                                                                    \
+      _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                  \
+        fh_[h] = -f32x2{freg[0][2 * h], freg[0][2 * h + 1]};   /* x - s == x + (-s) exactly: packed adds */ \
+        fl_[h] = -f32x2{freg[1][2 * h], freg[1][2 * h + 1]};                                           \
+        asm volatile("" : "+v"(fh_[h]), "+v"(fl_[h]));   /* keep them additions (v_pk_add_f32) */         \
+        fs_[h] = f32x2{freg[2][2 * h], freg[2][2 * h + 1]} * a_scale;   /* exact: a power of two */     \
+      }                                                                                                \
+      EOFX_AXB_CONVERT(areg, 0)                                                                        \
+      EOFX_LOAD_A(areg, next_a, 0);                                                                    \
+      EOFX_AXB_MFMA(0, buf);                                                                           \
+      EOFX_AXB_CONVERT(areg, 4)                                                                        \
+      EOFX_LOAD_F(freg, next_a);                                                                       \
+      EOFX_LOAD_A(areg, next_a, 4);                                                                    \
+      EOFX_AXB_MFMA(1, buf);                                                                           \
+    } else {                                                                                           \
+      EOFX_LOAD_A(areg, next_a, 0);                                                                    \
+      EOFX_LOAD_F(freg, next_a);                                                                       \
+      EOFX_LOAD_A(areg, next_a, 4);                                                                    \
+    }                                                                                                  \
+    __syncthreads();                                                                                   \
+  } while (0)
+
+  if (nslab > 0) {   // nslab is even (k_per_split and K are multiples of AXB_KG)
+    EOFX_LOAD_B(0);
+    EOFX_LOAD_F(f0, 0);
+    EOFX_LOAD_A(a0, 0, 0);
+    EOFX_LOAD_A(a0, 0, 4);
+    EOFX_STORE_B(0);
+    EOFX_LOAD_B(1);
+    EOFX_LOAD_F(f1, 1);
+    EOFX_LOAD_A(a1, 1, 0);
+    EOFX_LOAD_A(a1, 1, 4);
+    __syncthreads();
+    for (int c = 0; c < nslab; c += 2) {
+      const int c2 = c + 2 < nslab ? c + 2 : c;       // past the end: harmless re-reads of the last pair
+      const int c3 = c + 3 < nslab ? c + 3 : c + 1;
+      EOFX_SLAB(a0, f0, 0, c2, c2);     // slab c   (B of slab c+1 -> buffer 1, request B of c+2, A of c+2)
+      EOFX_SLAB(a1, f1, 1, c3, c3);     // slab c+1 (B of slab c+2 -> buffer 0, request B of c+3, A of c+3)
+    }
+  }
+#undef EOFX_AXB_LD
+#undef EOFX_LOAD_B
+#undef EOFX_LOAD_F
+#undef EOFX_LOAD_A
+#undef EOFX_STORE_B
+#undef EOFX_AXB_CONVERT
+#undef EOFX_AXB_MFMA
+#undef EOFX_SLAB
+
+  // D[i = 4 g + r][n = ln] of tile (j, q): row r0 + 16 j + 4 g + r, column 16 q + ln
+  float* Cs = C + (int64_t)split * c_rows * ldc;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = r0 + 16 * j + 4 * g + r;
+      if (row < c_rows) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+          Cs[(int64_t)row * ldc + bcol0 + 16 * q + ln] = row < a_rows ? acc[j][q][r] * out_scale : 0.f;
+      }
+    }
 }
 
 // max |v| over a (rows x cols) block with leading dimension ld -> *out (float bits, atomicMax on the
@@ -1278,7 +1528,7 @@ __global__ __launch_bounds__(256) void apply_kernel(const float* __restrict__ X,
                                                      int64_t p, float* __restrict__ Xc,
                                                      int64_t p_pad, float* __restrict__ Xt,
                                                      int64_t n_pad, int* __restrict__ nan_flag,
-                                                     unsigned* __restrict__ absmax) {
+                                                     const float* __restrict__ aff, int64_t aff_ld) {
   __shared__ float T[64][65];
   const int tid = threadIdx.x;
   const int tq = tid & 15, tr = tid >> 4;  // column quad 0..15, row 0..15 (+16 per pass)
@@ -1295,8 +1545,14 @@ __global__ __launch_bounds__(256) void apply_kernel(const float* __restrict__ X,
     slf[e] = 1.f;
     if (c < p) {
       sc[e] = col_map ? col_map[c] : c;
-      if (shift) aff_split(shift[sc[e]], shh[e], shl[e]);
-      if (scale) slf[e] = (float)scale[sc[e]];
+      if (aff) {   // the packed float triples of a raw / in-place matrix (aff_pack_kernel): the same map
+        shh[e] = aff[sc[e]];
+        shl[e] = aff[aff_ld + sc[e]];
+        slf[e] = aff[2 * aff_ld + sc[e]];
+      } else {
+        if (shift) aff_split(shift[sc[e]], shh[e], shl[e]);
+        if (scale) slf[e] = (float)scale[sc[e]];
+      }
     }
   }
   bool bad = false;
@@ -1330,9 +1586,8 @@ __global__ __launch_bounds__(256) void apply_kernel(const float* __restrict__ X,
       vmax = fmaxf(vmax, fabsf(v[e]));
     }
   }
-  if (bad) atomicOr(nan_flag, 1);
-  (void)vmax;
-  (void)absmax;  // the maximum comes from the column statistics (or panel_absmax_kernel): one atomic per
+  if (bad && nan_flag) atomicOr(nan_flag, 1);
+  (void)vmax;    // the maximum comes from the column statistics (or panel_absmax_kernel): one atomic per
                  // wave here would serialise 10^7 updates of a single word
   __syncthreads();
   // transposed write: thread owns 4 consecutive samples of one feature column per pass

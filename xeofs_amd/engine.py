@@ -128,10 +128,16 @@ class ResidentMatrix:
         """-> (has the feature-contiguous layout, reads the raw field instead): see eofx_ctx_set_layout"""
         hx, hr = C.c_int(), C.c_int()
         self.ctx.lib.eofx_mat_layout(self.handle, C.byref(hx), C.byref(hr))
-        return bool(hx.value), bool(hr.value)
+        return bool(hx.value & 1), bool(hr.value)
+
+    def has_sample_layout(self):
+        """False for an in-place matrix until an entry point that needs the sample-contiguous layout has built it"""
+        hx = C.c_int()
+        self.ctx.lib.eofx_mat_layout(self.handle, C.byref(hx), None)
+        return bool(hx.value & 2)
 
     def release_raw(self):
-        """Drop the reference to the raw field (raw mode); the feature-contiguous layout is rebuilt on demand."""
+        """Drop the reference to the raw field (raw / in-place mode); missing layouts are built first / on demand."""
         raise_for(self.ctx.lib.eofx_mat_release_raw(self.ctx.handle, self.handle), self.ctx.handle)
         self._keepalive = None
 
@@ -220,11 +226,13 @@ def from_dense(ctx: Context, X) -> ResidentMatrix:
 
 
 def preprocess(ctx: Context, X, center=True, standardize=False, feature_weights=None,
-               check_nans=True, want_stats=True, build=True, keep_raw=False):
+               check_nans=True, want_stats=True, build=True, keep_raw=False, in_place=False):
     """Scaler + Sanitizer + total variance on the stacked raw (n, P) field.
     Returns (ResidentMatrix | None, stats dict).  keep_raw: raw mode (include/eofx.h, eofx_ctx_set_layout) -- the
-    feature-contiguous layout is not written, the products read the raw field through the Scaler map; a device
-    field must then stay unmodified until `release_raw()` / `free()` (the matrix holds a reference to it)."""
+    feature-contiguous layout is not written, the products read the raw field through the Scaler map; in_place:
+    NO layout is written, both products stream the field where it lies (the sample-contiguous layout is built on
+    demand by the entry points that need it).  Either way a device field must stay unmodified until
+    `release_raw()` / `free()` (the matrix holds a reference to it); a host field is staged and owned."""
     X = _f32c(X)
     n, P = X.shape
     w = None if feature_weights is None else np.ascontiguousarray(feature_weights, dtype=np.float64)
@@ -237,7 +245,7 @@ def preprocess(ctx: Context, X, center=True, standardize=False, feature_weights=
     n_out, p_out = C.c_int64(), C.c_int64()
     tv = C.c_double()
     h = C.c_void_p()
-    ctx.lib.eofx_ctx_set_layout(ctx.handle, int(bool(keep_raw)))
+    ctx.lib.eofx_ctx_set_layout(ctx.handle, 2 if in_place else int(bool(keep_raw)))
     try:
         rc = ctx.lib.eofx_preprocess_f32(ctx.handle, ptr(X), n, P, int(center), int(standardize), ptr(w),
                                          int(check_nans), C.byref(h) if build else None, ptr(mean), ptr(std),
@@ -248,7 +256,7 @@ def preprocess(ctx: Context, X, center=True, standardize=False, feature_weights=
     stats = dict(mean=mean, std=std, valid_feature=vf.astype(bool), valid_sample=vs.astype(bool),
                  n=n_out.value, p=p_out.value, total_variance=tv.value)
     mat = ResidentMatrix(ctx, h) if build else None
-    if mat is not None and keep_raw and hasattr(X, "data_ptr"):
+    if mat is not None and (keep_raw or in_place) and hasattr(X, "data_ptr"):
         mat._keepalive = X
     return mat, stats
 

@@ -62,9 +62,12 @@ class _Field:
 
 
 class Preprocessor:
-    def __init__(self, center=True, standardize=False, use_coslat=False, check_nans=True, ctx=None):
+    def __init__(self, center=True, standardize=False, use_coslat=False, check_nans=True, ctx=None, in_place=False):
         self.center, self.standardize, self.use_coslat, self.check_nans = center, standardize, use_coslat, check_nans
         self.ctx = ctx
+        # in_place: the engine writes no copy of the matrix, the passes of the decomposition stream the (staged) field
+        # through the Scaler map (include/eofx.h, layout policy); a layout is built later only if something asks for it
+        self.in_place = in_place
 
     # ------------------------------------------------------------------ forward
     def _fields(self, X, sample_dims):
@@ -126,7 +129,8 @@ class Preprocessor:
             mat, _ = engine.apply(ctx, M, self.mean_, self.std_, self.feature_weights, self.valid_feature, self.check_nans)
             self.total_variance = mat.sumsq() / (mat.n - 1)
             return mat
-        mat, st = engine.preprocess(ctx, M, self.center, self.standardize, self.feature_weights, self.check_nans)
+        mat, st = engine.preprocess(ctx, M, self.center, self.standardize, self.feature_weights, self.check_nans,
+                                    in_place=self.in_place)
         self.mean_, self.std_ = (st["mean"] if self.center else None), (st["std"] if self.standardize else None)
         self.valid_feature, self.valid_sample = st["valid_feature"], st["valid_sample"]
         self.total_variance = st["total_variance"]

@@ -344,7 +344,7 @@ def _sum_scalar(comm: Comm, value: float) -> float:
 
 
 def sharded_preprocess(ctx, X_local, comm: Comm, center=True, standardize=False, feature_weights=None,
-                       check_nans=True, want_stats=True, keep_raw=False):
+                       check_nans=True, want_stats=True, keep_raw=False, in_place=False):
     """Scaler + Sanitizer + total variance (rows R1-R6) of this rank's slice of the stacked feature axis.
 
     Per-feature statistics, masks and the compaction are local (`eofx_preprocess_f32`); the global
@@ -356,7 +356,7 @@ def sharded_preprocess(ctx, X_local, comm: Comm, center=True, standardize=False,
     from . import engine
 
     mat, st = engine.preprocess(ctx, X_local, center=center, standardize=standardize, feature_weights=feature_weights,
-                                check_nans=check_nans, want_stats=want_stats, keep_raw=keep_raw)
+                                check_nans=check_nans, want_stats=want_stats, keep_raw=keep_raw, in_place=in_place)
     counts = _gather_counts(comm, mat.p)
     st["p_total"] = int(counts.sum())
     st["p_offset"] = int(counts[:comm.rank].sum())

@@ -30,7 +30,7 @@ class EOF(Deferred):
         self._decomposer_kwargs = dict(n_modes=n_modes, solver=solver, random_state=random_state, compute=compute,
                                        component_dim_name="mode", solver_kwargs=solver_kwargs, **kwargs)
         self.ctx = None
-        self.preprocessor = Preprocessor(center, standardize, use_coslat, check_nans)
+        self.preprocessor = Preprocessor(center, standardize, use_coslat, check_nans, in_place=True)   # rSVD streams the field
         # attrs as the reference stores them (base_model.py:38-46): bools/None stringified
         self.attrs = {"model": "EOF analysis", "software": "xeofs_amd", "version": __version__,
                       "date": datetime.datetime.now().strftime("%Y-%m-%d %H:%M:%S")}
@@ -182,6 +182,7 @@ class ComplexEOF(EOF):
         self._params.update({"padding": padding, "decay_factor": decay_factor})
         self.padding, self.decay_factor = padding, decay_factor
         self.preprocessor_imag = Preprocessor(center, False, use_coslat, check_nans)
+        self.preprocessor.in_place = False      # the Hilbert transform works on the sample-contiguous layout
 
     def _complex_parts(self, X, dim, weights):
         """preprocess Re and Im of a complex input with the same centring / weights"""
