@@ -279,7 +279,7 @@ def main():
     launch_ms = prof["ms"] / max(prof["launches"], 1)
     achieved_tflops = alg_flops_launch / (launch_ms * 1e-3) / 1e12 if launch_ms > 0 else 0.0
     pmc_traffic = None
-    tfile = os.path.join(ROOT, "profiles", "r02_atb_hbm_traffic.json")
+    tfile = os.path.join(ROOT, "profiles", "r02_stream_hbm_traffic.json")
     if os.path.exists(tfile):
         try:
             with open(tfile) as f:
@@ -300,8 +300,12 @@ def main():
         }
     else:
         roofline = {
-            "kernel": ("atb_f16_kernel<2, true|false> (C = A^T B, scaled split-fp16 MFMA 32x32x16, all 16 passes: 8 over the raw field "
-                       "through the Scaler map, 8 over the sample-contiguous layout; mean over all)"
+            "kernel": ({"inplace": "the two streaming kernels of the in-place layout, mean over all 16 passes: atb_f16_kernel<2,true> "
+                                   "(X^T Z, 8 passes) and axb_f16_kernel<4> (X Y, 8 passes), both over the raw field through "
+                                   "the Scaler map, scaled split-fp16 MFMA; per kernel in `by_kernel`",
+                        "raw": "atb_f16_kernel<2, true|false> (C = A^T B, scaled split-fp16 MFMA 32x32x16, all 16 passes: 8 over "
+                               "the raw field through the Scaler map, 8 over the sample-contiguous layout; mean over all)",
+                        "copy": "atb_f16_kernel<2> (C = A^T B, scaled split-fp16 MFMA 32x32x16, all 16 passes)"}[args.layout]
                        if args.precision == "f16x3" else
                        "atb_bf16_kernel<2,PARTS> (C = A^T B, split-bf16 MFMA 32x32x16: 15 launches bf16x3 + 1 launch "
                        "bf16x6 per fit; mean over all 16)"),
@@ -311,6 +315,12 @@ def main():
             "practical_read_ceiling": READ_CEILING_GBPS,
             "frac_of_read_ceiling": round(achieved_gbps / READ_CEILING_GBPS, 4),
         }
+    if prof.get("by_kernel"):
+        names = {"atb": "atb_f16_kernel (X^T Z" + ("" if args.layout == "inplace" else " and X Y") + ")",
+                 "axb": "axb_f16_kernel (X Y, in place)", "fused": "fused2_kernel"}
+        roofline["by_kernel"] = {names[k]: {"launches": v["launches"], "mean_launch_ms": round(v["ms"] / v["launches"], 4),
+                                            "GBps": round(alg_bytes_launch / (v["ms"] / v["launches"] * 1e-3) / 1e9, 1)}
+                                 for k, v in prof["by_kernel"].items()}
     roofline.update({
         "traffic": pmc_traffic, "launches_timed": prof["launches"], "mean_launch_ms": round(launch_ms, 4),
         "alg_bytes_per_launch": alg_bytes_launch, "alg_flops_per_launch": alg_flops_launch,
@@ -335,7 +345,7 @@ def main():
         torch.cuda.empty_cache()
         ns, nlat_s, nlon_s, ks = 10000, 720, 720, 50      # the workload's n and k on half of its grid: 10-15 s of CPU work
         Xs = make_field(ns, nlat_s, nlon_s, 0, nlat_s * nlon_s, device)
-        mat_s, _ = engine.preprocess(ctx, Xs, want_stats=False)
+        mat_s, _ = engine.preprocess(ctx, Xs, want_stats=False, **layout_kw)
         Ug, sg, Vg = engine.rsvd(ctx, mat_s, ks, N_OVERSAMPLES, "auto", random_state=5)
         Xc = mat_s.download()           # the centred float32 matrix the GPU decomposed
         mat_s.free()

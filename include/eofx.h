@@ -105,6 +105,10 @@ int eofx_peaked_spectrum(const double *G, int ld, int l);
 int eofx_ctx_profile(eofx_ctx *ctx, int enable);
 int eofx_ctx_profile_read(eofx_ctx *ctx, int64_t *launches, double *total_ms, double *flops,
                           double *bytes);
+/* the same launches of the LAST eofx_ctx_profile_read by streaming kernel: [0] the atb kernels (operand read with the
+ * reduction axis strided: X^T Z on the field, X Y on the sample-contiguous layout), [1] axb_f16_kernel (X Y on the
+ * field in place), [2] the fused product */
+int eofx_ctx_profile_by_kernel(const eofx_ctx *ctx, int64_t *launches3, double *ms3);
 
 /* ---- resident matrix ---------------------------------------------------
  * An eofx_mat holds the preprocessed matrix twice in HBM, zero padded:

@@ -35,6 +35,7 @@ SIGNATURES = {
     "eofx_ctx_set_precision": (_int, [_vp, _int, _int]),
     "eofx_ctx_profile": (_int, [_vp, _int]),
     "eofx_ctx_profile_read": (_int, [_vp, _pi64, _pd, _pd, _pd]),
+    "eofx_ctx_profile_by_kernel": (_int, [_vp, _pi64, _pd]),
     "eofx_preprocess_f32": (_int, [_vp, _vp, _i64, _i64, _int, _int, _vp, _int, C.POINTER(_vp),
                                    _vp, _vp, _vp, _vp, _pi64, _pi64, _pd]),
     "eofx_apply_f32": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _int, C.POINTER(_vp), _vp, _pi64]),

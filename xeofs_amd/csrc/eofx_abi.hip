@@ -55,7 +55,14 @@ struct eofx_ctx {
   int keep_raw = 0;
   // optional per-launch timing of the dominant kernel (atb_f32) with HIP events on `stream`
   bool profile = false;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+  struct ProfEvent {
+    hipEvent_t first, second;
+    int kind;   // 0: atb kernels, 1: axb (in-place row stream), 2: fused product
+    ProfEvent(hipEvent_t a, hipEvent_t b, int k = 0) : first(a), second(b), kind(k) {}
+  };
+  std::vector<ProfEvent> prof_events;
+  int64_t prof_kind_launches[3] = {0, 0, 0};   // of the last eofx_ctx_profile_read
+  double prof_kind_ms[3] = {0.0, 0.0, 0.0};
   double prof_flops = 0.0;  // 2*K*M*L summed over profiled launches (padded sizes)
   double prof_bytes = 0.0;  // K*M*4 (the A stream) summed over profiled launches
 };
@@ -208,10 +215,16 @@ extern "C" int eofx_ctx_profile_read(eofx_ctx* ctx, int64_t* launches, double* t
   CHK(set_device(ctx));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   double ms = 0.0;
+  for (int k = 0; k < 3; ++k) {
+    ctx->prof_kind_launches[k] = 0;
+    ctx->prof_kind_ms[k] = 0.0;
+  }
   for (auto& pr : ctx->prof_events) {
     float t = 0.f;
     HIPCHK(hipEventElapsedTime(&t, pr.first, pr.second));
     ms += t;
+    ctx->prof_kind_launches[pr.kind] += 1;
+    ctx->prof_kind_ms[pr.kind] += t;
     (void)hipEventDestroy(pr.first);
     (void)hipEventDestroy(pr.second);
   }
@@ -222,6 +235,17 @@ extern "C" int eofx_ctx_profile_read(eofx_ctx* ctx, int64_t* launches, double* t
   ctx->prof_events.clear();
   ctx->prof_flops = 0.0;
   ctx->prof_bytes = 0.0;
+  return EOFX_OK;
+}
+
+// launches / summed milliseconds of the LAST eofx_ctx_profile_read by streaming kernel: [0] atb (the transposed-operand
+// kernels, all variants), [1] axb_f16_kernel (the in-place row stream), [2] the fused product
+extern "C" int eofx_ctx_profile_by_kernel(const eofx_ctx* ctx, int64_t* launches3, double* ms3) {
+  if (!ctx) return EOFX_ERR_ARG;
+  for (int k = 0; k < 3; ++k) {
+    if (launches3) launches3[k] = ctx->prof_kind_launches[k];
+    if (ms3) ms3[k] = ctx->prof_kind_ms[k];
+  }
   return EOFX_OK;
 }
 
@@ -613,7 +637,7 @@ static int launch_axb(eofx_ctx* ctx, const float* raw, int64_t ld, int64_t rows,
   }
   if (ctx->profile) {
     HIPCHK(hipEventRecord(ev1, ctx->stream));
-    ctx->prof_events.emplace_back(ev0, ev1);
+    ctx->prof_events.emplace_back(ev0, ev1, 1);
     ctx->prof_flops += 2.0 * (double)K * (double)rows_pad * (double)L;
     ctx->prof_bytes += (double)K * (double)rows * 4.0 * (nfull + (rem ? 1 : 0));
   }
@@ -1517,7 +1541,7 @@ static int panel_fused(eofx_ctx* ctx, const eofx_mat* m, const float* Zn, float*
   HIPCHK(le);
   if (ctx->profile) {
     HIPCHK(hipEventRecord(ev1, ctx->stream));
-    ctx->prof_events.emplace_back(ev0, ev1);
+    ctx->prof_events.emplace_back(ev0, ev1, 2);
     ctx->prof_flops += 4.0 * (double)npad * (double)m->p_pad * 64.0;
     ctx->prof_bytes += (double)npad * (double)m->p_pad * 4.0;
   }

@@ -64,7 +64,10 @@ class Context:
         ms, fl, by = C.c_double(), C.c_double(), C.c_double()
         raise_for(self.lib.eofx_ctx_profile_read(self.handle, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)),
                   self.handle)
-        return dict(launches=n.value, ms=ms.value, flops=fl.value, bytes=by.value)
+        kl, km = (C.c_int64 * 3)(), (C.c_double * 3)()
+        raise_for(self.lib.eofx_ctx_profile_by_kernel(self.handle, kl, km), self.handle)
+        by_kernel = {name: dict(launches=int(kl[i]), ms=float(km[i])) for i, name in enumerate(("atb", "axb", "fused")) if kl[i]}
+        return dict(launches=n.value, ms=ms.value, flops=fl.value, bytes=by.value, by_kernel=by_kernel)
 
     def close(self):
         if getattr(self, "handle", None):
