@@ -676,7 +676,7 @@ static int launch_gram(eofx_ctx* ctx, const float* P, int64_t rows, int L, doubl
 
 static int launch_matmul(eofx_ctx* ctx, const float* P, int64_t rows, int L, const double* Mx, int Lo,
                          float* out) {
-  dim3 grid((int)((rows + 63) / 64), (Lo + 63) / 64);
+  dim3 grid((int)((rows + 255) / 256), (Lo + 63) / 64);
   hipLaunchKernelGGL(panel_matmul_kernel, grid, dim3(256), 0, ctx->stream, P, rows, L, Mx, Lo, out);
   KCHK();
   return EOFX_OK;

@@ -1167,55 +1167,76 @@ __global__ __launch_bounds__(256) void chol_rinv_kernel(const double* __restrict
 }
 
 // ---------------------------------------------------------------------------------
-// panel_matmul: out[rows x Lo] = P[rows x L] * Mx[L x Lo]  (Mx float64, accumulate float64)
-//   grid = (rows/64, ceil(Lo/64)); 64x64 output tile, 4x4 per thread.  out must not alias P.
+// panel_matmul: out[rows x Lo] = P[rows x L] * Mx[L x Lo]  (Mx float64; exact float64 products of the float32 panel
+// entries, float64 sums) on the fp64 matrix cores (v_mfma_f64_16x16x4_f64).  out must not alias P.
+//   grid = (ceil(rows / 256), ceil(Lo / 64)); block = 4 waves x 64 rows (four 16-row tiles each).
+//   A: lane (i = l % 16, kq = l / 16) loads the float4 P[row i][16 tt + 4 kq ..] (16 lanes x 4 = one 256-byte row
+//      per four lanes' worth of loads, straight into registers); element c of it is simply NAMED k index kq of
+//      MFMA step (tt, c), i.e. actual k = 16 tt + 4 kq + c, and the B fragment is read from LDS under the same
+//      naming: Ms[16 tt + 4 kq + c][16 q + i].  No LDS round trip for P.
+//   B: one 64 x 64 float64 block of Mx per K chunk in LDS (rows padded to 66), shared by the four waves and by each
+//      wave's four row tiles.
+//   D[kq + 4 r][i] of tile (t, q) (measured layout) = out[row0 + 16 t + kq + 4 r][c0 + 16 q + i].
 // ---------------------------------------------------------------------------------
+
 __global__ __launch_bounds__(256) void panel_matmul_kernel(const float* __restrict__ P,
                                                            int64_t rows, int L,
                                                            const double* __restrict__ Mx, int Lo,
                                                            float* __restrict__ out) {
-  __shared__ float Ps[64][65];
-  __shared__ double Ms[64][64];
+  __shared__ double Ms[64][66];
   const int tid = threadIdx.x;
-  const int ti = tid >> 4, tj = tid & 15;
-  const int64_t r0 = (int64_t)blockIdx.x * 64;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
   const int c0 = blockIdx.y * 64;
-  double acc[4][4];
+  const int64_t row0 = (int64_t)blockIdx.x * 256 + wave * 64;
+  f64x4 acc[4][4];
 #pragma unroll
-  for (int x = 0; x < 4; ++x)
+  for (int t = 0; t < 4; ++t)
 #pragma unroll
-    for (int y = 0; y < 4; ++y) acc[x][y] = 0.0;
-  for (int k0 = 0; k0 < L; k0 += 64) {
+    for (int q = 0; q < 4; ++q) acc[t][q] = f64x4{0.0, 0.0, 0.0, 0.0};
+  for (int kc = 0; kc < L; kc += 64) {
     for (int i = tid; i < 64 * 64; i += 256) {
       const int r = i >> 6, c = i & 63;
-      Ps[r][c] = (r0 + r < rows && k0 + c < L) ? P[(r0 + r) * L + k0 + c] : 0.f;
-      Ms[r][c] = (k0 + r < L && c0 + c < Lo) ? Mx[(int64_t)(k0 + r) * Lo + c0 + c] : 0.0;
+      Ms[r][c] = (kc + r < L && c0 + c < Lo) ? Mx[(int64_t)(kc + r) * Lo + c0 + c] : 0.0;
+    }
+    f32x4 a[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int64_t r = row0 + 16 * t + li;
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        const int k = kc + 16 * tt + 4 * lk;
+        a[t][tt] = (r < rows && k < L) ? *reinterpret_cast<const f32x4*>(P + r * L + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
     }
     __syncthreads();
-#pragma unroll 8
-    for (int k = 0; k < 64; ++k) {
-      double a[4], b[4];
 #pragma unroll
-      for (int x = 0; x < 4; ++x) a[x] = (double)Ps[4 * ti + x][k];
+    for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
-      for (int y = 0; y < 4; ++y) b[y] = Ms[k][4 * tj + y];
+      for (int c = 0; c < 4; ++c) {
+        double b[4];
 #pragma unroll
-      for (int x = 0; x < 4; ++x)
+        for (int q = 0; q < 4; ++q) b[q] = Ms[16 * tt + 4 * lk + c][16 * q + li];
 #pragma unroll
-        for (int y = 0; y < 4; ++y) acc[x][y] += a[x] * b[y];
-    }
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            acc[t][q] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a[t][tt][c], b[q], acc[t][q], 0, 0, 0);
+      }
     __syncthreads();
   }
 #pragma unroll
-  for (int x = 0; x < 4; ++x) {
-    const int64_t r = r0 + 4 * ti + x;
-    if (r >= rows) continue;
+  for (int t = 0; t < 4; ++t)
 #pragma unroll
-    for (int y = 0; y < 4; ++y) {
-      const int c = c0 + 4 * tj + y;
-      if (c < Lo) out[r * Lo + c] = (float)acc[x][y];
+    for (int r = 0; r < 4; ++r) {
+      const int64_t row = row0 + 16 * t + lk + 4 * r;
+      if (row >= rows) continue;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int col = c0 + 16 * q + li;
+        if (col < Lo) out[row * Lo + col] = (float)acc[t][q][r];
+      }
     }
-  }
 }
 
 // per-column max/min over rows [0, rows): partial per block, then a second tiny pass.
