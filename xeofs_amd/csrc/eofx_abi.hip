@@ -676,8 +676,17 @@ static int launch_gram(eofx_ctx* ctx, const float* P, int64_t rows, int L, doubl
 
 static int launch_matmul(eofx_ctx* ctx, const float* P, int64_t rows, int L, const double* Mx, int Lo,
                          float* out) {
-  dim3 grid((int)((rows + 255) / 256), (Lo + 63) / 64);
-  hipLaunchKernelGGL(panel_matmul_kernel, grid, dim3(256), 0, ctx->stream, P, rows, L, Mx, Lo, out);
+  const int KW = (int)std::min<int64_t>(round_up(L, 64), 256);      // rows of Mx held in LDS at a time
+  const size_t smem = (size_t)KW * PMM_LD * sizeof(double);         // 33 .. 132 KB
+  static size_t attr_smem = 0;    // opt in to more than 64 KB of dynamic LDS when a wide panel asks for it
+  if (smem > 64 * 1024 && smem > attr_smem) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_matmul_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    attr_smem = smem;
+  }
+  const int64_t units = (rows + 127) / 128;        // 4 waves x 32 rows
+  const int64_t gx = L <= KW ? std::min<int64_t>(units, 1024) : units;   // windowed form: one group per wave
+  dim3 grid((int)std::max<int64_t>(1, gx), (Lo + 63) / 64);
+  hipLaunchKernelGGL(panel_matmul_kernel, grid, dim3(256), smem, ctx->stream, P, rows, L, Mx, Lo, out, KW);
   KCHK();
   return EOFX_OK;
 }

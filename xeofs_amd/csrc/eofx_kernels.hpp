@@ -1169,74 +1169,123 @@ __global__ __launch_bounds__(256) void chol_rinv_kernel(const double* __restrict
 // ---------------------------------------------------------------------------------
 // panel_matmul: out[rows x Lo] = P[rows x L] * Mx[L x Lo]  (Mx float64; exact float64 products of the float32 panel
 // entries, float64 sums) on the fp64 matrix cores (v_mfma_f64_16x16x4_f64).  out must not alias P.
-//   grid = (ceil(rows / 256), ceil(Lo / 64)); block = 4 waves x 64 rows (four 16-row tiles each).
-//   A: lane (i = l % 16, kq = l / 16) loads the float4 P[row i][16 tt + 4 kq ..] (16 lanes x 4 = one 256-byte row
-//      per four lanes' worth of loads, straight into registers); element c of it is simply NAMED k index kq of
-//      MFMA step (tt, c), i.e. actual k = 16 tt + 4 kq + c, and the B fragment is read from LDS under the same
-//      naming: Ms[16 tt + 4 kq + c][16 q + i].  No LDS round trip for P.
-//   B: one 64 x 64 float64 block of Mx per K chunk in LDS (rows padded to 66), shared by the four waves and by each
-//      wave's four row tiles.
+//   grid = (G, ceil(Lo / 64)); block = 4 waves.  L <= KW (256): the 64-column slice of Mx sits in LDS for the whole
+//   launch (dynamic LDS: KW x 66 doubles); every wave walks 32-row groups g = wave id, wave id + 4 G, ... and, inside a
+//   group, the K axis in chunks of 64, with the NEXT chunk's panel entries already in flight (register double buffer).
+//   Wider inner dimensions (the PCA route's Rayleigh-Ritz panels): one group per wave, Mx passes through LDS in windows.
+//   A: lane (i = l % 16, kq = l / 16) loads the float4 P[row i][kc + 16 tt + 4 kq ..] straight into registers;
+//      element c of it is simply NAMED k index kq of MFMA step (tt, c), i.e. actual k = kc + 16 tt + 4 kq + c, and the
+//      B fragment is read from LDS under the same naming: Ms[kc + 16 tt + 4 kq + c][16 q + i].  No LDS trip for P.
 //   D[kq + 4 r][i] of tile (t, q) (measured layout) = out[row0 + 16 t + kq + 4 r][c0 + 16 q + i].
 // ---------------------------------------------------------------------------------
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+constexpr int PMM_LD = 66;   // doubles per staged row of Mx
 
 __global__ __launch_bounds__(256) void panel_matmul_kernel(const float* __restrict__ P,
                                                            int64_t rows, int L,
                                                            const double* __restrict__ Mx, int Lo,
-                                                           float* __restrict__ out) {
-  __shared__ double Ms[64][66];
+                                                           float* __restrict__ out, int KW) {
+  extern __shared__ __attribute__((aligned(16))) double Ms[];   // [KW][PMM_LD]: KW = multiple of 64, the K window in LDS
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lk = lane >> 4;
   const int c0 = blockIdx.y * 64;
-  const int64_t row0 = (int64_t)blockIdx.x * 256 + wave * 64;
-  f64x4 acc[4][4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) acc[t][q] = f64x4{0.0, 0.0, 0.0, 0.0};
-  for (int kc = 0; kc < L; kc += 64) {
-    for (int i = tid; i < 64 * 64; i += 256) {
+  const int Lc = (L + 63) / 64;          // K chunks of 64
+  const int64_t ngroups = (rows + 31) / 32;
+  const int64_t g0 = (int64_t)blockIdx.x * 4 + wave;
+  auto stage = [&](int k0) {             // rows [k0, k0 + KW) of the 64-column slice of Mx
+    for (int i = tid; i < KW * 64; i += 256) {
       const int r = i >> 6, c = i & 63;
-      Ms[r][c] = (kc + r < L && c0 + c < Lo) ? Mx[(int64_t)(kc + r) * Lo + c0 + c] : 0.0;
+      Ms[r * PMM_LD + c] = (k0 + r < L && c0 + c < Lo) ? Mx[(int64_t)(k0 + r) * Lo + c0 + c] : 0.0;
     }
-    f32x4 a[4][4];
+  };
+  auto fetch = [&](bool valid, int64_t g, int kc, f32x4 (&a)[2][4]) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int64_t r = row0 + 16 * t + li;
+    for (int t = 0; t < 2; ++t) {
+      const int64_t r = 32 * g + 16 * t + li;
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt) {
         const int k = kc + 16 * tt + 4 * lk;
-        a[t][tt] = (r < rows && k < L) ? *reinterpret_cast<const f32x4*>(P + r * L + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+        a[t][tt] = (valid && r < rows && k < L) ? *reinterpret_cast<const f32x4*>(P + r * L + k)
+                                               : f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
-    __syncthreads();
+  };
+  f64x4 acc[2][4];
+  // one K chunk of one 32-row group: 32 MFMA steps x 8 tiles; ms0 = first row of Mx held in LDS
+  auto compute = [&](int64_t g, int kc, int ms0, const f32x4 (&a)[2][4]) {
+    if (kc == 0) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[t][q] = f64x4{0.0, 0.0, 0.0, 0.0};
+    }
 #pragma unroll
     for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         double b[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) b[q] = Ms[16 * tt + 4 * lk + c][16 * q + li];
+        for (int q = 0; q < 4; ++q) b[q] = Ms[(kc - ms0 + 16 * tt + 4 * lk + c) * PMM_LD + 16 * q + li];
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
           for (int q = 0; q < 4; ++q)
             acc[t][q] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a[t][tt][c], b[q], acc[t][q], 0, 0, 0);
       }
+    if (kc + 64 >= L) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t row = 32 * g + 16 * t + lk + 4 * r;
+          if (row >= rows) continue;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int col = c0 + 16 * q + li;
+            if (col < Lo) out[row * Lo + col] = (float)acc[t][q][r];
+          }
+        }
+    }
+  };
+  f32x4 a0[2][4], a1[2][4];
+  if (Lc * 64 <= KW) {
+    // the whole slice fits: staged once, every wave walks groups g0, g0 + 4 G, ... with the next (group, chunk) in flight
+    stage(0);
     __syncthreads();
-  }
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int64_t row = row0 + 16 * t + lk + 4 * r;
-      if (row >= rows) continue;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int col = c0 + 16 * q + li;
-        if (col < Lo) out[row * Lo + col] = (float)acc[t][q][r];
+    const int64_t gstride = (int64_t)gridDim.x * 4;
+    const int64_t nitems = g0 < ngroups ? ((ngroups - g0 + gstride - 1) / gstride) * Lc : 0;
+    fetch(nitems > 0, g0, 0, a0);
+    for (int64_t item = 0; item < nitems; item += 2) {
+      fetch(item + 1 < nitems, g0 + ((item + 1) / Lc) * gstride, (int)((item + 1) % Lc) * 64, a1);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(g0 + (item / Lc) * gstride, (int)(item % Lc) * 64, 0, a0);
+      if (item + 1 < nitems) {
+        fetch(item + 2 < nitems, g0 + ((item + 2) / Lc) * gstride, (int)((item + 2) % Lc) * 64, a0);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(g0 + ((item + 1) / Lc) * gstride, (int)((item + 1) % Lc) * 64, 0, a1);
       }
     }
+  } else {
+    // wide inner dimension (the launcher gives every wave at most ONE group): windows of KW rows of Mx pass through LDS
+    const bool active = g0 < ngroups;
+    const int wc = KW / 64;
+    fetch(active, g0, 0, a0);
+    for (int w0 = 0; w0 < Lc; w0 += wc) {
+      __syncthreads();
+      stage(64 * w0);
+      __syncthreads();
+      const int we = w0 + wc < Lc ? w0 + wc : Lc;
+      for (int ch = w0; ch < we; ch += 2) {        // wc is even
+        fetch(active && ch + 1 < Lc, g0, 64 * (ch + 1), a1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (active) compute(g0, 64 * ch, 64 * w0, a0);
+        fetch(active && ch + 2 < Lc, g0, 64 * (ch + 2), a0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (active && ch + 1 < we) compute(g0, 64 * (ch + 1), 64 * w0, a1);
+      }
+    }
+  }
 }
 
 // per-column max/min over rows [0, rows): partial per block, then a second tiny pass.
