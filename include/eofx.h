@@ -260,6 +260,10 @@ int eofx_resample_f32(eofx_ctx *ctx, const eofx_mat *src, const int64_t *rows, i
  * Y are sharded over GPUs (with eofx_vec_dot_f64), (b) the exact PCA pre-reduction of the cross models
  * (preprocessing/pca.py:94-123): eigenvectors of the small-side Gram matrix span the PCA subspace.   */
 int eofx_mat_gram_f32(eofx_ctx *ctx, const eofx_mat *m, int side, float *G);
+/* G = A_a A_b^T (side 0, [n_pad x n_pad]) or A_a^T A_b (side 1, [p_pad x p_pad]) of two resident matrices of one shape:
+ * the imaginary blocks of the Hermitian Gram matrix of a complex field a + i b (complex PCA pre-reduction of the complex
+ * cross models, xeofs/cross/cpcca.py:1023-1173 with preprocessing/pca.py:94-123). */
+int eofx_mat_cross_gram_f32(eofx_ctx *ctx, const eofx_mat *a, const eofx_mat *b, int side, float *G);
 int eofx_vec_dot_f64(eofx_ctx *ctx, const float *a, const float *b, int64_t count, double *out);
 /* ---- complex randomized SVD (the decomposer's complex branch) -----------------------------------------------
  * Z = A + iB (two resident real matrices of equal shape) ~ U diag(s) V^H.  Replaces

@@ -618,9 +618,12 @@ def whitener_fit(X, alpha):
 
 
 def cpcca_fit(X, Y, n_modes, alpha=(0.2, 0.2), standardize=False, random_state=None, solver="auto", use_pca=True,
-              n_pca_modes=0.999, pca_init_rank_reduction=0.3, pca_random_state=None, pca_solver="auto"):
+              n_pca_modes=0.999, pca_init_rank_reduction=0.3, pca_random_state=None, pca_solver="auto", hilbert=None):
     """xeofs/cross/base_model_cross_set.py:269-321 + xeofs/cross/cpcca.py:168-225 for general alpha.
-    Returns the DataContainer entries plus the fitted transforms (V_i, T_i, Tinv_i)."""
+    Returns the DataContainer entries plus the fitted transforms (V_i, T_i, Tinv_i).
+    Complex X, Y: ComplexCPCCA / ComplexMCA (cpcca.py:1023-1173; the Decomposer takes its complex branch).
+    hilbert = (padding, decay_factor): HilbertCPCCA / HilbertMCA (cpcca.py:1328-1500): `_augment_data` between the PCA
+    and the whitener (base_model_cross_set.py:307-313)."""
     alpha = [alpha, alpha] if np.isscalar(alpha) else list(alpha)
     px = preprocess(X, True, standardize)
     py = preprocess(Y, True, standardize)
@@ -632,6 +635,8 @@ def cpcca_fit(X, Y, n_modes, alpha=(0.2, 0.2), standardize=False, random_state=N
             _, _, V = decomposer_fit(Z, nm, init_rank_reduction=pca_init_rank_reduction,
                                      random_state=pca_random_state, solver=pca_solver)
             Z = Z @ V
+        if hilbert is not None:
+            Z = hilbert_transform(Z, hilbert[0], hilbert[1])
         T, Tinv = whitener_fit(Z, a)
         if T is not None:
             Z = Z @ T

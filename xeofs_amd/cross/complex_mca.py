@@ -1,0 +1,317 @@
+"""Complex and Hilbert MCA (xeofs/cross/mca.py:224-489 on top of xeofs/cross/cpcca.py:1023-1500 with alpha = 1).
+
+`ComplexMCA` takes complex fields Z_x = U_x + i V_x, Z_y = U_y + i V_y; `HilbertMCA` takes real fields and augments them
+with their Hilbert transform.  Order of the stages as in base_model_cross_set.py:300-315:
+
+    preprocess -> PCA pre-reduction (default) -> [Hilbert transform of the PC scores: `_augment_data`] -> (alpha = 1: no
+    whitening) -> cross-covariance C = S_x^H S_y / (n - 1) -> SVD of C -> scores, norms, total squared covariance.
+
+What runs on the GPU: the preprocessor, the PCA pre-reductions -- `ResidentPCA` on the real fields of the Hilbert model
+(its analytic signal is taken of the n x m PC scores, through the same `eofx_hilbert_f32`), `ComplexResidentPCA`
+(Hermitian Gram route) on complex fields -- and every product with a resident field (back-projection of the singular
+vectors, projection of new data).  After the pre-reduction the analysis matrices are n x m with m of the order of tens to
+hundreds, and the m_x x m_y complex cross-covariance matrix is decomposed exactly on the host (the reference hands it to
+scipy's svds(lobpcg): same singular values / subspaces to its tolerance, vectors up to a unit phase per mode).
+Without PCA (`use_pca=False`) the fields themselves are the analysis matrices: supported while they are small enough to
+decompose densely (n * p <= MAX_DENSE); beyond that use the default PCA route.
+"""
+
+from __future__ import annotations
+
+import datetime
+import warnings
+
+import numpy as np
+
+from .. import __version__, engine, labelled
+from .._deferred import Deferred
+from ..cpca import ComplexResidentPCA
+from ..linalg.decomposer import sanity_check_n_modes
+from ..pca import ResidentPCA
+from ..preprocessing import Preprocessor
+
+MAX_DENSE = 50_000_000      # elements of a field decomposed without PCA pre-reduction
+
+
+def _pair(v):
+    return list(v) if isinstance(v, (list, tuple)) else [v, v]
+
+
+def _sign_rule(VT):
+    """utils/xarray_utils.py:273-301: +1 where |max| >= |min| per mode, numpy's lexicographic complex max / min"""
+    mx, mn = VT.max(axis=1), VT.min(axis=1)
+    return np.where(np.abs(mx) >= np.abs(mn), 1.0, -1.0)
+
+
+class _Field:
+    """one side after preprocessing and pre-reduction: analysis matrix S (n x m complex, host), maps back to features"""
+
+    def __init__(self, S, back, project, parts, pca):
+        self.S, self.back, self.project, self.parts, self.pca = S, back, project, parts, pca
+
+    def free(self):
+        for m in self.parts:
+            if m is not None:
+                m.free()
+        self.parts = ()
+
+
+class ComplexMCA(Deferred):
+    """Drop-in for xeofs.cross.ComplexMCA (cross/mca.py:224-338)."""
+
+    _model_name = "Complex MCA"
+    _hilbert = False
+
+    def __init__(self, n_modes: int = 2, standardize=False, use_coslat=False, check_nans=True, use_pca=True,
+                 n_pca_modes=0.999, pca_init_rank_reduction=0.3, compute: bool = True, sample_name: str = "sample",
+                 feature_name="feature", solver: str = "auto", random_state=None, solver_kwargs: dict = {}, **kwargs):
+        sanity_check_n_modes(n_modes)
+        if solver not in ("auto", "full", "randomized"):
+            raise ValueError(f"Unrecognized solver '{solver}'. Valid options are 'auto', 'full', and 'randomized'.")
+        self.n_modes = n_modes
+        std, cos, chk = _pair(standardize), _pair(use_coslat), _pair(check_nans)
+        self._params = dict(n_modes=n_modes, standardize=std, use_coslat=cos, check_nans=chk, use_pca=_pair(use_pca),
+                            n_pca_modes=_pair(n_pca_modes), pca_init_rank_reduction=_pair(pca_init_rank_reduction),
+                            sample_name=sample_name, feature_name=_pair(feature_name), random_state=random_state,
+                            compute=compute, solver=solver)
+        self.sample_name = sample_name
+        self.solver_kwargs = dict(solver_kwargs)
+        # CPCCA always centres (cpcca.py:145); real and imaginary parts share centring, scaling and weights
+        self.pre_re = [Preprocessor(True, std[i], cos[i], chk[i]) for i in range(2)]
+        self.pre_im = [Preprocessor(True, False, cos[i], chk[i]) for i in range(2)]
+        self.attrs = {"model": self._model_name, "software": "xeofs_amd", "version": __version__,
+                      "date": datetime.datetime.now().strftime("%Y-%m-%d %H:%M:%S")}
+        self.ctx = None
+        self.data = {}
+        self.field = [None, None]
+
+    def get_params(self):
+        return dict(self._params)
+
+    # ------------------------------------------------------------------ fit
+    def fit(self, X, Y, dim, weights_X=None, weights_Y=None):
+        if labelled.is_lazy(X) or labelled.is_lazy(Y):      # linalg/decomposer.py:172-177
+            raise NotImplementedError("Complex data together with dask is currently not implemented. See dask issue 7639 "
+                                      "https://github.com/dask/dask/issues/7639")
+        return self._fit_now(X, Y, dim, weights_X, weights_Y)
+
+    def _complex_parts(self, i, Z, dim, weights):
+        """preprocess Re and Im of a complex input with the same centring / weights (as `ComplexEOF`)"""
+        vals, dims, coords, name, attrs = labelled.unpack(Z)
+        if not np.iscomplexobj(vals):
+            warnings.warn("Expected complex-valued data but found real-valued data. For Hilbert model, use corresponding "
+                          "`Hilbert` class.")
+        vals = np.asarray(vals)
+        re = labelled.pack(np.ascontiguousarray(vals.real), dims, coords, name, attrs, Z)
+        im = labelled.pack(np.ascontiguousarray(vals.imag if np.iscomplexobj(vals) else np.zeros_like(vals)),
+                           dims, coords, name, attrs, Z)
+        pr, pi = self.pre_re[i], self.pre_im[i]
+        std_c = None
+        if self._params["standardize"][i]:
+            # scaler.py:105-108 on complex data: numpy's std of a complex array is the real sqrt(var Re + var Im)
+            pr.standardize = False
+            s_re, s_im = pr.peek_std(re, dim), pi.peek_std(im, dim)
+            std_c = np.maximum(np.sqrt(s_re ** 2 + s_im ** 2), np.finfo(np.float32).eps)
+        A = pr.fit_transform(re, dim, weights, std_override=std_c)
+        B = pi.fit_transform(im, dim, weights, std_override=std_c)
+        return A, B, pr.total_variance + pi.total_variance
+
+    def _dense(self, A, B):
+        if A.n * A.p > MAX_DENSE:
+            raise NotImplementedError(f"use_pca=False on a {A.n} x {A.p} field: the complex cross models decompose without "
+                                      "PCA pre-reduction only up to n * p = %d elements; use use_pca=True" % MAX_DENSE)
+        S = A.download().astype(np.float64) + 1j * B.download().astype(np.float64)
+        ctx = self.ctx
+
+        def back(Q):
+            return np.asarray(Q, dtype=np.complex64)
+
+        def project(An, Bn):
+            return An.download().astype(np.float64) + 1j * Bn.download().astype(np.float64)
+
+        return _Field(S, back, project, (A, B), None)
+
+    def _make_field(self, i, Z, dim, weights):
+        ctx = self.ctx
+        A, B, tv = self._complex_parts(i, Z, dim, weights)
+        if not self._params["use_pca"][i]:
+            return self._dense(A, B)
+        pca = ComplexResidentPCA(ctx, self._params["n_pca_modes"][i], self._params["pca_init_rank_reduction"][i])
+        pca.fit(A, B, tv)
+        return _Field(pca.scores(), pca.back_project, pca.transform, (A, B), pca)
+
+    def _fit_now(self, X, Y, dim, weights_X=None, weights_Y=None):
+        self.ctx = self.ctx or engine.default_context()
+        for p in self.pre_re + self.pre_im:
+            p.ctx = self.ctx
+        fx = self._make_field(0, X, dim, weights_X)
+        fy = self._make_field(1, Y, dim, weights_Y)
+        self.field = [fx, fy]
+        self.sample_dims = self.pre_re[0].sample_dims
+        Sx, Sy = fx.S, fy.S
+        if Sx.shape[0] != Sy.shape[0]:
+            raise ValueError("Both data matrices must have the same number of samples but found "
+                             f"{Sx.shape[0]} in the first and {Sy.shape[0]} in the second.")
+        n = Sx.shape[0]
+        k = int(self.n_modes)
+        C = np.ascontiguousarray(Sx.conj().T) @ Sy / (n - 1)     # cpcca.py:1008-1016
+        rank = min(C.shape)
+        if k > rank:
+            raise ValueError(f"n_modes must be less than or equal to the rank of the dataset (rank = {rank}).")
+        if rank >= 512:      # PC-space matrices of hundreds of modes: the dense complex SVD runs on the device
+            torch = engine._torch()
+            U, s, VT = (a.cpu().numpy() for a in torch.linalg.svd(torch.as_tensor(C, device=f"cuda:{self.ctx.device}"),
+                                                                  full_matrices=False))
+        else:
+            U, s, VT = np.linalg.svd(C, full_matrices=False)
+        U, s, VT = np.ascontiguousarray(U[:, :k]), s[:k], np.ascontiguousarray(VT[:k])
+        sgn = _sign_rule(VT)
+        Q1, Q2 = U * sgn[None, :], (VT * sgn[:, None]).conj().T   # decomposer.py:226: V = conj(VT).T
+        scores1, scores2 = Sx @ Q1, Sy @ Q2
+        norm1 = np.sqrt((scores1.conj() * scores1).sum(axis=0).real)
+        norm2 = np.sqrt((scores2.conj() * scores2).sum(axis=0).real)
+        self.data = dict(Q1=Q1, Q2=Q2, components1=fx.back(Q1), components2=fy.back(Q2), scores1=scores1, scores2=scores2,
+                         singular_values=s, squared_covariance=s ** 2,
+                         total_squared_covariance=float((np.abs(C) ** 2).sum()), norm1=norm1, norm2=norm2)
+        return self
+
+    # ------------------------------------------------------------------ accessors
+    def _pre(self, which):
+        return self.pre_re[which - 1]
+
+    def _mode_array(self, values, name):
+        k = len(values)
+        return labelled.pack(np.asarray(values), ("mode",), {"mode": np.arange(1, k + 1)}, name, dict(self.attrs),
+                             self.pre_re[0].fields[0].like)
+
+    def _components(self, normalized):
+        c1, c2 = self.data["components1"], self.data["components2"]
+        if not normalized:                                       # cpcca.py:308-316
+            c1, c2 = c1 * self.data["norm1"].astype(np.float32), c2 * self.data["norm2"].astype(np.float32)
+        return c1, c2
+
+    def _scores(self, normalized):
+        s1, s2 = self.data["scores1"], self.data["scores2"]
+        if normalized:                                           # cpcca.py:318-329
+            s1, s2 = s1 / self.data["norm1"], s2 / self.data["norm2"]
+        return s1, s2
+
+    def _wrap_components(self, c1, c2, name):
+        return (self.pre_re[0].inverse_transform_components(c1, name + "_X", self.attrs),
+                self.pre_re[1].inverse_transform_components(c2, name + "_Y", self.attrs))
+
+    def _wrap_scores(self, s1, s2, name):
+        return (self.pre_re[0].inverse_transform_scores(s1, name + "_X", self.attrs),
+                self.pre_re[1].inverse_transform_scores(s2, name + "_Y", self.attrs))
+
+    def components(self, normalized: bool = True):
+        return self._wrap_components(*self._components(normalized), "components")
+
+    def scores(self, normalized: bool = False):
+        return self._wrap_scores(*self._scores(normalized), "scores")
+
+    def components_amplitude(self, normalized: bool = True):
+        c1, c2 = self._components(normalized)
+        return self._wrap_components(np.abs(c1), np.abs(c2), "components_amplitude")
+
+    def components_phase(self, normalized: bool = True):
+        c1, c2 = self._components(normalized)
+        return self._wrap_components(np.angle(c1), np.angle(c2), "components_phase")
+
+    def scores_amplitude(self, normalized: bool = False):
+        s1, s2 = self._scores(normalized)
+        return self._wrap_scores(np.abs(s1), np.abs(s2), "scores_amplitude")
+
+    def scores_phase(self, normalized: bool = False):
+        s1, s2 = self._scores(normalized)
+        return self._wrap_scores(np.angle(s1), np.angle(s2), "scores_phase")
+
+    def singular_values(self):
+        return self._mode_array(self.data["singular_values"], "singular_values")
+
+    def squared_covariance(self):
+        return self._mode_array(self.data["squared_covariance"], "squared_covariance")
+
+    def total_squared_covariance(self):
+        return self.data["total_squared_covariance"]
+
+    def squared_covariance_fraction(self):
+        """cpcca.py:418-512 with alpha = 1: the residual form 1 - ||d_X^H d_Y||^2 / ||X^H Y||^2 of a rank-one deflation
+        equals sigma_i^2 / sum sigma^2 (the singular triplets are orthogonal)"""
+        scf = self.data["squared_covariance"] / self.data["total_squared_covariance"]
+        return self._mode_array(scf, "squared_covariance_fraction")
+
+    def covariance_fraction_CD95(self):
+        """mca.py:127-189"""
+        s = self.data["singular_values"]
+        cf = s[0] / np.cumsum(s)
+        if len(s) > 1 and (cf[-2] - cf[-1]) > 0.001:
+            warnings.warn("The curent estimate of CF is sensitive to the number of modes retained. Please increase "
+                          "`n_modes` for a better estimate.")
+        return self._mode_array(s / s.sum(), "covariance_fraction")
+
+    # ------------------------------------------------------------------ transform / inverse
+    def transform(self, X=None, Y=None, normalized: bool = False):
+        """base_model_cross_set.py:323-374 + cpcca.py:227-252"""
+        if X is None and Y is None:
+            raise ValueError("Either X or Y must be given.")
+        out = []
+        for i, Z in enumerate((X, Y)):
+            if Z is None:
+                continue
+            vals, dims, coords, name, attrs = labelled.unpack(Z)
+            vals = np.asarray(vals)
+            re = labelled.pack(np.ascontiguousarray(vals.real), dims, coords, name, attrs, Z)
+            im = labelled.pack(np.ascontiguousarray(vals.imag if np.iscomplexobj(vals) else np.zeros_like(vals)),
+                               dims, coords, name, attrs, Z)
+            An, fields, vs = self.pre_re[i].transform(re)
+            Bn, _, _ = self.pre_im[i].transform(im)
+            S = self.field[i].project(An, Bn) @ self.data[f"Q{i + 1}"]
+            An.free()
+            Bn.free()
+            if normalized:
+                S = S / self.data[f"norm{i + 1}"]
+            out.append(self.pre_re[i].inverse_transform_scores(S, "scores_" + "XY"[i], self.attrs, fields, vs))
+        return out[0] if len(out) == 1 else out
+
+
+class HilbertMCA(ComplexMCA):
+    """Drop-in for xeofs.cross.HilbertMCA (cross/mca.py:340-489, cpcca.py:1328-1500): real fields, analytic signal of the
+    (PCA-reduced) data along the sample axis, optional exponential padding against spectral leakage."""
+
+    _model_name = "Hilbert MCA"
+    _hilbert = True
+
+    def __init__(self, n_modes: int = 2, padding="exp", decay_factor=0.2, **kwargs):
+        super().__init__(n_modes=n_modes, **kwargs)
+        self._params["padding"] = _pair(padding)
+        self._params["decay_factor"] = _pair(decay_factor)
+
+    def _analytic(self, S, i):
+        """utils/hilbert_transform.py:40-72 of an n x m real matrix along the samples, through the engine"""
+        mat = engine.from_dense(self.ctx, np.ascontiguousarray(S, dtype=np.float32))
+        im, _ = engine.hilbert(self.ctx, mat, self._params["padding"][i], float(self._params["decay_factor"][i]))
+        out = S.astype(np.float64) + 1j * im.download().astype(np.float64)
+        im.free()
+        mat.free()
+        return out
+
+    def _make_field(self, i, Z, dim, weights):
+        ctx = self.ctx
+        pre = self.pre_re[i]
+        pre.standardize = self._params["standardize"][i]
+        mat = pre.fit_transform(Z, dim, weights)
+        if not self._params["use_pca"][i]:
+            im, _ = engine.hilbert(ctx, mat, self._params["padding"][i], float(self._params["decay_factor"][i]))
+            return self._dense(mat, im)
+        pca = ResidentPCA(ctx, self._params["n_pca_modes"][i], self._params["pca_init_rank_reduction"][i])
+        pca.fit(mat, pre.total_variance)
+
+        def back(Q):          # V Q with a real V: the two parts separately
+            Q = np.asarray(Q)
+            return pca.back_project(Q.real).astype(np.complex64) + 1j * pca.back_project(Q.imag)
+
+        return _Field(self._analytic(pca.scores(), i), back, None, (mat,), pca)
+
+    def transform(self, X=None, Y=None, normalized: bool = False):
+        raise NotImplementedError("Hilbert models do not support the transform method.")

@@ -1942,6 +1942,28 @@ extern "C" int eofx_mat_gram_f32(eofx_ctx* ctx, const eofx_mat* m, int side, flo
   return mat_gram(ctx, m, side, G);
 }
 
+// G = A_a A_b^T (side 0, [n_pad x n_pad]) or A_a^T A_b (side 1, [p_pad x p_pad]) of two resident matrices of the same shape:
+// the off-diagonal blocks of the Hermitian Gram matrix of a complex field Z = A + iB (Z Z^H = (A A^T + B B^T) + i (B A^T - A B^T)).
+extern "C" int eofx_mat_cross_gram_f32(eofx_ctx* ctx, const eofx_mat* a, const eofx_mat* b, int side, float* G) {
+  if (!ctx || !a || !b || !G || (side != 0 && side != 1)) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  if (a->n != b->n || a->p != b->p) return set_err(ctx, EOFX_ERR_SHAPE, "the two matrices must have the same shape");
+  CHK(set_device(ctx));
+  const int64_t d = side ? a->p_pad : a->n_pad, o = side ? a->n_pad : a->p_pad;
+  if (d > (1 << 16)) return set_err(ctx, EOFX_ERR_ARG, "Gram side of %lld is too large", (long long)d);
+  CHK(arena_reserve(ctx, atb_scratch_bytes(d, o, (int)d) + (1 << 20)));
+  const float amax = std::max(a->absmax, b->absmax);
+  if (side == 0) {
+    CHK(ensure_Xt(ctx, a));
+    CHK(ensure_Xt(ctx, b));
+    return launch_atb(ctx, a->Xt, d, round_up(a->p, ATB_KG), d, b->Xt, (int)d, (int)d, G, ctx->prec_final, amax,
+                      reinterpret_cast<const float*>(b->absmax_dev));
+  }
+  CHK(ensure_X(ctx, a));
+  CHK(ensure_X(ctx, b));
+  return launch_atb(ctx, a->X, d, round_up(a->n, ATB_KG), d, b->X, (int)d, (int)d, G, ctx->prec_final, amax,
+                    reinterpret_cast<const float*>(b->absmax_dev));
+}
+
 extern "C" int eofx_vec_dot_f64(eofx_ctx* ctx, const float* a, const float* b, int64_t count, double* out) {
   if (!ctx || !a || !b || !out || count < 0) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
   CHK(set_device(ctx));

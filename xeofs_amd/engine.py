@@ -127,6 +127,15 @@ class ResidentMatrix:
     def sample_gram(self):
         return self.gram(0)
 
+    def cross_gram(self, other: "ResidentMatrix", side: int = 0):
+        """side 0: A_self A_other^T [n_pad, n_pad]; side 1: A_self^T A_other [p_pad, p_pad] (float32 device tensor)"""
+        torch = _torch()
+        d = self.p_pad if side else self.n_pad
+        G = torch.empty((d, d), dtype=torch.float32, device=f"cuda:{self.ctx.device}")
+        raise_for(self.ctx.lib.eofx_mat_cross_gram_f32(self.ctx.handle, self.handle, other.handle, int(side), ptr(G)),
+                  self.ctx.handle)
+        return G
+
     def layout(self):
         """-> (has the feature-contiguous layout, reads the raw field instead): see eofx_ctx_set_layout"""
         hx, hr = C.c_int(), C.c_int()
