@@ -135,3 +135,73 @@ def test_eof_rotator_model(ctx, power):
         assert np.allclose(rec, rec0, atol=1e-3 * np.abs(rec0).max())
     with pytest.raises(NotImplementedError):
         rot.fit_transform(model)
+
+
+@pytest.mark.parametrize("power", [1, 2, 4])
+@pytest.mark.parametrize("m", [2, 5, 17])
+def test_complex_promax_vs_oracle(ctx, power, m):
+    """`rotation.cpromax_panel`: complex loadings as a [Re | Im] panel, the reference loop with the complex m x m matrices
+    in their real embedding (`eofx_panel_rot_step_f64` modes 2 / 3) against the oracle's complex `promax` (pinned to the
+    reference's own `_rotation.py` on complex inputs, fixture G8)."""
+    from xeofs_amd import engine, rotation
+
+    rng = np.random.default_rng(11 * m + power)
+    p = 3000 + 37 * m
+    base = (rng.standard_normal((p, m)) + 1j * rng.standard_normal((p, m))) * (2.0 * 0.8 ** np.arange(m))
+    base[rng.integers(0, p, p // 3), rng.integers(0, m, p // 3)] *= 4.0          # some simple structure to rotate towards
+    Xo, Ro, phio = orc.promax(base, power=power)
+    Xrot, pp, mm, R, phi = rotation.cpromax_panel(ctx, base.astype(np.complex64), power=power)
+    out = Xrot[:p].cpu().numpy()
+    Xg = out[:, :m] + 1j * out[:, rotation.CH:rotation.CH + m]
+    assert (pp, mm) == (p, m)
+    assert np.abs(R - Ro).max() < 2e-4 * np.abs(Ro).max()
+    assert np.abs(phi - phio).max() < 5e-4 * np.abs(phio).max()
+    assert np.abs(Xg - Xo).max() < 5e-4 * np.abs(Xo).max()
+
+
+@pytest.mark.parametrize("power", [1, 2])
+@pytest.mark.parametrize("kind", ["complex", "hilbert"])
+def test_complex_eof_rotator_model(ctx, power, kind):
+    """ComplexEOFRotator / HilbertEOFRotator (eof_rotator.py:294-400) on a fitted model against the oracle's
+    `eof_rotator_fit` fed with the SAME unrotated solution (the phases of a complex SVD are arbitrary, so the unrotated
+    model, not the data, is the common starting point)."""
+    import xeofs_amd as xe
+
+    rng = np.random.default_rng(7)
+    n, shape, k, mrot = 120, (14, 18), 6, 4
+    p = int(np.prod(shape))
+    t = np.arange(n)[:, None]
+    T = np.sin(2 * np.pi * t * np.arange(1, 6)[None, :] / 31.0 + rng.uniform(0, 6, 5)) * (3.0 * 0.75 ** np.arange(5))
+    A = T @ rng.standard_normal((5, p)) + 0.1 * rng.standard_normal((n, p))
+    if kind == "complex":
+        data = (A + 1j * (np.roll(T, 4, axis=0) @ rng.standard_normal((5, p)))).reshape((n,) + shape)
+        model = xe.single.ComplexEOF(n_modes=k, random_state=3)
+        Rot = xe.single.ComplexEOFRotator
+    else:
+        data = A.reshape((n,) + shape)
+        model = xe.single.HilbertEOF(n_modes=k, random_state=3)
+        Rot = xe.single.HilbertEOFRotator
+    X = xe.DataArray(data, dims=("time", "lat", "lon"))
+    model.fit(X, "time")
+    with pytest.raises(TypeError):
+        xe.single.EOFRotator(n_modes=mrot).fit(model)
+    rot = Rot(n_modes=mrot, power=power).fit(model)
+    eof = dict(components=np.asarray(model.data["components"]).astype(np.complex128),
+               scores=np.asarray(model.data["scores"]).astype(np.complex128),
+               norms=np.asarray(model.data["norms"], dtype=np.float64),
+               explained_variance=np.asarray(model.data["explained_variance"], dtype=np.float64),
+               total_variance=model.data["total_variance"], input_data=np.zeros((n, 1)))
+    ref = orc.eof_rotator_fit(eof, mrot, power=power)
+    c = rot.components().values.reshape(mrot, -1).T
+    s = rot.scores().values.reshape(mrot, -1).T
+    assert np.iscomplexobj(c) and rot.components().dims == ("mode", "lat", "lon")
+    assert np.allclose(rot.explained_variance().values, ref["explained_variance"], rtol=2e-4)
+    assert np.array_equal(rot.data["idx_modes_sorted"], ref["idx_modes_sorted"])
+    assert np.abs(c - ref["components"]).max() < 1e-3 * np.abs(ref["components"]).max()
+    assert np.abs(s - ref["scores"]).max() < 1e-3 * np.abs(ref["scores"]).max()
+    assert np.abs(rot.rotation_matrix() - ref["rotation_matrix"]).max() < 5e-4
+    assert np.abs(rot.phi_matrix() - ref["phi_matrix"]).max() < 1e-3
+    amp = rot.components_amplitude().values.reshape(mrot, -1).T
+    assert np.allclose(amp, np.abs(ref["components"]), atol=1e-3 * np.abs(ref["components"]).max())
+    with pytest.raises(NotImplementedError):
+        rot.transform(X)

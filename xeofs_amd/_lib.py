@@ -75,6 +75,7 @@ SIGNATURES = {
     "eofx_panel_colargminmax_f32": (_int, [_vp, _vp, _i64, _int, _vp, _vp]),
     "eofx_panel_row_normalize_f32": (_int, [_vp, _vp, _i64, _int, _vp]),
     "eofx_panel_rot_step_f64": (_int, [_vp, _vp, _i64, _int, _vp, _vp, _int, C.c_double, _vp]),
+    "eofx_cpanel_colabsmax_f32": (_int, [_vp, _vp, _i64, _int, _vp]),
     "eofx_sketch_gaussian_f32": (_int, [C.c_uint32, _i64, _i64, _vp]),
     "eofx_host_eigh_f64": (_int, [_vp, _int, _vp, _vp]),
 }

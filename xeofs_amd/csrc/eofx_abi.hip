@@ -2816,9 +2816,22 @@ extern "C" int eofx_panel_row_normalize_f32(eofx_ctx* ctx, const float* P, int64
   return EOFX_OK;
 }
 
+// max |column| over the rows of a complex [Re | Im] panel (L = 2 h columns, h a power of two <= 128) -> out[h] (device)
+extern "C" int eofx_cpanel_colabsmax_f32(eofx_ctx* ctx, const float* P, int64_t rows, int L, float* out) {
+  if (!ctx || !P || !out || L < 2 || L > 256 || (L & (L - 1))) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  CHK(set_device(ctx));
+  HIPCHK(hipMemsetAsync(out, 0, sizeof(float) * (L / 2), ctx->stream));
+  const int rstep = 256 / (L / 2);
+  hipLaunchKernelGGL(cpanel_colabsmax_kernel, dim3((int)std::max<int64_t>(1, std::min<int64_t>((rows + rstep - 1) / rstep, 2048))),
+                     dim3(256), 0, ctx->stream, P, rows, L, reinterpret_cast<unsigned*>(out));
+  KCHK();
+  return EOFX_OK;
+}
+
 extern "C" int eofx_panel_rot_step_f64(eofx_ctx* ctx, const float* X, int64_t rows_pad, int L, const double* R,
                                        const double* aux, int mode, double power, double* G) {
-  if (!ctx || !X || !R || !aux || !G || L > 64 || L % 32) return set_err(ctx, EOFX_ERR_ARG, "bad argument (L <= 64)");
+  if (!ctx || !X || !R || !aux || !G || L > 64 || L % 32 || mode < 0 || mode > 3 || (mode >= 2 && L != 64))
+    return set_err(ctx, EOFX_ERR_ARG, "bad argument (L <= 64; the complex modes 2 / 3 need the 32 | 32 panel)");
   CHK(set_device(ctx));
   const int nbx = (int)std::max<int64_t>(1, std::min<int64_t>((rows_pad + 31) / 32, 512));
   CHK(arena_reserve(ctx, (size_t)(nbx + 1) * L * L * sizeof(double) + 4096));

@@ -2009,6 +2009,21 @@ __global__ void colargminmax_final_kernel(const float* __restrict__ pmx, const i
   amin[c] = ib;
 }
 
+// max over the rows of |P[r, c] + i P[r, c + L/2]| for the L/2 complex columns of a [Re | Im] panel -> out[L/2]
+// (float bits through atomicMax on the unsigned view: non-negative values, order-independent; out zeroed first)
+__global__ __launch_bounds__(256) void cpanel_colabsmax_kernel(const float* __restrict__ P, int64_t rows, int L,
+                                                               unsigned* __restrict__ out) {
+  const int h = L / 2;
+  const int c = threadIdx.x % h;
+  const int rstep = 256 / h;
+  float m = 0.f;
+  for (int64_t r = (int64_t)blockIdx.x * rstep + threadIdx.x / h; r < rows; r += (int64_t)gridDim.x * rstep) {
+    const float a = P[r * L + c], b = P[r * L + h + c];
+    m = fmaxf(m, sqrtf(a * a + b * b));
+  }
+  if (threadIdx.x < rstep * h && m > 0.f) atomicMax(out + c, __float_as_uint(m));
+}
+
 // ---------------------------------------------------------------------------------
 // Varimax / Promax rotation of loadings (xeofs/linalg/_numpy/_rotation.py:6-187), modes <= 64.
 // The loadings panel X (rows = features, L = 64 columns) stays resident; one iteration of the
@@ -2016,6 +2031,10 @@ __global__ void colargminmax_final_kernel(const float* __restrict__ pmx, const i
 // per row  b = x R (float64),  t = f(b),  G += left^T t  with everything but the final m x m SVD on
 // the device.  mode 0 (varimax step):  left = x, t_j = b_j (b_j^2 - aw_j)
 //              mode 1 (promax fit)  :  left = b, t_j = (b_j / mx_j) |b_j / mx_j|^(power-1)
+// Complex loadings (modes 2 / 3 = complex versions of 0 / 1; "This implementation also works for complex numbers",
+// _rotation.py:16,105): the panel holds [Re (32 columns) | Im (32 columns)], R arrives as the real 64 x 64 embedding
+// [[Rr, Ri], [-Ri, Rr]] so that b = x R is the same row product, |b_j|^2 pairs column j with column j + 32, and the
+// 64 x 64 real result [Xr | Xi]^T [Tr | Ti] carries the four blocks of X^H T = (Xr^T Tr + Xi^T Ti) + i (Xr^T Ti - Xi^T Tr).
 // grid = (nblocks); each workgroup owns a strided set of 32-row tiles; partials reduced in fixed order.
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void rot_step_kernel(const float* __restrict__ X, int64_t rows, int L,
@@ -2040,7 +2059,7 @@ __global__ __launch_bounds__(256) void rot_step_kernel(const float* __restrict__
     for (int y = 0; y < 4; ++y) acc[x][y] = 0.0;
   double auxr[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) auxr[e] = (bc0 + e < L) ? aux[bc0 + e] : (mode ? 1.0 : 0.0);
+  for (int e = 0; e < 8; ++e) auxr[e] = (bc0 + e < L) ? aux[bc0 + e] : ((mode & 1) ? 1.0 : 0.0);
   __syncthreads();
   for (int64_t r0 = (int64_t)blockIdx.x * 32; r0 < rows; r0 += (int64_t)gridDim.x * 32) {
     for (int i = tid; i < 32 * 16; i += 256) {
@@ -2058,10 +2077,25 @@ __global__ __launch_bounds__(256) void rot_step_kernel(const float* __restrict__
 #pragma unroll
       for (int e = 0; e < 8; ++e) b[e] += xv * Rs[k][bc0 + e];
     }
+    if (mode >= 2) {       // complex: every entry needs the other part of its column (uniform branch)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) Ls[brow][bc0 + e] = b[e];
+      __syncthreads();
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       double t;
-      if (mode == 0) {
+      if (mode >= 2) {
+        const int cr = (bc0 + e) & 31;
+        const double br_ = Ls[brow][cr], bi_ = Ls[brow][cr + 32];
+        const double a2 = br_ * br_ + bi_ * bi_;
+        if (mode == 2) {
+          t = b[e] * (a2 - auxr[e]);
+        } else {
+          const double za = sqrt(a2) / auxr[e];
+          t = (power == 1.0 || !(za > 0.0)) ? b[e] / auxr[e] : (b[e] / auxr[e]) * pow(za, power - 1.0);
+        }
+      } else if (mode == 0) {
         t = b[e] * (b[e] * b[e] - auxr[e]);
       } else {
         const double z = b[e] / auxr[e];
@@ -2075,7 +2109,7 @@ __global__ __launch_bounds__(256) void rot_step_kernel(const float* __restrict__
     for (int r = 0; r < 32; ++r) {
       double a[4], c[4];
 #pragma unroll
-      for (int x = 0; x < 4; ++x) a[x] = mode ? Ls[r][4 * ti + x] : (double)Xs[r][4 * ti + x];
+      for (int x = 0; x < 4; ++x) a[x] = (mode & 1) ? Ls[r][4 * ti + x] : (double)Xs[r][4 * ti + x];
 #pragma unroll
       for (int y = 0; y < 4; ++y) c[y] = Ts[r][4 * tj + y];
 #pragma unroll

@@ -536,6 +536,15 @@ def panel_rot_step(ctx: Context, X, R, aux, mode: int, power: float = 1.0):
     return G
 
 
+def cpanel_colabsmax(ctx: Context, P, rows: int):
+    """max over the rows of |column| for the L/2 complex columns of a [Re | Im] panel -> float32 device tensor [L/2]"""
+    torch = _torch()
+    L = P.shape[1]
+    out = torch.empty(L // 2, dtype=torch.float32, device=P.device)
+    raise_for(ctx.lib.eofx_cpanel_colabsmax_f32(ctx.handle, ptr(P), int(rows), L, ptr(out)), ctx.handle)
+    return out
+
+
 def vec_dot(ctx: Context, a, b) -> float:
     """float64 dot product of two equally sized float32 device tensors (fixed reduction tree)"""
     out = C.c_double()

@@ -109,3 +109,108 @@ def finish_on_device(ctx, Xrot, p, m):
     M[idx, np.arange(m)] = sign[idx] / np.sqrt(expvar[idx])
     comps = engine.panel_export(ctx, engine.panel_matmul(ctx, Xrot, _dev(M, Xrot)), p, m)
     return comps, expvar, idx, sign
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# complex loadings (the rotation of ComplexEOF / HilbertEOF models, xeofs/single/eof_rotator.py:294-400; `_promax` /
+# `_varimax` "also work for complex numbers", _rotation.py:16,105)
+# ---------------------------------------------------------------------------------------------------------------------
+CH = 32            # complex panels are [Re (32 columns) | Im (32 columns)]: up to 32 complex modes
+
+
+def _cembed(M):
+    """real 64 x 64 matrix E with [Pr | Pi] @ E = [Re(P M) | Im(P M)] for a complex m x m' matrix M"""
+    l, m = M.shape
+    E = np.zeros((2 * CH, 2 * CH))
+    E[:l, :m] = M.real
+    E[CH:CH + l, :m] = -M.imag
+    E[:l, CH:CH + m] = M.imag
+    E[CH:CH + l, CH:CH + m] = M.real
+    return E
+
+
+def _cblocks(G, m):
+    """X^H T (complex m x m) from the real 64 x 64 product [Xr | Xi]^T [Tr | Ti]"""
+    rr, ri = G[:m, :m], G[:m, CH:CH + m]
+    ir, ii = G[CH:CH + m, :m], G[CH:CH + m, CH:CH + m]
+    return (rr + ii) + 1j * (ri - ir)
+
+
+def cpromax_panel(ctx, loadings: np.ndarray, power: int = 1, max_iter: int = 1000, rtol: float = 1e-8, col_scale=None):
+    """`promax_panel` for complex loadings [p, m] (m <= 32): -> ([Re | Im] panel on the device, p, m, complex rotation
+    matrix, complex phi).  Every step of the reference loop is the same fused pass (`eofx_panel_rot_step_f64`, modes
+    2 / 3) with the complex m x m matrices in their real embedding."""
+    loadings = np.asarray(loadings)
+    p, m = loadings.shape
+    if m < 2:
+        raise ValueError("Cannot rotate {:} modes (columns), but must be 2 or more.".format(m))
+    if m > CH:
+        raise NotImplementedError(f"rotation of more than {CH} complex modes is not supported by this build")
+    L = 2 * CH
+    rows_pad = (p + 511) // 512 * 512
+    host = np.zeros((p, L), np.float32)
+    host[:, :m], host[:, CH:CH + m] = loadings.real, loadings.imag
+    Lp = engine.panel_import(ctx, host, rows_pad, L)
+    del host
+    if col_scale is not None:
+        Lp = engine.panel_matmul(ctx, Lp, _dev(_cembed(np.diag(np.asarray(col_scale, dtype=np.float64)).astype(complex)), Lp))
+    Xn = engine.panel_row_normalize(ctx, Lp)                       # Kaiser: rows / (sqrt(sum |x|^2) + eps)
+    S = _cblocks(engine.panel_gram(ctx, Xn).cpu().numpy(), m)      # X^H X
+    S = 0.5 * (S + S.conj().T)
+    R = np.eye(m, dtype=complex)
+    alpha = 1.0 / p
+    delta = 0.0
+    for _ in range(int(max_iter)):
+        delta_old = delta
+        W = np.einsum("ij,ik,kj->j", R.conj(), S, R).real          # column sums of |X R|^2
+        aux = np.zeros(L)
+        aux[:m] = aux[CH:CH + m] = alpha * W
+        G = _cblocks(engine.panel_rot_step(ctx, Xn, _dev(_cembed(R), Xn), _dev(aux, Xn), 2).cpu().numpy(), m)
+        U, svals, VT = np.linalg.svd(G)
+        R = U @ VT
+        delta = float(np.sum(svals))
+        if abs(delta - delta_old) / delta < rtol:
+            break
+    if abs(delta - delta_old) / delta > rtol:
+        raise RuntimeError("Rotation process did not converge.")
+    rot_mat = R
+    phi = np.eye(m, dtype=complex)
+    if power != 1:
+        B = engine.panel_matmul(ctx, Xn, _dev(_cembed(R), Xn))     # X R (normalised, rotated)
+        cmax = engine.cpanel_colabsmax(ctx, B, p).cpu().numpy()[:m].astype(np.float64)
+        aux = np.ones(L)
+        aux[:m] = aux[CH:CH + m] = cmax
+        XtP = _cblocks(engine.panel_rot_step(ctx, Xn, _dev(_cembed(R), Xn), _dev(aux, Xn), 3, float(power)).cpu().numpy(), m)
+        XtX = R.conj().T @ S @ R
+        Lm = np.linalg.inv(XtX) @ XtP
+        try:
+            sigma_inv = np.diag(np.diag(np.linalg.inv(Lm.conj().T @ Lm)))
+        except np.linalg.LinAlgError:
+            sigma_inv = np.diag(np.diag(np.linalg.pinv(Lm.conj().T @ Lm)))
+        Lm = Lm @ np.sqrt(sigma_inv)
+        rot_mat = R @ Lm
+        L_inv = np.linalg.inv(Lm)
+        phi = L_inv @ L_inv.conj().T
+    Xrot = engine.panel_matmul(ctx, Lp, _dev(_cembed(rot_mat), Lp))   # (h Xn) rot_mat = loadings rot_mat
+    return Xrot, p, m, rot_mat, phi
+
+
+def cfinish_on_device(ctx, Xrot, p, m):
+    """`finish_on_device` for a complex [Re | Im] panel: explained variance = column sums of |x|^2, order, unit-norm
+    components, the reference's +-1 sign from numpy's lexicographic complex max / min (real part decides; ties on it are
+    measure-zero).  -> (components [p, m] complex64 host, expvar (unsorted), idx, sign (unsorted))."""
+    torch = engine._torch()
+    Gd = np.diag(engine.panel_gram(ctx, Xrot).cpu().numpy())
+    expvar = (Gd[:m] + Gd[CH:CH + m]).copy()
+    idx = np.argsort(expvar)[::-1]
+    amax, amin = engine.panel_colargminmax(ctx, Xrot, p)
+    cols = torch.arange(m, device=Xrot.device)
+    pick = lambda ix: (Xrot[ix[:m], cols].double().cpu().numpy(), Xrot[ix[:m], cols + CH].double().cpu().numpy())
+    (mr, mi), (nr, ni) = pick(amax), pick(amin)
+    sign = np.where(np.hypot(mr, mi) >= np.hypot(nr, ni), 1.0, -1.0)
+    M = np.zeros((m, m), dtype=complex)                   # column j of the output = column idx[j], scaled and signed
+    M[idx, np.arange(m)] = sign[idx] / np.sqrt(expvar[idx])
+    out = engine.panel_matmul(ctx, Xrot, _dev(_cembed(M), Xrot))[:p].cpu().numpy()
+    comps = np.empty((p, m), np.complex64)
+    comps.real, comps.imag = out[:, :m], out[:, CH:CH + m]
+    return comps, expvar, idx, sign

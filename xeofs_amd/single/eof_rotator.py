@@ -11,10 +11,12 @@ import datetime
 import numpy as np
 
 from .. import __version__, engine, rotation
-from .eof import EOF
+from .eof import EOF, ComplexEOF
 
 
 class EOFRotator(EOF):
+    _complex = False
+
     def __init__(self, n_modes: int = 2, power: int = 1, max_iter: int | None = None, rtol: float = 1e-8,
                  compute: bool = True):
         if max_iter is None:
@@ -38,24 +40,30 @@ class EOFRotator(EOF):
         self.preprocessor = model.preprocessor
         self.sample_name, self.feature_name = model.sample_name, model.feature_name
         self.sample_dims = getattr(model, "sample_dims", None)
+        for a in ("preprocessor_imag", "_real_reconstruction"):      # the complex models' inverse_transform needs them
+            if hasattr(model, a):
+                setattr(self, a, getattr(model, a))
         m = int(self._params["n_modes"])
         power = self._params["power"]
         comps = np.asarray(model.data["components"])[:, :m]
-        if np.iscomplexobj(comps):     # ComplexEOFRotator / HilbertEOFRotator (eof_rotator.py:294-400) are not built yet
-            raise NotImplementedError("EOFRotator rotates real models only; rotation of ComplexEOF / HilbertEOF models "
-                                      "(the reference's ComplexEOFRotator / HilbertEOFRotator) is not supported")
+        is_complex = np.iscomplexobj(comps)     # ComplexEOF / HilbertEOF models (eof_rotator.py:294-400)
+        if is_complex and not self._complex:
+            raise TypeError("EOFRotator rotates real models; use ComplexEOFRotator / HilbertEOFRotator for this model")
         m = comps.shape[1]
         expvar = np.asarray(model.data["explained_variance"], dtype=np.float64)[:m]
         # loadings = components * sqrt(expvar); rotation, explained variance, normalisation, sign and ordering all
         # happen on the resident panel -- the host sees the finished components once
-        Xrot, p, m, rot_matrix, phi = rotation.promax_panel(self.ctx, comps, power=power, max_iter=self._params["max_iter"],
-                                                            rtol=self._params["rtol"], col_scale=np.sqrt(expvar))
-        rot_sorted, expvar_r, idx, sign = rotation.finish_on_device(self.ctx, Xrot, p, m)
+        panel, finish = (rotation.cpromax_panel, rotation.cfinish_on_device) if is_complex else \
+            (rotation.promax_panel, rotation.finish_on_device)
+        Xrot, p, m, rot_matrix, phi = panel(self.ctx, comps, power=power, max_iter=self._params["max_iter"],
+                                            rtol=self._params["rtol"], col_scale=np.sqrt(expvar))
+        rot_sorted, expvar_r, idx, sign = finish(self.ctx, Xrot, p, m)
         del Xrot
-        n_samples = model.data["input_data"].n
+        inp = model.data["input_data"]
+        n_samples = (inp[0] if isinstance(inp, tuple) else inp).n
         norms = (expvar_r * (n_samples - 1)) ** 0.5
         svals = np.asarray(model.data["norms"], dtype=np.float64)[:m]
-        scores = np.asarray(model.data["scores"])[:, :m].astype(np.float64) / svals
+        scores = np.asarray(model.data["scores"])[:, :m].astype(np.complex128 if is_complex else np.float64) / svals
         RinvT = self._rot_mat_inv_trans(rot_matrix)
         scores = scores @ RinvT * norms
         scores = scores * sign
@@ -63,7 +71,7 @@ class EOFRotator(EOF):
         self.data = dict(
             input_data=model.data["input_data"],
             components=rot_sorted,
-            scores=np.ascontiguousarray(scores[:, idx].astype(np.float32)),
+            scores=np.ascontiguousarray(scores[:, idx].astype(np.complex64 if is_complex else np.float32)),
             norms=norms[idx], explained_variance=expvar_r[idx], total_variance=model.data["total_variance"],
             idx_modes_sorted=idx, rotation_matrix=rot_matrix, phi_matrix=phi, modes_sign=sign[idx],
         )
@@ -100,3 +108,27 @@ class EOFRotator(EOF):
 
     def phi_matrix(self):
         return self.data["phi_matrix"]
+
+
+class ComplexEOFRotator(EOFRotator, ComplexEOF):
+    """Drop-in for xeofs.single.ComplexEOFRotator (eof_rotator.py:294-337): Varimax / Promax rotation of a fitted
+    `ComplexEOF` model; the complex loadings are rotated on the device as a [Re | Im] panel (`rotation.cpromax_panel`),
+    up to 32 modes."""
+
+    _complex = True
+
+    def __init__(self, n_modes: int = 2, power: int = 1, max_iter: int | None = None, rtol: float = 1e-8,
+                 compute: bool = True):
+        EOFRotator.__init__(self, n_modes=n_modes, power=power, max_iter=max_iter, rtol=rtol, compute=compute)
+        self.attrs.update({"model": "Rotated Complex EOF analysis"})
+
+    def transform(self, X, normalized: bool = False):
+        raise NotImplementedError("ComplexEOFRotator/HilbertEOFRotator does not support transform()")
+
+
+class HilbertEOFRotator(ComplexEOFRotator):
+    """Drop-in for xeofs.single.HilbertEOFRotator (eof_rotator.py:339-400; `transform` is not implemented there either)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.attrs.update({"model": "Rotated Hilbert EOF analysis"})
