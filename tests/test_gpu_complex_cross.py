@@ -153,3 +153,50 @@ def test_complex_mca_errors(ctx):
         xe.cross.ComplexMCA(n_modes=36, use_pca=False).fit(X, Y, "time")
     with pytest.warns(UserWarning, match="Expected complex-valued data"):
         xe.cross.ComplexMCA(n_modes=2, use_pca=False).fit(xe.DataArray(A.real, dims=("time", "lat", "lon")), Y, "time")
+
+
+@pytest.mark.parametrize("power", [1, 2])
+@pytest.mark.parametrize("kind,use_pca", [("complex", True), ("complex", False), ("hilbert", True)])
+def test_complex_mca_rotator_vs_oracle(ctx, kind, use_pca, power):
+    """ComplexMCARotator / HilbertMCARotator (cross/mca_rotator.py:78-210 over cpcca_rotator.py:122-263) against the
+    oracle's `cpcca_rotator_fit` fed with the SAME unrotated solution (complex singular vectors have arbitrary phases)."""
+    import xeofs_amd as xe
+
+    k, mrot = 5, 4
+    if kind == "complex":
+        A, B = _complex_pair()
+        model, Rot = xe.cross.ComplexMCA(n_modes=k, use_pca=use_pca, random_state=3), xe.cross.ComplexMCARotator
+    else:
+        A, B = _real_pair()
+        model, Rot = xe.cross.HilbertMCA(n_modes=k, use_pca=use_pca, random_state=3), xe.cross.HilbertMCARotator
+    X = xe.DataArray(A, dims=("time", "lat", "lon"))
+    Y = xe.DataArray(B, dims=("time", "y", "x"))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model.fit(X, Y, "time")
+    rot = Rot(n_modes=mrot, power=power).fit(model)
+    V = [None if f.pca is None else np.asarray(f.pca.components()).astype(np.complex128) for f in model.field]
+    m = dict(singular_values=np.asarray(model.data["singular_values"], dtype=np.float64),
+             components1=np.asarray(model.data["components1"]).astype(np.complex128),
+             components2=np.asarray(model.data["components2"]).astype(np.complex128),
+             scores1=np.asarray(model.data["scores1"]), scores2=np.asarray(model.data["scores2"]),
+             V=V, T=[None, None], Tinv=[None, None], total_squared_covariance=model.data["total_squared_covariance"])
+    ref = orc.cpcca_rotator_fit(m, mrot, power=power)
+    assert np.array_equal(rot.data["idx_modes_sorted"], ref["idx_modes_sorted"])
+    assert np.allclose(rot.squared_covariance().values, ref["squared_covariance"], rtol=5e-4)
+    assert np.allclose(rot.data["norm1"], ref["norm1"], rtol=5e-4) and np.allclose(rot.data["norm2"], ref["norm2"], rtol=5e-4)
+    assert np.abs(rot.rotation_matrix() - ref["rotation_matrix"]).max() < 5e-4
+    assert np.abs(rot.phi_matrix() - ref["phi_matrix"]).max() < 1e-3
+    c1, c2 = rot.components()
+    s1, s2 = rot.scores()
+    for got, key in ((c1, "components1"), (c2, "components2"), (s1, "scores1"), (s2, "scores2")):
+        g = got.values.reshape(mrot, -1).T
+        assert np.abs(g - ref[key]).max() < 2e-3 * np.abs(ref[key]).max(), key
+    a1, _ = rot.components_amplitude()
+    assert np.allclose(a1.values.reshape(mrot, -1).T, np.abs(ref["components1"]), atol=2e-3 * np.abs(ref["components1"]).max())
+    if kind == "hilbert":
+        with pytest.raises(NotImplementedError):
+            rot.transform(X)
+    else:       # cpcca_rotator.py:282-372: the training data reproduce the rotated scores
+        t1 = rot.transform(X=X)
+        assert np.abs(t1.values - s1.values).max() < 3e-3 * np.abs(s1.values).max()

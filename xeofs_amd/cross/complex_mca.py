@@ -315,3 +315,181 @@ class HilbertMCA(ComplexMCA):
 
     def transform(self, X=None, Y=None, normalized: bool = False):
         raise NotImplementedError("Hilbert models do not support the transform method.")
+
+
+class ComplexMCARotator:
+    """Drop-in for xeofs.cross.ComplexMCARotator (cross/mca_rotator.py:78-140 over cpcca_rotator.py:20-420): Varimax
+    (power = 1) / Promax rotation of a fitted `ComplexMCA`.  The stacked complex feature-space loadings [Qx; Qy] sqrt(s)
+    are rotated on the device as one [Re | Im] panel (`rotation.cpromax_panel`, up to 32 modes); their images in the
+    analysis space are Q sqrt(s) rotation_matrix -- k x k algebra (as in `CPCCARotator`)."""
+
+    _model_name = "Rotated Complex MCA"
+    _hilbert = False
+
+    def __init__(self, n_modes: int = 10, power: int = 1, max_iter: int | None = None, rtol: float = 1e-8,
+                 compute: bool = True):
+        if max_iter is None:
+            max_iter = 1000 if compute else 100
+        self._params = dict(n_modes=n_modes, power=power, max_iter=max_iter, rtol=rtol, compute=compute)
+        self.attrs = {"model": self._model_name}
+        self.attrs.update(self._params)
+        self.attrs.update({"software": "xeofs_amd", "version": __version__,
+                           "date": datetime.datetime.now().strftime("%Y-%m-%d %H:%M:%S")})
+        self.data, self.model_data = {}, {}
+        self.sorted = False
+
+    def get_params(self):
+        return dict(self._params)
+
+    def _rot_mat_inv_trans(self, R):
+        return np.linalg.inv(R).conj().T if self._params["power"] > 1 else R
+
+    def fit(self, model):
+        """cpcca_rotator.py:122-263 (+ the post-compute sort by squared covariance) with complex loadings"""
+        from .. import rotation
+
+        torch = engine._torch()
+        self.model = model
+        self.ctx = model.ctx
+        self.pre = model.pre_re
+        k = int(self._params["n_modes"])
+        s = np.asarray(model.data["singular_values"], dtype=np.float64)[:k]
+        k = s.size
+        scaling = np.sqrt(s)
+        C1 = np.asarray(model.data["components1"])[:, :k]
+        C2 = np.asarray(model.data["components2"])[:, :k]
+        p1 = C1.shape[0]
+        Xrot, ptot, k, rot_matrix, phi = rotation.cpromax_panel(self.ctx, np.concatenate([C1, C2], axis=0),
+                                                                power=self._params["power"], max_iter=self._params["max_iter"],
+                                                                rtol=self._params["rtol"], col_scale=scaling)
+        Qr = [model.data[f"Q{i + 1}"][:, :k] * scaling @ rot_matrix for i in range(2)]
+        norm1, norm2 = np.linalg.norm(Qr[0], axis=0), np.linalg.norm(Qr[1], axis=0)
+        sqcov = (norm1 * norm2) ** 2
+        idx = np.argsort(sqcov)[::-1]
+        RinvT = self._rot_mat_inv_trans(rot_matrix)
+        sc1 = (np.asarray(model.data["scores1"])[:, :k] / scaling) @ RinvT * norm1
+        sc2 = (np.asarray(model.data["scores2"])[:, :k] / scaling) @ RinvT * norm2
+        # sign rule on the stacked rotated loadings (xarray_utils.py:273-301; numpy's lexicographic complex max / min)
+        CH = rotation.CH
+        amax, amin = engine.panel_colargminmax(self.ctx, Xrot, ptot)
+        cols = torch.arange(k, device=Xrot.device)
+        pick = lambda ix: (Xrot[ix[:k], cols].double().cpu().numpy(), Xrot[ix[:k], cols + CH].double().cpu().numpy())
+        (mr, mi), (nr, ni) = pick(amax), pick(amin)
+        sign = np.where(np.hypot(mr, mi) >= np.hypot(nr, ni), 1.0, -1.0)
+        F = []
+        for norm, lo, hi in ((norm1, 0, p1), (norm2, p1, ptot)):
+            M = np.zeros((k, k), dtype=complex)
+            M[idx, np.arange(k)] = sign[idx] / norm[idx]
+            blk = engine.panel_matmul(self.ctx, Xrot[lo:], rotation._dev(rotation._cembed(M), Xrot))[:hi - lo].cpu().numpy()
+            c = np.empty((hi - lo, k), np.complex64)
+            c.real, c.imag = blk[:, :k], blk[:, CH:CH + k]
+            F.append(c)
+        del Xrot
+        self.model_data = dict(singular_values=np.asarray(model.data["singular_values"]), components1=C1, components2=C2)
+        self.data = dict(
+            components1=F[0], components2=F[1],
+            scores1=(sc1 * sign)[:, idx].astype(np.complex64), scores2=(sc2 * sign)[:, idx].astype(np.complex64),
+            squared_covariance=sqcov[idx], total_squared_covariance=model.data["total_squared_covariance"],
+            idx_modes_sorted=idx, norm1=norm1[idx], norm2=norm2[idx], rotation_matrix=rot_matrix, phi_matrix=phi,
+            modes_sign=sign[idx],
+        )
+        self.sorted = True
+        return self
+
+    # ------------------------------------------------------------------ transform (cpcca_rotator.py:282-372)
+    def transform(self, X=None, Y=None, normalized: bool = False):
+        if self._hilbert:
+            raise NotImplementedError("Hilbert models do not support the transform method.")
+        if X is None and Y is None:
+            raise ValueError("No data provided. Please provide X and/or Y.")
+        k = self.data["norm1"].size
+        RinvT = self._rot_mat_inv_trans(self.data["rotation_matrix"])
+        scaling = np.sqrt(np.asarray(self.model_data["singular_values"], dtype=np.float64)[:k])
+        outs = []
+        for which, Z in ((1, X), (2, Y)):
+            if Z is None:
+                continue
+            un = self.model.transform(**{"XY"[which - 1]: Z})          # unrotated scores: data . back-projected components
+            vals, dims, coords, name, attrs = labelled.unpack(un)
+            kk = vals.shape[0]
+            S = np.asarray(vals).reshape(kk, -1).T[:, :k]
+            ok = ~np.isnan(S).all(axis=1)
+            proj = np.full(S.shape, np.nan, dtype=complex)
+            proj[ok] = (S[ok] / scaling) @ RinvT
+            proj = proj[:, self.data["idx_modes_sorted"]] * self.data["modes_sign"]
+            if not normalized:
+                proj = proj * self.data[f"norm{which}"]
+            coords = dict(coords, mode=np.arange(1, k + 1))
+            outs.append(labelled.pack(proj.T.reshape((k,) + vals.shape[1:]), dims, coords, f"scores{which}", dict(self.attrs), un))
+        return outs[0] if len(outs) == 1 else outs
+
+    # ------------------------------------------------------------------ accessors
+    def _components(self, normalized):
+        q1, q2 = self.data["components1"], self.data["components2"]
+        if not normalized:
+            q1, q2 = q1 * self.data["norm1"].astype(np.float32), q2 * self.data["norm2"].astype(np.float32)
+        return q1, q2
+
+    def _scores(self, normalized):
+        s1, s2 = self.data["scores1"], self.data["scores2"]
+        if normalized:
+            s1, s2 = s1 / self.data["norm1"].astype(np.float32), s2 / self.data["norm2"].astype(np.float32)
+        return s1, s2
+
+    def _wc(self, c1, c2, name):
+        return (self.pre[0].inverse_transform_components(c1, name + "1", self.attrs),
+                self.pre[1].inverse_transform_components(c2, name + "2", self.attrs))
+
+    def _ws(self, s1, s2, name):
+        return (self.pre[0].inverse_transform_scores(s1, name + "1", self.attrs),
+                self.pre[1].inverse_transform_scores(s2, name + "2", self.attrs))
+
+    def components(self, normalized: bool = True):
+        return self._wc(*self._components(normalized), "components")
+
+    def scores(self, normalized: bool = False):
+        return self._ws(*self._scores(normalized), "scores")
+
+    def components_amplitude(self, normalized: bool = True):
+        c1, c2 = self._components(normalized)
+        return self._wc(np.abs(c1), np.abs(c2), "components_amplitude")
+
+    def components_phase(self, normalized: bool = True):
+        c1, c2 = self._components(normalized)
+        return self._wc(np.angle(c1), np.angle(c2), "components_phase")
+
+    def scores_amplitude(self, normalized: bool = False):
+        s1, s2 = self._scores(normalized)
+        return self._ws(np.abs(s1), np.abs(s2), "scores_amplitude")
+
+    def scores_phase(self, normalized: bool = False):
+        s1, s2 = self._scores(normalized)
+        return self._ws(np.angle(s1), np.angle(s2), "scores_phase")
+
+    def _mode_array(self, values, name):
+        k = len(values)
+        return labelled.pack(np.asarray(values), ("mode",), {"mode": np.arange(1, k + 1)}, name, dict(self.attrs),
+                             self.pre[0].fields[0].like)
+
+    def squared_covariance(self):
+        return self._mode_array(self.data["squared_covariance"], "squared_covariance")
+
+    def squared_covariance_fraction(self):
+        return self._mode_array(self.data["squared_covariance"] / self.data["total_squared_covariance"],
+                                "squared_covariance_fraction")
+
+    def rotation_matrix(self):
+        return self.data["rotation_matrix"]
+
+    def phi_matrix(self):
+        return self.data["phi_matrix"]
+
+    def fit_transform(self, *a, **k):
+        raise NotImplementedError("The fit_transform method is not implemented for the rotator classes.")
+
+
+class HilbertMCARotator(ComplexMCARotator):
+    """Drop-in for xeofs.cross.HilbertMCARotator (cross/mca_rotator.py:143-210); `transform` is not implemented there either."""
+
+    _model_name = "Rotated Hilbert MCA"
+    _hilbert = True
