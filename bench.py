@@ -405,7 +405,7 @@ def main():
             "config": {"workload": f"xe.single.EOF n_modes={k} on synthetic fp32 {n}x({args.nlat}x{args.nlon}), "
                                    f"feature axis sharded over {world} GPU(s), n_iter={n_iter}, n_oversamples=10, "
                                    f"random_state=5",
-                       "n_samples": n, "n_features": P, "n_modes": k, "passes": passes},
+                       "n_samples": n, "n_features": P, "n_modes": k, "passes": passes, "layout": args.layout},
             "modes_per_s": round(k / (ms_step * 1e-3), 2),
             "phase_ms": {"preprocess": round(1e3 * phase["pre"] / args.steps, 3),
                          "svd": round(1e3 * phase["svd"] / args.steps, 3)},

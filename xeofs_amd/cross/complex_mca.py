@@ -121,7 +121,6 @@ class ComplexMCA(Deferred):
             raise NotImplementedError(f"use_pca=False on a {A.n} x {A.p} field: the complex cross models decompose without "
                                       "PCA pre-reduction only up to n * p = %d elements; use use_pca=True" % MAX_DENSE)
         S = A.download().astype(np.float64) + 1j * B.download().astype(np.float64)
-        ctx = self.ctx
 
         def back(Q):
             return np.asarray(Q, dtype=np.complex64)
@@ -410,7 +409,7 @@ class ComplexMCARotator:
             if Z is None:
                 continue
             un = self.model.transform(**{"XY"[which - 1]: Z})          # unrotated scores: data . back-projected components
-            vals, dims, coords, name, attrs = labelled.unpack(un)
+            vals, dims, coords, _, _ = labelled.unpack(un)
             kk = vals.shape[0]
             S = np.asarray(vals).reshape(kk, -1).T[:, :k]
             ok = ~np.isnan(S).all(axis=1)
