@@ -154,6 +154,9 @@ def test_mca_against_oracle_and_invariants():  # test_mca.py:20-119, test_cpcca.
     assert s1.dims == ("mode", "time") and np.allclose(s1.values, ref["scores1"].T, rtol=1e-3, atol=1e-3)
     assert np.isclose(m.total_squared_covariance(), ref["total_squared_covariance"], rtol=1e-5)
     assert m.squared_covariance_fraction().values.sum() <= 1 + 1e-5
+    with pytest.warns(UserWarning, match="sensitive to the number of modes"):     # mca.py:127-189, 3 modes of 28
+        cf = m.covariance_fraction_CD95().values
+    assert np.allclose(cf, ref["singular_values"] / ref["singular_values"].sum(), rtol=2e-5)
     t1, t2 = m.transform(X=X, Y=Y)
     assert np.allclose(t1.values, s1.values, rtol=1e-3, atol=1e-3) and not np.isnan(t2.values).any()
     with pytest.raises(ValueError, match="same number of samples"):

@@ -479,6 +479,16 @@ class MCA(CPCCA):
                          solver=solver, random_state=random_state, solver_kwargs=solver_kwargs)
         self._params.pop("alpha")
 
+    def covariance_fraction_CD95(self):
+        """mca.py:127-189 (Cheng & Dunkerton 1995): CF_i = sigma_i / sum_j sigma_j over the retained modes, with the
+        reference's warning when the estimate still moves by more than 1e-3 with the last mode."""
+        s = np.asarray(self.data["singular_values"], dtype=np.float64)
+        cf = s[0] / np.cumsum(s)
+        if len(s) > 1 and (cf[-2] - cf[-1]) > 0.001:
+            warnings.warn("The curent estimate of CF is sensitive to the number of modes retained. Please increase "
+                          "`n_modes` for a better estimate.")
+        return self._mode_array(s / s.sum(), "covariance_fraction")
+
 
 class CCA(CPCCA):
     """cross/cca.py: CPCCA with alpha = [0, 0]."""
