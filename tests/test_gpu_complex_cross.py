@@ -200,3 +200,60 @@ def test_complex_mca_rotator_vs_oracle(ctx, kind, use_pca, power):
     else:       # cpcca_rotator.py:282-372: the training data reproduce the rotated scores
         t1 = rot.transform(X=X)
         assert np.abs(t1.values - s1.values).max() < 3e-3 * np.abs(s1.values).max()
+
+
+@pytest.mark.parametrize("cls,alpha", [("ComplexCPCCA", 0.3), ("ComplexCPCCA", [0.8, 0.1]), ("ComplexCCA", [0.0, 0.0]),
+                                       ("ComplexRDA", [0.0, 1.0]), ("HilbertCPCCA", 0.5), ("HilbertCCA", [0.0, 0.0]),
+                                       ("HilbertRDA", [0.0, 1.0])])
+def test_complex_cpcca_family_vs_oracle(ctx, cls, alpha):
+    """ComplexCPCCA / HilbertCPCCA with fractional whitening (cpcca.py:1023-1500 over preprocessing/whitener.py:86-141)
+    and their fixed-alpha children ComplexCCA / ComplexRDA / HilbertCCA / HilbertRDA against the oracle's `cpcca_fit`
+    (PCA pre-reduction to a fixed number of modes so that both sides whiten the same space)."""
+    import xeofs_amd as xe
+
+    hil = cls.startswith("Hilbert")
+    A, B = _real_pair(noise=0.3) if hil else _complex_pair(noise=0.3)
+    n, k, npca = A.shape[0], 3, 8
+    X = xe.DataArray(A, dims=("time", "lat", "lon"))
+    Y = xe.DataArray(B, dims=("time", "y", "x"))
+    kw = dict(n_modes=k, use_pca=True, n_pca_modes=npca, random_state=3)
+    if cls.endswith("CPCCA"):
+        kw["alpha"] = alpha
+    m = getattr(xe.cross, cls)(**kw)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m.fit(X, Y, "time")
+        ref = orc.cpcca_fit(A.reshape(n, -1), B.reshape(n, -1), k, alpha=alpha, use_pca=True, n_pca_modes=npca,
+                            random_state=3, pca_random_state=3, pca_solver="full", solver="full",
+                            hilbert=("exp", 0.2) if hil else None)
+    assert m.alpha == [float(a) for a in (alpha if isinstance(alpha, list) else [alpha, alpha])]
+    s = m.singular_values().values
+    assert np.allclose(s, ref["singular_values"], rtol=5e-4), (s, ref["singular_values"])
+    assert np.isclose(m.total_squared_covariance(), ref["total_squared_covariance"], rtol=2e-3)
+    c1, c2 = m.components()
+    s1, s2 = m.scores()
+    C = [c1.values.reshape(k, -1).T.astype(np.complex128), c2.values.reshape(k, -1).T.astype(np.complex128)]
+    S = [s1.values.reshape(k, -1).T.astype(np.complex128), s2.values.reshape(k, -1).T.astype(np.complex128)]
+    ph = np.sum(ref["components1"].conj() * C[0], axis=0)
+    ph = ph / np.abs(ph)
+    for i in range(2):
+        R, Rs = ref[f"components{i + 1}"], ref[f"scores{i + 1}"]
+        assert np.abs(C[i] / ph - R).max() < 1e-2 * np.abs(R).max(), (cls, i)
+        assert np.abs(S[i] / ph - Rs).max() < 1e-2 * np.abs(Rs).max(), (cls, i)
+    assert np.allclose(m.data["norm1"], ref["norm1"], rtol=2e-3) and np.allclose(m.data["norm2"], ref["norm2"], rtol=2e-3)
+    if not hil:      # transform of the training data reproduces the scores through PCA, whitener and singular vectors
+        t1 = m.transform(X=X)
+        assert np.abs(t1.values - s1.values).max() < 5e-3 * np.abs(s1.values).max()
+    # rotation of a whitened complex model (cpcca_rotator.py:472-600)
+    Rot = xe.cross.HilbertCPCCARotator if hil else xe.cross.ComplexCPCCARotator
+    rot = Rot(n_modes=3, power=1).fit(m)
+    V = [np.asarray(f.pca.components()).astype(np.complex128) for f in m.field]
+    md = dict(singular_values=np.asarray(m.data["singular_values"], dtype=np.float64),
+              components1=np.asarray(m.data["components1"]).astype(np.complex128),
+              components2=np.asarray(m.data["components2"]).astype(np.complex128),
+              scores1=np.asarray(m.data["scores1"]), scores2=np.asarray(m.data["scores2"]),
+              V=V, T=m.T, Tinv=m.Tinv, total_squared_covariance=m.data["total_squared_covariance"])
+    rr = orc.cpcca_rotator_fit(md, 3, power=1)
+    assert np.allclose(rot.squared_covariance().values, rr["squared_covariance"], rtol=5e-3)
+    g1 = rot.components()[0].values.reshape(3, -1).T
+    assert np.abs(g1 - rr["components1"]).max() < 1e-2 * np.abs(rr["components1"]).max()

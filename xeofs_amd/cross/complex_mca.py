@@ -1,10 +1,13 @@
-"""Complex and Hilbert MCA (xeofs/cross/mca.py:224-489 on top of xeofs/cross/cpcca.py:1023-1500 with alpha = 1).
+"""The complex and Hilbert cross models: ComplexCPCCA / HilbertCPCCA (xeofs/cross/cpcca.py:1023-1500) and their fixed-alpha
+children ComplexMCA / HilbertMCA (cross/mca.py:224-489, alpha = 1), ComplexCCA / HilbertCCA (cross/cca.py:123-355,
+alpha = 0), ComplexRDA / HilbertRDA (cross/rda.py:123-355, alpha = [0, 1]), plus their rotators.
 
-`ComplexMCA` takes complex fields Z_x = U_x + i V_x, Z_y = U_y + i V_y; `HilbertMCA` takes real fields and augments them
-with their Hilbert transform.  Order of the stages as in base_model_cross_set.py:300-315:
+The `Complex*` classes take complex fields Z_x = U_x + i V_x, Z_y = U_y + i V_y; the `Hilbert*` classes take real fields and
+augment them with their Hilbert transform.  Order of the stages as in base_model_cross_set.py:300-315:
 
-    preprocess -> PCA pre-reduction (default) -> [Hilbert transform of the PC scores: `_augment_data`] -> (alpha = 1: no
-    whitening) -> cross-covariance C = S_x^H S_y / (n - 1) -> SVD of C -> scores, norms, total squared covariance.
+    preprocess -> PCA pre-reduction (default) -> [Hilbert transform of the PC scores: `_augment_data`] -> fractional
+    whitening T = (S^H S / n)^((alpha - 1) / 2) (identity for alpha = 1) -> cross-covariance C = S_x^H S_y / (n - 1) ->
+    SVD of C -> scores, norms, total squared covariance of the UNwhitened matrices.
 
 What runs on the GPU: the preprocessor, the PCA pre-reductions -- `ResidentPCA` on the real fields of the Hilbert model
 (its analytic signal is taken of the n x m PC scores, through the same `eofx_hilbert_f32`), `ComplexResidentPCA`
@@ -37,6 +40,13 @@ def _pair(v):
     return list(v) if isinstance(v, (list, tuple)) else [v, v]
 
 
+def _hermitian_power(C, power):
+    """linalg/_numpy/_utils.py:6-33 for a Hermitian PSD matrix: V s^power V^H, s <= eps dropped"""
+    w, V = np.linalg.eigh(0.5 * (C + C.conj().T))
+    keep = w > np.finfo(w.dtype).eps
+    return (V[:, keep] * w[keep] ** power) @ V[:, keep].conj().T
+
+
 def _sign_rule(VT):
     """utils/xarray_utils.py:273-301: +1 where |max| >= |min| per mode, numpy's lexicographic complex max / min"""
     mx, mn = VT.max(axis=1), VT.min(axis=1)
@@ -56,16 +66,17 @@ class _Field:
         self.parts = ()
 
 
-class ComplexMCA(Deferred):
-    """Drop-in for xeofs.cross.ComplexMCA (cross/mca.py:224-338)."""
+class ComplexCPCCA(Deferred):
+    """Drop-in for xeofs.cross.ComplexCPCCA (cross/cpcca.py:1023-1326)."""
 
-    _model_name = "Complex MCA"
+    _model_name = "Complex CPCCA"
     _hilbert = False
 
-    def __init__(self, n_modes: int = 2, standardize=False, use_coslat=False, check_nans=True, use_pca=True,
+    def __init__(self, n_modes: int = 2, alpha=0.2, standardize=False, use_coslat=False, check_nans=True, use_pca=True,
                  n_pca_modes=0.999, pca_init_rank_reduction=0.3, compute: bool = True, sample_name: str = "sample",
                  feature_name="feature", solver: str = "auto", random_state=None, solver_kwargs: dict = {}, **kwargs):
         sanity_check_n_modes(n_modes)
+        self.alpha = [float(a) for a in _pair(alpha)]
         if solver not in ("auto", "full", "randomized"):
             raise ValueError(f"Unrecognized solver '{solver}'. Valid options are 'auto', 'full', and 'randomized'.")
         self.n_modes = n_modes
@@ -73,7 +84,7 @@ class ComplexMCA(Deferred):
         self._params = dict(n_modes=n_modes, standardize=std, use_coslat=cos, check_nans=chk, use_pca=_pair(use_pca),
                             n_pca_modes=_pair(n_pca_modes), pca_init_rank_reduction=_pair(pca_init_rank_reduction),
                             sample_name=sample_name, feature_name=_pair(feature_name), random_state=random_state,
-                            compute=compute, solver=solver)
+                            compute=compute, solver=solver, alpha=list(self.alpha))
         self.sample_name = sample_name
         self.solver_kwargs = dict(solver_kwargs)
         # CPCCA always centres (cpcca.py:145); real and imaginary parts share centring, scaling and weights
@@ -147,10 +158,28 @@ class ComplexMCA(Deferred):
         fy = self._make_field(1, Y, dim, weights_Y)
         self.field = [fx, fy]
         self.sample_dims = self.pre_re[0].sample_dims
-        Sx, Sy = fx.S, fy.S
-        if Sx.shape[0] != Sy.shape[0]:
+        if fx.S.shape[0] != fy.S.shape[0]:
             raise ValueError("Both data matrices must have the same number of samples but found "
-                             f"{Sx.shape[0]} in the first and {Sy.shape[0]} in the second.")
+                             f"{fx.S.shape[0]} in the first and {fy.S.shape[0]} in the second.")
+        # fractional whitening in the analysis space (preprocessing/whitener.py:86-141; identity when alpha == 1, :46-60)
+        self.T, self.Tinv, Sw = [None, None], [None, None], []
+        for i, fld in enumerate((fx, fy)):
+            S = fld.S
+            if not np.isclose(self.alpha[i], 1.0):
+                n_, m_ = S.shape
+                if n_ < m_:                                          # whitener.py:101-104
+                    warnings.warn(f"The number of samples ({n_}) is smaller than the number of features ({m_}), leading to "
+                                  "an ill-conditioned problem. This may cause unstable results. Consider using PCA to "
+                                  "reduce dimensionality and stabilize the problem by setting `use_pca=True`.")
+                T = _hermitian_power(np.ascontiguousarray(S.conj().T) @ S / n_, (self.alpha[i] - 1) / 2)
+                try:
+                    Tinv = np.linalg.inv(T)
+                except np.linalg.LinAlgError:
+                    Tinv = np.linalg.pinv(T)
+                self.T[i], self.Tinv[i] = T, Tinv
+                S = S @ T
+            Sw.append(S)
+        Sx, Sy = Sw
         n = Sx.shape[0]
         k = int(self.n_modes)
         C = np.ascontiguousarray(Sx.conj().T) @ Sy / (n - 1)     # cpcca.py:1008-1016
@@ -169,9 +198,15 @@ class ComplexMCA(Deferred):
         scores1, scores2 = Sx @ Q1, Sy @ Q2
         norm1 = np.sqrt((scores1.conj() * scores1).sum(axis=0).real)
         norm2 = np.sqrt((scores2.conj() * scores2).sum(axis=0).real)
-        self.data = dict(Q1=Q1, Q2=Q2, components1=fx.back(Q1), components2=fy.back(Q2), scores1=scores1, scores2=scores2,
-                         singular_values=s, squared_covariance=s ** 2,
-                         total_squared_covariance=float((np.abs(C) ** 2).sum()), norm1=norm1, norm2=norm2)
+        Cu = C if self.Tinv[1] is None else C @ self.Tinv[1]        # cpcca.py:991-1000: of the unwhitened matrices
+        Cu = Cu.conj().T if self.Tinv[0] is None else Cu.conj().T @ self.Tinv[0]
+
+        def back(fld, Q, i):      # whitener.inverse_transform_components, then pca.inverse_transform_components
+            return fld.back(Q if self.Tinv[i] is None else self.Tinv[i].conj().T @ Q)
+
+        self.data = dict(Q1=Q1, Q2=Q2, components1=back(fx, Q1, 0), components2=back(fy, Q2, 1), scores1=scores1,
+                         scores2=scores2, singular_values=s, squared_covariance=s ** 2,
+                         total_squared_covariance=float((np.abs(Cu) ** 2).sum()), norm1=norm1, norm2=norm2)
         return self
 
     # ------------------------------------------------------------------ accessors
@@ -237,6 +272,8 @@ class ComplexMCA(Deferred):
     def squared_covariance_fraction(self):
         """cpcca.py:418-512 with alpha = 1: the residual form 1 - ||d_X^H d_Y||^2 / ||X^H Y||^2 of a rank-one deflation
         equals sigma_i^2 / sum sigma^2 (the singular triplets are orthogonal)"""
+        if not all(np.isclose(a, 1.0) for a in self.alpha):
+            raise NotImplementedError("squared_covariance_fraction of the complex models is provided for alpha = 1 (MCA)")
         scf = self.data["squared_covariance"] / self.data["total_squared_covariance"]
         return self._mode_array(scf, "squared_covariance_fraction")
 
@@ -265,7 +302,10 @@ class ComplexMCA(Deferred):
                                dims, coords, name, attrs, Z)
             An, fields, vs = self.pre_re[i].transform(re)
             Bn, _, _ = self.pre_im[i].transform(im)
-            S = self.field[i].project(An, Bn) @ self.data[f"Q{i + 1}"]
+            S = self.field[i].project(An, Bn)
+            if self.T[i] is not None:
+                S = S @ self.T[i]
+            S = S @ self.data[f"Q{i + 1}"]
             An.free()
             Bn.free()
             if normalized:
@@ -274,15 +314,15 @@ class ComplexMCA(Deferred):
         return out[0] if len(out) == 1 else out
 
 
-class HilbertMCA(ComplexMCA):
-    """Drop-in for xeofs.cross.HilbertMCA (cross/mca.py:340-489, cpcca.py:1328-1500): real fields, analytic signal of the
-    (PCA-reduced) data along the sample axis, optional exponential padding against spectral leakage."""
+class HilbertCPCCA(ComplexCPCCA):
+    """Drop-in for xeofs.cross.HilbertCPCCA (cpcca.py:1328-1500): real fields, analytic signal of the (PCA-reduced) data
+    along the sample axis, optional exponential padding against spectral leakage."""
 
-    _model_name = "Hilbert MCA"
+    _model_name = "Hilbert CPCCA"
     _hilbert = True
 
-    def __init__(self, n_modes: int = 2, padding="exp", decay_factor=0.2, **kwargs):
-        super().__init__(n_modes=n_modes, **kwargs)
+    def __init__(self, n_modes: int = 2, alpha=0.2, padding="exp", decay_factor=0.2, **kwargs):
+        super().__init__(n_modes=n_modes, alpha=alpha, **kwargs)
         self._params["padding"] = _pair(padding)
         self._params["decay_factor"] = _pair(decay_factor)
 
@@ -316,13 +356,13 @@ class HilbertMCA(ComplexMCA):
         raise NotImplementedError("Hilbert models do not support the transform method.")
 
 
-class ComplexMCARotator:
-    """Drop-in for xeofs.cross.ComplexMCARotator (cross/mca_rotator.py:78-140 over cpcca_rotator.py:20-420): Varimax
-    (power = 1) / Promax rotation of a fitted `ComplexMCA`.  The stacked complex feature-space loadings [Qx; Qy] sqrt(s)
+class ComplexCPCCARotator:
+    """Drop-in for xeofs.cross.ComplexCPCCARotator (cross/cpcca_rotator.py:472-534 over :20-420): Varimax
+    (power = 1) / Promax rotation of a fitted complex cross model.  The stacked complex feature-space loadings [Qx; Qy] sqrt(s)
     are rotated on the device as one [Re | Im] panel (`rotation.cpromax_panel`, up to 32 modes); their images in the
     analysis space are Q sqrt(s) rotation_matrix -- k x k algebra (as in `CPCCARotator`)."""
 
-    _model_name = "Rotated Complex MCA"
+    _model_name = "Rotated Complex CPCCA"
     _hilbert = False
 
     def __init__(self, n_modes: int = 10, power: int = 1, max_iter: int | None = None, rtol: float = 1e-8,
@@ -487,8 +527,41 @@ class ComplexMCARotator:
         raise NotImplementedError("The fit_transform method is not implemented for the rotator classes.")
 
 
-class HilbertMCARotator(ComplexMCARotator):
-    """Drop-in for xeofs.cross.HilbertMCARotator (cross/mca_rotator.py:143-210); `transform` is not implemented there either."""
+class HilbertCPCCARotator(ComplexCPCCARotator):
+    """Drop-in for xeofs.cross.HilbertCPCCARotator (cpcca_rotator.py:536-600); `transform` is not implemented there either."""
+
+    _model_name = "Rotated Hilbert CPCCA"
+    _hilbert = True
+
+
+class ComplexMCARotator(ComplexCPCCARotator):
+    """Drop-in for xeofs.cross.ComplexMCARotator (cross/mca_rotator.py:77-150)."""
+
+    _model_name = "Rotated Complex MCA"
+
+
+class HilbertMCARotator(HilbertCPCCARotator):
+    """Drop-in for xeofs.cross.HilbertMCARotator (cross/mca_rotator.py:153-230)."""
 
     _model_name = "Rotated Hilbert MCA"
-    _hilbert = True
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# the fixed-alpha children (cross/mca.py, cca.py, rda.py) and the rotator names of cross/cpcca_rotator.py, mca_rotator.py
+# --------------------------------------------------------------------------------------------------------------------
+def _fixed_alpha(base, alpha, name, doc):
+    def __init__(self, n_modes: int = 2, **kwargs):
+        kwargs.pop("alpha", None)
+        base.__init__(self, n_modes=n_modes, alpha=alpha, **kwargs)
+        self._params.pop("alpha", None)          # hard-coded for these classes (mca.py:120-123)
+        self.attrs["model"] = name
+
+    return type(name.replace(" ", ""), (base,), {"__init__": __init__, "__doc__": doc, "_model_name": name})
+
+
+ComplexMCA = _fixed_alpha(ComplexCPCCA, [1.0, 1.0], "Complex MCA", "Drop-in for xeofs.cross.ComplexMCA (cross/mca.py:224-338).")
+ComplexCCA = _fixed_alpha(ComplexCPCCA, [0.0, 0.0], "Complex CCA", "Drop-in for xeofs.cross.ComplexCCA (cross/cca.py:123-237).")
+ComplexRDA = _fixed_alpha(ComplexCPCCA, [0.0, 1.0], "Complex RDA", "Drop-in for xeofs.cross.ComplexRDA (cross/rda.py:123-237).")
+HilbertMCA = _fixed_alpha(HilbertCPCCA, [1.0, 1.0], "Hilbert MCA", "Drop-in for xeofs.cross.HilbertMCA (cross/mca.py:340-489).")
+HilbertCCA = _fixed_alpha(HilbertCPCCA, [0.0, 0.0], "Hilbert CCA", "Drop-in for xeofs.cross.HilbertCCA (cross/cca.py:239-355).")
+HilbertRDA = _fixed_alpha(HilbertCPCCA, [0.0, 1.0], "Hilbert RDA", "Drop-in for xeofs.cross.HilbertRDA (cross/rda.py:239-355).")
