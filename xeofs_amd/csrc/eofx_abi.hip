@@ -1086,7 +1086,9 @@ struct PreState {  // device arrays of length P
 static int run_colstats(eofx_ctx* ctx, const float* Xd, int64_t n, int64_t P, int center, int standardize,
                         const double* w_dev, PreState& ps, int64_t ld = 0, const int64_t* row_map = nullptr) {
   if (ld == 0) ld = P;
-  const int gx = (int)((P + 255) / 256);
+  const bool vec4 = P % 4 == 0 && ld % 4 == 0 && ((uintptr_t)Xd % 16) == 0;     // four features per thread, 16-byte loads
+  const int gxs = (int)((P + 255) / 256);                    // workgroups of the finalize kernel (one thread per feature)
+  const int gx = vec4 ? (int)((P / 4 + 255) / 256) : gxs;
   int64_t RS = std::max<int64_t>(1, (2048 + gx - 1) / gx);
   RS = std::min<int64_t>(RS, std::max<int64_t>(1, n / 64));
   const int64_t rps = (n + RS - 1) / RS;
@@ -1097,11 +1099,15 @@ static int run_colstats(eofx_ctx* ctx, const float* Xd, int64_t n, int64_t P, in
   ARENA(double, sq_p, (size_t)RS * P);
   ARENA(float, mn_p, (size_t)RS * P);
   ARENA(float, mx_p, (size_t)RS * P);
-  hipLaunchKernelGGL(colstats_kernel, dim3(gx, (int)RS), dim3(256), 0, ctx->stream, Xd, n, P, ld, row_map, rps,
-                     cnt_p, sum_p, sq_p, mn_p, mx_p);
+  if (vec4)
+    hipLaunchKernelGGL(colstats4_kernel, dim3(gx, (int)RS), dim3(256), 0, ctx->stream, Xd, n, P, ld, row_map, rps,
+                       cnt_p, sum_p, sq_p, mn_p, mx_p);
+  else
+    hipLaunchKernelGGL(colstats_kernel, dim3(gx, (int)RS), dim3(256), 0, ctx->stream, Xd, n, P, ld, row_map, rps,
+                       cnt_p, sum_p, sq_p, mn_p, mx_p);
   KCHK();
   HIPCHK(hipMemsetAsync(ps.absmax, 0, sizeof(unsigned), ctx->stream));
-  hipLaunchKernelGGL(colstats_finalize_kernel, dim3(gx), dim3(256), 0, ctx->stream, cnt_p, sum_p, sq_p, mn_p, mx_p,
+  hipLaunchKernelGGL(colstats_finalize_kernel, dim3(gxs), dim3(256), 0, ctx->stream, cnt_p, sum_p, sq_p, mn_p, mx_p,
                      (int)RS, P, center, standardize, w_dev, (double)1.1920928955078125e-07, ps.cnt,
                      ps.mean, ps.stdv, ps.shift, ps.scale, ps.m2, ps.absmax);
   KCHK();
@@ -1137,7 +1143,7 @@ static int run_feature_summary(eofx_ctx* ctx, const PreState& ps, int64_t P, Fea
 }
 
 static size_t colstats_scratch(int64_t n, int64_t P) {
-  const int64_t gx = (P + 255) / 256;
+  const int64_t gx = (P / 4 + 255) / 256;      // the four-features-per-thread kernel: fewer workgroups, more row splits
   int64_t RS = std::max<int64_t>(1, (2048 + gx - 1) / gx);
   RS = std::min<int64_t>(RS, std::max<int64_t>(1, n / 64));
   return (size_t)(RS + 1) * P * 32 + (size_t)P * 64 + (size_t)n * 16 + (1 << 20);

@@ -1458,6 +1458,59 @@ __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__
   vmax[o] = hi;
 }
 
+// The same statistics with FOUR adjacent features per thread (16-byte loads: one instruction of a wave covers 1 KiB of a
+// row instead of 256 B).  P % 4 == 0, ld % 4 == 0, X 16-byte aligned.  Rows are summed in the same order per split.
+__global__ __launch_bounds__(256) void colstats4_kernel(const float* __restrict__ X, int64_t n, int64_t P, int64_t ld,
+                                                         const int64_t* __restrict__ row_map, int64_t rows_per_split,
+                                                         int* __restrict__ cnt, double* __restrict__ sum,
+                                                         double* __restrict__ sumsq, float* __restrict__ vmin,
+                                                         float* __restrict__ vmax) {
+  const int64_t c = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (c >= P) return;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_split;
+  const int64_t r1 = (r0 + rows_per_split < n) ? r0 + rows_per_split : n;
+  int k[4] = {0, 0, 0, 0};
+  double s[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
+  float lo[4] = {INFINITY, INFINITY, INFINITY, INFINITY}, hi[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  auto take = [&](const f32x4& v) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      lo[e] = fminf(lo[e], v[e]);      // fminf / fmaxf skip NaN
+      hi[e] = fmaxf(hi[e], v[e]);
+      if (v[e] == v[e]) {
+        const double d = (double)v[e];
+        ++k[e];
+        s[e] += d;
+        q[e] += d * d;
+      }
+    }
+  };
+  int64_t r = r0;
+  for (; r + 8 <= r1; r += 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int64_t rr = row_map ? row_map[r + u] : r + u;      // wave-uniform -> scalar loads
+      v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(X + rr * ld + c));
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) take(v[u]);
+  }
+  for (; r < r1; ++r) {
+    const int64_t rr = row_map ? row_map[r] : r;
+    take(*reinterpret_cast<const f32x4*>(X + rr * ld + c));
+  }
+  const int64_t o = (int64_t)blockIdx.y * P + c;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    cnt[o + e] = k[e];
+    sum[o + e] = s[e];
+    sumsq[o + e] = q[e];
+    vmin[o + e] = lo[e];
+    vmax[o + e] = hi[e];
+  }
+}
+
 // One thread per feature.  weights may be null (ones).  Outputs per (uncompacted) feature.
 __global__ __launch_bounds__(256) void colstats_finalize_kernel(
     const int* __restrict__ cnt_p, const double* __restrict__ sum_p,
