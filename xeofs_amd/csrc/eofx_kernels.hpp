@@ -527,7 +527,7 @@ __global__ __launch_bounds__(256, 2) void axb_f16_kernel(const float* __restrict
                                                           int ldc, int64_t c_rows, int64_t K, int64_t k_per_split,
                                                           int splits, int row_tiles, int col_base, float a_scale,
                                                           const float* __restrict__ b_absmax) {
-  __shared__ __attribute__((aligned(16))) _Float16 Bs[2][2][4][64][8];
+  __shared__ __attribute__((aligned(16))) _Float16 Bs[2][2][8][64][8];    // [buffer][plane][k-group of 8][column slot][8]
   __shared__ __attribute__((aligned(16))) _Float16 As[4][2][64][AXB_LDA];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: scalar branches below
@@ -540,6 +540,7 @@ __global__ __launch_bounds__(256, 2) void axb_f16_kernel(const float* __restrict
   const bool live = r0 < a_rows;
   const bool full = r0 + 64 <= a_rows;
   const unsigned ldab = (unsigned)lda * 4u;   // row pitch in bytes
+  const unsigned lrl = (unsigned)lr * ldab;   // this lane's row inside a group of 8
   const int64_t kb = (int64_t)split * k_per_split;
   const int64_t ke = (kb + k_per_split < K) ? kb + k_per_split : K;
   const int nslab = (int)((ke - kb) / AXB_KC);
@@ -567,18 +568,18 @@ __global__ __launch_bounds__(256, 2) void axb_f16_kernel(const float* __restrict
   const bool b_loader = bc4 < 4 * NQ;
   const int bo = ((int)kb + bk) * ldb + bcol0 + 4 * (bc4 % (4 * NQ));
 
-  f32x4 a0[8], a1[8], f0[3], f1[3];
+  f32x4 a0[8], a1[8], fr[3];
   float m1 = -1.f;   // opaque to the optimiser: x - (float)h stays ONE v_fma_mix_f32 instead of a conversion and a subtraction
   asm volatile("" : "+v"(m1));
-  f32x4 bn0 = {0.f, 0.f, 0.f, 0.f}, bn1 = bn0;
+  f32x4 bn[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #define EOFX_AXB_LD(p_) ((DBG & 8) ? *reinterpret_cast<const f32x4*>(p_) : __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p_)))
   // Every thread issues the same loads on every path (the partial-tile branch issues as many as the full one): the
   // compiler's vmcnt bookkeeping stays exact, and a wait for an older load leaves the younger ones in flight.
-#define EOFX_LOAD_B(chunk)                                                                             \
+#define EOFX_LOAD_BH(pair, hb)   /* B slab = 64 features = TWO A slabs; half hb: rows bk, bk + 1 of that half */ \
   do {                                                                                                 \
     if (!(DBG & 4)) {                                                                                  \
-      bn0 = *reinterpret_cast<const f32x4*>(B + (bo + (chunk) * AXB_KC * ldb));                        \
-      bn1 = *reinterpret_cast<const f32x4*>(B + (bo + (chunk) * AXB_KC * ldb + ldb));                  \
+      bn[0] = *reinterpret_cast<const f32x4*>(B + (bo + ((pair) * AXB_KG + 32 * (hb)) * ldb));         \
+      bn[1] = *reinterpret_cast<const f32x4*>(B + (bo + ((pair) * AXB_KG + 32 * (hb) + 1) * ldb));     \
     }                                                                                                  \
   } while (0)
 #define EOFX_LOAD_F(freg, chunk)                                                                       \
@@ -596,8 +597,12 @@ __global__ __launch_bounds__(256, 2) void axb_f16_kernel(const float* __restrict
     const bool kin_ = fo + ko_ < a_cols;                                                               \
     const unsigned kof_ = kin_ ? (unsigned)(fo + ko_) * 4u : 0u;                                       \
     if (full) {                                                                                        \
+      /* per-slab base in ONE register + uniform multiples of the row pitch: nothing per row group for the */ \
+      /* optimiser to hoist out of the loop (eight hoisted offsets spilled, and a scratch reload drains vmcnt) */ \
+      unsigned base_ = lrl + kof_;                                                                     \
+      asm volatile("" : "+v"(base_));                                                                  \
       _Pragma("unroll") for (int u = (u0); u < (u0) + 4; ++u)                                          \
-          areg[u] = EOFX_AXB_LD(Ab + ((unsigned)(8 * u + lr) * ldab + kof_));                          \
+          areg[u] = EOFX_AXB_LD(Ab + (base_ + (unsigned)(8 * u) * ldab));                              \
     } else {                                                                                           \
       int lr_ = lr;   /* the one partial wave per split: recomputed per slab, nothing kept live */      \
       asm volatile("" : "+v"(lr_));                                                                    \
@@ -607,18 +612,18 @@ __global__ __launch_bounds__(256, 2) void axb_f16_kernel(const float* __restrict
       }                                                                                                \
     }                                                                                                  \
   } while (0)
-#define EOFX_STORE_B(buf)                                                                              \
+#define EOFX_STORE_BH(buf, hb)                                                                         \
   do {                                                                                                 \
     if (b_loader) _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                      \
       const int col_ = 4 * bc4 + e;                                                                    \
       const int sl_ = col_ ^ ((col_ >> 3) & 7);                                                        \
-      const float v0_ = bn0[e] * b_scale, v1_ = bn1[e] * b_scale;                                      \
+      const float v0_ = bn[0][e] * b_scale, v1_ = bn[1][e] * b_scale;                                  \
       const fp16x2_t h_ = __builtin_amdgcn_cvt_pkrtz(v0_, v1_);                                        \
       fp16x2_t l_;                                                                                     \
       l_[0] = (__fp16)__builtin_fmaf((float)h_[0], m1, v0_);                                           \
       l_[1] = (__fp16)__builtin_fmaf((float)h_[1], m1, v1_);                                           \
-      *reinterpret_cast<unsigned*>(&Bs[buf][0][wave][sl_][bt]) = __builtin_bit_cast(unsigned, h_);     \
-      *reinterpret_cast<unsigned*>(&Bs[buf][1][wave][sl_][bt]) = __builtin_bit_cast(unsigned, l_);     \
+      *reinterpret_cast<unsigned*>(&Bs[buf][0][wave + 4 * (hb)][sl_][bt]) = __builtin_bit_cast(unsigned, h_); \
+      *reinterpret_cast<unsigned*>(&Bs[buf][1][wave + 4 * (hb)][sl_][bt]) = __builtin_bit_cast(unsigned, l_); \
     }                                                                                                  \
   } while (0)
   // map + split this lane's 4 features of row groups u0 .. u0+3 into the wave's LDS region
@@ -644,7 +649,7 @@ __global__ __launch_bounds__(256, 2) void axb_f16_kernel(const float* __restrict
     *reinterpret_cast<u32x2*>(&As[wave][1][8 * u + lr][4 * lc]) = lo_;                                 \
   }
   // 32 rows (two 16-row tiles) x NQ column tiles: the three products ordered so that dependent MFMAs are 2 NQ apart
-#define EOFX_AXB_MFMA(jh, buf)                                                                         \
+#define EOFX_AXB_MFMA(jh, buf, hs)     /* hs: which half of the 64-feature B slab this A slab is */      \
   do {                                                                                                 \
     f16x8 af_[2][2], bf_[2][NQ];                                                                       \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int s = 0; s < 2; ++s)        \
@@ -652,8 +657,8 @@ __global__ __launch_bounds__(256, 2) void axb_f16_kernel(const float* __restrict
     _Pragma("unroll") for (int q = 0; q < NQ; ++q) {                                                   \
       const int col_ = 16 * q + ln;                                                                    \
       const int sl_ = col_ ^ ((col_ >> 3) & 7);                                                        \
-      bf_[0][q] = *reinterpret_cast<const f16x8*>(&Bs[buf][0][g][sl_][0]);                             \
-      bf_[1][q] = *reinterpret_cast<const f16x8*>(&Bs[buf][1][g][sl_][0]);                             \
+      bf_[0][q] = *reinterpret_cast<const f16x8*>(&Bs[buf][0][g + 4 * (hs)][sl_][0]);                  \
+      bf_[1][q] = *reinterpret_cast<const f16x8*>(&Bs[buf][1][g + 4 * (hs)][sl_][0]);                  \
     }                                                                                                  \
     if (DBG & 1) {                                                                                     \
       _Pragma("unroll") for (int q = 0; q < NQ; ++q) _Pragma("unroll") for (int j = 0; j < 2; ++j)     \
@@ -668,59 +673,68 @@ __global__ __launch_bounds__(256, 2) void axb_f16_kernel(const float* __restrict
           acc[2 * (jh) + j][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af_[j][0], bf_[0][q], acc[2 * (jh) + j][q], 0, 0, 0); \
     }                                                                                                  \
   } while (0)
-  // One slab: the B rows fetched during the previous slab go to the other LDS buffer and the next ones are requested;
-  // rows 0..31 are converted, their registers immediately take the loads of the slab AFTER the next (two slabs of A stay
-  // in flight per wave through the matrix work and the barrier), their MFMAs run under the conversion of rows 32..63.
-#define EOFX_SLAB(areg, freg, buf, next_b, next_a)                                                     \
+  // One A slab (32 features, half `hs` of the current 64-feature B slab in LDS buffer `buf`): rows 0..31 are converted,
+  // their registers immediately take the loads of the slab AFTER the next (two slabs of A stay in flight per wave
+  // through the matrix work and the barrier), their MFMAs run under the conversion of rows 32..63.
+#define EOFX_SLAB(areg, buf, hs, next_f, next_a)                                                       \
   do {                                                                                                 \
-    EOFX_STORE_B(1 - (buf));                                                                           \
-    EOFX_LOAD_B(next_b);                                                                               \
     if (live) {                                                                                        \
       f32x2 fh_[2], fl_[2], fs_[2];                                                                    \
       _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                  \
-        fh_[h] = -f32x2{freg[0][2 * h], freg[0][2 * h + 1]};   /* x - s == x + (-s) exactly: packed adds */ \
-        fl_[h] = -f32x2{freg[1][2 * h], freg[1][2 * h + 1]};                                           \
+        fh_[h] = -f32x2{fr[0][2 * h], fr[0][2 * h + 1]};   /* x - s == x + (-s) exactly: packed adds */  \
+        fl_[h] = -f32x2{fr[1][2 * h], fr[1][2 * h + 1]};                                               \
         asm volatile("" : "+v"(fh_[h]), "+v"(fl_[h]));   /* keep them additions (v_pk_add_f32) */         \
-        fs_[h] = f32x2{freg[2][2 * h], freg[2][2 * h + 1]} * a_scale;   /* exact: a power of two */     \
+        fs_[h] = f32x2{fr[2][2 * h], fr[2][2 * h + 1]} * a_scale;   /* exact: a power of two */         \
       }                                                                                                \
+      EOFX_LOAD_F(fr, next_f);    /* the triples of the NEXT slab (L2 hits: one slab of lead is enough) */ \
       EOFX_AXB_CONVERT(areg, 0)                                                                        \
       EOFX_LOAD_A(areg, next_a, 0);                                                                    \
-      EOFX_AXB_MFMA(0, buf);                                                                           \
+      EOFX_AXB_MFMA(0, buf, hs);                                                                       \
       EOFX_AXB_CONVERT(areg, 4)                                                                        \
-      EOFX_LOAD_F(freg, next_a);                                                                       \
       EOFX_LOAD_A(areg, next_a, 4);                                                                    \
-      EOFX_AXB_MFMA(1, buf);                                                                           \
+      EOFX_AXB_MFMA(1, buf, hs);                                                                       \
     } else {                                                                                           \
+      EOFX_LOAD_F(fr, next_f);                                                                         \
       EOFX_LOAD_A(areg, next_a, 0);                                                                    \
-      EOFX_LOAD_F(freg, next_a);                                                                       \
       EOFX_LOAD_A(areg, next_a, 4);                                                                    \
     }                                                                                                  \
-    __syncthreads();                                                                                   \
   } while (0)
 
-  if (nslab > 0) {   // nslab is even (k_per_split and K are multiples of AXB_KG)
-    EOFX_LOAD_B(0);
-    EOFX_LOAD_F(f0, 0);
+  if (nslab > 0) {   // nslab is even (k_per_split and K are multiples of AXB_KG = 64 = one B slab = two A slabs)
+    const int npair = nslab / 2;
+    EOFX_LOAD_BH(0, 0);
+    EOFX_LOAD_F(fr, 0);
     EOFX_LOAD_A(a0, 0, 0);
     EOFX_LOAD_A(a0, 0, 4);
-    EOFX_STORE_B(0);
-    EOFX_LOAD_B(1);
-    EOFX_LOAD_F(f1, 1);
+    EOFX_STORE_BH(0, 0);
+    EOFX_LOAD_BH(0, 1);
     EOFX_LOAD_A(a1, 1, 0);
     EOFX_LOAD_A(a1, 1, 4);
+    EOFX_STORE_BH(0, 1);
+    EOFX_LOAD_BH(npair > 1 ? 1 : 0, 0);
     __syncthreads();
-    for (int c = 0; c < nslab; c += 2) {
-      const int c2 = c + 2 < nslab ? c + 2 : c;       // past the end: harmless re-reads of the last pair
-      const int c3 = c + 3 < nslab ? c + 3 : c + 1;
-      EOFX_SLAB(a0, f0, 0, c2, c2);     // slab c   (B of slab c+1 -> buffer 1, request B of c+2, A of c+2)
-      EOFX_SLAB(a1, f1, 1, c3, c3);     // slab c+1 (B of slab c+2 -> buffer 0, request B of c+3, A of c+3)
+    // One pair = one 64-feature B slab (LDS buffer pb) = two A slabs.  The B slab of the NEXT pair goes to the other
+    // buffer half by half (8 registers in flight, not 16): its first half was requested during the previous pair, its
+    // second half is requested now and stored between the two slabs.  ONE workgroup barrier per pair: the B hand-over is
+    // the only shared state (with a barrier per slab the kernel ran 3 % slower).
+    for (int pr = 0; pr < npair; ++pr) {
+      const int pb = pr & 1;
+      const int c2 = pr + 1 < npair ? 2 * pr + 2 : 2 * pr;          // past the end: harmless re-reads of the last pair
+      const int p1 = pr + 1 < npair ? pr + 1 : npair - 1, p2 = pr + 2 < npair ? pr + 2 : npair - 1;
+      EOFX_STORE_BH(1 - pb, 0);
+      EOFX_LOAD_BH(p1, 1);
+      EOFX_SLAB(a0, pb, 0, 2 * pr + 1, c2);
+      EOFX_STORE_BH(1 - pb, 1);
+      EOFX_LOAD_BH(p2, 0);
+      EOFX_SLAB(a1, pb, 1, c2, c2 + 1);
+      __syncthreads();
     }
   }
 #undef EOFX_AXB_LD
-#undef EOFX_LOAD_B
+#undef EOFX_LOAD_BH
 #undef EOFX_LOAD_F
 #undef EOFX_LOAD_A
-#undef EOFX_STORE_B
+#undef EOFX_STORE_BH
 #undef EOFX_AXB_CONVERT
 #undef EOFX_AXB_MFMA
 #undef EOFX_SLAB
