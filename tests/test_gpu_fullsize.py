@@ -19,15 +19,20 @@ def _device_field(n, nlat, nlon):
     return bench.make_field(n, nlat, nlon, 0, nlat * nlon, torch.device("cuda:0"))
 
 
+@pytest.mark.parametrize("layout", ["inplace", "copy"])
 @pytest.mark.parametrize("n,nlat,nlon,k", [(5000, 360, 720, 50), (10000, 720, 1440, 50)],
                          ids=["config2_5000x259200", "config4_10000x1036800"])
-def test_eof_properties_at_baseline_sizes(ctx, n, nlat, nlon, k):
+def test_eof_properties_at_baseline_sizes(ctx, n, nlat, nlon, k, layout):
+    """Size-independent properties at BASELINE sizes, in the in-place layout (bench.py's and the EOF model's default:
+    both products stream the raw field) and with both layouts written."""
     import torch
 
     from xeofs_amd import engine
 
+    kw = {"in_place": layout == "inplace"}
     X = _device_field(n, nlat, nlon)
-    mat, st = engine.preprocess(ctx, X, want_stats=False)
+    mat, st = engine.preprocess(ctx, X, want_stats=False, **kw)
+    assert mat.has_sample_layout() == (layout == "copy")
     assert (st["n"], st["p"]) == (n, nlat * nlon)
     U, s, V = engine.rsvd(ctx, mat, k, random_state=5, device_out=True)
     Ud, Vd = U.double(), V.double()
@@ -46,9 +51,10 @@ def test_eof_properties_at_baseline_sizes(ctx, n, nlat, nlon, k):
     assert np.array_equal(s, s2) and torch.equal(U, U2) and torch.equal(V, V2)
     # the resident matrix is centred: projecting it on V gives zero-mean scores
     assert float(XV.mean(dim=0).abs().max()) <= 1e-6 * float(sd[0])
+    assert mat.has_sample_layout() == (layout == "copy")     # nothing on this path materialised a layout
     mat.free()
     # linearity: decomposing 2 X doubles the singular values and leaves the vectors
-    mat2, _ = engine.preprocess(ctx, X * 2.0, want_stats=False)
+    mat2, _ = engine.preprocess(ctx, X * 2.0, want_stats=False, **kw)
     U3, s3, V3 = engine.rsvd(ctx, mat2, k, random_state=5, device_out=True)
     assert np.allclose(s3, 2.0 * s, rtol=1e-6)
     assert float((V3.double() - Vd).abs().max()) < 1e-5
