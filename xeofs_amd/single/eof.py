@@ -217,6 +217,10 @@ class ComplexEOF(EOF):
                                       "https://github.com/dask/dask/issues/7639")
 
     def _fit_complex(self, A, B, total_variance, omega=None):
+        if not isinstance(self.n_modes, (int, np.integer)):
+            # decomposer.py:89-106: a float n_modes asks for int(0.3 rank) modes first -- hundreds of complex columns
+            raise NotImplementedError("variance-based (float) n_modes is not supported for ComplexEOF / HilbertEOF: the "
+                                      "complex decomposer holds n_modes + n_oversamples <= 64 columns; pass an integer")
         kw = dict(self._solver_kwargs)
         om = None if omega is None else omega.result()
         if om is not None and om.shape[0] != min(A.n, A.p):     # samples or features were dropped: draw again
