@@ -1081,6 +1081,7 @@ struct PreState {  // device arrays of length P
   int* cnt;
   double *mean, *stdv, *shift, *scale, *m2;
   unsigned* absmax;  // device scalar: max |transformed value| (float bits)
+  float *vmin = nullptr, *vmax = nullptr;   // optional: per-feature extremes of the data (eofx_apply_f32)
 };
 
 static int run_colstats(eofx_ctx* ctx, const float* Xd, int64_t n, int64_t P, int center, int standardize,
@@ -1109,7 +1110,7 @@ static int run_colstats(eofx_ctx* ctx, const float* Xd, int64_t n, int64_t P, in
   HIPCHK(hipMemsetAsync(ps.absmax, 0, sizeof(unsigned), ctx->stream));
   hipLaunchKernelGGL(colstats_finalize_kernel, dim3(gxs), dim3(256), 0, ctx->stream, cnt_p, sum_p, sq_p, mn_p, mx_p,
                      (int)RS, P, center, standardize, w_dev, (double)1.1920928955078125e-07, ps.cnt,
-                     ps.mean, ps.stdv, ps.shift, ps.scale, ps.m2, ps.absmax);
+                     ps.mean, ps.stdv, ps.shift, ps.scale, ps.m2, ps.absmax, ps.vmin, ps.vmax);
   KCHK();
   return EOFX_OK;
 }
@@ -1335,7 +1336,9 @@ extern "C" int eofx_apply_f32(eofx_ctx* ctx, const float* X, int64_t n, int64_t 
   ARENA(double, dscale, P);
   ARENA(double, dm2, P);
   ARENA(unsigned, dabsmax, 1);
-  ps = {cnt, dmean, dstd, dshift, dscale, dm2, dabsmax};
+  ARENA(float, dvmin, P);
+  ARENA(float, dvmax, P);
+  ps = {cnt, dmean, dstd, dshift, dscale, dm2, dabsmax, dvmin, dvmax};
   CHK(run_colstats(ctx, st.dev, n, P, 0, 0, nullptr, ps));
   // overwrite shift/scale with the fitted state
   std::vector<double> hshift(P, 0.0), hscale(P, 1.0);
@@ -1350,10 +1353,16 @@ extern "C" int eofx_apply_f32(eofx_ctx* ctx, const float* X, int64_t n, int64_t 
   }
   CHK(copy_in(ctx, ps.shift, hshift.data(), sizeof(double) * P));
   CHK(copy_in(ctx, ps.scale, hscale.data(), sizeof(double) * P));
+  // max |x'| under the FITTED map from the extremes of the new data: no extra read of the matrix for the fp16 scaling,
+  // and the in-place layout (which writes nothing) becomes available for transform() too
+  HIPCHK(hipMemsetAsync(ps.absmax, 0, sizeof(unsigned), ctx->stream));
+  hipLaunchKernelGGL(fitted_absmax_kernel, dim3((int)((P + 255) / 256)), dim3(256), 0, ctx->stream, ps.cnt, ps.vmin, ps.vmax,
+                     ps.shift, ps.scale, P, ps.absmax);
+  KCHK();
   HIPCHK(hipStreamSynchronize(ctx->stream));
   std::vector<int> hcnt;
   int64_t ns = 0, pv = 0;
-  CHK(sanitize_and_apply(ctx, st.dev, n, P, ps, false, valid_feature, check_nans, out, nullptr, valid_sample, &ns,
+  CHK(sanitize_and_apply(ctx, st.dev, n, P, ps, true, valid_feature, check_nans, out, nullptr, valid_sample, &ns,
                          &pv, hcnt));
   adopt_staged(out, st, (size_t)n * P * sizeof(float));
   if (n_out) *n_out = ns;

@@ -1532,7 +1532,8 @@ __global__ __launch_bounds__(256) void colstats_finalize_kernel(
     const float* __restrict__ vmax_p, int splits, int64_t P, int center, int standardize,
     const double* __restrict__ weights, double eps, int* __restrict__ cnt, double* __restrict__ mean,
     double* __restrict__ stdv, double* __restrict__ shift, double* __restrict__ scale,
-    double* __restrict__ m2, unsigned* __restrict__ absmax) {
+    double* __restrict__ m2, unsigned* __restrict__ absmax, float* __restrict__ vmin_out = nullptr,
+    float* __restrict__ vmax_out = nullptr) {
   const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
   float amax = 0.f;
   if (c < P) {
@@ -1547,6 +1548,10 @@ __global__ __launch_bounds__(256) void colstats_finalize_kernel(
     hi = fmaxf(hi, vmax_p[(int64_t)sp * P + c]);
   }
   cnt[c] = k;
+  if (vmin_out) {       // kept for eofx_apply_f32: the maximum of the FITTED map is taken from them
+    vmin_out[c] = lo;
+    vmax_out[c] = hi;
+  }
   double mu = NAN, sd = NAN, M2 = 0.0;
   if (k > 0) {
     mu = s / k;
@@ -1565,6 +1570,22 @@ __global__ __launch_bounds__(256) void colstats_finalize_kernel(
   // max |(x - shift) * scale| of this feature after the transform (1 ulp headroom for the float cast)
   if (k > 0) amax = (float)(fmax(fabs((double)hi - sh), fabs((double)lo - sh)) * fabs(sc) * 1.000001);
   }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+  if ((threadIdx.x & 63) == 0 && amax > 0.f && amax < INFINITY) atomicMax(absmax, __float_as_uint(amax));
+}
+
+// max over the features of |(x - shift) * scale| from the per-feature extremes of the data and a GIVEN (fitted) shift /
+// scale: the transform path of new data (eofx_apply_f32) then needs no extra read of the written matrix.  The map is
+// monotone in x, so the extreme values decide; same 1-ulp headroom as colstats_finalize_kernel.
+__global__ __launch_bounds__(256) void fitted_absmax_kernel(const int* __restrict__ cnt, const float* __restrict__ vmin,
+                                                            const float* __restrict__ vmax, const double* __restrict__ shift,
+                                                            const double* __restrict__ scale, int64_t P,
+                                                            unsigned* __restrict__ absmax) {
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  float amax = 0.f;
+  if (c < P && cnt[c] > 0)
+    amax = (float)(fmax(fabs((double)vmax[c] - shift[c]), fabs((double)vmin[c] - shift[c])) * fabs(scale[c]) * 1.000001);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
   if ((threadIdx.x & 63) == 0 && amax > 0.f && amax < INFINITY) atomicMax(absmax, __float_as_uint(amax));

@@ -288,8 +288,9 @@ def preprocess(ctx: Context, X, center=True, standardize=False, feature_weights=
     return mat, stats
 
 
-def apply(ctx: Context, X, mean, std, feature_weights, valid_feature, check_nans=True):
-    """Preprocessor.transform on new data with fitted state."""
+def apply(ctx: Context, X, mean, std, feature_weights, valid_feature, check_nans=True, in_place=False):
+    """Preprocessor.transform on new data with fitted state.  in_place: as in `preprocess` -- nothing is written, the
+    projection that follows streams the (staged) field through the fitted map."""
     X = _f32c(X)
     n, P = X.shape
     f64 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float64)
@@ -298,10 +299,17 @@ def apply(ctx: Context, X, mean, std, feature_weights, valid_feature, check_nans
     vs = np.empty(n, np.uint8)
     n_out = C.c_int64()
     h = C.c_void_p()
-    rc = ctx.lib.eofx_apply_f32(ctx.handle, ptr(X), n, P, ptr(mean), ptr(std), ptr(w), ptr(vf),
-                                int(check_nans), C.byref(h), ptr(vs), C.byref(n_out))
+    ctx.lib.eofx_ctx_set_layout(ctx.handle, 2 if in_place else 0)
+    try:
+        rc = ctx.lib.eofx_apply_f32(ctx.handle, ptr(X), n, P, ptr(mean), ptr(std), ptr(w), ptr(vf),
+                                    int(check_nans), C.byref(h), ptr(vs), C.byref(n_out))
+    finally:
+        ctx.lib.eofx_ctx_set_layout(ctx.handle, 0)
     raise_for(rc, ctx.handle)
-    return ResidentMatrix(ctx, h), vs.astype(bool)
+    mat = ResidentMatrix(ctx, h)
+    if in_place and hasattr(X, "data_ptr"):
+        mat._keepalive = X
+    return mat, vs.astype(bool)
 
 
 def rsvd(ctx: Context, mat: ResidentMatrix, k: int, n_oversamples: int = 10, n_iter: int | str = "auto",

@@ -140,7 +140,8 @@ class Preprocessor:
         ctx = self.ctx or engine.default_context()
         fields = self._fields_like(X)
         M, _ = self._stack(fields, None)
-        mat, vs = engine.apply(ctx, M, self.mean_, self.std_, self.feature_weights, self.valid_feature, self.check_nans)
+        mat, vs = engine.apply(ctx, M, self.mean_, self.std_, self.feature_weights, self.valid_feature, self.check_nans,
+                               in_place=self.in_place)
         return mat, fields, vs
 
     def _fields_like(self, X):
