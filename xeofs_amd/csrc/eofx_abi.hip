@@ -4,6 +4,9 @@
 #include "eofx_kernels.hpp"
 #include "eofx_fused.hpp"
 
+#if !defined(__HIP_DEVICE_COMPILE__)
+#include <immintrin.h>
+#endif
 #include <algorithm>
 #include <cmath>
 #include <complex>
@@ -13,6 +16,7 @@
 #include <functional>
 #include <string>
 #include <thread>
+#include <memory>
 #include <vector>
 
 #include <hipfft/hipfft.h>
@@ -391,9 +395,11 @@ struct AtbPlan {
 };
 // split-K factor from a small cost model: 512 resident workgroups, ~10 GB/s of A per
 // workgroup slot, partial-sum traffic at ~4 TB/s.
-static AtbPlan atb_plan(int64_t M, int64_t K, int L) {
+static bool atb_wide(int L) { return L >= 256; }   // 128-column tiles (atb_f16_kernel<4>), one workgroup per CU
+static AtbPlan atb_plan(int64_t M, int64_t K, int L, bool wide = false) {
   const int bx = (int)(M / ATB_BM);
-  const int bz = (L + 63) / 64;
+  const int bz = wide ? (L + 127) / 128 : (L + 63) / 64;
+  const double resident = wide ? 256.0 : 512.0;
   AtbPlan best{1, K};
   double best_t = 1e30;
   for (int S = 1; S <= 128; ++S) {
@@ -401,7 +407,7 @@ static AtbPlan atb_plan(int64_t M, int64_t K, int L) {
     const int s_eff = (int)((K + kps - 1) / kps);
     if (s_eff != S) continue;
     const double blocks = (double)bx * bz * s_eff;
-    const double rounds = std::ceil(blocks / 512.0);
+    const double rounds = std::ceil(blocks / resident);
     double t = rounds * (double)kps * 2048.0 / 1.0e10;
     if (s_eff > 1) t += (2.0 * s_eff + 1.0) * (double)M * L * 4.0 / 4.0e12;
     if (t < best_t * 0.98) {
@@ -440,8 +446,9 @@ static AtbPlan axb_plan(int64_t rows_pad, int64_t K) {
   return best;
 }
 static size_t atb_scratch_bytes(int64_t M, int64_t K, int L) {
-  const AtbPlan pl = atb_plan(M, K, L);
-  size_t b = pl.S > 1 ? (size_t)pl.S * M * L * (sizeof(float) + sizeof(double)) + 4096 : 4096;   // f32 or f64 partials
+  const AtbPlan pl = atb_plan(M, K, L), plw = atb_plan(M, K, L, true);
+  const int smax = std::max(pl.S, atb_wide(L) ? plw.S : 1);
+  size_t b = smax > 1 ? (size_t)smax * M * L * (sizeof(float) + sizeof(double)) + 4096 : 4096;   // f32 or f64 partials
   const AtbPlan px = axb_plan(M, round_up(K, AXB_KG));      // in case M is the sample side of an in-place matrix
   if (px.S > 1) b = std::max(b, (size_t)px.S * M * round_up(L, 64) * sizeof(float) + 4096);
   return b;
@@ -460,38 +467,45 @@ static void launch_atb_variant(int prec, dim3 grid, hipStream_t st, const float*
                                const float* B, int ldb, float* out, int L, int64_t M, int64_t K,
                                int64_t kps, int col_base, float a_scale, const float* b_absmax,
                                const AffView* aff = nullptr, const float* A2 = nullptr, const float* B2 = nullptr,
-                               int s_half = 0) {
+                               int s_half = 0, int sym = 0) {
   if (prec == EOFX_PREC_F16X3 && A2)
     hipLaunchKernelGGL(atb_f16_kernel<NB>, grid, dim3(256), 0, st, A, lda, B, ldb, out, L, M, K, kps, col_base,
-                       a_scale, b_absmax, (const float*)nullptr, (int64_t)0, 0, (int64_t)0, A2, B2, s_half);
+                       a_scale, b_absmax, (const float*)nullptr, (int64_t)0, 0, (int64_t)0, A2, B2, s_half, 0);
   else if (prec == EOFX_PREC_F16X3 && aff)
     hipLaunchKernelGGL((atb_f16_kernel<NB, true>), grid, dim3(256), 0, st, A, lda, B, ldb, out, L, M, K, kps, col_base,
-                       a_scale, b_absmax, aff->aff, aff->ld, aff->rows, aff->cols, (const float*)nullptr, (const float*)nullptr, 0);
+                       a_scale, b_absmax, aff->aff, aff->ld, aff->rows, aff->cols, (const float*)nullptr, (const float*)nullptr, 0, sym);
   else if (prec == EOFX_PREC_F16X3)
     hipLaunchKernelGGL(atb_f16_kernel<NB>, grid, dim3(256), 0, st, A, lda, B, ldb, out, L, M, K, kps, col_base,
-                       a_scale, b_absmax, (const float*)nullptr, (int64_t)0, 0, (int64_t)0, (const float*)nullptr, (const float*)nullptr, 0);
-  else if (prec == EOFX_PREC_BF16X3)
-    hipLaunchKernelGGL((atb_bf16_kernel<NB, 2>), grid, dim3(256), 0, st, A, lda, B, ldb, out, L, M, K, kps, col_base);
-  else if (prec == EOFX_PREC_BF16X6)
-    hipLaunchKernelGGL((atb_bf16_kernel<NB, 3>), grid, dim3(256), 0, st, A, lda, B, ldb, out, L, M, K, kps, col_base);
-  else
-    hipLaunchKernelGGL(atb_f32_kernel<NB>, grid, dim3(256), 0, st, A, lda, B, ldb, out, L, M, K, kps, col_base);
+                       a_scale, b_absmax, (const float*)nullptr, (int64_t)0, 0, (int64_t)0, (const float*)nullptr, (const float*)nullptr, 0, sym);
+  else if constexpr (NB <= 2) {     // the 128-column tile exists for the split-fp16 kernel only
+    if (prec == EOFX_PREC_BF16X3)
+      hipLaunchKernelGGL((atb_bf16_kernel<NB, 2>), grid, dim3(256), 0, st, A, lda, B, ldb, out, L, M, K, kps, col_base);
+    else if (prec == EOFX_PREC_BF16X6)
+      hipLaunchKernelGGL((atb_bf16_kernel<NB, 3>), grid, dim3(256), 0, st, A, lda, B, ldb, out, L, M, K, kps, col_base);
+    else
+      hipLaunchKernelGGL(atb_f32_kernel<NB>, grid, dim3(256), 0, st, A, lda, B, ldb, out, L, M, K, kps, col_base);
+  }
 }
 
 // a_absmax: max |a| over A (host); b_absmax_dev: device scalar with max |b| (nullptr: measured here).
 // Both are only used by the fp16-split variant.
+// sym: C = A^T A (B is A itself, L == M): tiles strictly below the diagonal are skipped and mirrored afterwards
 static int launch_atb(eofx_ctx* ctx, const float* A, int64_t lda, int64_t K, int64_t M,
                       const float* B, int ldb, int L, float* C, int prec = EOFX_PREC_F32,
                       float a_absmax = 0.f, const float* b_absmax_dev = nullptr, const AffView* aff = nullptr,
-                      const float* A2 = nullptr, const float* B2 = nullptr) {
+                      const float* A2 = nullptr, const float* B2 = nullptr, int sym = 0) {
   if (aff && prec != EOFX_PREC_F16X3) return set_err(ctx, EOFX_ERR_ARG, "atb: the raw view needs the f16x3 kernel");
   if (A2 && (prec != EOFX_PREC_F16X3 || aff || !B2)) return set_err(ctx, EOFX_ERR_ARG, "atb: the two-matrix form needs the f16x3 kernel");
   if (M % ATB_BM || K % ATB_KG || L % 32 || L <= 0)
     return set_err(ctx, EOFX_ERR_ARG, "atb: bad geometry M=%lld K=%lld L=%d", (long long)M,
                    (long long)K, L);
   const int bx = (int)(M / ATB_BM);
-  const int nfull = L / 64, rem = L % 64;
-  const AtbPlan plan = atb_plan(M, K, L);
+  // wide products (Gram matrices, PCA panels) in 128-column tiles of the split-fp16 kernel, then 64 / 32-column rests
+  const bool wide = atb_wide(L) && prec == EOFX_PREC_F16X3 && !A2;
+  if (sym && !(wide && !aff && L == M)) sym = 0;
+  const int n4 = wide ? L / 128 : 0, cb4 = 128 * n4;
+  const int nfull = (L - cb4) / 64, rem = (L - cb4) % 64;
+  const AtbPlan plan = atb_plan(M, K, L, wide);
   int best_s = plan.S;
   int64_t best_kps = plan.kps;
   ArenaScope scope(ctx);
@@ -561,27 +575,37 @@ static int launch_atb(eofx_ctx* ctx, const float* A, int64_t lda, int64_t K, int
     }
     return EOFX_OK;
   }
+  if (n4 > 0) {
+    dim3 grid(bx, best_s, n4);
+    launch_atb_variant<4>(prec, grid, ctx->stream, A, lda, B, ldb, out, L, M, K, best_kps, 0, a_scale, b_absmax_dev, aff, A2, B2, s_half, sym);
+    KCHK();
+  }
   if (nfull > 0) {
     dim3 grid(bx, best_s, nfull);
-    launch_atb_variant<2>(prec, grid, ctx->stream, A, lda, B, ldb, out, L, M, K, best_kps, 0, a_scale, b_absmax_dev, aff, A2, B2, s_half);
+    launch_atb_variant<2>(prec, grid, ctx->stream, A, lda, B, ldb, out, L, M, K, best_kps, cb4, a_scale, b_absmax_dev, aff, A2, B2, s_half, sym);
     KCHK();
   }
   if (rem) {
     dim3 grid(bx, best_s, 1);
-    launch_atb_variant<1>(prec, grid, ctx->stream, A, lda, B, ldb, out, L, M, K, best_kps, nfull * 64, a_scale, b_absmax_dev, aff, A2, B2, s_half);
+    launch_atb_variant<1>(prec, grid, ctx->stream, A, lda, B, ldb, out, L, M, K, best_kps, cb4 + nfull * 64, a_scale, b_absmax_dev, aff, A2, B2, s_half, sym);
     KCHK();
   }
   if (ctx->profile) {
     HIPCHK(hipEventRecord(ev1, ctx->stream));
     ctx->prof_events.emplace_back(ev0, ev1);
     ctx->prof_flops += 2.0 * (double)K * (double)M * (double)L * (A2 ? 2 : 1);
-    ctx->prof_bytes += (double)K * (double)M * 4.0 * (nfull + (rem ? 1 : 0)) * (A2 ? 2 : 1);
+    ctx->prof_bytes += (double)K * (double)M * 4.0 * (n4 + nfull + (rem ? 1 : 0)) * (A2 ? 2 : 1);
   }
   if (best_s > 1) {
     const int64_t count4 = M * L / 4;
     const int blocks = (int)std::min<int64_t>((count4 + 255) / 256, 4096);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, ctx->stream, out, C, count4,
                        best_s);
+    KCHK();
+  }
+  if (sym) {
+    const int nt = (int)((M + 63) / 64);
+    hipLaunchKernelGGL(symmetrize_lower_kernel, dim3(nt, nt), dim3(256), 0, ctx->stream, C, M, (int64_t)L);
     KCHK();
   }
   return EOFX_OK;
@@ -1922,12 +1946,12 @@ static int mat_gram(eofx_ctx* ctx, const eofx_mat* m, int side, float* G) {
     const int64_t npad = m->n_pad;
     CHK(ensure_Xt(ctx, m));
     return launch_atb(ctx, m->Xt, npad, round_up(m->p, ATB_KG), npad, m->Xt, (int)npad, (int)npad, G, ctx->prec_final,
-                      m->absmax, reinterpret_cast<const float*>(m->absmax_dev));
+                      m->absmax, reinterpret_cast<const float*>(m->absmax_dev), nullptr, nullptr, nullptr, 1);
   }
   const int64_t ppad = m->p_pad;
   CHK(ensure_X(ctx, m));
   return launch_atb(ctx, m->X, ppad, round_up(m->n, ATB_KG), ppad, m->X, (int)ppad, (int)ppad, G, ctx->prec_final,
-                    m->absmax, reinterpret_cast<const float*>(m->absmax_dev));
+                    m->absmax, reinterpret_cast<const float*>(m->absmax_dev), nullptr, nullptr, nullptr, 1);
 }
 static int sample_gram(eofx_ctx* ctx, const eofx_mat* m, float* G) { return mat_gram(ctx, m, 0, G); }
 
@@ -2696,101 +2720,125 @@ struct MT19937 {
 };
 }  // namespace
 
-// Parallel, still bit-identical.  Every candidate pair of the polar method consumes exactly four
-// MT19937 words whether it is accepted or not, so candidate i always sits at words 4i..4i+3 of the
-// stream.  Only the raw MT recurrence is sequential (~0.7 ns per word); tempering, the conversion to
-// doubles, the accept test, the prefix count of accepted candidates and the log/sqrt transforms are
-// data-parallel over candidates.
+// Parallel, still bit-identical.  Every candidate pair of the polar method consumes exactly four MT19937 words whether
+// it is accepted or not, so candidate i always sits at words 4i..4i+3 of the stream.  Only the raw MT recurrence is
+// sequential -- written as ONE linear recurrence x[i] = x[i-227] ^ f(x[i-624], x[i-623]) over the whole stream (no
+// 624-word refill blocks, no copies), eight words per AVX2 step where the host has it: 0.55 ns per word on the GPU box,
+// bound by one core's store bandwidth (40 MB for a 129 600 x 30 sketch).  Tempering, the conversion to doubles, the accept test and the log / sqrt of the accepted
+// pairs are data-parallel over candidates: every worker thread turns its contiguous share of the candidates into its
+// own list of deviates in ONE pass, and the lists are concatenated in order.
+namespace {
+#define EOFX_MT_FILL_BODY                                                                                     \
+  for (int64_t i = 624; i < count; ++i) {                                                                     \
+    const uint32_t y = (x[i - 624] & 0x80000000u) | (x[i - 623] & 0x7fffffffu);                               \
+    x[i] = x[i - 227] ^ (y >> 1) ^ ((uint32_t)(-(int32_t)(y & 1u)) & 0x9908b0dfu);                            \
+  }
+#if !defined(__HIP_DEVICE_COMPILE__)
+// eight words per step: every load lies at least 220 words behind the eight words being written
+__attribute__((target("avx2"))) void mt_fill_avx2(uint32_t* __restrict__ x, int64_t count) {
+  const __m256i upper = _mm256_set1_epi32((int)0x80000000u), lower = _mm256_set1_epi32(0x7fffffff);
+  const __m256i one = _mm256_set1_epi32(1), matrix = _mm256_set1_epi32((int)0x9908b0dfu), zero = _mm256_setzero_si256();
+  int64_t i = 624;
+  for (; i + 8 <= count; i += 8) {
+    const __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(x + i - 624));
+    const __m256i b = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(x + i - 623));
+    const __m256i c = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(x + i - 227));
+    const __m256i y = _mm256_or_si256(_mm256_and_si256(a, upper), _mm256_and_si256(b, lower));
+    const __m256i mag = _mm256_and_si256(_mm256_sub_epi32(zero, _mm256_and_si256(y, one)), matrix);
+    _mm256_storeu_si256(reinterpret_cast<__m256i*>(x + i), _mm256_xor_si256(_mm256_xor_si256(c, _mm256_srli_epi32(y, 1)), mag));
+  }
+  for (; i < count; ++i) {
+    const uint32_t y = (x[i - 624] & 0x80000000u) | (x[i - 623] & 0x7fffffffu);
+    x[i] = x[i - 227] ^ (y >> 1) ^ ((uint32_t)(-(int32_t)(y & 1u)) & 0x9908b0dfu);
+  }
+}
+#else
+void mt_fill_avx2(uint32_t* __restrict__ x, int64_t count);
+#endif
+void mt_fill_generic(uint32_t* __restrict__ x, int64_t count) { EOFX_MT_FILL_BODY }
+#undef EOFX_MT_FILL_BODY
+inline uint32_t mt_temper(uint32_t y) {
+  y ^= (y >> 11);
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= (y >> 18);
+  return y;
+}
+}  // namespace
+
 extern "C" int eofx_sketch_gaussian_f32(uint32_t seed, int64_t rows, int64_t cols, float* out) {
   if (!out || rows < 0 || cols < 0) return EOFX_ERR_ARG;
   const int64_t total = rows * cols;
   if (total == 0) return EOFX_OK;
   const int64_t npairs = (total + 1) / 2;
-  MT19937 g(seed);
-  auto temper = [](uint32_t y) {
-    y ^= (y >> 11);
-    y ^= (y << 7) & 0x9d2c5680u;
-    y ^= (y << 15) & 0xefc60000u;
-    y ^= (y >> 18);
-    return y;
-  };
   const int hw = (int)std::thread::hardware_concurrency();
-  int max_threads = std::max(1, std::min(16, hw > 0 ? hw : 1));
+  int max_threads = std::max(1, std::min(32, hw > 0 ? hw : 1));
   if (const char* ev = getenv("EOFX_SKETCH_THREADS")) max_threads = std::max(1, atoi(ev));
+  static const bool have_avx2 = __builtin_cpu_supports("avx2");
+  // x[0..623]: the generator state (init_genrand seeding); x[624 + w]: raw (untempered) output word w of the stream
+  uint32_t state[624];
+  {
+    const MT19937 g(seed);
+    std::memcpy(state, g.mt, sizeof(state));
+  }
   int64_t done_pairs = 0;
-  std::vector<uint32_t> raw;
-  std::vector<unsigned char> ok;
-  std::vector<int64_t> pos;
   while (done_pairs < npairs) {
     const int64_t need = npairs - done_pairs;
     // acceptance probability pi/4: ask for slightly more candidates than expected, at least a few
     const int64_t ncand = (int64_t)((double)need / 0.7853981633974483 * 1.01) + 64;
     const int64_t nwords = 4 * ncand;
-    raw.resize((size_t)nwords);
-    // sequential part: the untempered state words in stream order
-    for (int64_t w = 0; w < nwords;) {
-      if (g.idx >= 624) g.refill();
-      const int64_t take = std::min<int64_t>(624 - g.idx, nwords - w);
-      std::memcpy(&raw[(size_t)w], &g.mt[g.idx], sizeof(uint32_t) * (size_t)take);
-      g.idx += (int)take;
-      w += take;
+    // one grow-only buffer per calling thread: 40 MB of fresh pages per call cost more than the recurrence itself
+    static thread_local std::unique_ptr<uint32_t[]> xbuf;
+    static thread_local size_t xcap = 0;
+    if (xcap < (size_t)(624 + nwords)) {
+      xbuf.reset(new uint32_t[(size_t)(624 + nwords)]);   // uninitialised on purpose
+      xcap = (size_t)(624 + nwords);
     }
-    ok.assign((size_t)ncand, 0);
-    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(max_threads, ncand / 8192));
+    uint32_t* x = xbuf.get();
+    std::memcpy(x, state, sizeof(state));
+    if (have_avx2) mt_fill_avx2(x, 624 + nwords);
+    else mt_fill_generic(x, 624 + nwords);
+
+    std::memcpy(state, x + nwords, sizeof(state));     // the state after these words (a rare second round continues here)
+    const uint32_t* raw = x + 624;
+    // a thread costs ~40 us to start and a candidate ~45 ns: no more threads than pay for themselves
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(max_threads, ncand / 20000));
     const int64_t step = (ncand + nt - 1) / nt;
-    std::vector<int64_t> cnt((size_t)nt, 0);
-    auto cand = [&](int64_t i, double& a, double& b, double& r) {
-      const uint32_t w0 = temper(raw[(size_t)(4 * i)]) >> 5, w1 = temper(raw[(size_t)(4 * i + 1)]) >> 6;
-      const uint32_t w2 = temper(raw[(size_t)(4 * i + 2)]) >> 5, w3 = temper(raw[(size_t)(4 * i + 3)]) >> 6;
-      a = 2.0 * ((w0 * 67108864.0 + w1) / 9007199254740992.0) - 1.0;
-      b = 2.0 * ((w2 * 67108864.0 + w3) / 9007199254740992.0) - 1.0;
-      r = a * a + b * b;
-    };
-    auto phase1 = [&](int t) {
+    std::vector<std::vector<float>> dev((size_t)nt);    // deviates of each share, in stream order: (f b, f a) per accepted pair
+    auto work = [&](int t) {
       const int64_t lo = t * step, hi = std::min<int64_t>(ncand, (t + 1) * step);
-      int64_t c = 0;
+      std::vector<float>& d = dev[(size_t)t];
+      d.resize((size_t)(2 * std::max<int64_t>(hi - lo, 0)));
+      size_t q = 0;
       for (int64_t i = lo; i < hi; ++i) {
-        double a, b, r;
-        cand(i, a, b, r);
-        const bool acc = !(r >= 1.0 || r == 0.0);
-        ok[(size_t)i] = acc;
-        c += acc;
-      }
-      cnt[(size_t)t] = c;
-    };
-    {
-      std::vector<std::thread> th;
-      for (int t = 1; t < nt; ++t) th.emplace_back(phase1, t);
-      phase1(0);
-      for (auto& x : th) x.join();
-    }
-    std::vector<int64_t> base((size_t)nt + 1, 0);
-    for (int t = 0; t < nt; ++t) base[(size_t)t + 1] = base[(size_t)t] + cnt[(size_t)t];
-    const int64_t accepted = base[(size_t)nt];
-    const int64_t use = std::min(accepted, need);  // pairs taken from this round
-    // candidates beyond the `use`-th accepted one belong to later draws of the stream: if we
-    // overshoot, the generator state is simply discarded (nothing else is drawn from it)
-    auto phase2 = [&](int t) {
-      const int64_t lo = t * step, hi = std::min<int64_t>(ncand, (t + 1) * step);
-      int64_t q = base[(size_t)t];
-      for (int64_t i = lo; i < hi && q < use; ++i) {
-        if (!ok[(size_t)i]) continue;
-        double a, b, r;
-        cand(i, a, b, r);
+        const uint32_t w0 = mt_temper(raw[4 * i]) >> 5, w1 = mt_temper(raw[4 * i + 1]) >> 6;
+        const uint32_t w2 = mt_temper(raw[4 * i + 2]) >> 5, w3 = mt_temper(raw[4 * i + 3]) >> 6;
+        const double a = 2.0 * ((w0 * 67108864.0 + w1) / 9007199254740992.0) - 1.0;
+        const double b = 2.0 * ((w2 * 67108864.0 + w3) / 9007199254740992.0) - 1.0;
+        const double r = a * a + b * b;
+        if (r >= 1.0 || r == 0.0) continue;
         const double f = std::sqrt(-2.0 * std::log(r) / r);
-        const int64_t o = 2 * (done_pairs + q);
-        out[o] = (float)(f * b);                          // returned first
-        if (o + 1 < total) out[o + 1] = (float)(f * a);   // the cached deviate
-        ++q;
+        d[q++] = (float)(f * b);      // returned first
+        d[q++] = (float)(f * a);      // the cached deviate
       }
+      d.resize(q);
     };
     {
       std::vector<std::thread> th;
-      for (int t = 1; t < nt; ++t) th.emplace_back(phase2, t);
-      phase2(0);
-      for (auto& x : th) x.join();
+      for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
+      work(0);
+      for (auto& w : th) w.join();
     }
-    done_pairs += use;
+    // concatenate in order; deviates beyond `total` belong to later draws of the stream and are dropped
+    int64_t o = 2 * done_pairs;
+    for (int t = 0; t < nt && o < total; ++t) {
+      const std::vector<float>& d = dev[(size_t)t];
+      const int64_t take = std::min<int64_t>((int64_t)d.size(), total - o);
+      std::memcpy(out + o, d.data(), sizeof(float) * (size_t)take);
+      o += take;
+    }
+    done_pairs = (o + 1) / 2;
+    if (o >= total) break;
   }
   return EOFX_OK;
 }

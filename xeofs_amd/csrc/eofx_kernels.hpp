@@ -349,8 +349,12 @@ __device__ __forceinline__ float f16_scale_for(float m) {
 // applied on the fly (the exact power-of-two a_scale folded into the scale), and the feature-contiguous copy of the
 // matrix never exists.  Rows >= a_rows are read from the last row (their B rows are zero), 16-byte column chunks
 // >= a_cols from chunk 0 with scale 0.  aff = {hi[aff_ld], lo[aff_ld], scale[aff_ld]} from aff_pack_kernel.
+// NB = 32-column sub-tiles of B per workgroup: 2 (64 columns: the sketch-width passes, two workgroups per CU), 1 (a
+// 32-column remainder) or 4 (128 columns, one workgroup per CU with 256 accumulator registers: the WIDE products -- Gram
+// matrices, PCA panels -- re-read A half as often).  sym: C is a symmetric product (B = A): 128-column tiles lying
+// entirely below the diagonal are skipped (symmetrize_lower_kernel fills them in afterwards).
 template <int NB, bool AFF = false>
-__global__ __launch_bounds__(256, 2) void atb_f16_kernel(const float* __restrict__ A, int64_t lda,
+__global__ __launch_bounds__(256, NB > 2 ? 1 : 2) void atb_f16_kernel(const float* __restrict__ A, int64_t lda,
                                                           const float* __restrict__ B, int ldb,
                                                           float* __restrict__ C, int ldc, int64_t M,
                                                           int64_t K, int64_t k_per_split, int col_base,
@@ -359,7 +363,7 @@ __global__ __launch_bounds__(256, 2) void atb_f16_kernel(const float* __restrict
                                                           const float* __restrict__ aff = nullptr,
                                                           int64_t aff_ld = 0, int a_rows = 0, int64_t a_cols = 0,
                                                           const float* A2 = nullptr, const float* B2 = nullptr,
-                                                          int s_half = 0) {
+                                                          int s_half = 0, int sym = 0) {
   // Two-matrix form (complex passes, eofx_rsvd_c64): splits [s_half, 2 s_half) stream a second matrix A2 (same shape)
   // against its own panel B2 -- C = A^T B + A2^T B2 in one launch, summed by the split-K reduction.
   __shared__ __attribute__((aligned(16))) _Float16 Bs[2][2][2][32 * NB][8];
@@ -377,7 +381,8 @@ __global__ __launch_bounds__(256, 2) void atb_f16_kernel(const float* __restrict
   const int64_t kb = (int64_t)sy_ * k_per_split;
   const int64_t ke = (kb + k_per_split < K) ? kb + k_per_split : K;
   const int nchunks = (int)((ke - kb) / ATB_KC);
-  const int bcol0 = col_base + blockIdx.z * 64;
+  const int bcol0 = col_base + blockIdx.z * (NB > 2 ? 32 * NB : 64);
+  if (sym && bcol0 + 32 * NB <= (int64_t)blockIdx.x * ATB_BM) return;   // strictly below the diagonal (uniform)
   const float b_scale = f16_scale_for(*b_absmax);
   const float out_scale = 1.f / (a_scale * b_scale);   // exact: both are powers of two
 
@@ -399,15 +404,20 @@ __global__ __launch_bounds__(256, 2) void atb_f16_kernel(const float* __restrict
     sla_ = *reinterpret_cast<const f32x4*>(aff + 2 * aff_ld + m0 + 4 * li) * a_scale;   // exact: a power of two
   }
   constexpr int BV = 8 * NB;
+  constexpr int BREP = (16 * BV + 255) / 256;      // 16-byte loads of the B slab per thread (2 for the 128-column tile)
+  constexpr int BROWS = 256 / BV < 16 ? 256 / BV : 16;   // slab rows covered by one such load of the workgroup
   const bool b_loader = tid < 16 * BV;
-  const int brow = tid / BV, bc4 = tid % BV;
-  const float* Bp = B + (kb + brow) * (int64_t)ldb + bcol0 + 4 * bc4;
+  const int brow0 = tid / BV, bc4 = tid % BV;
+  const float* Bp = B + (kb + brow0) * (int64_t)ldb + bcol0 + 4 * bc4;
 
   f32x4 a0[8], a1[8];
-  f32x4 bn = {0.f, 0.f, 0.f, 0.f};
+  f32x4 bn[BREP];
+#pragma unroll
+  for (int r = 0; r < BREP; ++r) bn[r] = f32x4{0.f, 0.f, 0.f, 0.f};
 #define EOFX_LOAD_SLAB(areg, chunk)                                                              \
   do {                                                                                           \
-    if (b_loader) bn = *reinterpret_cast<const f32x4*>(Bp + (int64_t)(chunk) * ATB_KC * ldb);   \
+    if (b_loader) _Pragma("unroll") for (int r = 0; r < BREP; ++r)                               \
+        bn[r] = *reinterpret_cast<const f32x4*>(Bp + ((int64_t)(chunk) * ATB_KC + BROWS * r) * ldb); \
     if (AFF) {                                                                                   \
       const int r0_ = (int)kb + (chunk) * ATB_KC + lh;                                           \
       if ((int)kb + (chunk) * ATB_KC + ATB_KC <= a_rows) {   /* whole slab inside the field */    \
@@ -429,8 +439,9 @@ __global__ __launch_bounds__(256, 2) void atb_f16_kernel(const float* __restrict
 #define EOFX_STORE_B(buf)                                                                        \
   do {                                                                                           \
     if (b_loader) {                                                                              \
-      _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                            \
-        const float r_ = bn[e] * b_scale;                                                        \
+      _Pragma("unroll") for (int r = 0; r < BREP; ++r) _Pragma("unroll") for (int e = 0; e < 4; ++e) { \
+        const int brow = brow0 + BROWS * r;                                                      \
+        const float r_ = bn[r][e] * b_scale;                                                     \
         const fp16x2_t h_ = __builtin_amdgcn_cvt_pkrtz(r_, 0.f);                                 \
         const _Float16 m_ = (_Float16)(r_ - (float)h_[0]);                                       \
         Bs[buf][0][brow & 1][4 * bc4 + e][brow >> 1] = (_Float16)h_[0];                          \
@@ -928,6 +939,23 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // gram_f64: Gpart[bx][L x L] = sum over this block's rows of P[r,:]^T P[r,:]  (float64)
 //   grid = (nbx, nb*nb) where nb = ceil(L/64); each block owns one 64x64 sub-block of G
 //   and a strided set of 32-row slabs.  HBM-bound on P (rows x L x 4 B), tiny.
+// lower triangle of a symmetric product from its upper one: C[m][l] = C[l][m] for l < m  (64 x 64 tiles through LDS)
+__global__ __launch_bounds__(256) void symmetrize_lower_kernel(float* __restrict__ C, int64_t n, int64_t ld) {
+  __shared__ float T[64][65];
+  const int bi = blockIdx.y, bj = blockIdx.x;      // tile row / column of the LOWER triangle being written
+  if (bj > bi) return;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4) {               // read the mirror tile (bj, bi)
+    const int64_t gr = (int64_t)bj * 64 + r, gc = (int64_t)bi * 64 + tx;
+    T[r][tx] = (gr < n && gc < n) ? C[gr * ld + gc] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 64; r += 4) {
+    const int64_t gr = (int64_t)bi * 64 + r, gc = (int64_t)bj * 64 + tx;
+    if (gr < n && gc < n && gc < gr) C[gr * ld + gc] = T[tx][r];
+  }
+}
+
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gram_f64_kernel(const float* __restrict__ P, int64_t rows,
                                                         int L, double* __restrict__ Gpart) {

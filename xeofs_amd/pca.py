@@ -6,7 +6,8 @@ The reference computes those int(0.3 * rank) modes with an *unseeded* randomized
 10 passes over X).  At that width the MI355X-first route is the exact one, in two wide passes over X:
 
   1. G = X X^T (sample space, n x n; or X^T X when p < n) through the streaming `atb` kernel
-     (`eofx_mat_gram_f32`, one launch, the matrix read n_pad/64 times from HBM),
+     (`eofx_mat_gram_f32`: 128-column tiles, those below the diagonal skipped and mirrored; the matrix is read
+     ~n_pad/256 times from HBM),
   2. symmetric eigendecomposition of G (float64, rocSOLVER through torch.linalg.eigh; 0.2 s at n = 5000) ->
      the whole spectrum, hence the reference's truncation rule evaluated exactly, and the basis U_m,
   3. B = X^T U_m (wide panel product, the same kernel) and a Rayleigh-Ritz step on B^T B (float64 Gram, m x m
