@@ -2157,25 +2157,30 @@ __global__ __launch_bounds__(256) void rot_step_kernel(const float* __restrict__
                                                        const double* __restrict__ R,
                                                        const double* __restrict__ aux, int mode,
                                                        double power, double* __restrict__ Gpart) {
-  __shared__ float Xs[32][64];
-  __shared__ double Rs[64][64];
-  __shared__ double Ts[32][64];
-  __shared__ double Ls[32][64];   // left factor (mode 1 only)
+  // Both matrix products of a 32-row tile run on the fp64 matrix cores (v_mfma_f64_16x16x4_f64; operand / result lane
+  // maps as in gram_mfma_kernel): b = x R as 2 x 4 tiles over 16 k-steps (wave w: row tile w & 1, column tiles
+  // 2 (w >> 1) + {0, 1}), then G += left^T t as 4 x 4 tiles over 8 k-steps (wave w: tile row w, accumulators kept
+  // across the whole launch).  Only the elementwise transform in between is vector-ALU work.  LDS rows are padded by
+  // two doubles (float: four) so that the four k-rows a wave reads at once fall into different banks.
+  __shared__ float Xs[32][68];
+  __shared__ double Rs[64][66];
+  __shared__ double Ts[32][66];
+  __shared__ double Ls[32][66];   // b = x R (the left factor in modes 1 / 3, the partner parts in modes 2 / 3)
   const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
   for (int i = tid; i < 64 * 64; i += 256) {
     const int r = i >> 6, c = i & 63;
     Rs[r][c] = (r < L && c < L) ? R[(int64_t)r * L + c] : 0.0;
   }
-  const int ti = tid >> 4, tj = tid & 15;
-  const int brow = tid >> 3, bc0 = (tid & 7) * 8;   // b entries: row brow, columns bc0..bc0+7
-  double acc[4][4];
+  const int brow = tid >> 3, bc0 = (tid & 7) * 8;   // elementwise step: row brow, columns bc0..bc0+7
+  f64x4 acc[4];
 #pragma unroll
-  for (int x = 0; x < 4; ++x)
-#pragma unroll
-    for (int y = 0; y < 4; ++y) acc[x][y] = 0.0;
+  for (int y = 0; y < 4; ++y) acc[y] = f64x4{0.0, 0.0, 0.0, 0.0};
   double auxr[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) auxr[e] = (bc0 + e < L) ? aux[bc0 + e] : ((mode & 1) ? 1.0 : 0.0);
+  const int rt = wave & 1, ct0 = 2 * (wave >> 1);
   __syncthreads();
   for (int64_t r0 = (int64_t)blockIdx.x * 32; r0 < rows; r0 += (int64_t)gridDim.x * 32) {
     for (int i = tid; i < 32 * 16; i += 256) {
@@ -2185,63 +2190,60 @@ __global__ __launch_bounds__(256) void rot_step_kernel(const float* __restrict__
       *reinterpret_cast<f32x4*>(&Xs[rr][c4]) = v;
     }
     __syncthreads();
-    double b[8];
+    // b = x R
+    f64x4 bt[2] = {f64x4{0.0, 0.0, 0.0, 0.0}, f64x4{0.0, 0.0, 0.0, 0.0}};
 #pragma unroll
-    for (int e = 0; e < 8; ++e) b[e] = 0.0;
-    for (int k = 0; k < 64; ++k) {
-      const double xv = (double)Xs[brow][k];
+    for (int s = 0; s < 16; ++s) {
+      const double a = (double)Xs[16 * rt + li][4 * s + lk];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) b[e] += xv * Rs[k][bc0 + e];
+      for (int c = 0; c < 2; ++c)
+        bt[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Rs[4 * s + lk][16 * (ct0 + c) + li], bt[c], 0, 0, 0);
     }
-    if (mode >= 2) {       // complex: every entry needs the other part of its column (uniform branch)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) Ls[brow][bc0 + e] = b[e];
-      __syncthreads();
-    }
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Ls[16 * rt + lk + 4 * r][16 * (ct0 + c) + li] = bt[c][r];   // D[lk + 4 r][li]
+    __syncthreads();
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
+      const double b = Ls[brow][bc0 + e];
       double t;
-      if (mode >= 2) {
+      if (mode >= 2) {       // complex: column j pairs with column j + 32
         const int cr = (bc0 + e) & 31;
         const double br_ = Ls[brow][cr], bi_ = Ls[brow][cr + 32];
         const double a2 = br_ * br_ + bi_ * bi_;
         if (mode == 2) {
-          t = b[e] * (a2 - auxr[e]);
+          t = b * (a2 - auxr[e]);
         } else {
           const double za = sqrt(a2) / auxr[e];
-          t = (power == 1.0 || !(za > 0.0)) ? b[e] / auxr[e] : (b[e] / auxr[e]) * pow(za, power - 1.0);
+          t = (power == 1.0 || !(za > 0.0)) ? b / auxr[e] : (b / auxr[e]) * pow(za, power - 1.0);
         }
       } else if (mode == 0) {
-        t = b[e] * (b[e] * b[e] - auxr[e]);
+        t = b * (b * b - auxr[e]);
       } else {
-        const double z = b[e] / auxr[e];
+        const double z = b / auxr[e];
         t = (power == 1.0) ? z : z * pow(fabs(z), power - 1.0);
-        Ls[brow][bc0 + e] = b[e];
       }
       Ts[brow][bc0 + e] = t;
     }
     __syncthreads();
-#pragma unroll 4
-    for (int r = 0; r < 32; ++r) {
-      double a[4], c[4];
+    // G += left^T t  (left = x in modes 0 / 2, b in modes 1 / 3): k runs over the 32 rows of the tile
 #pragma unroll
-      for (int x = 0; x < 4; ++x) a[x] = (mode & 1) ? Ls[r][4 * ti + x] : (double)Xs[r][4 * ti + x];
+    for (int s = 0; s < 8; ++s) {
+      const double a = (mode & 1) ? Ls[4 * s + lk][16 * wave + li] : (double)Xs[4 * s + lk][16 * wave + li];
 #pragma unroll
-      for (int y = 0; y < 4; ++y) c[y] = Ts[r][4 * tj + y];
-#pragma unroll
-      for (int x = 0; x < 4; ++x)
-#pragma unroll
-        for (int y = 0; y < 4; ++y) acc[x][y] += a[x] * c[y];
+      for (int y = 0; y < 4; ++y)
+        acc[y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Ts[4 * s + lk][16 * y + li], acc[y], 0, 0, 0);
     }
     __syncthreads();
   }
   double* G = Gpart + (int64_t)blockIdx.x * L * L;
 #pragma unroll
-  for (int x = 0; x < 4; ++x)
+  for (int y = 0; y < 4; ++y)
 #pragma unroll
-    for (int y = 0; y < 4; ++y) {
-      const int gi = 4 * ti + x, gj = 4 * tj + y;
-      if (gi < L && gj < L) G[(int64_t)gi * L + gj] = acc[x][y];
+    for (int r = 0; r < 4; ++r) {
+      const int gi = 16 * wave + lk + 4 * r, gj = 16 * y + li;      // D[lk + 4 r][li] of tile (wave, y)
+      if (gi < L && gj < L) G[(int64_t)gi * L + gj] = acc[y][r];
     }
 }
 
