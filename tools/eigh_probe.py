@@ -1,24 +1,11 @@
-import time, numpy as np, torch, sys
-import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
-rng = np.random.default_rng(0)
-A = rng.standard_normal((n, 2 * n)).astype(np.float32)
-G = torch.as_tensor(A @ A.T, device="cuda")
-for dt in (torch.float32, torch.float64):
-    Gd = G.to(dt)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    w, U = torch.linalg.eigh(Gd)
-    torch.cuda.synchronize(); t1 = time.perf_counter()
-    w, U = torch.linalg.eigh(Gd)
-    torch.cuda.synchronize(); t2 = time.perf_counter()
-    print(dt, "gpu eigh first %.2f s, second %.2f s" % (t1 - t0, t2 - t1), flush=True)
-Gh = G.double().cpu().numpy()
-t0 = time.perf_counter(); w2, U2 = np.linalg.eigh(Gh); t1 = time.perf_counter()
-print("numpy eigh fp64 %.2f s" % (t1 - t0), flush=True)
-import scipy.linalg as sla
-t0 = time.perf_counter(); w3, U3 = sla.eigh(Gh, subset_by_index=[n - int(0.3 * n), n - 1]); t1 = time.perf_counter()
-print("scipy eigh subset 30%% fp64 %.2f s" % (t1 - t0), flush=True)
-t0 = time.perf_counter(); w3, U3 = sla.eigh(Gh.astype(np.float32), subset_by_index=[n - int(0.3 * n), n - 1]); t1 = time.perf_counter()
-print("scipy eigh subset 30%% fp32 %.2f s" % (t1 - t0), flush=True)
-print("max rel diff gpu64 vs numpy:", float(np.abs(w.cpu().numpy() - w2).max() / w2.max()))
-import os; print("cpus", os.cpu_count())
+import torch, time
+for n in (1536, 5000, 10000):
+    A = torch.randn(n, n + 500, device="cuda", dtype=torch.float64); G = A @ A.T
+    for dt in (torch.float64, torch.float32):
+        H = G.to(dt); torch.linalg.eigh(H); torch.cuda.synchronize()
+        t = time.perf_counter(); w, V = torch.linalg.eigh(H); torch.cuda.synchronize()
+        print(n, dt, f"{(time.perf_counter()-t)*1e3:.1f} ms", flush=True)
+    t = time.perf_counter(); w = torch.linalg.eigvalsh(G); torch.cuda.synchronize(); print(n, "eigvalsh f64", f"{(time.perf_counter()-t)*1e3:.1f} ms")
+    t = time.perf_counter(); L = torch.linalg.cholesky(G); torch.cuda.synchronize(); print(n, "chol f64", f"{(time.perf_counter()-t)*1e3:.1f} ms")
+    t = time.perf_counter(); Q, R = torch.linalg.qr(G); torch.cuda.synchronize(); print(n, "qr f64", f"{(time.perf_counter()-t)*1e3:.1f} ms")
+    t = time.perf_counter(); C = G @ G; torch.cuda.synchronize(); print(n, "gemm f64", f"{(time.perf_counter()-t)*1e3:.1f} ms")

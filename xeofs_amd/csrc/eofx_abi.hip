@@ -1,6 +1,7 @@
 // eofx_abi.hip -- C ABI (include/eofx.h) of the MI355X-native EOF / randomized-SVD engine:
 // launch logic, the randomized-SVD drivers and the small host-side linear algebra.
 // Kernels live in eofx_kernels.hpp.  gfx950 only.
+#include "eofx_hfft.hpp"
 #include "eofx_kernels.hpp"
 #include "eofx_fused.hpp"
 
@@ -48,7 +49,8 @@ struct eofx_ctx {
     int64_t n = 0, P = 0;
     int padding = 0;
     double decay = 0.0;
-    void* chat = nullptr;  // device cfloat[P/2+1]
+    void* chat = nullptr;  // device cfloat[P/2+1]   (hipFFT route, P > 16384)
+    float* hperm = nullptr;  // device float[P]: filter table of the one-kernel route, in its LDS order (P <= 16384)
     float* u = nullptr;    // device float[4 n]
   };
   std::vector<HilbertSetup> hsetups;
@@ -195,6 +197,7 @@ extern "C" int eofx_ctx_destroy(eofx_ctx* ctx) {
   }
   for (auto& h : ctx->hsetups) {
     if (h.chat) (void)hipFree(h.chat);
+    if (h.hperm) (void)hipFree(h.hperm);
     if (h.u) (void)hipFree(h.u);
   }
   delete ctx;
@@ -2157,12 +2160,47 @@ static int get_fft_plans(eofx_ctx* ctx, int64_t P, int64_t ldw, int64_t nh, int6
   return EOFX_OK;
 }
 
+// forward transform of a power-of-two length, float64, in place (host; filter table of the one-kernel Hilbert route)
+static void host_fft_f64(std::vector<std::complex<double>>& a) {
+  const size_t N = a.size();
+  for (size_t i = 1, j = 0; i < N; ++i) {
+    size_t bit = N >> 1;
+    for (; j & bit; bit >>= 1) j ^= bit;
+    j ^= bit;
+    if (i < j) std::swap(a[i], a[j]);
+  }
+  for (size_t len = 2; len <= N; len <<= 1) {
+    std::vector<std::complex<double>> w(len / 2);
+    for (size_t k = 0; k < len / 2; ++k) {
+      const double ang = -2.0 * M_PI * (double)k / (double)len;
+      w[k] = std::complex<double>(std::cos(ang), std::sin(ang));
+    }
+    for (size_t i = 0; i < N; i += len)
+      for (size_t k = 0; k < len / 2; ++k) {
+        const std::complex<double> x = a[i + k], y = a[i + k + len / 2] * w[k];
+        a[i + k] = x + y;
+        a[i + k + len / 2] = x - y;
+      }
+  }
+}
+
+// circular length of the convolution behind the Hilbert stage: power of two >= 2 n (>= 128); the one-kernel route
+// (eofx_hfft.hpp) holds it in LDS up to 2^14
+static int64_t hilbert_length(int64_t n, int* log2_out) {
+  int L = 7;
+  while (((int64_t)1 << L) < 2 * n) ++L;
+  if (log2_out) *log2_out = L;
+  return (int64_t)1 << L;
+}
+static const int HFFT_MAX_LOG2 = 14;
+
 // kernel spectrum and correction vectors for series length n (cached per context)
 static int get_hilbert_setup(eofx_ctx* ctx, int64_t n, int padding, double decay, int64_t P,
-                             const cfloat** chat_out, const float** u_out) {
+                             const cfloat** chat_out, const float** hperm_out, const float** u_out) {
   for (auto& h : ctx->hsetups)
     if (h.n == n && h.padding == padding && h.decay == decay && h.P == P) {
       *chat_out = (const cfloat*)h.chat;
+      *hperm_out = h.hperm;
       *u_out = h.u;
       return EOFX_OK;
     }
@@ -2170,20 +2208,34 @@ static int get_hilbert_setup(eofx_ctx* ctx, int64_t n, int padding, double decay
   const int64_t nh = P / 2 + 1, ldw = P + 2;
   eofx_ctx::HilbertSetup hs;
   hs.n = n; hs.P = P; hs.padding = padding; hs.decay = decay;
-  // circular embedding of the Toeplitz kernel, lags -(n-1) .. n-1, scaled by 1/P (unnormalised inverse)
-  std::vector<float> c((size_t)ldw, 0.f);
-  for (int64_t d = -(n - 1); d <= n - 1; ++d)
-    c[(size_t)((d % P + P) % P)] = (float)(hilbert_kappa(N, d) / (double)P);
-  float* cdev = nullptr;
-  HIPCHK(hipMalloc((void**)&cdev, sizeof(float) * ldw));
-  HIPCHK(hipMalloc(&hs.chat, sizeof(cfloat) * nh));
-  HIPCHK(hipMemcpy(cdev, c.data(), sizeof(float) * ldw, hipMemcpyHostToDevice));
-  hipfftHandle pf, pb;
-  CHK(get_fft_plans(ctx, P, ldw, nh, 1, pf, pb));
-  if (hipfftExecR2C(pf, cdev, (hipfftComplex*)hs.chat) != HIPFFT_SUCCESS)
-    return set_err(ctx, EOFX_ERR_HIP, "hipfftExecR2C failed (kernel spectrum)");
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  (void)hipFree(cdev);
+  int L = 0;
+  while (((int64_t)1 << L) < P) ++L;
+  if (L <= HFFT_MAX_LOG2) {
+    // the kernel is real and odd, so its spectrum is i h[k] with h real: one float per frequency, stored in the order
+    // the forward stages leave the spectrum in LDS; 1/P of the unnormalised inverse folded in
+    std::vector<std::complex<double>> c((size_t)P, 0.0);
+    for (int64_t d = -(n - 1); d <= n - 1; ++d) c[(size_t)((d % P + P) % P)] = hilbert_kappa(N, d) / (double)P;
+    host_fft_f64(c);
+    std::vector<float> hp((size_t)P);
+    for (int64_t pos = 0; pos < P; ++pos) hp[(size_t)pos] = (float)c[(size_t)hfft::position_frequency(L, pos)].imag();
+    HIPCHK(hipMalloc((void**)&hs.hperm, sizeof(float) * P));
+    HIPCHK(hipMemcpy(hs.hperm, hp.data(), sizeof(float) * P, hipMemcpyHostToDevice));
+  } else {
+    // circular embedding of the Toeplitz kernel, lags -(n-1) .. n-1, scaled by 1/P (unnormalised inverse)
+    std::vector<float> c((size_t)ldw, 0.f);
+    for (int64_t d = -(n - 1); d <= n - 1; ++d)
+      c[(size_t)((d % P + P) % P)] = (float)(hilbert_kappa(N, d) / (double)P);
+    float* cdev = nullptr;
+    HIPCHK(hipMalloc((void**)&cdev, sizeof(float) * ldw));
+    HIPCHK(hipMalloc(&hs.chat, sizeof(cfloat) * nh));
+    HIPCHK(hipMemcpy(cdev, c.data(), sizeof(float) * ldw, hipMemcpyHostToDevice));
+    hipfftHandle pf, pb;
+    CHK(get_fft_plans(ctx, P, ldw, nh, 1, pf, pb));
+    if (hipfftExecR2C(pf, cdev, (hipfftComplex*)hs.chat) != HIPFFT_SUCCESS)
+      return set_err(ctx, EOFX_ERR_HIP, "hipfftExecR2C failed (kernel spectrum)");
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    (void)hipFree(cdev);
+  }
   if (padding) {
     // u1 = K_pre e_rev, u2 = K_pos e, u3 = (K_pre + K_pos) 1, u4 = K_pre (t - n) + K_pos (t + n)
     // with K_pre[t][s] = kappa((n + t) - s), K_pos[t][s] = kappa((n + t) - (2n + s)); float64, threaded
@@ -2215,8 +2267,33 @@ static int get_hilbert_setup(eofx_ctx* ctx, int64_t n, int padding, double decay
   }
   ctx->hsetups.push_back(hs);
   *chat_out = (const cfloat*)hs.chat;
+  *hperm_out = hs.hperm;
   *u_out = hs.u;
   return EOFX_OK;
+}
+
+// launch of the one-kernel route for one plan (L = log2 of the circular length)
+template <int L>
+static hipError_t launch_hilbert_fused(eofx_ctx* ctx, const float* Xt, int64_t n_pad, int64_t n, int64_t p, int padding,
+                                       const float* hperm, const float* u, float* Bt, float* At, unsigned* bmax,
+                                       unsigned* amax) {
+  using PL = hfft::plan<L>;
+  auto kern = hfft::hilbert_fft_kernel<L>;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PL::lds);
+  if (e != hipSuccess) return e;
+  const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>((int64_t)(163840 / PL::lds), 2048 / PL::WG));
+  const int64_t groups = ((p + 1) / 2 + PL::G - 1) / PL::G;
+  static int cu_count = 0;
+  if (cu_count <= 0) {
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, ctx->device);
+    if (e != hipSuccess) return e;
+    cu_count = prop.multiProcessorCount;
+  }
+  const int grid = (int)std::min<int64_t>(groups, (int64_t)cu_count * per_cu);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(PL::WG), PL::lds, ctx->stream, Xt, n_pad, (int)n, p, padding, hperm, u, Bt, At,
+                     bmax, amax);
+  return hipGetLastError();
 }
 
 extern "C" int eofx_hilbert_f32(eofx_ctx* ctx, const eofx_mat* a, int padding, double decay_factor,
@@ -2225,12 +2302,14 @@ extern "C" int eofx_hilbert_f32(eofx_ctx* ctx, const eofx_mat* a, int padding, d
   if (padding && !(decay_factor > 0.0)) return set_err(ctx, EOFX_ERR_ARG, "decay_factor must be positive");
   CHK(set_device(ctx));
   const int64_t n = a->n, p = a->p, n_pad = a->n_pad, p_pad = a->p_pad;
-  int64_t P = 2;
-  while (P < 2 * n) P *= 2;                 // circular length: power of two >= 2n
+  int L = 0;
+  const int64_t P = hilbert_length(n, &L);  // circular length: power of two >= 2n
+  const bool fused = L <= HFFT_MAX_LOG2;    // the whole stage in one kernel (eofx_hfft.hpp); longer series: hipFFT route
   const int64_t nh = P / 2 + 1, ldw = P + 2;
   const cfloat* chat = nullptr;
+  const float* hperm = nullptr;
   const float* u = nullptr;
-  CHK(get_hilbert_setup(ctx, n, padding ? 1 : 0, padding ? decay_factor : 0.0, P, &chat, &u));
+  CHK(get_hilbert_setup(ctx, n, padding ? 1 : 0, padding ? decay_factor : 0.0, P, &chat, &hperm, &u));
   CHK(ensure_Xt(ctx, a));
   // features per FFT batch: real series + half spectrum of about 3 GB together
   int64_t Fc = std::max<int64_t>(1, std::min<int64_t>(p, (int64_t)(3.0e9 / (4.0 * (double)ldw + 8.0 * (double)nh))));
@@ -2245,13 +2324,28 @@ extern "C" int eofx_hilbert_f32(eofx_ctx* ctx, const eofx_mat* a, int padding, d
   const size_t work_bytes = (size_t)Fc * ldw * sizeof(float), spec_bytes = (size_t)Fc * nh * sizeof(cfloat);
   const size_t coef_bytes = (size_t)Fc * 4 * sizeof(float);
   if (rc != EOFX_OK) goto done;
-  if (pool_malloc(ctx, (void**)&work, work_bytes) != hipSuccess ||
+  if (fused) {
+    hipError_t e = hipSuccess;
+    float* At = mr ? mr->Xt : nullptr;
+    unsigned* amax = mr ? mr->absmax_dev : nullptr;
+    switch (L) {
+#define EOFX_HF(LL) \
+  case LL: e = launch_hilbert_fused<LL>(ctx, a->Xt, n_pad, n, p, padding ? 1 : 0, hperm, u, mi->Xt, At, mi->absmax_dev, amax); break;
+      EOFX_HF(7) EOFX_HF(8) EOFX_HF(9) EOFX_HF(10) EOFX_HF(11) EOFX_HF(12) EOFX_HF(13) EOFX_HF(14)
+#undef EOFX_HF
+      default: e = hipErrorInvalidValue;
+    }
+    if (e != hipSuccess) {
+      rc = set_err(ctx, EOFX_ERR_HIP, "hilbert stage failed: %s", hipGetErrorString(e));
+      goto done;
+    }
+  } else if (pool_malloc(ctx, (void**)&work, work_bytes) != hipSuccess ||
       pool_malloc(ctx, (void**)&spec, spec_bytes) != hipSuccess ||
       pool_malloc(ctx, (void**)&coef, coef_bytes) != hipSuccess) {
     rc = set_err(ctx, EOFX_ERR_NOMEM, "cannot allocate the FFT work buffers");
     goto done;
   }
-  {
+  if (!fused) {
     rc = get_fft_plans(ctx, P, ldw, nh, Fc, plan_f, plan_b);
     if (rc != EOFX_OK) goto done;
     const int64_t tail = p % Fc;
@@ -2273,6 +2367,8 @@ extern "C" int eofx_hilbert_f32(eofx_ctx* ctx, const eofx_mat* a, int padding, d
                          f0, padding ? 1 : 0, coef, u, a->Xt, mi->Xt, mr ? mr->Xt : nullptr, mi->absmax_dev,
                          mr ? mr->absmax_dev : nullptr);
     }
+  }
+  {
     // zero the padding feature rows, then build the feature-contiguous layout by transposition
     const size_t pad_bytes = (size_t)(p_pad - p) * n_pad * sizeof(float);
     if (pad_bytes) {

@@ -1,0 +1,533 @@
+// The Hilbert stage of HilbertEOF / HilbertMCA (xeofs/utils/hilbert_transform.py:40-114) as ONE kernel per field.
+//
+// For the middle n samples of the exponentially padded series the transform is  Im = T y + (four rank-one corrections)
+// (see eofx_kernels.hpp, "Hilbert transform along the sample axis"), T the n x n Toeplitz block of the Hilbert kernel:
+// a circular convolution of power-of-two length P >= 2n with a REAL, ODD kernel c.  So
+//   * two features share one complex transform, z = y_a + i y_b: c * z = (c * y_a) + i (c * y_b);
+//   * the kernel spectrum is purely imaginary, FFT(c)[k] = i h[k]: the filter is one real table;
+//   * a decimation-in-frequency forward transform leaves the spectrum digit-reversed, the mirrored
+//     decimation-in-time inverse takes it from there: no reordering pass, the table is stored in that order.
+// One workgroup of P/16 threads owns a pair of features for the whole trip: the series come from HBM straight into
+// the registers of the first butterfly (thread t holds samples t + c P/16; the zero padding is never materialised),
+// the transform lives in LDS (P complex values, skewed against bank conflicts), and the last inverse butterfly
+// hands thread t the samples it started with -- corrections, centring and the store happen in registers.  HBM
+// traffic is the algorithmic minimum (read y once, write Im once); the next pair's loads are in flight during the
+// LDS stages.  Radix 16 butterflies (4 x 4 in registers), one optional leading radix 2 / 4 / 8 stage, twiddle factors
+// per thread computed once in float64 and kept in registers (a thread meets the same butterfly for every pair).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#ifndef HFFT_WAVES
+#define HFFT_WAVES 4
+#endif
+namespace hfft {
+
+typedef float cf __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ cf cmul(cf a, cf b) { return cf{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+__device__ __forceinline__ cf cmulc(cf a, cf b) { return cf{a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y}; }  // a conj(b)
+// DIR = +1: forward (factors exp(-i ...)), DIR = -1: inverse (their conjugates)
+template <int DIR> __device__ __forceinline__ cf twm(cf a, cf w) { return DIR > 0 ? cmul(a, w) : cmulc(a, w); }
+template <int DIR> __device__ __forceinline__ cf rot90(cf a) { return DIR > 0 ? cf{a.y, -a.x} : cf{-a.y, a.x}; }  // * (-+ i)
+
+// a * w16^K, w16 = exp(-+ 2 pi i / 16)
+template <int DIR, int K> __device__ __forceinline__ cf mulw16(cf a) {
+  constexpr int k = K & 15;
+  constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, H = 0.70710678118654752f;
+  if constexpr (k == 0) return a;
+  else if constexpr (k == 4) return rot90<DIR>(a);
+  else if constexpr (k == 8) return cf{-a.x, -a.y};
+  else if constexpr (k == 12) return rot90<-DIR>(a);
+  else if constexpr (k == 2) return DIR > 0 ? cf{H * (a.x + a.y), H * (a.y - a.x)} : cf{H * (a.x - a.y), H * (a.x + a.y)};
+  else if constexpr (k == 6) return DIR > 0 ? cf{H * (a.y - a.x), -H * (a.x + a.y)} : cf{-H * (a.x + a.y), H * (a.x - a.y)};
+  else if constexpr (k == 10) return mulw16<DIR, 2>(cf{-a.x, -a.y});
+  else if constexpr (k == 14) return mulw16<DIR, 6>(cf{-a.x, -a.y});
+  else {
+    constexpr float c = (k == 1 || k == 15) ? C1 : (k == 3 || k == 13) ? S1 : (k == 5 || k == 11) ? -S1 : -C1;  // cos(pi k / 8)
+    constexpr float s = (k == 1 || k == 7) ? S1 : (k == 3 || k == 5) ? C1 : (k == 9 || k == 15) ? -S1 : -C1;    // sin(pi k / 8)
+    return twm<DIR>(a, cf{c, -s});
+  }
+}
+
+template <int DIR> __device__ __forceinline__ void dft4(cf& a0, cf& a1, cf& a2, cf& a3) {
+  const cf s02 = a0 + a2, d02 = a0 - a2, s13 = a1 + a3, d13 = rot90<DIR>(a1 - a3);
+  a0 = s02 + s13; a1 = d02 + d13; a2 = s02 - s13; a3 = d02 - d13;
+}
+template <int DIR> __device__ __forceinline__ void dft4_lo(cf& a0, cf& a1, cf& a2, cf& a3) {   // a2 = a3 = 0 on entry
+  const cf x0 = a0, x1 = a1, r = rot90<DIR>(a1);
+  a0 = x0 + x1; a1 = x0 + r; a2 = x0 - x1; a3 = x0 - r;
+}
+
+// 16-point transform in registers, natural order in; result q sits in v[slot16(q)].  HALF: v[8..15] are zero on entry.
+__host__ __device__ constexpr int slot16(int q) { return 4 * (q & 3) + (q >> 2); }
+template <int DIR, bool HALF> __device__ __forceinline__ void dft16(cf* v) {
+#pragma unroll
+  for (int j1 = 0; j1 < 4; ++j1) {
+    if constexpr (HALF) dft4_lo<DIR>(v[j1], v[j1 + 4], v[j1 + 8], v[j1 + 12]);
+    else dft4<DIR>(v[j1], v[j1 + 4], v[j1 + 8], v[j1 + 12]);
+  }
+  v[5] = mulw16<DIR, 1>(v[5]);   v[9] = mulw16<DIR, 2>(v[9]);    v[13] = mulw16<DIR, 3>(v[13]);
+  v[6] = mulw16<DIR, 2>(v[6]);   v[10] = mulw16<DIR, 4>(v[10]);  v[14] = mulw16<DIR, 6>(v[14]);
+  v[7] = mulw16<DIR, 3>(v[7]);   v[11] = mulw16<DIR, 6>(v[11]);  v[15] = mulw16<DIR, 9>(v[15]);
+#pragma unroll
+  for (int q2 = 0; q2 < 4; ++q2) dft4<DIR>(v[4 * q2], v[4 * q2 + 1], v[4 * q2 + 2], v[4 * q2 + 3]);
+}
+// 8-point transform on a0..a7 (natural order in); result q sits in slot8(q) = 2 (q & 3) + (q >> 2)
+__host__ __device__ constexpr int slot8(int q) { return 2 * (q & 3) + (q >> 2); }
+template <int DIR, bool HALF> __device__ __forceinline__ void dft8(cf& a0, cf& a1, cf& a2, cf& a3, cf& a4, cf& a5,
+                                                                   cf& a6, cf& a7) {
+  if constexpr (HALF) { dft4_lo<DIR>(a0, a2, a4, a6); dft4_lo<DIR>(a1, a3, a5, a7); }
+  else { dft4<DIR>(a0, a2, a4, a6); dft4<DIR>(a1, a3, a5, a7); }
+  a3 = mulw16<DIR, 2>(a3); a5 = mulw16<DIR, 4>(a5); a7 = mulw16<DIR, 6>(a7);
+  cf t;
+  t = a0; a0 = t + a1; a1 = t - a1;
+  t = a2; a2 = t + a3; a3 = t - a3;
+  t = a4; a4 = t + a5; a5 = t - a5;
+  t = a6; a6 = t + a7; a7 = t - a7;
+}
+
+// LDS position of element idx: 16 B of padding per 16 elements (the stride-1 stage reads 128 B per lane) and
+// 128 B more per 256 elements (the stride-16 stage)
+__host__ __device__ constexpr int phys(int idx) { return idx + 2 * (idx >> 4) + 16 * (idx >> 8); }
+
+__device__ __forceinline__ cf unit(double num, double den) {   // exp(-2 pi i num / den)
+  double s, c;
+  sincospi(-2.0 * num / den, &s, &c);
+  return cf{(float)c, (float)s};
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// stored powers w^1 w^2 w^4 w^8 of a butterfly's base factor (each rounded from float64); w^3 = w^1 w^2 and
+// w^12 = w^4 w^8 are formed per stage, and w^q = w^(4a) w^b -- at most three float32 roundings away from exact
+struct tw4 {
+  cf w1, w2, w4, w8;
+};
+struct tw6 {
+  cf w1, w2, w3, w4, w8, w12;
+};
+__device__ __forceinline__ tw4 make_tw4(int lo, int span) {
+  return tw4{unit(lo, span), unit(2.0 * lo, span), unit(4.0 * lo, span), unit(8.0 * lo, span)};
+}
+__device__ __forceinline__ tw6 expand(const tw4& s) { return tw6{s.w1, s.w2, cmul(s.w1, s.w2), s.w4, s.w8, cmul(s.w4, s.w8)}; }
+template <int DIR, int Q> __device__ __forceinline__ cf apply_tw(cf a, const tw6& t) {
+  constexpr int hi = Q >> 2, lo = Q & 3;
+  if constexpr (lo == 1) a = twm<DIR>(a, t.w1);
+  if constexpr (lo == 2) a = twm<DIR>(a, t.w2);
+  if constexpr (lo == 3) a = twm<DIR>(a, t.w3);
+  if constexpr (hi == 1) a = twm<DIR>(a, t.w4);
+  if constexpr (hi == 2) a = twm<DIR>(a, t.w8);
+  if constexpr (hi == 3) a = twm<DIR>(a, t.w12);
+  return a;
+}
+
+// one radix-16 stage through LDS: elements base + j S.  Forward: transform, then the stage's factors; inverse: mirrored.
+// (S is 16 or 256 and base has no bits at S .. 16 S, so phys(base + j S) = phys(base) + phys(j S): `at` = data + phys(base))
+template <int DIR, int S> __device__ __forceinline__ void stage16(cf* at, const tw4& ts) {
+  static_assert(S == 16 || S == 256, "stride");
+  const tw6 t = expand(ts);
+  cf v[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) v[j] = at[phys(j * S)];
+  if constexpr (DIR > 0) {
+    dft16<1, false>(v);
+#define HFFT_ST(Q) at[phys(Q * S)] = apply_tw<1, Q>(v[slot16(Q)], t);
+    HFFT_ST(0) HFFT_ST(1) HFFT_ST(2) HFFT_ST(3) HFFT_ST(4) HFFT_ST(5) HFFT_ST(6) HFFT_ST(7)
+    HFFT_ST(8) HFFT_ST(9) HFFT_ST(10) HFFT_ST(11) HFFT_ST(12) HFFT_ST(13) HFFT_ST(14) HFFT_ST(15)
+#undef HFFT_ST
+  } else {
+#define HFFT_LD(Q) v[Q] = apply_tw<-1, Q>(v[Q], t);
+    HFFT_LD(1) HFFT_LD(2) HFFT_LD(3) HFFT_LD(4) HFFT_LD(5) HFFT_LD(6) HFFT_LD(7)
+    HFFT_LD(8) HFFT_LD(9) HFFT_LD(10) HFFT_LD(11) HFFT_LD(12) HFFT_LD(13) HFFT_LD(14) HFFT_LD(15)
+#undef HFFT_LD
+    dft16<-1, false>(v);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) at[phys(j * S)] = v[slot16(j)];
+  }
+}
+
+// The register-resident outer stage on e[c] <-> element t + c NT (NT = P/16): the leading radix-RL stage, or the first
+// radix-16 stage when there is none.  Forward: e[8..15] are zero on entry.  w holds the powers of exp(-2 pi i t / P).
+template <int RL, int DIR> __device__ __forceinline__ void outer_stage(cf* e, const tw4& ws) {
+  const tw6 w = expand(ws);
+  if constexpr (RL == 1) {
+    if constexpr (DIR > 0) {
+      dft16<1, true>(e);
+      cf o[16];
+#define HFFT_O(Q) o[Q] = apply_tw<1, Q>(e[slot16(Q)], w);
+      HFFT_O(0) HFFT_O(1) HFFT_O(2) HFFT_O(3) HFFT_O(4) HFFT_O(5) HFFT_O(6) HFFT_O(7)
+      HFFT_O(8) HFFT_O(9) HFFT_O(10) HFFT_O(11) HFFT_O(12) HFFT_O(13) HFFT_O(14) HFFT_O(15)
+#undef HFFT_O
+#pragma unroll
+      for (int q = 0; q < 16; ++q) e[q] = o[q];
+    } else {
+#define HFFT_I(Q) e[Q] = apply_tw<-1, Q>(e[Q], w);
+      HFFT_I(1) HFFT_I(2) HFFT_I(3) HFFT_I(4) HFFT_I(5) HFFT_I(6) HFFT_I(7)
+      HFFT_I(8) HFFT_I(9) HFFT_I(10) HFFT_I(11) HFFT_I(12) HFFT_I(13) HFFT_I(14) HFFT_I(15)
+#undef HFFT_I
+      dft16<-1, false>(e);
+      cf o[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) o[j] = e[slot16(j)];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) e[j] = o[j];
+    }
+  } else if constexpr (RL == 2) {
+    // butterflies m = 0..7 on (e[m], e[m + 8]); factor of output 1: w^1 w16^m
+#define HFFT_B2(M)                                                        \
+    if constexpr (DIR > 0) {                                              \
+      e[M + 8] = mulw16<1, M>(twm<1>(e[M], w.w1));                        \
+    } else {                                                              \
+      const cf y1 = mulw16<-1, M>(twm<-1>(e[M + 8], w.w1));               \
+      const cf y0 = e[M];                                                 \
+      e[M] = y0 + y1; e[M + 8] = y0 - y1;                                 \
+    }
+    HFFT_B2(0) HFFT_B2(1) HFFT_B2(2) HFFT_B2(3) HFFT_B2(4) HFFT_B2(5) HFFT_B2(6) HFFT_B2(7)
+#undef HFFT_B2
+  } else if constexpr (RL == 4) {
+    // butterflies m = 0..3 on e[m + 4 j]; factor of output q: w^q w16^(m q)
+#define HFFT_B4(M)                                                                         \
+    if constexpr (DIR > 0) {                                                               \
+      dft4_lo<1>(e[M], e[M + 4], e[M + 8], e[M + 12]);                                     \
+      e[M + 4] = mulw16<1, M>(twm<1>(e[M + 4], w.w1));                                     \
+      e[M + 8] = mulw16<1, 2 * M>(twm<1>(e[M + 8], w.w2));                                 \
+      e[M + 12] = mulw16<1, 3 * M>(twm<1>(e[M + 12], w.w3));                               \
+    } else {                                                                               \
+      e[M + 4] = mulw16<-1, M>(twm<-1>(e[M + 4], w.w1));                                   \
+      e[M + 8] = mulw16<-1, 2 * M>(twm<-1>(e[M + 8], w.w2));                               \
+      e[M + 12] = mulw16<-1, 3 * M>(twm<-1>(e[M + 12], w.w3));                             \
+      dft4<-1>(e[M], e[M + 4], e[M + 8], e[M + 12]);                                       \
+    }
+    HFFT_B4(0) HFFT_B4(1) HFFT_B4(2) HFFT_B4(3)
+#undef HFFT_B4
+  } else {
+    // RL == 8: butterflies m = 0, 1 on e[m + 2 j]; factor of output q: w^q w16^(m q)
+    const cf w5 = cmul(w.w4, w.w1), w6 = cmul(w.w4, w.w2), w7 = cmul(w.w4, w.w3);
+#define HFFT_B8(M)                                                                                        \
+    { if constexpr (DIR > 0) {                                                                              \
+      dft8<1, true>(e[M], e[M + 2], e[M + 4], e[M + 6], e[M + 8], e[M + 10], e[M + 12], e[M + 14]);       \
+      cf o[8];                                                                                            \
+      o[0] = e[M + 2 * slot8(0)];                                                                         \
+      o[1] = mulw16<1, M>(twm<1>(e[M + 2 * slot8(1)], w.w1));                                             \
+      o[2] = mulw16<1, 2 * M>(twm<1>(e[M + 2 * slot8(2)], w.w2));                                         \
+      o[3] = mulw16<1, 3 * M>(twm<1>(e[M + 2 * slot8(3)], w.w3));                                         \
+      o[4] = mulw16<1, 4 * M>(twm<1>(e[M + 2 * slot8(4)], w.w4));                                         \
+      o[5] = mulw16<1, 5 * M>(twm<1>(e[M + 2 * slot8(5)], w5));                                           \
+      o[6] = mulw16<1, 6 * M>(twm<1>(e[M + 2 * slot8(6)], w6));                                           \
+      o[7] = mulw16<1, 7 * M>(twm<1>(e[M + 2 * slot8(7)], w7));                                           \
+      _Pragma("unroll") for (int q = 0; q < 8; ++q) e[M + 2 * q] = o[q];                                  \
+    } else {                                                                                              \
+      e[M + 2] = mulw16<-1, M>(twm<-1>(e[M + 2], w.w1));                                                  \
+      e[M + 4] = mulw16<-1, 2 * M>(twm<-1>(e[M + 4], w.w2));                                              \
+      e[M + 6] = mulw16<-1, 3 * M>(twm<-1>(e[M + 6], w.w3));                                              \
+      e[M + 8] = mulw16<-1, 4 * M>(twm<-1>(e[M + 8], w.w4));                                              \
+      e[M + 10] = mulw16<-1, 5 * M>(twm<-1>(e[M + 10], w5));                                              \
+      e[M + 12] = mulw16<-1, 6 * M>(twm<-1>(e[M + 12], w6));                                              \
+      e[M + 14] = mulw16<-1, 7 * M>(twm<-1>(e[M + 14], w7));                                              \
+      dft8<-1, false>(e[M], e[M + 2], e[M + 4], e[M + 6], e[M + 8], e[M + 10], e[M + 12], e[M + 14]);     \
+      cf o[8];                                                                                            \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j) o[j] = e[M + 2 * slot8(j)];                           \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j) e[M + 2 * j] = o[j];                                  \
+    } }
+    HFFT_B8(0) HFFT_B8(1)
+#undef HFFT_B8
+  }
+}
+
+// Frequency held by LDS position pos after the forward stages (host side: order of the filter table)
+inline int64_t position_frequency(int L, int64_t pos) {
+  const int rl_bits = L & 3;
+  int64_t k = 0, weight = 1, span = (int64_t)1 << L;
+  if (rl_bits) {
+    span >>= rl_bits;
+    k += (pos / span) * weight;
+    pos %= span;
+    weight <<= rl_bits;
+  }
+  while (span > 1) {
+    span >>= 4;
+    k += (pos / span) * weight;
+    pos %= span;
+    weight <<= 4;
+  }
+  return k;
+}
+
+// L = log2 P in [7, 14].  A group of NT = P/16 threads owns a pair of features (persistent over pairs); a workgroup is
+// one group, or 64 / NT groups when NT < 64.
+//   Xt [p][n_pad] sample-contiguous input; Bt same shape: Im of the analytic signal minus its mean over the samples;
+//   At (optional): the input minus its mean; hperm [P]: filter table in LDS-position order (1/P folded in);
+//   u [4][n]: correction vectors (padding only); bmax / amax: running absmax of the outputs (float bits).
+template <int L> struct plan {
+  static constexpr int P = 1 << L, NT = P / 16, RL = 1 << (L & 3), N16 = L / 4;
+  static constexpr int G = NT >= 64 ? 1 : 64 / NT;     // pairs per workgroup
+  static constexpr int WG = NT * G;                    // threads per workgroup
+  static constexpr int NW = (NT + 63) / 64;            // waves per group
+  static constexpr int S0 = P / RL;                    // span entering the radix-16 stages
+  static constexpr int FIRST16 = (RL == 1) ? 1 : 0;    // radix-16 stages through LDS: FIRST16 .. N16 - 2, then the middle
+  static constexpr int NIN = N16 - 1 - FIRST16;        // twiddled LDS stages: 0, 1 or 2
+  static constexpr int SA = (S0 >> 4) >> (4 * FIRST16), SB = SA >> 4;   // their strides
+  static constexpr size_t lds = (size_t)G * phys(P) * 8 + 1536;
+};
+
+template <int NT> __device__ __forceinline__ double group_partial(double v) {   // sum over the group's lanes of this wave
+#pragma unroll
+  for (int o = (NT < 64 ? NT : 64) / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// keeps the optimiser from carrying values derived from x across iterations of the pair loop (it would hoist eight
+// 64-bit addresses per array, the float64 sample indices, negated copies of every factor, ... and spill them)
+template <typename T> __device__ __forceinline__ void fresh(T& x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void fresh(cf& x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void fresh(tw4& w) { fresh(w.w1); fresh(w.w2); fresh(w.w4); fresh(w.w8); }
+__device__ __forceinline__ float ld_nt(const float* base, unsigned byte_off) {
+  return __builtin_nontemporal_load(reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off));
+}
+__device__ __forceinline__ float ld(const float* base, unsigned byte_off) {
+  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ void st_nt(float v, float* base, unsigned byte_off) {
+  __builtin_nontemporal_store(v, reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off));
+}
+
+template <int L>
+__global__ __launch_bounds__(plan<L>::WG, HFFT_WAVES) void hilbert_fft_kernel(const float* __restrict__ Xt, int64_t n_pad,
+                                                                              int n, int64_t p, int padding,
+                                                                              const float* __restrict__ hperm,
+                                                                              const float* __restrict__ u,
+                                                                              float* __restrict__ Bt, float* __restrict__ At,
+                                                                              unsigned* __restrict__ bmax,
+                                                                              unsigned* __restrict__ amax) {
+  using PL = plan<L>;
+  constexpr int P = PL::P, NT = PL::NT, RL = PL::RL, G = PL::G, NW = PL::NW, NIN = PL::NIN, SA = PL::SA, SB = PL::SB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int t0 = tid & (NT - 1), sub = G > 1 ? tid / NT : 0;
+  cf* const data = reinterpret_cast<cf*>(smem) + (size_t)sub * phys(P);
+  double* const red1 = reinterpret_cast<double*>(smem + (size_t)G * phys(P) * 8);   // [16][4]  (NW > 1 only)
+  double* const red2 = red1 + 64;                                                    // [16][2]
+  float* const coef = reinterpret_cast<float*>(red2 + 32) + sub * 16;                // [2][6]: amp_pre amp_pos c0 c1 mean_y -
+  float* const edge = coef + 12;                                                     // y_a[0] y_a[n-1] y_b[0] y_b[n-1]
+
+  // per-thread factors, once
+  tw4 wout = make_tw4(t0, P);
+  tw4 wa = NIN >= 1 ? make_tw4(t0 & (SA - 1), 16 * SA) : tw4{};
+  tw4 wb = NIN >= 2 ? make_tw4(t0 & (SB - 1), 16 * SB) : tw4{};
+  const int cl = (n - 1) / NT, tl = (n - 1) % NT;   // owner of the last sample
+  const double tbar = 0.5 * (double)(n - 1);
+  const int64_t npairs = (p + 1) / 2;
+  const bool sums = padding || At;
+  const unsigned nb = (unsigned)n * 4u, npb = (unsigned)n_pad * 4u;
+
+  float run_mx = 0.f, run_my = 0.f;   // running absmax of this thread's outputs (one atomic per wave at the end)
+  float ya[8], yb[8];
+  auto load_pair = [&](int64_t pr, unsigned tb4) {
+    const int64_t fa = 2 * pr, fb = fa + 1;
+    const float* pa = Xt + fa * n_pad;
+    const float* pb = Xt + fb * n_pad;
+    const bool hb = fb < p;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const unsigned o = tb4 + (unsigned)(c * NT * 4);
+      ya[c] = (o < nb) ? ld_nt(pa, o) : 0.f;
+      yb[c] = (hb && o < nb) ? ld_nt(pb, o) : 0.f;
+    }
+  };
+#pragma unroll
+  for (int c = 0; c < 8; ++c) ya[c] = yb[c] = 0.f;
+  const int64_t stride = (int64_t)gridDim.x * G;
+  int64_t pair = (int64_t)blockIdx.x * G + sub;
+  if (pair < npairs) load_pair(pair, (unsigned)t0 * 4u);
+  for (int64_t lead = (int64_t)blockIdx.x * G; lead < npairs; lead += stride, pair += stride) {
+    int t = t0;
+    fresh(t);
+    fresh(wout);
+    if constexpr (NIN >= 1) fresh(wa);
+    if constexpr (NIN >= 2) fresh(wb);
+    const unsigned tb4 = (unsigned)t * 4u;
+    cf* const at_o = data + phys(t);                                                       // element t + c NT at at_o[phys(c NT)]
+    cf* const at_a = data + phys((t / (SA > 0 ? SA : 1)) * 16 * SA + (t & (SA - 1)));
+    cf* const at_b = data + phys((t / (SB > 0 ? SB : 1)) * 16 * SB + (t & (SB - 1)));
+    cf* const row = data + phys(16 * t);
+    const bool live = pair < npairs;
+    const int64_t fa = 2 * pair, fb = fa + 1;
+    const bool hb = live && fb < p;
+    // ---- linear fit and pad amplitudes (float64 sums over the group)
+    double sa = 0.0, ta = 0.0, sb = 0.0, tb = 0.0;
+    if (sums) {
+      double s1a = 0.0, s1b = 0.0;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {   // sample index t + c NT; zero samples beyond n add nothing
+        sa += (double)ya[c]; s1a += (double)c * (double)ya[c];
+        sb += (double)yb[c]; s1b += (double)c * (double)yb[c];
+      }
+      const double tc = (double)t - tbar;
+      ta = tc * sa + (double)NT * s1a;
+      tb = tc * sb + (double)NT * s1b;
+      sa = group_partial<NT>(sa); ta = group_partial<NT>(ta); sb = group_partial<NT>(sb); tb = group_partial<NT>(tb);
+      if constexpr (NW > 1)
+        if (lane == 0) { red1[wave * 4 + 0] = sa; red1[wave * 4 + 1] = ta; red1[wave * 4 + 2] = sb; red1[wave * 4 + 3] = tb; }
+      if (t == 0) { edge[0] = ya[0]; edge[2] = yb[0]; }
+      if (t == tl) {
+        float la = 0.f, lb = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) if (c == cl) { la = ya[c]; lb = yb[c]; }
+        edge[1] = la; edge[3] = lb;
+      }
+    }
+    // ---- outer forward stage in registers -> LDS
+    {
+      cf e[16];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) { e[c] = cf{ya[c], yb[c]}; e[c + 8] = cf{0.f, 0.f}; }
+      outer_stage<RL, 1>(e, wout);
+#pragma unroll
+      for (int c = 0; c < 16; ++c) at_o[phys(c * NT)] = e[c];
+    }
+    __syncthreads();
+    if (sums && (NW == 1 || wave == 0)) {
+      if constexpr (NW > 1) {
+        sa = ta = sb = tb = 0.0;
+        if (lane < NW) { sa = red1[lane * 4]; ta = red1[lane * 4 + 1]; sb = red1[lane * 4 + 2]; tb = red1[lane * 4 + 3]; }
+        sa = group_partial<64>(sa); ta = group_partial<64>(ta); sb = group_partial<64>(sb); tb = group_partial<64>(tb);
+      }
+      if (t < 2) {
+        const double sy = t ? sb : sa, sty = t ? tb : ta;
+        const double stt = (double)n * ((double)n * (double)n - 1.0) / 12.0;
+        const double c1 = (n > 1) ? sty / stt : 0.0;
+        const double c0 = sy / (double)n - c1 * tbar;       // fit(t) = c0 + c1 t  (numpy polyfit deg 1)
+        float* cfo = coef + t * 6;
+        cfo[0] = (float)((double)edge[2 * t] - c0);                                   // amp_pre
+        cfo[1] = (float)((double)edge[2 * t + 1] - (c0 + c1 * (double)(n - 1)));      // amp_pos
+        cfo[2] = (float)c0;
+        cfo[3] = (float)c1;
+        cfo[4] = (float)(sy / (double)n);
+      }
+    }
+    // ---- forward stages through LDS
+    if constexpr (NIN >= 1) { stage16<1, SA>(at_a, wa); __syncthreads(); }
+    if constexpr (NIN >= 2) { stage16<1, SB>(at_b, wb); __syncthreads(); }
+    // ---- middle: last forward stage, the filter, first inverse stage
+    {
+      cf v[16], w[16];
+#pragma unroll
+      for (int j = 0; j < 16; j += 2) {
+        const f4 q = *reinterpret_cast<const f4*>(row + j);
+        v[j] = cf{q.x, q.y}; v[j + 1] = cf{q.z, q.w};
+      }
+      dft16<1, false>(v);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f4 h = *reinterpret_cast<const f4*>(reinterpret_cast<const char*>(hperm) + (tb4 * 16u + 16u * g));
+        const cf z0 = v[slot16(4 * g)], z1 = v[slot16(4 * g + 1)], z2 = v[slot16(4 * g + 2)], z3 = v[slot16(4 * g + 3)];
+        w[4 * g] = cf{-h.x * z0.y, h.x * z0.x};      // * i h
+        w[4 * g + 1] = cf{-h.y * z1.y, h.y * z1.x};
+        w[4 * g + 2] = cf{-h.z * z2.y, h.z * z2.x};
+        w[4 * g + 3] = cf{-h.w * z3.y, h.w * z3.x};
+      }
+      dft16<-1, false>(w);
+#pragma unroll
+      for (int j = 0; j < 16; j += 2) {
+        const cf a = w[slot16(j)], b = w[slot16(j + 1)];
+        *reinterpret_cast<f4*>(row + j) = f4{a.x, a.y, b.x, b.y};
+      }
+    }
+    __syncthreads();
+    // the next pair's samples travel during the inverse stages (their registers are free until the next outer stage)
+    if (pair + stride < npairs) load_pair(pair + stride, tb4);
+    // ---- inverse stages through LDS
+    if constexpr (NIN >= 2) { stage16<-1, SB>(at_b, wb); __syncthreads(); }
+    if constexpr (NIN >= 1) { stage16<-1, SA>(at_a, wa); __syncthreads(); }
+    // ---- outer inverse stage LDS -> registers; corrections, centring, store
+    {
+      cf e[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) e[c] = at_o[phys(c * NT)];
+      outer_stage<RL, -1>(e, wout);
+      float a1a = 0.f, a2a = 0.f, a3a = 0.f, a4a = 0.f, a1b = 0.f, a2b = 0.f, a3b = 0.f, a4b = 0.f;
+      if (padding) {
+        a1a = coef[0]; a2a = coef[1]; a3a = coef[2]; a4a = coef[3];
+        a1b = coef[6]; a2b = coef[7]; a3b = coef[8]; a4b = coef[9];
+      }
+      float va[8], vb[8];
+      double ua = 0.0, ub = 0.0;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const unsigned o = tb4 + (unsigned)(c * NT * 4);
+        float xa = 0.f, xb = 0.f;
+        if (o < nb) {
+          xa = e[c].x; xb = e[c].y;
+          if (padding) {
+            const float u1 = ld(u, o), u2 = ld(u + n, o), u3 = ld(u + 2 * (int64_t)n, o), u4 = ld(u + 3 * (int64_t)n, o);
+            xa += a1a * u1 + a2a * u2 + a3a * u3 + a4a * u4;
+            xb += a1b * u1 + a2b * u2 + a3b * u3 + a4b * u4;
+          }
+          ua += (double)xa; ub += (double)xb;
+        }
+        va[c] = xa; vb[c] = xb;
+      }
+      ua = group_partial<NT>(ua); ub = group_partial<NT>(ub);
+      if constexpr (NW > 1) {
+        if (lane == 0) { red2[wave * 2] = ua; red2[wave * 2 + 1] = ub; }
+        __syncthreads();
+        ua = ub = 0.0;
+        if (lane < NW) { ua = red2[lane * 2]; ub = red2[lane * 2 + 1]; }
+        ua = group_partial<64>(ua); ub = group_partial<64>(ub);
+      }
+      const double m0 = ua / (double)n, m1 = ub / (double)n;
+      float mx = 0.f, my = 0.f;
+      float* oa = Bt + fa * n_pad;
+      float* ob = Bt + fb * n_pad;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const unsigned o = tb4 + (unsigned)(c * NT * 4);
+        if (o < npb) {
+          const float xa = (o < nb) ? (float)((double)va[c] - m0) : 0.f;
+          const float xb = (o < nb) ? (float)((double)vb[c] - m1) : 0.f;
+          if (live) { st_nt(xa, oa, o); mx = fmaxf(mx, fabsf(xa)); }
+          if (hb) { st_nt(xb, ob, o); mx = fmaxf(mx, fabsf(xb)); }
+        }
+      }
+      if (At) {   // the re-centred input (only asked for when the field was not centred before): second read of y
+        const double ma = (double)coef[4], mb = (double)coef[10];
+        const float* pa = Xt + fa * n_pad;
+        const float* pb = Xt + fb * n_pad;
+        float* qa = At + fa * n_pad;
+        float* qb = At + fb * n_pad;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const unsigned o = tb4 + (unsigned)(c * NT * 4);
+          if (o < npb) {
+            if (live) {
+              const float xa = (o < nb) ? (float)((double)ld(pa, o) - ma) : 0.f;
+              st_nt(xa, qa, o);
+              my = fmaxf(my, fabsf(xa));
+            }
+            if (hb) {
+              const float xb = (o < nb) ? (float)((double)ld(pb, o) - mb) : 0.f;
+              st_nt(xb, qb, o);
+              my = fmaxf(my, fabsf(xb));
+            }
+          }
+        }
+      }
+      run_mx = fmaxf(run_mx, mx);
+      run_my = fmaxf(run_my, my);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { run_mx = fmaxf(run_mx, __shfl_xor(run_mx, o)); run_my = fmaxf(run_my, __shfl_xor(run_my, o)); }
+  if (lane == 0) {
+    if (run_mx > 0.f) atomicMax(bmax, __float_as_uint(run_mx));
+    if (At && run_my > 0.f) atomicMax(amax, __float_as_uint(run_my));
+  }
+}
+
+}  // namespace hfft
