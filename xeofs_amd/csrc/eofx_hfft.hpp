@@ -26,11 +26,43 @@ namespace hfft {
 typedef float cf __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ cf cmul(cf a, cf b) { return cf{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
-__device__ __forceinline__ cf cmulc(cf a, cf b) { return cf{a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y}; }  // a conj(b)
+// Complex products and quarter turns as packed-f32 instructions with explicit operand selection: a product is two
+// instructions (the compiler's rendering of the same arithmetic is four or five: it forms both sign variants and
+// merges halves with moves), x +- i y folds the turn into the add.
+__device__ __forceinline__ cf cmul(cf a, cf b) {    // a b
+  cf r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "+v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ cf cmulc(cf a, cf b) {   // a conj(b)
+  cf r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "+v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ cf cmul_k(cf a, cf b) {    // a b, b uniform (scalar registers)
+  cf r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(r) : "v"(a), "s"(b));
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "+v"(r) : "v"(a), "s"(b));
+  return r;
+}
+__device__ __forceinline__ cf cmulc_k(cf a, cf b) {   // a conj(b), b uniform
+  cf r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "s"(b));
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "+v"(r) : "v"(a), "s"(b));
+  return r;
+}
 // DIR = +1: forward (factors exp(-i ...)), DIR = -1: inverse (their conjugates)
 template <int DIR> __device__ __forceinline__ cf twm(cf a, cf w) { return DIR > 0 ? cmul(a, w) : cmulc(a, w); }
 template <int DIR> __device__ __forceinline__ cf rot90(cf a) { return DIR > 0 ? cf{a.y, -a.x} : cf{-a.y, a.x}; }  // * (-+ i)
+// a + rot90<DIR>(t): forward (a.x + t.y, a.y - t.x), inverse (a.x - t.y, a.y + t.x)
+template <int DIR> __device__ __forceinline__ cf add_rot(cf a, cf t) {
+  cf r;
+  if constexpr (DIR > 0) asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(t));
+  else asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(t));
+  return r;
+}
 
 // a * w16^K, w16 = exp(-+ 2 pi i / 16)
 template <int DIR, int K> __device__ __forceinline__ cf mulw16(cf a) {
@@ -40,24 +72,22 @@ template <int DIR, int K> __device__ __forceinline__ cf mulw16(cf a) {
   else if constexpr (k == 4) return rot90<DIR>(a);
   else if constexpr (k == 8) return cf{-a.x, -a.y};
   else if constexpr (k == 12) return rot90<-DIR>(a);
-  else if constexpr (k == 2) return DIR > 0 ? cf{H * (a.x + a.y), H * (a.y - a.x)} : cf{H * (a.x - a.y), H * (a.x + a.y)};
-  else if constexpr (k == 6) return DIR > 0 ? cf{H * (a.y - a.x), -H * (a.x + a.y)} : cf{-H * (a.x + a.y), H * (a.x - a.y)};
-  else if constexpr (k == 10) return mulw16<DIR, 2>(cf{-a.x, -a.y});
-  else if constexpr (k == 14) return mulw16<DIR, 6>(cf{-a.x, -a.y});
   else {
-    constexpr float c = (k == 1 || k == 15) ? C1 : (k == 3 || k == 13) ? S1 : (k == 5 || k == 11) ? -S1 : -C1;  // cos(pi k / 8)
-    constexpr float s = (k == 1 || k == 7) ? S1 : (k == 3 || k == 5) ? C1 : (k == 9 || k == 15) ? -S1 : -C1;    // sin(pi k / 8)
-    return twm<DIR>(a, cf{c, -s});
+    constexpr float c = (k == 1 || k == 15) ? C1 : (k == 3 || k == 13) ? S1 : (k == 5 || k == 11) ? -S1 : (k == 7 || k == 9) ? -C1
+                        : (k == 2 || k == 14) ? H : -H;                                                   // cos(pi k / 8)
+    constexpr float sn = (k == 1 || k == 7) ? S1 : (k == 3 || k == 5) ? C1 : (k == 9 || k == 15) ? -S1 : (k == 11 || k == 13) ? -C1
+                         : (k == 2 || k == 6) ? H : -H;                                                   // sin(pi k / 8)
+    return DIR > 0 ? cmul_k(a, cf{c, -sn}) : cmulc_k(a, cf{c, -sn});
   }
 }
 
 template <int DIR> __device__ __forceinline__ void dft4(cf& a0, cf& a1, cf& a2, cf& a3) {
-  const cf s02 = a0 + a2, d02 = a0 - a2, s13 = a1 + a3, d13 = rot90<DIR>(a1 - a3);
-  a0 = s02 + s13; a1 = d02 + d13; a2 = s02 - s13; a3 = d02 - d13;
+  const cf s02 = a0 + a2, d02 = a0 - a2, s13 = a1 + a3, d13 = a1 - a3;
+  a0 = s02 + s13; a1 = add_rot<DIR>(d02, d13); a2 = s02 - s13; a3 = add_rot<-DIR>(d02, d13);
 }
 template <int DIR> __device__ __forceinline__ void dft4_lo(cf& a0, cf& a1, cf& a2, cf& a3) {   // a2 = a3 = 0 on entry
-  const cf x0 = a0, x1 = a1, r = rot90<DIR>(a1);
-  a0 = x0 + x1; a1 = x0 + r; a2 = x0 - x1; a3 = x0 - r;
+  const cf x0 = a0, x1 = a1;
+  a0 = x0 + x1; a1 = add_rot<DIR>(x0, x1); a2 = x0 - x1; a3 = add_rot<-DIR>(x0, x1);
 }
 
 // 16-point transform in registers, natural order in; result q sits in v[slot16(q)].  HALF: v[8..15] are zero on entry.
@@ -276,6 +306,37 @@ template <int L> struct plan {
   static constexpr size_t lds = (size_t)G * phys(P) * 8 + 1536;
 };
 
+// Several sums at once over a full wave: every exchange step also halves the number of values a lane carries, so
+// four sums cost 7 exchanges instead of 24.  reduce4: lanes of group g = lane >> 4 end with the total of value g
+// (a, b, c, d); reduce2: lanes 0-31 the total of a, lanes 32-63 the total of b.
+__device__ __forceinline__ double tail16(double k) {
+  k += __shfl_xor(k, 8); k += __shfl_xor(k, 4); k += __shfl_xor(k, 2); k += __shfl_xor(k, 1);
+  return k;
+}
+__device__ __forceinline__ double reduce4(double a, double b, double c, double d, int lane) {
+  const bool h32 = lane & 32, h16 = lane & 16;
+  double k0 = h32 ? c : a, k1 = h32 ? d : b;
+  k0 += __shfl_xor(h32 ? a : c, 32);
+  k1 += __shfl_xor(h32 ? b : d, 32);
+  double k = h16 ? k1 : k0;
+  k += __shfl_xor(h16 ? k0 : k1, 16);
+  return tail16(k);
+}
+__device__ __forceinline__ double reduce2(double a, double b, int lane) {
+  const bool h32 = lane & 32;
+  double k = h32 ? b : a;
+  k += __shfl_xor(h32 ? a : b, 32);
+  k += __shfl_xor(k, 16);
+  return tail16(k);
+}
+__device__ __forceinline__ double lane_value(double v, int src) {   // v of lane src (compile-time), uniform
+  union { double d; int i[2]; } x;
+  x.d = v;
+  x.i[0] = __builtin_amdgcn_readlane(x.i[0], src);
+  x.i[1] = __builtin_amdgcn_readlane(x.i[1], src);
+  return x.d;
+}
+
 template <int NT> __device__ __forceinline__ double group_partial(double v) {   // sum over the group's lanes of this wave
 #pragma unroll
   for (int o = (NT < 64 ? NT : 64) / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -287,15 +348,23 @@ template <int NT> __device__ __forceinline__ double group_partial(double v) {   
 template <typename T> __device__ __forceinline__ void fresh(T& x) { asm volatile("" : "+v"(x)); }
 __device__ __forceinline__ void fresh(cf& x) { asm volatile("" : "+v"(x)); }
 __device__ __forceinline__ void fresh(tw4& w) { fresh(w.w1); fresh(w.w2); fresh(w.w4); fresh(w.w8); }
-__device__ __forceinline__ float ld_nt(const float* base, unsigned byte_off) {
-  return __builtin_nontemporal_load(reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off));
+// Rows are addressed through buffer resources: a lane beyond the row's byte count reads 0 / stores nothing, so the
+// ragged ends (n is not a multiple of the group size, the odd last feature, idle groups) need no branches, and a
+// lane's address is one 32-bit offset shared by every row.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t row_rsrc(const float* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)bytes, 0x00020000);
 }
-__device__ __forceinline__ float ld(const float* base, unsigned byte_off) {
-  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+__device__ __forceinline__ float ld_nt(rsrc_t r, unsigned off, unsigned soff = 0) {   // streaming (nt) load
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, soff, 2));
 }
-__device__ __forceinline__ void st_nt(float v, float* base, unsigned byte_off) {
-  __builtin_nontemporal_store(v, reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off));
+__device__ __forceinline__ float ld(rsrc_t r, unsigned off, unsigned soff = 0) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, soff, 0));
 }
+__device__ __forceinline__ void st_nt(float v, rsrc_t r, unsigned off) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, 2);
+}
+__device__ __forceinline__ unsigned absbits(float x) { return __builtin_bit_cast(unsigned, x) & 0x7fffffffu; }
 
 template <int L>
 __global__ __launch_bounds__(plan<L>::WG, HFFT_WAVES) void hilbert_fft_kernel(const float* __restrict__ Xt, int64_t n_pad,
@@ -326,25 +395,24 @@ __global__ __launch_bounds__(plan<L>::WG, HFFT_WAVES) void hilbert_fft_kernel(co
   const bool sums = padding || At;
   const unsigned nb = (unsigned)n * 4u, npb = (unsigned)n_pad * 4u;
 
-  float run_mx = 0.f, run_my = 0.f;   // running absmax of this thread's outputs (one atomic per wave at the end)
+  unsigned run_mx = 0u, run_my = 0u;   // running absmax of this thread's outputs (one atomic per wave at the end)
   float ya[8], yb[8];
   auto load_pair = [&](int64_t pr, unsigned tb4) {
     const int64_t fa = 2 * pr, fb = fa + 1;
-    const float* pa = Xt + fa * n_pad;
-    const float* pb = Xt + fb * n_pad;
-    const bool hb = fb < p;
+    const rsrc_t ra = row_rsrc(Xt + fa * n_pad, pr < npairs ? nb : 0u);
+    const rsrc_t rb = row_rsrc(Xt + fb * n_pad, fb < p ? nb : 0u);
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const unsigned o = tb4 + (unsigned)(c * NT * 4);
-      ya[c] = (o < nb) ? ld_nt(pa, o) : 0.f;
-      yb[c] = (hb && o < nb) ? ld_nt(pb, o) : 0.f;
+      ya[c] = ld_nt(ra, o);
+      yb[c] = ld_nt(rb, o);
     }
   };
 #pragma unroll
   for (int c = 0; c < 8; ++c) ya[c] = yb[c] = 0.f;
   const int64_t stride = (int64_t)gridDim.x * G;
   int64_t pair = (int64_t)blockIdx.x * G + sub;
-  if (pair < npairs) load_pair(pair, (unsigned)t0 * 4u);
+  load_pair(pair, (unsigned)t0 * 4u);
   for (int64_t lead = (int64_t)blockIdx.x * G; lead < npairs; lead += stride, pair += stride) {
     int t = t0;
     fresh(t);
@@ -371,9 +439,12 @@ __global__ __launch_bounds__(plan<L>::WG, HFFT_WAVES) void hilbert_fft_kernel(co
       const double tc = (double)t - tbar;
       ta = tc * sa + (double)NT * s1a;
       tb = tc * sb + (double)NT * s1b;
-      sa = group_partial<NT>(sa); ta = group_partial<NT>(ta); sb = group_partial<NT>(sb); tb = group_partial<NT>(tb);
-      if constexpr (NW > 1)
-        if (lane == 0) { red1[wave * 4 + 0] = sa; red1[wave * 4 + 1] = ta; red1[wave * 4 + 2] = sb; red1[wave * 4 + 3] = tb; }
+      if constexpr (NW > 1) {
+        const double k = reduce4(sa, ta, sb, tb, lane);
+        if ((lane & 15) == 0) red1[wave * 4 + (lane >> 4)] = k;
+      } else {
+        sa = group_partial<NT>(sa); ta = group_partial<NT>(ta); sb = group_partial<NT>(sb); tb = group_partial<NT>(tb);
+      }
       if (t == 0) { edge[0] = ya[0]; edge[2] = yb[0]; }
       if (t == tl) {
         float la = 0.f, lb = 0.f;
@@ -393,19 +464,24 @@ __global__ __launch_bounds__(plan<L>::WG, HFFT_WAVES) void hilbert_fft_kernel(co
     }
     __syncthreads();
     if (sums && (NW == 1 || wave == 0)) {
-      if constexpr (NW > 1) {
-        sa = ta = sb = tb = 0.0;
-        if (lane < NW) { sa = red1[lane * 4]; ta = red1[lane * 4 + 1]; sb = red1[lane * 4 + 2]; tb = red1[lane * 4 + 3]; }
-        sa = group_partial<64>(sa); ta = group_partial<64>(ta); sb = group_partial<64>(sb); tb = group_partial<64>(tb);
+      int ft = t;              // feature of the pair this lane finishes (0 / 1), if any
+      bool fin = t < 2;
+      if constexpr (NW > 1) {   // lane l: value l >> 4 of wave l & 15
+        double k = ((lane & 15) < NW) ? red1[(lane & 15) * 4 + (lane >> 4)] : 0.0;
+        k = tail16(k);
+        const double o = __shfl_xor(k, 16);
+        sa = sb = k; ta = tb = o;      // lanes 0 / 32 hold (sum y, sum t y) of features a / b
+        ft = lane >> 5;
+        fin = (lane & 31) == 0;
       }
-      if (t < 2) {
-        const double sy = t ? sb : sa, sty = t ? tb : ta;
+      if (fin) {
+        const double sy = ft ? sb : sa, sty = ft ? tb : ta;
         const double stt = (double)n * ((double)n * (double)n - 1.0) / 12.0;
         const double c1 = (n > 1) ? sty / stt : 0.0;
         const double c0 = sy / (double)n - c1 * tbar;       // fit(t) = c0 + c1 t  (numpy polyfit deg 1)
-        float* cfo = coef + t * 6;
-        cfo[0] = (float)((double)edge[2 * t] - c0);                                   // amp_pre
-        cfo[1] = (float)((double)edge[2 * t + 1] - (c0 + c1 * (double)(n - 1)));      // amp_pos
+        float* cfo = coef + ft * 6;
+        cfo[0] = (float)((double)edge[2 * ft] - c0);                                   // amp_pre
+        cfo[1] = (float)((double)edge[2 * ft + 1] - (c0 + c1 * (double)(n - 1)));      // amp_pos
         cfo[2] = (float)c0;
         cfo[3] = (float)c1;
         cfo[4] = (float)(sy / (double)n);
@@ -441,7 +517,7 @@ __global__ __launch_bounds__(plan<L>::WG, HFFT_WAVES) void hilbert_fft_kernel(co
     }
     __syncthreads();
     // the next pair's samples travel during the inverse stages (their registers are free until the next outer stage)
-    if (pair + stride < npairs) load_pair(pair + stride, tb4);
+    load_pair(pair + stride, tb4);
     // ---- inverse stages through LDS
     if constexpr (NIN >= 2) { stage16<-1, SB>(at_b, wb); __syncthreads(); }
     if constexpr (NIN >= 1) { stage16<-1, SA>(at_a, wa); __syncthreads(); }
@@ -458,75 +534,67 @@ __global__ __launch_bounds__(plan<L>::WG, HFFT_WAVES) void hilbert_fft_kernel(co
       }
       float va[8], vb[8];
       double ua = 0.0, ub = 0.0;
+      const rsrc_t ru = row_rsrc(u, padding ? 4u * nb : 0u);
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         const unsigned o = tb4 + (unsigned)(c * NT * 4);
-        float xa = 0.f, xb = 0.f;
-        if (o < nb) {
-          xa = e[c].x; xb = e[c].y;
-          if (padding) {
-            const float u1 = ld(u, o), u2 = ld(u + n, o), u3 = ld(u + 2 * (int64_t)n, o), u4 = ld(u + 3 * (int64_t)n, o);
-            xa += a1a * u1 + a2a * u2 + a3a * u3 + a4a * u4;
-            xb += a1b * u1 + a2b * u2 + a3b * u3 + a4b * u4;
-          }
-          ua += (double)xa; ub += (double)xb;
+        float xa = e[c].x, xb = e[c].y;
+        if (padding) {
+          const float u1 = ld(ru, o), u2 = ld(ru, o, nb), u3 = ld(ru, o, 2u * nb), u4 = ld(ru, o, 3u * nb);
+          xa += a1a * u1 + a2a * u2 + a3a * u3 + a4a * u4;
+          xb += a1b * u1 + a2b * u2 + a3b * u3 + a4b * u4;
         }
+        xa = (o < nb) ? xa : 0.f;
+        xb = (o < nb) ? xb : 0.f;
+        ua += (double)xa; ub += (double)xb;
         va[c] = xa; vb[c] = xb;
       }
-      ua = group_partial<NT>(ua); ub = group_partial<NT>(ub);
       if constexpr (NW > 1) {
-        if (lane == 0) { red2[wave * 2] = ua; red2[wave * 2 + 1] = ub; }
+        const double k = reduce2(ua, ub, lane);
+        if ((lane & 31) == 0) red2[wave * 2 + (lane >> 5)] = k;
         __syncthreads();
-        ua = ub = 0.0;
-        if (lane < NW) { ua = red2[lane * 2]; ub = red2[lane * 2 + 1]; }
-        ua = group_partial<64>(ua); ub = group_partial<64>(ub);
+        double m = ((lane & 15) < NW) ? red2[(lane & 15) * 2 + ((lane >> 4) & 1)] : 0.0;   // value (l >> 4) & 1 of wave l & 15
+        m = tail16(m);
+        ua = lane_value(m, 0);
+        ub = lane_value(m, 16);
+      } else {
+        ua = group_partial<NT>(ua); ub = group_partial<NT>(ub);
       }
-      const double m0 = ua / (double)n, m1 = ub / (double)n;
-      float mx = 0.f, my = 0.f;
-      float* oa = Bt + fa * n_pad;
-      float* ob = Bt + fb * n_pad;
+      const float m0 = (float)(ua / (double)n), m1 = (float)(ub / (double)n);
+      const rsrc_t wa_ = row_rsrc(Bt + fa * n_pad, live ? npb : 0u);
+      const rsrc_t wb_ = row_rsrc(Bt + fb * n_pad, hb ? npb : 0u);
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         const unsigned o = tb4 + (unsigned)(c * NT * 4);
-        if (o < npb) {
-          const float xa = (o < nb) ? (float)((double)va[c] - m0) : 0.f;
-          const float xb = (o < nb) ? (float)((double)vb[c] - m1) : 0.f;
-          if (live) { st_nt(xa, oa, o); mx = fmaxf(mx, fabsf(xa)); }
-          if (hb) { st_nt(xb, ob, o); mx = fmaxf(mx, fabsf(xb)); }
-        }
+        const float xa = (o < nb) ? va[c] - m0 : 0.f;
+        const float xb = (o < nb) ? vb[c] - m1 : 0.f;
+        st_nt(xa, wa_, o);
+        st_nt(xb, wb_, o);
+        run_mx = max(run_mx, max(absbits(xa), absbits(xb)));   // (idle rows carry zeros)
       }
       if (At) {   // the re-centred input (only asked for when the field was not centred before): second read of y
-        const double ma = (double)coef[4], mb = (double)coef[10];
-        const float* pa = Xt + fa * n_pad;
-        const float* pb = Xt + fb * n_pad;
-        float* qa = At + fa * n_pad;
-        float* qb = At + fb * n_pad;
+        const float ma = coef[4], mb = coef[10];
+        const rsrc_t ra = row_rsrc(Xt + fa * n_pad, live ? nb : 0u);
+        const rsrc_t rb = row_rsrc(Xt + fb * n_pad, hb ? nb : 0u);
+        const rsrc_t qa = row_rsrc(At + fa * n_pad, live ? npb : 0u);
+        const rsrc_t qb = row_rsrc(At + fb * n_pad, hb ? npb : 0u);
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
           const unsigned o = tb4 + (unsigned)(c * NT * 4);
-          if (o < npb) {
-            if (live) {
-              const float xa = (o < nb) ? (float)((double)ld(pa, o) - ma) : 0.f;
-              st_nt(xa, qa, o);
-              my = fmaxf(my, fabsf(xa));
-            }
-            if (hb) {
-              const float xb = (o < nb) ? (float)((double)ld(pb, o) - mb) : 0.f;
-              st_nt(xb, qb, o);
-              my = fmaxf(my, fabsf(xb));
-            }
-          }
+          const float xa = (live && o < nb) ? ld(ra, o) - ma : 0.f;
+          const float xb = (hb && o < nb) ? ld(rb, o) - mb : 0.f;
+          st_nt(xa, qa, o);
+          st_nt(xb, qb, o);
+          run_my = max(run_my, max(absbits(xa), absbits(xb)));
         }
       }
-      run_mx = fmaxf(run_mx, mx);
-      run_my = fmaxf(run_my, my);
     }
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { run_mx = fmaxf(run_mx, __shfl_xor(run_mx, o)); run_my = fmaxf(run_my, __shfl_xor(run_my, o)); }
-  if (lane == 0) {
-    if (run_mx > 0.f) atomicMax(bmax, __float_as_uint(run_mx));
-    if (At && run_my > 0.f) atomicMax(amax, __float_as_uint(run_my));
+  for (int o = 32; o > 0; o >>= 1) { run_mx = max(run_mx, (unsigned)__shfl_xor((int)run_mx, o)); run_my = max(run_my, (unsigned)__shfl_xor((int)run_my, o)); }
+  if (lane == 0) {   // bit patterns of non-negative floats order like the floats
+    if (run_mx) atomicMax(bmax, run_mx);
+    if (At && run_my) atomicMax(amax, run_my);
   }
 }
 
