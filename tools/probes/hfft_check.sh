@@ -1,7 +1,7 @@
 #!/bin/bash
 # correctness sweep of the fused Hilbert kernel over all plan variants, then timing at config-5 size
 B=build/hfft_probe
-for n in 33 40 64 100 128 200 256 400 512 777 1000 1024 2000 2048 4000 4096 8000 8192; do
+for n in 33 100 240 512 513 777 1000 1024 2000 2048 4000 4096 8000 8192; do
   for pad in 1 0; do
     timeout 120 $B $n 1001 $pad 1 1 | tail -1 | sed "s/^/n=$n pad=$pad: /"
   done

@@ -48,7 +48,7 @@ template <int L> static void launch(const float* Xt, int64_t n_pad, int n, int64
   auto kern = hfft::hilbert_fft_kernel<L>;
   CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PL::lds));
   const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(163840 / PL::lds, 2048 / PL::WG));
-  const int64_t groups = ((p + 1) / 2 + PL::G - 1) / PL::G;
+  const int64_t groups = (p + 1) / 2;
   const int grid = (int)std::min<int64_t>(groups, (int64_t)cus * per_cu);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(PL::WG), PL::lds, 0, Xt, n_pad, n, p, padding, hperm, u, Bt, At, bmax, amax);
 }
@@ -59,8 +59,8 @@ int main(int argc, char** argv) {
   const int padding = argc > 3 ? atoi(argv[3]) : 1;
   const int want_real = argc > 4 ? atoi(argv[4]) : 0;
   const int reps = argc > 5 ? atoi(argv[5]) : 3;
-  const int64_t n_pad = (n + 63) / 64 * 64;
-  int L = 7;
+  const int64_t n_pad = (n + 511) / 512 * 512;   // the library's padding of the sample axis
+  int L = 10;
   while ((1 << L) < 2 * n) ++L;
   if (L > 14) { printf("n too large\n"); return 1; }
   const int P = 1 << L;
@@ -94,6 +94,8 @@ int main(int argc, char** argv) {
   if (want_real) CK(hipMalloc((void**)&dA, bytes));
   CK(hipMalloc((void**)&dh, P * 4)); CK(hipMalloc((void**)&du, 4 * n * 4)); CK(hipMalloc((void**)&dmax, 8));
   CK(hipMemset(dmax, 0, 8));
+  CK(hipMemset(dB, 0xFF, bytes));   // NaN everywhere: every element of the padded rows has to be written
+  if (dA) CK(hipMemset(dA, 0xFF, bytes));
   CK(hipMemcpy(dh, hperm.data(), P * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(du, hu.data(), 4 * n * 4, hipMemcpyHostToDevice));
   {
@@ -112,7 +114,7 @@ int main(int argc, char** argv) {
   auto run = [&]() {
     switch (L) {
 #define CASE(LL) case LL: launch<LL>(dX, n_pad, n, p, padding, dh, du, dB, dA, dmax, dmax + 1, cus); break;
-      CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14)
+      CASE(10) CASE(11) CASE(12) CASE(13) CASE(14)
 #undef CASE
     }
   };
@@ -151,7 +153,7 @@ int main(int argc, char** argv) {
     if (want_real) CK(hipMemcpy(gota.data(), dA + f * n_pad, n_pad * 4, hipMemcpyDeviceToHost));
     for (int i = 0; i < n_pad; ++i) {
       const double ref = i < n ? out[i] - mean : 0.0;
-      worst = std::max(worst, std::fabs(ref - (double)got[i]));
+      worst = std::max(worst, std::isfinite(got[i]) ? std::fabs(ref - (double)got[i]) : 1e30);
       scale = std::max(scale, std::fabs(ref));
       refmax = std::max(refmax, (float)std::fabs(ref));
       if (want_real) worst_a = std::max(worst_a, std::fabs((i < n ? (double)y[i] - sy / n : 0.0) - (double)gota[i]));

@@ -2184,10 +2184,11 @@ static void host_fft_f64(std::vector<std::complex<double>>& a) {
   }
 }
 
-// circular length of the convolution behind the Hilbert stage: power of two >= 2 n (>= 128); the one-kernel route
-// (eofx_hfft.hpp) holds it in LDS up to 2^14
+// circular length of the convolution behind the Hilbert stage: power of two >= 2 n, and >= 1024 so that half of it
+// covers the padded series length (n_pad = round_up(n, 512) <= P / 2: the one-kernel route writes samples [0, P / 2));
+// that route (eofx_hfft.hpp) holds the transform in LDS up to 2^14
 static int64_t hilbert_length(int64_t n, int* log2_out) {
-  int L = 7;
+  int L = 10;
   while (((int64_t)1 << L) < 2 * n) ++L;
   if (log2_out) *log2_out = L;
   return (int64_t)1 << L;
@@ -2195,10 +2196,10 @@ static int64_t hilbert_length(int64_t n, int* log2_out) {
 static const int HFFT_MAX_LOG2 = 14;
 
 // kernel spectrum and correction vectors for series length n (cached per context)
-static int get_hilbert_setup(eofx_ctx* ctx, int64_t n, int padding, double decay, int64_t P,
+static int get_hilbert_setup(eofx_ctx* ctx, int64_t n, int padding, double decay, int64_t P, bool fused,
                              const cfloat** chat_out, const float** hperm_out, const float** u_out) {
   for (auto& h : ctx->hsetups)
-    if (h.n == n && h.padding == padding && h.decay == decay && h.P == P) {
+    if (h.n == n && h.padding == padding && h.decay == decay && h.P == P && (fused ? h.hperm != nullptr : h.chat != nullptr)) {
       *chat_out = (const cfloat*)h.chat;
       *hperm_out = h.hperm;
       *u_out = h.u;
@@ -2210,7 +2211,7 @@ static int get_hilbert_setup(eofx_ctx* ctx, int64_t n, int padding, double decay
   hs.n = n; hs.P = P; hs.padding = padding; hs.decay = decay;
   int L = 0;
   while (((int64_t)1 << L) < P) ++L;
-  if (L <= HFFT_MAX_LOG2) {
+  if (fused) {
     // the kernel is real and odd, so its spectrum is i h[k] with h real: one float per frequency, stored in the order
     // the forward stages leave the spectrum in LDS; 1/P of the unnormalised inverse folded in
     std::vector<std::complex<double>> c((size_t)P, 0.0);
@@ -2282,7 +2283,7 @@ static hipError_t launch_hilbert_fused(eofx_ctx* ctx, const float* Xt, int64_t n
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PL::lds);
   if (e != hipSuccess) return e;
   const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>((int64_t)(163840 / PL::lds), 2048 / PL::WG));
-  const int64_t groups = ((p + 1) / 2 + PL::G - 1) / PL::G;
+  const int64_t groups = (p + 1) / 2;
   static int cu_count = 0;
   if (cu_count <= 0) {
     hipDeviceProp_t prop;
@@ -2304,12 +2305,12 @@ extern "C" int eofx_hilbert_f32(eofx_ctx* ctx, const eofx_mat* a, int padding, d
   const int64_t n = a->n, p = a->p, n_pad = a->n_pad, p_pad = a->p_pad;
   int L = 0;
   const int64_t P = hilbert_length(n, &L);  // circular length: power of two >= 2n
-  const bool fused = L <= HFFT_MAX_LOG2;    // the whole stage in one kernel (eofx_hfft.hpp); longer series: hipFFT route
+  const bool fused = L <= HFFT_MAX_LOG2 && n_pad <= P / 2;   // the whole stage in one kernel (eofx_hfft.hpp); longer series: hipFFT route
   const int64_t nh = P / 2 + 1, ldw = P + 2;
   const cfloat* chat = nullptr;
   const float* hperm = nullptr;
   const float* u = nullptr;
-  CHK(get_hilbert_setup(ctx, n, padding ? 1 : 0, padding ? decay_factor : 0.0, P, &chat, &hperm, &u));
+  CHK(get_hilbert_setup(ctx, n, padding ? 1 : 0, padding ? decay_factor : 0.0, P, fused, &chat, &hperm, &u));
   CHK(ensure_Xt(ctx, a));
   // features per FFT batch: real series + half spectrum of about 3 GB together
   int64_t Fc = std::max<int64_t>(1, std::min<int64_t>(p, (int64_t)(3.0e9 / (4.0 * (double)ldw + 8.0 * (double)nh))));
@@ -2331,7 +2332,7 @@ extern "C" int eofx_hilbert_f32(eofx_ctx* ctx, const eofx_mat* a, int padding, d
     switch (L) {
 #define EOFX_HF(LL) \
   case LL: e = launch_hilbert_fused<LL>(ctx, a->Xt, n_pad, n, p, padding ? 1 : 0, hperm, u, mi->Xt, At, mi->absmax_dev, amax); break;
-      EOFX_HF(7) EOFX_HF(8) EOFX_HF(9) EOFX_HF(10) EOFX_HF(11) EOFX_HF(12) EOFX_HF(13) EOFX_HF(14)
+      EOFX_HF(10) EOFX_HF(11) EOFX_HF(12) EOFX_HF(13) EOFX_HF(14)
 #undef EOFX_HF
       default: e = hipErrorInvalidValue;
     }

@@ -128,12 +128,6 @@ __device__ __forceinline__ cf unit(double num, double den) {   // exp(-2 pi i nu
   return cf{(float)c, (float)s};
 }
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
-
 // stored powers w^1 w^2 w^4 w^8 of a butterfly's base factor (each rounded from float64); w^3 = w^1 w^2 and
 // w^12 = w^4 w^8 are formed per stage, and w^q = w^(4a) w^b -- at most three float32 roundings away from exact
 struct tw4 {
@@ -289,21 +283,21 @@ inline int64_t position_frequency(int L, int64_t pos) {
   return k;
 }
 
-// L = log2 P in [7, 14].  A group of NT = P/16 threads owns a pair of features (persistent over pairs); a workgroup is
-// one group, or 64 / NT groups when NT < 64.
+// L = log2 P in [10, 14].  One workgroup of NT = P/16 threads owns a pair of features (persistent over pairs).
 //   Xt [p][n_pad] sample-contiguous input; Bt same shape: Im of the analytic signal minus its mean over the samples;
+//   the kernel writes samples [0, P/2) of a row, so it needs n_pad <= P/2 (true for n_pad = round_up(n, 512), P >= 1024);
 //   At (optional): the input minus its mean; hperm [P]: filter table in LDS-position order (1/P folded in);
 //   u [4][n]: correction vectors (padding only); bmax / amax: running absmax of the outputs (float bits).
 template <int L> struct plan {
+  static_assert(L >= 10 && L <= 14, "circular length 2^10 .. 2^14");
   static constexpr int P = 1 << L, NT = P / 16, RL = 1 << (L & 3), N16 = L / 4;
-  static constexpr int G = NT >= 64 ? 1 : 64 / NT;     // pairs per workgroup
-  static constexpr int WG = NT * G;                    // threads per workgroup
-  static constexpr int NW = (NT + 63) / 64;            // waves per group
+  static constexpr int WG = NT;                        // threads per workgroup
+  static constexpr int NW = NT / 64;                   // waves per workgroup
   static constexpr int S0 = P / RL;                    // span entering the radix-16 stages
   static constexpr int FIRST16 = (RL == 1) ? 1 : 0;    // radix-16 stages through LDS: FIRST16 .. N16 - 2, then the middle
-  static constexpr int NIN = N16 - 1 - FIRST16;        // twiddled LDS stages: 0, 1 or 2
+  static constexpr int NIN = N16 - 1 - FIRST16;        // twiddled LDS stages: 1 or 2
   static constexpr int SA = (S0 >> 4) >> (4 * FIRST16), SB = SA >> 4;   // their strides
-  static constexpr size_t lds = (size_t)G * phys(P) * 8 + 1536;
+  static constexpr size_t lds = (size_t)phys(P) * 8 + 1536;
 };
 
 // Several sums at once over a full wave: every exchange step also halves the number of values a lane carries, so
@@ -337,9 +331,9 @@ __device__ __forceinline__ double lane_value(double v, int src) {   // v of lane
   return x.d;
 }
 
-template <int NT> __device__ __forceinline__ double group_partial(double v) {   // sum over the group's lanes of this wave
+__device__ __forceinline__ double wave_total(double v) {   // every lane ends with the sum over the wave
 #pragma unroll
-  for (int o = (NT < 64 ? NT : 64) / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
 
@@ -375,14 +369,14 @@ __global__ __launch_bounds__(plan<L>::WG, HFFT_WAVES) void hilbert_fft_kernel(co
                                                                               unsigned* __restrict__ bmax,
                                                                               unsigned* __restrict__ amax) {
   using PL = plan<L>;
-  constexpr int P = PL::P, NT = PL::NT, RL = PL::RL, G = PL::G, NW = PL::NW, NIN = PL::NIN, SA = PL::SA, SB = PL::SB;
+  constexpr int P = PL::P, NT = PL::NT, RL = PL::RL, NW = PL::NW, NIN = PL::NIN, SA = PL::SA, SB = PL::SB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int t0 = tid & (NT - 1), sub = G > 1 ? tid / NT : 0;
-  cf* const data = reinterpret_cast<cf*>(smem) + (size_t)sub * phys(P);
-  double* const red1 = reinterpret_cast<double*>(smem + (size_t)G * phys(P) * 8);   // [16][4]  (NW > 1 only)
+  const int t0 = tid;
+  cf* const data = reinterpret_cast<cf*>(smem);
+  double* const red1 = reinterpret_cast<double*>(smem + (size_t)phys(P) * 8);   // [16][4]  (NW > 1 only)
   double* const red2 = red1 + 64;                                                    // [16][2]
-  float* const coef = reinterpret_cast<float*>(red2 + 32) + sub * 16;                // [2][6]: amp_pre amp_pos c0 c1 mean_y -
+  float* const coef = reinterpret_cast<float*>(red2 + 32);                           // [2][6]: amp_pre amp_pos c0 c1 mean_y -
   float* const edge = coef + 12;                                                     // y_a[0] y_a[n-1] y_b[0] y_b[n-1]
 
   // per-thread factors, once
@@ -410,10 +404,10 @@ __global__ __launch_bounds__(plan<L>::WG, HFFT_WAVES) void hilbert_fft_kernel(co
   };
 #pragma unroll
   for (int c = 0; c < 8; ++c) ya[c] = yb[c] = 0.f;
-  const int64_t stride = (int64_t)gridDim.x * G;
-  int64_t pair = (int64_t)blockIdx.x * G + sub;
+  const int64_t stride = gridDim.x;
+  int64_t pair = blockIdx.x;
   load_pair(pair, (unsigned)t0 * 4u);
-  for (int64_t lead = (int64_t)blockIdx.x * G; lead < npairs; lead += stride, pair += stride) {
+  for (; pair < npairs; pair += stride) {
     int t = t0;
     fresh(t);
     fresh(wout);
@@ -421,12 +415,11 @@ __global__ __launch_bounds__(plan<L>::WG, HFFT_WAVES) void hilbert_fft_kernel(co
     if constexpr (NIN >= 2) fresh(wb);
     const unsigned tb4 = (unsigned)t * 4u;
     cf* const at_o = data + phys(t);                                                       // element t + c NT at at_o[phys(c NT)]
-    cf* const at_a = data + phys((t / (SA > 0 ? SA : 1)) * 16 * SA + (t & (SA - 1)));
-    cf* const at_b = data + phys((t / (SB > 0 ? SB : 1)) * 16 * SB + (t & (SB - 1)));
+    cf* const at_a = data + phys((t / SA) * 16 * SA + (t & (SA - 1)));
+    cf* const at_b = data + phys((t / SB) * 16 * SB + (t & (SB - 1)));
     cf* const row = data + phys(16 * t);
-    const bool live = pair < npairs;
     const int64_t fa = 2 * pair, fb = fa + 1;
-    const bool hb = live && fb < p;
+    const bool hb = fb < p;
     // ---- linear fit and pad amplitudes (float64 sums over the group)
     double sa = 0.0, ta = 0.0, sb = 0.0, tb = 0.0;
     if (sums) {
@@ -443,7 +436,7 @@ __global__ __launch_bounds__(plan<L>::WG, HFFT_WAVES) void hilbert_fft_kernel(co
         const double k = reduce4(sa, ta, sb, tb, lane);
         if ((lane & 15) == 0) red1[wave * 4 + (lane >> 4)] = k;
       } else {
-        sa = group_partial<NT>(sa); ta = group_partial<NT>(ta); sb = group_partial<NT>(sb); tb = group_partial<NT>(tb);
+        sa = wave_total(sa); ta = wave_total(ta); sb = wave_total(sb); tb = wave_total(tb);
       }
       if (t == 0) { edge[0] = ya[0]; edge[2] = yb[0]; }
       if (t == tl) {
@@ -558,10 +551,10 @@ __global__ __launch_bounds__(plan<L>::WG, HFFT_WAVES) void hilbert_fft_kernel(co
         ua = lane_value(m, 0);
         ub = lane_value(m, 16);
       } else {
-        ua = group_partial<NT>(ua); ub = group_partial<NT>(ub);
+        ua = wave_total(ua); ub = wave_total(ub);
       }
       const float m0 = (float)(ua / (double)n), m1 = (float)(ub / (double)n);
-      const rsrc_t wa_ = row_rsrc(Bt + fa * n_pad, live ? npb : 0u);
+      const rsrc_t wa_ = row_rsrc(Bt + fa * n_pad, npb);
       const rsrc_t wb_ = row_rsrc(Bt + fb * n_pad, hb ? npb : 0u);
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
@@ -574,14 +567,14 @@ __global__ __launch_bounds__(plan<L>::WG, HFFT_WAVES) void hilbert_fft_kernel(co
       }
       if (At) {   // the re-centred input (only asked for when the field was not centred before): second read of y
         const float ma = coef[4], mb = coef[10];
-        const rsrc_t ra = row_rsrc(Xt + fa * n_pad, live ? nb : 0u);
+        const rsrc_t ra = row_rsrc(Xt + fa * n_pad, nb);
         const rsrc_t rb = row_rsrc(Xt + fb * n_pad, hb ? nb : 0u);
-        const rsrc_t qa = row_rsrc(At + fa * n_pad, live ? npb : 0u);
+        const rsrc_t qa = row_rsrc(At + fa * n_pad, npb);
         const rsrc_t qb = row_rsrc(At + fb * n_pad, hb ? npb : 0u);
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
           const unsigned o = tb4 + (unsigned)(c * NT * 4);
-          const float xa = (live && o < nb) ? ld(ra, o) - ma : 0.f;
+          const float xa = (o < nb) ? ld(ra, o) - ma : 0.f;
           const float xb = (hb && o < nb) ? ld(rb, o) - mb : 0.f;
           st_nt(xa, qa, o);
           st_nt(xb, qb, o);
