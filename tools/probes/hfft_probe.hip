@@ -97,7 +97,11 @@ int main(int argc, char** argv) {
   CK(hipMemset(dB, 0xFF, bytes));   // NaN everywhere: every element of the padded rows has to be written
   if (dA) CK(hipMemset(dA, 0xFF, bytes));
   CK(hipMemcpy(dh, hperm.data(), P * 4, hipMemcpyHostToDevice));
-  CK(hipMemcpy(du, hu.data(), 4 * n * 4, hipMemcpyHostToDevice));
+  {
+    std::vector<float> il((size_t)4 * n);   // the kernel reads the four vectors interleaved per sample
+    for (int i = 0; i < n; ++i) for (int k = 0; k < 4; ++k) il[(size_t)4 * i + k] = hu[(size_t)k * n + i];
+    CK(hipMemcpy(du, il.data(), 4 * n * 4, hipMemcpyHostToDevice));
+  }
   {
     std::vector<float> chunk;
     const int64_t per = std::min<int64_t>(p, 4096);

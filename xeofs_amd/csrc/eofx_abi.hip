@@ -51,7 +51,7 @@ struct eofx_ctx {
     double decay = 0.0;
     void* chat = nullptr;  // device cfloat[P/2+1]   (hipFFT route, P > 16384)
     float* hperm = nullptr;  // device float[P]: filter table of the one-kernel route, in its LDS order (P <= 16384)
-    float* u = nullptr;    // device float[4 n]
+    float* u = nullptr;    // device float[4 n]: [4][n] (hipFFT route) or [n][4] (one-kernel route)
   };
   std::vector<HilbertSetup> hsetups;
   // cached hipFFT plans of the Hilbert stage: key = (P, batch) -> (R2C plan, C2R plan)
@@ -2255,7 +2255,11 @@ static int get_hilbert_setup(eofx_ctx* ctx, int64_t n, int padding, double decay
           a3 += kp + kq;
           a4 += kp * (double)(sidx - n) + kq * (double)(sidx + n);
         }
-        hu[t] = (float)a1; hu[n + t] = (float)a2; hu[2 * n + t] = (float)a3; hu[3 * n + t] = (float)a4;
+        if (fused) {   // the one-kernel route reads the four vectors interleaved per sample
+          hu[4 * t] = (float)a1; hu[4 * t + 1] = (float)a2; hu[4 * t + 2] = (float)a3; hu[4 * t + 3] = (float)a4;
+        } else {
+          hu[t] = (float)a1; hu[n + t] = (float)a2; hu[2 * n + t] = (float)a3; hu[3 * n + t] = (float)a4;
+        }
       }
     };
     const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(16, n / 256));

@@ -287,7 +287,8 @@ inline int64_t position_frequency(int L, int64_t pos) {
 //   Xt [p][n_pad] sample-contiguous input; Bt same shape: Im of the analytic signal minus its mean over the samples;
 //   the kernel writes samples [0, P/2) of a row, so it needs n_pad <= P/2 (true for n_pad = round_up(n, 512), P >= 1024);
 //   At (optional): the input minus its mean; hperm [P]: filter table in LDS-position order (1/P folded in);
-//   u [4][n]: correction vectors (padding only); bmax / amax: running absmax of the outputs (float bits).
+//   u [n][4]: the four correction vectors, interleaved per sample (padding only); bmax / amax: running absmax of the
+//   outputs (float bits).
 template <int L> struct plan {
   static_assert(L >= 10 && L <= 14, "circular length 2^10 .. 2^14");
   static constexpr int P = 1 << L, NT = P / 16, RL = 1 << (L & 3), N16 = L / 4;
@@ -527,15 +528,15 @@ __global__ __launch_bounds__(plan<L>::WG, HFFT_WAVES) void hilbert_fft_kernel(co
       }
       float va[8], vb[8];
       double ua = 0.0, ub = 0.0;
-      const rsrc_t ru = row_rsrc(u, padding ? 4u * nb : 0u);
+      const rsrc_t ru = row_rsrc(u, padding ? 4u * nb : 0u);   // [n][4]: 16 bytes per sample
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         const unsigned o = tb4 + (unsigned)(c * NT * 4);
         float xa = e[c].x, xb = e[c].y;
         if (padding) {
-          const float u1 = ld(ru, o), u2 = ld(ru, o, nb), u3 = ld(ru, o, 2u * nb), u4 = ld(ru, o, 3u * nb);
-          xa += a1a * u1 + a2a * u2 + a3a * u3 + a4a * u4;
-          xb += a1b * u1 + a2b * u2 + a3b * u3 + a4b * u4;
+          const f4 uu = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(ru, 4u * o, 0, 0));
+          xa += a1a * uu.x + a2a * uu.y + a3a * uu.z + a4a * uu.w;
+          xb += a1b * uu.x + a2b * uu.y + a3b * uu.z + a4b * uu.w;
         }
         xa = (o < nb) ? xa : 0.f;
         xb = (o < nb) ? xb : 0.f;
