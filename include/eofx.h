@@ -277,6 +277,14 @@ int eofx_vec_dot_f64(eofx_ctx *ctx, const float *a, const float *b, int64_t coun
 int eofx_rsvd_c64(eofx_ctx *ctx, const eofx_mat *A, const eofx_mat *B, int k, int n_oversamples, int n_iter,
                   const float *omega, int flip_signs, float *U, float *s, float *V);
 
+/* One pass of the complex operator Z = A + iB on a [Re | Im] panel of L = 64 or 128 real columns (device pointers):
+ *   conj_left = 1: out [p_pad x L] = Z^H W, W [n_pad x L];   conj_left = 0: out [n_pad x L] = Z Y, Y [p_pad x L].
+ * One launch of the streaming kernel over both parts in the default precision (the step a feature-sharded driver
+ * all-reduces around; the reference's svds(lobpcg) call at xeofs/linalg/decomposer.py:149-160 has no counterpart --
+ * it never exposes its matvec).  final_pass selects the context's final-pass precision.                          */
+int eofx_cmat_mul_f32(eofx_ctx *ctx, const eofx_mat *A, const eofx_mat *B, int conj_left, const float *P_in, int L,
+                      int final_pass, float *P_out);
+
 /* Complex panels are real panels [Re | Im] (Re in columns [0, L/2), Im in [L/2, L)).
  * With P1 = op(A) W and P2 = op(B) W for a complex matrix Z = A + iB (A, B real resident):
  *   conj_left = 1:  out = Z^H W :  out.re = P1.re + P2.im, out.im = P1.im - P2.re

@@ -71,6 +71,7 @@ SIGNATURES = {
     "eofx_mat_gram_f32": (_int, [_vp, _vp, _int, _vp]),
     "eofx_mat_cross_gram_f32": (_int, [_vp, _vp, _vp, _int, _vp]),
     "eofx_vec_dot_f64": (_int, [_vp, _vp, _vp, _i64, _pd]),
+    "eofx_cmat_mul_f32": (_int, [_vp, _vp, _vp, _int, _vp, _int, _int, _vp]),
     "eofx_cpanel_combine_f32": (_int, [_vp, _vp, _vp, _int, _i64, _int, _vp]),
     "eofx_panel_colargminmax_f32": (_int, [_vp, _vp, _i64, _int, _vp, _vp]),
     "eofx_panel_row_normalize_f32": (_int, [_vp, _vp, _i64, _int, _vp]),

@@ -2,9 +2,9 @@
 matrices -- the complex branch of the decomposer (xeofs/linalg/decomposer.py:149-160, which the
 reference hands to scipy's svds(lobpcg)).
 
-Every pass over the data is two launches of the same real kernel that serves the real path
-(one over A, one over B) on a 64-wide real panel holding [Re | Im] of a complex panel of up to
-32 columns, followed by a tiny complex recombination kernel.  Orthonormalisation is a complex
+Every pass over the data is one launch of the streaming kernel in its two-matrix form
+(`eofx_cmat_mul_f32`; other precisions than the default: one launch per part + a recombination
+kernel) on a 64-wide real panel holding [Re | Im] of a complex panel of up to 32 columns.  Orthonormalisation is a complex
 Cholesky-free QR from the Hermitian Gram matrix (one 64x64 float64 Gram of the real panel gives
 all four blocks); the l x l Hermitian eigen-problems are solved on the host in float64.
 
@@ -60,12 +60,16 @@ class ComplexOps:
 
     def zh_mul(self, Wn, final=False):      # feature-side panel = Z^H W   (local)
         pr = self.ctx.precision[1 if final else 0]
+        if pr == "f16x3":                   # one launch over both parts
+            return engine.cmat_mul(self.ctx, self.A, self.B, Wn, True, final)
         P1 = engine.panel_tmul(self.ctx, self.A, Wn, prec=pr)
         P2 = engine.panel_tmul(self.ctx, self.B, Wn, prec=pr)
         return engine.cpanel_combine(self.ctx, P1, P2, True, out=P1)
 
     def z_mul(self, Yp, final=False):       # sample-side panel = Z Y     (partial sum over features)
         pr = self.ctx.precision[1 if final else 0]
+        if pr == "f16x3":
+            return engine.cmat_mul(self.ctx, self.A, self.B, Yp, False, final)
         P1 = engine.panel_mul(self.ctx, self.A, Yp, prec=pr)
         P2 = engine.panel_mul(self.ctx, self.B, Yp, prec=pr)
         return engine.cpanel_combine(self.ctx, P1, P2, False, out=P1)
@@ -194,10 +198,19 @@ def complex_rsvd(ctx, A, B, k: int, n_oversamples: int = 10, n_iter="auto", rand
     sg = np.concatenate([sign, np.ones(HALF - k), sign, np.ones(HALF - k)])
 
     def export(P, rows):
-        full = ops.export(P, rows, sg)
-        out = np.empty((rows, k), dtype=np.complex64)      # no complex128 temporaries on 1M-row panels
-        out.real = full[:, :k]
-        out.imag = full[:, HALF:HALF + k]
+        """signed [Re | Im] columns -> interleaved complex64 on the device -> one copy into a page-locked host array
+        (the 64-wide panel of a 1M-row factor is 265 MB; its k complex columns are 166 MB at k = 20)"""
+        torch = engine._torch()
+        if not torch.is_tensor(P) or rows == 0:
+            full = ops.export(P, rows, sg)
+            out = np.empty((rows, k), dtype=np.complex64)
+            out.real = full[:, :k]
+            out.imag = full[:, HALF:HALF + k]
+            return out
+        sgt = torch.as_tensor(sign, dtype=torch.float32, device=P.device)
+        z = torch.stack((P[:rows, :k] * sgt, P[:rows, HALF:HALF + k] * sgt), dim=-1)     # [rows, k, 2]
+        out = engine._host_out((rows, k), np.complex64)
+        torch.from_numpy(out.view(np.float32).reshape(rows, k, 2)).copy_(z)
         return out
 
     return export(Up, n), s.astype(np.float32), export(Vp, p_loc)

@@ -2595,6 +2595,32 @@ struct CplxOps {
   }
 };
 
+// One pass of the complex operator on a [Re | Im] panel (the step the feature-sharded driver all-reduces around):
+// conj_left = 1: out [p_pad x L] = Z^H W for W [n_pad x L]; conj_left = 0: out [n_pad x L] = Z Y for Y [p_pad x L].
+// In the default precision this is ONE launch of the streaming kernel over both parts (as inside eofx_rsvd_c64).
+extern "C" int eofx_cmat_mul_f32(eofx_ctx* ctx, const eofx_mat* A, const eofx_mat* B, int conj_left, const float* Pin, int L,
+                                 int final_pass, float* Pout) {
+  if (!ctx || !A || !B || !Pin || !Pout) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  if (A->n != B->n || A->p != B->p) return set_err(ctx, EOFX_ERR_SHAPE, "real and imaginary parts must have the same shape");
+  if (L != 64 && L != 128) return set_err(ctx, EOFX_ERR_ARG, "complex panels are 64 or 128 real columns wide");
+  CHK(set_device(ctx));
+  CHK(ensure_X(ctx, A));
+  CHK(ensure_X(ctx, B));
+  const int prec = final_pass ? ctx->prec_final : ctx->prec_power;
+  const int64_t big = std::max(A->n_pad, A->p_pad);
+  size_t need = (size_t)2 * big * L * 4 + (8 << 20);
+  need += (size_t)2 * big * L * 4;   // the two partial results of a two-matrix launch that needs no split
+  need += 2 * atb_scratch_bytes(A->p_pad, round_up(A->n, ATB_KG), L) + 2 * atb_scratch_bytes(A->n_pad, round_up(A->p, ATB_KG), L);
+  CHK(arena_reserve(ctx, need));
+  ArenaScope scope(ctx);
+  ARENA(float, rot, (size_t)big * L);
+  ARENA(float, tmp, (size_t)big * L);
+  CplxOps ops{ctx, A, B, L, rot, tmp, std::max(A->absmax, B->absmax)};
+  CHK(conj_left ? ops.zh_mul(Pin, Pout, prec) : ops.z_mul(Pin, Pout, prec));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return EOFX_OK;
+}
+
 // U [n x k] and V [p x k] are complex64, row-major, interleaved (re, im); s [k] float32; all host|device.
 // omega: [min(n, p) x (k + n_oversamples)] REAL Gaussian start (host), as the reference's random_state would draw.
 extern "C" int eofx_rsvd_c64(eofx_ctx* ctx, const eofx_mat* A, const eofx_mat* B, int k, int n_oversamples, int n_iter,

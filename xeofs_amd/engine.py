@@ -505,6 +505,15 @@ def hilbert(ctx: Context, mat: ResidentMatrix, padding="exp", decay_factor: floa
     return ResidentMatrix(ctx, hi), (ResidentMatrix(ctx, hr) if want_real else None)
 
 
+def cmat_mul(ctx: Context, A: ResidentMatrix, B: ResidentMatrix, P, conj_left: bool, final: bool = False):
+    """one pass of Z = A + iB over a [Re | Im] panel: Z^H P (conj_left, P on the sample side) or Z P -- one launch"""
+    torch = _torch()
+    out = torch.empty((A.p_pad if conj_left else A.n_pad, P.shape[1]), dtype=torch.float32, device=P.device)
+    raise_for(ctx.lib.eofx_cmat_mul_f32(ctx.handle, A.handle, B.handle, int(conj_left), ptr(P), P.shape[1], int(final),
+                                        ptr(out)), ctx.handle)
+    return out
+
+
 def cpanel_combine(ctx: Context, P1, P2, conj_left: bool, out=None):
     torch = _torch()
     if out is None:
