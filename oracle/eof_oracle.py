@@ -738,6 +738,25 @@ def pearson_patterns(data, scores):
     return corr, 2 * st.beta(a, a, loc=-1, scale=2).cdf(-np.abs(corr))
 
 
+def holm_sidak(p):
+    """What `correction=<any valid name>` does in the reference (utils/optional/statistics.py:108-157): every mode's
+    p-values go to statsmodels.stats.multitest.multipletests with that function's DEFAULTS (the wrapper forwards neither
+    `method` nor `alpha`), i.e. Holm-Sidak step-down.  statsmodels (0.14; absent from both images, so this function is
+    a restatement of its published algorithm and its parity is unpinned): sort; 1 - (1 - p_(i))^(m - i); running
+    maximum; clip at 1; unsort.  Plain loops on purpose -- the product code is vectorised."""
+    p = np.asarray(p, dtype=np.float64)
+    out = np.empty_like(p)
+    m = p.shape[0]
+    for j in range(p.shape[1]):
+        order = np.argsort(p[:, j], kind="stable")
+        run = 0.0
+        for rank, i in enumerate(order):
+            raw = 1.0 - (1.0 - p[i, j]) ** (m - rank)
+            run = max(run, raw)
+            out[i, j] = min(run, 1.0)
+    return out
+
+
 def cpcca_patterns(m, kind="homogeneous"):
     """cpcca.py:642-845: data are taken back through whitener and PCA (i.e. the PCA-truncated fields)."""
     fields = []

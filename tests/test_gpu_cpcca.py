@@ -117,8 +117,17 @@ def test_correlation_patterns_vs_oracle(ctx, alpha, use_pca, kind):
     assert np.abs(P1).max() <= 1 + 1e-4
     big = q1 > 1e-6      # p-values: compared where they are not astronomically small
     assert np.allclose(v1.values.reshape(3, -1).T[big], q1[big], rtol=5e-2, atol=1e-6)
-    with pytest.raises(NotImplementedError):
-        m.homogeneous_patterns(correction="fdr_bh")
+    # `correction=`: the reference validates the name and then calls statsmodels' multipletests with ITS defaults
+    # (utils/optional/statistics.py:150-157 forwards neither method nor alpha): Holm-Sidak step-down per mode
+    (_, _), (c1, c2) = getattr(m, f"{kind}_patterns")(correction="fdr_bh")
+    raw, adj = v1.values.reshape(3, -1).T.astype(np.float64), c1.values.reshape(3, -1).T.astype(np.float64)
+    assert np.allclose(adj, orc.holm_sidak(raw), rtol=1e-5, atol=1e-12)
+    assert np.all(adj >= raw * (1 - 1e-6)) and np.all(adj <= 1.0)
+    for j in range(3):        # step-down: adjusted values are monotone in the raw ones
+        o = np.argsort(raw[:, j], kind="stable")
+        assert np.all(np.diff(adj[o, j]) >= -1e-7)
+    with pytest.raises(ValueError, match="is not in the accepted methods"):
+        m.homogeneous_patterns(correction="benjamini")
 
 
 @pytest.mark.parametrize("alpha,use_pca", [(0.2, True), (1.0, False), (1.0, True)])

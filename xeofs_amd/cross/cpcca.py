@@ -436,9 +436,8 @@ class CPCCA(Deferred):
 
     # ------------------------------------------------------------------ correlation patterns (cpcca.py:642-845)
     def _patterns(self, kind, correction, alpha):
-        if correction is not None:
-            raise NotImplementedError("multiple-test corrections need statsmodels (an optional dependency of the "
-                                      "reference as well); only correction=None is available")
+        if correction is not None and correction not in MULTIPLE_TESTS:      # statistics.py:145-149
+            raise ValueError(f"Your method '{correction}' is not in the accepted methods: {MULTIPLE_TESTS}")
         from scipy.special import betainc
 
         n = self.side[0].n
@@ -452,6 +451,8 @@ class CPCCA(Deferred):
                 corr = num / std[:, None] / n
             a = n / 2 - 1                                         # statistics.py:85-101: beta(a, a) on [-1, 1]
             pv = 2 * betainc(a, a, np.clip((1 - np.abs(corr)) / 2, 0, 1))
+            if correction is not None:
+                pv = holm_sidak(pv)
             pre = self.preprocessor1 if i == 0 else self.preprocessor2
             side = "left" if i == 0 else "right"
             pats.append(pre.inverse_transform_components(corr.astype(np.float32), f"{side}_{kind}_patterns", self.attrs))
@@ -464,6 +465,32 @@ class CPCCA(Deferred):
 
     def heterogeneous_patterns(self, correction=None, alpha=0.05):
         return self._patterns("heterogeneous", correction, alpha)
+
+
+MULTIPLE_TESTS = ["bonferroni", "sidak", "holm-sidak", "holm", "simes-hochberg", "hommel", "fdr_bh", "fdr_by", "fdr_tsbh",
+                  "fdr_tsbky"]          # utils/constants.py:21-32
+
+
+def holm_sidak(p):
+    """Adjusted p-values per column (mode) over the rows (features) -- what the reference's `correction=` delivers.
+
+    utils/optional/statistics.py:150-157 hands every mode's p-values to statsmodels' `multipletests` WITHOUT forwarding
+    `method` or `alpha`, so whatever valid name the caller passes, the adjustment is that function's default: Holm-Sidak
+    step-down.  statsmodels (0.14, an optional dependency absent from both images) computes it as: sort ascending;
+    raw_i = 1 - (1 - p_(i))^(m - i), i = 0..m-1 (via expm1 / log1p); running maximum; clip at 1; undo the sort.
+    The rejection flags the reference also computes are discarded there (statistics.py:83-86)."""
+    p = np.asarray(p, dtype=np.float64)
+    m = p.shape[0]
+    order = np.argsort(p, axis=0, kind="stable")                  # NaN (constant features) sort last and stay NaN
+    ps = np.take_along_axis(p, order, axis=0)
+    expo = np.arange(m, 0, -1, dtype=np.float64).reshape((m,) + (1,) * (p.ndim - 1))
+    with np.errstate(invalid="ignore", divide="ignore"):
+        raw = -np.expm1(expo * np.log1p(-ps))
+    with np.errstate(invalid="ignore"):
+        adj = np.minimum(np.where(np.isnan(raw), np.nan, np.fmax.accumulate(raw, axis=0)), 1.0)
+    out = np.empty_like(adj)
+    np.put_along_axis(out, order, adj, axis=0)
+    return out
 
 
 class MCA(CPCCA):
