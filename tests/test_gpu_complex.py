@@ -39,11 +39,13 @@ def test_hilbert_stage_vs_oracle(ctx, n, p, padding):
 
 
 @pytest.mark.parametrize("n,p", [(33, 9), (64, 130), (100, 65), (129, 8), (256, 33), (400, 21), (513, 4), (1000, 7),
-                                 (1024, 2), (2000, 5), (2049, 3), (4000, 3), (4097, 2), (8000, 3), (8192, 1)])
+                                 (1024, 2), (2000, 5), (2049, 3), (4000, 3), (4097, 2), (8000, 3), (8192, 1),
+                                 (8193, 2), (10000, 3), (12001, 1), (16384, 2)])
 @pytest.mark.parametrize("padding", ["exp", None])
 def test_hilbert_every_plan(ctx, n, p, padding):
-    """every instantiation of the one-kernel route (circular lengths 2^10 .. 2^14: leading radix 4 / 8 / none / 2, two or
-    three radix-16 stages, odd feature counts, series that end inside a wave) against the float64 oracle"""
+    """every instantiation of the one-kernel route (circular lengths 2^10 .. 2^14 with two features per transform: leading
+    radix 4 / 8 / none / 2, two or three radix-16 stages, odd feature counts, series that end inside a wave; 2^15 with one
+    feature per workgroup through the half-length transform of its even / odd samples) against the float64 oracle"""
     from xeofs_amd import engine
 
     rng = np.random.default_rng(n + p)
@@ -78,10 +80,10 @@ def test_hilbert_every_plan(ctx, n, p, padding):
 
 
 def test_hilbert_long_series_route(ctx):
-    """series longer than 8192 samples (circular length 2^15) take the hipFFT route; same contract"""
+    """series longer than 16384 samples (circular length 2^16) take the hipFFT route; same contract"""
     from xeofs_amd import engine
 
-    n, p = 8200, 40
+    n, p = 16500, 12
     X = _waves(n, p, seed=4)
     mat, _ = engine.preprocess(ctx, X)
     ref = orc.hilbert_transform(mat.download().astype(np.float64), padding="exp", decay_factor=0.2)

@@ -42,13 +42,13 @@ static void fft_host(std::vector<std::complex<double>>& a) {   // forward, radix
   }
 }
 
-template <int L> static void launch(const float* Xt, int64_t n_pad, int n, int64_t p, int padding, const float* hperm,
+template <int L, int MODE> static void launch(const float* Xt, int64_t n_pad, int n, int64_t p, int padding, const float* hperm,
                                     const float* u, float* Bt, float* At, unsigned* bmax, unsigned* amax, int cus) {
   using PL = hfft::plan<L>;
-  auto kern = hfft::hilbert_fft_kernel<L>;
+  auto kern = hfft::hilbert_fft_kernel<L, MODE>;
   CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PL::lds));
   const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(163840 / PL::lds, 2048 / PL::WG));
-  const int64_t groups = (p + 1) / 2;
+  const int64_t groups = MODE ? p : (p + 1) / 2;
   const int grid = (int)std::min<int64_t>(groups, (int64_t)cus * per_cu);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(PL::WG), PL::lds, 0, Xt, n_pad, n, p, padding, hperm, u, Bt, At, bmax, amax);
 }
@@ -62,20 +62,29 @@ int main(int argc, char** argv) {
   const int64_t n_pad = (n + 511) / 512 * 512;   // the library's padding of the sample axis
   int L = 10;
   while ((1 << L) < 2 * n) ++L;
-  if (L > 14) { printf("n too large\n"); return 1; }
-  const int P = 1 << L;
+  const int single = (argc > 6 ? atoi(argv[6]) : 0) || L == 15;   // one feature per workgroup through the half-length transform
+  if (L > 15 || (single && L < 11)) { printf("n out of range\n"); return 1; }
+  const int P = 1 << L;                   // circular length of the real convolution
+  const int LK = single ? L - 1 : L;      // log2 of the complex transform the kernel runs
   const int64_t N = padding ? 3 * (int64_t)n : n;
-  printf("n=%d p=%lld P=%d L=%d padding=%d\n", n, (long long)p, P, L, padding);
+  printf("n=%d p=%lld P=%d L=%d padding=%d single=%d\n", n, (long long)p, P, L, padding, single);
   // filter table
   std::vector<std::complex<double>> c((size_t)P, 0.0);
   for (int64_t d = -(n - 1); d <= n - 1; ++d) c[(size_t)((d % P + P) % P)] = kappa(N, d) / (double)P;
   fft_host(c);
   std::vector<float> hperm((size_t)P);
   double maxre = 0;
-  for (int pos = 0; pos < P; ++pos) {
-    const auto v = c[(size_t)hfft::position_frequency(L, pos)];
-    hperm[pos] = (float)v.imag();
-    maxre = std::max(maxre, std::fabs(v.real()));
+  for (int pos = 0; pos < P; ++pos) maxre = std::max(maxre, std::fabs(c[pos].real()));
+  if (single) {   // [hm | hp2] over the M = P/2 positions of the half-length transform
+    const int M = P / 2;
+    for (int pos = 0; pos < M; ++pos) {
+      const int64_t k = hfft::position_frequency(LK, pos);
+      const double hk = c[(size_t)k].imag(), hkp = k ? c[(size_t)(M - k)].imag() : 0.0;
+      hperm[pos] = (float)(hk - hkp);
+      hperm[M + pos] = (float)(0.5 * (hk + hkp));
+    }
+  } else {
+    for (int pos = 0; pos < P; ++pos) hperm[pos] = (float)c[(size_t)hfft::position_frequency(L, pos)].imag();
   }
   printf("max |Re spectrum| = %.3e (should be ~0)\n", maxre);
   std::vector<float> hu((size_t)4 * n);
@@ -116,8 +125,9 @@ int main(int argc, char** argv) {
   hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
   const int cus = prop.multiProcessorCount;
   auto run = [&]() {
-    switch (L) {
-#define CASE(LL) case LL: launch<LL>(dX, n_pad, n, p, padding, dh, du, dB, dA, dmax, dmax + 1, cus); break;
+    switch (LK + 100 * single) {
+#define CASE(LL) case LL: launch<LL, 0>(dX, n_pad, n, p, padding, dh, du, dB, dA, dmax, dmax + 1, cus); break; \
+                 case 100 + LL: launch<LL, 1>(dX, n_pad, n, p, padding, dh, du, dB, dA, dmax, dmax + 1, cus); break;
       CASE(10) CASE(11) CASE(12) CASE(13) CASE(14)
 #undef CASE
     }

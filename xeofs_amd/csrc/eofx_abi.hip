@@ -2193,7 +2193,7 @@ static int64_t hilbert_length(int64_t n, int* log2_out) {
   if (log2_out) *log2_out = L;
   return (int64_t)1 << L;
 }
-static const int HFFT_MAX_LOG2 = 14;
+static const int HFFT_MAX_LOG2 = 15;   // 2^14 complex points in LDS: two features up to P = 2^14, one feature (even / odd samples) at P = 2^15
 
 // kernel spectrum and correction vectors for series length n (cached per context)
 static int get_hilbert_setup(eofx_ctx* ctx, int64_t n, int padding, double decay, int64_t P, bool fused,
@@ -2218,7 +2218,19 @@ static int get_hilbert_setup(eofx_ctx* ctx, int64_t n, int padding, double decay
     for (int64_t d = -(n - 1); d <= n - 1; ++d) c[(size_t)((d % P + P) % P)] = hilbert_kappa(N, d) / (double)P;
     host_fft_f64(c);
     std::vector<float> hp((size_t)P);
-    for (int64_t pos = 0; pos < P; ++pos) hp[(size_t)pos] = (float)c[(size_t)hfft::position_frequency(L, pos)].imag();
+    if (L <= 14) {
+      for (int64_t pos = 0; pos < P; ++pos) hp[(size_t)pos] = (float)c[(size_t)hfft::position_frequency(L, pos)].imag();
+    } else {
+      // one feature per workgroup through the half-length transform (M = P/2 positions): the two tables of the
+      // split-filter-merge step, hm = h[k] - h[M-k] and hp2 = (h[k] + h[M-k]) / 2  (h[M] = 0)
+      const int64_t M = P / 2;
+      for (int64_t pos = 0; pos < M; ++pos) {
+        const int64_t k = hfft::position_frequency(L - 1, pos);
+        const double hk = c[(size_t)k].imag(), hkp = k ? c[(size_t)(M - k)].imag() : 0.0;
+        hp[(size_t)pos] = (float)(hk - hkp);
+        hp[(size_t)(M + pos)] = (float)(0.5 * (hk + hkp));
+      }
+    }
     HIPCHK(hipMalloc((void**)&hs.hperm, sizeof(float) * P));
     HIPCHK(hipMemcpy(hs.hperm, hp.data(), sizeof(float) * P, hipMemcpyHostToDevice));
   } else {
@@ -2278,16 +2290,16 @@ static int get_hilbert_setup(eofx_ctx* ctx, int64_t n, int padding, double decay
 }
 
 // launch of the one-kernel route for one plan (L = log2 of the circular length)
-template <int L>
+template <int L, int MODE>
 static hipError_t launch_hilbert_fused(eofx_ctx* ctx, const float* Xt, int64_t n_pad, int64_t n, int64_t p, int padding,
                                        const float* hperm, const float* u, float* Bt, float* At, unsigned* bmax,
                                        unsigned* amax) {
   using PL = hfft::plan<L>;
-  auto kern = hfft::hilbert_fft_kernel<L>;
+  auto kern = hfft::hilbert_fft_kernel<L, MODE>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PL::lds);
   if (e != hipSuccess) return e;
   const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>((int64_t)(163840 / PL::lds), 2048 / PL::WG));
-  const int64_t groups = (p + 1) / 2;
+  const int64_t groups = MODE ? p : (p + 1) / 2;
   static int cu_count = 0;
   if (cu_count <= 0) {
     hipDeviceProp_t prop;
@@ -2335,9 +2347,12 @@ extern "C" int eofx_hilbert_f32(eofx_ctx* ctx, const eofx_mat* a, int padding, d
     unsigned* amax = mr ? mr->absmax_dev : nullptr;
     switch (L) {
 #define EOFX_HF(LL) \
-  case LL: e = launch_hilbert_fused<LL>(ctx, a->Xt, n_pad, n, p, padding ? 1 : 0, hperm, u, mi->Xt, At, mi->absmax_dev, amax); break;
+  case LL: e = launch_hilbert_fused<LL, 0>(ctx, a->Xt, n_pad, n, p, padding ? 1 : 0, hperm, u, mi->Xt, At, mi->absmax_dev, amax); break;
       EOFX_HF(10) EOFX_HF(11) EOFX_HF(12) EOFX_HF(13) EOFX_HF(14)
 #undef EOFX_HF
+      case 15:   // 8193 .. 16384 samples: one feature per workgroup, half-length transform of its even / odd samples
+        e = launch_hilbert_fused<14, 1>(ctx, a->Xt, n_pad, n, p, padding ? 1 : 0, hperm, u, mi->Xt, At, mi->absmax_dev, amax);
+        break;
       default: e = hipErrorInvalidValue;
     }
     if (e != hipSuccess) {

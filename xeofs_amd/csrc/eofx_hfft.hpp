@@ -14,6 +14,13 @@
 // traffic is the algorithmic minimum (read y once, write Im once); the next pair's loads are in flight during the
 // LDS stages.  Radix 16 butterflies (4 x 4 in registers), one optional leading radix 2 / 4 / 8 stage, twiddle factors
 // per thread computed once in float64 and kept in registers (a thread meets the same butterfly for every pair).
+//
+// MODE 1 (series of 8193 .. 16384 samples, circular length 2^15): one feature per workgroup through the half-length
+// complex transform of its even / odd samples, z[j] = y[2j] + i y[2j+1].  The real-input split, the filter and the merge
+// back collapse into one step on the pair (Z[k], Z[M-k]):  W[k] = i hm[k] Z[k] + hp2[k] (w^k D - conj(w^k) S),
+// D = Z[k] - conj Z[M-k], S = Z[k] + conj Z[M-k], hm = h[k] - h[M-k], hp2 = (h[k] + h[M-k]) / 2, w = exp(-2 pi i / 2M).
+// In the digit-reversed layout the 16 frequencies of a middle-stage row have their partners in ONE other row, in
+// reverse order, so the step costs one extra trip through LDS in the middle stage.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -347,6 +354,7 @@ __device__ __forceinline__ void fresh(tw4& w) { fresh(w.w1); fresh(w.w2); fresh(
 // ragged ends (n is not a multiple of the group size, the odd last feature, idle groups) need no branches, and a
 // lane's address is one 32-bit offset shared by every row.
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef unsigned int u32x2v __attribute__((__vector_size__(2 * sizeof(unsigned int))));
 __device__ __forceinline__ rsrc_t row_rsrc(const float* base, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)bytes, 0x00020000);
 }
@@ -361,7 +369,39 @@ __device__ __forceinline__ void st_nt(float v, rsrc_t r, unsigned off) {
 }
 __device__ __forceinline__ unsigned absbits(float x) { return __builtin_bit_cast(unsigned, x) & 0x7fffffffu; }
 
-template <int L>
+// Middle-stage row t holds the frequencies klow(t) + q 2^(L-4), q = 0..15 (digit reversal of the stages above it)
+template <int L> __device__ __forceinline__ int klow_of_row(int t) {
+  constexpr int r = L & 3, ND = L / 4 - 1;
+  int k = 0, w = 0, shift = 4 * ND;
+  if constexpr (r > 0) { k = (t >> shift) & ((1 << r) - 1); w = r; }
+#pragma unroll
+  for (int d = 0; d < ND; ++d) { shift -= 4; k |= ((t >> shift) & 15) << w; w += 4; }
+  return k;
+}
+template <int L> __device__ __forceinline__ int row_of_klow(int k) {
+  constexpr int r = L & 3, ND = L / 4 - 1;
+  int t = 0, w = 0, shift = 4 * ND;
+  if constexpr (r > 0) { t = (k & ((1 << r) - 1)) << shift; w = r; }
+#pragma unroll
+  for (int d = 0; d < ND; ++d) { shift -= 4; t |= ((k >> w) & 15) << shift; w += 4; }
+  return t;
+}
+// a * exp(-2 pi i Q / 32)
+template <int Q> __device__ __forceinline__ cf mulw32(cf a) {
+  constexpr float C[16] = {1.f, 0.98078528040323044f, 0.92387953251128674f, 0.83146961230254524f, 0.70710678118654752f,
+                           0.55557023301960222f, 0.38268343236508977f, 0.19509032201612827f, 0.f, -0.19509032201612827f,
+                           -0.38268343236508977f, -0.55557023301960222f, -0.70710678118654752f, -0.83146961230254524f,
+                           -0.92387953251128674f, -0.98078528040323044f};
+  constexpr float S[16] = {0.f, 0.19509032201612827f, 0.38268343236508977f, 0.55557023301960222f, 0.70710678118654752f,
+                           0.83146961230254524f, 0.92387953251128674f, 0.98078528040323044f, 1.f, 0.98078528040323044f,
+                           0.92387953251128674f, 0.83146961230254524f, 0.70710678118654752f, 0.55557023301960222f,
+                           0.38268343236508977f, 0.19509032201612827f};
+  if constexpr (Q == 0) return a;
+  else if constexpr (Q == 8) return rot90<1>(a);
+  else return cmul_k(a, cf{C[Q], -S[Q]});
+}
+
+template <int L, int MODE>
 __global__ __launch_bounds__(plan<L>::WG, HFFT_WAVES) void hilbert_fft_kernel(const float* __restrict__ Xt, int64_t n_pad,
                                                                               int n, int64_t p, int padding,
                                                                               const float* __restrict__ hperm,
@@ -384,23 +424,41 @@ __global__ __launch_bounds__(plan<L>::WG, HFFT_WAVES) void hilbert_fft_kernel(co
   tw4 wout = make_tw4(t0, P);
   tw4 wa = NIN >= 1 ? make_tw4(t0 & (SA - 1), 16 * SA) : tw4{};
   tw4 wb = NIN >= 2 ? make_tw4(t0 & (SB - 1), 16 * SB) : tw4{};
-  const int cl = (n - 1) / NT, tl = (n - 1) % NT;   // owner of the last sample
+  // MODE 0: thread t holds samples t + c NT of two features; MODE 1: samples 2 j, 2 j + 1 (j = t + c NT) of one feature
+  const int jl = MODE ? (n - 1) >> 1 : n - 1;
+  const int cl = jl / NT, tl = jl % NT;             // owner of the last sample
   const double tbar = 0.5 * (double)(n - 1);
-  const int64_t npairs = (p + 1) / 2;
+  const int64_t npairs = MODE ? p : (p + 1) / 2;   // work items: features (MODE 1) or pairs of features
+  cf wmid = cf{1.f, 0.f};
+  int trow = 0;                                     // MODE 1: the row holding the partner frequencies M - k
+  if constexpr (MODE == 1) {
+    const int kl = klow_of_row<L>(t0);
+    wmid = unit(kl, 2.0 * P);
+    trow = row_of_klow<L>((NT - kl) & (NT - 1));
+  }
   const bool sums = padding || At;
   const unsigned nb = (unsigned)n * 4u, npb = (unsigned)n_pad * 4u;
 
   unsigned run_mx = 0u, run_my = 0u;   // running absmax of this thread's outputs (one atomic per wave at the end)
   float ya[8], yb[8];
   auto load_pair = [&](int64_t pr, unsigned tb4) {
-    const int64_t fa = 2 * pr, fb = fa + 1;
-    const rsrc_t ra = row_rsrc(Xt + fa * n_pad, pr < npairs ? nb : 0u);
-    const rsrc_t rb = row_rsrc(Xt + fb * n_pad, fb < p ? nb : 0u);
+    if constexpr (MODE == 1) {   // (the padded tail of a row is zero: whole 8-byte pairs up to n_pad)
+      const rsrc_t ra = row_rsrc(Xt + pr * n_pad, pr < npairs ? npb : 0u);
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const unsigned o = tb4 + (unsigned)(c * NT * 4);
-      ya[c] = ld_nt(ra, o);
-      yb[c] = ld_nt(rb, o);
+      for (int c = 0; c < 8; ++c) {
+        const cf v = __builtin_bit_cast(cf, __builtin_amdgcn_raw_buffer_load_b64(ra, 2u * (tb4 + (unsigned)(c * NT * 4)), 0, 2));
+        ya[c] = v.x; yb[c] = v.y;
+      }
+    } else {
+      const int64_t fa = 2 * pr, fb = fa + 1;
+      const rsrc_t ra = row_rsrc(Xt + fa * n_pad, pr < npairs ? nb : 0u);
+      const rsrc_t rb = row_rsrc(Xt + fb * n_pad, fb < p ? nb : 0u);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const unsigned o = tb4 + (unsigned)(c * NT * 4);
+        ya[c] = ld_nt(ra, o);
+        yb[c] = ld_nt(rb, o);
+      }
     }
   };
 #pragma unroll
@@ -419,8 +477,8 @@ __global__ __launch_bounds__(plan<L>::WG, HFFT_WAVES) void hilbert_fft_kernel(co
     cf* const at_a = data + phys((t / SA) * 16 * SA + (t & (SA - 1)));
     cf* const at_b = data + phys((t / SB) * 16 * SB + (t & (SB - 1)));
     cf* const row = data + phys(16 * t);
-    const int64_t fa = 2 * pair, fb = fa + 1;
-    const bool hb = fb < p;
+    const int64_t fa = MODE ? pair : 2 * pair, fb = fa + 1;
+    const bool hb = MODE ? false : fb < p;
     // ---- linear fit and pad amplitudes (float64 sums over the group)
     double sa = 0.0, ta = 0.0, sb = 0.0, tb = 0.0;
     if (sums) {
@@ -430,9 +488,15 @@ __global__ __launch_bounds__(plan<L>::WG, HFFT_WAVES) void hilbert_fft_kernel(co
         sa += (double)ya[c]; s1a += (double)c * (double)ya[c];
         sb += (double)yb[c]; s1b += (double)c * (double)yb[c];
       }
-      const double tc = (double)t - tbar;
-      ta = tc * sa + (double)NT * s1a;
-      tb = tc * sb + (double)NT * s1b;
+      if constexpr (MODE == 1) {   // samples 2 j and 2 j + 1
+        const double tc = 2.0 * (double)t - tbar;
+        ta = tc * sa + 2.0 * (double)NT * s1a;
+        tb = (tc + 1.0) * sb + 2.0 * (double)NT * s1b;
+      } else {
+        const double tc = (double)t - tbar;
+        ta = tc * sa + (double)NT * s1a;
+        tb = tc * sb + (double)NT * s1b;
+      }
       if constexpr (NW > 1) {
         const double k = reduce4(sa, ta, sb, tb, lane);
         if ((lane & 15) == 0) red1[wave * 4 + (lane >> 4)] = k;
@@ -444,6 +508,7 @@ __global__ __launch_bounds__(plan<L>::WG, HFFT_WAVES) void hilbert_fft_kernel(co
         float la = 0.f, lb = 0.f;
 #pragma unroll
         for (int c = 0; c < 8; ++c) if (c == cl) { la = ya[c]; lb = yb[c]; }
+        if constexpr (MODE == 1) la = ((n - 1) & 1) ? lb : la;   // sample n - 1 is the odd or the even one of its pair
         edge[1] = la; edge[3] = lb;
       }
     }
@@ -467,6 +532,13 @@ __global__ __launch_bounds__(plan<L>::WG, HFFT_WAVES) void hilbert_fft_kernel(co
         sa = sb = k; ta = tb = o;      // lanes 0 / 32 hold (sum y, sum t y) of features a / b
         ft = lane >> 5;
         fin = (lane & 31) == 0;
+        if constexpr (MODE == 1) {     // one series: its even and odd halves add up
+          sa += __shfl_xor(k, 32); ta += __shfl_xor(o, 32);
+          fin = lane == 0;
+        }
+      } else if constexpr (MODE == 1) {
+        sa += sb; ta += tb;
+        fin = t == 0;
       }
       if (fin) {
         const double sy = ft ? sb : sa, sty = ft ? tb : ta;
@@ -493,14 +565,45 @@ __global__ __launch_bounds__(plan<L>::WG, HFFT_WAVES) void hilbert_fft_kernel(co
         v[j] = cf{q.x, q.y}; v[j + 1] = cf{q.z, q.w};
       }
       dft16<1, false>(v);
+      if constexpr (MODE == 1) {
+        // the spectrum of this row, in frequency order, for the partner row; then the partner's, reversed
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f4 h = *reinterpret_cast<const f4*>(reinterpret_cast<const char*>(hperm) + (tb4 * 16u + 16u * g));
-        const cf z0 = v[slot16(4 * g)], z1 = v[slot16(4 * g + 1)], z2 = v[slot16(4 * g + 2)], z3 = v[slot16(4 * g + 3)];
-        w[4 * g] = cf{-h.x * z0.y, h.x * z0.x};      // * i h
-        w[4 * g + 1] = cf{-h.y * z1.y, h.y * z1.x};
-        w[4 * g + 2] = cf{-h.z * z2.y, h.z * z2.x};
-        w[4 * g + 3] = cf{-h.w * z3.y, h.w * z3.x};
+        for (int j = 0; j < 16; j += 2) {
+          const cf a = v[slot16(j)], b = v[slot16(j + 1)];
+          *reinterpret_cast<f4*>(row + j) = f4{a.x, a.y, b.x, b.y};
+        }
+        __syncthreads();
+        int tr = trow;
+        fresh(tr);
+        const cf* const rowp = data + phys(16 * tr);
+        const bool self0 = t == 0;      // row 0 pairs k = q M/16 with (16 - q) M/16 inside itself
+        cf zp[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) zp[q] = rowp[self0 ? ((16 - q) & 15) : (15 - q)];
+        __syncthreads();                // every row has been read before any is overwritten
+        cf wm = wmid;
+        fresh(wm);
+#define HFFT_MB(Q)                                                                                        \
+        {                                                                                                 \
+          const cf a = v[slot16(Q)], bc = cf{zp[Q].x, -zp[Q].y};                                          \
+          const cf wq = mulw32<Q>(wm);                                                                    \
+          const cf r = cmul(a - bc, wq) - cmulc(a + bc, wq);                                              \
+          const float hm = hperm[16 * t + Q], hp2 = hperm[P + 16 * t + Q];                                \
+          w[Q] = cf{hp2 * r.x - hm * a.y, hp2 * r.y + hm * a.x};                                          \
+        }
+        HFFT_MB(0) HFFT_MB(1) HFFT_MB(2) HFFT_MB(3) HFFT_MB(4) HFFT_MB(5) HFFT_MB(6) HFFT_MB(7)
+        HFFT_MB(8) HFFT_MB(9) HFFT_MB(10) HFFT_MB(11) HFFT_MB(12) HFFT_MB(13) HFFT_MB(14) HFFT_MB(15)
+#undef HFFT_MB
+      } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f4 h = *reinterpret_cast<const f4*>(reinterpret_cast<const char*>(hperm) + (tb4 * 16u + 16u * g));
+          const cf z0 = v[slot16(4 * g)], z1 = v[slot16(4 * g + 1)], z2 = v[slot16(4 * g + 2)], z3 = v[slot16(4 * g + 3)];
+          w[4 * g] = cf{-h.x * z0.y, h.x * z0.x};      // * i h
+          w[4 * g + 1] = cf{-h.y * z1.y, h.y * z1.x};
+          w[4 * g + 2] = cf{-h.z * z2.y, h.z * z2.x};
+          w[4 * g + 3] = cf{-h.w * z3.y, h.w * z3.x};
+        }
       }
       dft16<-1, false>(w);
 #pragma unroll
@@ -524,7 +627,7 @@ __global__ __launch_bounds__(plan<L>::WG, HFFT_WAVES) void hilbert_fft_kernel(co
       float a1a = 0.f, a2a = 0.f, a3a = 0.f, a4a = 0.f, a1b = 0.f, a2b = 0.f, a3b = 0.f, a4b = 0.f;
       if (padding) {
         a1a = coef[0]; a2a = coef[1]; a3a = coef[2]; a4a = coef[3];
-        a1b = coef[6]; a2b = coef[7]; a3b = coef[8]; a4b = coef[9];
+        a1b = coef[MODE ? 0 : 6]; a2b = coef[MODE ? 1 : 7]; a3b = coef[MODE ? 2 : 8]; a4b = coef[MODE ? 3 : 9];
       }
       float va[8], vb[8];
       double ua = 0.0, ub = 0.0;
@@ -533,13 +636,24 @@ __global__ __launch_bounds__(plan<L>::WG, HFFT_WAVES) void hilbert_fft_kernel(co
       for (int c = 0; c < 8; ++c) {
         const unsigned o = tb4 + (unsigned)(c * NT * 4);
         float xa = e[c].x, xb = e[c].y;
-        if (padding) {
-          const f4 uu = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(ru, 4u * o, 0, 0));
-          xa += a1a * uu.x + a2a * uu.y + a3a * uu.z + a4a * uu.w;
-          xb += a1b * uu.x + a2b * uu.y + a3b * uu.z + a4b * uu.w;
+        if constexpr (MODE == 1) {      // samples 2 j, 2 j + 1: byte offsets 2 o, 2 o + 4
+          if (padding) {
+            const f4 ue = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(ru, 8u * o, 0, 0));
+            const f4 uo = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(ru, 8u * o + 16u, 0, 0));
+            xa += a1a * ue.x + a2a * ue.y + a3a * ue.z + a4a * ue.w;
+            xb += a1a * uo.x + a2a * uo.y + a3a * uo.z + a4a * uo.w;
+          }
+          xa = (2u * o < nb) ? xa : 0.f;
+          xb = (2u * o + 4u < nb) ? xb : 0.f;
+        } else {
+          if (padding) {
+            const f4 uu = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(ru, 4u * o, 0, 0));
+            xa += a1a * uu.x + a2a * uu.y + a3a * uu.z + a4a * uu.w;
+            xb += a1b * uu.x + a2b * uu.y + a3b * uu.z + a4b * uu.w;
+          }
+          xa = (o < nb) ? xa : 0.f;
+          xb = (o < nb) ? xb : 0.f;
         }
-        xa = (o < nb) ? xa : 0.f;
-        xb = (o < nb) ? xb : 0.f;
         ua += (double)xa; ub += (double)xb;
         va[c] = xa; vb[c] = xb;
       }
@@ -554,17 +668,25 @@ __global__ __launch_bounds__(plan<L>::WG, HFFT_WAVES) void hilbert_fft_kernel(co
       } else {
         ua = wave_total(ua); ub = wave_total(ub);
       }
+      if constexpr (MODE == 1) ua = ub = ua + ub;      // one series: one mean
       const float m0 = (float)(ua / (double)n), m1 = (float)(ub / (double)n);
       const rsrc_t wa_ = row_rsrc(Bt + fa * n_pad, npb);
       const rsrc_t wb_ = row_rsrc(Bt + fb * n_pad, hb ? npb : 0u);
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         const unsigned o = tb4 + (unsigned)(c * NT * 4);
-        const float xa = (o < nb) ? va[c] - m0 : 0.f;
-        const float xb = (o < nb) ? vb[c] - m1 : 0.f;
-        st_nt(xa, wa_, o);
-        st_nt(xb, wb_, o);
-        run_mx = max(run_mx, max(absbits(xa), absbits(xb)));   // (idle rows carry zeros)
+        if constexpr (MODE == 1) {
+          const float xa = (2u * o < nb) ? va[c] - m0 : 0.f;
+          const float xb = (2u * o + 4u < nb) ? vb[c] - m0 : 0.f;
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, cf{xa, xb}), wa_, 2u * o, 0, 2);
+          run_mx = max(run_mx, max(absbits(xa), absbits(xb)));
+        } else {
+          const float xa = (o < nb) ? va[c] - m0 : 0.f;
+          const float xb = (o < nb) ? vb[c] - m1 : 0.f;
+          st_nt(xa, wa_, o);
+          st_nt(xb, wb_, o);
+          run_mx = max(run_mx, max(absbits(xa), absbits(xb)));   // (idle rows carry zeros)
+        }
       }
       if (At) {   // the re-centred input (only asked for when the field was not centred before): second read of y
         const float ma = coef[4], mb = coef[10];
@@ -575,11 +697,19 @@ __global__ __launch_bounds__(plan<L>::WG, HFFT_WAVES) void hilbert_fft_kernel(co
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
           const unsigned o = tb4 + (unsigned)(c * NT * 4);
-          const float xa = (o < nb) ? ld(ra, o) - ma : 0.f;
-          const float xb = (hb && o < nb) ? ld(rb, o) - mb : 0.f;
-          st_nt(xa, qa, o);
-          st_nt(xb, qb, o);
-          run_my = max(run_my, max(absbits(xa), absbits(xb)));
+          if constexpr (MODE == 1) {
+            const cf y2 = __builtin_bit_cast(cf, __builtin_amdgcn_raw_buffer_load_b64(row_rsrc(Xt + fa * n_pad, npb), 2u * o, 0, 0));
+            const float xa = (2u * o < nb) ? y2.x - ma : 0.f;
+            const float xb = (2u * o + 4u < nb) ? y2.y - ma : 0.f;
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, cf{xa, xb}), qa, 2u * o, 0, 2);
+            run_my = max(run_my, max(absbits(xa), absbits(xb)));
+          } else {
+            const float xa = (o < nb) ? ld(ra, o) - ma : 0.f;
+            const float xb = (hb && o < nb) ? ld(rb, o) - mb : 0.f;
+            st_nt(xa, qa, o);
+            st_nt(xb, qb, o);
+            run_my = max(run_my, max(absbits(xa), absbits(xb)));
+          }
         }
       }
     }
