@@ -2186,7 +2186,7 @@ static void host_fft_f64(std::vector<std::complex<double>>& a) {
 
 // circular length of the convolution behind the Hilbert stage: power of two >= 2 n, and >= 1024 so that half of it
 // covers the padded series length (n_pad = round_up(n, 512) <= P / 2: the one-kernel route writes samples [0, P / 2));
-// that route (eofx_hfft.hpp) holds the transform in LDS up to 2^14
+// that route (eofx_hfft.hpp) holds 2^14 complex points in LDS: circular lengths up to 2^15
 static int64_t hilbert_length(int64_t n, int* log2_out) {
   int L = 10;
   while (((int64_t)1 << L) < 2 * n) ++L;
