@@ -54,7 +54,7 @@ def test_rot_step_matches_numpy(ctx, p, m):
 
 
 @pytest.mark.parametrize("power", [1, 2, 4])
-@pytest.mark.parametrize("p,m", [(900, 4), (30000, 12)])
+@pytest.mark.parametrize("p,m", [(900, 4), (30000, 12), (4000, 70), (2500, 130)])   # > 64 modes: the wide (library GEMM) step
 def test_promax_matches_oracle(ctx, p, m, power):
     from xeofs_amd import rotation
 
@@ -135,6 +135,30 @@ def test_eof_rotator_model(ctx, power):
         assert np.allclose(rec, rec0, atol=1e-3 * np.abs(rec0).max())
     with pytest.raises(NotImplementedError):
         rot.fit_transform(model)
+
+
+def test_eof_rotator_more_than_64_modes(ctx):
+    """the whole rotator path (device-side finish, scores, transform) on 128-wide panels"""
+    import xeofs_amd as xe
+
+    n, nlat, nlon, k = 300, 15, 20, 72
+    vals = orc.synthetic_field(n, nlat, nlon, rank=90, seed=6)[0].reshape(n, nlat, nlon)
+    X = xe.DataArray(vals, dims=("time", "lat", "lon"))
+    model = xe.single.EOF(n_modes=k + 4, random_state=2, solver="full").fit(X, "time")
+    rot = xe.single.EOFRotator(n_modes=k, power=1, rtol=1e-10).fit(model)
+    Xs = vals.reshape(n, -1).astype(np.float64)
+    eof = orc.eof_fit(Xs, k + 4, random_state=2, solver="full")
+    eof["input_data"] = Xs
+    ref = orc.eof_rotator_fit(eof, k, power=1, rtol=1e-10)
+    ev = rot.explained_variance().values
+    assert np.allclose(ev, ref["explained_variance"], rtol=5e-4)
+    assert np.isclose(ev.sum(), model.explained_variance().values[:k].sum(), rtol=1e-5)
+    comps = rot.components().values.reshape(k, -1).T
+    cos = np.abs((comps * ref["components"]).sum(0)) / np.linalg.norm(comps, axis=0) / np.linalg.norm(ref["components"], axis=0)
+    assert cos.min() > 1 - 1e-3, cos.min()
+    sc = rot.scores().values.reshape(k, -1).T
+    tr = rot.transform(X).values.reshape(k, -1).T
+    assert np.allclose(tr, sc, atol=2e-3 * np.abs(sc).max())
 
 
 @pytest.mark.parametrize("power", [1, 2, 4])

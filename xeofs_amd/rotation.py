@@ -5,6 +5,9 @@ The p x m loadings stay on the GPU as a 64-wide panel.  Each iteration of the re
 R = U VT`) is one fused pass over the panel (`eofx_panel_rot_step_f64`, float64 row arithmetic) plus an
 m x m SVD on the host; `W = diag(R^T (X^T X) R)` comes from the m x m Gram matrix computed once.
 Convergence test, error and outputs are the reference's.
+
+More than 64 modes (up to 256; rare) keep the same driver on 128 / 256-wide panels; the step is then three library
+products in float64 per block of rows (`_rot_step_wide`) instead of the fused kernel.
 """
 
 from __future__ import annotations
@@ -13,7 +16,8 @@ import numpy as np
 
 from . import engine
 
-MAX_ROT_MODES = 64
+MAX_ROT_MODES = 256
+FUSED_ROT_MODES = 64      # widest panel of the fused step kernel
 
 
 def _dev(a, like):
@@ -26,6 +30,35 @@ def _pad(M, L):
     m = M.shape[0]
     out[:m, :m] = M
     return out
+
+
+def _rot_width(m):
+    """panel width for m modes: the fused kernel's 32 / 64, else the next power of two (row normalisation needs one)"""
+    return engine.panel_width(m) if m <= FUSED_ROT_MODES else (128 if m <= 128 else 256)
+
+
+def _rot_step_wide(ctx, X, R, aux, mode, power=1.0, block=1 << 17):
+    """The step of `eofx_panel_rot_step_f64` for panels wider than the fused kernel takes (modes 0 / 1 of its contract:
+    G = X^T (b (b^2 - aux)) or G = b^T (z |z|^(power-1)), b = X R, z = b / aux), float64, block of rows by block of rows
+    through the library's GEMM."""
+    torch = engine._torch()
+    L = X.shape[1]
+    G = torch.zeros((L, L), dtype=torch.float64, device=X.device)
+    for r0 in range(0, X.shape[0], block):
+        x = X[r0:r0 + block].double()
+        b = x @ R
+        if mode == 0:
+            G += x.T @ (b * (b * b - aux))
+        else:
+            z = b / aux
+            G += b.T @ (z if power == 1.0 else z * z.abs().pow(power - 1.0))
+    return G
+
+
+def _rot_step(ctx, X, R, aux, mode, power=1.0):
+    if X.shape[1] <= FUSED_ROT_MODES:
+        return engine.panel_rot_step(ctx, X, R, aux, mode, power)
+    return _rot_step_wide(ctx, X, R, aux, mode, float(power))
 
 
 def promax(ctx, loadings: np.ndarray, power: int = 1, max_iter: int = 1000, rtol: float = 1e-8):
@@ -44,7 +77,7 @@ def promax_panel(ctx, loadings: np.ndarray, power: int = 1, max_iter: int = 1000
         raise ValueError("Cannot rotate {:} modes (columns), but must be 2 or more.".format(m))
     if m > MAX_ROT_MODES:
         raise NotImplementedError(f"rotation of more than {MAX_ROT_MODES} modes is not supported by this build")
-    L = engine.panel_width(m)
+    L = _rot_width(m)
     rows_pad = (p + 511) // 512 * 512
     Lp = engine.panel_import(ctx, loadings, rows_pad, L)           # loadings
     if col_scale is not None:
@@ -62,7 +95,7 @@ def promax_panel(ctx, loadings: np.ndarray, power: int = 1, max_iter: int = 1000
         W = np.einsum("ij,ik,kj->j", R, S, R)                      # column sums of (X R)^2
         aux = np.zeros(L)
         aux[:m] = alpha * W
-        G = engine.panel_rot_step(ctx, Xn, _dev(_pad(R, L), Xn), _dev(aux, Xn), 0).cpu().numpy()[:m, :m]
+        G = _rot_step(ctx, Xn, _dev(_pad(R, L), Xn), _dev(aux, Xn), 0).cpu().numpy()[:m, :m]
         U, svals, VT = np.linalg.svd(G)
         R = U @ VT
         delta = float(np.sum(svals))
@@ -79,7 +112,7 @@ def promax_panel(ctx, loadings: np.ndarray, power: int = 1, max_iter: int = 1000
         cmax = np.maximum(np.abs(mx.cpu().numpy()), np.abs(mn.cpu().numpy()))[:m].astype(np.float64)
         aux = np.ones(L)
         aux[:m] = cmax
-        XtP = engine.panel_rot_step(ctx, Xn, _dev(_pad(R, L), Xn), _dev(aux, Xn), 1, float(power)).cpu().numpy()[:m, :m]
+        XtP = _rot_step(ctx, Xn, _dev(_pad(R, L), Xn), _dev(aux, Xn), 1, float(power)).cpu().numpy()[:m, :m]
         XtX = R.T @ S @ R
         Lm = np.linalg.inv(XtX) @ XtP
         try:
