@@ -122,6 +122,45 @@ def test_complex_rsvd_vs_exact(ctx, n, p, k):
     assert np.all(np.abs(s - so) <= 1e-5 * so + 2e-6 * so[0])
 
 
+@pytest.mark.parametrize("n_modes", [60, 0.9])
+def test_complex_eof_many_or_variance_based_modes(ctx, n_modes):
+    """more modes than the 64-column complex sketch holds, and a variance-based (float) n_modes -- int(0.3 rank) modes,
+    truncated at the requested explained variance (decomposer.py:89-106, _svd.py:215-241) -- against the exact SVD"""
+    import xeofs_amd as xe
+
+    n, p = 220, 31 * 17
+    rng = np.random.default_rng(3)
+    r = 90
+    Z = ((rng.standard_normal((n, r)) + 1j * rng.standard_normal((n, r))) * (5.0 * 0.93 ** np.arange(r))) @ \
+        (rng.standard_normal((r, p)) + 1j * rng.standard_normal((r, p))) / np.sqrt(r)
+    Z = Z + 0.05 * (rng.standard_normal((n, p)) + 1j * rng.standard_normal((n, p)))
+    da = xe.DataArray(Z.reshape(n, 31, 17), dims=("time", "y", "x"))
+    m = xe.single.ComplexEOF(n_modes=n_modes, random_state=1).fit(da, "time")
+    Zc = Z - Z.mean(axis=0)
+    Ue, se, Vhe = np.linalg.svd(Zc, full_matrices=False)
+    if isinstance(n_modes, float):
+        n_pre = int(0.3 * min(n, p))
+        tv = (np.abs(Zc) ** 2).sum() / (n - 1)
+        cum = np.cumsum(se[:n_pre] ** 2 / (n - 1) / tv)
+        k = n_pre - int((cum >= n_modes).sum()) + 1
+        assert 1 < k < n_pre
+    else:
+        k = n_modes
+    s = m.singular_values().values
+    assert s.shape == (k,)
+    assert np.all(np.abs(s - se[:k]) <= 2e-5 * se[0])
+    V = m.components().values.reshape(k, -1).T
+    U = m.scores(normalized=True).values.reshape(k, -1).T
+    for j in (0, 1, k // 2, k - 1):
+        assert abs(np.vdot(Vhe[j].conj(), V[:, j])) / np.linalg.norm(V[:, j]) >= 1 - 1e-4, j
+        assert abs(np.vdot(Ue[:, j], U[:, j])) / np.linalg.norm(U[:, j]) >= 1 - 1e-4, j
+    assert (orc.deterministic_sign_multiplier(V.conj().T) == 1).all()
+    # U s V^H reproduces the rank-k truncation (phases of U and V are consistent)
+    rec = (U * s) @ V.conj().T
+    best = (Ue[:, :k] * se[:k]) @ Vhe[:k]
+    assert np.linalg.norm(rec - best) <= 1e-3 * np.linalg.norm(best)
+
+
 def test_hilbert_eof_model_vs_oracle(ctx):
     import xeofs_amd as xe
 

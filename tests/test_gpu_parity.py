@@ -394,8 +394,8 @@ def test_documented_size_limits_fail_loudly(ctx):
     from xeofs_amd import engine, rotation
     from xeofs_amd.complex_svd import complex_rsvd
 
-    with pytest.raises(NotImplementedError, match="more than 64 modes"):
-        rotation.promax(ctx, np.ones((200, 65), np.float32))
+    with pytest.raises(NotImplementedError, match="more than 256 modes"):
+        rotation.promax(ctx, np.ones((600, 257), np.float32))
     rng = np.random.default_rng(0)
     A = engine.from_dense(ctx, rng.standard_normal((300, 400)).astype(np.float32))
     B = engine.from_dense(ctx, rng.standard_normal((300, 400)).astype(np.float32))

@@ -217,18 +217,39 @@ class ComplexEOF(EOF):
                                       "https://github.com/dask/dask/issues/7639")
 
     def _fit_complex(self, A, B, total_variance, omega=None):
-        if not isinstance(self.n_modes, (int, np.integer)):
-            # decomposer.py:89-106: a float n_modes asks for int(0.3 rank) modes first -- hundreds of complex columns
-            raise NotImplementedError("variance-based (float) n_modes is not supported for ComplexEOF / HilbertEOF: the "
-                                      "complex decomposer holds n_modes + n_oversamples <= 64 columns; pass an integer")
         kw = dict(self._solver_kwargs)
+        n_over = int(kw.get("n_oversamples", 10))
+        if not isinstance(self.n_modes, (int, np.integer)) or int(self.n_modes) + n_over > 64:
+            return self._fit_complex_wide(A, B, total_variance)
         om = None if omega is None else omega.result()
         if om is not None and om.shape[0] != min(A.n, A.p):     # samples or features were dropped: draw again
             om = None
-        U, s, V = engine.rsvd_c64(self.ctx, A, B, int(self.n_modes), int(kw.get("n_oversamples", 10)),
+        U, s, V = engine.rsvd_c64(self.ctx, A, B, int(self.n_modes), n_over,
                                   kw.get("n_iter", "auto"), self._params["random_state"], omega=om)
         s64 = s.astype(np.float64)
         self.data = dict(input_data=(A, B), components=V, scores=U * s, norms=s64,
+                         explained_variance=s64 ** 2 / (A.n - 1), total_variance=total_variance)
+        return self
+
+    def _fit_complex_wide(self, A, B, total_variance):
+        """More modes than the 64-column complex sketch holds, or a variance-based (float) n_modes -- which asks for
+        int(init_rank_reduction * rank) modes first and truncates by explained variance (decomposer.py:89-106,
+        _svd.py:215-241): the exact Hermitian-Gram route of the complex cross models' PCA pre-reduction
+        (xeofs_amd/cpca.py), followed by the decomposer's sign rule."""
+        from ..cpca import ComplexResidentPCA
+
+        if A.n > A.p:
+            raise NotImplementedError("ComplexEOF / HilbertEOF with more than 54 modes (or a variance-based n_modes) needs "
+                                      "n_samples <= n_features (the Hermitian Gram matrix lives on the sample side)")
+        pca = ComplexResidentPCA(self.ctx, self.n_modes, self._decomposer_kwargs.get("init_rank_reduction", 0.3))
+        pca.fit(A, B, total_variance)
+        V = pca.components()                                          # p x m complex64
+        mx, mn = V.conj().max(axis=0), V.conj().min(axis=0)           # utils/xarray_utils.py:273-301 on VT = conj(V)^T
+        sgn = np.where(np.abs(mx) >= np.abs(mn), 1.0, -1.0)
+        V *= sgn.astype(np.float32)
+        s64 = np.asarray(pca.s, dtype=np.float64)
+        scores = (pca.U * sgn) * s64
+        self.data = dict(input_data=(A, B), components=V, scores=scores.astype(np.complex64), norms=s64,
                          explained_variance=s64 ** 2 / (A.n - 1), total_variance=total_variance)
         return self
 
