@@ -122,19 +122,20 @@ def test_complex_rsvd_vs_exact(ctx, n, p, k):
     assert np.all(np.abs(s - so) <= 1e-5 * so + 2e-6 * so[0])
 
 
+@pytest.mark.parametrize("shape", [(220, 31, 17), (600, 12, 8)])      # Gram matrix on the sample / on the feature side
 @pytest.mark.parametrize("n_modes", [60, 0.9])
-def test_complex_eof_many_or_variance_based_modes(ctx, n_modes):
+def test_complex_eof_many_or_variance_based_modes(ctx, n_modes, shape):
     """more modes than the 64-column complex sketch holds, and a variance-based (float) n_modes -- int(0.3 rank) modes,
     truncated at the requested explained variance (decomposer.py:89-106, _svd.py:215-241) -- against the exact SVD"""
     import xeofs_amd as xe
 
-    n, p = 220, 31 * 17
+    n, p = shape[0], shape[1] * shape[2]
     rng = np.random.default_rng(3)
     r = 90
     Z = ((rng.standard_normal((n, r)) + 1j * rng.standard_normal((n, r))) * (5.0 * 0.93 ** np.arange(r))) @ \
         (rng.standard_normal((r, p)) + 1j * rng.standard_normal((r, p))) / np.sqrt(r)
     Z = Z + 0.05 * (rng.standard_normal((n, p)) + 1j * rng.standard_normal((n, p)))
-    da = xe.DataArray(Z.reshape(n, 31, 17), dims=("time", "y", "x"))
+    da = xe.DataArray(Z.reshape(shape), dims=("time", "y", "x"))
     m = xe.single.ComplexEOF(n_modes=n_modes, random_state=1).fit(da, "time")
     Zc = Z - Z.mean(axis=0)
     Ue, se, Vhe = np.linalg.svd(Zc, full_matrices=False)

@@ -13,8 +13,7 @@ Same exact route as the real `xeofs_amd.pca.ResidentPCA`, with Hermitian algebra
 
 A complex panel of m columns is a real [rows_pad, 2 Lh] panel, Lh = round_up(m, 32): columns [0, m) real parts,
 [Lh, Lh + m) imaginary parts.  V stays resident; scores U s live on the host (n x m complex128).
-Fields with more samples than features are rare here (the PC-space matrices never come back through this class) and
-are not supported.
+With more samples than features the Gram matrix is Z^H Z (features x features) and the roles of the two sides swap.
 """
 
 from __future__ import annotations
@@ -66,12 +65,16 @@ class ComplexResidentPCA(ResidentPCA):
         n, p = A.n, A.p
         if (B.n, B.p) != (n, p):
             raise ValueError("real and imaginary parts must have the same shape")
-        if n > p:
-            raise NotImplementedError("complex PCA pre-reduction needs n_samples <= n_features")
+        side = 0 if n <= p else 1                              # Hermitian Gram matrix on the small side
+        r = n if side == 0 else p
         rank = min(n, p)
         n_pre = self._n_modes_precompute(rank)
-        Gr = (A.gram(0)[:n, :n].double() + B.gram(0)[:n, :n].double())
-        X = B.cross_gram(A, 0)[:n, :n].double()               # B A^T
+        if side == 0:      # Z Z^H = (A A^T + B B^T) + i (B A^T - A B^T)
+            Gr = (A.gram(0)[:r, :r].double() + B.gram(0)[:r, :r].double())
+            X = B.cross_gram(A, 0)[:r, :r].double()            # B A^T
+        else:              # Z^H Z = (A^T A + B^T B) + i (A^T B - B^T A)
+            Gr = (A.gram(1)[:r, :r].double() + B.gram(1)[:r, :r].double())
+            X = A.cross_gram(B, 1)[:r, :r].double()            # A^T B
         G = torch.complex(0.5 * (Gr + Gr.T), X - X.T)
         del Gr, X
         if not bool(torch.isfinite(G.real).all() and torch.isfinite(G.imag).all()):
@@ -92,21 +95,32 @@ class ComplexResidentPCA(ResidentPCA):
                 m = n_pre
         Lh = _round32(m)
         dev = f"cuda:{ctx.device}"
-        Es = torch.zeros((A.n_pad, 2 * Lh), dtype=torch.float32, device=dev)
+        Es = torch.zeros((A.n_pad if side == 0 else A.p_pad, 2 * Lh), dtype=torch.float32, device=dev)
         Em = np.ascontiguousarray(E[:, :m])      # (BLAS needs plain strides: a sliced / reversed view multiplies 100x slower)
-        Es[:n, :m] = torch.as_tensor(Em.real, dtype=torch.float32)
-        Es[:n, Lh:Lh + m] = torch.as_tensor(Em.imag, dtype=torch.float32)
+        Es[:r, :m] = torch.as_tensor(Em.real, dtype=torch.float32)
+        Es[:r, Lh:Lh + m] = torch.as_tensor(Em.imag, dtype=torch.float32)
         pr = ctx.precision[1]
-        P = engine.cpanel_combine(ctx, engine.panel_tmul(ctx, A, Es, prec=pr), engine.panel_tmul(ctx, B, Es, prec=pr), True)
+        if side == 0:      # tall side = features: P = Z^H E_m
+            P = engine.cpanel_combine(ctx, engine.panel_tmul(ctx, A, Es, prec=pr), engine.panel_tmul(ctx, B, Es, prec=pr), True)
+        else:              # tall side = samples:  P = Z E_m
+            P = engine.cpanel_combine(ctx, engine.panel_mul(ctx, A, Es, prec=pr), engine.panel_mul(ctx, B, Es, prec=pr), False)
         H = hermitian_from_real_gram(engine.panel_gram(ctx, P).cpu().numpy(), Lh, m)
         th, W = _eigh_desc(torch.as_tensor(H, device=dev) if m >= 512 else H)
         th, W = np.clip(th, 0.0, None), np.ascontiguousarray(W)
         s = np.sqrt(th)
         tiny = th[0] * 1e-14 if m else 0.0
         inv = np.where(th > tiny, 1.0 / np.sqrt(np.maximum(th, 1e-300)), 0.0)
-        self.Vp = engine.panel_matmul(ctx, P, torch.as_tensor(embed_right(W * inv, Lh, Lh), device=P.device))   # p_pad x 2 Lh
+        Tall = engine.panel_matmul(ctx, P, torch.as_tensor(embed_right(W * inv, Lh, Lh), device=P.device))   # rows_pad x 2 Lh
         del P
-        self.U = Em @ W                                         # n x m complex128, orthonormal
+        Small = Em @ W                                          # r x m complex128, orthonormal
+        if side == 0:
+            self.Vp, self.U = Tall, Small                       # V: p_pad x 2 Lh panel, U: n x m
+        else:                                                   # features are the small side: V = E_m W, U = the tall side
+            Vp = torch.zeros((A.p_pad, 2 * Lh), dtype=torch.float32, device=dev)
+            Vp[:p, :m] = torch.as_tensor(Small.real, dtype=torch.float32)
+            Vp[:p, Lh:Lh + m] = torch.as_tensor(Small.imag, dtype=torch.float32)
+            t = Tall[:n].double().cpu().numpy()
+            self.Vp, self.U = Vp, t[:, :m] + 1j * t[:, Lh:Lh + m]
         self.s = s
         self.m, self.Lh, self.n, self.p, self.p_pad = m, Lh, n, p, A.p_pad
         self.singular_values_all = np.sqrt(lam)

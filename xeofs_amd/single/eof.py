@@ -238,9 +238,6 @@ class ComplexEOF(EOF):
         (xeofs_amd/cpca.py), followed by the decomposer's sign rule."""
         from ..cpca import ComplexResidentPCA
 
-        if A.n > A.p:
-            raise NotImplementedError("ComplexEOF / HilbertEOF with more than 54 modes (or a variance-based n_modes) needs "
-                                      "n_samples <= n_features (the Hermitian Gram matrix lives on the sample side)")
         pca = ComplexResidentPCA(self.ctx, self.n_modes, self._decomposer_kwargs.get("init_rank_reduction", 0.3))
         pca.fit(A, B, total_variance)
         V = pca.components()                                          # p x m complex64
