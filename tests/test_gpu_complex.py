@@ -284,6 +284,15 @@ def test_engine_complex_rsvd_vs_exact(ctx, n, p, k, prec):
     assert np.linalg.norm(Z - rec) <= np.linalg.norm(Z - best) * (1 + 1e-4)
     assert np.abs(U.conj().T @ U - np.eye(k)).max() < 2e-5 and np.abs(V.conj().T @ V - np.eye(k)).max() < 2e-5
     assert (orc.deterministic_sign_multiplier(V.conj().T) == 1).all()
+    if prec == "f16x3":
+        # the panel-level driver (the feature-sharded path's single-rank form; 33 .. 64 columns: 128-wide real panels)
+        from xeofs_amd.complex_svd import complex_rsvd
+
+        Up, sp, Vp = complex_rsvd(ctx, A, B, k, random_state=3)
+        assert np.all(np.abs(sp - se[:k]) <= 1e-5 * se[:k] + 2e-6 * se[0]), (sp, se[:k])
+        recp = (Up.astype(np.complex128) * sp) @ Vp.astype(np.complex128).conj().T
+        assert np.linalg.norm(Z - recp) <= np.linalg.norm(Z - best) * (1 + 1e-4)
+        assert (orc.deterministic_sign_multiplier(Vp.conj().T) == 1).all()
     A.free(); B.free()
 
 

@@ -400,7 +400,7 @@ def test_documented_size_limits_fail_loudly(ctx):
     A = engine.from_dense(ctx, rng.standard_normal((300, 400)).astype(np.float32))
     B = engine.from_dense(ctx, rng.standard_normal((300, 400)).astype(np.float32))
     with pytest.raises(NotImplementedError, match="complex sketch width"):
-        complex_rsvd(ctx, A, B, 30)                      # panel-level (sharded) driver: 30 + 10 oversamples > 32
+        complex_rsvd(ctx, A, B, 60)                      # panel-level (sharded) driver: 60 + 10 oversamples > 64
     with pytest.raises(ValueError, match="complex sketch width"):
         engine.rsvd_c64(ctx, A, B, 60)                   # engine entry: 60 + 10 oversamples > 64
     Z = torch.zeros((A.n_pad, 32), device="cuda")

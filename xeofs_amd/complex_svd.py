@@ -20,25 +20,26 @@ import numpy as np
 
 from . import engine
 
-HALF = 32          # complex panels are [Re(32 cols) | Im(32 cols)]
+HALF = 32          # complex panels are [Re(32 cols) | Im(32 cols)]; sketches of 33 .. 64 columns: [Re(64) | Im(64)]
 LP = 2 * HALF
+MAX_HALF = 64
 
 
-def _embed_right(M):
-    """real 64x64 matrix E with [Pr|Pi] @ E = [Re(P M) | Im(P M)] for complex M (l x m, padded)."""
-    E = np.zeros((LP, LP))
+def _embed_right(M, half=HALF):
+    """real (2 half) x (2 half) matrix E with [Pr|Pi] @ E = [Re(P M) | Im(P M)] for complex M (l x m, padded)."""
+    E = np.zeros((2 * half, 2 * half))
     l, m = M.shape
     E[:l, :m] = M.real
-    E[HALF:HALF + l, :m] = -M.imag
-    E[:l, HALF:HALF + m] = M.imag
-    E[HALF:HALF + l, HALF:HALF + m] = M.real
+    E[half:half + l, :m] = -M.imag
+    E[:l, half:half + m] = M.imag
+    E[half:half + l, half:half + m] = M.real
     return E
 
 
-def _hermitian_gram(G, l):
-    """complex l x l Gram P^H P from the real 64x64 Gram of [Pr|Pi]."""
-    rr, ri = G[:l, :l], G[:l, HALF:HALF + l]
-    ir, ii = G[HALF:HALF + l, :l], G[HALF:HALF + l, HALF:HALF + l]
+def _hermitian_gram(G, l, half=HALF):
+    """complex l x l Gram P^H P from the real Gram of [Pr|Pi]."""
+    rr, ri = G[:l, :l], G[:l, half:half + l]
+    ir, ii = G[half:half + l, :l], G[half:half + l, half:half + l]
     H = (rr + ii) + 1j * (ri - ir)
     return 0.5 * (H + H.conj().T)
 
@@ -54,9 +55,13 @@ class ComplexOps:
             raise ValueError("real and imaginary parts must have the same shape")
         self.ctx, self.A, self.B = ctx, A, B
         self.n, self.p, self.n_pad, self.p_pad = A.n, A.p, A.n_pad, A.p_pad
+        self.half = HALF
+
+    def set_half(self, half):               # 32 or 64 complex columns per panel
+        self.half = int(half)
 
     def import_panel(self, host, side):
-        return engine.panel_import(self.ctx, host, self.n_pad if side == "n" else self.p_pad, LP)
+        return engine.panel_import(self.ctx, host, self.n_pad if side == "n" else self.p_pad, 2 * self.half)
 
     def zh_mul(self, Wn, final=False):      # feature-side panel = Z^H W   (local)
         pr = self.ctx.precision[1 if final else 0]
@@ -79,13 +84,13 @@ class ComplexOps:
 
     def right_mul(self, P, M):
         torch = engine._torch()
-        return engine.panel_matmul(self.ctx, P, torch.as_tensor(_embed_right(M), device=P.device))
+        return engine.panel_matmul(self.ctx, P, torch.as_tensor(_embed_right(M, self.half), device=P.device))
 
     def argminmax(self, P, rows):
         return engine.panel_colargminmax(self.ctx, P, rows)
 
     def export(self, P, rows, sign):
-        return engine.panel_export(self.ctx, P, rows, LP, sign)
+        return engine.panel_export(self.ctx, P, rows, 2 * self.half, sign)
 
 
 class _NoComm:
@@ -110,9 +115,15 @@ def complex_rsvd(ctx, A, B, k: int, n_oversamples: int = 10, n_iter="auto", rand
     if k > r:
         raise ValueError(f"n_modes must be less than or equal to the rank of the dataset (rank = {r}).")
     l = min(k + n_oversamples, r)
-    if l > HALF:
-        raise NotImplementedError(f"complex sketch width {l} > {HALF} is not supported by this build "
-                                  f"(n_modes + n_oversamples <= {HALF})")
+    if l > MAX_HALF:
+        raise NotImplementedError(f"complex sketch width {l} > {MAX_HALF} is not supported by this build "
+                                  f"(n_modes + n_oversamples <= {MAX_HALF})")
+    half = HALF if l <= HALF else MAX_HALF      # wider sketches: 128-column real panels, two column blocks per pass
+    if hasattr(ops, "set_half"):
+        ops.set_half(half)
+    elif half != HALF:
+        raise NotImplementedError(f"these panel operations hold {HALF} complex columns (sketch width {l})")
+    lp = 2 * half
     if n_iter == "auto" or n_iter is None:
         n_iter = 7 if k < 0.1 * r else 4
     if l == r:      # full-width sketch spans everything: identity, not an ill-conditioned square Gaussian
@@ -131,7 +142,7 @@ def complex_rsvd(ctx, A, B, k: int, n_oversamples: int = 10, n_iter="auto", rand
         G = ops.gram_real(P)
         if side == "p":
             G = comm.sum_(G)
-        return _hermitian_gram(G.detach().cpu().numpy(), l)
+        return _hermitian_gram(G.detach().cpu().numpy(), l, half)
 
     def orth(P, side):
         """Q = P (V diag(w^-1/2)), P^H P = V diag(w) V^H; dependent directions -> zero columns"""
@@ -147,14 +158,14 @@ def complex_rsvd(ctx, A, B, k: int, n_oversamples: int = 10, n_iter="auto", rand
     else:
         small, tall, fwd, bwd = "p", "n", to_sample, to_feature
         rows0 = omega[p_offset:p_offset + p_loc]
-    host = np.zeros((rows0.shape[0], LP), np.float32)
+    host = np.zeros((rows0.shape[0], lp), np.float32)
     host[:, :l] = rows0
     Z = ops.import_panel(host, small)
     # like the real driver: re-normalise the tall panel inside the iteration while it is small (sharded.py)
     tall_total = n if tall == "n" else p
     from .sharded import _orth_tall
 
-    orth_tall = _orth_tall(tall_total, LP, getattr(ctx, "precision", ("f16x3",))[0])
+    orth_tall = _orth_tall(tall_total, lp, getattr(ctx, "precision", ("f16x3",))[0])
     orth_rest = orth_tall
     for it in range(int(n_iter)):
         Yt = fwd(Z)
@@ -187,7 +198,7 @@ def complex_rsvd(ctx, A, B, k: int, n_oversamples: int = 10, n_iter="auto", rand
         for idx in (amax[:k].cpu(), amin[:k].cpu()):
             if p_loc > 0:
                 vr = Vp[idx, cols].detach().cpu().numpy().astype(np.float64)
-                vi = Vp[idx, cols + HALF].detach().cpu().numpy().astype(np.float64)
+                vi = Vp[idx, cols + half].detach().cpu().numpy().astype(np.float64)
             else:
                 vr, vi = np.full(k, np.nan), np.zeros(k)
             cand.append((vr, -vi))          # conj flips the imaginary part
@@ -195,7 +206,7 @@ def complex_rsvd(ctx, A, B, k: int, n_oversamples: int = 10, n_iter="auto", rand
         if comm.world > 1:
             mr, mi, nr, ni = _global_lex_extrema(comm, mr, mi, nr, ni)
         sign = np.where(np.hypot(mr, mi) >= np.hypot(nr, ni), 1.0, -1.0)
-    sg = np.concatenate([sign, np.ones(HALF - k), sign, np.ones(HALF - k)])
+    sg = np.concatenate([sign, np.ones(half - k), sign, np.ones(half - k)])
 
     def export(P, rows):
         """signed [Re | Im] columns -> interleaved complex64 on the device -> one copy into a page-locked host array
@@ -205,10 +216,10 @@ def complex_rsvd(ctx, A, B, k: int, n_oversamples: int = 10, n_iter="auto", rand
             full = ops.export(P, rows, sg)
             out = np.empty((rows, k), dtype=np.complex64)
             out.real = full[:, :k]
-            out.imag = full[:, HALF:HALF + k]
+            out.imag = full[:, half:half + k]
             return out
         sgt = torch.as_tensor(sign, dtype=torch.float32, device=P.device)
-        z = torch.stack((P[:rows, :k] * sgt, P[:rows, HALF:HALF + k] * sgt), dim=-1)     # [rows, k, 2]
+        z = torch.stack((P[:rows, :k] * sgt, P[:rows, half:half + k] * sgt), dim=-1)     # [rows, k, 2]
         out = engine._host_out((rows, k), np.complex64)
         torch.from_numpy(out.view(np.float32).reshape(rows, k, 2)).copy_(z)
         return out
