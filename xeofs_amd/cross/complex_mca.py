@@ -410,7 +410,7 @@ class HilbertCPCCA(ComplexCPCCA):
 class ComplexCPCCARotator:
     """Drop-in for xeofs.cross.ComplexCPCCARotator (cross/cpcca_rotator.py:472-534 over :20-420): Varimax
     (power = 1) / Promax rotation of a fitted complex cross model.  The stacked complex feature-space loadings [Qx; Qy] sqrt(s)
-    are rotated on the device as one [Re | Im] panel (`rotation.cpromax_panel`, up to 32 modes); their images in the
+    are rotated on the device as one [Re | Im] panel (`rotation.cpromax_panel`); their images in the
     analysis space are Q sqrt(s) rotation_matrix -- k x k algebra (as in `CPCCARotator`)."""
 
     _model_name = "Rotated Complex CPCCA"
@@ -460,7 +460,7 @@ class ComplexCPCCARotator:
         sc1 = (np.asarray(model.data["scores1"])[:, :k] / scaling) @ RinvT * norm1
         sc2 = (np.asarray(model.data["scores2"])[:, :k] / scaling) @ RinvT * norm2
         # sign rule on the stacked rotated loadings (xarray_utils.py:273-301; numpy's lexicographic complex max / min)
-        CH = rotation.CH
+        CH = Xrot.shape[1] // 2
         amax, amin = engine.panel_colargminmax(self.ctx, Xrot, ptot)
         cols = torch.arange(k, device=Xrot.device)
         pick = lambda ix: (Xrot[ix[:k], cols].double().cpu().numpy(), Xrot[ix[:k], cols + CH].double().cpu().numpy())
@@ -470,7 +470,7 @@ class ComplexCPCCARotator:
         for norm, lo, hi in ((norm1, 0, p1), (norm2, p1, ptot)):
             M = np.zeros((k, k), dtype=complex)
             M[idx, np.arange(k)] = sign[idx] / norm[idx]
-            blk = engine.panel_matmul(self.ctx, Xrot[lo:], rotation._dev(rotation._cembed(M), Xrot))[:hi - lo].cpu().numpy()
+            blk = engine.panel_matmul(self.ctx, Xrot[lo:], rotation._dev(rotation._cembed(M, CH), Xrot))[:hi - lo].cpu().numpy()
             c = np.empty((hi - lo, k), np.complex64)
             c.real, c.imag = blk[:, :k], blk[:, CH:CH + k]
             F.append(c)

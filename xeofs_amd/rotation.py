@@ -148,47 +148,82 @@ def finish_on_device(ctx, Xrot, p, m):
 # complex loadings (the rotation of ComplexEOF / HilbertEOF models, xeofs/single/eof_rotator.py:294-400; `_promax` /
 # `_varimax` "also work for complex numbers", _rotation.py:16,105)
 # ---------------------------------------------------------------------------------------------------------------------
-CH = 32            # complex panels are [Re (32 columns) | Im (32 columns)]: up to 32 complex modes
+CH = 32            # complex panels of the fused step: [Re (32 columns) | Im (32 columns)]
+MAX_CROT_MODES = 128
 
 
-def _cembed(M):
-    """real 64 x 64 matrix E with [Pr | Pi] @ E = [Re(P M) | Im(P M)] for a complex m x m' matrix M"""
+def _cwidth(m):
+    """complex columns per panel half: 32 (fused step kernel), else 64 / 128 (library-GEMM step)"""
+    return CH if m <= CH else (64 if m <= 64 else 128)
+
+
+def _cembed(M, ch=CH):
+    """real (2 ch) x (2 ch) matrix E with [Pr | Pi] @ E = [Re(P M) | Im(P M)] for a complex m x m' matrix M"""
     l, m = M.shape
-    E = np.zeros((2 * CH, 2 * CH))
+    E = np.zeros((2 * ch, 2 * ch))
     E[:l, :m] = M.real
-    E[CH:CH + l, :m] = -M.imag
-    E[:l, CH:CH + m] = M.imag
-    E[CH:CH + l, CH:CH + m] = M.real
+    E[ch:ch + l, :m] = -M.imag
+    E[:l, ch:ch + m] = M.imag
+    E[ch:ch + l, ch:ch + m] = M.real
     return E
 
 
-def _cblocks(G, m):
-    """X^H T (complex m x m) from the real 64 x 64 product [Xr | Xi]^T [Tr | Ti]"""
-    rr, ri = G[:m, :m], G[:m, CH:CH + m]
-    ir, ii = G[CH:CH + m, :m], G[CH:CH + m, CH:CH + m]
+def _cblocks(G, m, ch=CH):
+    """X^H T (complex m x m) from the real product [Xr | Xi]^T [Tr | Ti]"""
+    rr, ri = G[:m, :m], G[:m, ch:ch + m]
+    ir, ii = G[ch:ch + m, :m], G[ch:ch + m, ch:ch + m]
     return (rr + ii) + 1j * (ri - ir)
 
 
+def _crot_step(ctx, X, R, auxh, mode, power, ch, m, block=1 << 17):
+    """One step of the complex loop on the [Re | Im] panel X: the complex m x m matrix X^H (b (|b|^2 - aux)) (mode 2) or
+    b^H ((b / aux) (|b| / aux)^(power-1)) (mode 3), b = X R.  32 columns per half: the fused kernel (modes 2 / 3 of
+    `eofx_panel_rot_step_f64`); wider: complex128 library GEMMs block of rows by block of rows."""
+    if ch == CH:
+        aux = np.zeros(2 * ch) if mode == 2 else np.ones(2 * ch)
+        aux[:m] = aux[ch:ch + m] = auxh
+        G = engine.panel_rot_step(ctx, X, _dev(_cembed(R, ch), X), _dev(aux, X), mode, float(power))
+        return _cblocks(G.cpu().numpy(), m, ch)
+    torch = engine._torch()
+    Rc = torch.zeros((ch, ch), dtype=torch.complex128, device=X.device)
+    Rc[:m, :m] = torch.as_tensor(np.ascontiguousarray(R), device=X.device)
+    a = torch.zeros(ch, dtype=torch.float64, device=X.device) if mode == 2 else torch.ones(ch, dtype=torch.float64, device=X.device)
+    a[:m] = torch.as_tensor(np.asarray(auxh, dtype=np.float64), device=X.device)
+    G = torch.zeros((ch, ch), dtype=torch.complex128, device=X.device)
+    for r0 in range(0, X.shape[0], block):
+        x = torch.complex(X[r0:r0 + block, :ch].double(), X[r0:r0 + block, ch:].double())
+        b = x @ Rc
+        a2 = b.real * b.real + b.imag * b.imag
+        if mode == 2:
+            G += x.conj().T @ (b * (a2 - a))
+        else:
+            z = b / a
+            G += b.conj().T @ (z if power == 1 else z * (a2.sqrt() / a).pow(power - 1.0))
+    return G[:m, :m].cpu().numpy()
+
+
 def cpromax_panel(ctx, loadings: np.ndarray, power: int = 1, max_iter: int = 1000, rtol: float = 1e-8, col_scale=None):
-    """`promax_panel` for complex loadings [p, m] (m <= 32): -> ([Re | Im] panel on the device, p, m, complex rotation
-    matrix, complex phi).  Every step of the reference loop is the same fused pass (`eofx_panel_rot_step_f64`, modes
-    2 / 3) with the complex m x m matrices in their real embedding."""
+    """`promax_panel` for complex loadings [p, m]: -> ([Re | Im] panel on the device, p, m, complex rotation
+    matrix, complex phi).  Up to 32 modes every step of the reference loop is the same fused pass
+    (`eofx_panel_rot_step_f64`, modes 2 / 3) with the complex m x m matrices in their real embedding; 33 .. 128 modes
+    (rare) run the step as complex128 library GEMMs on 64 / 128-column halves (`_crot_step`)."""
     loadings = np.asarray(loadings)
     p, m = loadings.shape
     if m < 2:
         raise ValueError("Cannot rotate {:} modes (columns), but must be 2 or more.".format(m))
-    if m > CH:
-        raise NotImplementedError(f"rotation of more than {CH} complex modes is not supported by this build")
-    L = 2 * CH
+    if m > MAX_CROT_MODES:
+        raise NotImplementedError(f"rotation of more than {MAX_CROT_MODES} complex modes is not supported by this build")
+    ch = _cwidth(m)
+    L = 2 * ch
     rows_pad = (p + 511) // 512 * 512
     host = np.zeros((p, L), np.float32)
-    host[:, :m], host[:, CH:CH + m] = loadings.real, loadings.imag
+    host[:, :m], host[:, ch:ch + m] = loadings.real, loadings.imag
     Lp = engine.panel_import(ctx, host, rows_pad, L)
     del host
     if col_scale is not None:
-        Lp = engine.panel_matmul(ctx, Lp, _dev(_cembed(np.diag(np.asarray(col_scale, dtype=np.float64)).astype(complex)), Lp))
+        Lp = engine.panel_matmul(ctx, Lp, _dev(_cembed(np.diag(np.asarray(col_scale, dtype=np.float64)).astype(complex), ch), Lp))
     Xn = engine.panel_row_normalize(ctx, Lp)                       # Kaiser: rows / (sqrt(sum |x|^2) + eps)
-    S = _cblocks(engine.panel_gram(ctx, Xn).cpu().numpy(), m)      # X^H X
+    S = _cblocks(engine.panel_gram(ctx, Xn).cpu().numpy(), m, ch)  # X^H X
     S = 0.5 * (S + S.conj().T)
     R = np.eye(m, dtype=complex)
     alpha = 1.0 / p
@@ -196,9 +231,7 @@ def cpromax_panel(ctx, loadings: np.ndarray, power: int = 1, max_iter: int = 100
     for _ in range(int(max_iter)):
         delta_old = delta
         W = np.einsum("ij,ik,kj->j", R.conj(), S, R).real          # column sums of |X R|^2
-        aux = np.zeros(L)
-        aux[:m] = aux[CH:CH + m] = alpha * W
-        G = _cblocks(engine.panel_rot_step(ctx, Xn, _dev(_cembed(R), Xn), _dev(aux, Xn), 2).cpu().numpy(), m)
+        G = _crot_step(ctx, Xn, R, alpha * W, 2, 1.0, ch, m)
         U, svals, VT = np.linalg.svd(G)
         R = U @ VT
         delta = float(np.sum(svals))
@@ -209,11 +242,9 @@ def cpromax_panel(ctx, loadings: np.ndarray, power: int = 1, max_iter: int = 100
     rot_mat = R
     phi = np.eye(m, dtype=complex)
     if power != 1:
-        B = engine.panel_matmul(ctx, Xn, _dev(_cembed(R), Xn))     # X R (normalised, rotated)
+        B = engine.panel_matmul(ctx, Xn, _dev(_cembed(R, ch), Xn)) # X R (normalised, rotated)
         cmax = engine.cpanel_colabsmax(ctx, B, p).cpu().numpy()[:m].astype(np.float64)
-        aux = np.ones(L)
-        aux[:m] = aux[CH:CH + m] = cmax
-        XtP = _cblocks(engine.panel_rot_step(ctx, Xn, _dev(_cembed(R), Xn), _dev(aux, Xn), 3, float(power)).cpu().numpy(), m)
+        XtP = _crot_step(ctx, Xn, R, cmax, 3, float(power), ch, m)
         XtX = R.conj().T @ S @ R
         Lm = np.linalg.inv(XtX) @ XtP
         try:
@@ -224,7 +255,7 @@ def cpromax_panel(ctx, loadings: np.ndarray, power: int = 1, max_iter: int = 100
         rot_mat = R @ Lm
         L_inv = np.linalg.inv(Lm)
         phi = L_inv @ L_inv.conj().T
-    Xrot = engine.panel_matmul(ctx, Lp, _dev(_cembed(rot_mat), Lp))   # (h Xn) rot_mat = loadings rot_mat
+    Xrot = engine.panel_matmul(ctx, Lp, _dev(_cembed(rot_mat, ch), Lp))   # (h Xn) rot_mat = loadings rot_mat
     return Xrot, p, m, rot_mat, phi
 
 
@@ -233,6 +264,7 @@ def cfinish_on_device(ctx, Xrot, p, m):
     components, the reference's +-1 sign from numpy's lexicographic complex max / min (real part decides; ties on it are
     measure-zero).  -> (components [p, m] complex64 host, expvar (unsorted), idx, sign (unsorted))."""
     torch = engine._torch()
+    CH = Xrot.shape[1] // 2
     Gd = np.diag(engine.panel_gram(ctx, Xrot).cpu().numpy())
     expvar = (Gd[:m] + Gd[CH:CH + m]).copy()
     idx = np.argsort(expvar)[::-1]
@@ -243,7 +275,7 @@ def cfinish_on_device(ctx, Xrot, p, m):
     sign = np.where(np.hypot(mr, mi) >= np.hypot(nr, ni), 1.0, -1.0)
     M = np.zeros((m, m), dtype=complex)                   # column j of the output = column idx[j], scaled and signed
     M[idx, np.arange(m)] = sign[idx] / np.sqrt(expvar[idx])
-    out = engine.panel_matmul(ctx, Xrot, _dev(_cembed(M), Xrot))[:p].cpu().numpy()
+    out = engine.panel_matmul(ctx, Xrot, _dev(_cembed(M, CH), Xrot))[:p].cpu().numpy()
     comps = np.empty((p, m), np.complex64)
     comps.real, comps.imag = out[:, :m], out[:, CH:CH + m]
     return comps, expvar, idx, sign
