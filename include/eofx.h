@@ -248,6 +248,9 @@ int eofx_mat_sumsq_f64(eofx_ctx *ctx, const eofx_mat *m, double *out);
  * the cross models divide by (utils/optional/statistics.py:50-54, cross/cpcca.py:642-845).            */
 int eofx_panel_rownorm_f64(eofx_ctx *ctx, const float *P, int64_t rows, int L, double *out);
 int eofx_mat_feature_norms_f64(eofx_ctx *ctx, const eofx_mat *m, double *out);
+/* Euclidean norm of every SAMPLE (row) of the resident matrix, out[n]; an in-place matrix is read through its Scaler map
+ * (no layout is built).  The bootstrap members' total variance is a count-weighted sum of their squares.      */
+int eofx_mat_sample_norms_f64(eofx_ctx *ctx, const eofx_mat *m, double *out);
 /* Bootstrap resampling (validation/bootstrapper.py:78-91): out = rows `rows[0..n_rows)` (host indices
  * into src, drawn with replacement) of the resident matrix, re-centred per feature when `center`
  * (the bootstrap model is `EOF(n_modes)` with its default center=True).  mean (host, [p], may be NULL)

@@ -62,3 +62,39 @@ def test_eof_bootstrapper_vs_oracle(ctx):
     bs2 = xe.validation.EOFBootstrapper(n_bootstraps=5, seed=11).fit(model, random_state=0)
     assert np.array_equal(bs2.data["scores"], bs.data["scores"])
     assert (bs.explained_variance_ratio().values <= 1).all()
+
+
+def test_bootstrap_member_operator(ctx, monkeypatch):
+    """`BootstrapOps`: the member X_b = H X through panel products on the ORIGINAL matrix -- against the resampled,
+    re-centred matrix itself, for both renderings of H (dense GEMM up to DENSE_MAX samples, sorted segment sums beyond),
+    on an in-place matrix (no layout is built), plus the member's total variance from the row norms."""
+    import torch
+    from xeofs_amd import engine
+    from xeofs_amd.validation.bootstrapper import BootstrapOps
+
+    n, p = 333, 1100
+    rng = np.random.default_rng(4)
+    X = (rng.standard_normal((n, p)) * rng.uniform(0.5, 3, p) + rng.standard_normal(p)).astype(np.float32)
+    mat, _ = engine.preprocess(ctx, torch.as_tensor(X, device="cuda"), want_stats=False, keep_raw=True, in_place=True)
+    Xc = X.astype(np.float64) - X.astype(np.float64).mean(0)
+    idx = rng.integers(0, n, n)
+    Xb = Xc[idx] - Xc[idx].mean(0)
+    Z = torch.zeros((mat.n_pad, 32), device="cuda"); Z[:n] = torch.randn((n, 32), device="cuda")
+    Y = torch.zeros((mat.p_pad, 32), device="cuda"); Y[:p] = torch.randn((p, 32), device="cuda")
+    outs = []
+    for dense_max in (BootstrapOps.DENSE_MAX, 0):
+        monkeypatch.setattr(BootstrapOps, "DENSE_MAX", dense_max)
+        ops = BootstrapOps(ctx, mat, idx)
+        assert (ops.H is not None) == (dense_max > 0)
+        t = ops.tmul(Z)[:p].double().cpu().numpy()
+        m = ops.mul(Y)[:n].double().cpu().numpy()
+        want_t = Xb.T @ Z[:n].double().cpu().numpy()
+        want_m = Xb @ Y[:p].double().cpu().numpy()
+        assert np.abs(t - want_t).max() <= 2e-5 * np.abs(want_t).max()
+        assert np.abs(m - want_m).max() <= 2e-5 * np.abs(want_m).max()
+        c = ops.counts.cpu().numpy()
+        tv = (c @ engine.sample_norms(ctx, mat) ** 2 - n * ops.mean_sumsq()) / (n - 1)
+        assert np.isclose(tv, (Xb ** 2).sum() / (n - 1), rtol=1e-5)
+        outs.append((t, m))
+    assert np.allclose(outs[0][0], outs[1][0], rtol=0, atol=2e-5 * np.abs(outs[0][0]).max())
+    assert mat.layout()[0] in (False, 0)          # still in place: no layout was materialised

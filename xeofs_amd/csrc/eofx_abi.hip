@@ -3012,6 +3012,26 @@ extern "C" int eofx_mat_feature_norms_f64(eofx_ctx* ctx, const eofx_mat* m, doub
   return launch_rownorm(ctx, m->Xt, m->p, m->n, m->n_pad, out);   // rows of X^T = features
 }
 
+// Euclidean norm of every sample (row) of the resident matrix, out[n] float64 host|device: without building a layout
+// for an in-place matrix (the raw field goes through the Scaler map on the fly)
+extern "C" int eofx_mat_sample_norms_f64(eofx_ctx* ctx, const eofx_mat* m, double* out) {
+  if (!ctx || !m || !out) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  CHK(set_device(ctx));
+  CHK(arena_reserve(ctx, (size_t)m->n * sizeof(double) + 4096));
+  if (!m->X && m->raw && m->aff) {
+    ArenaScope scope(ctx);
+    ARENA(double, tmp, m->n);
+    hipLaunchKernelGGL(rownorm_aff_kernel, dim3((int)((m->n + 3) / 4)), dim3(256), 0, ctx->stream, m->raw, m->n, m->p, m->raw_ld,
+                       m->aff, m->p_pad, tmp);
+    KCHK();
+    HIPCHK(hipMemcpyAsync(out, tmp, sizeof(double) * m->n, hipMemcpyDefault, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return EOFX_OK;
+  }
+  CHK(ensure_X(ctx, m));
+  return launch_rownorm(ctx, m->X, m->n, m->p, m->p_pad, out);
+}
+
 extern "C" int eofx_panel_row_normalize_f32(eofx_ctx* ctx, const float* P, int64_t rows_pad, int L, float* out) {
   if (!ctx || !P || !out) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
   CHK(set_device(ctx));

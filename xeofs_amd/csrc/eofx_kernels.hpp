@@ -2281,4 +2281,21 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ 
   if (lane == 0) out[r] = sqrt(s);
 }
 
+// the same over the RAW field of an in-place matrix: rows of aff_map(raw) (see atb_f16_kernel<NB, true>)
+__global__ __launch_bounds__(256) void rownorm_aff_kernel(const float* __restrict__ P, int64_t rows, int64_t L, int64_t ld,
+                                                          const float* __restrict__ aff, int64_t aff_ld,
+                                                          double* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  double s = 0.0;
+  for (int64_t c = lane; c < L; c += 64) {
+    const double v = (double)aff_map(P[r * ld + c], aff[c], aff[aff_ld + c], aff[2 * aff_ld + c]);
+    s += v * v;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) out[r] = sqrt(s);
+}
+
 }  // namespace eofx

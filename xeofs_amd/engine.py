@@ -594,6 +594,13 @@ def feature_norms(ctx: Context, mat: ResidentMatrix) -> np.ndarray:
     return out
 
 
+def sample_norms(ctx: Context, mat: ResidentMatrix) -> np.ndarray:
+    """sqrt(sum over features of x^2) per sample of the resident matrix (no layout is built for an in-place matrix)"""
+    out = np.empty(mat.n, np.float64)
+    raise_for(ctx.lib.eofx_mat_sample_norms_f64(ctx.handle, mat.handle, ptr(out)), ctx.handle)
+    return out
+
+
 def rsvd_c64(ctx: Context, A: ResidentMatrix, B: ResidentMatrix, k: int, n_oversamples: int = 10, n_iter="auto",
              random_state=None, flip: bool = True, omega=None, device_out: bool = False):
     """complex randomized SVD of Z = A + iB (eofx_rsvd_c64) -> (U[n,k] complex64, s[k] float32, V[p,k] complex64);

@@ -2,10 +2,16 @@
 (xeofs/validation/bootstrapper.py:40-135): refit the EOF model `n_bootstraps` times on rows of the
 preprocessed data drawn with replacement.
 
-The fitted model's matrix is already resident in HBM, so a bootstrap member is a row gather inside the
-statistics / apply kernels (`eofx_resample_f32`: re-centre + both layouts, no host round trip), the usual
-randomized SVD, and one projection of the *original* resident matrix on the member's components
-(`bst_model.transform(input_data)` = (X - 1 mean_b^T) V_b = X V_b - mean_b^T V_b).
+The fitted model's matrix X is already resident in HBM and a member never copies it: rows drawn with replacement and
+re-centred are  X_b = H X  with the n x n matrix  H = G - 1 c^T / n  (G the row selector, c the draw counts), so both
+products of the member's randomized SVD run on the ORIGINAL matrix with the small sample-side panel transformed,
+    X_b^T Z = X^T (H^T Z),      X_b Y = H (X Y)
+(`BootstrapOps`: a deterministic segment sum and a row gather on n x 64 panels), the member's total variance is
+(c . |x_r|^2 - n |m_b|^2) / (n - 1) from the row norms of X (once) and one extra product X^T c, and
+`bst_model.transform(input_data)` = (X - 1 m_b^T) V_b = X V_b - c^T (X V_b) / n.  A member therefore costs its 16
+passes over the field plus one, and bootstrapping an in-place model keeps HBM at 1x the field (the earlier
+`eofx_resample_f32` route -- gather inside the statistics / apply kernels into a second two-layout matrix -- remains
+for callers that want the resampled matrix itself).
 The resampling indices come from `np.random.default_rng(seed).choice(n, n, replace=True)` exactly as in the
 reference, so a seed selects the same bootstrap members.
 """
@@ -17,7 +23,87 @@ import datetime
 import numpy as np
 
 from .. import __version__, engine, labelled
+from ..sharded import HipPanelOps, sharded_rsvd
 from ..single.eof import EOF
+
+
+class _Solo:
+    """the panel-level driver's communicator for one rank (a member never communicates, whatever the process group)"""
+    active, rank, world = False, 0, 1
+
+    def sum_(self, t):
+        return t
+
+    max_ = min_ = sum_
+
+
+class BootstrapOps(HipPanelOps):
+    """Panel products of the bootstrap member X_b = H X on the resident X (H = G - 1 c^T / n, see the module docstring).
+    Sample-side panels are indexed by draw; everything added here is float64 arithmetic on n x L panels in a fixed
+    order (sorted segment sums, no atomics), so a member is reproducible bit for bit."""
+
+    DENSE_MAX = 24000       # up to this many samples H is held as a dense float32 matrix (2.3 GB at the limit)
+
+    def __init__(self, ctx, mat, idx):
+        super().__init__(ctx, mat)
+        torch = engine._torch()
+        dev = f"cuda:{ctx.device}"
+        n = mat.n
+        self.idx = torch.as_tensor(np.ascontiguousarray(idx, dtype=np.int64), device=dev)
+        self.counts = torch.bincount(self.idx, minlength=n).double()
+        self.H = None
+        if n <= self.DENSE_MAX:
+            # H = G - 1 c^T / n as a dense n x n float32 matrix: both transformations are one library GEMM on an
+            # n x L panel (0.2 ms at n = 10 000); entries 1 - c/n, -c/n are rounded once, sums have <= max(c) + 1 terms
+            H = (-self.counts / n).float().repeat(n, 1)
+            H[torch.arange(n, device=dev), self.idx] += 1.0
+            self.H = H
+        else:
+            self.order = torch.argsort(self.idx, stable=True)
+            uniq, cnt = torch.unique_consecutive(self.idx[self.order], return_counts=True)
+            self.uniq, self.ends = uniq, torch.cumsum(cnt, 0) - 1
+
+    def _ht(self, Zn):            # H^T Z = G^T Z - c (1^T Z) / n
+        torch = engine._torch()
+        n = self.n
+        out = torch.zeros_like(Zn)
+        if self.H is not None:
+            torch.matmul(self.H.T, Zn[:n], out=out[:n])
+            return out
+        Zd = Zn[:n].double()
+        cs = torch.cumsum(Zd[self.order], 0)                  # sorted segment sums: fixed order, no atomics
+        seg = cs[self.ends].clone()
+        seg[1:] -= cs[self.ends[:-1]]
+        acc = torch.zeros((n, Zn.shape[1]), dtype=torch.float64, device=Zn.device)
+        acc[self.uniq] = seg
+        acc -= self.counts[:, None] * (Zd.sum(0) / n)
+        out[:n] = acc.float()
+        return out
+
+    def _h(self, Wn):             # H W = W[idx] - 1 (c^T W) / n
+        torch = engine._torch()
+        n = self.n
+        out = torch.zeros_like(Wn)
+        if self.H is not None:
+            torch.matmul(self.H, Wn[:n], out=out[:n])
+            return out
+        Wd = Wn[:n].double()
+        out[:n] = (Wd[self.idx] - (self.counts @ Wd) / n).float()
+        return out
+
+    def tmul(self, Zn, final=False):
+        return super().tmul(self._ht(Zn), final)
+
+    def mul(self, Yp, final=False):
+        return self._h(super().mul(Yp, final))
+
+    def mean_sumsq(self):
+        """|m_b|^2 = |X^T c|^2 / n^2 (one product with c in the first column of a 32-wide panel)"""
+        torch = engine._torch()
+        Z = torch.zeros((self.n_pad, 32), dtype=torch.float32, device=self.idx.device)
+        Z[:self.n, 0] = self.counts.float()
+        Y = super().tmul(Z, True)
+        return float(self.gram(Y)[0, 0]) / float(self.n) ** 2
 
 
 class EOFBootstrapper(EOF):
@@ -49,18 +135,20 @@ class EOFBootstrapper(EOF):
         totvar = np.empty(n_boot)
         comps = np.empty((n_boot, p, k), np.float32)
         scores = np.empty((n_boot, n, k), np.float32)
+        r2 = engine.sample_norms(ctx, mat) ** 2                        # |x_r|^2, once
+        comm = _Solo()
         for b in range(n_boot):
             idx = rng.choice(n, n, replace=True)                       # bootstrapper.py:79
-            bmat, mean_b, tv = engine.resample(ctx, mat, idx, center=True)
-            U, s, V = engine.rsvd(ctx, bmat, k, random_state=None if random_state is None else random_state + b)
-            bmat.free()
+            ops = BootstrapOps(ctx, mat, idx)
+            U, s, V = sharded_rsvd(ops, comm, k, p, 0, random_state=None if random_state is None else random_state + b)
             s64 = s.astype(np.float64)
             expvar[b] = s64 ** 2 / (n - 1)                             # eof.py:104
-            totvar[b] = tv
+            c = ops.counts.cpu().numpy()
+            totvar[b] = (float(c @ r2) - n * ops.mean_sumsq()) / (n - 1)
             comps[b] = V
             # bst_model.transform(input_data): centre with the member's mean, project (eof.py:123-132)
-            proj = engine.project(ctx, mat, V).astype(np.float64) - mean_b @ V.astype(np.float64)
-            scores[b] = proj
+            proj = engine.project(ctx, mat, V).astype(np.float64)
+            scores[b] = proj - (c @ proj) / n
         # sign of each member's modes from the correlation with the model's scores (bootstrapper.py:112-121)
         ms = np.asarray(model.data["scores"], dtype=np.float64)[:, :k]
         sc = scores.astype(np.float64)
