@@ -101,15 +101,16 @@ int main(int argc, char** argv) {
   const size_t bytes = (size_t)p * n_pad * 4;
   CK(hipMalloc((void**)&dX, bytes)); CK(hipMalloc((void**)&dB, bytes));
   if (want_real) CK(hipMalloc((void**)&dA, bytes));
-  CK(hipMalloc((void**)&dh, P * 4)); CK(hipMalloc((void**)&du, 4 * n * 4)); CK(hipMalloc((void**)&dmax, 8));
+  CK(hipMalloc((void**)&dh, P * 4)); CK(hipMalloc((void**)&du, (4 * n + 4) * 4)); CK(hipMalloc((void**)&dmax, 8));
   CK(hipMemset(dmax, 0, 8));
   CK(hipMemset(dB, 0xFF, bytes));   // NaN everywhere: every element of the padded rows has to be written
   if (dA) CK(hipMemset(dA, 0xFF, bytes));
   CK(hipMemcpy(dh, hperm.data(), P * 4, hipMemcpyHostToDevice));
   {
-    std::vector<float> il((size_t)4 * n);   // the kernel reads the four vectors interleaved per sample
+    std::vector<float> il((size_t)4 * n + 4);   // the four vectors interleaved per sample, then their means
     for (int i = 0; i < n; ++i) for (int k = 0; k < 4; ++k) il[(size_t)4 * i + k] = hu[(size_t)k * n + i];
-    CK(hipMemcpy(du, il.data(), 4 * n * 4, hipMemcpyHostToDevice));
+    for (int k = 0; k < 4; ++k) { double m = 0; for (int i = 0; i < n; ++i) m += hu[(size_t)k * n + i]; il[(size_t)4 * n + k] = (float)(m / n); }
+    CK(hipMemcpy(du, il.data(), (4 * n + 4) * 4, hipMemcpyHostToDevice));
   }
   {
     std::vector<float> chunk;

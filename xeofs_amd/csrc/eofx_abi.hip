@@ -2255,7 +2255,7 @@ static int get_hilbert_setup(eofx_ctx* ctx, int64_t n, int padding, double decay
     std::vector<double> e((size_t)n), kap((size_t)(4 * n + 1));
     for (int64_t t = 0; t < n; ++t) e[t] = std::exp(-(double)t / (double)n / decay);
     for (int64_t d = -2 * n; d <= 2 * n; ++d) kap[(size_t)(d + 2 * n)] = hilbert_kappa(N, d);
-    std::vector<float> hu((size_t)4 * n);
+    std::vector<float> hu((size_t)4 * n + 4, 0.f);   // (+ the four means over the samples, one-kernel route)
     auto work = [&](int64_t lo, int64_t hi) {
       for (int64_t t = lo; t < hi; ++t) {
         double a1 = 0, a2 = 0, a3 = 0, a4 = 0;
@@ -2279,8 +2279,14 @@ static int get_hilbert_setup(eofx_ctx* ctx, int64_t n, int padding, double decay
     const int64_t step = (n + nt - 1) / nt;
     for (int t = 0; t < nt; ++t) th.emplace_back(work, t * step, std::min<int64_t>(n, (t + 1) * step));
     for (auto& t : th) t.join();
-    HIPCHK(hipMalloc((void**)&hs.u, sizeof(float) * 4 * n));
-    HIPCHK(hipMemcpy(hs.u, hu.data(), sizeof(float) * 4 * n, hipMemcpyHostToDevice));
+    if (fused)       // means of the (float32-rounded) vectors: the kernel adds coefficient * mean to the output's mean
+      for (int k = 0; k < 4; ++k) {
+        double m = 0.0;
+        for (int64_t t = 0; t < n; ++t) m += (double)hu[(size_t)(4 * t + k)];
+        hu[(size_t)(4 * n + k)] = (float)(m / (double)n);
+      }
+    HIPCHK(hipMalloc((void**)&hs.u, sizeof(float) * (4 * n + 4)));
+    HIPCHK(hipMemcpy(hs.u, hu.data(), sizeof(float) * (4 * n + 4), hipMemcpyHostToDevice));
   }
   ctx->hsetups.push_back(hs);
   *chat_out = (const cfloat*)hs.chat;

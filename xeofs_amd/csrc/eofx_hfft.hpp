@@ -294,8 +294,8 @@ inline int64_t position_frequency(int L, int64_t pos) {
 //   Xt [p][n_pad] sample-contiguous input; Bt same shape: Im of the analytic signal minus its mean over the samples;
 //   the kernel writes samples [0, P/2) of a row, so it needs n_pad <= P/2 (true for n_pad = round_up(n, 512), P >= 1024);
 //   At (optional): the input minus its mean; hperm [P]: filter table in LDS-position order (1/P folded in);
-//   u [n][4]: the four correction vectors, interleaved per sample (padding only); bmax / amax: running absmax of the
-//   outputs (float bits).
+//   u [n][4]: the four correction vectors, interleaved per sample, followed by their four means over the samples
+//   (padding only; without padding the table loads return zeros); bmax / amax: running absmax of the outputs (float bits).
 template <int L> struct plan {
   static_assert(L >= 10 && L <= 14, "circular length 2^10 .. 2^14");
   static constexpr int P = 1 << L, NT = P / 16, RL = 1 << (L & 3), N16 = L / 4;
@@ -629,28 +629,20 @@ __global__ __launch_bounds__(plan<L>::WG, HFFT_WAVES) void hilbert_fft_kernel(co
         a1a = coef[0]; a2a = coef[1]; a3a = coef[2]; a4a = coef[3];
         a1b = coef[MODE ? 0 : 6]; a2b = coef[MODE ? 1 : 7]; a3b = coef[MODE ? 2 : 8]; a4b = coef[MODE ? 3 : 9];
       }
+      // The mean over the samples of (convolution + corrections) is the mean of the convolution plus the coefficients
+      // times the means of the correction vectors (four per-setup constants stored behind the table): the reduction needs
+      // no table access, and the corrections are applied in the store loop, where registers are free to keep several
+      // 16-byte table loads in flight (one load at a time is an exposed L2 round trip per sample group).
       float va[8], vb[8];
       double ua = 0.0, ub = 0.0;
-      const rsrc_t ru = row_rsrc(u, padding ? 4u * nb : 0u);   // [n][4]: 16 bytes per sample
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         const unsigned o = tb4 + (unsigned)(c * NT * 4);
         float xa = e[c].x, xb = e[c].y;
         if constexpr (MODE == 1) {      // samples 2 j, 2 j + 1: byte offsets 2 o, 2 o + 4
-          if (padding) {
-            const f4 ue = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(ru, 8u * o, 0, 0));
-            const f4 uo = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(ru, 8u * o + 16u, 0, 0));
-            xa += a1a * ue.x + a2a * ue.y + a3a * ue.z + a4a * ue.w;
-            xb += a1a * uo.x + a2a * uo.y + a3a * uo.z + a4a * uo.w;
-          }
           xa = (2u * o < nb) ? xa : 0.f;
           xb = (2u * o + 4u < nb) ? xb : 0.f;
         } else {
-          if (padding) {
-            const f4 uu = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(ru, 4u * o, 0, 0));
-            xa += a1a * uu.x + a2a * uu.y + a3a * uu.z + a4a * uu.w;
-            xb += a1b * uu.x + a2b * uu.y + a3b * uu.z + a4b * uu.w;
-          }
           xa = (o < nb) ? xa : 0.f;
           xb = (o < nb) ? xb : 0.f;
         }
@@ -669,23 +661,50 @@ __global__ __launch_bounds__(plan<L>::WG, HFFT_WAVES) void hilbert_fft_kernel(co
         ua = wave_total(ua); ub = wave_total(ub);
       }
       if constexpr (MODE == 1) ua = ub = ua + ub;      // one series: one mean
-      const float m0 = (float)(ua / (double)n), m1 = (float)(ub / (double)n);
+      float m0 = (float)(ua / (double)n), m1 = (float)(ub / (double)n);
+      if (padding) {
+        const float* ubar = u + 4 * (size_t)n;         // means of the four correction vectors
+        const float b1 = ubar[0], b2 = ubar[1], b3 = ubar[2], b4 = ubar[3];
+        m0 += a1a * b1 + a2a * b2 + a3a * b3 + a4a * b4;
+        m1 += a1b * b1 + a2b * b2 + a3b * b3 + a4b * b4;
+      }
+      const rsrc_t ru = row_rsrc(u, padding ? 4u * nb : 0u);   // [n][4]: 16 bytes per sample
       const rsrc_t wa_ = row_rsrc(Bt + fa * n_pad, npb);
       const rsrc_t wb_ = row_rsrc(Bt + fb * n_pad, hb ? npb : 0u);
+      constexpr int UB = MODE ? 2 : 4;                         // sample groups per batch of table loads
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const unsigned o = tb4 + (unsigned)(c * NT * 4);
-        if constexpr (MODE == 1) {
-          const float xa = (2u * o < nb) ? va[c] - m0 : 0.f;
-          const float xb = (2u * o + 4u < nb) ? vb[c] - m0 : 0.f;
-          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, cf{xa, xb}), wa_, 2u * o, 0, 2);
-          run_mx = max(run_mx, max(absbits(xa), absbits(xb)));
-        } else {
-          const float xa = (o < nb) ? va[c] - m0 : 0.f;
-          const float xb = (o < nb) ? vb[c] - m1 : 0.f;
-          st_nt(xa, wa_, o);
-          st_nt(xb, wb_, o);
-          run_mx = max(run_mx, max(absbits(xa), absbits(xb)));   // (idle rows carry zeros)
+      for (int c0 = 0; c0 < 8; c0 += UB) {
+        f4 ue[UB], uo[UB];
+#pragma unroll
+        for (int q = 0; q < UB; ++q) {
+          const unsigned o = tb4 + (unsigned)((c0 + q) * NT * 4);
+          if constexpr (MODE == 1) {                           // vectors of samples 2 j and 2 j + 1
+            ue[q] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(ru, 8u * o, 0, 0));
+            uo[q] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(ru, 8u * o + 16u, 0, 0));
+          } else {
+            ue[q] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(ru, 4u * o, 0, 0));
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < UB; ++q) {
+          const int c = c0 + q;
+          const unsigned o = tb4 + (unsigned)(c * NT * 4);
+          if constexpr (MODE == 1) {
+            float xa = va[c] + (a1a * ue[q].x + a2a * ue[q].y + a3a * ue[q].z + a4a * ue[q].w) - m0;
+            float xb = vb[c] + (a1a * uo[q].x + a2a * uo[q].y + a3a * uo[q].z + a4a * uo[q].w) - m0;
+            xa = (2u * o < nb) ? xa : 0.f;
+            xb = (2u * o + 4u < nb) ? xb : 0.f;
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, cf{xa, xb}), wa_, 2u * o, 0, 2);
+            run_mx = max(run_mx, max(absbits(xa), absbits(xb)));
+          } else {
+            float xa = va[c] + (a1a * ue[q].x + a2a * ue[q].y + a3a * ue[q].z + a4a * ue[q].w) - m0;
+            float xb = vb[c] + (a1b * ue[q].x + a2b * ue[q].y + a3b * ue[q].z + a4b * ue[q].w) - m1;
+            xa = (o < nb) ? xa : 0.f;
+            xb = (o < nb) ? xb : 0.f;
+            st_nt(xa, wa_, o);
+            st_nt(xb, wb_, o);
+            run_mx = max(run_mx, max(absbits(xa), absbits(xb)));   // (idle rows carry zeros)
+          }
         }
       }
       if (At) {   // the re-centred input (only asked for when the field was not centred before): second read of y
