@@ -577,15 +577,12 @@ __global__ __launch_bounds__(plan<L>::WG, HFFT_WAVES) void hilbert_fft_kernel(co
         fresh(tr);
         const cf* const rowp = data + phys(16 * tr);
         const bool self0 = t == 0;      // row 0 pairs k = q M/16 with (16 - q) M/16 inside itself
-        cf zp[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) zp[q] = rowp[self0 ? ((16 - q) & 15) : (15 - q)];
-        __syncthreads();                // every row has been read before any is overwritten
         cf wm = wmid;
         fresh(wm);
 #define HFFT_MB(Q)                                                                                        \
         {                                                                                                 \
-          const cf a = v[slot16(Q)], bc = cf{zp[Q].x, -zp[Q].y};                                          \
+          const cf zq = rowp[self0 ? ((16 - Q) & 15) : (15 - Q)];                                         \
+          const cf a = v[slot16(Q)], bc = cf{zq.x, -zq.y};                                                \
           const cf wq = mulw32<Q>(wm);                                                                    \
           const cf r = cmul(a - bc, wq) - cmulc(a + bc, wq);                                              \
           const float hm = hperm[16 * t + Q], hp2 = hperm[P + 16 * t + Q];                                \
@@ -594,6 +591,7 @@ __global__ __launch_bounds__(plan<L>::WG, HFFT_WAVES) void hilbert_fft_kernel(co
         HFFT_MB(0) HFFT_MB(1) HFFT_MB(2) HFFT_MB(3) HFFT_MB(4) HFFT_MB(5) HFFT_MB(6) HFFT_MB(7)
         HFFT_MB(8) HFFT_MB(9) HFFT_MB(10) HFFT_MB(11) HFFT_MB(12) HFFT_MB(13) HFFT_MB(14) HFFT_MB(15)
 #undef HFFT_MB
+        __syncthreads();                // every row has been read before any is overwritten
       } else {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
