@@ -2901,7 +2901,7 @@ __attribute__((target("avx2"))) void mt_fill_avx2(uint32_t* __restrict__ x, int6
   }
 }
 #else
-void mt_fill_avx2(uint32_t* __restrict__ x, int64_t count);
+inline void mt_fill_avx2(uint32_t*, int64_t) {}   // (device pass of the single-source compile: host code only)
 #endif
 void mt_fill_generic(uint32_t* __restrict__ x, int64_t count) { EOFX_MT_FILL_BODY }
 #undef EOFX_MT_FILL_BODY
