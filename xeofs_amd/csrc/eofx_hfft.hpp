@@ -669,7 +669,7 @@ __global__ __launch_bounds__(plan<L>::WG, HFFT_WAVES) void hilbert_fft_kernel(co
       const rsrc_t ru = row_rsrc(u, padding ? 4u * nb : 0u);   // [n][4]: 16 bytes per sample
       const rsrc_t wa_ = row_rsrc(Bt + fa * n_pad, npb);
       const rsrc_t wb_ = row_rsrc(Bt + fb * n_pad, hb ? npb : 0u);
-      constexpr int UB = MODE ? 2 : 4;                         // sample groups per batch of table loads
+      constexpr int UB = 2;                                    // sample groups per batch of table loads
 #pragma unroll
       for (int c0 = 0; c0 < 8; c0 += UB) {
         f4 ue[UB], uo[UB];
