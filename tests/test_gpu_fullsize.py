@@ -288,3 +288,34 @@ def test_config5_hilbert_complex_full_size(ctx):
     assert np.array_equal(s, s2) and np.array_equal(V, V2)
     A.free(); B.free()
     ctx.trim()
+
+
+def test_hilbert_of_the_config4_field_full_size(ctx):
+    """The Hilbert stage on the 10 000 time steps of the config-4 field (circular length 2^15: one feature per workgroup
+    through the half-length transform): sampled features against the oracle, the padded buffer holds nothing else
+    (sum of squares over the whole buffer = sum over the valid part), bitwise reproducible."""
+    import torch
+
+    from xeofs_amd import engine
+
+    n, nlat, nlon = 10000, 720, 1440
+    p = nlat * nlon
+    X = _device_field(n, nlat, nlon)
+    A, st = engine.preprocess(ctx, X, want_stats=False)
+    del X
+    torch.cuda.empty_cache()
+    B, _ = engine.hilbert(ctx, A, "exp", 0.2)
+    cols = np.array([0, 1, 2, 77777, p // 2 + 1, p - 2, p - 1])
+    E = np.zeros((p, len(cols)), np.float32)
+    E[cols, np.arange(len(cols))] = 1.0
+    a = engine.project(ctx, A, E).astype(np.float64)
+    b = engine.project(ctx, B, E).astype(np.float64)
+    ref = orc.hilbert_transform(a, padding="exp", decay_factor=0.2)
+    assert np.abs(b - ref.imag).max() <= 2e-6 * np.abs(ref.imag).max()
+    ssq = B.sumsq()
+    B2, _ = engine.hilbert(ctx, A, "exp", 0.2)
+    assert B2.sumsq() == ssq and np.array_equal(engine.project(ctx, B2, E), engine.project(ctx, B, E))
+    # energy of the transform of centred series is close to the input's (the filter has unit gain away from DC)
+    assert 0.5 * A.sumsq() < ssq < 1.5 * A.sumsq()
+    A.free(); B.free(); B2.free()
+    ctx.trim()
