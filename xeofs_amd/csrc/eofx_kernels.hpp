@@ -1044,19 +1044,33 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(const float* __restrict_
     }
     if (same) vb = va;
   };
+  // A k-step is 4 rows (1 KB) against 10 or 16 products of 64 cycles each: the loads run GRAM_PF steps ahead (one step
+  // ahead leaves every wave waiting on an HBM round trip per step: 300 us instead of ~130 for a 1M x 64 panel)
+  constexpr int GRAM_PF = 4;
   int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * 4;
-  f32x4 va, vb, na, nb_;
-  fetch(r0, va, vb);
-  for (; r0 < rows; r0 += wstride) {
-    fetch(r0 + wstride, na, nb_);                           // rows >= `rows` load zeros
-    __builtin_amdgcn_sched_barrier(0);
+  f32x4 pa[GRAM_PF], pb[GRAM_PF];
 #pragma unroll
-    for (int x = 0; x < 4; ++x)
+  for (int d = 0; d < GRAM_PF; ++d) fetch(r0 + d * wstride, pa[d], pb[d]);      // rows >= `rows` load zeros
+  for (; r0 < rows; r0 += GRAM_PF * wstride) {
 #pragma unroll
-      for (int y = 0; y < 4; ++y)
-        acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)va[x], (double)vb[y], acc[x][y], 0, 0, 0);
-    va = na;
-    vb = nb_;
+    for (int d = 0; d < GRAM_PF; ++d) {
+      const f32x4 va = pa[d], vb = pb[d];
+      fetch(r0 + (GRAM_PF + d) * wstride, pa[d], pb[d]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (same) {       // diagonal sub-block: tile (x, y) is the transpose of tile (y, x) -- 10 of the 16 products
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+          for (int y = x; y < 4; ++y)
+            acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)va[x], (double)vb[y], acc[x][y], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+          for (int y = 0; y < 4; ++y)
+            acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)va[x], (double)vb[y], acc[x][y], 0, 0, 0);
+      }
+    }
   }
   double* G = Gpart + ((int64_t)blockIdx.x * 4 + wave) * (int64_t)L * L;
 #pragma unroll
@@ -1067,9 +1081,10 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(const float* __restrict_
       for (int q = 0; q < 4; ++q) {
         const int i = lk + 4 * q, j = lc;                       // D[lane / 16 + 4 reg][lane % 16] (measured layout)
         const int gi = 64 * bi + 4 * i + x, gj = 64 * bj + 4 * j + y;
+        if (same && x > y) continue;                            // (written by tile (y, x) below)
         if (gi < L && gj < L) {
           G[(int64_t)gi * L + gj] = acc[x][y][q];
-          if (!same) G[(int64_t)gj * L + gi] = acc[x][y][q];
+          if (!same || x < y) G[(int64_t)gj * L + gi] = acc[x][y][q];
         }
       }
 }
