@@ -175,6 +175,32 @@ def test_two_rank_sharded_mca_and_eof_on_one_gpu(ctx, nan, pca):
     assert d["mca_norm1"] < 1e-4 and d["mca_tsc"] < 1e-5 and d["eof_tv"] < 1e-6
 
 
+@pytest.mark.parametrize("modes", [12, 40])        # 40 + 10 oversamples: the 128-column panels of the wide sketch
+def test_two_rank_sharded_hilbert_complex_on_one_gpu(ctx, modes):
+    """The multi-rank form of config 5 with the real HIP kernels (tools/sharded_complex_worker.py): two processes share
+    cuda:0, each preprocesses and Hilbert-transforms its half of the features and takes part in the feature-sharded
+    complex rSVD (one-launch complex passes, all-reduce over gloo).  Singular values equal the single-rank engine
+    entry's, the global identity Z V = U s holds, the gathered V is orthonormal and spans the same modes."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29531",
+                          os.path.join(root, "tools", "sharded_complex_worker.py"), "--backend", "gloo", "--same-gpu",
+                          "--modes", str(modes)], capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    assert run.returncode == 0, run.stderr[-2000:]
+    d = json.loads([ln for ln in run.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert d["world"] == 2
+    assert d["s_rel"] < 1e-5 and d["zv_us"] < 2e-5
+    assert d["orth_v"] < 2e-5 and d["orth_u"] < 2e-5
+    if modes == 12:
+        assert d["v_cos_min"] > 1 - 1e-4       # (well separated leading modes; the 40-mode run ends in the noise bulk)
+
+
 def test_mca_properties_at_config3(ctx):
     """BASELINE config 3: MCA(n_modes=20) on two 5000 x (360 x 360) halves, `use_pca=False` semantics, through
     size-independent properties: orthonormal singular vectors, C Q2 = Q1 diag(s) with C = X^T Y / (n - 1) applied
