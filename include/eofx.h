@@ -106,8 +106,8 @@ int eofx_ctx_profile(eofx_ctx *ctx, int enable);
 int eofx_ctx_profile_read(eofx_ctx *ctx, int64_t *launches, double *total_ms, double *flops,
                           double *bytes);
 /* the same launches of the LAST eofx_ctx_profile_read by streaming kernel: [0] the atb kernels (operand read with the
- * reduction axis strided: X^T Z on the field, X Y on the sample-contiguous layout), [1] axb_f16_kernel (X Y on the
- * field in place), [2] the fused product */
+ * reduction axis strided: X^T Z on the field -- including the statistics-carrying first pass of eofx_fit_f32 --, X Y on
+ * the sample-contiguous layout), [1] axb_f16_kernel (X Y on the field in place), [2] unused */
 int eofx_ctx_profile_by_kernel(const eofx_ctx *ctx, int64_t *launches3, double *ms3);
 
 /* ---- resident matrix ---------------------------------------------------
@@ -180,6 +180,32 @@ int eofx_mat_layout(const eofx_mat *m, int *layouts, int *has_raw);
 int eofx_rsvd_f32(eofx_ctx *ctx, const eofx_mat *m, int k, int n_oversamples, int n_iter,
                   const float *omega, int flip, float *U, float *s, float *V);
 
+/* ---- the fused fit (Scaler.fit + Sanitizer + Decomposer.fit in ONE call) ----
+ * Replaces, for the model classes, the pair eofx_preprocess_f32 -> eofx_rsvd_f32, i.e. xeofs'
+ * Preprocessor.fit_transform (xeofs/single/base_model_single_set.py:123-161 -> preprocessing/scaler.py:69-154,
+ * sanitizer.py:46-126) followed by Decomposer.fit (xeofs/single/eof.py:85-97 -> linalg/decomposer.py:76-226).
+ * Same arguments and outputs as the two calls it replaces; what changes is the traffic: the column statistics are taken
+ * DURING the first pass of the randomized SVD (Y = X'^T Omega is linear in the data, so it is computed with a
+ * provisional per-feature shift and corrected by a rank-one term once the mean is known; xeofs_amd/csrc/eofx_fit.hpp),
+ * and the field is read 2 n_iter + 2 times instead of 2 n_iter + 3.  Taken when the layout policy is "in place"
+ * (eofx_ctx_set_layout 2), the passes run in EOFX_PREC_F16X3, n < P, P % 4 == 0, k + n_oversamples <= 64 and < n, and the
+ * field holds no NaN / inf; otherwise (and whenever the first pass meets a NaN or exceeds its provisional fp16 range)
+ * the call runs the two-step path itself -- the NaN policies are the Sanitizer's either way.  *fused tells which.
+ *   omega       host, omega_rows x (k + n_oversamples): the sketch for the UNcompacted shape (omega_rows >= min(n, P));
+ *               numpy fills it row by row, so its leading rows are the reference's draw when samples / features drop out
+ *   U, V        host|device, room for n x k and P x k; filled densely with n_out x k and (*out)->p x k values
+ *   *out        the resident (in-place when possible) matrix, as from eofx_preprocess_f32                          */
+int eofx_fit_f32(eofx_ctx *ctx, const float *X, int64_t n, int64_t P, int center, int standardize,
+                 const double *feat_weights, int check_nans, int k, int n_oversamples, int n_iter,
+                 const float *omega, int64_t omega_rows, int flip, eofx_mat **out, double *mean, double *std,
+                 uint8_t *valid_feature, uint8_t *valid_sample, int64_t *n_out, int64_t *p_out,
+                 double *total_variance, float *U, float *s, float *V, int *fused);
+/* info3: [0] 1 when the last eofx_fit_f32 took the fused path, [1] milliseconds of its non-pass work (probe kernel,
+ * statistics finalisation, rank-one correction; HIP events, only while profiling is on), [2] why it did not: 0 fused,
+ * -1 not eligible, 1 NaN / constant data in the sampled rows, 3 NaN or inf in the field, 4 provisional fp16 range
+ * exceeded, 5 both.                                                                                              */
+int eofx_ctx_fit_info(const eofx_ctx *ctx, double *info3);
+
 /* scores = X V (eof.py:129).  V host|device [p x k]; out host|device [n x k].   */
 int eofx_project_f32(eofx_ctx *ctx, const eofx_mat *m, const float *V, int k, float *out);
 /* Xhat = S V^T (eof.py:151-153).  S [n x k], V [p x k] -> out [n x p] host|device. */
@@ -206,17 +232,16 @@ int eofx_panel_tmul_f32(eofx_ctx *ctx, const eofx_mat *m, const float *Zn, float
                         int precision); /* Yp[p_pad x L] = X^T Zn[n_pad x L]; EOFX_PREC_* */
 int eofx_panel_mul_f32(eofx_ctx *ctx, const eofx_mat *m, const float *Yp, float *Wn, int L,
                        int precision);
-/* Wn = X (X^T Zn), optionally also Yp = X^T Zn (Yp may be NULL) -- both products of a power iteration in one pass
- * over the sample-contiguous layout (persistent cooperative kernel, xeofs_amd/csrc/eofx_fused.hpp; split-fp16 MFMA).
- * L must be 64, n_pad one of 3072 / 5120 / 8192 / 10240, 256-CU part; EOFX_ERR_ARG otherwise (callers fall back to
- * eofx_panel_tmul_f32 + eofx_panel_mul_f32, which the rSVD drivers do on their own).                                  */
-int eofx_panel_fused_f32(eofx_ctx *ctx, const eofx_mat *m, const float *Zn, float *Wn, float *Yp, int L);
 /* G[L x L] (device, float64) = P^T P, accumulated in float64 with a fixed tree. */
 int eofx_panel_gram_f64(eofx_ctx *ctx, const float *P, int64_t rows_pad, int L, double *G);
 /* Cholesky-QR step from a (possibly all-reduced) Gram matrix: out = P R^-1 with
  * G = R^T R restricted to the leading l x l block; rank-deficient columns -> 0. */
 int eofx_panel_cholqr_f32(eofx_ctx *ctx, const float *P, int64_t rows_pad, int L, int l,
                           const double *G, float *out);
+/* Rinv[L x L] (device float64) = R^-1 of the Cholesky factor G = R^T R, leading l x l block (zero elsewhere;
+ * rank-deficient columns -> 0): the factor eofx_panel_cholqr_f32 applies, on its own -- the second step of
+ * CholeskyQR2 is applied on the small side and folded into the final rotation (rsvd_core), not to the tall panel. */
+int eofx_panel_rinv_f64(eofx_ctx *ctx, const double *G, int L, int l, double *Rinv);
 /* out[rows_pad x Lo] = P[rows_pad x L] * M[L x Lo]  (M device float64 row-major). */
 int eofx_panel_matmul_f32(eofx_ctx *ctx, const float *P, int64_t rows_pad, int L,
                           const double *M, int Lo, float *out);

@@ -359,32 +359,101 @@ def test_sharded_world1_equals_driver_bitwise(ctx):
         assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("n,p", [(5000, 6000), (3000, 9000), (8100, 20000), (10000, 33000)])
-def test_fused_power_product(ctx, n, p):
-    """`eofx_panel_fused_f32` (W = X (X^T Z) and Y = X^T Z in one pass over X^T: persistent cooperative kernel with an
-    in-L2 exchange between the 32 CUs of an XCD) against the two-pass exact-f32 products.
-    Tolerance: float32-class (split-fp16 MFMA products, different summation order); bitwise reproducible."""
-    import torch
+def _check_factors(U, s, V, ref, k, tol=1e-5):
+    assert np.all(np.abs(s - ref["norms"]) <= tol * ref["norms"][0]), (s, ref["norms"])
+    sv = ref["norms"]
+    for j in range(k):
+        if _gap_ok(sv, j):
+            c = float(np.dot(V[:, j].astype(np.float64), ref["components"][:, j]))
+            assert c >= 1 - _cos_tol(sv, j), (j, c)          # same sign, same direction
+            cu = float(np.dot(U[:, j].astype(np.float64), ref["scores"][:, j])) / float(np.linalg.norm(ref["scores"][:, j]))
+            assert cu >= 1 - _cos_tol(sv, j), (j, cu)
+
+
+@pytest.mark.parametrize("n,p,k,opts", [
+    (300, 2048, 6, {}),
+    (200, 5000, 20, {"standardize": True}),
+    (517, 4100, 12, {"weights": True}),                 # n % 16 != 0: the tail rows come from the finalize kernel
+    (1000, 9000, 50, {"standardize": True, "weights": True}),
+    (333, 1036, 8, {"center": False}),
+    (96, 40000, 10, {}),                                 # several column blocks, one slab pair per split
+    (5000, 20480, 22, {}),                               # L = 32 sketch (k + 10 = 32): the one-sub-tile variant
+])
+def test_fused_fit_vs_two_step_and_oracle(ctx, n, p, k, opts):
+    """eofx_fit_f32: the column statistics ride on the first pass of the randomized SVD (eofx_fit.hpp).  The result must
+    be the two-step result (statistics pass, then the decomposition) to float32 rounding, and match the float64
+    oracle within the same tolerances as the two-step path."""
     from xeofs_amd import engine
 
-    g = torch.Generator(device="cuda").manual_seed(n + p)
-    X = torch.randn((n, p), device="cuda", dtype=torch.float32, generator=g)
-    X *= torch.logspace(-2, 1, p, device="cuda")           # features of very different scales
-    mat = engine.from_dense(ctx, X)
-    if mat.n_pad not in (3072, 5120, 8192, 10240):
-        pytest.skip("fused product: n_pad not instantiated")
-    Z = torch.randn((mat.n_pad, 64), device="cuda", generator=g)
-    Z[n:] = 0
-    Z = Z / Z.norm(dim=0)
-    Yref = engine.panel_tmul(ctx, mat, Z, prec="f32")
-    ref = engine.panel_mul(ctx, mat, Yref, prec="f32")
-    got, Y = engine.panel_fused(ctx, mat, Z, want_y=True)
-    got2 = engine.panel_fused(ctx, mat, Z)
-    assert torch.equal(got, got2)                                         # fixed-order exchange: bitwise reproducible
-    assert float((Y - Yref).abs().max()) <= 2e-6 * float(Yref.abs().max())
-    assert float((got - ref).abs().max()) <= 5e-6 * float(ref.abs().max())
-    assert not bool(got[n:].any())                                        # padded samples stay zero
-    assert not bool(Y[p:].any())                                          # padded features too
+    rng = np.random.default_rng(n + p)
+    X = _field(n, p, rank=10, seed=n + k)
+    X += (10.0 * rng.standard_normal(p)).astype(np.float32)          # per-feature offsets well above the noise
+    w = (0.2 + rng.random(p)) if opts.get("weights") else None
+    center, standardize = opts.get("center", True), opts.get("standardize", False)
+    mat, st, U, s, V = engine.fit(ctx, X, k, center=center, standardize=standardize, feature_weights=w, random_state=7)
+    assert st["fused"], engine.fit_info(ctx)
+    assert mat.layout() == (False, True) and not mat.has_sample_layout()     # in place: nothing was written
+    mat2, st2 = engine.preprocess(ctx, X, center, standardize, w, in_place=True)
+    U2, s2, V2 = engine.rsvd(ctx, mat2, k, random_state=7)
+    # statistics: float64 sums of float32-exact terms on both paths
+    np.testing.assert_allclose(st["mean"], st2["mean"], rtol=0, atol=2e-6 * (np.abs(st2["mean"]).max() + st2["std"].max()))
+    np.testing.assert_allclose(st["std"], st2["std"], rtol=2e-6)
+    assert abs(st["total_variance"] - st2["total_variance"]) <= 2e-6 * st2["total_variance"]
+    assert st["n"] == n and st["p"] == p and st["valid_feature"].all() and st["valid_sample"].all()
+    assert np.all(np.abs(s - s2) <= 2e-6 * s2[0]), (s, s2)
+    ref = orc.eof_fit(X.astype(np.float64), k, center=center, standardize=standardize, feature_weights=w, random_state=7)
+    _check_factors(U, s, V, ref, k)
+    assert abs(st["total_variance"] - ref["total_variance"]) <= 1e-6 * ref["total_variance"]
+    # the matrix it leaves behind is the two-step matrix: same projection
+    P1 = engine.project(ctx, mat, V2)
+    P2 = engine.project(ctx, mat2, V2)
+    assert np.abs(P1 - P2).max() <= 2e-6 * np.abs(P2).max()
+    # bitwise reproducible
+    mat3, st3, U3, s3, V3 = engine.fit(ctx, X, k, center=center, standardize=standardize, feature_weights=w, random_state=7)
+    assert np.array_equal(U, U3) and np.array_equal(s, s3) and np.array_equal(V, V3)
+    assert np.array_equal(st["mean"], st3["mean"])
+    for m_ in (mat, mat2, mat3):
+        m_.free()
+
+
+def test_fused_fit_falls_back(ctx):
+    """NaN fields, sketches wider than 64 columns and n >= P take the two-step path inside the same call -- with the
+    Sanitizer's policies and error messages -- and say so."""
+    from xeofs_amd import engine
+
+    X, lat = orc.synthetic_field(240, 16, 32, rank=6, seed=3, nan_frac=0.25)     # all-NaN grid points (land mask)
+    X = np.ascontiguousarray(X.reshape(240, -1), dtype=np.float32)
+    mat, st, U, s, V = engine.fit(ctx, X, 5, random_state=2)
+    assert not st["fused"] and engine.fit_info(ctx)["reason"] in (1, 3)
+    pv = int(st["valid_feature"].sum())
+    assert 0 < pv < X.shape[1] and V.shape == (pv, 5) and U.shape == (240, 5)
+    mat2, st2 = engine.preprocess(ctx, X, in_place=True)
+    U2, s2, V2 = engine.rsvd(ctx, mat2, 5, random_state=2)
+    assert np.array_equal(s, s2) and np.array_equal(U, U2) and np.array_equal(V, V2)
+    mat.free(); mat2.free()
+    # a NaN that the eight sampled rows do not see: found by the statistics of the first pass
+    Y = _field(400, 1024, seed=5)
+    Y[137, 900] = np.nan
+    with pytest.raises(ValueError, match="partial NaN"):
+        engine.fit(ctx, Y, 4, random_state=1)
+    assert engine.fit_info(ctx)["reason"] == 3
+    Y[:, 900] = np.nan                              # the whole feature: dropped, as by the Sanitizer
+    mat, st, U, s, V = engine.fit(ctx, Y, 4, random_state=1)
+    assert not st["fused"] and V.shape == (1023, 4) and not st["valid_feature"][900]
+    mat.free()
+    Z = _field(600, 400, seed=6)                    # n >= P: the sketch lives on the feature side
+    mat, st, U, s, V = engine.fit(ctx, Z, 4, random_state=1)
+    assert not st["fused"] and engine.fit_info(ctx)["reason"] == -1
+    ref = orc.eof_fit(Z.astype(np.float64), 4, random_state=1)
+    _check_factors(U, s, V, ref, 4)
+    mat.free()
+    # an outlier far outside what the sampled rows suggest: the provisional fp16 range overflows, the call recovers
+    Wd = _field(512, 2048, seed=8)
+    Wd[300, 77] = 3.0e7
+    mat, st, U, s, V = engine.fit(ctx, Wd, 3, random_state=1)
+    assert not st["fused"] and engine.fit_info(ctx)["reason"] == 4
+    ref = orc.eof_fit(Wd.astype(np.float64), 3, random_state=1)
+    assert np.all(np.abs(s - ref["norms"]) <= 1e-5 * ref["norms"][0])
     mat.free()
 
 
@@ -403,9 +472,6 @@ def test_documented_size_limits_fail_loudly(ctx):
         complex_rsvd(ctx, A, B, 60)                      # panel-level (sharded) driver: 60 + 10 oversamples > 64
     with pytest.raises(ValueError, match="complex sketch width"):
         engine.rsvd_c64(ctx, A, B, 60)                   # engine entry: 60 + 10 oversamples > 64
-    Z = torch.zeros((A.n_pad, 32), device="cuda")
-    with pytest.raises(ValueError, match="fused product needs"):
-        engine.panel_fused(ctx, A, Z)                    # L != 64
     with pytest.raises(ValueError, match="rank of the dataset"):
         engine.rsvd(ctx, A, 301)
     A.free(); B.free()

@@ -60,7 +60,13 @@ class NumpyPanelOps:
         out[:, :l] = (P.numpy()[:, :l].astype(np.float64) @ np.linalg.inv(R)).astype(np.float32)
         return self._t(out)
 
+    def rinv(self, G, l):
+        out = np.zeros_like(G.numpy())
+        out[:l, :l] = np.linalg.inv(np.linalg.cholesky(G.numpy()[:l, :l]).T)
+        return self._t(out, np.float64)
+
     def matmul(self, P, M):
+        M = M.numpy() if hasattr(M, "numpy") else M
         return self._t((P.numpy().astype(np.float64) @ M).astype(np.float32))
 
     def colminmax(self, P, rows):

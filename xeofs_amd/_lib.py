@@ -52,13 +52,16 @@ SIGNATURES = {
     "eofx_panel_mul_f32": (_int, [_vp, _vp, _vp, _vp, _int, _int]),
     "eofx_panel_gram_f64": (_int, [_vp, _vp, _i64, _int, _vp]),
     "eofx_panel_cholqr_f32": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp]),
+    "eofx_panel_rinv_f64": (_int, [_vp, _vp, _int, _int, _vp]),
     "eofx_panel_matmul_f32": (_int, [_vp, _vp, _i64, _int, _vp, _int, _vp]),
     "eofx_panel_colminmax_f32": (_int, [_vp, _vp, _i64, _int, _vp, _vp]),
     "eofx_panel_export_f32": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp]),
     "eofx_panel_import_f32": (_int, [_vp, _vp, _i64, _int, _vp, _i64, _int]),
     "eofx_hilbert_f32": (_int, [_vp, _vp, _int, C.c_double, C.POINTER(_vp), C.POINTER(_vp)]),
     "eofx_mat_sumsq_f64": (_int, [_vp, _vp, _pd]),
-    "eofx_panel_fused_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _int]),
+    "eofx_fit_f32": (_int, [_vp, _vp, _i64, _i64, _int, _int, _vp, _int, _int, _int, _int, _vp, _i64, _int,
+                            C.POINTER(_vp), _vp, _vp, _vp, _vp, _pi64, _pi64, _pd, _vp, _vp, _vp, C.POINTER(C.c_int)]),
+    "eofx_ctx_fit_info": (_int, [_vp, _pd]),
     "eofx_rsvd_c64": (_int, [_vp, _vp, _vp, _int, _int, _int, _vp, _int, _vp, _vp, _vp]),
     "eofx_orth_tall_rule": (_int, [_i64, _int, _int]),
     "eofx_peaked_spectrum": (_int, [_vp, _int, _int]),

@@ -3,7 +3,7 @@
 // Kernels live in eofx_kernels.hpp.  gfx950 only.
 #include "eofx_hfft.hpp"
 #include "eofx_kernels.hpp"
-#include "eofx_fused.hpp"
+#include "eofx_fit.hpp"
 
 #if !defined(__HIP_DEVICE_COMPILE__)
 #include <immintrin.h>
@@ -63,7 +63,7 @@ struct eofx_ctx {
   bool profile = false;
   struct ProfEvent {
     hipEvent_t first, second;
-    int kind;   // 0: atb kernels, 1: axb (in-place row stream), 2: fused product
+    int kind;   // 0: atb kernels (incl. the statistics-carrying first pass), 1: axb (in-place row stream), 2: unused
     ProfEvent(hipEvent_t a, hipEvent_t b, int k = 0) : first(a), second(b), kind(k) {}
   };
   std::vector<ProfEvent> prof_events;
@@ -71,7 +71,20 @@ struct eofx_ctx {
   double prof_kind_ms[3] = {0.0, 0.0, 0.0};
   double prof_flops = 0.0;  // 2*K*M*L summed over profiled launches (padded sizes)
   double prof_bytes = 0.0;  // K*M*4 (the A stream) summed over profiled launches
+  // Panel maxima taken where a panel is WRITTEN (split-K reduction, panel_matmul, import, atb epilogue) instead of
+  // by one more read of it before the split-fp16 pass that consumes it.  Live only inside an AmaxScope (the rSVD
+  // drivers): a pool of zeroed device words, one per produced panel, looked up by the panel's address.
+  unsigned* amax_slots = nullptr;
+  int amax_next = 0, amax_depth = 0;
+  std::vector<std::pair<const float*, const unsigned*>> amax_known;
+  // page-locked host scratch for small asynchronous downloads (Gram matrices, flags)
+  double* pinned = nullptr;
+  // the last eofx_fit_f32: [0] 1 when the statistics rode on the first pass, [1] ms of the non-pass work of the
+  // fused preprocessor (probe, finalize, correction; HIP events, only with profiling on), [2] fallback reason
+  double fit_info[4] = {0.0, 0.0, 0.0, 0.0};
 };
+constexpr int EOFX_AMAX_SLOTS = 1024;
+constexpr size_t EOFX_PINNED_DOUBLES = 2 * 256 * 256 + 64;
 
 struct eofx_mat {
   int64_t n = 0, p = 0, n_pad = 0, p_pad = 0;
@@ -86,6 +99,11 @@ struct eofx_mat {
   float* aff = nullptr;      // [3][p_pad]: shift hi, shift lo, scale (aff_pack_kernel)
   unsigned* absmax_dev = nullptr;  // float bits of max |x| (device scalar, for the fp16-split scaling)
   float absmax = 0.f;              // host copy, valid once the matrix is built
+  // in-place matrix of a field with all-NaN grid points (land / sea mask): the invalid features stay where they are as
+  // ZERO columns (scale 0 in `aff`, bits ANDed to +0 by the MASK kernels) instead of being compacted away; p counts them,
+  // p_valid does not.  The host shell compacts / scatters the feature axis of the factors.
+  bool masked = false;
+  int64_t p_valid = 0;
 };
 
 static int set_err(eofx_ctx* ctx, int code, const char* fmt, ...) {
@@ -191,6 +209,8 @@ extern "C" int eofx_ctx_destroy(eofx_ctx* ctx) {
     (void)hipFree(ctx->arena);
   }
   pool_trim(ctx);
+  if (ctx->amax_slots) (void)hipFree(ctx->amax_slots);
+  if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   for (auto& e : ctx->fft_plans) {
     hipfftDestroy((hipfftHandle)e.second.first);
     hipfftDestroy((hipfftHandle)e.second.second);
@@ -246,7 +266,7 @@ extern "C" int eofx_ctx_profile_read(eofx_ctx* ctx, int64_t* launches, double* t
 }
 
 // launches / summed milliseconds of the LAST eofx_ctx_profile_read by streaming kernel: [0] atb (the transposed-operand
-// kernels, all variants), [1] axb_f16_kernel (the in-place row stream), [2] the fused product
+// kernels, all variants), [1] axb_f16_kernel (the in-place row stream), [2] unused
 extern "C" int eofx_ctx_profile_by_kernel(const eofx_ctx* ctx, int64_t* launches3, double* ms3) {
   if (!ctx) return EOFX_ERR_ARG;
   for (int k = 0; k < 3; ++k) {
@@ -265,6 +285,56 @@ static int copy_out(eofx_ctx* ctx, void* dst, const void* src_dev, size_t bytes)
 static int copy_in(eofx_ctx* ctx, void* dst_dev, const void* src, size_t bytes) {
   if (bytes == 0) return EOFX_OK;
   HIPCHK(hipMemcpyAsync(dst_dev, src, bytes, hipMemcpyDefault, ctx->stream));
+  return EOFX_OK;
+}
+
+// ---- panel maxima recorded by the producers (see eofx_ctx::amax_slots) -------------------------------------------
+struct AmaxScope {
+  eofx_ctx* ctx;
+  explicit AmaxScope(eofx_ctx* c) : ctx(c) {
+    if (ctx->amax_depth++ == 0) {
+      ctx->amax_known.clear();
+      ctx->amax_next = 0;
+      if (!ctx->amax_slots && hipMalloc((void**)&ctx->amax_slots, sizeof(unsigned) * EOFX_AMAX_SLOTS) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->amax_slots = nullptr;
+      }
+      if (ctx->amax_slots &&
+          hipMemsetAsync(ctx->amax_slots, 0, sizeof(unsigned) * EOFX_AMAX_SLOTS, ctx->stream) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->amax_next = EOFX_AMAX_SLOTS;   // unusable: every lookup misses
+      }
+    }
+  }
+  ~AmaxScope() {
+    if (--ctx->amax_depth == 0) ctx->amax_known.clear();
+  }
+};
+static void amax_forget(eofx_ctx* ctx, const float* panel) {
+  for (size_t i = 0; i < ctx->amax_known.size(); ++i)
+    if (ctx->amax_known[i].first == panel) {
+      ctx->amax_known.erase(ctx->amax_known.begin() + i);
+      return;
+    }
+}
+// a fresh zeroed word for the producer of `panel` (nullptr outside a scope / when the pool is used up)
+static unsigned* amax_new(eofx_ctx* ctx, const float* panel) {
+  if (ctx->amax_depth == 0) return nullptr;
+  amax_forget(ctx, panel);
+  if (!ctx->amax_slots || ctx->amax_next >= EOFX_AMAX_SLOTS) return nullptr;
+  unsigned* slot = ctx->amax_slots + ctx->amax_next++;
+  ctx->amax_known.emplace_back(panel, slot);
+  return slot;
+}
+static const float* amax_get(const eofx_ctx* ctx, const float* panel) {
+  if (ctx->amax_depth == 0) return nullptr;
+  for (auto& e : ctx->amax_known)
+    if (e.first == panel) return reinterpret_cast<const float*>(e.second);
+  return nullptr;
+}
+static int pinned_scratch(eofx_ctx* ctx, double** out) {
+  if (!ctx->pinned) HIPCHK(hipHostMalloc((void**)&ctx->pinned, sizeof(double) * EOFX_PINNED_DOUBLES, hipHostMallocDefault));
+  *out = ctx->pinned;
   return EOFX_OK;
 }
 
@@ -464,22 +534,26 @@ struct AffView {
   int64_t ld = 0;
   int rows = 0;        // valid rows of the raw field
   int64_t cols = 0;    // valid columns
+  bool masked = false; // some features carry scale 0 = all-NaN grid points kept as zero columns (MASK kernels)
 };
 template <int NB>
 static void launch_atb_variant(int prec, dim3 grid, hipStream_t st, const float* A, int64_t lda,
                                const float* B, int ldb, float* out, int L, int64_t M, int64_t K,
                                int64_t kps, int col_base, float a_scale, const float* b_absmax,
                                const AffView* aff = nullptr, const float* A2 = nullptr, const float* B2 = nullptr,
-                               int s_half = 0, int sym = 0) {
+                               int s_half = 0, int sym = 0, unsigned* amax_out = nullptr) {
   if (prec == EOFX_PREC_F16X3 && A2)
     hipLaunchKernelGGL(atb_f16_kernel<NB>, grid, dim3(256), 0, st, A, lda, B, ldb, out, L, M, K, kps, col_base,
-                       a_scale, b_absmax, (const float*)nullptr, (int64_t)0, 0, (int64_t)0, A2, B2, s_half, 0);
+                       a_scale, b_absmax, (const float*)nullptr, (int64_t)0, 0, (int64_t)0, A2, B2, s_half, 0, amax_out);
+  else if (prec == EOFX_PREC_F16X3 && aff && aff->masked)
+    hipLaunchKernelGGL((atb_f16_kernel<NB, true, true>), grid, dim3(256), 0, st, A, lda, B, ldb, out, L, M, K, kps, col_base,
+                       a_scale, b_absmax, aff->aff, aff->ld, aff->rows, aff->cols, (const float*)nullptr, (const float*)nullptr, 0, sym, amax_out);
   else if (prec == EOFX_PREC_F16X3 && aff)
     hipLaunchKernelGGL((atb_f16_kernel<NB, true>), grid, dim3(256), 0, st, A, lda, B, ldb, out, L, M, K, kps, col_base,
-                       a_scale, b_absmax, aff->aff, aff->ld, aff->rows, aff->cols, (const float*)nullptr, (const float*)nullptr, 0, sym);
+                       a_scale, b_absmax, aff->aff, aff->ld, aff->rows, aff->cols, (const float*)nullptr, (const float*)nullptr, 0, sym, amax_out);
   else if (prec == EOFX_PREC_F16X3)
     hipLaunchKernelGGL(atb_f16_kernel<NB>, grid, dim3(256), 0, st, A, lda, B, ldb, out, L, M, K, kps, col_base,
-                       a_scale, b_absmax, (const float*)nullptr, (int64_t)0, 0, (int64_t)0, (const float*)nullptr, (const float*)nullptr, 0, sym);
+                       a_scale, b_absmax, (const float*)nullptr, (int64_t)0, 0, (int64_t)0, (const float*)nullptr, (const float*)nullptr, 0, sym, amax_out);
   else if constexpr (NB <= 2) {     // the 128-column tile exists for the split-fp16 kernel only
     if (prec == EOFX_PREC_BF16X3)
       hipLaunchKernelGGL((atb_bf16_kernel<NB, 2>), grid, dim3(256), 0, st, A, lda, B, ldb, out, L, M, K, kps, col_base);
@@ -531,6 +605,7 @@ static int launch_atb(eofx_ctx* ctx, const float* A, int64_t lda, int64_t K, int
       (void)std::frexp(a_absmax, &e);
       a_scale = std::ldexp(1.f, 14 - e);
     }
+    if (!b_absmax_dev && ldb == L && !A2) b_absmax_dev = amax_get(ctx, B);   // recorded where the panel was written
     if (!b_absmax_dev) {
       unsigned* bm = arena_alloc<unsigned>(ctx, 1);
       if (!bm) return set_err(ctx, EOFX_ERR_NOMEM, "arena exhausted (panel max)");
@@ -542,6 +617,8 @@ static int launch_atb(eofx_ctx* ctx, const float* A, int64_t lda, int64_t K, int
       b_absmax_dev = reinterpret_cast<const float*>(bm);
     }
   }
+  // the maximum of the panel this launch produces, for the pass that will consume it (split-fp16, whole-panel outputs)
+  unsigned* amax_out = (prec == EOFX_PREC_F16X3 && !sym && !wide && !A2) ? amax_new(ctx, C) : (amax_forget(ctx, C), nullptr);
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (ctx->profile) {
     HIPCHK(hipEventCreate(&ev0));
@@ -578,19 +655,20 @@ static int launch_atb(eofx_ctx* ctx, const float* A, int64_t lda, int64_t K, int
     }
     return EOFX_OK;
   }
+  unsigned* amax_direct = best_s == 1 ? amax_out : nullptr;   // single split: the kernels' own epilogues take the maximum
   if (n4 > 0) {
     dim3 grid(bx, best_s, n4);
-    launch_atb_variant<4>(prec, grid, ctx->stream, A, lda, B, ldb, out, L, M, K, best_kps, 0, a_scale, b_absmax_dev, aff, A2, B2, s_half, sym);
+    launch_atb_variant<4>(prec, grid, ctx->stream, A, lda, B, ldb, out, L, M, K, best_kps, 0, a_scale, b_absmax_dev, aff, A2, B2, s_half, sym, amax_direct);
     KCHK();
   }
   if (nfull > 0) {
     dim3 grid(bx, best_s, nfull);
-    launch_atb_variant<2>(prec, grid, ctx->stream, A, lda, B, ldb, out, L, M, K, best_kps, cb4, a_scale, b_absmax_dev, aff, A2, B2, s_half, sym);
+    launch_atb_variant<2>(prec, grid, ctx->stream, A, lda, B, ldb, out, L, M, K, best_kps, cb4, a_scale, b_absmax_dev, aff, A2, B2, s_half, sym, amax_direct);
     KCHK();
   }
   if (rem) {
     dim3 grid(bx, best_s, 1);
-    launch_atb_variant<1>(prec, grid, ctx->stream, A, lda, B, ldb, out, L, M, K, best_kps, cb4 + nfull * 64, a_scale, b_absmax_dev, aff, A2, B2, s_half, sym);
+    launch_atb_variant<1>(prec, grid, ctx->stream, A, lda, B, ldb, out, L, M, K, best_kps, cb4 + nfull * 64, a_scale, b_absmax_dev, aff, A2, B2, s_half, sym, amax_direct);
     KCHK();
   }
   if (ctx->profile) {
@@ -603,7 +681,7 @@ static int launch_atb(eofx_ctx* ctx, const float* A, int64_t lda, int64_t K, int
     const int64_t count4 = M * L / 4;
     const int blocks = (int)std::min<int64_t>((count4 + 255) / 256, 4096);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, ctx->stream, out, C, count4,
-                       best_s);
+                       best_s, amax_out);
     KCHK();
   }
   if (sym) {
@@ -618,7 +696,7 @@ static int launch_atb(eofx_ctx* ctx, const float* A, int64_t lda, int64_t K, int
 // W[n_pad x L] = X' Y with X' = the raw field [rows x cols] (ld) through the affine map, read in place (axb_f16_kernel).
 // Y: [>= round_up(cols, 64) x L] panel whose rows >= cols are zero.  L a multiple of 32.
 static int launch_axb(eofx_ctx* ctx, const float* raw, int64_t ld, int64_t rows, int64_t cols, int64_t rows_pad,
-                      const float* aff, int64_t aff_ld, float a_absmax, const float* Y, int L, float* W) {
+                      const float* aff, int64_t aff_ld, float a_absmax, const float* Y, int L, float* W, bool masked = false) {
   const int64_t K = round_up(cols, AXB_KG);
   if (L % 32 || L <= 0 || rows_pad % AXB_BM || rows >= ((int64_t)1 << 31) || K * L >= ((int64_t)1 << 31) ||
       64 * ld + K >= ((int64_t)1 << 30))     // the kernel's 32-bit offsets
@@ -638,13 +716,18 @@ static int launch_axb(eofx_ctx* ctx, const float* raw, int64_t ld, int64_t rows,
     (void)std::frexp(a_absmax, &e);
     a_scale = std::ldexp(1.f, 14 - e);
   }
-  unsigned* bm = arena_alloc<unsigned>(ctx, 1);
-  if (!bm) return set_err(ctx, EOFX_ERR_NOMEM, "arena exhausted (panel max)");
-  HIPCHK(hipMemsetAsync(bm, 0, sizeof(unsigned), ctx->stream));
-  const int64_t total4 = K * (L / 4);
-  hipLaunchKernelGGL(panel_absmax_kernel, dim3((int)std::max<int64_t>(1, std::min<int64_t>((total4 + 1023) / 1024, 1024))),
-                     dim3(256), 0, ctx->stream, Y, K, L, (int64_t)L, bm);
-  KCHK();
+  const float* bmax = amax_get(ctx, Y);      // recorded where the panel was written
+  if (!bmax) {
+    unsigned* bm = arena_alloc<unsigned>(ctx, 1);
+    if (!bm) return set_err(ctx, EOFX_ERR_NOMEM, "arena exhausted (panel max)");
+    HIPCHK(hipMemsetAsync(bm, 0, sizeof(unsigned), ctx->stream));
+    const int64_t total4 = K * (L / 4);
+    hipLaunchKernelGGL(panel_absmax_kernel, dim3((int)std::max<int64_t>(1, std::min<int64_t>((total4 + 1023) / 1024, 1024))),
+                       dim3(256), 0, ctx->stream, Y, K, L, (int64_t)L, bm);
+    KCHK();
+    bmax = reinterpret_cast<const float*>(bm);
+  }
+  unsigned* amax_out = plan.S > 1 ? amax_new(ctx, W) : (amax_forget(ctx, W), nullptr);
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (ctx->profile) {
     HIPCHK(hipEventCreate(&ev0));
@@ -653,13 +736,21 @@ static int launch_axb(eofx_ctx* ctx, const float* raw, int64_t ld, int64_t rows,
   }
   const int gx = plan.S > 1 ? 8 * rt * ((plan.S + 7) / 8) : rt;
   if (nfull > 0) {
-    hipLaunchKernelGGL(axb_f16_kernel<4>, dim3(gx, nfull), dim3(256), 0, ctx->stream, raw, ld, (int)rows, cols, aff, aff_ld, Y, L, out,
-                       L, rows_pad, K, plan.kps, plan.S, rt, 0, a_scale, reinterpret_cast<const float*>(bm));
+    if (masked)
+      hipLaunchKernelGGL((axb_f16_kernel<4, 0, true>), dim3(gx, nfull), dim3(256), 0, ctx->stream, raw, ld, (int)rows, cols, aff, aff_ld, Y,
+                         L, out, L, rows_pad, K, plan.kps, plan.S, rt, 0, a_scale, bmax);
+    else
+      hipLaunchKernelGGL(axb_f16_kernel<4>, dim3(gx, nfull), dim3(256), 0, ctx->stream, raw, ld, (int)rows, cols, aff, aff_ld, Y, L, out,
+                         L, rows_pad, K, plan.kps, plan.S, rt, 0, a_scale, bmax);
     KCHK();
   }
   if (rem) {
-    hipLaunchKernelGGL(axb_f16_kernel<2>, dim3(gx, 1), dim3(256), 0, ctx->stream, raw, ld, (int)rows, cols, aff, aff_ld, Y, L, out,
-                       L, rows_pad, K, plan.kps, plan.S, rt, nfull * 64, a_scale, reinterpret_cast<const float*>(bm));
+    if (masked)
+      hipLaunchKernelGGL((axb_f16_kernel<2, 0, true>), dim3(gx, 1), dim3(256), 0, ctx->stream, raw, ld, (int)rows, cols, aff, aff_ld, Y, L,
+                         out, L, rows_pad, K, plan.kps, plan.S, rt, nfull * 64, a_scale, bmax);
+    else
+      hipLaunchKernelGGL(axb_f16_kernel<2>, dim3(gx, 1), dim3(256), 0, ctx->stream, raw, ld, (int)rows, cols, aff, aff_ld, Y, L, out,
+                         L, rows_pad, K, plan.kps, plan.S, rt, nfull * 64, a_scale, bmax);
     KCHK();
   }
   if (ctx->profile) {
@@ -671,7 +762,7 @@ static int launch_axb(eofx_ctx* ctx, const float* raw, int64_t ld, int64_t rows,
   if (plan.S > 1) {
     const int64_t count4 = rows_pad * L / 4;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)std::min<int64_t>((count4 + 255) / 256, 4096)), dim3(256), 0, ctx->stream,
-                       out, W, count4, plan.S);
+                       out, W, count4, plan.S, amax_out);
     KCHK();
   }
   return EOFX_OK;
@@ -713,7 +804,7 @@ static int launch_matmul(eofx_ctx* ctx, const float* P, int64_t rows, int L, con
   const int64_t units = (rows + 127) / 128;        // 4 waves x 32 rows
   const int64_t gx = L <= KW ? std::min<int64_t>(units, 1024) : units;   // windowed form: one group per wave
   dim3 grid((int)std::max<int64_t>(1, gx), (Lo + 63) / 64);
-  hipLaunchKernelGGL(panel_matmul_kernel, grid, dim3(256), smem, ctx->stream, P, rows, L, Mx, Lo, out, KW);
+  hipLaunchKernelGGL(panel_matmul_kernel, grid, dim3(256), smem, ctx->stream, P, rows, L, Mx, Lo, out, KW, amax_new(ctx, out));
   KCHK();
   return EOFX_OK;
 }
@@ -757,21 +848,12 @@ static void host_chol_rinv(const double* G, int L, int l, double* Rinv, double t
 }
 
 // out = P R^-1 with G = R^T R (leading l x l block)
+static int launch_rinv(eofx_ctx* ctx, const double* G, int L, int l, double* Rinv);
 static int launch_cholqr(eofx_ctx* ctx, const float* P, int64_t rows, int L, int l, const double* G,
                          float* out) {
   ArenaScope scope(ctx);
   ARENA(double, Rinv, (size_t)L * L);
-  if (l <= 64) {
-    hipLaunchKernelGGL(chol_rinv_kernel, dim3(1), dim3(256), 0, ctx->stream, G, L, l, Rinv, 1e-13);
-    KCHK();
-  } else {
-    std::vector<double> hG((size_t)L * L), hR((size_t)L * L);
-    HIPCHK(hipMemcpyAsync(hG.data(), G, sizeof(double) * L * L, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    host_chol_rinv(hG.data(), L, l, hR.data(), 1e-13);
-    HIPCHK(hipMemcpyAsync(Rinv, hR.data(), sizeof(double) * L * L, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-  }
+  CHK(launch_rinv(ctx, G, L, l, Rinv));
   return launch_matmul(ctx, P, rows, L, Rinv, L, out);
 }
 
@@ -831,7 +913,7 @@ static int import_panel(eofx_ctx* ctx, const float* src, int64_t rows, int l, fl
   const int64_t total = rows_pad * L;
   const int blocks = (int)std::min<int64_t>((total + 255) / 256, 8192);
   hipLaunchKernelGGL(panel_import_kernel, dim3(blocks), dim3(256), 0, ctx->stream, dsrc, rows, l, P,
-                     rows_pad, L);
+                     rows_pad, L, amax_new(ctx, P));
   KCHK();
   if (dsrc != src) HIPCHK(hipStreamSynchronize(ctx->stream));  // staging is released on return
   return EOFX_OK;
@@ -1455,6 +1537,7 @@ static int panel_tmul(eofx_ctx* ctx, const eofx_mat* m, const float* Zn, float* 
     av.ld = m->p_pad;
     av.rows = (int)m->n;
     av.cols = m->p;
+    av.masked = m->masked;
     return launch_atb(ctx, m->raw, m->raw_ld, round_up(m->n, ATB_KG), m->p_pad, Zn, L, L, Yp, prec, m->absmax, nullptr, &av);
   }
   CHK(ensure_X(ctx, m));
@@ -1464,7 +1547,7 @@ static int panel_mul(eofx_ctx* ctx, const eofx_mat* m, const float* Yp, float* W
   if (!m->Xt && m->raw && m->aff && prec == EOFX_PREC_F16X3 &&
       round_up(m->p, AXB_KG) * (int64_t)L < ((int64_t)1 << 31) &&
       64 * m->raw_ld + round_up(m->p, AXB_KG) < ((int64_t)1 << 30))   // in place: stream the raw field along its rows
-    return launch_axb(ctx, m->raw, m->raw_ld, m->n, m->p, m->n_pad, m->aff, m->p_pad, m->absmax, Yp, L, Wn);
+    return launch_axb(ctx, m->raw, m->raw_ld, m->n, m->p, m->n_pad, m->aff, m->p_pad, m->absmax, Yp, L, Wn, m->masked);
   CHK(ensure_Xt(ctx, m));
   return launch_atb(ctx, m->Xt, m->n_pad, round_up(m->p, ATB_KG), m->n_pad, Yp, L, L, Wn, prec, m->absmax);
 }
@@ -1486,143 +1569,6 @@ extern "C" int eofx_panel_tmul_f32(eofx_ctx* ctx, const eofx_mat* m, const float
   CHK(arena_reserve(ctx, atb_scratch_bytes(m->p_pad, round_up(m->n, ATB_KG), L)));
   return panel_tmul(ctx, m, Zn, Yp, L, prec);
 }
-// W = X (X^T Z) in one pass over X^T (fused power-iteration product, eofx_fused.hpp); optionally Y = X^T Z too.
-// Needs the 8-XCD / 256-CU part, a 64-wide panel and n_pad = 1024 KS with an instantiated KS.
-static bool fused_ks_ok(int64_t n_pad) {
-  if (n_pad % 1024) return false;
-  const int64_t ks = n_pad / 1024;
-  return ks == 3 || ks == 5 || ks == 8 || ks == 10;
-}
-static bool fused_supported(const eofx_ctx* ctx, const eofx_mat* m, int L) {
-  static int cu_count = -1, coop = 0;
-  if (cu_count < 0) {
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) return false;
-    cu_count = prop.multiProcessorCount;
-    coop = prop.cooperativeLaunch;
-  }
-  return cu_count == FX_GROUPS * FX_MEMBERS && coop && L == 64 && fused_ks_ok(m->n_pad) && m->p_pad % 512 == 0;
-}
-static size_t fused_arena_bytes(const eofx_mat* m) {
-  return (size_t)FX_GROUPS * FX_SLOTS * (FX_MEMBERS + 1) * FX_TILE_GRAN * 16 + (size_t)FX_GROUPS * m->n_pad * 64 * 4 + (1 << 20);
-}
-template <int KS, int DBG = 0>
-static hipError_t fused_launch(const FxParams& prm, hipStream_t st) {
-  constexpr int R = 32 * KS;
-  const size_t smem = (size_t)2 * 32 * (R + 16) * 2 + (size_t)32 * (R + 4) * 4 + 256 * 4 + 64 * 4 + 8192;
-  static bool attr_set = false;    // opt in to more than 64 KB of dynamic LDS (exactly what this launch needs)
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused2_kernel<KS, DBG>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  FxParams p = prm;
-  void* args[] = {(void*)&p};
-  return hipLaunchCooperativeKernel(reinterpret_cast<const void*>(fused2_kernel<KS, DBG>), dim3(FX_GROUPS * FX_MEMBERS), dim3(512),
-                                    args, smem, st);
-}
-// Yp may be null.  Both outputs are complete when the call returns (it reads the kernel's status word).
-static int panel_fused(eofx_ctx* ctx, const eofx_mat* m, const float* Zn, float* Wn, float* Yp) {
-  const int64_t npad = m->n_pad;
-  CHK(ensure_Xt(ctx, m));
-  ArenaScope scope(ctx);
-  const size_t e1_gran = (size_t)FX_GROUPS * FX_SLOTS * FX_MEMBERS * FX_TILE_GRAN;
-  const size_t e2_gran = (size_t)FX_GROUPS * FX_SLOTS * FX_TILE_GRAN;
-  ARENA(u32x4, exch, e1_gran + e2_gran);
-  ARENA(int, ctl, 64);
-  ARENA(unsigned, zmax, 1);
-  ARENA(float, Wpart, (size_t)FX_GROUPS * npad * 64);
-  HIPCHK(hipMemsetAsync(exch, 0, (e1_gran + e2_gran) * 16, ctx->stream));
-  HIPCHK(hipMemsetAsync(ctl, 0, sizeof(int) * 64, ctx->stream));
-  HIPCHK(hipMemsetAsync(zmax, 0, sizeof(unsigned), ctx->stream));
-  const int64_t total4 = npad * 16;
-  hipLaunchKernelGGL(panel_absmax_kernel, dim3((int)std::max<int64_t>(1, std::min<int64_t>((total4 + 1023) / 1024, 1024))),
-                     dim3(256), 0, ctx->stream, Zn, npad, 64, (int64_t)64, zmax);
-  KCHK();
-  float a_scale = 1.f;
-  if (m->absmax > 0.f && std::isfinite(m->absmax)) {
-    int e;
-    (void)std::frexp(m->absmax, &e);
-    a_scale = std::ldexp(1.f, 14 - e);
-  }
-  int lg = 0;
-  while (((int64_t)1 << lg) < npad) ++lg;
-  FxParams prm;
-  prm.Xt = m->Xt;
-  prm.ldx = npad;
-  prm.niter = m->p_pad / 32 / FX_GROUPS;
-  prm.Z = Zn;
-  prm.Wpart = Wpart;
-  prm.E1 = exch;
-  prm.E2 = exch + e1_gran;
-  prm.Yout = Yp;
-  prm.z_absmax = reinterpret_cast<const float*>(zmax);
-  prm.a_scale = a_scale;
-  prm.s1 = std::ldexp(1.f, -(13 + lg));
-  prm.ctl = ctl;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  if (ctx->profile) {
-    HIPCHK(hipEventCreate(&ev0));
-    HIPCHK(hipEventCreate(&ev1));
-    HIPCHK(hipEventRecord(ev0, ctx->stream));
-  }
-  hipError_t le = hipErrorInvalidValue;
-  switch (npad / 1024) {
-    case 3: le = fused_launch<3>(prm, ctx->stream); break;
-    case 5: le = fused_launch<5>(prm, ctx->stream); break;
-    case 8: le = fused_launch<8>(prm, ctx->stream); break;
-    case 10: {
-      const char* dbg = std::getenv("EOFX_FUSED_TIMING");   // probe builds of the C4 shape: see DBG in eofx_fused.hpp
-      switch (dbg ? std::atoi(dbg) : 0) {
-        case 1: le = fused_launch<10, 1>(prm, ctx->stream); break;
-        case 3: le = fused_launch<10, 3>(prm, ctx->stream); break;
-        case 5: le = fused_launch<10, 5>(prm, ctx->stream); break;
-        case 9: le = fused_launch<10, 9>(prm, ctx->stream); break;
-        case 17: le = fused_launch<10, 17>(prm, ctx->stream); break;
-        case 33: le = fused_launch<10, 33>(prm, ctx->stream); break;
-        case 67: le = fused_launch<10, 67>(prm, ctx->stream); break;
-        case 31: le = fused_launch<10, 31>(prm, ctx->stream); break;
-        case 133: le = fused_launch<10, 133>(prm, ctx->stream); break;
-        default: le = fused_launch<10>(prm, ctx->stream); break;
-      }
-    } break;
-    default: break;
-  }
-  HIPCHK(le);
-  if (ctx->profile) {
-    HIPCHK(hipEventRecord(ev1, ctx->stream));
-    ctx->prof_events.emplace_back(ev0, ev1, 2);
-    ctx->prof_flops += 4.0 * (double)npad * (double)m->p_pad * 64.0;
-    ctx->prof_bytes += (double)npad * (double)m->p_pad * 4.0;
-  }
-  const int64_t count4 = npad * 64 / 4;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)std::min<int64_t>((count4 + 255) / 256, 4096)), dim3(256), 0, ctx->stream,
-                     Wpart, Wn, count4, FX_GROUPS);
-  KCHK();
-  int herr = 0;
-  HIPCHK(hipMemcpyAsync(&herr, ctl, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  if (std::getenv("EOFX_FUSED_TIMING") && npad == 10240) {
-    long long ts[17];
-    HIPCHK(hipMemcpy(ts, ctl + 2, sizeof(ts), hipMemcpyDeviceToHost));
-    const double f = 1e-2 / (double)std::max<long long>(ts[16], 1);   // wall_clock64 ticks at 100 MHz -> us per slab
-    fprintf(stderr, "[fused] per slab (us)  A: stage %.2f  issue %.2f  barrier %.2f  phase1+post %.2f  barrier %.2f |  B: consume+stage %.2f  "
-            "issue %.2f  barrier %.2f  reduce %.2f  phase2 %.2f  barrier %.2f  (%lld iterations)\n", ts[0] * f, ts[1] * f, ts[2] * f,
-            ts[3] * f, ts[4] * f, ts[8] * f, ts[9] * f, ts[10] * f, ts[11] * f, ts[12] * f, ts[13] * f, ts[16]);
-  }
-  if (herr == 2) return set_err(ctx, EOFX_ERR_HIP, "fused product: workgroups are not dispatched round robin over the XCDs");
-  if (herr) return set_err(ctx, EOFX_ERR_HIP, "fused product: a workgroup timed out waiting for its group");
-  return EOFX_OK;
-}
-extern "C" int eofx_panel_fused_f32(eofx_ctx* ctx, const eofx_mat* m, const float* Zn, float* Wn, float* Yp, int L) {
-  if (!ctx || !m || !Zn || !Wn) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
-  CHK(set_device(ctx));
-  if (!fused_supported(ctx, m, L))
-    return set_err(ctx, EOFX_ERR_ARG, "fused product needs a 256-CU device, L = 64 and n_pad in {3072, 5120, 8192, 10240}");
-  CHK(arena_reserve(ctx, fused_arena_bytes(m)));
-  return panel_fused(ctx, m, Zn, Wn, Yp);
-}
 extern "C" int eofx_panel_mul_f32(eofx_ctx* ctx, const eofx_mat* m, const float* Yp, float* Wn, int L,
                                   int prec) {
   if (!ctx || !m || !Wn || !Yp || !valid_prec(prec)) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
@@ -1642,6 +1588,11 @@ extern "C" int eofx_panel_cholqr_f32(eofx_ctx* ctx, const float* P, int64_t rows
   CHK(set_device(ctx));
   CHK(arena_reserve(ctx, (size_t)2 * L * L * sizeof(double)));
   return launch_cholqr(ctx, P, rows_pad, L, l, G, out);
+}
+extern "C" int eofx_panel_rinv_f64(eofx_ctx* ctx, const double* G, int L, int l, double* Rinv) {
+  if (!ctx || !G || !Rinv || L <= 0 || l <= 0 || l > L || G == Rinv) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  CHK(set_device(ctx));
+  return launch_rinv(ctx, G, L, l, Rinv);
 }
 extern "C" int eofx_panel_matmul_f32(eofx_ctx* ctx, const float* P, int64_t rows_pad, int L,
                                      const double* M, int Lo, float* out) {
@@ -1727,10 +1678,32 @@ extern "C" int eofx_peaked_spectrum(const double* G, int ld, int l) {
   return std::sqrt(hi / lo) > EOFX_PEAKED_RATIO ? 1 : 0;
 }
 
+// R^-1 (device, L x L float64, leading l x l block) of the Cholesky factor of G: the device kernel up to one
+// wavefront's 64 columns, the host beyond
+static int launch_rinv(eofx_ctx* ctx, const double* G, int L, int l, double* Rinv) {
+  if (l <= 64) {
+    hipLaunchKernelGGL(chol_rinv_kernel, dim3(1), dim3(256), 0, ctx->stream, G, L, l, Rinv, 1e-13);
+    KCHK();
+  } else {
+    std::vector<double> hG((size_t)L * L), hR((size_t)L * L);
+    HIPCHK(hipMemcpyAsync(hG.data(), G, sizeof(double) * L * L, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    host_chol_rinv(hG.data(), L, l, hR.data(), 1e-13);
+    HIPCHK(hipMemcpyAsync(Rinv, hR.data(), sizeof(double) * L * L, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
+  return EOFX_OK;
+}
+
+// first_fwd (optional): replaces the FIRST product A * Zs of the run (the fused fit computes it together with the
+// column statistics, eofx_fit.hpp).  It may return EOFX_FIT_FALLBACK (> 0), which is passed through to the caller.
+constexpr int EOFX_FIT_FALLBACK = 1;
+typedef std::function<int(const float*, float*, int)> FirstFwd;
 static int rsvd_core(eofx_ctx* ctx, const LinOp& op, int k, int l, int n_iter, const float* omega,
-                     RsvdOut& out) {
+                     RsvdOut& out, const FirstFwd* first_fwd = nullptr) {
   const int L = (int)round_up(l, 32);
   const int Lo = (int)round_up(k, 32);
+  AmaxScope amax_scope(ctx);
   ARENA(float, Zs, (size_t)op.small_pad * L);
   ARENA(float, Ws, (size_t)op.small_pad * L);
   ARENA(float, Yt, (size_t)op.tall_pad * L);
@@ -1738,9 +1711,24 @@ static int rsvd_core(eofx_ctx* ctx, const LinOp& op, int k, int l, int n_iter, c
   ARENA(float, Tv, (size_t)op.tall_pad * Lo);
   ARENA(float, Sv, (size_t)op.small_pad * Lo);
   ARENA(double, G, (size_t)L * L);
+  ARENA(double, G0, (size_t)L * L);
+  ARENA(double, R2, (size_t)L * L);
   ARENA(double, Md, (size_t)L * Lo);
+  ARENA(double, Md2, (size_t)L * Lo);
+  double* pin = nullptr;
+  CHK(pinned_scratch(ctx, &pin));
+  if ((size_t)2 * L * L > EOFX_PINNED_DOUBLES) return set_err(ctx, EOFX_ERR_ARG, "internal: sketch too wide for the host scratch");
 
   CHK(import_panel(ctx, omega, op.small, l, Zs, op.small_pad, L));
+  bool first_done = false;
+  auto fwd = [&](const float* z, float* y, int prec) -> int {
+    if (first_fwd && !first_done) {
+      first_done = true;
+      return (*first_fwd)(z, y, L);
+    }
+    first_done = true;
+    return op.fwd(z, y, L, prec);
+  };
   // power iterations: Z <- orth(A^T (A Z)).  Only the small-side panel is orthonormalised
   // (Cholesky-QR with a float64 Gram matrix); the tall panel is never factorised here.
   const int pp = ctx->prec_power, pf = ctx->prec_final;
@@ -1752,37 +1740,66 @@ static int rsvd_core(eofx_ctx* ctx, const LinOp& op, int k, int l, int n_iter, c
   // config-4 fit, so it is skipped there.
   const bool orth_always = orth_tall_rule(op.tall_pad, L, pp);
   bool orth_rest = orth_always;
-  for (int it = 0; it < n_iter; ++it) {
-    CHK(op.fwd(Zs, Yt, L, pp));
+  // The peaked-spectrum question (one L x L download per fit) is asked after the first iteration and answered in the
+  // MIDDLE of the second: the copy goes to page-locked memory behind an event, the next product is launched, and the
+  // host solves its l x l eigen-problem while that product streams the matrix.
+  hipEvent_t peaked_ev = nullptr;
+  bool peaked_pending = false;
+  int rc = EOFX_OK;
+  for (int it = 0; it < n_iter && rc == EOFX_OK; ++it) {
+    rc = fwd(Zs, Yt, pp);
+    if (rc != EOFX_OK) break;
+    if (peaked_pending) {
+      peaked_pending = false;
+      if (hipEventSynchronize(peaked_ev) != hipSuccess) rc = set_err(ctx, EOFX_ERR_HIP, "event wait failed");
+      else orth_rest = eofx_peaked_spectrum(pin, L, l) != 0;
+      if (rc != EOFX_OK) break;
+    }
     if (it == 0 || orth_rest) {
-      CHK(launch_gram(ctx, Yt, op.tall_pad, L, G));
-      CHK(launch_cholqr(ctx, Yt, op.tall_pad, L, l, G, Qt));
-      CHK(op.bwd(Qt, Ws, L, pp));
+      if ((rc = launch_gram(ctx, Yt, op.tall_pad, L, G)) != EOFX_OK) break;
+      if ((rc = launch_cholqr(ctx, Yt, op.tall_pad, L, l, G, Qt)) != EOFX_OK) break;
+      rc = op.bwd(Qt, Ws, L, pp);
     } else {
-      CHK(op.bwd(Yt, Ws, L, pp));
+      rc = op.bwd(Yt, Ws, L, pp);
     }
-    CHK(launch_gram(ctx, Ws, op.small_pad, L, G));
-    if (it == 0 && !orth_always && n_iter > 1) {   // peaked spectrum?  (one small download per fit)
-      std::vector<double> hG0((size_t)L * L);
-      HIPCHK(hipMemcpyAsync(hG0.data(), G, sizeof(double) * L * L, hipMemcpyDeviceToHost, ctx->stream));
-      HIPCHK(hipStreamSynchronize(ctx->stream));
-      orth_rest = eofx_peaked_spectrum(hG0.data(), L, l) != 0;
+    if (rc != EOFX_OK) break;
+    const bool ask = it == 0 && !orth_always && n_iter > 1;
+    if ((rc = launch_gram(ctx, Ws, op.small_pad, L, ask ? G0 : G)) != EOFX_OK) break;
+    if (ask) {   // peaked spectrum?
+      if (hipMemcpyAsync(pin, G0, sizeof(double) * L * L, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+          (!peaked_ev && hipEventCreateWithFlags(&peaked_ev, hipEventDisableTiming) != hipSuccess) ||
+          hipEventRecord(peaked_ev, ctx->stream) != hipSuccess) {
+        rc = set_err(ctx, EOFX_ERR_HIP, "asynchronous Gram download failed");
+        break;
+      }
+      peaked_pending = true;
     }
-    CHK(launch_cholqr(ctx, Ws, op.small_pad, L, l, G, Zs));
+    rc = launch_cholqr(ctx, Ws, op.small_pad, L, l, ask ? G0 : G, Zs);
   }
-  // range basis on the tall side: Q = orth(A Z), CholeskyQR2
-  // the range-basis pass only fixes a subspace (Q is re-orthonormalised): power-pass precision is
-  // enough; the projection B^T = A^T Q below decides the singular values and uses the final one
-  CHK(op.fwd(Zs, Yt, L, pp));
+  if (peaked_ev) {
+    if (peaked_pending) (void)hipEventSynchronize(peaked_ev);
+    (void)hipEventDestroy(peaked_ev);
+  }
+  if (rc != EOFX_OK) return rc;
+  // range basis on the tall side: Q = orth(A Z), CholeskyQR2.  The first factor is applied to the tall panel
+  // (Q1 = Y R1^-1, float32); the second one, R2 = chol(Q1^T Q1) = I + O(eps cond^2), is not: B^T = A^T Q =
+  // (A^T Q1) R2^-1 is a product on the SMALL side and U = Q Uh = Q1 (R2^-1 Uh) folds it into the final rotation --
+  // one pass over the tall panel less, and Q itself is never rounded to float32.
+  // The range-basis pass only fixes a subspace: power-pass precision is enough; the projection B^T = A^T Q below
+  // decides the singular values and uses the final one.
+  CHK(fwd(Zs, Yt, pp));
   CHK(launch_gram(ctx, Yt, op.tall_pad, L, G));
-  CHK(launch_cholqr(ctx, Yt, op.tall_pad, L, l, G, Qt));
+  CHK(launch_cholqr(ctx, Yt, op.tall_pad, L, l, G, Qt));      // Q1
   CHK(launch_gram(ctx, Qt, op.tall_pad, L, G));
-  CHK(launch_cholqr(ctx, Qt, op.tall_pad, L, l, G, Yt));  // Q now in Yt
+  CHK(launch_rinv(ctx, G, L, l, R2));                          // R2^-1
   // B^T = A^T Q  (small x l);  B B^T = (B^T)^T (B^T)
-  CHK(op.bwd(Yt, Ws, L, pf));
+  CHK(op.bwd(Qt, Zs, L, pf));                                  // A^T Q1 (Zs is free now)
+  CHK(launch_matmul(ctx, Zs, op.small_pad, L, R2, L, Ws));     // (A^T Q1) R2^-1
   CHK(launch_gram(ctx, Ws, op.small_pad, L, G));
-  std::vector<double> hG((size_t)L * L);
-  HIPCHK(hipMemcpyAsync(hG.data(), G, sizeof(double) * L * L, hipMemcpyDeviceToHost, ctx->stream));
+  double* hG = pin;
+  double* hR2 = pin + (size_t)L * L;
+  HIPCHK(hipMemcpyAsync(hG, G, sizeof(double) * L * L, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(hR2, R2, sizeof(double) * L * L, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   std::vector<double> Gl((size_t)l * l), w(l), Uh((size_t)l * l);
   for (int i = 0; i < l; ++i)
@@ -1801,16 +1818,17 @@ static int rsvd_core(eofx_ctx* ctx, const LinOp& op, int k, int l, int n_iter, c
     out.s[j] = sv;
     const double inv = sv > 0.0 ? 1.0 / sv : 0.0;
     for (int i = 0; i < l; ++i) {
-      M1[(size_t)i * Lo + j] = Uh[(size_t)i * l + j];
+      double t = 0.0;                                          // (R2^-1 Uh)[i][j]
+      for (int q = 0; q < l; ++q) t += hR2[(size_t)i * L + q] * Uh[(size_t)q * l + j];
+      M1[(size_t)i * Lo + j] = t;
       M2[(size_t)i * Lo + j] = Uh[(size_t)i * l + j] * inv;
     }
   }
   HIPCHK(hipMemcpyAsync(Md, M1.data(), sizeof(double) * L * Lo, hipMemcpyHostToDevice, ctx->stream));
-  CHK(launch_matmul(ctx, Yt, op.tall_pad, L, Md, Lo, Tv));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  HIPCHK(hipMemcpyAsync(Md, M2.data(), sizeof(double) * L * Lo, hipMemcpyHostToDevice, ctx->stream));
-  CHK(launch_matmul(ctx, Ws, op.small_pad, L, Md, Lo, Sv));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipMemcpyAsync(Md2, M2.data(), sizeof(double) * L * Lo, hipMemcpyHostToDevice, ctx->stream));
+  CHK(launch_matmul(ctx, Qt, op.tall_pad, L, Md, Lo, Tv));
+  CHK(launch_matmul(ctx, Ws, op.small_pad, L, Md2, Lo, Sv));
+  HIPCHK(hipStreamSynchronize(ctx->stream));      // M1 / M2 are host vectors of this frame
   out.Tvec = Tv;
   out.Svec = Sv;
   out.Lo = Lo;
@@ -1824,7 +1842,7 @@ static size_t rsvd_scratch_bytes(int64_t tall_pad, int64_t small_pad, int l, int
   b += atb_scratch_bytes(small_pad, tall_pad, (int)L);        // split-K partials (small side)
   b += atb_scratch_bytes(tall_pad, small_pad, (int)L);        // split-K partials (tall side)
   b += atb_scratch_bytes(small_pad, tall_pad, (int)Lo);
-  b += (size_t)(4 * gram_parts(std::max(tall_pad, small_pad), (int)L) + 4) * L * L * 8 + L * Lo * 8;  // gram partials, Rinv, M
+  b += (size_t)(4 * gram_parts(std::max(tall_pad, small_pad), (int)L) + 8) * L * L * 8 + 2 * L * Lo * 8 + 4096;  // gram partials, Rinv, G0, R2, M1, M2
   b += (size_t)std::max(tall_pad, small_pad) * (Lo + L) * 4;  // export / import staging
   b += 4 << 20;
   return b;
@@ -1843,6 +1861,24 @@ static int sign_rule(eofx_ctx* ctx, const float* Vpanel, int64_t rows, int Lo, i
   HIPCHK(hipStreamSynchronize(ctx->stream));
   sign.assign(k, 1.0);
   for (int j = 0; j < k; ++j) sign[j] = (std::fabs(hmx[j]) >= std::fabs(hmn[j])) ? 1.0 : -1.0;
+  return EOFX_OK;
+}
+
+// sign rule, U / s / V to the caller (host|device)
+static int rsvd_finish(eofx_ctx* ctx, const RsvdOut& ro, bool transposed, int64_t n, int64_t p, int k, int flip,
+                       float* U, float* s, float* V) {
+  const float* Vp = transposed ? ro.Tvec : ro.Svec;
+  const float* Up = transposed ? ro.Svec : ro.Tvec;
+  std::vector<double> sign;
+  if (flip) CHK(sign_rule(ctx, Vp, p, ro.Lo, k, sign));
+  CHK(export_panel(ctx, Up, n, ro.Lo, k, flip ? sign.data() : nullptr, U));
+  CHK(export_panel(ctx, Vp, p, ro.Lo, k, flip ? sign.data() : nullptr, V));
+  if (s) {
+    std::vector<float> hs(k);
+    for (int j = 0; j < k; ++j) hs[j] = (float)ro.s[j];
+    HIPCHK(hipMemcpy(s, hs.data(), sizeof(float) * k, hipMemcpyDefault));
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
   return EOFX_OK;
 }
 
@@ -1890,18 +1926,255 @@ extern "C" int eofx_rsvd_f32(eofx_ctx* ctx, const eofx_mat* m, int k, int n_over
   }
   RsvdOut ro;
   CHK(rsvd_core(ctx, op, k, l, n_iter, om, ro));
-  const float* Vp = transposed ? ro.Tvec : ro.Svec;
-  const float* Up = transposed ? ro.Svec : ro.Tvec;
-  std::vector<double> sign;
-  if (flip) CHK(sign_rule(ctx, Vp, p, ro.Lo, k, sign));
-  CHK(export_panel(ctx, Up, n, ro.Lo, k, flip ? sign.data() : nullptr, U));
-  CHK(export_panel(ctx, Vp, p, ro.Lo, k, flip ? sign.data() : nullptr, V));
-  if (s) {
-    std::vector<float> hs(k);
-    for (int j = 0; j < k; ++j) hs[j] = (float)ro.s[j];
-    HIPCHK(hipMemcpy(s, hs.data(), sizeof(float) * k, hipMemcpyDefault));
+  return rsvd_finish(ctx, ro, transposed, n, p, k, flip, U, s, V);
+}
+
+// ------------------------------------------------------------------------------------
+// The fused fit: Scaler.fit + Sanitizer + Decomposer.fit with the column statistics taken during the FIRST pass of
+// the randomized SVD (eofx_fit.hpp): 2 n_iter + 2 reads of the field instead of 2 n_iter + 3.
+// ------------------------------------------------------------------------------------
+static int fit_fused(eofx_ctx* ctx, const float* Xd, int64_t n, int64_t P, int center, int standardize,
+                     const double* feat_weights, int k, int l, int n_iter, const float* omega, int flip,
+                     eofx_mat** out, double* mean, double* std_, double* total_variance, float* U, float* s, float* V) {
+  const int L = (int)round_up(l, 32);
+  const int64_t p_pad = round_up(P, ATB_BM), n_pad = round_up(n, ATB_BM);
+  const int64_t K = round_up(n, ATB_KG);
+  const AtbPlan plan = atb_plan(p_pad, K, L);
+  const int S = plan.S;
+  const int NPART = 64;
+  size_t need = rsvd_scratch_bytes(p_pad, n_pad, l, k);
+  need += (size_t)S * p_pad * (8 + 8 + 4) + (size_t)P * (4 + 6 * 8) + (size_t)p_pad * 4 + (size_t)P * 8;
+  need += (size_t)(NPART + 1) * L * 8 + (size_t)S * p_pad * L * 4 + (1 << 20);
+  CHK(arena_reserve(ctx, need));
+  ArenaScope scope(ctx);
+  PreState ps;
+  ARENA(int, cnt, P);
+  ARENA(double, dmean, P);
+  ARENA(double, dstd, P);
+  ARENA(double, dshift, P);
+  ARENA(double, dscale, P);
+  ARENA(double, dm2, P);
+  ARENA(unsigned, dabsmax, 4);
+  ps = {cnt, dmean, dstd, dshift, dscale, dm2, dabsmax};
+  ARENA(double, dcorr, P);
+  ARENA(float, cshift, p_pad);
+  ARENA(double, st_sum, (size_t)S * p_pad);
+  ARENA(double, st_sq, (size_t)S * p_pad);
+  ARENA(float, st_max, (size_t)S * p_pad);
+  ARENA(double, wpart, (size_t)NPART * L);
+  ARENA(double, wbar, L);
+  ARENA(int, dflags, 4);
+  double* wdev = nullptr;
+  if (feat_weights) {
+    wdev = arena_alloc<double>(ctx, P);
+    if (!wdev) return set_err(ctx, EOFX_ERR_NOMEM, "arena exhausted (weights)");
+    CHK(copy_in(ctx, wdev, feat_weights, sizeof(double) * P));
   }
+  double* pin = nullptr;
+  CHK(pinned_scratch(ctx, &pin));
+  unsigned* hword = reinterpret_cast<unsigned*>(pin + EOFX_PINNED_DOUBLES - 8);   // 4 words beyond what rsvd_core uses
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  struct EvGuard {
+    hipEvent_t* e;
+    ~EvGuard() {
+      for (int i = 0; i < 4; ++i)
+        if (e[i]) (void)hipEventDestroy(e[i]);
+    }
+  } evg{ev};
+  if (ctx->profile) {
+    for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreate(&ev[i]));
+    HIPCHK(hipEventRecord(ev[0], ctx->stream));
+  }
+  // provisional shift (first sample) and scale (sampled max |x - c|, with 2^6 of headroom: the lo fp16 term keeps
+  // 11 bits down to 2^-17 of the largest value, so a generous scale costs nothing; an underestimate is caught by the
+  // overflow flag and sends the fit back to the two-step path)
+  HIPCHK(hipMemsetAsync(dabsmax, 0, sizeof(unsigned) * 4, ctx->stream));
+  HIPCHK(hipMemsetAsync(dflags, 0, sizeof(int) * 4, ctx->stream));
+  hipLaunchKernelGGL(fit_probe_kernel, dim3((int)((p_pad / 4 + 255) / 256)), dim3(256), 0, ctx->stream, Xd, n, P, P, p_pad, cshift,
+                     dabsmax + 1, dflags);
+  KCHK();
+  HIPCHK(hipMemcpyAsync(hword, dabsmax + 1, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(hword + 1, dflags, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  float est;
+  std::memcpy(&est, hword, sizeof(float));
+  if ((hword[1] & 1) || !(est > 0.f) || !std::isfinite(est)) {
+    ctx->fit_info[2] = 1.0;    // NaN in the sampled rows / constant or non-finite sample
+    return EOFX_FIT_FALLBACK;
+  }
+  int e2;
+  (void)std::frexp(est, &e2);
+  const float a_scale = std::ldexp(1.f, 14 - e2 - 6);
+
+  eofx_mat* m = nullptr;
+  CHK(mat_alloc(ctx, n, P, &m, false, false));
+  struct MatGuard {
+    eofx_ctx* c;
+    eofx_mat** m;
+    ~MatGuard() {
+      if (*m) eofx_mat_destroy(c, *m);
+    }
+  } mg{ctx, &m};
+  if (hipMalloc((void**)&m->aff, sizeof(float) * 3 * (size_t)p_pad) != hipSuccess) {
+    (void)hipGetLastError();
+    m->aff = nullptr;
+    return set_err(ctx, EOFX_ERR_NOMEM, "cannot allocate the affine map");
+  }
+  m->raw = Xd;
+  m->raw_ld = P;
+  m->p_valid = P;
+  FeatSummary fs;
+  FirstFwd first = [&](const float* Zs, float* Yt, int LL) -> int {
+    // sum_i Omega[i, :] of the rank-one correction
+    hipLaunchKernelGGL(panel_colsum_part_kernel, dim3(NPART), dim3(256), 0, ctx->stream, Zs, n, LL, wpart);
+    KCHK();
+    hipLaunchKernelGGL(panel_colsum_final_kernel, dim3(1), dim3(256), 0, ctx->stream, wpart, NPART, LL, wbar);
+    KCHK();
+    const float* bmax = amax_get(ctx, Zs);
+    if (!bmax) {
+      unsigned* bm = dabsmax + 2;
+      const int64_t total4 = n_pad * (LL / 4);
+      hipLaunchKernelGGL(panel_absmax_kernel, dim3((int)std::max<int64_t>(1, std::min<int64_t>((total4 + 1023) / 1024, 1024))),
+                         dim3(256), 0, ctx->stream, Zs, n_pad, LL, (int64_t)LL, bm);
+      KCHK();
+      bmax = reinterpret_cast<const float*>(bm);
+    }
+    float* part = Yt;
+    if (S > 1) {
+      part = arena_alloc<float>(ctx, (size_t)S * p_pad * LL);
+      if (!part) return set_err(ctx, EOFX_ERR_NOMEM, "arena exhausted (first-pass partials)");
+    }
+    hipEvent_t p0 = nullptr, p1 = nullptr;
+    if (ctx->profile) {
+      HIPCHK(hipEventRecord(ev[1], ctx->stream));
+      HIPCHK(hipEventCreate(&p0));
+      HIPCHK(hipEventCreate(&p1));
+      HIPCHK(hipEventRecord(p0, ctx->stream));
+    }
+    const dim3 grid((int)(p_pad / ATB_BM), S, 1);
+    if (LL == 64)
+      hipLaunchKernelGGL(atb_f16_fit_kernel<2>, grid, dim3(256), 0, ctx->stream, Xd, P, (int)n, P, cshift, Zs, LL, part, LL, p_pad, K,
+                         plan.kps, a_scale, bmax, st_sum, st_sq, st_max, p_pad);
+    else
+      hipLaunchKernelGGL(atb_f16_fit_kernel<1>, grid, dim3(256), 0, ctx->stream, Xd, P, (int)n, P, cshift, Zs, LL, part, LL, p_pad, K,
+                         plan.kps, a_scale, bmax, st_sum, st_sq, st_max, p_pad);
+    KCHK();
+    if (ctx->profile) {
+      HIPCHK(hipEventRecord(p1, ctx->stream));
+      ctx->prof_events.emplace_back(p0, p1, 0);
+      ctx->prof_flops += 2.0 * (double)K * (double)p_pad * (double)LL;
+      ctx->prof_bytes += (double)n * (double)P * 4.0;
+      HIPCHK(hipEventRecord(ev[2], ctx->stream));
+    }
+    hipLaunchKernelGGL(fit_finalize_kernel, dim3((int)((p_pad + 255) / 256)), dim3(256), 0, ctx->stream, st_sum, st_sq, st_max, p_pad, S,
+                       Xd, P, n, (n / ATB_KC) * ATB_KC, P, p_pad, cshift, a_scale, center, standardize, wdev,
+                       (double)1.1920928955078125e-07, ps.cnt, ps.mean, ps.stdv, ps.shift, ps.scale, ps.m2, m->aff, dcorr,
+                       ps.absmax, dflags + 1);
+    KCHK();
+    HIPCHK(hipMemcpyAsync(hword + 2, dflags + 1, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(hword + 3, ps.absmax, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(m->absmax_dev, ps.absmax, sizeof(unsigned), hipMemcpyDeviceToDevice, ctx->stream));
+    // the rank-one correction does not wait for the verdict on the statistics: it is queued behind them
+    hipLaunchKernelGGL(fit_reduce_kernel, dim3((int)std::min<int64_t>((p_pad * (LL / 4) + 255) / 256, 8192)), dim3(256), 0, ctx->stream,
+                       part, Yt, p_pad, LL, S, P, dcorr, ps.scale, wbar, amax_new(ctx, Yt));
+    KCHK();
+    if (ctx->profile) HIPCHK(hipEventRecord(ev[3], ctx->stream));
+    CHK(run_feature_summary(ctx, ps, P, fs));       // total variance; synchronises
+    if (hword[2] != 0) {
+      ctx->fit_info[2] = 2.0 + (double)hword[2];   // 3: NaN / inf in the field, 4: fp16 overflow of the provisional scale, 5: both
+      return EOFX_FIT_FALLBACK;
+    }
+    std::memcpy(&m->absmax, hword + 3, sizeof(float));
+    return EOFX_OK;
+  };
+  LinOp op = {P, n, p_pad, n_pad,
+              [&](const float* z, float* y, int LL, int pr) { return panel_tmul(ctx, m, z, y, LL, pr); },
+              [&](const float* y, float* w, int LL, int pr) { return panel_mul(ctx, m, y, w, LL, pr); }};
+  RsvdOut ro;
+  int rc = rsvd_core(ctx, op, k, l, n_iter, omega, ro, &first);
+  if (rc != EOFX_OK) return rc;
+  CHK(rsvd_finish(ctx, ro, true, n, P, k, flip, U, s, V));
+  if (mean) HIPCHK(hipMemcpyAsync(mean, ps.mean, sizeof(double) * P, hipMemcpyDeviceToHost, ctx->stream));
+  if (std_) HIPCHK(hipMemcpyAsync(std_, ps.stdv, sizeof(double) * P, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (total_variance) *total_variance = fs.tv;
+  if (ctx->profile) {
+    float t01 = 0.f, t23 = 0.f;
+    (void)hipEventElapsedTime(&t01, ev[0], ev[1]);
+    (void)hipEventElapsedTime(&t23, ev[2], ev[3]);
+    ctx->fit_info[1] = (double)t01 + (double)t23;
+  }
+  *out = m;
+  m = nullptr;
+  return EOFX_OK;
+}
+
+extern "C" int eofx_fit_f32(eofx_ctx* ctx, const float* X, int64_t n, int64_t P, int center, int standardize,
+                            const double* feat_weights, int check_nans, int k, int n_oversamples, int n_iter,
+                            const float* omega, int64_t omega_rows, int flip, eofx_mat** out, double* mean, double* std_,
+                            uint8_t* valid_feature, uint8_t* valid_sample, int64_t* n_out, int64_t* p_out,
+                            double* total_variance, float* U, float* s, float* V, int* fused) {
+  if (!ctx || !X || !out || !omega || n <= 0 || P <= 0 || k <= 0 || n_oversamples < 0)
+    return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  CHK(set_device(ctx));
+  if (fused) *fused = 0;
+  ctx->fit_info[0] = ctx->fit_info[1] = ctx->fit_info[2] = 0.0;
+  Staged st;
+  CHK(stage_input(ctx, X, (size_t)n * P, st));
+  const int l_req = k + n_oversamples;
+  const int l = (int)std::min<int64_t>(l_req, std::min(n, P));
+  const int iters = n_iter < 0 ? rsvd_auto_iters(k, n, P) : n_iter;
+  const bool eligible = ctx->keep_raw == 2 && ctx->prec_power == EOFX_PREC_F16X3 && n < P && k <= n && l == l_req && l < n &&
+                        round_up(l, 32) <= 64 && P % 4 == 0 && ((uintptr_t)st.dev % 16) == 0 && n < ((int64_t)1 << 31) &&
+                        omega_rows >= n && !is_device_ptr(omega) && !std::getenv("EOFX_NO_FUSED_FIT");
+  if (eligible) {
+    const int rc = fit_fused(ctx, st.dev, n, P, center, standardize, feat_weights, k, l, iters, omega, flip, out, mean, std_,
+                             total_variance, U, s, V);
+    if (rc < 0) return rc;
+    if (rc == EOFX_OK) {
+      adopt_staged(out, st, (size_t)n * P * sizeof(float));
+      if (valid_feature) std::memset(valid_feature, 1, (size_t)P);
+      if (valid_sample) std::memset(valid_sample, 1, (size_t)n);
+      if (n_out) *n_out = n;
+      if (p_out) *p_out = P;
+      if (fused) *fused = 1;
+      ctx->fit_info[0] = 1.0;
+      return EOFX_OK;
+    }
+  } else {
+    ctx->fit_info[2] = -1.0;   // shape / precision / layout outside the fused path
+  }
+  // the two-step path: statistics pass, NaN policies of the Sanitizer, then the decomposition
+  eofx_mat* m = nullptr;
+  int64_t ns = 0, pv = 0;
+  CHK(eofx_preprocess_f32(ctx, st.dev, n, P, center, standardize, feat_weights, check_nans, &m, mean, std_, valid_feature,
+                          valid_sample, &ns, &pv, total_variance));
+  adopt_staged(&m, st, (size_t)n * P * sizeof(float));
+  if (n_out) *n_out = ns;
+  if (p_out) *p_out = pv;
+  const int64_t small = std::min(m->n, m->p);
+  int rc = EOFX_OK;
+  if (omega_rows < small)
+    rc = set_err(ctx, EOFX_ERR_ARG, "omega has %lld rows, the compacted matrix needs %lld", (long long)omega_rows, (long long)small);
+  // numpy fills the sketch row by row, so the (small x l) draw of the reference is the leading part of a taller one
+  if (rc == EOFX_OK) rc = eofx_rsvd_f32(ctx, m, k, n_oversamples, n_iter, omega, flip, U, s, V);
+  if (rc != EOFX_OK) {
+    const std::string keep = ctx->err;
+    eofx_mat_destroy(ctx, m);
+    ctx->err = keep;
+    return rc;
+  }
+  *out = m;
+  return EOFX_OK;
+}
+
+// [0] 1 when the last eofx_fit_f32 took the fused path, [1] milliseconds of its non-pass work (probe, finalize,
+// correction; measured with HIP events when profiling is on, else 0), [2] why not: 0 fused, -1 not eligible (shape,
+// precision, layout), 1 NaN / constant data in the sampled rows, 3 NaN or inf in the field, 4 fp16 range of the
+// provisional scale exceeded, 5 both
+extern "C" int eofx_ctx_fit_info(const eofx_ctx* ctx, double* info3) {
+  if (!ctx || !info3) return EOFX_ERR_ARG;
+  for (int i = 0; i < 3; ++i) info3[i] = ctx->fit_info[i];
   return EOFX_OK;
 }
 

@@ -353,7 +353,11 @@ __device__ __forceinline__ float f16_scale_for(float m) {
 // 32-column remainder) or 4 (128 columns, one workgroup per CU with 256 accumulator registers: the WIDE products -- Gram
 // matrices, PCA panels -- re-read A half as often).  sym: C is a symmetric product (B = A): 128-column tiles lying
 // entirely below the diagonal are skipped (symmetrize_lower_kernel fills them in afterwards).
-template <int NB, bool AFF = false>
+// MASK (with AFF): features whose scale is 0 are the field's all-NaN grid points (land / sea masks, sanitizer.py:80-126)
+// kept as zero columns instead of being compacted away: their bits are ANDed to +0 before the map, so NaN never reaches
+// the matrix cores (one v_and per element; a NaN inside a VALID feature still propagates, as it must).
+// amax_out (may be null; single split only): max |C| by atomicMax on the float bits -- the next pass' panel maximum.
+template <int NB, bool AFF = false, bool MASK = false>
 __global__ __launch_bounds__(256, NB > 2 ? 1 : 2) void atb_f16_kernel(const float* __restrict__ A, int64_t lda,
                                                           const float* __restrict__ B, int ldb,
                                                           float* __restrict__ C, int ldc, int64_t M,
@@ -363,7 +367,8 @@ __global__ __launch_bounds__(256, NB > 2 ? 1 : 2) void atb_f16_kernel(const floa
                                                           const float* __restrict__ aff = nullptr,
                                                           int64_t aff_ld = 0, int a_rows = 0, int64_t a_cols = 0,
                                                           const float* A2 = nullptr, const float* B2 = nullptr,
-                                                          int s_half = 0, int sym = 0) {
+                                                          int s_half = 0, int sym = 0,
+                                                          unsigned* __restrict__ amax_out = nullptr) {
   // Two-matrix form (complex passes, eofx_rsvd_c64): splits [s_half, 2 s_half) stream a second matrix A2 (same shape)
   // against its own panel B2 -- C = A^T B + A2^T B2 in one launch, summed by the split-K reduction.
   __shared__ __attribute__((aligned(16))) _Float16 Bs[2][2][2][32 * NB][8];
@@ -456,8 +461,11 @@ __global__ __launch_bounds__(256, NB > 2 ? 1 : 2) void atb_f16_kernel(const floa
         bf_[s][q] = *reinterpret_cast<const f16x8*>(&Bs[buf][s][lh][32 * q + li][0]);            \
     _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                              \
       f32x8 x_;                                                                                  \
-      _Pragma("unroll") for (int t = 0; t < 8; ++t)                                              \
-          x_[t] = AFF ? aff_map(areg[t][j], shh_[j], shl_[j], sla_[j]) : areg[t][j] * a_scale;     \
+      const unsigned msk_ = (AFF && MASK) ? (sla_[j] != 0.f ? 0xffffffffu : 0u) : 0xffffffffu;   \
+      _Pragma("unroll") for (int t = 0; t < 8; ++t) {                                            \
+        const float xr_ = (AFF && MASK) ? __uint_as_float(__float_as_uint(areg[t][j]) & msk_) : areg[t][j]; \
+        x_[t] = AFF ? aff_map(xr_, shh_[j], shl_[j], sla_[j]) : xr_ * a_scale;                    \
+      }                                                                                          \
       f16x8 af_[2];                                                                              \
       split_f16(x_, af_);                                                                        \
       _Pragma("unroll") for (int q = 0; q < NB; ++q) {                                           \
@@ -501,6 +509,19 @@ __global__ __launch_bounds__(256, NB > 2 ? 1 : 2) void atb_f16_kernel(const floa
         const int64_t m = m0 + 4 * ii + j;
         Cs[m * ldc + bcol0 + 32 * q + li] = acc[j][q][r] * out_scale;
       }
+  if (amax_out) {
+    float mx = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int q = 0; q < NB; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fabsf(acc[j][q][r]));
+    mx *= out_scale;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if (lane == 0 && mx > 0.f) atomicMax(amax_out, __float_as_uint(mx));
+  }
 }
 
 // ---------------------------------------------------------------------------------
@@ -531,7 +552,8 @@ constexpr int AXB_BM = 256;   // rows per workgroup
 constexpr int AXB_LDA = 40;   // halves per staged row (32 + 8 of padding)
 
 // DBG (tools/probes/axb_probe.hip only): 1 no MFMA, 2 no conversion either, 4 no B / map loads, 8 cached A loads
-template <int NQ, int DBG = 0>   // 16-column tiles per workgroup column block: 4 (64 columns) or 2 (a 32-column remainder)
+// MASK: as in atb_f16_kernel -- features with scale 0 (all-NaN grid points kept as zero columns) are ANDed to +0.
+template <int NQ, int DBG = 0, bool MASK = false>   // 16-column tiles per workgroup column block: 4 (64 columns) or 2 (a 32-column remainder)
 __global__ __launch_bounds__(256, 2) void axb_f16_kernel(const float* __restrict__ A, int64_t lda, int a_rows,
                                                           int64_t a_cols, const float* __restrict__ aff, int64_t aff_ld,
                                                           const float* __restrict__ B, int ldb, float* __restrict__ C,
@@ -647,7 +669,8 @@ __global__ __launch_bounds__(256, 2) void axb_f16_kernel(const float* __restrict
     } else {                                                                                           \
       _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                  \
         /* aff_map on a pair (packed float32 arithmetic: the same three roundings per element) */       \
-        const f32x2 x_ = {areg[u][2 * h], areg[u][2 * h + 1]};                                         \
+        const f32x2 x_ = {MASK ? __uint_as_float(__float_as_uint(areg[u][2 * h]) & mk_[2 * h]) : areg[u][2 * h],           \
+                          MASK ? __uint_as_float(__float_as_uint(areg[u][2 * h + 1]) & mk_[2 * h + 1]) : areg[u][2 * h + 1]}; \
         const f32x2 v_ = ((x_ + fh_[h]) + fl_[h]) * fs_[h];   /* fh_, fl_ hold the NEGATED shift pair */ \
         const fp16x2_t p_ = __builtin_amdgcn_cvt_pkrtz(v_[0], v_[1]);                                  \
         const fp16x2_t q_ = __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf((float)p_[0], m1, v_[0]),        \
@@ -697,6 +720,9 @@ __global__ __launch_bounds__(256, 2) void axb_f16_kernel(const float* __restrict
         asm volatile("" : "+v"(fh_[h]), "+v"(fl_[h]));   /* keep them additions (v_pk_add_f32) */         \
         fs_[h] = f32x2{fr[2][2 * h], fr[2][2 * h + 1]} * a_scale;   /* exact: a power of two */         \
       }                                                                                                \
+      unsigned mk_[4];                                                                                 \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e) mk_[e] = (MASK && fr[2][e] == 0.f) ? 0u : 0xffffffffu; \
+      (void)mk_;                                                                                       \
       EOFX_LOAD_F(fr, next_f);    /* the triples of the NEXT slab (L2 hits: one slab of lead is enough) */ \
       EOFX_AXB_CONVERT(areg, 0)                                                                        \
       EOFX_LOAD_A(areg, next_a, 0);                                                                    \
@@ -917,10 +943,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_f64_kernel(const double* __
 }
 
 // out[i] = sum_s part[s][i], fixed order, float64 accumulate.  count4 = elements / 4.
+// amax_out (may be null): max |out| by atomicMax on the float bits (order independent) -- the panel maximum the next
+// split-fp16 pass scales by, taken where the panel is written instead of by one more read of it.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part,
                                                             float* __restrict__ out,
-                                                            int64_t count4, int splits) {
+                                                            int64_t count4, int splits,
+                                                            unsigned* __restrict__ amax_out = nullptr) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  float mx = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count4; i += stride) {
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
     for (int s = 0; s < splits; ++s) {
@@ -932,6 +962,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
     f32x4 o = {(float)s0, (float)s1, (float)s2, (float)s3};
     reinterpret_cast<f32x4*>(out)[i] = o;
+    mx = fmaxf(mx, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
+  }
+  if (amax_out) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(amax_out, __float_as_uint(mx));
   }
 }
 
@@ -1241,8 +1277,10 @@ constexpr int PMM_LD = 66;   // doubles per staged row of Mx
 __global__ __launch_bounds__(256) void panel_matmul_kernel(const float* __restrict__ P,
                                                            int64_t rows, int L,
                                                            const double* __restrict__ Mx, int Lo,
-                                                           float* __restrict__ out, int KW) {
-  extern __shared__ __attribute__((aligned(16))) double Ms[];   // [KW][PMM_LD]: KW = multiple of 64, the K window in LDS
+                                                           float* __restrict__ out, int KW,
+                                                           unsigned* __restrict__ amax_out = nullptr) {
+  extern __shared__ __attribute__((aligned(16))) double Ms[];
+  float amx = 0.f;   // [KW][PMM_LD]: KW = multiple of 64, the K window in LDS
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lk = lane >> 4;
@@ -1300,7 +1338,11 @@ __global__ __launch_bounds__(256) void panel_matmul_kernel(const float* __restri
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int col = c0 + 16 * q + li;
-            if (col < Lo) out[row * Lo + col] = (float)acc[t][q][r];
+            if (col < Lo) {
+              const float o_ = (float)acc[t][q][r];
+              out[row * Lo + col] = o_;
+              amx = fmaxf(amx, fabsf(o_));
+            }
           }
         }
     }
@@ -1342,6 +1384,11 @@ __global__ __launch_bounds__(256) void panel_matmul_kernel(const float* __restri
         if (active && ch + 1 < we) compute(g0, 64 * (ch + 1), 64 * w0, a1);
       }
     }
+  }
+  if (amax_out) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amx = fmaxf(amx, __shfl_xor(amx, o));
+    if (lane == 0 && amx > 0.f) atomicMax(amax_out, __float_as_uint(amx));
   }
 }
 
@@ -1440,13 +1487,21 @@ __global__ __launch_bounds__(256) void panel_export_kernel(const float* __restri
 __global__ __launch_bounds__(256) void panel_import_kernel(const float* __restrict__ src,
                                                            int64_t rows, int l,
                                                            float* __restrict__ P, int64_t rows_pad,
-                                                           int L) {
+                                                           int L, unsigned* __restrict__ amax_out = nullptr) {
   const int64_t total = rows_pad * L;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  float mx = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
     const int64_t r = i / L;
     const int c = (int)(i - r * L);
-    P[i] = (r < rows && c < l) ? src[r * l + c] : 0.f;
+    const float v = (r < rows && c < l) ? src[r * l + c] : 0.f;
+    P[i] = v;
+    mx = fmaxf(mx, fabsf(v));
+  }
+  if (amax_out) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(amax_out, __float_as_uint(mx));
   }
 }
 
@@ -1776,8 +1831,10 @@ __global__ __launch_bounds__(256) void apply_kernel(const float* __restrict__ X,
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         if (sc[e] >= 0) {
-          if (x[e] != x[e]) bad = true;
-          v[e] = aff_map(x[e], shh[e], shl[e], slf[e]);
+          // scale 0 in the packed triples of an in-place matrix = an all-NaN grid point kept as a zero column
+          const bool masked_ = aff && slf[e] == 0.f;
+          if (x[e] != x[e] && !masked_) bad = true;
+          v[e] = masked_ ? 0.f : aff_map(x[e], shh[e], shl[e], slf[e]);
         }
     }
     if (Xc) *reinterpret_cast<f32x4*>(Xc + r * p_pad + cb) = v;   // absent in raw mode (eofx_ctx_set_layout)
@@ -2305,7 +2362,8 @@ __global__ __launch_bounds__(256) void rownorm_aff_kernel(const float* __restric
   if (r >= rows) return;
   double s = 0.0;
   for (int64_t c = lane; c < L; c += 64) {
-    const double v = (double)aff_map(P[r * ld + c], aff[c], aff[aff_ld + c], aff[2 * aff_ld + c]);
+    const float sl = aff[2 * aff_ld + c];      // 0: an all-NaN grid point kept as a zero column
+    const double v = sl == 0.f ? 0.0 : (double)aff_map(P[r * ld + c], aff[c], aff[aff_ld + c], sl);
     s += v * v;
   }
 #pragma unroll

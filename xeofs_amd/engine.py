@@ -66,7 +66,7 @@ class Context:
                   self.handle)
         kl, km = (C.c_int64 * 3)(), (C.c_double * 3)()
         raise_for(self.lib.eofx_ctx_profile_by_kernel(self.handle, kl, km), self.handle)
-        by_kernel = {name: dict(launches=int(kl[i]), ms=float(km[i])) for i, name in enumerate(("atb", "axb", "fused")) if kl[i]}
+        by_kernel = {name: dict(launches=int(kl[i]), ms=float(km[i])) for i, name in enumerate(("atb", "axb")) if kl[i]}
         return dict(launches=n.value, ms=ms.value, flops=fl.value, bytes=by.value, by_kernel=by_kernel)
 
     def close(self):
@@ -288,6 +288,72 @@ def preprocess(ctx: Context, X, center=True, standardize=False, feature_weights=
     return mat, stats
 
 
+def fit(ctx: Context, X, k: int, center=True, standardize=False, feature_weights=None, check_nans=True,
+        n_oversamples: int = 10, n_iter: int | str = "auto", random_state=None, flip: bool = True, omega=None,
+        want_stats=True, device_out: bool = False, in_place: bool = True):
+    """Scaler + Sanitizer + randomized SVD in one engine call (eofx_fit_f32): with the in-place layout the column
+    statistics ride on the first pass of the decomposition, so the field is read 2 n_iter + 2 times, not 2 n_iter + 3.
+    Same results as `preprocess(..., in_place=True)` followed by `rsvd(...)` (which is what the engine falls back to by
+    itself for NaN fields, other precisions, wide sketches, n >= P).
+    -> (ResidentMatrix, stats dict (as `preprocess`, plus `fused`), U[n', k], s[k], V[p', k])"""
+    X = _f32c(X)
+    n, P = X.shape
+    k = int(k)
+    w = None if feature_weights is None else np.ascontiguousarray(feature_weights, dtype=np.float64)
+    if w is not None and w.shape != (P,):
+        raise ValueError("feature_weights must have one entry per stacked feature")
+    small = min(n, P)
+    if omega is None:
+        omega = sketch_matrix(small, k + n_oversamples, random_state)
+    elif isinstance(omega, SketchFuture):
+        omega = omega.result()
+    omega = np.ascontiguousarray(omega, dtype=np.float32)
+    if omega.ndim != 2 or omega.shape[1] != k + n_oversamples or omega.shape[0] < small:
+        raise ValueError(f"omega must have shape {(small, k + n_oversamples)}")
+    mean = np.empty(P, np.float64) if want_stats else None
+    std = np.empty(P, np.float64) if want_stats else None
+    vf = np.empty(P, np.uint8)
+    vs = np.empty(n, np.uint8)
+    n_out, p_out = C.c_int64(), C.c_int64()
+    tv = C.c_double()
+    fused = C.c_int()
+    h = C.c_void_p()
+    if device_out:
+        torch = _torch()
+        U = torch.empty((n, k), dtype=torch.float32, device=f"cuda:{ctx.device}")
+        V = torch.empty((P, k), dtype=torch.float32, device=f"cuda:{ctx.device}")
+    else:
+        U = _host_out((n, k))
+        V = _host_out((P, k))
+    s = np.empty(k, np.float32)
+    it = -1 if n_iter == "auto" else int(n_iter)
+    ctx.lib.eofx_ctx_set_layout(ctx.handle, 2 if in_place else 0)
+    try:
+        rc = ctx.lib.eofx_fit_f32(ctx.handle, ptr(X), n, P, int(center), int(standardize), ptr(w), int(check_nans), k,
+                                  int(n_oversamples), it, ptr(omega), omega.shape[0], int(flip), C.byref(h), ptr(mean),
+                                  ptr(std), ptr(vf), ptr(vs), C.byref(n_out), C.byref(p_out), C.byref(tv), ptr(U), ptr(s),
+                                  ptr(V), C.byref(fused))
+    finally:
+        ctx.lib.eofx_ctx_set_layout(ctx.handle, 0)
+    raise_for(rc, ctx.handle)
+    mat = ResidentMatrix(ctx, h)
+    if hasattr(X, "data_ptr"):
+        mat._keepalive = X
+    stats = dict(mean=mean, std=std, valid_feature=vf.astype(bool), valid_sample=vs.astype(bool),
+                 n=n_out.value, p=p_out.value, total_variance=tv.value, fused=bool(fused.value))
+    if mat.n != n or mat.p != P:     # the factors were written densely with the compacted shape
+        U = U.reshape(-1)[: mat.n * k].reshape(mat.n, k)
+        V = V.reshape(-1)[: mat.p * k].reshape(mat.p, k)
+    return mat, stats, U, s, V
+
+
+def fit_info(ctx: Context):
+    """-> dict(fused, preprocess_ms, reason) of the last `fit` on this context (include/eofx.h, eofx_ctx_fit_info)"""
+    info = (C.c_double * 3)()
+    raise_for(ctx.lib.eofx_ctx_fit_info(ctx.handle, info), ctx.handle)
+    return dict(fused=bool(info[0]), preprocess_ms=float(info[1]), reason=int(info[2]))
+
+
 def apply(ctx: Context, X, mean, std, feature_weights, valid_feature, check_nans=True, in_place=False):
     """Preprocessor.transform on new data with fitted state.  in_place: as in `preprocess` -- nothing is written, the
     projection that follows streams the (staged) field through the fitted map."""
@@ -472,6 +538,14 @@ def panel_cholqr(ctx: Context, P, l: int, G, out=None):
     return out
 
 
+def panel_rinv(ctx: Context, G, l: int):
+    """R^-1 (L x L float64 device tensor) of the Cholesky factor of the leading l x l block of G"""
+    torch = _torch()
+    out = torch.empty_like(G)
+    raise_for(ctx.lib.eofx_panel_rinv_f64(ctx.handle, ptr(G), G.shape[0], int(l), ptr(out)), ctx.handle)
+    return out
+
+
 def panel_matmul(ctx: Context, P, M, out=None):
     torch = _torch()
     Lo = M.shape[1]
@@ -632,14 +706,3 @@ def rsvd_c64(ctx: Context, A: ResidentMatrix, B: ResidentMatrix, k: int, n_overs
     raise_for(ctx.lib.eofx_rsvd_c64(ctx.handle, A.handle, B.handle, k, int(n_oversamples), it, ptr(omega), int(flip),
                                     ptr(U), ptr(s), ptr(V)), ctx.handle)
     return U, s, V
-
-
-def panel_fused(ctx: Context, mat: ResidentMatrix, Zn, out=None, want_y=False):
-    """Wn[n_pad, 64] = X (X^T Zn) in one pass over the matrix; with want_y also Yp[p_pad, 64] = X^T Zn"""
-    torch = _torch()
-    if out is None:
-        out = torch.empty((mat.n_pad, Zn.shape[1]), dtype=torch.float32, device=Zn.device)
-    Y = torch.empty((mat.p_pad, Zn.shape[1]), dtype=torch.float32, device=Zn.device) if want_y else None
-    raise_for(ctx.lib.eofx_panel_fused_f32(ctx.handle, mat.handle, ptr(Zn), ptr(out), ptr(Y) if want_y else None,
-                                           Zn.shape[1]), ctx.handle)
-    return (out, Y) if want_y else out

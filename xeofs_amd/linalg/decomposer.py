@@ -51,27 +51,27 @@ class Decomposer:
         # branch keeps its parameters: sketch width max(20, k + 10), n_power_iter (default 4) power passes.
         self.lazy_input = bool(lazy_input)
 
-    def fit(self, X, dims=("sample", "feature"), total_variance=None, omega=None):
-        """`omega`: optional pre-drawn sketch (engine.SketchFuture / ndarray) so the host-side sampling can
-        overlap the preprocessing kernels; it must be the matrix `sketch_matrix` would draw."""
-        ctx = self.ctx or engine.default_context()
-        mat = X if isinstance(X, engine.ResidentMatrix) else engine.from_dense(ctx, np.asarray(X))
-        n, p = mat.shape
+    def policy(self, n, p, quiet=False):
+        """The solver ladder of decomposer.py:86-131 for an (n x p) matrix -> (k, n_oversamples, n_iter, wide):
+        the sketch the engine is asked for, and whether it is wider than the sketch kernels hold.  Raises / warns as
+        the reference does (quiet: no warning, for a provisional look before the NaN compaction is known)."""
         rank = min(n, p)
+        k_pre = self.n_modes
         if self.is_based_on_variance:
-            self.n_modes_precompute = int(rank * self.init_rank_reduction)
-            if self.n_modes_precompute < 1:
-                warnings.warn(
-                    f"`init_rank_reduction={self.init_rank_reduction}` is too low resulting in zero components. One component will be computed instead."
-                )
-                self.n_modes_precompute = 1
-        if self.n_modes_precompute > rank:
+            k_pre = int(rank * self.init_rank_reduction)
+            if k_pre < 1:
+                if not quiet:
+                    warnings.warn(
+                        f"`init_rank_reduction={self.init_rank_reduction}` is too low resulting in zero components. One component will be computed instead."
+                    )
+                k_pre = 1
+        if k_pre > rank:
             raise ValueError(
                 f"n_modes must be less than or equal to the rank of the dataset (rank = {rank})."
             )
         is_small_data = max(n, p) < 500
         if self.solver == "auto":
-            use_exact = bool(is_small_data and self.n_modes_precompute > int(0.8 * rank) and not self.lazy_input)
+            use_exact = bool(is_small_data and k_pre > int(0.8 * rank) and not self.lazy_input)
         elif self.solver == "full":
             use_exact = True
         elif self.solver == "randomized":
@@ -81,11 +81,10 @@ class Decomposer:
                 f"Unrecognized solver '{self.solver}'. "
                 "Valid options are 'auto', 'full', and 'randomized'."
             )
-        k = int(self.n_modes_precompute)
+        k = int(k_pre)
         kw = dict(self.solver_kwargs)
         for name in ("power_iteration_normalizer", "transpose", "flip_sign", "svd_lapack_driver"):
             kw.pop(name, None)  # sklearn knobs without effect on the result here
-        wide = False
         if use_exact:
             # A full-width sketch spans the whole row/column space: the same kernels then return the
             # exact truncated SVD (no power iterations needed).
@@ -102,6 +101,17 @@ class Decomposer:
             n_over = int(kw.pop("n_oversamples", 10))
             n_iter = kw.pop("n_iter", "auto")
             wide = min(k + n_over, rank) > MAX_SKETCH
+        return k, n_over, n_iter, wide
+
+    def fit(self, X, dims=("sample", "feature"), total_variance=None, omega=None):
+        """`omega`: optional pre-drawn sketch (engine.SketchFuture / ndarray) so the host-side sampling can
+        overlap the preprocessing kernels; it must be the matrix `sketch_matrix` would draw."""
+        ctx = self.ctx or engine.default_context()
+        mat = X if isinstance(X, engine.ResidentMatrix) else engine.from_dense(ctx, np.asarray(X))
+        n, p = mat.shape
+        rank = min(n, p)
+        k, n_over, n_iter, wide = self.policy(n, p)
+        self.n_modes_precompute = k
         if wide:
             # more modes than the sketch kernels hold (e.g. float n_modes -> int(0.3 * rank) modes): at that
             # width the exact small-side Gram route is cheaper than the randomized passes (xeofs_amd/pca.py)
@@ -119,6 +129,30 @@ class Decomposer:
                 om = None      # drawn for another policy branch: fall back to drawing it now
         U, s, V = engine.rsvd(ctx, mat, k, n_over, n_iter, random_state=self.random_state, flip=bool(self.flip_signs),
                               omega=om)
+        return self._finish(U, s, V, n, k, total_variance)
+
+    def fused_plan(self, n, P):
+        """(k, n_oversamples, n_iter) when an (n x P) raw field can go through the engine's fused fit (eofx_fit_f32:
+        statistics during the first pass of the randomized SVD), else None.  Only where the policy cannot change under
+        NaN compaction: randomized branch, sketch of at most 64 columns on the sample side, not 'small data'."""
+        if self.lazy_input or self.is_based_on_variance or max(n, P) < 500 or n >= P:
+            return None
+        try:
+            k, n_over, n_iter, wide = self.policy(n, P, quiet=True)
+        except ValueError:
+            return None
+        if wide or n_iter == 0 or not (0 < k + n_over <= 64) or k + n_over >= n:
+            return None
+        return k, n_over, n_iter
+
+    def adopt(self, mat, U, s, V, total_variance, plan):
+        """Take the factors the fused fit produced with `plan` = fused_plan(raw shape).  If NaN compaction changed the
+        shape so much that the solver ladder would have chosen differently, decompose again the reference's way."""
+        n, p = mat.shape
+        k, n_over, n_iter = plan
+        if self.policy(n, p) != (k, n_over, n_iter, False):
+            return self.fit(mat, total_variance=total_variance)
+        self.n_modes_precompute = k
         return self._finish(U, s, V, n, k, total_variance)
 
     def _finish(self, U, s, V, n, k, total_variance):

@@ -136,6 +136,33 @@ class Preprocessor:
         self.total_variance = st["total_variance"]
         return mat
 
+    def fit_transform_decompose(self, X, sample_dims, weights, decomposer, omega=None):
+        """Preprocessor.fit_transform and Decomposer.fit in ONE engine call where the shape allows (engine.fit /
+        eofx_fit_f32: the Scaler's statistics ride on the first pass of the randomized SVD); otherwise the two steps.
+        -> the resident matrix; `decomposer` holds U_, s_, V_ afterwards."""
+        self.sample_dims = _as_tuple(sample_dims)
+        ctx = self.ctx or engine.default_context()
+        self.fields = self._fields(X, self.sample_dims)
+        M, self.feature_weights = self._stack(self.fields, weights)
+        n, P = M.shape
+        plan = decomposer.fused_plan(n, P) if self.in_place and ctx.precision[0] == "f16x3" else None
+        if plan is None:
+            mat, st = engine.preprocess(ctx, M, self.center, self.standardize, self.feature_weights, self.check_nans,
+                                        in_place=self.in_place)
+        else:
+            k, n_over, n_iter = plan
+            mat, st, U, s, V = engine.fit(ctx, M, k, self.center, self.standardize, self.feature_weights, self.check_nans,
+                                          n_over, n_iter, random_state=decomposer.random_state,
+                                          flip=bool(decomposer.flip_signs), omega=omega)
+        self.mean_, self.std_ = (st["mean"] if self.center else None), (st["std"] if self.standardize else None)
+        self.valid_feature, self.valid_sample = st["valid_feature"], st["valid_sample"]
+        self.total_variance = st["total_variance"]
+        if plan is None:
+            decomposer.fit(mat, total_variance=self.total_variance, omega=omega)
+        else:
+            decomposer.adopt(mat, U, s, V, self.total_variance, plan)
+        return mat
+
     def transform(self, X):
         ctx = self.ctx or engine.default_context()
         fields = self._fields_like(X)

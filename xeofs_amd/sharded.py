@@ -31,21 +31,60 @@ class Comm:
         self.active = init and (dist.get_world_size(group) > 1 or force)
         self.rank = dist.get_rank(group) if (dist.is_available() and dist.is_initialized()) else 0
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self._prof = None
+
+    # Measurement aid (bench.py `comm`): with profiling on, every collective is bracketed by events on the current
+    # stream (device tensors: the stream waits for RCCL's, so the interval covers the collective) or by wall time
+    # (host tensors); profile_read() -> dict(calls, bytes, ms) since profile(True) and resets.
+    def profile(self, enable=True):
+        self._prof = dict(calls=0, bytes=0, ms=0.0, events=[]) if enable else None
+
+    def profile_read(self):
+        pr = self._prof or dict(calls=0, bytes=0, ms=0.0, events=[])
+        ms = pr["ms"]
+        if pr["events"]:
+            import torch
+
+            torch.cuda.synchronize()
+            ms += sum(a.elapsed_time(b) for a, b in pr["events"])
+        out = dict(calls=pr["calls"], bytes=pr["bytes"], ms=ms)
+        if self._prof is not None:
+            self.profile(True)
+        return out
+
+    def _reduce(self, t, op):
+        if not self.active:
+            return t
+        pr = self._prof
+        if pr is None:
+            self.dist.all_reduce(t, op=op, group=self.group)
+            return t
+        pr["calls"] += 1
+        pr["bytes"] += t.numel() * t.element_size()
+        if t.is_cuda:
+            import torch
+
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            self.dist.all_reduce(t, op=op, group=self.group)
+            b.record()
+            pr["events"].append((a, b))
+        else:
+            import time
+
+            t0 = time.perf_counter()
+            self.dist.all_reduce(t, op=op, group=self.group)
+            pr["ms"] += 1e3 * (time.perf_counter() - t0)
+        return t
 
     def sum_(self, t):
-        if self.active:
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
-        return t
+        return self._reduce(t, self.dist.ReduceOp.SUM)
 
     def max_(self, t):
-        if self.active:
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
-        return t
+        return self._reduce(t, self.dist.ReduceOp.MAX)
 
     def min_(self, t):
-        if self.active:
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.group)
-        return t
+        return self._reduce(t, self.dist.ReduceOp.MIN)
 
 
 class HipPanelOps:
@@ -77,10 +116,13 @@ class HipPanelOps:
     def cholqr(self, P, l, G):
         return self.e.panel_cholqr(self.ctx, P, l, G)
 
+    def rinv(self, G, l):
+        return self.e.panel_rinv(self.ctx, G, l)
+
     def matmul(self, P, M):
         import torch
 
-        Md = torch.as_tensor(np.ascontiguousarray(M, dtype=np.float64), device=P.device)
+        Md = M if torch.is_tensor(M) else torch.as_tensor(np.ascontiguousarray(M, dtype=np.float64), device=P.device)
         return self.e.panel_matmul(self.ctx, P, Md)
 
     def colminmax(self, P, rows):
@@ -163,8 +205,10 @@ def _rsvd_panels(la, to_tall, to_small, gram_small, gram_tall, Z, l, k, n_iter, 
         Z = la.cholqr(W, l, Gs)
     Yt = to_tall(Z, False)                       # range basis: a subspace only, power-pass precision
     Q = la.cholqr(Yt, l, gram_tall(Yt))
-    Q = la.cholqr(Q, l, gram_tall(Q))            # CholeskyQR2
-    Bt = to_small(Q, True)
+    # CholeskyQR2 as in rsvd_core: the second factor R2 = chol(Q^T Q) is applied on the SMALL side, B^T = (A^T Q) R2^-1,
+    # and folded into the final rotation of the tall panel -- one pass over the tall panel less
+    R2 = la.rinv(gram_tall(Q), l)
+    Bt = la.matmul(to_small(Q, True), R2)
     G = gram_small(Bt)
     Gh = G.detach().cpu().numpy()[:l, :l]
     Gh = 0.5 * (Gh + Gh.T)
@@ -176,13 +220,23 @@ def _rsvd_panels(la, to_tall, to_small, gram_small, gram_tall, Z, l, k, n_iter, 
     Lo = (k + 31) // 32 * 32
     M1 = np.zeros((L, Lo))
     M2 = np.zeros((L, Lo))
-    M1[:l, :k] = Uh[:, :k]
+    R2h = R2.detach().cpu().numpy() if hasattr(R2, "detach") else np.asarray(R2)
+    M1[:l, :k] = _matmul_rowwise(R2h[:l, :l], Uh[:, :k])
     with np.errstate(divide="ignore"):
         inv = np.where(s > 0, 1.0 / s, 0.0)
     M2[:l, :k] = Uh[:, :k] * inv
     Tv = la.matmul(Q, M1)       # singular vectors on the tall side
     Sv = la.matmul(Bt, M2)      # singular vectors on the small side
     return Tv, Sv, s
+
+
+def _matmul_rowwise(A, B):
+    """A @ B summed over the inner index in ascending order with one accumulator per entry (the loop of rsvd_core:
+    numpy's BLAS would block the sum differently and the two drivers must agree bit for bit)"""
+    out = np.zeros((A.shape[0], B.shape[1]))
+    for q in range(A.shape[1]):
+        out += A[:, q:q + 1] * B[q:q + 1, :]
+    return out
 
 
 def _sign_from_extrema(comm, ops, Vp, rows, k):

@@ -51,9 +51,12 @@ class EOF(Deferred):
         self.preprocessor.ctx = self.ctx
         self._decomposer_kwargs["lazy_input"] = labelled.is_lazy(X)
         omega = None if self._decomposer_kwargs["lazy_input"] else self._sketch_ahead(X, dim)
-        mat = self.preprocessor.fit_transform(X, dim, weights)      # fused HIP preprocess
+        # Preprocessor.fit_transform + Decomposer.fit (eof.py:85-97) as ONE engine call where the shape allows: the
+        # column statistics ride on the first pass of the randomized SVD (eofx_fit_f32)
+        dec = Decomposer(ctx=self.ctx, **self._decomposer_kwargs)
+        mat = self.preprocessor.fit_transform_decompose(X, dim, weights, dec, omega)
         self.sample_dims = self.preprocessor.sample_dims
-        return self._fit_algorithm(mat, omega)
+        return self._fit_algorithm(mat, dec=dec)
 
     def _sketch_ahead(self, X, dim):
         """Start drawing the sketch (host, sklearn's RandomState stream) on a worker thread so it
@@ -74,11 +77,12 @@ class EOF(Deferred):
         except Exception:
             return None
 
-    def _fit_algorithm(self, mat, omega=None):
+    def _fit_algorithm(self, mat, omega=None, dec=None):
         """xeofs/single/eof.py:85-118."""
         total_variance = self.preprocessor.total_variance                     # eof.py:93
-        dec = Decomposer(ctx=self.ctx, **self._decomposer_kwargs)
-        dec.fit(mat, dims=(self.sample_name, self.feature_name), total_variance=total_variance, omega=omega)
+        if dec is None:
+            dec = Decomposer(ctx=self.ctx, **self._decomposer_kwargs)
+            dec.fit(mat, dims=(self.sample_name, self.feature_name), total_variance=total_variance, omega=omega)
         s = dec.s_.astype(np.float64)
         n_samples = mat.n
         self.data = dict(
