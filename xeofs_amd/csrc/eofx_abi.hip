@@ -1943,7 +1943,7 @@ static int fit_fused(eofx_ctx* ctx, const float* Xd, int64_t n, int64_t P, int c
   const int S = plan.S;
   const int NPART = 64;
   size_t need = rsvd_scratch_bytes(p_pad, n_pad, l, k);
-  need += (size_t)S * p_pad * (8 + 8 + 4) + (size_t)P * (4 + 6 * 8) + (size_t)p_pad * 4 + (size_t)P * 8;
+  need += (size_t)S * p_pad * (8 + 4) + (size_t)P * (4 + 6 * 8) + (size_t)p_pad * 4 + (size_t)P * 8;
   need += (size_t)(NPART + 1) * L * 8 + (size_t)S * p_pad * L * 4 + (1 << 20);
   CHK(arena_reserve(ctx, need));
   ArenaScope scope(ctx);
@@ -1958,7 +1958,6 @@ static int fit_fused(eofx_ctx* ctx, const float* Xd, int64_t n, int64_t P, int c
   ps = {cnt, dmean, dstd, dshift, dscale, dm2, dabsmax};
   ARENA(double, dcorr, P);
   ARENA(float, cshift, p_pad);
-  ARENA(double, st_sum, (size_t)S * p_pad);
   ARENA(double, st_sq, (size_t)S * p_pad);
   ARENA(float, st_max, (size_t)S * p_pad);
   ARENA(double, wpart, (size_t)NPART * L);
@@ -2054,10 +2053,10 @@ static int fit_fused(eofx_ctx* ctx, const float* Xd, int64_t n, int64_t P, int c
     const dim3 grid((int)(p_pad / ATB_BM), S, 1);
     if (LL == 64)
       hipLaunchKernelGGL(atb_f16_fit_kernel<2>, grid, dim3(256), 0, ctx->stream, Xd, P, (int)n, P, cshift, Zs, LL, part, LL, p_pad, K,
-                         plan.kps, a_scale, bmax, st_sum, st_sq, st_max, p_pad);
+                         plan.kps, a_scale, bmax, st_sq, st_max, p_pad);
     else
       hipLaunchKernelGGL(atb_f16_fit_kernel<1>, grid, dim3(256), 0, ctx->stream, Xd, P, (int)n, P, cshift, Zs, LL, part, LL, p_pad, K,
-                         plan.kps, a_scale, bmax, st_sum, st_sq, st_max, p_pad);
+                         plan.kps, a_scale, bmax, st_sq, st_max, p_pad);
     KCHK();
     if (ctx->profile) {
       HIPCHK(hipEventRecord(p1, ctx->stream));
@@ -2066,9 +2065,9 @@ static int fit_fused(eofx_ctx* ctx, const float* Xd, int64_t n, int64_t P, int c
       ctx->prof_bytes += (double)n * (double)P * 4.0;
       HIPCHK(hipEventRecord(ev[2], ctx->stream));
     }
-    hipLaunchKernelGGL(fit_finalize_kernel, dim3((int)((p_pad + 255) / 256)), dim3(256), 0, ctx->stream, st_sum, st_sq, st_max, p_pad, S,
-                       Xd, P, n, (n / ATB_KC) * ATB_KC, P, p_pad, cshift, a_scale, center, standardize, wdev,
-                       (double)1.1920928955078125e-07, ps.cnt, ps.mean, ps.stdv, ps.shift, ps.scale, ps.m2, m->aff, dcorr,
+    hipLaunchKernelGGL(fit_finalize_kernel, dim3((int)((p_pad + 255) / 256)), dim3(256), 0, ctx->stream, part, p_pad, LL, st_sq, st_max,
+                       p_pad, S, Xd, P, n, K - n, P, p_pad, cshift, a_scale, center, standardize, wdev,
+                       (double)1.1920928955078125e-07, bmax, ps.cnt, ps.mean, ps.stdv, ps.shift, ps.scale, ps.m2, m->aff, dcorr,
                        ps.absmax, dflags + 1);
     KCHK();
     HIPCHK(hipMemcpyAsync(hword + 2, dflags + 1, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -2076,7 +2075,7 @@ static int fit_fused(eofx_ctx* ctx, const float* Xd, int64_t n, int64_t P, int c
     HIPCHK(hipMemcpyAsync(m->absmax_dev, ps.absmax, sizeof(unsigned), hipMemcpyDeviceToDevice, ctx->stream));
     // the rank-one correction does not wait for the verdict on the statistics: it is queued behind them
     hipLaunchKernelGGL(fit_reduce_kernel, dim3((int)std::min<int64_t>((p_pad * (LL / 4) + 255) / 256, 8192)), dim3(256), 0, ctx->stream,
-                       part, Yt, p_pad, LL, S, P, dcorr, ps.scale, wbar, amax_new(ctx, Yt));
+                       part, Yt, p_pad, LL, l, S, P, dcorr, ps.scale, wbar, amax_new(ctx, Yt));
     KCHK();
     if (ctx->profile) HIPCHK(hipEventRecord(ev[3], ctx->stream));
     CHK(run_feature_summary(ctx, ps, P, fs));       // total variance; synchronises
@@ -2125,7 +2124,7 @@ extern "C" int eofx_fit_f32(eofx_ctx* ctx, const float* X, int64_t n, int64_t P,
   const int l = (int)std::min<int64_t>(l_req, std::min(n, P));
   const int iters = n_iter < 0 ? rsvd_auto_iters(k, n, P) : n_iter;
   const bool eligible = ctx->keep_raw == 2 && ctx->prec_power == EOFX_PREC_F16X3 && n < P && k <= n && l == l_req && l < n &&
-                        round_up(l, 32) <= 64 && P % 4 == 0 && ((uintptr_t)st.dev % 16) == 0 && n < ((int64_t)1 << 31) &&
+                        round_up(l, 32) <= 64 && l % 32 != 0 && P % 4 == 0 && ((uintptr_t)st.dev % 16) == 0 && n < ((int64_t)1 << 31) &&
                         omega_rows >= n && !is_device_ptr(omega) && !std::getenv("EOFX_NO_FUSED_FIT");
   if (eligible) {
     const int rc = fit_fused(ctx, st.dev, n, P, center, standardize, feat_weights, k, l, iters, omega, flip, out, mean, std_,

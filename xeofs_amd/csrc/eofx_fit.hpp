@@ -6,12 +6,14 @@
 //
 //     Y[j, :] = scale_j * ( sum_i (x_ij - c_j) Omega[i, :]  -  (mean_j - c_j) * sum_i Omega[i, :] )
 //
-// with any provisional shift c_j (here: the feature's first sample, which keeps x - c small, so the split-fp16
+// with any provisional shift c_j (here: the mean of nine sampled rows, which keeps x - c small, so the split-fp16
 // product loses nothing to cancellation).  atb_f16_fit_kernel computes the first sum on the matrix cores exactly like
-// atb_f16_kernel<NB, true> and, from the registers it converts anyway, the per-feature sums of (x - c) and
-// (x - c)^2 and max |x - c|; fit_finalize_kernel turns those into mean / std / shift / scale (the same formulas as
-// colstats_finalize_kernel) and fit_reduce_kernel applies the rank-one correction while it reduces the split-K
-// partials.  A fit then reads the field 2 n_iter + 2 times instead of 2 n_iter + 3.
+// atb_f16_kernel<NB, true>; the per-feature sum of (x - c) comes out of the SAME matrix product -- the sketch panel is
+// 64 (32) columns wide and the sketch uses fewer, so a spare column of the B operand is set to ones --, and the sums of
+// (x - c)^2 and max |x - c| are taken from the registers the kernel converts anyway; fit_finalize_kernel turns those
+// into mean / std / shift / scale (the same formulas as colstats_finalize_kernel) and fit_reduce_kernel applies the
+// rank-one correction while it reduces the split-K partials.  A fit then reads the field 2 n_iter + 2 times instead
+// of 2 n_iter + 3.
 //
 // NaN anywhere, a non-finite value or an overflow of the provisional fp16 scaling shows up in the statistics
 // (NaN / inf propagate through the sums; the maximum is compared with the fp16 range) and sends the caller back to
@@ -21,8 +23,9 @@
 
 namespace eofx {
 
-// Provisional shift c_j = x[0][j] and an estimate of max |x - c| from eight sampled rows.  One thread per four
-// adjacent features (P % 4 == 0, 16-byte aligned rows).  flags bit 0: a NaN was seen in the sampled rows.
+// Provisional shift c_j = mean of nine sampled rows (first, last, seven in between) and an estimate of max |x - c|
+// from the same rows.  One thread per four adjacent features (P % 4 == 0, 16-byte aligned rows).  flags bit 0: a NaN or
+// an infinity was seen in the sampled rows.
 __global__ __launch_bounds__(256) void fit_probe_kernel(const float* __restrict__ X, int64_t n, int64_t P, int64_t ld,
                                                          int64_t p_pad, float* __restrict__ cshift,
                                                          unsigned* __restrict__ est, int* __restrict__ flags) {
@@ -30,27 +33,27 @@ __global__ __launch_bounds__(256) void fit_probe_kernel(const float* __restrict_
   float m = 0.f;
   bool bad = false;
   if (c < P) {
-    f32x4 c0 = *reinterpret_cast<const f32x4*>(X + c);
+    f32x4 v[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int64_t r = t == 8 ? n - 1 : (n * t) / 8;
+      v[t] = *reinterpret_cast<const f32x4*>(X + (r < n ? r : n - 1) * ld + c);
+    }
+    f32x4 c0 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 9; ++t) c0 += v[t];
+    c0 *= (1.f / 9.f);
 #pragma unroll
     for (int e = 0; e < 4; ++e)
-      if (!(c0[e] == c0[e]) || fabsf(c0[e]) == INFINITY) {
+      if (!(fabsf(c0[e]) < INFINITY)) {     // NaN or inf among the samples
         bad = true;
         c0[e] = 0.f;
       }
     *reinterpret_cast<f32x4*>(cshift + c) = c0;
-    f32x4 v[8];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      const int64_t r = t == 7 ? n - 1 : (n * (t + 1)) / 8;
-      v[t] = *reinterpret_cast<const f32x4*>(X + (r < n ? r : n - 1) * ld + c);
-    }
+    for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int t = 0; t < 8; ++t)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        bad = bad || !(v[t][e] == v[t][e]);
-        m = fmaxf(m, fabsf(v[t][e] - c0[e]));
-      }
+      for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(v[t][e] - c0[e]));
   } else if (c < p_pad) {
     *reinterpret_cast<f32x4*>(cshift + c) = f32x4{0.f, 0.f, 0.f, 0.f};
   }
@@ -65,18 +68,28 @@ __global__ __launch_bounds__(256) void fit_probe_kernel(const float* __restrict_
 
 // ---------------------------------------------------------------------------------
 // atb_f16_fit: C = A'^T B with A' = (A - c) * a_scale, A the RAW field [a_rows x a_cols] (lda), plus per-feature
-// statistics of A' over the 16-row slabs that lie entirely inside the field (rows [0, 16 floor(a_rows / 16)); the
-// < 16 remaining rows are added by fit_finalize_kernel).  Structure, operand layout and split-fp16 arithmetic are
-// those of atb_f16_kernel<NB, true> (eofx_kernels.hpp); what differs:
+// statistics of A'.  Structure, operand layout and split-fp16 arithmetic are those of atb_f16_kernel<NB, true>
+// (eofx_kernels.hpp); what differs:
 //   * the map is one subtraction and one exact power-of-two scale (2 instead of 3 VALU per element);
-//   * per slab and feature the lane sums its 8 values, their squares and max |v| in float32 (8 terms: no
-//     accumulation error worth the name) and adds them to float64 accumulators that live in LDS -- the kernel has no
-//     registers to spare (246 of 256) -- with fire-and-forget LDS atomics on addresses only this lane touches
-//     (program order, hence deterministic);
+//   * column 32 NB - 1 of the B operand -- a padding column of the sketch panel, zero in B itself -- is staged as ONES for
+//     the rows inside the field: C[:, 32 NB - 1] = (FIT_ONE / b_scale) sum_i (x - c) comes out of the matrix product at
+//     no cost;
+//   * per slab and feature the lane adds its 8 squares to a float32 accumulator and folds max |v| into one register
+//     shared by its four features (the maximum only fixes a power-of-two scale: a bound over neighbours will do); every
+//     FIT_FLUSH slabs (128 terms: no accumulation error worth the name) the squares move to float64 accumulators that
+//     live in LDS -- the kernel has no registers to spare -- by fire-and-forget LDS atomics on addresses only this lane
+//     touches (program order, hence deterministic).  The hot loop carries no row test: the K range is padded to a
+//     multiple of 32 rows and the rows beyond the field re-read its LAST row (their B rows are zero, ones column
+//     included), so the squares hold K - a_rows extra copies of that row's term; fit_finalize_kernel takes them out;
 //   * the epilogue adds the two half-waves (rows 2t and 2t+1) and writes the partial statistics of this split:
-//     st_sum / st_sq [split][st_ld] float64, st_max [split][st_ld] float32.
-// grid = (M / 512, splits, 1), NB = 1 or 2 (L = 32 NB columns).
+//     st_sq [split][st_ld] float64, st_max [split][st_ld] float32.
+// grid = (M / 512, splits, 1), NB = 1 or 2 (L = 32 NB columns, of which the sketch uses at most L - 1).
 // ---------------------------------------------------------------------------------
+constexpr int FIT_FLUSH = 16;   // slabs between two flushes of the float32 sums of squares (even)
+// The "ones" of the spare column as the fp16 operand sees them: 2^13, whatever the panel's own scale (a literal 1.0
+// times the panel scale could leave fp16's range for panels with tiny entries); fit_finalize_kernel divides it out.
+constexpr float FIT_ONE = 8192.f;
+
 template <int NB>
 __global__ __launch_bounds__(256, 2) void atb_f16_fit_kernel(const float* __restrict__ A, int64_t lda, int a_rows,
                                                               int64_t a_cols, const float* __restrict__ cshift,
@@ -84,11 +97,10 @@ __global__ __launch_bounds__(256, 2) void atb_f16_fit_kernel(const float* __rest
                                                               float* __restrict__ C, int ldc, int64_t M, int64_t K,
                                                               int64_t k_per_split, float a_scale,
                                                               const float* __restrict__ b_absmax,
-                                                              double* __restrict__ st_sum, double* __restrict__ st_sq,
+                                                              double* __restrict__ st_sq,
                                                               float* __restrict__ st_max, int64_t st_ld) {
   __shared__ __attribute__((aligned(16))) _Float16 Bs[2][2][2][32 * NB][8];
-  __shared__ double Ss[4][256], Sq[4][256];
-  __shared__ unsigned Sm[4][256];
+  __shared__ double Sq[4][256];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -108,27 +120,32 @@ __global__ __launch_bounds__(256, 2) void atb_f16_fit_kernel(const float* __rest
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][b][r] = 0.f;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    Ss[j][tid] = 0.0;
-    Sq[j][tid] = 0.0;
-    Sm[j][tid] = 0u;
-  }
+  for (int j = 0; j < 4; ++j) Sq[j][tid] = 0.0;
+  float qa[4] = {0.f, 0.f, 0.f, 0.f};
+  float mall = 0.f;        // max |v| over this lane's FOUR features: one register; an upper bound is all the scaling needs
 
   const bool colok = m0 + 4 * li < a_cols;
   const float* Ap = A + (colok ? m0 + 4 * li : 0);
   f32x4 cs_ = {0.f, 0.f, 0.f, 0.f};
   if (colok) cs_ = *reinterpret_cast<const f32x4*>(cshift + m0 + 4 * li);
   const float asc_ = colok ? a_scale : 0.f;      // 16-byte chunks beyond the field read chunk 0 and count as zeros
+  const f32x4 ncs_ = -cs_ * asc_;                // (x - c) a = fma(x, a, -c a): one rounding, one instruction (a = 2^k)
+  float m1 = -1.f;   // opaque to the optimiser: x - (float)h stays ONE v_fma_mix_f32 instead of a conversion and a subtraction
+  asm volatile("" : "+v"(m1));
   constexpr int BV = 8 * NB;
   const bool b_loader = tid < 16 * BV;
   const int brow0 = tid / BV, bc4 = tid % BV;
+  const bool b_ones = bc4 == BV - 1;             // this loader thread stages columns 32 NB - 4 .. 32 NB - 1
   const float* Bp = B + (kb + brow0) * (int64_t)ldb + 4 * bc4;
 
   f32x4 a0[8], a1[8];
   f32x4 bn = {0.f, 0.f, 0.f, 0.f};
 #define EOFX_FIT_LOAD(areg, chunk)                                                               \
   do {                                                                                           \
-    if (b_loader) bn = *reinterpret_cast<const f32x4*>(Bp + (int64_t)(chunk) * ATB_KC * ldb);    \
+    if (b_loader) {                                                                              \
+      bn = *reinterpret_cast<const f32x4*>(Bp + (int64_t)(chunk) * ATB_KC * ldb);                \
+      if (b_ones) bn[3] = ((int)kb + (chunk) * ATB_KC + brow0 < a_rows) ? FIT_ONE / b_scale : 0.f; \
+    }                                                                                            \
     const int r0_ = (int)kb + (chunk) * ATB_KC + lh;                                             \
     if ((int)kb + (chunk) * ATB_KC + ATB_KC <= a_rows) {   /* whole slab inside the field */      \
       const float* pa_ = Ap + (int64_t)r0_ * lda;                                                \
@@ -153,34 +170,37 @@ __global__ __launch_bounds__(256, 2) void atb_f16_fit_kernel(const float* __rest
       }                                                                                          \
     }                                                                                            \
   } while (0)
-#define EOFX_FIT_COMPUTE(areg, buf, chunk)                                                       \
+#define EOFX_FIT_COMPUTE(areg, buf)                                                              \
   do {                                                                                           \
-    const bool st_ok_ = (int)kb + (chunk) * ATB_KC + ATB_KC <= a_rows;   /* uniform */           \
     f16x8 bf_[2][NB];                                                                            \
     _Pragma("unroll") for (int s = 0; s < 2; ++s) _Pragma("unroll") for (int q = 0; q < NB; ++q) \
         bf_[s][q] = *reinterpret_cast<const f16x8*>(&Bs[buf][s][lh][32 * q + li][0]);            \
     _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                              \
       f32x8 x_;                                                                                  \
-      _Pragma("unroll") for (int t = 0; t < 8; ++t) x_[t] = (areg[t][j] - cs_[j]) * asc_;        \
-      if (st_ok_) {                                                                              \
-        const float s_ = ((x_[0] + x_[1]) + (x_[2] + x_[3])) + ((x_[4] + x_[5]) + (x_[6] + x_[7])); \
-        float q_ = x_[0] * x_[0];                                                                \
-        float m_ = fabsf(x_[0]);                                                                 \
-        _Pragma("unroll") for (int t = 1; t < 8; ++t) {                                          \
-          q_ = __builtin_fmaf(x_[t], x_[t], q_);                                                 \
-          m_ = fmaxf(m_, fabsf(x_[t]));                                                          \
-        }                                                                                        \
-        (void)__hip_atomic_fetch_add(&Ss[j][tid], (double)s_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
-        (void)__hip_atomic_fetch_add(&Sq[j][tid], (double)q_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
-        (void)__hip_atomic_fetch_max(&Sm[j][tid], __float_as_uint(m_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+      /* plain single-lane-pair instructions, spelled out: left to itself the compiler packs these into v_pk_fma_f32 */ \
+      /* (slower beside MFMAs, and the register pairs it needs push the kernel into scratch)                      */ \
+      _Pragma("unroll") for (int t = 0; t < 8; ++t) {                                            \
+        float xv_;                                                                               \
+        asm("v_fma_f32 %0, %1, %2, %3" : "=v"(xv_) : "v"(areg[t][j]), "v"(asc_), "v"(ncs_[j]));  \
+        x_[t] = xv_;                                                                             \
       }                                                                                          \
+      _Pragma("unroll") for (int t = 0; t < 8; ++t) asm("v_fmac_f32 %0, %1, %1" : "+v"(qa[j]) : "v"(x_[t])); \
+      _Pragma("unroll") for (int t = 0; t < 8; t += 2)     /* NaN operands are skipped, as by fmaxf */ \
+          asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(mall) : "v"(x_[t]), "v"(x_[t + 1]));       \
       f16x8 af_[2];                                                                              \
-      split_f16(x_, af_);                                                                        \
+      split_f16_mix(x_, m1, af_);                                                                \
       _Pragma("unroll") for (int q = 0; q < NB; ++q) {                                           \
         acc[j][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af_[1], bf_[0][q], acc[j][q], 0, 0, 0); \
         acc[j][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af_[0], bf_[1][q], acc[j][q], 0, 0, 0); \
         acc[j][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af_[0], bf_[0][q], acc[j][q], 0, 0, 0); \
       }                                                                                          \
+    }                                                                                            \
+  } while (0)
+#define EOFX_FIT_FLUSH()                                                                         \
+  do {                                                                                           \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                              \
+      (void)__hip_atomic_fetch_add(&Sq[j][tid], (double)qa[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+      qa[j] = 0.f;                                                                               \
     }                                                                                            \
   } while (0)
 
@@ -191,20 +211,23 @@ __global__ __launch_bounds__(256, 2) void atb_f16_fit_kernel(const float* __rest
     for (int c = 0; c < nchunks; c += 2) {
       EOFX_FIT_LOAD(a1, c + 1);
       __builtin_amdgcn_sched_barrier(0);
-      EOFX_FIT_COMPUTE(a0, 0, c);
+      EOFX_FIT_COMPUTE(a0, 0);
       EOFX_FIT_STORE_B(1);
       __syncthreads();
       const int c2 = (c + 2 < nchunks) ? c + 2 : c + 1;
       EOFX_FIT_LOAD(a0, c2);
       __builtin_amdgcn_sched_barrier(0);
-      EOFX_FIT_COMPUTE(a1, 1, c + 1);
+      EOFX_FIT_COMPUTE(a1, 1);
       EOFX_FIT_STORE_B(0);
+      if ((c & (FIT_FLUSH - 2)) == FIT_FLUSH - 2) EOFX_FIT_FLUSH();
       __syncthreads();
     }
   }
+  EOFX_FIT_FLUSH();
 #undef EOFX_FIT_LOAD
 #undef EOFX_FIT_COMPUTE
 #undef EOFX_FIT_STORE_B
+#undef EOFX_FIT_FLUSH
 
   float* Cs = C + (int64_t)blockIdx.y * M * ldc;
 #pragma unroll
@@ -219,66 +242,66 @@ __global__ __launch_bounds__(256, 2) void atb_f16_fit_kernel(const float* __rest
       }
   // statistics of this split: rows 2t (lh = 0) + rows 2t + 1 (lh = 1), in that order
   {
-    f64x4 s4, q4;
+    f64x4 q4;
     f32x4 m4;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const double s_ = Ss[j][tid], q_ = Sq[j][tid];
-      const float m_ = __uint_as_float(Sm[j][tid]);
-      const double so_ = __shfl_xor(s_, 32), qo_ = __shfl_xor(q_, 32);
-      const float mo_ = __shfl_xor(m_, 32);
-      s4[j] = s_ + so_;      // only the lh == 0 lanes store: (rows 2t) + (rows 2t + 1)
-      q4[j] = q_ + qo_;
-      m4[j] = fmaxf(m_, mo_);
+      const double q_ = Sq[j][tid];
+      const double qo_ = __shfl_xor(q_, 32);
+      const float mo_ = __shfl_xor(mall, 32);
+      q4[j] = q_ + qo_;      // only the lh == 0 lanes store: (rows 2t) + (rows 2t + 1)
+      m4[j] = fmaxf(mall, mo_);
     }
     if (lh == 0 && colok) {
       const int64_t o = (int64_t)blockIdx.y * st_ld + m0 + 4 * li;
-      *reinterpret_cast<f64x4*>(st_sum + o) = s4;
       *reinterpret_cast<f64x4*>(st_sq + o) = q4;
       *reinterpret_cast<f32x4*>(st_max + o) = m4;
     }
   }
 }
 
-// Statistics of the scaled, provisionally shifted values -> the Scaler's state.  One thread per feature c < p_pad.
-//   v = (x - cshift) * a_scale;  S1 = sum v, S2 = sum v^2 over the n samples (split partials in fixed order + the
-//   n - n_full tail rows read here), M = max |v|.
-//   mean = cshift + S1 / (n a);  M2 = (S2 - S1^2 / n) / a^2;  std = sqrt(M2 / n) clipped at eps  (scaler.py:101-108)
+// Statistics of the provisionally shifted values -> the Scaler's state.  One thread per feature c < p_pad.
+//   S1 = sum (x - cshift) over all n samples: column L - 1 of the split-K partials of the first pass (the ones column,
+//        times FIT_ONE / b_scale), summed over the splits in fixed order;
+//   S2 = sum v^2, M = max |v| with v = (x - cshift) * a_scale (split partials in fixed order); the kernel's K range
+//        is padded with `extra` = K - n re-reads of the last row, whose squares are subtracted here.
+//   mean = cshift + S1 / n;  M2 = S2 / a^2 - S1^2 / n;  std = sqrt(M2 / n) clipped at eps        (scaler.py:101-108)
 //   shift = center ? mean : 0;  scale = (standardize ? 1 / std : 1) * weight                   (scaler.py:128-154)
 // flags: bit 0 a sum is not finite (NaN / inf in the data), bit 1 the provisional fp16 scaling overflowed.
 // Also written: the float triples of the in-place view (aff_pack_kernel's layout), dcorr = shift - cshift for
 // fit_reduce_kernel, and max |(x - shift) * scale| (an upper bound within a factor of two) into *absmax.
 __global__ __launch_bounds__(256) void fit_finalize_kernel(
-    const double* __restrict__ st_sum, const double* __restrict__ st_sq, const float* __restrict__ st_max, int64_t st_ld,
-    int splits, const float* __restrict__ X, int64_t ld, int64_t n, int64_t n_full, int64_t P, int64_t p_pad,
-    const float* __restrict__ cshift, float a_scale, int center, int standardize, const double* __restrict__ weights,
-    double eps, int* __restrict__ cnt, double* __restrict__ mean, double* __restrict__ stdv, double* __restrict__ shift,
-    double* __restrict__ scale, double* __restrict__ m2, float* __restrict__ aff, double* __restrict__ dcorr,
-    unsigned* __restrict__ absmax, int* __restrict__ flags) {
+    const float* __restrict__ part, int64_t part_rows, int L, const double* __restrict__ st_sq,
+    const float* __restrict__ st_max, int64_t st_ld, int splits, const float* __restrict__ X, int64_t ld, int64_t n,
+    int64_t extra, int64_t P, int64_t p_pad, const float* __restrict__ cshift, float a_scale, int center, int standardize,
+    const double* __restrict__ weights, double eps, const float* __restrict__ b_absmax, int* __restrict__ cnt,
+    double* __restrict__ mean, double* __restrict__ stdv, double* __restrict__ shift, double* __restrict__ scale,
+    double* __restrict__ m2, float* __restrict__ aff, double* __restrict__ dcorr, unsigned* __restrict__ absmax,
+    int* __restrict__ flags) {
   const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
   float amax = 0.f;
   int fl = 0;
   if (c < P) {
-    double s = 0.0, q = 0.0;
+    const double unit = (double)f16_scale_for(*b_absmax) / (double)FIT_ONE;   // exact: powers of two
+    double S1 = 0.0, q = 0.0;
     float mx = 0.f;
     for (int sp = 0; sp < splits; ++sp) {
-      s += st_sum[(int64_t)sp * st_ld + c];
+      S1 += (double)part[((int64_t)sp * part_rows + c) * L + (L - 1)];
       q += st_sq[(int64_t)sp * st_ld + c];
       mx = fmaxf(mx, st_max[(int64_t)sp * st_ld + c]);
     }
+    S1 *= unit;
     const float cs = cshift[c];
-    for (int64_t r = n_full; r < n; ++r) {
-      const float v = (X[r * ld + c] - cs) * a_scale;
-      s += (double)v;
-      q += (double)v * (double)v;
-      mx = fmaxf(mx, fabsf(v));
+    if (extra > 0) {
+      const float v = __builtin_fmaf(X[(n - 1) * ld + c], a_scale, -cs * a_scale);    // the kernel's own expression
+      q -= (double)extra * ((double)v * (double)v);
     }
-    if (!(fabs(s) < INFINITY) || !(fabs(q) < INFINITY)) fl |= 1;
+    if (!(fabs(S1) < INFINITY) || !(fabs(q) < INFINITY)) fl |= 1;
     if (!(mx < 60000.f)) fl |= 2;
     const double ia = 1.0 / (double)a_scale;          // exact: a power of two
-    const double S1 = s * ia, nn = (double)n;
+    const double nn = (double)n;
     const double mu = (double)cs + S1 / nn;
-    double M2 = (q - s * s / nn) * ia * ia;
+    double M2 = q * ia * ia - S1 * S1 / nn;
     if (!(M2 > 0.0)) M2 = 0.0;
     double sd = sqrt(M2 / nn);
     if (sd < eps) sd = eps;
@@ -338,10 +361,10 @@ __global__ __launch_bounds__(256) void panel_colsum_final_kernel(const double* _
   }
 }
 
-// Y[j, :] = scale_j * (sum_splits part[s][j, :] - dcorr_j * wbar[:]) for j < P, 0 for the padding rows; float64
-// arithmetic, fixed order.  part may alias out when splits == 1.  amax_out (may be null): max |Y| by atomicMax on the
-// float bits (order independent).  count4 = rows_pad * L / 4.
-__global__ __launch_bounds__(256) void fit_reduce_kernel(const float* part, float* out, int64_t rows_pad, int L,
+// Y[j, c] = scale_j * (sum_splits part[s][j, c] - dcorr_j * wbar[c]) for j < P and c < l, 0 for the padding rows and
+// columns (the ones column of the first pass among them); float64 arithmetic, fixed order.  part may alias out when
+// splits == 1.  amax_out (may be null): max |Y| by atomicMax on the float bits (order independent).
+__global__ __launch_bounds__(256) void fit_reduce_kernel(const float* part, float* out, int64_t rows_pad, int L, int l,
                                                           int splits, int64_t P, const double* __restrict__ dcorr,
                                                           const double* __restrict__ scale,
                                                           const double* __restrict__ wbar,
@@ -364,10 +387,10 @@ __global__ __launch_bounds__(256) void fit_reduce_kernel(const float* part, floa
         s3 += v[3];
       }
       const double d = dcorr[j], sc = scale[j];
-      o[0] = (float)((s0 - d * wbar[c]) * sc);
-      o[1] = (float)((s1 - d * wbar[c + 1]) * sc);
-      o[2] = (float)((s2 - d * wbar[c + 2]) * sc);
-      o[3] = (float)((s3 - d * wbar[c + 3]) * sc);
+      o[0] = c < l ? (float)((s0 - d * wbar[c]) * sc) : 0.f;
+      o[1] = c + 1 < l ? (float)((s1 - d * wbar[c + 1]) * sc) : 0.f;
+      o[2] = c + 2 < l ? (float)((s2 - d * wbar[c + 2]) * sc) : 0.f;
+      o[3] = c + 3 < l ? (float)((s3 - d * wbar[c + 3]) * sc) : 0.f;
       m = fmaxf(m, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
     }
     reinterpret_cast<f32x4*>(out)[i] = o;

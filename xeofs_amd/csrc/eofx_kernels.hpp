@@ -26,6 +26,13 @@ __device__ __forceinline__ void aff_split(double sh, float& hi, float& lo) {
 __device__ __forceinline__ float aff_map(float x, float sh_hi, float sh_lo, float scale) {
   return ((x - sh_hi) - sh_lo) * scale;
 }
+// The same map as the streaming kernels issue it: two instructions instead of three -- (x - hi) s - lo s with the second
+// step one fused multiply-add, nls = -(lo * s) prepared once per feature.  One rounding less than aff_map; identical to it
+// whenever s is a power of two (no standardisation, no weights: the products are exact), within one ulp otherwise --
+// the written layouts and the streamed view already differed by that much.
+__device__ __forceinline__ float aff_fma(float x, float sh_hi, float s, float nls) {
+  return __builtin_fmaf(x - sh_hi, s, nls);
+}
 
 // ---------------------------------------------------------------------------------
 // atb_f32: C[M x L] = A[K x M]^T * B[K x L]        (the dominant kernel)
@@ -336,6 +343,23 @@ __device__ __forceinline__ void split_f16(f32x8 r, f16x8 (&out)[2]) {
   }
 }
 
+// The same split with the residual x - (float)hi taken by ONE v_fma_mix_f32 (fp16 operand converted on the fly) instead
+// of a conversion and a subtraction: m1 must hold -1.0f in a register the optimiser cannot see through
+// (asm volatile("" : "+v"(m1))), otherwise it folds the product away and emits the two-instruction form.  Same values.
+__device__ __forceinline__ void split_f16_mix(const f32x8 r, float m1, f16x8 (&out)[2]) {
+  u32x4 hi, lo;
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+    const fp16x2_t p = __builtin_amdgcn_cvt_pkrtz(r[2 * h], r[2 * h + 1]);
+    const fp16x2_t q = __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf((float)p[0], m1, r[2 * h]),
+                                                  __builtin_fmaf((float)p[1], m1, r[2 * h + 1]));
+    hi[h] = __builtin_bit_cast(unsigned, p);
+    lo[h] = __builtin_bit_cast(unsigned, q);
+  }
+  out[0] = __builtin_bit_cast(f16x8, hi);
+  out[1] = __builtin_bit_cast(f16x8, lo);
+}
+
 // scale = 2^(14 - e) with |m| <= 2^e (m = max |value|); 1 for an all-zero operand
 __device__ __forceinline__ float f16_scale_for(float m) {
   if (!(m > 0.f) || !(m < INFINITY)) return 1.f;
@@ -408,6 +432,9 @@ __global__ __launch_bounds__(256, NB > 2 ? 1 : 2) void atb_f16_kernel(const floa
     shl_ = *reinterpret_cast<const f32x4*>(aff + aff_ld + m0 + 4 * li);
     sla_ = *reinterpret_cast<const f32x4*>(aff + 2 * aff_ld + m0 + 4 * li) * a_scale;   // exact: a power of two
   }
+  const f32x4 nls_ = -(shl_ * sla_);
+  float m1 = -1.f;   // opaque to the optimiser (split_f16_mix)
+  asm volatile("" : "+v"(m1));
   constexpr int BV = 8 * NB;
   constexpr int BREP = (16 * BV + 255) / 256;      // 16-byte loads of the B slab per thread (2 for the 128-column tile)
   constexpr int BROWS = 256 / BV < 16 ? 256 / BV : 16;   // slab rows covered by one such load of the workgroup
@@ -464,10 +491,10 @@ __global__ __launch_bounds__(256, NB > 2 ? 1 : 2) void atb_f16_kernel(const floa
       const unsigned msk_ = (AFF && MASK) ? (sla_[j] != 0.f ? 0xffffffffu : 0u) : 0xffffffffu;   \
       _Pragma("unroll") for (int t = 0; t < 8; ++t) {                                            \
         const float xr_ = (AFF && MASK) ? __uint_as_float(__float_as_uint(areg[t][j]) & msk_) : areg[t][j]; \
-        x_[t] = AFF ? aff_map(xr_, shh_[j], shl_[j], sla_[j]) : xr_ * a_scale;                    \
+        x_[t] = AFF ? aff_fma(xr_, shh_[j], sla_[j], nls_[j]) : xr_ * a_scale;                    \
       }                                                                                          \
       f16x8 af_[2];                                                                              \
-      split_f16(x_, af_);                                                                        \
+      split_f16_mix(x_, m1, af_);                                                                \
       _Pragma("unroll") for (int q = 0; q < NB; ++q) {                                           \
         acc[j][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af_[1], bf_[0][q], acc[j][q], 0, 0, 0); \
         acc[j][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af_[0], bf_[1][q], acc[j][q], 0, 0, 0); \
@@ -671,7 +698,7 @@ __global__ __launch_bounds__(256, 2) void axb_f16_kernel(const float* __restrict
         /* aff_map on a pair (packed float32 arithmetic: the same three roundings per element) */       \
         const f32x2 x_ = {MASK ? __uint_as_float(__float_as_uint(areg[u][2 * h]) & mk_[2 * h]) : areg[u][2 * h],           \
                           MASK ? __uint_as_float(__float_as_uint(areg[u][2 * h + 1]) & mk_[2 * h + 1]) : areg[u][2 * h + 1]}; \
-        const f32x2 v_ = ((x_ + fh_[h]) + fl_[h]) * fs_[h];   /* fh_, fl_ hold the NEGATED shift pair */ \
+        const f32x2 v_ = __builtin_elementwise_fma(x_ + fh_[h], fs_[h], fl_[h]);   /* aff_fma: fh_ = -hi, fl_ = -(lo s) */ \
         const fp16x2_t p_ = __builtin_amdgcn_cvt_pkrtz(v_[0], v_[1]);                                  \
         const fp16x2_t q_ = __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf((float)p_[0], m1, v_[0]),        \
                                                        __builtin_fmaf((float)p_[1], m1, v_[1]));        \
@@ -719,6 +746,7 @@ __global__ __launch_bounds__(256, 2) void axb_f16_kernel(const float* __restrict
         fl_[h] = -f32x2{fr[1][2 * h], fr[1][2 * h + 1]};                                               \
         asm volatile("" : "+v"(fh_[h]), "+v"(fl_[h]));   /* keep them additions (v_pk_add_f32) */         \
         fs_[h] = f32x2{fr[2][2 * h], fr[2][2 * h + 1]} * a_scale;   /* exact: a power of two */         \
+        fl_[h] = fl_[h] * fs_[h];                                   /* -(lo * s), as aff_fma wants it */  \
       }                                                                                                \
       unsigned mk_[4];                                                                                 \
       _Pragma("unroll") for (int e = 0; e < 4; ++e) mk_[e] = (MASK && fr[2][e] == 0.f) ? 0u : 0xffffffffu; \

@@ -141,7 +141,7 @@ class Decomposer:
             k, n_over, n_iter, wide = self.policy(n, P, quiet=True)
         except ValueError:
             return None
-        if wide or n_iter == 0 or not (0 < k + n_over <= 64) or k + n_over >= n:
+        if wide or n_iter == 0 or not (0 < k + n_over < 64) or (k + n_over) % 32 == 0 or k + n_over >= n:
             return None
         return k, n_over, n_iter
 
