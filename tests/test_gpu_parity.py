@@ -377,7 +377,7 @@ def _check_factors(U, s, V, ref, k, tol=1e-5):
     (1000, 9000, 50, {"standardize": True, "weights": True}),
     (333, 1036, 8, {"center": False}),
     (96, 40000, 10, {}),                                 # several column blocks, one slab pair per split
-    (5000, 20480, 22, {}),                               # L = 32 sketch (k + 10 = 32): the one-sub-tile variant
+    (5000, 20480, 20, {}),                               # L = 32 panel (k + 10 = 30): the one-sub-tile variant
 ])
 def test_fused_fit_vs_two_step_and_oracle(ctx, n, p, k, opts):
     """eofx_fit_f32: the column statistics ride on the first pass of the randomized SVD (eofx_fit.hpp).  The result must
@@ -440,6 +440,10 @@ def test_fused_fit_falls_back(ctx):
     Y[:, 900] = np.nan                              # the whole feature: dropped, as by the Sanitizer
     mat, st, U, s, V = engine.fit(ctx, Y, 4, random_state=1)
     assert not st["fused"] and V.shape == (1023, 4) and not st["valid_feature"][900]
+    mat.free()
+    Y = _field(400, 2048, seed=5)                   # k + 10 = 32 fills the panel: no spare column for the ones
+    mat, st, U, s, V = engine.fit(ctx, Y, 22, random_state=1)
+    assert not st["fused"] and engine.fit_info(ctx)["reason"] == -1
     mat.free()
     Z = _field(600, 400, seed=6)                    # n >= P: the sketch lives on the feature side
     mat, st, U, s, V = engine.fit(ctx, Z, 4, random_state=1)

@@ -177,16 +177,25 @@ __global__ __launch_bounds__(256, 2) void atb_f16_fit_kernel(const float* __rest
         bf_[s][q] = *reinterpret_cast<const f16x8*>(&Bs[buf][s][lh][32 * q + li][0]);            \
     _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                              \
       f32x8 x_;                                                                                  \
-      /* plain single-lane-pair instructions, spelled out: left to itself the compiler packs these into v_pk_fma_f32 */ \
-      /* (slower beside MFMAs, and the register pairs it needs push the kernel into scratch)                      */ \
+      /* Left to itself the SLP vectoriser packs these fmas (across t, across j) into v_pk_fma_f32: slower beside MFMAs, \
+         and the register pairs push the kernel into scratch.  The empty asm statements make each value opaque, which  \
+         keeps the scalar forms without pinning the instruction order (spelled-out asm made the scheduler pad with      \
+         s_nop and bunch the MFMAs).                                                                                    */ \
       _Pragma("unroll") for (int t = 0; t < 8; ++t) {                                            \
-        float xv_;                                                                               \
-        asm("v_fma_f32 %0, %1, %2, %3" : "=v"(xv_) : "v"(areg[t][j]), "v"(asc_), "v"(ncs_[j]));  \
+        float xv_ = __builtin_fmaf(areg[t][j], asc_, ncs_[j]);                                   \
+        asm("" : "+v"(xv_));                                                                     \
         x_[t] = xv_;                                                                             \
       }                                                                                          \
-      _Pragma("unroll") for (int t = 0; t < 8; ++t) asm("v_fmac_f32 %0, %1, %1" : "+v"(qa[j]) : "v"(x_[t])); \
-      _Pragma("unroll") for (int t = 0; t < 8; t += 2)     /* NaN operands are skipped, as by fmaxf */ \
-          asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(mall) : "v"(x_[t]), "v"(x_[t + 1]));       \
+      {                                                                                          \
+        float q_ = qa[j], mm_ = mall;                                                            \
+        _Pragma("unroll") for (int t = 0; t < 8; ++t) {                                          \
+          q_ = __builtin_fmaf(x_[t], x_[t], q_);                                                 \
+          mm_ = __builtin_fmaxf(mm_, __builtin_fabsf(x_[t]));     /* NaN operands are skipped */ \
+        }                                                                                        \
+        asm("" : "+v"(q_), "+v"(mm_));                                                           \
+        qa[j] = q_;                                                                              \
+        mall = mm_;                                                                              \
+      }                                                                                          \
       f16x8 af_[2];                                                                              \
       split_f16_mix(x_, m1, af_);                                                                \
       _Pragma("unroll") for (int q = 0; q < NB; ++q) {                                           \
