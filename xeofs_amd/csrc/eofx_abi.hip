@@ -910,7 +910,7 @@ static int import_panel(eofx_ctx* ctx, const float* src, int64_t rows, int l, fl
     CHK(copy_in(ctx, tmp, src, sizeof(float) * rows * l));
     dsrc = tmp;
   }
-  const int64_t total = rows_pad * L;
+  const int64_t total = rows_pad * (L / 4);
   const int blocks = (int)std::min<int64_t>((total + 255) / 256, 8192);
   hipLaunchKernelGGL(panel_import_kernel, dim3(blocks), dim3(256), 0, ctx->stream, dsrc, rows, l, P,
                      rows_pad, L, amax_new(ctx, P));
@@ -1012,7 +1012,11 @@ extern "C" int eofx_mat_destroy(eofx_ctx* ctx, eofx_mat* m) {
     if (m->Xt) (void)hipFree(m->Xt);
     if (m->raw_owned) (void)hipFree(m->raw_owned);
   }
-  if (m->aff) (void)hipFree(m->aff);
+  if (m->aff) {
+    const size_t abytes = sizeof(float) * 3 * (size_t)m->p_pad;
+    if (ctx) pool_give(ctx, m->aff, abytes);
+    else (void)hipFree(m->aff);
+  }
   delete m;
   return EOFX_OK;
 }
@@ -1328,7 +1332,7 @@ static int sanitize_and_apply(eofx_ctx* ctx, const float* Xd, int64_t n, int64_t
   int rc = EOFX_OK;
   if (raw_mode) {
     const size_t abytes = sizeof(float) * 3 * (size_t)m->p_pad;
-    if (hipMalloc((void**)&m->aff, abytes) != hipSuccess) {
+    if (pool_malloc(ctx, (void**)&m->aff, abytes) != hipSuccess) {
       (void)hipGetLastError();
       m->aff = nullptr;
       eofx_mat_destroy(ctx, m);
@@ -2014,7 +2018,7 @@ static int fit_fused(eofx_ctx* ctx, const float* Xd, int64_t n, int64_t P, int c
       if (*m) eofx_mat_destroy(c, *m);
     }
   } mg{ctx, &m};
-  if (hipMalloc((void**)&m->aff, sizeof(float) * 3 * (size_t)p_pad) != hipSuccess) {
+  if (pool_malloc(ctx, (void**)&m->aff, sizeof(float) * 3 * (size_t)p_pad) != hipSuccess) {
     (void)hipGetLastError();
     m->aff = nullptr;
     return set_err(ctx, EOFX_ERR_NOMEM, "cannot allocate the affine map");

@@ -140,12 +140,15 @@ __global__ __launch_bounds__(256, 2) void atb_f16_fit_kernel(const float* __rest
 
   f32x4 a0[8], a1[8];
   f32x4 bn = {0.f, 0.f, 0.f, 0.f};
-#define EOFX_FIT_LOAD(areg, chunk)                                                               \
+#define EOFX_FIT_LOAD_B(chunk)                                                                   \
   do {                                                                                           \
     if (b_loader) {                                                                              \
       bn = *reinterpret_cast<const f32x4*>(Bp + (int64_t)(chunk) * ATB_KC * ldb);                \
       if (b_ones) bn[3] = ((int)kb + (chunk) * ATB_KC + brow0 < a_rows) ? FIT_ONE / b_scale : 0.f; \
     }                                                                                            \
+  } while (0)
+#define EOFX_FIT_LOAD_A(areg, chunk)                                                             \
+  do {                                                                                           \
     const int r0_ = (int)kb + (chunk) * ATB_KC + lh;                                             \
     if ((int)kb + (chunk) * ATB_KC + ATB_KC <= a_rows) {   /* whole slab inside the field */      \
       const float* pa_ = Ap + (int64_t)r0_ * lda;                                                \
@@ -170,40 +173,53 @@ __global__ __launch_bounds__(256, 2) void atb_f16_fit_kernel(const float* __rest
       }                                                                                          \
     }                                                                                            \
   } while (0)
-#define EOFX_FIT_COMPUTE(areg, buf)                                                              \
+  /* Left to itself the SLP vectoriser packs the fmas below (across t, across j) into v_pk_fma_f32: slower beside MFMAs,
+     and the register pairs push the kernel into scratch.  The empty asm statements make each value opaque, which keeps
+     the scalar forms without pinning the instruction order (spelled-out asm made the scheduler pad with s_nop and bunch
+     the MFMAs). */
+#define EOFX_FIT_CONVERT_J(areg, j, af_)                                                         \
+  do {                                                                                           \
+    f32x8 x_;                                                                                    \
+    _Pragma("unroll") for (int t = 0; t < 8; ++t) {                                              \
+      float xv_ = __builtin_fmaf(areg[t][j], asc_, ncs_[j]);                                     \
+      asm("" : "+v"(xv_));                                                                       \
+      x_[t] = xv_;                                                                               \
+    }                                                                                            \
+    {                                                                                            \
+      float q_ = qa[j], mm_ = mall;                                                              \
+      _Pragma("unroll") for (int t = 0; t < 8; ++t) {                                            \
+        q_ = __builtin_fmaf(x_[t], x_[t], q_);                                                   \
+        mm_ = __builtin_fmaxf(mm_, __builtin_fabsf(x_[t]));     /* NaN operands are skipped */   \
+      }                                                                                          \
+      asm("" : "+v"(q_), "+v"(mm_));                                                             \
+      qa[j] = q_;                                                                                \
+      mall = mm_;                                                                                \
+    }                                                                                            \
+    split_f16_mix(x_, m1, af_);                                                                  \
+  } while (0)
+#define EOFX_FIT_MFMA_J(j, af_)                                                                  \
+  _Pragma("unroll") for (int q = 0; q < NB; ++q) {                                               \
+    acc[j][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af_[1], bf_[0][q], acc[j][q], 0, 0, 0);   \
+    acc[j][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af_[0], bf_[1][q], acc[j][q], 0, 0, 0);   \
+    acc[j][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af_[0], bf_[0][q], acc[j][q], 0, 0, 0);   \
+  }
+  // as in atb_f16_kernel: the slab's registers are refilled right after its last conversion
+#define EOFX_FIT_COMPUTE(areg, buf, refill)                                                      \
   do {                                                                                           \
     f16x8 bf_[2][NB];                                                                            \
     _Pragma("unroll") for (int s = 0; s < 2; ++s) _Pragma("unroll") for (int q = 0; q < NB; ++q) \
         bf_[s][q] = *reinterpret_cast<const f16x8*>(&Bs[buf][s][lh][32 * q + li][0]);            \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                              \
-      f32x8 x_;                                                                                  \
-      /* Left to itself the SLP vectoriser packs these fmas (across t, across j) into v_pk_fma_f32: slower beside MFMAs, \
-         and the register pairs push the kernel into scratch.  The empty asm statements make each value opaque, which  \
-         keeps the scalar forms without pinning the instruction order (spelled-out asm made the scheduler pad with      \
-         s_nop and bunch the MFMAs).                                                                                    */ \
-      _Pragma("unroll") for (int t = 0; t < 8; ++t) {                                            \
-        float xv_ = __builtin_fmaf(areg[t][j], asc_, ncs_[j]);                                   \
-        asm("" : "+v"(xv_));                                                                     \
-        x_[t] = xv_;                                                                             \
-      }                                                                                          \
-      {                                                                                          \
-        float q_ = qa[j], mm_ = mall;                                                            \
-        _Pragma("unroll") for (int t = 0; t < 8; ++t) {                                          \
-          q_ = __builtin_fmaf(x_[t], x_[t], q_);                                                 \
-          mm_ = __builtin_fmaxf(mm_, __builtin_fabsf(x_[t]));     /* NaN operands are skipped */ \
-        }                                                                                        \
-        asm("" : "+v"(q_), "+v"(mm_));                                                           \
-        qa[j] = q_;                                                                              \
-        mall = mm_;                                                                              \
-      }                                                                                          \
+    _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                              \
       f16x8 af_[2];                                                                              \
-      split_f16_mix(x_, m1, af_);                                                                \
-      _Pragma("unroll") for (int q = 0; q < NB; ++q) {                                           \
-        acc[j][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af_[1], bf_[0][q], acc[j][q], 0, 0, 0); \
-        acc[j][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af_[0], bf_[1][q], acc[j][q], 0, 0, 0); \
-        acc[j][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af_[0], bf_[0][q], acc[j][q], 0, 0, 0); \
-      }                                                                                          \
+      EOFX_FIT_CONVERT_J(areg, j, af_);                                                          \
+      EOFX_FIT_MFMA_J(j, af_)                                                                    \
     }                                                                                            \
+    f16x8 al_[2];                                                                                \
+    EOFX_FIT_CONVERT_J(areg, 3, al_);                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    EOFX_FIT_LOAD_A(areg, refill);                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    EOFX_FIT_MFMA_J(3, al_)                                                                      \
   } while (0)
 #define EOFX_FIT_FLUSH()                                                                         \
   do {                                                                                           \
@@ -213,28 +229,33 @@ __global__ __launch_bounds__(256, 2) void atb_f16_fit_kernel(const float* __rest
     }                                                                                            \
   } while (0)
 
+  // The statistics see every slab once: the two refills past the end of the K range (harmless re-reads for the
+  // product) are made of the LAST pair again but never converted.
   if (nchunks > 0) {
-    EOFX_FIT_LOAD(a0, 0);
+    EOFX_FIT_LOAD_B(0);
+    EOFX_FIT_LOAD_A(a0, 0);
+    EOFX_FIT_LOAD_A(a1, 1);
     EOFX_FIT_STORE_B(0);
     __syncthreads();
     for (int c = 0; c < nchunks; c += 2) {
-      EOFX_FIT_LOAD(a1, c + 1);
-      __builtin_amdgcn_sched_barrier(0);
-      EOFX_FIT_COMPUTE(a0, 0);
+      const int c2 = (c + 2 < nchunks) ? c + 2 : c;
+      EOFX_FIT_LOAD_B(c + 1);
+      EOFX_FIT_COMPUTE(a0, 0, c2);
       EOFX_FIT_STORE_B(1);
       __syncthreads();
-      const int c2 = (c + 2 < nchunks) ? c + 2 : c + 1;
-      EOFX_FIT_LOAD(a0, c2);
-      __builtin_amdgcn_sched_barrier(0);
-      EOFX_FIT_COMPUTE(a1, 1);
+      EOFX_FIT_LOAD_B(c2);
+      EOFX_FIT_COMPUTE(a1, 1, c2 + 1);
       EOFX_FIT_STORE_B(0);
       if ((c & (FIT_FLUSH - 2)) == FIT_FLUSH - 2) EOFX_FIT_FLUSH();
       __syncthreads();
     }
   }
   EOFX_FIT_FLUSH();
-#undef EOFX_FIT_LOAD
+#undef EOFX_FIT_LOAD_B
+#undef EOFX_FIT_LOAD_A
 #undef EOFX_FIT_COMPUTE
+#undef EOFX_FIT_CONVERT_J
+#undef EOFX_FIT_MFMA_J
 #undef EOFX_FIT_STORE_B
 #undef EOFX_FIT_FLUSH
 
@@ -378,13 +399,18 @@ __global__ __launch_bounds__(256) void fit_reduce_kernel(const float* part, floa
                                                           const double* __restrict__ scale,
                                                           const double* __restrict__ wbar,
                                                           unsigned* __restrict__ amax_out) {
-  const int64_t count4 = rows_pad * (L / 4);
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  // thread (row group, quad): quad = 4 adjacent columns, fixed for the thread, so its four wbar values are loaded once;
+  // rows stride by the number of row slots of the grid.  L / 4 is 8 or 16: 32 or 16 rows per 256-thread workgroup.
   const int l4 = L / 4;
+  const int quad = threadIdx.x % l4, rslot = threadIdx.x / l4, rper = 256 / l4;
+  const int c = 4 * quad;
+  const int64_t count4 = rows_pad * l4;
+  double w[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) w[e] = c + e < l ? wbar[c + e] : 0.0;
   float m = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count4; i += stride) {
-    const int64_t j = i / l4;
-    const int c = (int)(i - j * l4) * 4;
+  for (int64_t j = (int64_t)blockIdx.x * rper + rslot; j < rows_pad; j += (int64_t)gridDim.x * rper) {
+    const int64_t i = j * l4 + quad;
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
     if (j < P) {
       double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
@@ -396,10 +422,10 @@ __global__ __launch_bounds__(256) void fit_reduce_kernel(const float* part, floa
         s3 += v[3];
       }
       const double d = dcorr[j], sc = scale[j];
-      o[0] = c < l ? (float)((s0 - d * wbar[c]) * sc) : 0.f;
-      o[1] = c + 1 < l ? (float)((s1 - d * wbar[c + 1]) * sc) : 0.f;
-      o[2] = c + 2 < l ? (float)((s2 - d * wbar[c + 2]) * sc) : 0.f;
-      o[3] = c + 3 < l ? (float)((s3 - d * wbar[c + 3]) * sc) : 0.f;
+      o[0] = c < l ? (float)((s0 - d * w[0]) * sc) : 0.f;
+      o[1] = c + 1 < l ? (float)((s1 - d * w[1]) * sc) : 0.f;
+      o[2] = c + 2 < l ? (float)((s2 - d * w[2]) * sc) : 0.f;
+      o[3] = c + 3 < l ? (float)((s3 - d * w[3]) * sc) : 0.f;
       m = fmaxf(m, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
     }
     reinterpret_cast<f32x4*>(out)[i] = o;

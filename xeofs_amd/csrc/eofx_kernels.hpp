@@ -446,10 +446,13 @@ __global__ __launch_bounds__(256, NB > 2 ? 1 : 2) void atb_f16_kernel(const floa
   f32x4 bn[BREP];
 #pragma unroll
   for (int r = 0; r < BREP; ++r) bn[r] = f32x4{0.f, 0.f, 0.f, 0.f};
-#define EOFX_LOAD_SLAB(areg, chunk)                                                              \
+#define EOFX_LOAD_B(chunk)                                                                       \
   do {                                                                                           \
     if (b_loader) _Pragma("unroll") for (int r = 0; r < BREP; ++r)                               \
         bn[r] = *reinterpret_cast<const f32x4*>(Bp + ((int64_t)(chunk) * ATB_KC + BROWS * r) * ldb); \
+  } while (0)
+#define EOFX_LOAD_A(areg, chunk)                                                                 \
+  do {                                                                                           \
     if (AFF) {                                                                                   \
       const int r0_ = (int)kb + (chunk) * ATB_KC + lh;                                           \
       if ((int)kb + (chunk) * ATB_KC + ATB_KC <= a_rows) {   /* whole slab inside the field */    \
@@ -481,48 +484,67 @@ __global__ __launch_bounds__(256, NB > 2 ? 1 : 2) void atb_f16_kernel(const floa
       }                                                                                          \
     }                                                                                            \
   } while (0)
-#define EOFX_COMPUTE_SLAB(areg, buf)                                                             \
+#define EOFX_CONVERT_J(areg, j, af_)                                                             \
+  do {                                                                                           \
+    f32x8 x_;                                                                                    \
+    const unsigned msk_ = (AFF && MASK) ? (sla_[j] != 0.f ? 0xffffffffu : 0u) : 0xffffffffu;     \
+    _Pragma("unroll") for (int t = 0; t < 8; ++t) {                                              \
+      const float xr_ = (AFF && MASK) ? __uint_as_float(__float_as_uint(areg[t][j]) & msk_) : areg[t][j]; \
+      x_[t] = AFF ? aff_fma(xr_, shh_[j], sla_[j], nls_[j]) : xr_ * a_scale;                      \
+    }                                                                                            \
+    split_f16_mix(x_, m1, af_);                                                                  \
+  } while (0)
+#define EOFX_MFMA_J(j, af_)                                                                      \
+  _Pragma("unroll") for (int q = 0; q < NB; ++q) {                                               \
+    acc[j][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af_[1], bf_[0][q], acc[j][q], 0, 0, 0);   \
+    acc[j][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af_[0], bf_[1][q], acc[j][q], 0, 0, 0);   \
+    acc[j][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af_[0], bf_[0][q], acc[j][q], 0, 0, 0);   \
+  }
+  // One slab: its registers are REFILLED (slab `refill`) as soon as the last of its four feature groups has been
+  // converted -- before that group's MFMAs, the B staging and the barrier: a slab's registers are out of the memory
+  // pipeline only for the length of their conversion.  (Refilling after the whole slab cost 4-5 % of the bandwidth:
+  // two slabs per wave in flight against ~3.6 us of loaded latency is what paces the kernel.)
+#define EOFX_COMPUTE_SLAB(areg, buf, refill)                                                     \
   do {                                                                                           \
     f16x8 bf_[2][NB];                                                                            \
     _Pragma("unroll") for (int s = 0; s < 2; ++s) _Pragma("unroll") for (int q = 0; q < NB; ++q) \
         bf_[s][q] = *reinterpret_cast<const f16x8*>(&Bs[buf][s][lh][32 * q + li][0]);            \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                              \
-      f32x8 x_;                                                                                  \
-      const unsigned msk_ = (AFF && MASK) ? (sla_[j] != 0.f ? 0xffffffffu : 0u) : 0xffffffffu;   \
-      _Pragma("unroll") for (int t = 0; t < 8; ++t) {                                            \
-        const float xr_ = (AFF && MASK) ? __uint_as_float(__float_as_uint(areg[t][j]) & msk_) : areg[t][j]; \
-        x_[t] = AFF ? aff_fma(xr_, shh_[j], sla_[j], nls_[j]) : xr_ * a_scale;                    \
-      }                                                                                          \
+    _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                              \
       f16x8 af_[2];                                                                              \
-      split_f16_mix(x_, m1, af_);                                                                \
-      _Pragma("unroll") for (int q = 0; q < NB; ++q) {                                           \
-        acc[j][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af_[1], bf_[0][q], acc[j][q], 0, 0, 0); \
-        acc[j][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af_[0], bf_[1][q], acc[j][q], 0, 0, 0); \
-        acc[j][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af_[0], bf_[0][q], acc[j][q], 0, 0, 0); \
-      }                                                                                          \
+      EOFX_CONVERT_J(areg, j, af_);                                                              \
+      EOFX_MFMA_J(j, af_)                                                                        \
     }                                                                                            \
+    f16x8 al_[2];                                                                                \
+    EOFX_CONVERT_J(areg, 3, al_);                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    EOFX_LOAD_A(areg, refill);                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    EOFX_MFMA_J(3, al_)                                                                          \
   } while (0)
 
-  if (nchunks > 0) {
-    EOFX_LOAD_SLAB(a0, 0);
+  if (nchunks > 0) {     // nchunks is even (K and k_per_split are multiples of ATB_KG = two slabs)
+    EOFX_LOAD_B(0);
+    EOFX_LOAD_A(a0, 0);
+    EOFX_LOAD_A(a1, 1);
     EOFX_STORE_B(0);
     __syncthreads();
     for (int c = 0; c < nchunks; c += 2) {
-      EOFX_LOAD_SLAB(a1, c + 1);
-      __builtin_amdgcn_sched_barrier(0);
-      EOFX_COMPUTE_SLAB(a0, 0);
+      const int c2 = (c + 2 < nchunks) ? c + 2 : c;      // past the end: harmless re-reads of this pair
+      EOFX_LOAD_B(c + 1);
+      EOFX_COMPUTE_SLAB(a0, 0, c2);
       EOFX_STORE_B(1);
       __syncthreads();
-      const int c2 = (c + 2 < nchunks) ? c + 2 : c + 1;
-      EOFX_LOAD_SLAB(a0, c2);
-      __builtin_amdgcn_sched_barrier(0);
-      EOFX_COMPUTE_SLAB(a1, 1);
+      EOFX_LOAD_B(c2);
+      EOFX_COMPUTE_SLAB(a1, 1, c2 + 1);
       EOFX_STORE_B(0);
       __syncthreads();
     }
   }
-#undef EOFX_LOAD_SLAB
+#undef EOFX_LOAD_B
+#undef EOFX_LOAD_A
 #undef EOFX_COMPUTE_SLAB
+#undef EOFX_CONVERT_J
+#undef EOFX_MFMA_J
 #undef EOFX_STORE_B
 
   float* Cs = C + (int64_t)blockIdx.y * M * ldc;
@@ -1511,20 +1533,38 @@ __global__ __launch_bounds__(256) void panel_export_kernel(const float* __restri
     dst[i] = v;
   }
 }
-// P[rows_pad x L] <- src[rows x l] zero padded
+// P[rows_pad x L] <- src[rows x l] zero padded.  One thread per four adjacent columns (one 16-byte store); 32-bit
+// index arithmetic whenever the panel has fewer than 2^31 quads (a 64-bit division per element cost 100 us on the
+// 10000 x 60 sketch).
 __global__ __launch_bounds__(256) void panel_import_kernel(const float* __restrict__ src,
                                                            int64_t rows, int l,
                                                            float* __restrict__ P, int64_t rows_pad,
                                                            int L, unsigned* __restrict__ amax_out = nullptr) {
-  const int64_t total = rows_pad * L;
+  const int l4 = L / 4;
+  const int64_t total = rows_pad * l4;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const bool small = total < ((int64_t)1 << 31);
   float mx = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-    const int64_t r = i / L;
-    const int c = (int)(i - r * L);
-    const float v = (r < rows && c < l) ? src[r * l + c] : 0.f;
-    P[i] = v;
-    mx = fmaxf(mx, fabsf(v));
+    int64_t r;
+    int c;
+    if (small) {
+      const unsigned iu = (unsigned)i, ru = iu / (unsigned)l4;
+      r = ru;
+      c = (int)(iu - ru * (unsigned)l4) * 4;
+    } else {
+      r = i / l4;
+      c = (int)(i - r * l4) * 4;
+    }
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (r < rows) {
+      const float* sp = src + r * l + c;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (c + e < l) v[e] = sp[e];
+    }
+    reinterpret_cast<f32x4*>(P)[i] = v;
+    mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
   }
   if (amax_out) {
 #pragma unroll
