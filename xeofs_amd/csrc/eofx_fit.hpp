@@ -132,19 +132,40 @@ __global__ __launch_bounds__(256, 2) void atb_f16_fit_kernel(const float* __rest
   const f32x4 ncs_ = -cs_ * asc_;                // (x - c) a = fma(x, a, -c a): one rounding, one instruction (a = 2^k)
   float m1 = -1.f;   // opaque to the optimiser: x - (float)h stays ONE v_fma_mix_f32 instead of a conversion and a subtraction
   asm volatile("" : "+v"(m1));
-  constexpr int BV = 8 * NB;
-  const bool b_loader = tid < 16 * BV;
-  const int brow0 = tid / BV, bc4 = tid % BV;
-  const bool b_ones = bc4 == BV - 1;             // this loader thread stages columns 32 NB - 4 .. 32 NB - 1
-  const float* Bp = B + (kb + brow0) * (int64_t)ldb + 4 * bc4;
+  // B staging as in atb_f16_kernel: item = (column pair cp, parity lh, row pair tp), two 8-byte loads, one packed 4-byte
+  // LDS store per column and plane, bank-conflict free; three registers of per-thread state
+  constexpr int CP = 16 * NB;
+  const bool b_odd = (tid >> 4) & 1;
+  int b_off, b_w0, b_w1, b_r0;
+  bool b_loader, b_ones;
+  {
+    const int tp_ = tid & 3, lh_ = (tid >> 4) & 1;
+    const int cp_ = ((tid >> 2) & 3) | ((tid >> 5) << 2);
+    b_loader = cp_ < CP;
+    b_ones = cp_ == CP - 1;            // this loader stages columns 32 NB - 2 and 32 NB - 1: the latter is the ones column
+    b_r0 = (int)kb + 4 * tp_ + lh_;    // its rows of slab 0: b_r0 and b_r0 + 2
+    b_off = (4 * tp_ + lh_) * ldb + 2 * cp_;
+    const int w_ = ((lh_ * 32 * NB + 2 * cp_) * 8 + 2 * tp_) * 2;
+    b_w0 = w_ + 16 * lh_;
+    b_w1 = w_ + 16 * (1 - lh_);
+  }
+  char* const Bsb = reinterpret_cast<char*>(&Bs[0][0][0][0][0]);
+  constexpr int B_PLANE = 2 * 32 * NB * 8 * 2, B_BUF = 2 * B_PLANE;
 
   f32x4 a0[8], a1[8];
-  f32x4 bn = {0.f, 0.f, 0.f, 0.f};
+  f32x4 bn = {0.f, 0.f, 0.f, 0.f};      // {row r0: col 2cp, 2cp+1; row r0 + 2: col 2cp, 2cp+1}
 #define EOFX_FIT_LOAD_B(chunk)                                                                   \
   do {                                                                                           \
     if (b_loader) {                                                                              \
-      bn = *reinterpret_cast<const f32x4*>(Bp + (int64_t)(chunk) * ATB_KC * ldb);                \
-      if (b_ones) bn[3] = ((int)kb + (chunk) * ATB_KC + brow0 < a_rows) ? FIT_ONE / b_scale : 0.f; \
+      const float* bp_ = B + (kb + (int64_t)(chunk) * ATB_KC) * ldb + b_off;                       \
+      const f32x2 lo_ = *reinterpret_cast<const f32x2*>(bp_);                                    \
+      const f32x2 hi_ = *reinterpret_cast<const f32x2*>(bp_ + 2 * ldb);                          \
+      bn = f32x4{lo_[0], lo_[1], hi_[0], hi_[1]};                                                \
+      if (b_ones) {                                                                              \
+        const int row_ = b_r0 + (chunk) * ATB_KC;                                                \
+        bn[1] = row_ < a_rows ? FIT_ONE / b_scale : 0.f;                                         \
+        bn[3] = row_ + 2 < a_rows ? FIT_ONE / b_scale : 0.f;                                     \
+      }                                                                                          \
     }                                                                                            \
   } while (0)
 #define EOFX_FIT_LOAD_A(areg, chunk)                                                             \
@@ -163,14 +184,16 @@ __global__ __launch_bounds__(256, 2) void atb_f16_fit_kernel(const float* __rest
   } while (0)
 #define EOFX_FIT_STORE_B(buf)                                                                    \
   do {                                                                                           \
-    if (b_loader) {                                                                              \
-      _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                            \
-        const float r_ = bn[e] * b_scale;                                                        \
-        const fp16x2_t h_ = __builtin_amdgcn_cvt_pkrtz(r_, 0.f);                                 \
-        const _Float16 m_ = (_Float16)(r_ - (float)h_[0]);                                       \
-        Bs[buf][0][brow0 & 1][4 * bc4 + e][brow0 >> 1] = (_Float16)h_[0];                        \
-        Bs[buf][1][brow0 & 1][4 * bc4 + e][brow0 >> 1] = m_;                                     \
-      }                                                                                          \
+    if (b_loader) _Pragma("unroll") for (int e2 = 0; e2 < 2; ++e2) {                             \
+      const bool sec_ = (e2 != 0) != b_odd;                                                      \
+      const float v0_ = (sec_ ? bn[1] : bn[0]) * b_scale, v1_ = (sec_ ? bn[3] : bn[2]) * b_scale; \
+      const fp16x2_t h_ = __builtin_amdgcn_cvt_pkrtz(v0_, v1_);                                  \
+      fp16x2_t l_;                                                                               \
+      l_[0] = (__fp16)__builtin_fmaf((float)h_[0], m1, v0_);                                     \
+      l_[1] = (__fp16)__builtin_fmaf((float)h_[1], m1, v1_);                                     \
+      char* w_ = Bsb + (buf) * B_BUF + (e2 ? b_w1 : b_w0);                                       \
+      *reinterpret_cast<unsigned*>(w_) = __builtin_bit_cast(unsigned, h_);                       \
+      *reinterpret_cast<unsigned*>(w_ + B_PLANE) = __builtin_bit_cast(unsigned, l_);             \
     }                                                                                            \
   } while (0)
   /* Left to itself the SLP vectoriser packs the fmas below (across t, across j) into v_pk_fma_f32: slower beside MFMAs,

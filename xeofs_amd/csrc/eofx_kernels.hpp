@@ -435,21 +435,46 @@ __global__ __launch_bounds__(256, NB > 2 ? 1 : 2) void atb_f16_kernel(const floa
   const f32x4 nls_ = -(shl_ * sla_);
   float m1 = -1.f;   // opaque to the optimiser (split_f16_mix)
   asm volatile("" : "+v"(m1));
-  constexpr int BV = 8 * NB;
-  constexpr int BREP = (16 * BV + 255) / 256;      // 16-byte loads of the B slab per thread (2 for the 128-column tile)
-  constexpr int BROWS = 256 / BV < 16 ? 256 / BV : 16;   // slab rows covered by one such load of the workgroup
-  const bool b_loader = tid < 16 * BV;
-  const int brow0 = tid / BV, bc4 = tid % BV;
-  const float* Bp = B + (kb + brow0) * (int64_t)ldb + bcol0 + 4 * bc4;
+  // B staging.  The MFMA fragment of a lane is Bs[plane][lh][column][0..7] = slab rows lh, lh + 2, .., lh + 14 of one
+  // column, so a loader item is (column PAIR cp, parity lh, row pair tp): two 8-byte loads (rows 4 tp + lh and + 2) give
+  // two columns x two rows, and each column's two rows are ONE packed fp16 pair = one 4-byte LDS store per plane.
+  // Item bits, low to high: tp (2), cp low (2), lh (1), cp high; the lh = 1 lanes write their two columns in the
+  // opposite order, so the 64 lanes of one store instruction cover all 32 banks twice (free).  [One 2-byte store per
+  // element, row per thread, was an 8- to 16-way bank conflict: 88 % of the kernel's LDS cycles,
+  // profiles/r03_sq_counters.txt.]
+  constexpr int CP = 16 * NB;                      // column pairs of the slab
+  constexpr int BREP = (8 * CP + 255) / 256;       // items per thread: 1 (NB = 1: half the threads, NB = 2: all), 2 (NB = 4)
+  // per-thread state kept to THREE registers (the kernel has none to spare; a spilled pointer is reloaded from scratch
+  // inside the loop, and waiting for a scratch load drains every streaming load in flight): a 32-bit element offset
+  // into the slab of B (the slab's first row is a uniform 64-bit base) and the LDS byte offsets of its two stores.
+  const bool b_odd = (tid >> 4) & 1;                           // lh
+  int b_off, b_w0, b_w1;
+  {
+    const int tp_ = tid & 3, lh_ = (tid >> 4) & 1;
+    const int cp_ = ((tid >> 2) & 3) | ((tid >> 5) << 2);      // + 32 for the second item of the 128-column tile
+    b_off = (4 * tp_ + lh_) * ldb + bcol0 + 2 * cp_;               // relative to the slab's first row (uniform part: SGPRs)
+    const int w_ = ((lh_ * 32 * NB + 2 * cp_) * 8 + 2 * tp_) * 2;    // bytes of Bs[.][.][lh][2 cp][2 tp]
+    b_w0 = w_ + 16 * lh_;
+    b_w1 = w_ + 16 * (1 - lh_);
+  }
+  const bool b_item0 = (((tid >> 2) & 3) | ((tid >> 5) << 2)) < CP;   // NB = 1: only the first 128 threads stage B
+  char* const Bsb = reinterpret_cast<char*>(&Bs[0][0][0][0][0]);
+  constexpr int B_PLANE = 2 * 32 * NB * 8 * 2, B_BUF = 2 * B_PLANE;   // bytes per fp16 plane / per buffer
 
   f32x4 a0[8], a1[8];
-  f32x4 bn[BREP];
+  f32x4 bn[BREP];      // {row r0: col 2cp, 2cp+1; row r0 + 2: col 2cp, 2cp+1}
 #pragma unroll
   for (int r = 0; r < BREP; ++r) bn[r] = f32x4{0.f, 0.f, 0.f, 0.f};
 #define EOFX_LOAD_B(chunk)                                                                       \
   do {                                                                                           \
-    if (b_loader) _Pragma("unroll") for (int r = 0; r < BREP; ++r)                               \
-        bn[r] = *reinterpret_cast<const f32x4*>(Bp + ((int64_t)(chunk) * ATB_KC + BROWS * r) * ldb); \
+    _Pragma("unroll") for (int r = 0; r < BREP; ++r) {                                           \
+      if (b_item0) {                                                                             \
+        const float* bp_ = B + (kb + (int64_t)(chunk) * ATB_KC) * ldb + (b_off + 64 * r);         \
+        const f32x2 lo_ = *reinterpret_cast<const f32x2*>(bp_);                                  \
+        const f32x2 hi_ = *reinterpret_cast<const f32x2*>(bp_ + 2 * ldb);                        \
+        bn[r] = f32x4{lo_[0], lo_[1], hi_[0], hi_[1]};                                           \
+      }                                                                                          \
+    }                                                                                            \
   } while (0)
 #define EOFX_LOAD_A(areg, chunk)                                                                 \
   do {                                                                                           \
@@ -473,14 +498,17 @@ __global__ __launch_bounds__(256, NB > 2 ? 1 : 2) void atb_f16_kernel(const floa
   } while (0)
 #define EOFX_STORE_B(buf)                                                                        \
   do {                                                                                           \
-    if (b_loader) {                                                                              \
-      _Pragma("unroll") for (int r = 0; r < BREP; ++r) _Pragma("unroll") for (int e = 0; e < 4; ++e) { \
-        const int brow = brow0 + BROWS * r;                                                      \
-        const float r_ = bn[r][e] * b_scale;                                                     \
-        const fp16x2_t h_ = __builtin_amdgcn_cvt_pkrtz(r_, 0.f);                                 \
-        const _Float16 m_ = (_Float16)(r_ - (float)h_[0]);                                       \
-        Bs[buf][0][brow & 1][4 * bc4 + e][brow >> 1] = (_Float16)h_[0];                          \
-        Bs[buf][1][brow & 1][4 * bc4 + e][brow >> 1] = m_;                                       \
+    _Pragma("unroll") for (int r = 0; r < BREP; ++r) {                                           \
+      if (b_item0) _Pragma("unroll") for (int e2 = 0; e2 < 2; ++e2) {                            \
+        const bool sec_ = (e2 != 0) != b_odd;        /* which column of the pair this store takes */ \
+        const float v0_ = (sec_ ? bn[r][1] : bn[r][0]) * b_scale, v1_ = (sec_ ? bn[r][3] : bn[r][2]) * b_scale; \
+        const fp16x2_t h_ = __builtin_amdgcn_cvt_pkrtz(v0_, v1_);                                \
+        fp16x2_t l_;                                                                             \
+        l_[0] = (__fp16)__builtin_fmaf((float)h_[0], m1, v0_);                                   \
+        l_[1] = (__fp16)__builtin_fmaf((float)h_[1], m1, v1_);                                   \
+        char* w_ = Bsb + (buf) * B_BUF + (e2 ? b_w1 : b_w0) + 64 * 16 * r;                       \
+        *reinterpret_cast<unsigned*>(w_) = __builtin_bit_cast(unsigned, h_);                     \
+        *reinterpret_cast<unsigned*>(w_ + B_PLANE) = __builtin_bit_cast(unsigned, l_);           \
       }                                                                                          \
     }                                                                                            \
   } while (0)
