@@ -161,11 +161,20 @@ int eofx_mat_download_f32(eofx_ctx *ctx, const eofx_mat *m, float *dst);
  *         HBM instead of 3x.  Entry points that need a layout (other precisions than EOFX_PREC_F16X3, the Hilbert
  *         transform, Gram matrices, download, resampling) build it on demand from the field through the same map.
  * Modes 1 and 2 apply whenever nothing is dropped (no all-NaN feature or sample) and the raw field is 16-byte aligned
- * with P % 4 == 0; otherwise mode 0 is used silently.  A DEVICE field handed to the preprocessor must stay alive and
+ * with P % 4 == 0; otherwise mode 0 is used silently (but see mode 3).  A DEVICE field handed to the preprocessor must stay alive and
  * unmodified until eofx_mat_release_raw (which first builds what only the field could provide) or eofx_mat_destroy; a
  * host field is staged and owned by the matrix.  eofx_mat_layout: bit 0 / bit 1 of *layouts = feature- /
- * sample-contiguous layout present.                                                                              */
+ * sample-contiguous layout present.
+ * mode 3  mode 2, and a field with all-NaN grid points (a land / sea mask; sanitizer.py:80-126 drops them) may keep them
+ *         as ZERO columns of the in-place matrix instead of being compacted into a second copy: their scale is 0 in the
+ *         map and the streaming kernels' MASK variants AND their bits to +0, so no product, Gram matrix or norm changes.
+ *         Taken when fewer than 40 % of the features are masked and n < (valid features).  eofx_mat_shape then reports
+ *         p = P (the physical column count), eofx_mat_masked the number of valid ones; factors with a feature axis come
+ *         back with P rows (zeros at the masked features) and are expected that way: the CALLER compacts / scatters
+ *         (xeofs_amd/engine.py does).  Only for callers prepared for that.                                        */
 int eofx_ctx_set_layout(eofx_ctx *ctx, int mode);
+/* masked: 1 for a mode-3 matrix with zero columns; p_valid: its number of valid features (= p otherwise). */
+int eofx_mat_masked(const eofx_mat *m, int *masked, int64_t *p_valid);
 int eofx_mat_release_raw(eofx_ctx *ctx, eofx_mat *m);
 int eofx_mat_layout(const eofx_mat *m, int *layouts, int *has_raw);
 

@@ -62,6 +62,48 @@ def test_eof_properties_at_baseline_sizes(ctx, n, nlat, nlon, k, layout):
     ctx.trim()
 
 
+def test_masked_config4_in_place(ctx):
+    """SURVEY 8d's NaN variant of config 4 -- a 30 % land mask (all-NaN grid points) and cos-lat weights on the
+    10000 x (720 x 1440) field -- decomposed IN PLACE (layout mode 3): 1x the field in HBM, nothing written, and the
+    size-independent properties of the unmasked run hold on the valid features."""
+    import torch
+
+    from xeofs_amd import engine
+
+    n, nlat, nlon, k = 10000, 720, 1440, 50
+    X = _device_field(n, nlat, nlon)
+    mask = torch.rand(nlat * nlon, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1)) < 0.3
+    X[:, mask] = float("nan")
+    lat = np.linspace(-89.75, 89.75, nlat)
+    w = np.repeat(np.sqrt(np.cos(np.deg2rad(lat)).clip(0, 1)), nlon)
+    free0 = torch.cuda.mem_get_info()[0]
+    mat, st = engine.preprocess(ctx, X, True, False, w, want_stats=False, in_place=True, allow_masked=True)
+    pv = int((~mask).sum())
+    assert mat.masked and mat.p == pv == st["p"] and not mat.has_sample_layout()
+    assert free0 - torch.cuda.mem_get_info()[0] < 4 << 30          # no copy of the 41 GB field was made
+    U, s, V = engine.rsvd(ctx, mat, k, random_state=5, device_out=True)
+    assert tuple(V.shape) == (pv, k) and not mat.has_sample_layout()
+    Ud, Vd = U.double(), V.double()
+    sd = torch.as_tensor(s.astype(np.float64), device=Ud.device)
+    eye = torch.eye(k, dtype=torch.float64, device=Ud.device)
+    assert float((Ud.T @ Ud - eye).abs().max()) < 1e-6
+    assert float((Vd.T @ Vd - eye).abs().max()) < 1e-6
+    XV = torch.as_tensor(engine.project(ctx, mat, V), device=Ud.device).double()
+    assert float((XV - Ud * sd).norm() / (Ud * sd).norm()) < 1e-5
+    assert (s.astype(np.float64) ** 2).sum() / (n - 1) <= st["total_variance"] * (1 + 1e-5)
+    U2, s2, V2 = engine.rsvd(ctx, mat, k, random_state=5, device_out=True)
+    assert np.array_equal(s, s2) and torch.equal(V, V2)
+    mat.free()
+    # the same field through the compaction route (three times the memory): same singular values
+    del Ud, Vd, XV, U2, V2
+    mat2, st2 = engine.preprocess(ctx, X, True, False, w, want_stats=False)
+    U3, s3, V3 = engine.rsvd(ctx, mat2, k, random_state=5, device_out=True)
+    assert np.allclose(s3, s, rtol=2e-6)
+    assert float((V3.double() - V.double()).abs().max()) < 1e-5
+    mat2.free()
+    ctx.trim()
+
+
 def test_config1_shape_vs_oracle(ctx):
     """BASELINE config 1: xe.single.EOF(n_modes=10) on the air_temperature shape 2920 x (25 x 53)
     (synthetic stand-in of the same shape), use_coslat as in the README quickstart."""

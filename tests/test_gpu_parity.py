@@ -461,6 +461,64 @@ def test_fused_fit_falls_back(ctx):
     mat.free()
 
 
+@pytest.mark.parametrize("opts", [{}, {"standardize": True}, {"weights": True}])
+def test_masked_in_place_layout(ctx, opts):
+    """Layout mode 3: a field with all-NaN grid points (land / sea mask, sanitizer.py:80-126) stays IN PLACE -- the masked
+    features are zero columns of the engine's matrix (scale 0, bits ANDed to +0 by the MASK kernels) instead of being
+    compacted into a second copy.  Same factors as the compacted matrix, same oracle tolerances, nothing written."""
+    from xeofs_amd import engine
+
+    n, nlat, nlon, k = 300, 24, 40, 8
+    X, lat = orc.synthetic_field(n, nlat, nlon, rank=8, seed=11, nan_frac=0.3)
+    X = np.ascontiguousarray(X, dtype=np.float32)
+    w = np.repeat(orc.sqrt_cos_lat_weights(lat), nlon) if opts.get("weights") else None
+    std = opts.get("standardize", False)
+    mat, st = engine.preprocess(ctx, X, True, std, w, in_place=True, allow_masked=True)
+    pv = int(st["valid_feature"].sum())
+    assert mat.masked and mat.p == pv == st["p"] and mat.p_phys == X.shape[1] and 0.6 * X.shape[1] < pv < X.shape[1]
+    assert mat.layout() == (False, True) and not mat.has_sample_layout()          # nothing was written
+    U, s, V = engine.rsvd(ctx, mat, k, random_state=4)
+    assert V.shape == (pv, k) and U.shape == (n, k)
+    assert not mat.has_sample_layout()                                               # the passes streamed the field
+    ref = orc.eof_fit(X.astype(np.float64), k, standardize=std, feature_weights=w, random_state=4)
+    assert np.array_equal(st["valid_feature"], ref["valid_feature"])
+    _check_factors(U, s, V, ref, k)
+    assert abs(st["total_variance"] - ref["total_variance"]) <= 1e-6 * ref["total_variance"]
+    # against the compacted two-layout matrix of the same field
+    mat2, st2 = engine.preprocess(ctx, X, True, std, w)
+    assert not mat2.masked and mat2.p == pv
+    U2, s2, V2 = engine.rsvd(ctx, mat2, k, random_state=4)
+    assert np.all(np.abs(s - s2) <= 2e-6 * s2[0])
+    D1, D2 = mat.download(), mat2.download()            # the masked view, compacted by the engine wrapper
+    assert D1.shape == D2.shape and np.abs(D1 - D2).max() <= 2e-6 * np.abs(D2).max()
+    P1, P2 = engine.project(ctx, mat, V2), engine.project(ctx, mat2, V2)
+    assert np.abs(P1 - P2).max() <= 2e-6 * np.abs(P2).max()
+    assert np.allclose(engine.feature_norms(ctx, mat), engine.feature_norms(ctx, mat2), rtol=2e-6)
+    assert np.allclose(engine.sample_norms(ctx, mat), engine.sample_norms(ctx, mat2), rtol=2e-6)
+    # the one-call fit takes the same route when it meets the mask
+    mat3, st3, U3, s3, V3 = engine.fit(ctx, X, k, standardize=std, feature_weights=w, random_state=4, allow_masked=True)
+    assert not st3["fused"] and mat3.masked and V3.shape == (pv, k)
+    assert np.array_equal(s3, s) and np.array_equal(V3, V) and np.array_equal(U3, U)
+    # transform of new data with the same mask: in place again, scores of the training data come back
+    mat4, vs4 = engine.apply(ctx, X, st["mean"], st["std"] if std else None, w, st["valid_feature"], in_place=True,
+                             allow_masked=True)
+    assert mat4.masked and not mat4.has_sample_layout()
+    S4 = engine.project(ctx, mat4, V)
+    assert np.abs(S4 - U * s).max() <= 1e-5 * s[0]
+    for m_ in (mat, mat2, mat3, mat4):
+        m_.free()
+    # an isolated NaN inside a valid feature is still the Sanitizer's error
+    Y = X.copy()
+    Y[17, int(np.flatnonzero(st["valid_feature"])[5])] = np.nan
+    with pytest.raises(ValueError, match="partial NaN"):
+        engine.preprocess(ctx, Y, in_place=True, allow_masked=True)
+    # more than 40 % masked (or fewer valid features than samples): compaction, as before
+    Z, _ = orc.synthetic_field(n, nlat, nlon, rank=8, seed=12, nan_frac=0.55)
+    mat5, st5 = engine.preprocess(ctx, np.ascontiguousarray(Z, dtype=np.float32), in_place=True, allow_masked=True)
+    assert not mat5.masked and mat5.p == st5["p"] == mat5.p_phys
+    mat5.free()
+
+
 def test_documented_size_limits_fail_loudly(ctx):
     """The limits DESIGN.md §13 lists raise instead of degrading silently."""
     import torch

@@ -59,6 +59,9 @@ struct eofx_ctx {
   // layout policy of the next preprocess / apply (eofx_ctx_set_layout): 0 = write both layouts, 1 = keep a reference to
   // the raw field instead of the feature-contiguous layout, 2 = in place: write nothing, both products stream the field
   int keep_raw = 0;
+  // layout mode 3: in place, and a field with all-NaN grid points (land / sea mask) keeps them as ZERO columns instead of
+  // being compacted (eofx_mat::masked); only for callers that compact / scatter the feature axis of the factors themselves
+  bool allow_masked = false;
   // optional per-launch timing of the dominant kernel (atb_f32) with HIP events on `stream`
   bool profile = false;
   struct ProfEvent {
@@ -1124,7 +1127,9 @@ static int ensure_X(eofx_ctx* ctx, const eofx_mat* cm) {
   return EOFX_OK;
 }
 extern "C" int eofx_ctx_set_layout(eofx_ctx* ctx, int keep_raw) {
-  if (!ctx || keep_raw < 0 || keep_raw > 2) return EOFX_ERR_ARG;
+  if (!ctx || keep_raw < 0 || keep_raw > 3) return EOFX_ERR_ARG;
+  ctx->allow_masked = keep_raw == 3;
+  if (keep_raw == 3) keep_raw = 2;
   ctx->keep_raw = keep_raw;
   return EOFX_OK;
 }
@@ -1137,6 +1142,12 @@ extern "C" int eofx_mat_release_raw(eofx_ctx* ctx, eofx_mat* m) {
   m->raw_owned = nullptr;
   m->raw_owned_bytes = 0;
   m->raw = nullptr;
+  return EOFX_OK;
+}
+extern "C" int eofx_mat_masked(const eofx_mat* m, int* masked, int64_t* p_valid) {
+  if (!m) return EOFX_ERR_ARG;
+  if (masked) *masked = m->masked ? 1 : 0;
+  if (p_valid) *p_valid = m->masked ? m->p_valid : m->p;
   return EOFX_OK;
 }
 extern "C" int eofx_mat_layout(const eofx_mat* m, int* has_x, int* has_raw) {
@@ -1325,10 +1336,18 @@ static int sanitize_and_apply(eofx_ctx* ctx, const float* Xd, int64_t n, int64_t
 
   // raw mode (eofx_ctx_set_layout): nothing is dropped or reordered, so the raw field itself -- read through the
   // affine map -- is the feature-contiguous layout; only the sample-contiguous one is written.  P < 2^31 rows: int.
-  const bool raw_mode = ctx->keep_raw && pv == P && ns == n && P % 4 == 0 && ((uintptr_t)Xd % 16) == 0 && n < ((int64_t)1 << 31);
+  const bool raw_ok = ctx->keep_raw && ns == n && P % 4 == 0 && ((uintptr_t)Xd % 16) == 0 && n < ((int64_t)1 << 31);
+  // masked in place (layout mode 3): all-NaN grid points (sanitizer.py:80-126 would drop them) stay in the matrix as zero
+  // columns -- scale 0 in the map, bits ANDed to +0 by the MASK kernels -- when they are a minority and the sketch lives
+  // on the sample side; a zero column changes no product, Gram matrix or norm, so the factors are those of the compacted
+  // matrix with zero rows in V at the masked features (the caller drops them).  1x the field in HBM instead of 3x.
+  const bool masked_mode = raw_ok && ctx->keep_raw == 2 && ctx->allow_masked && stats_absmax && pv < P && 10 * pv >= 6 * P && n < pv;
+  const bool raw_mode = (raw_ok && pv == P) || masked_mode;
   eofx_mat* m = nullptr;
   const bool in_place = raw_mode && ctx->keep_raw == 2;
-  CHK(mat_alloc(ctx, ns, pv, &m, !raw_mode, !in_place));
+  CHK(mat_alloc(ctx, ns, masked_mode ? P : pv, &m, !raw_mode, !in_place));
+  m->p_valid = pv;
+  m->masked = masked_mode;
   int rc = EOFX_OK;
   if (raw_mode) {
     const size_t abytes = sizeof(float) * 3 * (size_t)m->p_pad;
@@ -1339,7 +1358,7 @@ static int sanitize_and_apply(eofx_ctx* ctx, const float* Xd, int64_t n, int64_t
       return set_err(ctx, EOFX_ERR_NOMEM, "cannot allocate the affine map (%zu bytes)", abytes);
     }
     hipLaunchKernelGGL(aff_pack_kernel, dim3((int)((m->p_pad + 255) / 256)), dim3(256), 0, ctx->stream, ps.shift, ps.scale, P,
-                       m->p_pad, m->aff);
+                       m->p_pad, m->aff, masked_mode ? ps.cnt : (const int*)nullptr);
     if (hipGetLastError() != hipSuccess) {
       eofx_mat_destroy(ctx, m);
       return set_err(ctx, EOFX_ERR_HIP, "raw mode: affine map kernel failed");
@@ -1352,7 +1371,7 @@ static int sanitize_and_apply(eofx_ctx* ctx, const float* Xd, int64_t n, int64_t
     int64_t* dcol = nullptr;
     int64_t* drow = nullptr;
     int* flag = arena_alloc<int>(ctx, 1);
-    if (pv < P) {
+    if (pv < P && !masked_mode) {
       std::vector<int64_t> col_map;
       col_map.reserve(pv);
       for (int64_t c = 0; c < P; ++c)
@@ -1370,7 +1389,7 @@ static int sanitize_and_apply(eofx_ctx* ctx, const float* Xd, int64_t n, int64_t
         rc = EOFX_ERR_HIP;
       if (rc == EOFX_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = EOFX_ERR_HIP;
     }
-    if (!flag || (pv < P && !dcol) || (ns < n && !drow)) rc = set_err(ctx, EOFX_ERR_NOMEM, "arena exhausted (maps)");
+    if (!flag || (pv < P && !masked_mode && !dcol) || (ns < n && !drow)) rc = set_err(ctx, EOFX_ERR_NOMEM, "arena exhausted (maps)");
     if (rc == EOFX_OK && hipMemsetAsync(flag, 0, sizeof(int), ctx->stream) != hipSuccess) rc = EOFX_ERR_HIP;
     if (rc == EOFX_OK && in_place && !stats_absmax) rc = set_err(ctx, EOFX_ERR_ARG, "in-place layout needs the column statistics");
     if (rc == EOFX_OK && in_place) {   // nothing to write: max |x'| comes from the column statistics

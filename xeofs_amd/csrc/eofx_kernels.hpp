@@ -1851,13 +1851,16 @@ __global__ __launch_bounds__(256) void rowcount_kernel(const float* __restrict__
   if (threadIdx.x == 0) rowcnt[r] = red[0];
 }
 
-// shift / scale (float64, per source column) -> {hi, lo, scale} float triples of the raw view; columns >= p: zeros
+// shift / scale (float64, per source column) -> {hi, lo, scale} float triples of the raw view; columns >= p: zeros.
+// cnt (may be null): features without a single value (all-NaN grid points kept as zero columns of a masked in-place
+// matrix) get the zero triple too -- scale 0 is what the MASK kernels key on.
 __global__ __launch_bounds__(256) void aff_pack_kernel(const double* __restrict__ shift, const double* __restrict__ scale,
-                                                        int64_t p, int64_t p_pad, float* __restrict__ out) {
+                                                        int64_t p, int64_t p_pad, float* __restrict__ out,
+                                                        const int* __restrict__ cnt = nullptr) {
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= p_pad) return;
   float hi = 0.f, lo = 0.f, sl = 0.f;
-  if (c < p) {
+  if (c < p && (!cnt || cnt[c] > 0)) {
     aff_split(shift ? shift[c] : 0.0, hi, lo);
     sl = scale ? (float)scale[c] : 1.f;
   }

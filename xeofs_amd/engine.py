@@ -100,15 +100,63 @@ class ResidentMatrix:
         ctx.lib.eofx_mat_shape(handle, C.byref(n), C.byref(p), C.byref(npad), C.byref(ppad))
         self.n, self.p, self.n_pad, self.p_pad = n.value, p.value, npad.value, ppad.value
         self._keepalive = None     # the device field a raw-mode matrix reads (must outlive it)
+        # Masked in-place matrix (layout mode 3, include/eofx.h): all-NaN grid points stay in the matrix as zero columns.
+        # `p` is the number of VALID features -- what every caller means by it --, `p_phys` the column count of the
+        # engine's matrix; `valid_index` (int64, ascending) maps one onto the other.  The functions of this module
+        # compact / scatter the feature axis of the factors, so callers never see the zero columns.
+        self.p_phys = self.p
+        self.valid_index = None
+        mk, pv = C.c_int(), C.c_int64()
+        ctx.lib.eofx_mat_masked(handle, C.byref(mk), C.byref(pv))
+        self.masked = bool(mk.value)
+        if self.masked:
+            self.p = pv.value
+
+    def set_valid(self, valid_feature):
+        """the boolean mask of valid features of a masked matrix (from the preprocessing statistics)"""
+        idx = np.flatnonzero(np.asarray(valid_feature, dtype=bool)).astype(np.int64)
+        if idx.size != self.p or (idx.size and idx[-1] >= self.p_phys):
+            raise ValueError("valid-feature mask does not match the masked matrix")
+        self.valid_index = idx
+        self._valid_dev = None
+
+    def _vidx(self, device=None):
+        """valid_index as a torch tensor on `device` (cached)"""
+        torch = _torch()
+        dev = device if device is not None else f"cuda:{self.ctx.device}"
+        if getattr(self, "_valid_dev", None) is None or str(self._valid_dev.device) != str(torch.device(dev)):
+            self._valid_dev = torch.as_tensor(self.valid_index, device=dev)
+        return self._valid_dev
+
+    def compact_rows(self, V):
+        """rows of the valid features of a factor with p_phys rows (numpy array or torch tensor)"""
+        if not self.masked:
+            return V
+        if hasattr(V, "data_ptr"):
+            return V.index_select(0, self._vidx(V.device)).contiguous()
+        return np.ascontiguousarray(V[self.valid_index])
+
+    def scatter_rows(self, V):
+        """a factor with p rows -> p_phys rows, zeros at the masked features"""
+        if not self.masked:
+            return V
+        if hasattr(V, "data_ptr"):
+            torch = _torch()
+            out = torch.zeros((self.p_phys,) + tuple(V.shape[1:]), dtype=V.dtype, device=V.device)
+            out.index_copy_(0, self._vidx(V.device), V)
+            return out
+        out = np.zeros((self.p_phys,) + V.shape[1:], dtype=V.dtype)
+        out[self.valid_index] = V
+        return out
 
     @property
     def shape(self):
         return (self.n, self.p)
 
     def download(self) -> np.ndarray:
-        out = np.empty((self.n, self.p), dtype=np.float32)
+        out = np.empty((self.n, self.p_phys), dtype=np.float32)
         raise_for(self.ctx.lib.eofx_mat_download_f32(self.ctx.handle, self.handle, ptr(out)), self.ctx.handle)
-        return out
+        return np.ascontiguousarray(out[:, self.valid_index]) if self.masked else out
 
     def sumsq(self) -> float:
         out = C.c_double()
@@ -119,6 +167,8 @@ class ResidentMatrix:
         """side 0: X X^T as an [n_pad, n_pad] float32 device tensor; side 1: X^T X [p_pad, p_pad]
         (rows/columns beyond n / p are zero)."""
         torch = _torch()
+        if side and self.masked:
+            raise NotImplementedError("feature-space Gram matrix of a masked in-place matrix")
         d = self.p_pad if side else self.n_pad
         G = torch.empty((d, d), dtype=torch.float32, device=f"cuda:{self.ctx.device}")
         raise_for(self.ctx.lib.eofx_mat_gram_f32(self.ctx.handle, self.handle, int(side), ptr(G)), self.ctx.handle)
@@ -252,14 +302,21 @@ def from_dense(ctx: Context, X) -> ResidentMatrix:
     return ResidentMatrix(ctx, h)
 
 
+def _layout_mode(keep_raw, in_place, allow_masked):
+    return (3 if allow_masked else 2) if in_place else int(bool(keep_raw))
+
+
 def preprocess(ctx: Context, X, center=True, standardize=False, feature_weights=None,
-               check_nans=True, want_stats=True, build=True, keep_raw=False, in_place=False):
+               check_nans=True, want_stats=True, build=True, keep_raw=False, in_place=False, allow_masked=False):
     """Scaler + Sanitizer + total variance on the stacked raw (n, P) field.
     Returns (ResidentMatrix | None, stats dict).  keep_raw: raw mode (include/eofx.h, eofx_ctx_set_layout) -- the
     feature-contiguous layout is not written, the products read the raw field through the Scaler map; in_place:
     NO layout is written, both products stream the field where it lies (the sample-contiguous layout is built on
     demand by the entry points that need it).  Either way a device field must stay unmodified until
-    `release_raw()` / `free()` (the matrix holds a reference to it); a host field is staged and owned."""
+    `release_raw()` / `free()` (the matrix holds a reference to it); a host field is staged and owned.
+    allow_masked (with in_place): a field whose NaN pattern is a mask of all-NaN grid points stays in place as well -- the
+    masked features become zero columns of the engine's matrix (layout mode 3, include/eofx.h) and this module
+    compacts / scatters the feature axis of every factor, so `mat.p` and the factors have the valid features only."""
     X = _f32c(X)
     n, P = X.shape
     w = None if feature_weights is None else np.ascontiguousarray(feature_weights, dtype=np.float64)
@@ -272,7 +329,7 @@ def preprocess(ctx: Context, X, center=True, standardize=False, feature_weights=
     n_out, p_out = C.c_int64(), C.c_int64()
     tv = C.c_double()
     h = C.c_void_p()
-    ctx.lib.eofx_ctx_set_layout(ctx.handle, 2 if in_place else int(bool(keep_raw)))
+    ctx.lib.eofx_ctx_set_layout(ctx.handle, _layout_mode(keep_raw, in_place, allow_masked))
     try:
         rc = ctx.lib.eofx_preprocess_f32(ctx.handle, ptr(X), n, P, int(center), int(standardize), ptr(w),
                                          int(check_nans), C.byref(h) if build else None, ptr(mean), ptr(std),
@@ -285,12 +342,14 @@ def preprocess(ctx: Context, X, center=True, standardize=False, feature_weights=
     mat = ResidentMatrix(ctx, h) if build else None
     if mat is not None and (keep_raw or in_place) and hasattr(X, "data_ptr"):
         mat._keepalive = X
+    if mat is not None and mat.masked:
+        mat.set_valid(stats["valid_feature"])
     return mat, stats
 
 
 def fit(ctx: Context, X, k: int, center=True, standardize=False, feature_weights=None, check_nans=True,
         n_oversamples: int = 10, n_iter: int | str = "auto", random_state=None, flip: bool = True, omega=None,
-        want_stats=True, device_out: bool = False, in_place: bool = True):
+        want_stats=True, device_out: bool = False, in_place: bool = True, allow_masked: bool = False):
     """Scaler + Sanitizer + randomized SVD in one engine call (eofx_fit_f32): with the in-place layout the column
     statistics ride on the first pass of the decomposition, so the field is read 2 n_iter + 2 times, not 2 n_iter + 3.
     Same results as `preprocess(..., in_place=True)` followed by `rsvd(...)` (which is what the engine falls back to by
@@ -327,7 +386,7 @@ def fit(ctx: Context, X, k: int, center=True, standardize=False, feature_weights
         V = _host_out((P, k))
     s = np.empty(k, np.float32)
     it = -1 if n_iter == "auto" else int(n_iter)
-    ctx.lib.eofx_ctx_set_layout(ctx.handle, 2 if in_place else 0)
+    ctx.lib.eofx_ctx_set_layout(ctx.handle, _layout_mode(False, in_place, allow_masked))
     try:
         rc = ctx.lib.eofx_fit_f32(ctx.handle, ptr(X), n, P, int(center), int(standardize), ptr(w), int(check_nans), k,
                                   int(n_oversamples), it, ptr(omega), omega.shape[0], int(flip), C.byref(h), ptr(mean),
@@ -341,10 +400,12 @@ def fit(ctx: Context, X, k: int, center=True, standardize=False, feature_weights
         mat._keepalive = X
     stats = dict(mean=mean, std=std, valid_feature=vf.astype(bool), valid_sample=vs.astype(bool),
                  n=n_out.value, p=p_out.value, total_variance=tv.value, fused=bool(fused.value))
-    if mat.n != n or mat.p != P:     # the factors were written densely with the compacted shape
+    if mat.masked:
+        mat.set_valid(stats["valid_feature"])
+    if mat.n != n or mat.p_phys != P:     # the factors were written densely with the compacted shape
         U = U.reshape(-1)[: mat.n * k].reshape(mat.n, k)
-        V = V.reshape(-1)[: mat.p * k].reshape(mat.p, k)
-    return mat, stats, U, s, V
+        V = V.reshape(-1)[: mat.p_phys * k].reshape(mat.p_phys, k)
+    return mat, stats, U, s, mat.compact_rows(V)
 
 
 def fit_info(ctx: Context):
@@ -354,7 +415,7 @@ def fit_info(ctx: Context):
     return dict(fused=bool(info[0]), preprocess_ms=float(info[1]), reason=int(info[2]))
 
 
-def apply(ctx: Context, X, mean, std, feature_weights, valid_feature, check_nans=True, in_place=False):
+def apply(ctx: Context, X, mean, std, feature_weights, valid_feature, check_nans=True, in_place=False, allow_masked=False):
     """Preprocessor.transform on new data with fitted state.  in_place: as in `preprocess` -- nothing is written, the
     projection that follows streams the (staged) field through the fitted map."""
     X = _f32c(X)
@@ -365,7 +426,7 @@ def apply(ctx: Context, X, mean, std, feature_weights, valid_feature, check_nans
     vs = np.empty(n, np.uint8)
     n_out = C.c_int64()
     h = C.c_void_p()
-    ctx.lib.eofx_ctx_set_layout(ctx.handle, 2 if in_place else 0)
+    ctx.lib.eofx_ctx_set_layout(ctx.handle, _layout_mode(False, in_place, allow_masked))
     try:
         rc = ctx.lib.eofx_apply_f32(ctx.handle, ptr(X), n, P, ptr(mean), ptr(std), ptr(w), ptr(vf),
                                     int(check_nans), C.byref(h), ptr(vs), C.byref(n_out))
@@ -375,6 +436,8 @@ def apply(ctx: Context, X, mean, std, feature_weights, valid_feature, check_nans
     mat = ResidentMatrix(ctx, h)
     if in_place and hasattr(X, "data_ptr"):
         mat._keepalive = X
+    if mat.masked:
+        mat.set_valid(vf)
     return mat, vs.astype(bool)
 
 
@@ -389,19 +452,21 @@ def rsvd(ctx: Context, mat: ResidentMatrix, k: int, n_oversamples: int = 10, n_i
     omega = np.ascontiguousarray(omega, dtype=np.float32)
     if omega.shape != (small, k + n_oversamples):
         raise ValueError(f"omega must have shape {(small, k + n_oversamples)}")
+    if mat.masked and mat.p < mat.n:
+        raise NotImplementedError("masked in-place matrix with fewer valid features than samples")   # the engine never builds one
     if device_out:
         torch = _torch()
         U = torch.empty((mat.n, k), dtype=torch.float32, device=f"cuda:{ctx.device}")
-        V = torch.empty((mat.p, k), dtype=torch.float32, device=f"cuda:{ctx.device}")
+        V = torch.empty((mat.p_phys, k), dtype=torch.float32, device=f"cuda:{ctx.device}")
     else:
         U = _host_out((mat.n, k))
-        V = _host_out((mat.p, k))
+        V = _host_out((mat.p_phys, k))
     s = np.empty(k, np.float32)
     it = -1 if n_iter == "auto" else int(n_iter)
     rc = ctx.lib.eofx_rsvd_f32(ctx.handle, mat.handle, k, int(n_oversamples), it, ptr(omega), int(flip),
                                ptr(U), ptr(s), ptr(V))
     raise_for(rc, ctx.handle)
-    return U, s, V
+    return U, s, mat.compact_rows(V)
 
 
 def project(ctx: Context, mat: ResidentMatrix, V) -> np.ndarray:
@@ -411,6 +476,7 @@ def project(ctx: Context, mat: ResidentMatrix, V) -> np.ndarray:
                          "(a different NaN pattern in the new data?)")
     k = V.shape[1]
     out = np.empty((mat.n, k), np.float32)
+    V = mat.scatter_rows(V)
     raise_for(ctx.lib.eofx_project_f32(ctx.handle, mat.handle, ptr(V), k, ptr(out)), ctx.handle)
     return out
 
@@ -431,6 +497,8 @@ def crosscov_rsvd(ctx: Context, x: ResidentMatrix, y: ResidentMatrix, k: int, n_
                   want_tsc: bool = True):
     """Matrix-free rSVD of C = X^T Y/(n-1) -> dict (cpcca.py:168-225 quantities)."""
     k = int(k)
+    if x.masked or y.masked:
+        raise NotImplementedError("cross-covariance of masked in-place matrices (preprocess without allow_masked)")
     small = min(x.p, y.p)
     if omega is None:
         omega = sketch_matrix(small, k + n_oversamples, random_state)
@@ -576,6 +644,8 @@ def hilbert(ctx: Context, mat: ResidentMatrix, padding="exp", decay_factor: floa
     rc = ctx.lib.eofx_hilbert_f32(ctx.handle, mat.handle, int(padding == "exp"), float(decay_factor),
                                   C.byref(hi), C.byref(hr) if want_real else None)
     raise_for(rc, ctx.handle)
+    if mat.masked:
+        raise NotImplementedError("Hilbert transform of a masked in-place matrix (preprocess without allow_masked)")
     return ResidentMatrix(ctx, hi), (ResidentMatrix(ctx, hr) if want_real else None)
 
 
@@ -646,6 +716,8 @@ def vec_dot(ctx: Context, a, b) -> float:
 def resample(ctx: Context, mat: ResidentMatrix, rows, center: bool = True):
     """Bootstrap member of a resident matrix: rows drawn with replacement, re-centred.
     -> (ResidentMatrix, mean[p] float64, total_variance)"""
+    if mat.masked:
+        raise NotImplementedError("resampled copy of a masked in-place matrix (the bootstrapper works on the matrix in place)")
     rows = np.ascontiguousarray(rows, dtype=np.int64)
     mean = np.empty(mat.p, np.float64)
     tv = C.c_double()
@@ -663,9 +735,9 @@ def panel_rownorm(ctx: Context, P, rows: int) -> np.ndarray:
 
 def feature_norms(ctx: Context, mat: ResidentMatrix) -> np.ndarray:
     """sqrt(sum over samples of x^2) per feature of the resident matrix"""
-    out = np.empty(mat.p, np.float64)
+    out = np.empty(mat.p_phys, np.float64)
     raise_for(ctx.lib.eofx_mat_feature_norms_f64(ctx.handle, mat.handle, ptr(out)), ctx.handle)
-    return out
+    return out[mat.valid_index] if mat.masked else out
 
 
 def sample_norms(ctx: Context, mat: ResidentMatrix) -> np.ndarray:
@@ -680,6 +752,8 @@ def rsvd_c64(ctx: Context, A: ResidentMatrix, B: ResidentMatrix, k: int, n_overs
     """complex randomized SVD of Z = A + iB (eofx_rsvd_c64) -> (U[n,k] complex64, s[k] float32, V[p,k] complex64);
     device_out: U and V stay on the device as torch complex64 tensors (V is 8 p k bytes: 166 MB at config 5)"""
     k = int(k)
+    if A.masked or B.masked:
+        raise NotImplementedError("complex rSVD of masked in-place matrices (preprocess without allow_masked)")
     r = min(A.n, A.p)
     if k > r:
         raise ValueError(f"n_modes must be less than or equal to the rank of the dataset (rank = {r}).")

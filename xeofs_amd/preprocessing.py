@@ -62,9 +62,14 @@ class _Field:
 
 
 class Preprocessor:
-    def __init__(self, center=True, standardize=False, use_coslat=False, check_nans=True, ctx=None, in_place=False):
+    def __init__(self, center=True, standardize=False, use_coslat=False, check_nans=True, ctx=None, in_place=False,
+                 masked_ok=False):
         self.center, self.standardize, self.use_coslat, self.check_nans = center, standardize, use_coslat, check_nans
         self.ctx = ctx
+        # masked_ok (with in_place): a field with all-NaN grid points (land / sea mask) stays in place too -- the engine keeps
+        # the masked features as zero columns (layout mode 3) and xeofs_amd.engine compacts the factors; for models whose
+        # every use of the resident matrix goes through engine.rsvd / fit / project / the panel-level ops
+        self.masked_ok = bool(masked_ok) and bool(in_place)
         # in_place: the engine writes no copy of the matrix, the passes of the decomposition stream the (staged) field
         # through the Scaler map (include/eofx.h, layout policy); a layout is built later only if something asks for it
         self.in_place = in_place
@@ -130,7 +135,7 @@ class Preprocessor:
             self.total_variance = mat.sumsq() / (mat.n - 1)
             return mat
         mat, st = engine.preprocess(ctx, M, self.center, self.standardize, self.feature_weights, self.check_nans,
-                                    in_place=self.in_place)
+                                    in_place=self.in_place, allow_masked=self.masked_ok)
         self.mean_, self.std_ = (st["mean"] if self.center else None), (st["std"] if self.standardize else None)
         self.valid_feature, self.valid_sample = st["valid_feature"], st["valid_sample"]
         self.total_variance = st["total_variance"]
@@ -148,12 +153,12 @@ class Preprocessor:
         plan = decomposer.fused_plan(n, P) if self.in_place and ctx.precision[0] == "f16x3" else None
         if plan is None:
             mat, st = engine.preprocess(ctx, M, self.center, self.standardize, self.feature_weights, self.check_nans,
-                                        in_place=self.in_place)
+                                        in_place=self.in_place, allow_masked=self.masked_ok)
         else:
             k, n_over, n_iter = plan
             mat, st, U, s, V = engine.fit(ctx, M, k, self.center, self.standardize, self.feature_weights, self.check_nans,
                                           n_over, n_iter, random_state=decomposer.random_state,
-                                          flip=bool(decomposer.flip_signs), omega=omega)
+                                          flip=bool(decomposer.flip_signs), omega=omega, allow_masked=self.masked_ok)
         self.mean_, self.std_ = (st["mean"] if self.center else None), (st["std"] if self.standardize else None)
         self.valid_feature, self.valid_sample = st["valid_feature"], st["valid_sample"]
         self.total_variance = st["total_variance"]
@@ -168,7 +173,7 @@ class Preprocessor:
         fields = self._fields_like(X)
         M, _ = self._stack(fields, None)
         mat, vs = engine.apply(ctx, M, self.mean_, self.std_, self.feature_weights, self.valid_feature, self.check_nans,
-                               in_place=self.in_place)
+                               in_place=self.in_place, allow_masked=self.masked_ok)
         return mat, fields, vs
 
     def _fields_like(self, X):

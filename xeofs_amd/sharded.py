@@ -102,6 +102,8 @@ class HipPanelOps:
     def import_panel(self, src, side):
         rows_pad = self.n_pad if side == "n" else self.p_pad
         L = self.e.panel_width(src.shape[1])
+        if side == "p":
+            src = self.mat.scatter_rows(src)      # masked in-place matrix: zero rows at the masked features
         return self.e.panel_import(self.ctx, src, rows_pad, L)
 
     def tmul(self, Zn, final=False):   # feature panel = X_g^T Zn
@@ -125,10 +127,17 @@ class HipPanelOps:
         Md = M if torch.is_tensor(M) else torch.as_tensor(np.ascontiguousarray(M, dtype=np.float64), device=P.device)
         return self.e.panel_matmul(self.ctx, P, Md)
 
+    def _feature_side(self, P, rows):
+        return self.mat.masked and P.shape[0] == self.p_pad and rows == self.p
+
     def colminmax(self, P, rows):
+        if self._feature_side(P, rows):
+            rows = self.mat.p_phys               # zero rows cannot change which of |max|, |min| is larger
         return self.e.panel_colminmax(self.ctx, P, rows)
 
     def export(self, P, rows, k, sign=None, device_out=False):
+        if self._feature_side(P, rows):          # masked in-place matrix: drop the rows of the masked features
+            return self.mat.compact_rows(self.e.panel_export(self.ctx, P, self.mat.p_phys, k, sign, device_out))
         return self.e.panel_export(self.ctx, P, rows, k, sign, device_out)
 
     def eigh(self, G):

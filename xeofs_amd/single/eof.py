@@ -30,7 +30,10 @@ class EOF(Deferred):
         self._decomposer_kwargs = dict(n_modes=n_modes, solver=solver, random_state=random_state, compute=compute,
                                        component_dim_name="mode", solver_kwargs=solver_kwargs, **kwargs)
         self.ctx = None
-        self.preprocessor = Preprocessor(center, standardize, use_coslat, check_nans, in_place=True)   # rSVD streams the field
+        # rSVD streams the field where it lies; for the plain EOF model (every later use of the matrix goes through
+        # engine.project / the panel ops) a land / sea mask stays in place as well (zero columns, layout mode 3)
+        self.preprocessor = Preprocessor(center, standardize, use_coslat, check_nans, in_place=True,
+                                         masked_ok=type(self).__name__ in ("EOF", "EOFBootstrapper"))
         # attrs as the reference stores them (base_model.py:38-46): bools/None stringified
         self.attrs = {"model": "EOF analysis", "software": "xeofs_amd", "version": __version__,
                       "date": datetime.datetime.now().strftime("%Y-%m-%d %H:%M:%S")}
