@@ -215,8 +215,16 @@ def leg_configs(ctx, device, orc, layout_kw, quick=False):
     pub()
     tmin, tmean, m = timed(pub, 3)            # the reference script reports the best of 3 repeats too
     sp = np.asarray(m.singular_values().values, dtype=np.float64)
-    # i.i.d. N(0,1): the leading singular values sit at the Marchenko-Pastur edge sqrt(n) + sqrt(p) (within 1 %)
+    # i.i.d. N(0,1) has no spectral gap: the exact leading singular values sit at the Marchenko-Pastur edge sqrt(n) + sqrt(p)
+    # and 7 power iterations of a 12-column sketch stop a few per cent below it (scikit-learn's result is the same: the
+    # oracle comparison on a tenth of the grid below); the check here is only that the value is a sane bulk-edge estimate
     edge = np.sqrt(n) + np.sqrt(nf)
+    ns_, nf_ = 2000, 20000
+    sub = np.ascontiguousarray(host.reshape(n, nf)[:ns_, :nf_])
+    msub = xe.single.EOF(n_modes=2, random_state=5).fit(xe.DataArray(sub.reshape(ns_, nf_ // 10, 10), dims=("time", "a", "b")), dim="time")
+    rsub = orc.eof_fit(sub.astype(np.float64), 2, random_state=5)
+    rel_sub = float(np.max(np.abs(np.asarray(msub.singular_values().values, dtype=np.float64) - rsub["norms"]) / rsub["norms"]))
+    del msub, sub, rsub
     out["published"] = {"what": "xe.single.EOF(n_modes=2, random_state=5).fit on 10000x(10000x10) standard normal fp32 handed "
                                 "over as a HOST array (whole fit, upload included) = the reference's published grid point "
                                 "(docs/perf/xeofs_timings.py:18-57)",
@@ -224,9 +232,10 @@ def leg_configs(ctx, device, orc, layout_kw, quick=False):
                         "reference_hardware": "a standard laptop (docs/content/user_guide/core_functionalities/efficient.rst:8)",
                         "speedup": round(PUBLISHED_FIT_S / (tmin * 1e-3), 1),
                         "parity": {"s": [float(x) for x in sp], "marchenko_pastur_edge": float(edge),
-                                   "s0_over_edge": float(sp[0] / edge)}}
-    if not (0.97 <= sp[0] / edge <= 1.01):
-        gate.append(f"published workload: s0 / (sqrt(n)+sqrt(p)) = {sp[0] / edge:.4f}")
+                                   "s0_over_edge": float(sp[0] / edge),
+                                   "sv_relerr_vs_f64_oracle_on_2000x20000_corner": rel_sub}}
+    if not (0.9 <= sp[0] / edge <= 1.001) or not rel_sub <= 1e-5:
+        gate.append(f"published workload: s0 / (sqrt(n)+sqrt(p)) = {sp[0] / edge:.4f}, corner vs oracle {rel_sub:.2e}")
     del m, da, host
     torch.cuda.empty_cache()
 
@@ -255,10 +264,12 @@ def leg_configs(ctx, device, orc, layout_kw, quick=False):
         t, A, B, U, s, V = c5()
         alg5 = 16 * n * P * 8.0
         # size-independent properties: orthonormal U, orthonormal V, and s_j = |Z v_j| through one more pass
-        UhU = (U.conj().T @ U)
+        U128, V128 = U.to(torch.complex128), V.to(torch.complex128)      # float32 sums over 1M rows would be the error
+        UhU = (U128.conj().T @ U128)
         orth_u = float((UhU - torch.eye(k, device=device, dtype=UhU.dtype)).abs().max())
-        VhV = (V.conj().T @ V)
+        VhV = (V128.conj().T @ V128)
         orth_v = float((VhV - torch.eye(k, device=device, dtype=VhV.dtype)).abs().max())
+        del U128, V128
         L = 64
         Pn = torch.zeros((A.p_pad, L), device=device, dtype=torch.float32)
         Pn[:P, :k] = V.real

@@ -291,6 +291,13 @@ int eofx_mat_sample_norms_f64(eofx_ctx *ctx, const eofx_mat *m, double *out);
  * receives the per-feature mean that was removed, total_variance the ddof=1 variance sum.          */
 int eofx_resample_f32(eofx_ctx *ctx, const eofx_mat *src, const int64_t *rows, int64_t n_rows, int center,
                       eofx_mat **out, double *mean, double *total_variance);
+/* A bootstrap member as an operator on the RESIDENT matrix (no resampled copy): rows drawn with replacement and
+ * re-centred are X_b = H X, H = G - 1 c^T / n, so the member's two products are X^T (H^T Z) and H (X Y).  This applies H
+ * (transpose = 0: out[i] = P[idx[i]] - mean of the gathered rows) or H^T (transpose = 1: out[r] = sum of the draws of row
+ * r - c_r * mean-like term) to an n x L sample-side panel; idx [n] = the draw, order [n] = its stable argsort,
+ * rowptr [n + 1] = segment starts of `order` per source row (device int64).  Float64 sums in draw order: reproducible. */
+int eofx_panel_bootstrap_f32(eofx_ctx *ctx, const float *P_in, int64_t n, int64_t rows_pad, int L, const int64_t *idx,
+                             const int64_t *order, const int64_t *rowptr, int transpose, float *P_out);
 /* Gram matrix of a resident matrix (float32, device): side 0 = sample space G[n_pad x n_pad] = X X^T,
  * side 1 = feature space G[p_pad x p_pad] = X^T X (rows/columns beyond n / p are zero).  Used for
  * (a) the total squared covariance sum(|X^T Y|^2) = <X X^T, Y Y^T> (cross/cpcca.py:991-1000) when X and

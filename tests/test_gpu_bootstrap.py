@@ -64,10 +64,10 @@ def test_eof_bootstrapper_vs_oracle(ctx):
     assert (bs.explained_variance_ratio().values <= 1).all()
 
 
-def test_bootstrap_member_operator(ctx, monkeypatch):
+def test_bootstrap_member_operator(ctx):
     """`BootstrapOps`: the member X_b = H X through panel products on the ORIGINAL matrix -- against the resampled,
-    re-centred matrix itself, for both renderings of H (dense GEMM up to DENSE_MAX samples, sorted segment sums beyond),
-    on an in-place matrix (no layout is built), plus the member's total variance from the row norms."""
+    re-centred matrix itself; H / H^T are the engine's gather / segment-sum kernels (`eofx_panel_bootstrap_f32`, no
+    library GEMM), on an in-place matrix (no layout is built), plus the member's total variance from the row norms."""
     import torch
     from xeofs_amd import engine
     from xeofs_amd.validation.bootstrapper import BootstrapOps
@@ -82,10 +82,15 @@ def test_bootstrap_member_operator(ctx, monkeypatch):
     Z = torch.zeros((mat.n_pad, 32), device="cuda"); Z[:n] = torch.randn((n, 32), device="cuda")
     Y = torch.zeros((mat.p_pad, 32), device="cuda"); Y[:p] = torch.randn((p, 32), device="cuda")
     outs = []
-    for dense_max in (BootstrapOps.DENSE_MAX, 0):
-        monkeypatch.setattr(BootstrapOps, "DENSE_MAX", dense_max)
+    for rep in range(2):
         ops = BootstrapOps(ctx, mat, idx)
-        assert (ops.H is not None) == (dense_max > 0)
+        # H and H^T on their own against dense float64 algebra
+        Hd = -np.bincount(idx, minlength=n)[None, :].repeat(n, 0) / n
+        Hd[np.arange(n), idx] += 1.0
+        Zh = Z[:n].double().cpu().numpy()
+        assert np.abs(ops._h(Z)[:n].double().cpu().numpy() - Hd @ Zh).max() <= 1e-6 * np.abs(Zh).max()
+        assert np.abs(ops._ht(Z)[:n].double().cpu().numpy() - Hd.T @ Zh).max() <= 1e-6 * np.abs(Zh).max()
+        assert not bool(ops._h(Z)[n:].any()) and not bool(ops._ht(Z)[n:].any())      # padding rows stay zero
         t = ops.tmul(Z)[:p].double().cpu().numpy()
         m = ops.mul(Y)[:n].double().cpu().numpy()
         want_t = Xb.T @ Z[:n].double().cpu().numpy()
@@ -96,5 +101,5 @@ def test_bootstrap_member_operator(ctx, monkeypatch):
         tv = (c @ engine.sample_norms(ctx, mat) ** 2 - n * ops.mean_sumsq()) / (n - 1)
         assert np.isclose(tv, (Xb ** 2).sum() / (n - 1), rtol=1e-5)
         outs.append((t, m))
-    assert np.allclose(outs[0][0], outs[1][0], rtol=0, atol=2e-5 * np.abs(outs[0][0]).max())
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])     # bitwise reproducible
     assert mat.layout()[0] in (False, 0)          # still in place: no layout was materialised

@@ -72,6 +72,7 @@ SIGNATURES = {
     "eofx_panel_rownorm_f64": (_int, [_vp, _vp, _i64, _int, _vp]),
     "eofx_mat_feature_norms_f64": (_int, [_vp, _vp, _vp]),
     "eofx_mat_sample_norms_f64": (_int, [_vp, _vp, _vp]),
+    "eofx_panel_bootstrap_f32": (_int, [_vp, _vp, _i64, _i64, _int, _vp, _vp, _vp, _int, _vp]),
     "eofx_resample_f32": (_int, [_vp, _vp, _vp, _i64, _int, C.POINTER(_vp), _vp, _pd]),
     "eofx_mat_gram_f32": (_int, [_vp, _vp, _int, _vp]),
     "eofx_mat_cross_gram_f32": (_int, [_vp, _vp, _vp, _int, _vp]),

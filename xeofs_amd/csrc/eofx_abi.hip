@@ -471,7 +471,9 @@ struct AtbPlan {
 };
 // split-K factor from a small cost model: 512 resident workgroups, ~10 GB/s of A per
 // workgroup slot, partial-sum traffic at ~4 TB/s.
-static bool atb_wide(int L) { return L >= 256; }   // 128-column tiles (atb_f16_kernel<4>), one workgroup per CU
+// 128-column tiles (atb_f16_kernel<4>, one workgroup per CU): the wide products (Gram matrices, PCA panels) and the
+// two-matrix form of a 128-column complex panel (33-64 complex columns: Re and Im are then streamed ONCE per pass)
+static bool atb_wide(int L, bool two_matrix = false) { return L >= 256 || (two_matrix && L >= 128); }
 static AtbPlan atb_plan(int64_t M, int64_t K, int L, bool wide = false) {
   const int bx = (int)(M / ATB_BM);
   const int bz = wide ? (L + 127) / 128 : (L + 63) / 64;
@@ -523,7 +525,7 @@ static AtbPlan axb_plan(int64_t rows_pad, int64_t K) {
 }
 static size_t atb_scratch_bytes(int64_t M, int64_t K, int L) {
   const AtbPlan pl = atb_plan(M, K, L), plw = atb_plan(M, K, L, true);
-  const int smax = std::max(pl.S, atb_wide(L) ? plw.S : 1);
+  const int smax = std::max(pl.S, atb_wide(L, true) ? plw.S : 1);
   size_t b = smax > 1 ? (size_t)smax * M * L * (sizeof(float) + sizeof(double)) + 4096 : 4096;   // f32 or f64 partials
   const AtbPlan px = axb_plan(M, round_up(K, AXB_KG));      // in case M is the sample side of an in-place matrix
   if (px.S > 1) b = std::max(b, (size_t)px.S * M * round_up(L, 64) * sizeof(float) + 4096);
@@ -581,7 +583,7 @@ static int launch_atb(eofx_ctx* ctx, const float* A, int64_t lda, int64_t K, int
                    (long long)K, L);
   const int bx = (int)(M / ATB_BM);
   // wide products (Gram matrices, PCA panels) in 128-column tiles of the split-fp16 kernel, then 64 / 32-column rests
-  const bool wide = atb_wide(L) && prec == EOFX_PREC_F16X3 && !A2;
+  const bool wide = atb_wide(L, A2 != nullptr) && prec == EOFX_PREC_F16X3;
   if (sym && !(wide && !aff && L == M)) sym = 0;
   const int n4 = wide ? L / 128 : 0, cb4 = 128 * n4;
   const int nfull = (L - cb4) / 64, rem = (L - cb4) % 64;
@@ -2187,6 +2189,38 @@ extern "C" int eofx_fit_f32(eofx_ctx* ctx, const float* X, int64_t n, int64_t P,
     return rc;
   }
   *out = m;
+  return EOFX_OK;
+}
+
+// H W (transpose = 0) / H^T Z (transpose = 1) of a bootstrap member on an n x L sample-side panel (device pointers):
+// idx [n] the draw, order [n] = stable argsort of idx, rowptr [n + 1] = first position in `order` of every source row
+// (all int64, device).  See the kernels in eofx_fit.hpp; P_in and P_out are [rows_pad x L] panels and must differ.
+extern "C" int eofx_panel_bootstrap_f32(eofx_ctx* ctx, const float* P_in, int64_t n, int64_t rows_pad, int L,
+                                        const int64_t* idx, const int64_t* order, const int64_t* rowptr, int transpose,
+                                        float* P_out) {
+  if (!ctx || !P_in || !P_out || P_in == P_out || !idx || !order || !rowptr || n <= 0 || rows_pad < n || L <= 0 || L % 4)
+    return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  CHK(set_device(ctx));
+  const int NPART = 64;
+  CHK(arena_reserve(ctx, (size_t)(NPART + 1) * L * 8 + 4096));
+  ArenaScope scope(ctx);
+  ARENA(double, wpart, (size_t)NPART * L);
+  ARENA(double, wsum, L);
+  const int blocks = (int)std::min<int64_t>((rows_pad * (L / 4) + 255) / 256, 4096);
+  if (transpose) {
+    hipLaunchKernelGGL(bst_segsum_kernel, dim3(blocks), dim3(256), 0, ctx->stream, P_in, order, rowptr, n, rows_pad, L, P_out);
+    KCHK();
+    hipLaunchKernelGGL(panel_colsum_part_kernel, dim3(NPART), dim3(256), 0, ctx->stream, P_in, n, L, wpart);     // sum_i Z[i]
+  } else {
+    hipLaunchKernelGGL(bst_gather_kernel, dim3(blocks), dim3(256), 0, ctx->stream, P_in, idx, n, rows_pad, L, P_out);
+    KCHK();
+    hipLaunchKernelGGL(panel_colsum_part_kernel, dim3(NPART), dim3(256), 0, ctx->stream, P_out, n, L, wpart);    // c^T W
+  }
+  KCHK();
+  hipLaunchKernelGGL(panel_colsum_final_kernel, dim3(1), dim3(256), 0, ctx->stream, wpart, NPART, L, wsum);
+  KCHK();
+  hipLaunchKernelGGL(bst_rankone_kernel, dim3(blocks), dim3(256), 0, ctx->stream, P_out, wsum, transpose ? rowptr : (const int64_t*)nullptr, n, L);
+  KCHK();
   return EOFX_OK;
 }
 

@@ -460,4 +460,64 @@ __global__ __launch_bounds__(256) void fit_reduce_kernel(const float* part, floa
   }
 }
 
+// ---------------------------------------------------------------------------------
+// Bootstrap member as an operator (validation/bootstrapper.py:78-91): rows drawn with replacement and re-centred are
+// X_b = H X with H = G - 1 c^T / n (G the row selector of the draw idx, c its counts), so the member's products are the
+// original matrix' products with the small sample-side panel transformed:
+//   H   W : out[i] = W[idx[i]] - (sum_i W[idx[i]]) / n                         (bst_gather_kernel, then the column sums)
+//   H^T Z : out[r] = sum_{i : idx[i] = r} Z[i] - c_r (sum_i Z[i]) / n          (bst_segsum_kernel over the sorted draw)
+// Float64 sums in a fixed order (segments are walked in draw order): a member is reproducible bit for bit.  These two
+// kernels replace a dense n x n library GEMM per pass.
+// ---------------------------------------------------------------------------------
+// one thread per (row, 4 columns): out[i, :] = P[idx[i], :] for i < n, 0 for the padding rows
+__global__ __launch_bounds__(256) void bst_gather_kernel(const float* __restrict__ P, const int64_t* __restrict__ idx,
+                                                          int64_t n, int64_t rows_pad, int L, float* __restrict__ out) {
+  const int l4 = L / 4;
+  const int64_t total = rows_pad * l4;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int64_t i = t / l4;
+    const int q = (int)(t - i * l4);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (i < n) v = reinterpret_cast<const f32x4*>(P)[idx[i] * l4 + q];
+    reinterpret_cast<f32x4*>(out)[t] = v;
+  }
+}
+// out[r, :] = sum over the draws i in [rowptr[r], rowptr[r+1]) of Z[order[i], :]  (float64, draw order) for r < n
+__global__ __launch_bounds__(256) void bst_segsum_kernel(const float* __restrict__ Z, const int64_t* __restrict__ order,
+                                                          const int64_t* __restrict__ rowptr, int64_t n, int64_t rows_pad,
+                                                          int L, float* __restrict__ out) {
+  const int l4 = L / 4;
+  const int64_t total = rows_pad * l4;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int64_t r = t / l4;
+    const int q = (int)(t - r * l4);
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    if (r < n)
+      for (int64_t i = rowptr[r]; i < rowptr[r + 1]; ++i) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(Z)[order[i] * l4 + q];
+        s0 += v[0];
+        s1 += v[1];
+        s2 += v[2];
+        s3 += v[3];
+      }
+    reinterpret_cast<f32x4*>(out)[t] = f32x4{(float)s0, (float)s1, (float)s2, (float)s3};
+  }
+}
+// out[r, :] -= w_r * colsum[:] / n for r < n, with w_r = rowptr[r+1] - rowptr[r] (the draw count c_r) or 1 (rowptr null)
+__global__ __launch_bounds__(256) void bst_rankone_kernel(float* __restrict__ out, const double* __restrict__ colsum,
+                                                           const int64_t* __restrict__ rowptr, int64_t n, int L) {
+  const int l4 = L / 4;
+  const int64_t total = n * l4;
+  const double inv = 1.0 / (double)n;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int64_t r = t / l4;
+    const int c = (int)(t - r * l4) * 4;
+    const double w = rowptr ? (double)(rowptr[r + 1] - rowptr[r]) * inv : inv;
+    f32x4 v = reinterpret_cast<f32x4*>(out)[t];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (float)((double)v[e] - w * colsum[c + e]);
+    reinterpret_cast<f32x4*>(out)[t] = v;
+  }
+}
+
 }  // namespace eofx

@@ -727,6 +727,16 @@ def resample(ctx: Context, mat: ResidentMatrix, rows, center: bool = True):
     return ResidentMatrix(ctx, h), mean, tv.value
 
 
+def panel_bootstrap(ctx: Context, P, n: int, idx, order, rowptr, transpose: bool):
+    """H P (transpose False) or H^T P (True) of a bootstrap member on a sample-side panel (eofx_panel_bootstrap_f32);
+    idx / order / rowptr: int64 device tensors describing the draw"""
+    torch = _torch()
+    out = torch.empty_like(P)
+    raise_for(ctx.lib.eofx_panel_bootstrap_f32(ctx.handle, ptr(P), int(n), P.shape[0], P.shape[1], ptr(idx), ptr(order),
+                                               ptr(rowptr), int(bool(transpose)), ptr(out)), ctx.handle)
+    return out
+
+
 def panel_rownorm(ctx: Context, P, rows: int) -> np.ndarray:
     out = np.empty(rows, np.float64)
     raise_for(ctx.lib.eofx_panel_rownorm_f64(ctx.handle, ptr(P), rows, P.shape[1], ptr(out)), ctx.handle)

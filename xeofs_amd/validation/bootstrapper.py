@@ -39,57 +39,29 @@ class _Solo:
 
 class BootstrapOps(HipPanelOps):
     """Panel products of the bootstrap member X_b = H X on the resident X (H = G - 1 c^T / n, see the module docstring).
-    Sample-side panels are indexed by draw; everything added here is float64 arithmetic on n x L panels in a fixed
-    order (sorted segment sums, no atomics), so a member is reproducible bit for bit."""
-
-    DENSE_MAX = 24000       # up to this many samples H is held as a dense float32 matrix (2.3 GB at the limit)
+    Sample-side panels are indexed by draw; H and H^T are applied by two small HIP kernels (`eofx_panel_bootstrap_f32`:
+    row gather / segment sums over the sorted draw + a rank-one term, float64 sums in draw order, no atomics), so a member
+    is reproducible bit for bit and its trace holds no library GEMM."""
 
     def __init__(self, ctx, mat, idx):
         super().__init__(ctx, mat)
         torch = engine._torch()
         dev = f"cuda:{ctx.device}"
         n = mat.n
-        self.idx = torch.as_tensor(np.ascontiguousarray(idx, dtype=np.int64), device=dev)
-        self.counts = torch.bincount(self.idx, minlength=n).double()
-        self.H = None
-        if n <= self.DENSE_MAX:
-            # H = G - 1 c^T / n as a dense n x n float32 matrix: both transformations are one library GEMM on an
-            # n x L panel (0.2 ms at n = 10 000); entries 1 - c/n, -c/n are rounded once, sums have <= max(c) + 1 terms
-            H = (-self.counts / n).float().repeat(n, 1)
-            H[torch.arange(n, device=dev), self.idx] += 1.0
-            self.H = H
-        else:
-            self.order = torch.argsort(self.idx, stable=True)
-            uniq, cnt = torch.unique_consecutive(self.idx[self.order], return_counts=True)
-            self.uniq, self.ends = uniq, torch.cumsum(cnt, 0) - 1
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
+        order = np.argsort(idx, kind="stable").astype(np.int64)       # the draws of every source row, in draw order
+        counts = np.bincount(idx, minlength=n)
+        rowptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        self.idx = torch.as_tensor(idx, device=dev)
+        self.order = torch.as_tensor(order, device=dev)
+        self.rowptr = torch.as_tensor(rowptr, device=dev)
+        self.counts = torch.as_tensor(counts, device=dev).double()
 
-    def _ht(self, Zn):            # H^T Z = G^T Z - c (1^T Z) / n
-        torch = engine._torch()
-        n = self.n
-        out = torch.zeros_like(Zn)
-        if self.H is not None:
-            torch.matmul(self.H.T, Zn[:n], out=out[:n])
-            return out
-        Zd = Zn[:n].double()
-        cs = torch.cumsum(Zd[self.order], 0)                  # sorted segment sums: fixed order, no atomics
-        seg = cs[self.ends].clone()
-        seg[1:] -= cs[self.ends[:-1]]
-        acc = torch.zeros((n, Zn.shape[1]), dtype=torch.float64, device=Zn.device)
-        acc[self.uniq] = seg
-        acc -= self.counts[:, None] * (Zd.sum(0) / n)
-        out[:n] = acc.float()
-        return out
+    def _ht(self, Zn):            # H^T Z = G^T Z - c (1^T Z) / n : segment sums over the sorted draw + a rank-one term
+        return engine.panel_bootstrap(self.ctx, Zn, self.n, self.idx, self.order, self.rowptr, True)
 
-    def _h(self, Wn):             # H W = W[idx] - 1 (c^T W) / n
-        torch = engine._torch()
-        n = self.n
-        out = torch.zeros_like(Wn)
-        if self.H is not None:
-            torch.matmul(self.H, Wn[:n], out=out[:n])
-            return out
-        Wd = Wn[:n].double()
-        out[:n] = (Wd[self.idx] - (self.counts @ Wd) / n).float()
-        return out
+    def _h(self, Wn):             # H W = W[idx] - 1 (c^T W) / n : a row gather + a rank-one term
+        return engine.panel_bootstrap(self.ctx, Wn, self.n, self.idx, self.order, self.rowptr, False)
 
     def tmul(self, Zn, final=False):
         return super().tmul(self._ht(Zn), final)
