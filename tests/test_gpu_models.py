@@ -246,6 +246,22 @@ def test_compute_false_defers_the_fit(ctx):
     assert c.is_deferred
     ce = xe.cross.MCA(n_modes=3, random_state=1).fit(lazy, lz2, "time")
     assert np.allclose(c.singular_values().values, ce.singular_values().values, rtol=1e-6) and not c.is_deferred
+    # consumers that read the fitted state before any accessor run the pending fit themselves
+    m4 = xe.single.EOF(n_modes=5, random_state=3, compute=False).fit(lazy, "time")
+    assert m4.is_deferred
+    assert np.allclose(m4.transform(lazy).values, eager.transform(lazy).values, atol=1e-5) and not m4.is_deferred
+    m5 = xe.single.EOF(n_modes=5, random_state=3, compute=False).fit(lazy, "time")
+    r5 = xe.single.EOFRotator(n_modes=3).fit(m5)
+    re = xe.single.EOFRotator(n_modes=3).fit(eager)
+    assert not m5.is_deferred and np.array_equal(r5.components().values, re.components().values)
+    m6 = xe.single.EOF(n_modes=5, random_state=3, compute=False).fit(lazy, "time")
+    b6 = xe.validation.EOFBootstrapper(n_bootstraps=2, seed=1).fit(m6, random_state=0)
+    be = xe.validation.EOFBootstrapper(n_bootstraps=2, seed=1).fit(eager, random_state=0)
+    assert not m6.is_deferred and np.array_equal(b6.explained_variance().values, be.explained_variance().values)
+    c2 = xe.cross.MCA(n_modes=3, random_state=1, compute=False).fit(lazy, lz2, "time")
+    t2 = c2.transform(lazy, lz2)
+    te = ce.transform(lazy, lz2)
+    assert not c2.is_deferred and np.allclose(t2[0].values, te[0].values, atol=1e-5)
 
 
 def test_dataset_in_dataset_out(ctx):

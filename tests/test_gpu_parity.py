@@ -123,11 +123,9 @@ def test_preprocess_vs_oracle(ctx, center, standardize, weights, nan_kind):
     assert np.array_equal(st["valid_sample"], ref["valid_sample"])
     got = mat.download()
     assert got.shape == ref["X"].shape
-    scale = np.abs(ref["X"]).max()
-    # float32 statistics in the reference (numpy nanmean on float32) vs float64 here: the
-    # difference is bounded by float32 rounding of the mean, ~1e-7 * |mean| / std-scale
-    tol = 4e-5 if not standardize else 2e-3
-    assert np.abs(got - ref["X"]).max() <= tol * max(scale, 1.0)
+    # `ref` ran on the float32 field (numpy nanmean / nanstd in float32): its own statistics carry eps32 * |mean| / std of
+    # rounding (250 / 0.1-ish here), so it only pins masks and shapes; the VALUES are gated against the float64-statistics
+    # oracle below -- the arithmetic xeofs itself runs (it promotes the field, utils/xarray_utils.py:78-100) -- at 2e-6
     vf = ref["valid_feature"]
     if center:
         assert np.allclose(st["mean"][vf], ref["mean"][vf], rtol=2e-6)

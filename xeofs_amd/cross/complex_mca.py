@@ -70,11 +70,13 @@ def _part32(vals, imag):
     return out
 
 
-def _leading_svd_device(C, k, device, block=24, max_iter=80, tol=1e-12):
+def _leading_svd_device(C, k, device, block=24, max_iter=80, tol=1e-10):
     """k leading singular triplets of a dense complex matrix (hundreds x hundreds, float64) by block power iteration on
     the device: each step is two complex GEMMs and a QR of a (k + block)-column panel, iterated until the residuals
-    ||C^H u - s v|| of the k wanted triplets are below tol * s_1 -- to the accuracy of the dense SVD it replaces
-    (0.6 s through rocSOLVER at 1500 x 1500), which remains the fallback if the iteration has not converged."""
+    ||C v - s u|| of the k wanted triplets are below tol * s_1 -- to the accuracy of the dense SVD it replaces
+    (0.6 s through rocSOLVER at 1500 x 1500), which remains the fallback if the iteration has not converged.
+    (The OTHER residual, ||C^H u - s v||, vanishes by construction -- V and s come from the factorisation of C^H Y
+    itself -- and says nothing about convergence: ADVICE r02.)"""
     torch = engine._torch()
     dev = f"cuda:{device}"
     Cd = torch.as_tensor(C, device=dev)
@@ -93,7 +95,7 @@ def _leading_svd_device(C, k, device, block=24, max_iter=80, tol=1e-12):
             Ub, sb, Vbh = torch.linalg.svd(R.conj().T, full_matrices=False)    # Y^H C = R^H Q^H
             U = Y @ Ub[:, :k]
             V = Q @ Vbh.conj().T[:, :k]
-            res = torch.linalg.norm(CH @ U - V * sb[:k], dim=0).max()
+            res = torch.linalg.norm(Cd @ V - U * sb[:k], dim=0).max()
             if float(res) <= tol * float(sb[0]):
                 return U.cpu().numpy(), sb[:k].cpu().numpy(), V.conj().T.cpu().numpy()
     out = torch.linalg.svd(Cd, full_matrices=False)
@@ -130,6 +132,8 @@ class ComplexCPCCA(Deferred):
                  feature_name="feature", solver: str = "auto", random_state=None, solver_kwargs: dict = {}, **kwargs):
         sanity_check_n_modes(n_modes)
         self.alpha = [float(a) for a in _pair(alpha)]
+        if any(a < 0 for a in self.alpha):       # preprocessing/whitener.py:63-66
+            raise ValueError("`alpha` must be greater than or equal to 0")
         if solver not in ("auto", "full", "randomized"):
             raise ValueError(f"Unrecognized solver '{solver}'. Valid options are 'auto', 'full', and 'randomized'.")
         self.n_modes = n_modes
@@ -218,7 +222,7 @@ class ComplexCPCCA(Deferred):
         self.T, self.Tinv, Sw = [None, None], [None, None], []
         for i, fld in enumerate((fx, fy)):
             S = fld.S
-            if not np.isclose(self.alpha[i], 1.0):
+            if not (1.0 - self.alpha[i]) < np.finfo(np.float64).eps:     # whitener.py:46-60: alpha >= 1 is the identity
                 n_, m_ = S.shape
                 if n_ < m_:                                          # whitener.py:101-104
                     warnings.warn(f"The number of samples ({n_}) is smaller than the number of features ({m_}), leading to "
@@ -436,6 +440,7 @@ class ComplexCPCCARotator:
 
     def fit(self, model):
         """cpcca_rotator.py:122-263 (+ the post-compute sort by squared covariance) with complex loadings"""
+        getattr(model, "compute", lambda: None)()      # a deferred fit runs now: ctx / preprocessor / data are read below
         from .. import rotation
 
         torch = engine._torch()

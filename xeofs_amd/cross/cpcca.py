@@ -279,6 +279,7 @@ class CPCCA(Deferred):
 
     def transform(self, X=None, Y=None, normalized: bool = False):
         """base_model_cross_set.py:323-374 + cpcca.py:227-252."""
+        self.compute()          # a deferred fit (compute=False on a lazy input) runs now: the fitted state is needed
         if X is None and Y is None:
             raise ValueError("Either X or Y must be provided.")
         outs = []
@@ -294,6 +295,7 @@ class CPCCA(Deferred):
 
     def predict(self, X):
         """base_model_cross_set.py:427-449 + cpcca.py:273-302: pseudo scores of Y from new X."""
+        self.compute()          # a deferred fit (compute=False on a lazy input) runs now: the fitted state is needed
         proj, fields, vs = self._project(1, X)
         Rx, Ry = self.data["scores1"].astype(np.float64), self.data["scores2"].astype(np.float64)
         G = Rx.T @ Ry / np.linalg.norm(Rx, axis=0) ** 2
@@ -302,6 +304,7 @@ class CPCCA(Deferred):
 
     def inverse_transform(self, X=None, Y=None):
         """base_model_cross_set.py:376-425 + cpcca.py:254-271: scores (with a 'mode' dimension) back to the fields."""
+        self.compute()          # a deferred fit (compute=False on a lazy input) runs now: the fitted state is needed
         if X is None and Y is None:
             raise ValueError("Either X or Y must be provided.")
         outs = []

@@ -40,6 +40,7 @@ class CPCCARotator:
 
     def fit(self, model):
         """cpcca_rotator.py:122-263 (+ the post-compute sort by squared covariance)."""
+        getattr(model, "compute", lambda: None)()      # a deferred fit runs now: ctx / preprocessor / data are read below
         self.model = model
         self.ctx = model.ctx
         self.preprocessor1, self.preprocessor2 = model.preprocessor1, model.preprocessor2

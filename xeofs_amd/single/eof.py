@@ -98,6 +98,7 @@ class EOF(Deferred):
     # ------------------------------------------------------------------ transform / inverse
     def transform(self, X, normalized: bool = False):
         """base_model_single_set.py:180-203 + eof.py:123-132: preprocess with the fitted state, X V."""
+        self.compute()          # a deferred fit (compute=False on a lazy input) runs now: the fitted state is needed
         mat, fields, vs = self.preprocessor.transform(X)
         proj = engine.project(self.ctx, mat, self.data["components"])
         mat.free()
@@ -137,6 +138,7 @@ class EOF(Deferred):
 
     def inverse_transform(self, scores, normalized: bool = False):
         """base_model_single_set.py:205-286 + eof.py:134-156: Xhat = scores . conj(V)^T, then un-scale."""
+        self.compute()          # a deferred fit (compute=False on a lazy input) runs now: the fitted state is needed
         S, modes, vs, fields = self._parse_scores(scores, normalized, np.float32)
         V = np.ascontiguousarray(self.data["components"][:, modes - 1])
         rec = engine.reconstruct(self.ctx, S, V)

@@ -36,6 +36,7 @@ class EOFRotator(EOF):
     # ------------------------------------------------------------------ fit
     def fit(self, model):
         """eof_rotator.py:103-205 (+ `_sort_by_variance`, :207-218; the engine is eager)."""
+        getattr(model, "compute", lambda: None)()      # a deferred fit runs now: ctx / preprocessor / data are read below
         self.ctx = model.ctx
         self.preprocessor = model.preprocessor
         self.sample_name, self.feature_name = model.sample_name, model.feature_name

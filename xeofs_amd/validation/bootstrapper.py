@@ -93,6 +93,7 @@ class EOFBootstrapper(EOF):
 
     def fit(self, model: EOF, random_state=None):
         """`random_state` seeds the members' randomized SVDs (the reference leaves them unseeded)."""
+        getattr(model, "compute", lambda: None)()      # a deferred fit runs now: ctx / preprocessor / data are read below
         self.model = model
         self.ctx = ctx = model.ctx
         self.preprocessor = model.preprocessor
