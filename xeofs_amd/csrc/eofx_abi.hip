@@ -17,6 +17,9 @@
 #include <functional>
 #include <string>
 #include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <deque>
 #include <memory>
 #include <vector>
 
@@ -3206,16 +3209,17 @@ struct MT19937 {
 // own list of deviates in ONE pass, and the lists are concatenated in order.
 namespace {
 #define EOFX_MT_FILL_BODY                                                                                     \
-  for (int64_t i = 624; i < count; ++i) {                                                                     \
+  for (int64_t i = from; i < count; ++i) {                                                                     \
     const uint32_t y = (x[i - 624] & 0x80000000u) | (x[i - 623] & 0x7fffffffu);                               \
     x[i] = x[i - 227] ^ (y >> 1) ^ ((uint32_t)(-(int32_t)(y & 1u)) & 0x9908b0dfu);                            \
   }
 #if !defined(__HIP_DEVICE_COMPILE__)
-// eight words per step: every load lies at least 220 words behind the eight words being written
-__attribute__((target("avx2"))) void mt_fill_avx2(uint32_t* __restrict__ x, int64_t count) {
+// eight words per step: every load lies at least 220 words behind the eight words being written.  [from, count): the
+// words [0, from) are final (from >= 624), so the stream can be extended chunk by chunk.
+__attribute__((target("avx2"))) void mt_fill_avx2_range(uint32_t* __restrict__ x, int64_t from, int64_t count) {
   const __m256i upper = _mm256_set1_epi32((int)0x80000000u), lower = _mm256_set1_epi32(0x7fffffff);
   const __m256i one = _mm256_set1_epi32(1), matrix = _mm256_set1_epi32((int)0x9908b0dfu), zero = _mm256_setzero_si256();
-  int64_t i = 624;
+  int64_t i = from;
   for (; i + 8 <= count; i += 8) {
     const __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(x + i - 624));
     const __m256i b = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(x + i - 623));
@@ -3230,9 +3234,9 @@ __attribute__((target("avx2"))) void mt_fill_avx2(uint32_t* __restrict__ x, int6
   }
 }
 #else
-inline void mt_fill_avx2(uint32_t*, int64_t) {}   // (device pass of the single-source compile: host code only)
+inline void mt_fill_avx2_range(uint32_t*, int64_t, int64_t) {}   // (device pass of the single-source compile: host code only)
 #endif
-void mt_fill_generic(uint32_t* __restrict__ x, int64_t count) { EOFX_MT_FILL_BODY }
+void mt_fill_generic_range(uint32_t* __restrict__ x, int64_t from, int64_t count) { EOFX_MT_FILL_BODY }
 #undef EOFX_MT_FILL_BODY
 inline uint32_t mt_temper(uint32_t y) {
   y ^= (y >> 11);
@@ -3243,15 +3247,75 @@ inline uint32_t mt_temper(uint32_t y) {
 }
 }  // namespace
 
+namespace {
+// A small persistent pool for the data-parallel half of the sketch generator (starting a std::thread costs ~40 us; a
+// 10000 x 60 sketch is ~1.5 ms of work in total, so eighteen fresh threads per call were a third of its wall time).
+struct SketchPool {
+  std::mutex mu;
+  std::condition_variable cv_work, cv_done;
+  std::vector<std::thread> threads;
+  std::deque<std::function<void()>> tasks;
+  int pending = 0;
+  bool stop = false;
+  void ensure(int n) {
+    std::lock_guard<std::mutex> lk(mu);
+    while ((int)threads.size() < n) threads.emplace_back([this] { loop(); });
+  }
+  void loop() {
+    for (;;) {
+      std::function<void()> job;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_work.wait(lk, [this] { return stop || !tasks.empty(); });
+        if (stop && tasks.empty()) return;
+        job = std::move(tasks.front());
+        tasks.pop_front();
+      }
+      job();
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        if (--pending == 0) cv_done.notify_all();
+      }
+    }
+  }
+  void submit(std::function<void()> f) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      tasks.push_back(std::move(f));
+      ++pending;
+    }
+    cv_work.notify_one();
+  }
+  void wait() {
+    std::unique_lock<std::mutex> lk(mu);
+    cv_done.wait(lk, [this] { return pending == 0; });
+  }
+  ~SketchPool() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      stop = true;
+    }
+    cv_work.notify_all();
+    for (auto& t : threads) t.join();
+  }
+};
+SketchPool& sketch_pool() {
+  static SketchPool* pool = new SketchPool();     // leaked on purpose: worker threads must not be joined at exit order
+  return *pool;
+}
+std::mutex g_sketch_call;    // one generation at a time (the pool's completion counter is per call)
+}  // namespace
+
 extern "C" int eofx_sketch_gaussian_f32(uint32_t seed, int64_t rows, int64_t cols, float* out) {
   if (!out || rows < 0 || cols < 0) return EOFX_ERR_ARG;
   const int64_t total = rows * cols;
   if (total == 0) return EOFX_OK;
   const int64_t npairs = (total + 1) / 2;
   const int hw = (int)std::thread::hardware_concurrency();
-  int max_threads = std::max(1, std::min(32, hw > 0 ? hw : 1));
+  int max_threads = std::max(1, std::min(16, hw > 1 ? hw - 1 : 1));
   if (const char* ev = getenv("EOFX_SKETCH_THREADS")) max_threads = std::max(1, atoi(ev));
   static const bool have_avx2 = __builtin_cpu_supports("avx2");
+  std::lock_guard<std::mutex> call_lock(g_sketch_call);
   // x[0..623]: the generator state (init_genrand seeding); x[624 + w]: raw (untempered) output word w of the stream
   uint32_t state[624];
   {
@@ -3273,18 +3337,16 @@ extern "C" int eofx_sketch_gaussian_f32(uint32_t seed, int64_t rows, int64_t col
     }
     uint32_t* x = xbuf.get();
     std::memcpy(x, state, sizeof(state));
-    if (have_avx2) mt_fill_avx2(x, 624 + nwords);
-    else mt_fill_generic(x, 624 + nwords);
-
-    std::memcpy(state, x + nwords, sizeof(state));     // the state after these words (a rare second round continues here)
     const uint32_t* raw = x + 624;
-    // a thread costs ~40 us to start and a candidate ~45 ns: no more threads than pay for themselves
-    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(max_threads, ncand / 20000));
-    const int64_t step = (ncand + nt - 1) / nt;
-    std::vector<std::vector<float>> dev((size_t)nt);    // deviates of each share, in stream order: (f b, f a) per accepted pair
-    auto work = [&](int t) {
-      const int64_t lo = t * step, hi = std::min<int64_t>(ncand, (t + 1) * step);
-      std::vector<float>& d = dev[(size_t)t];
+    // The raw recurrence is sequential and runs on this thread, chunk by chunk; every finished chunk of candidates goes
+    // to the pool at once, so tempering / accept test / log / sqrt of chunk c overlap the recurrence of chunk c + 1:
+    // the call takes about as long as the recurrence alone (0.55 ns per word).
+    const int64_t chunk = 16384;                                    // candidates per task (64 K words, ~0.7 ms of deviate work)
+    const int64_t nchunks = (ncand + chunk - 1) / chunk;
+    std::vector<std::vector<float>> dev((size_t)nchunks);          // deviates of each chunk, in stream order: (f b, f a) per accepted pair
+    auto work = [&dev, raw, ncand, chunk](int64_t c) {
+      const int64_t lo = c * chunk, hi = std::min<int64_t>(ncand, lo + chunk);
+      std::vector<float>& d = dev[(size_t)c];
       d.resize((size_t)(2 * std::max<int64_t>(hi - lo, 0)));
       size_t q = 0;
       for (int64_t i = lo; i < hi; ++i) {
@@ -3300,16 +3362,25 @@ extern "C" int eofx_sketch_gaussian_f32(uint32_t seed, int64_t rows, int64_t col
       }
       d.resize(q);
     };
-    {
-      std::vector<std::thread> th;
-      for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
-      work(0);
-      for (auto& w : th) w.join();
+    const bool pooled = max_threads > 1 && nchunks > 1;
+    SketchPool& pool = sketch_pool();
+    if (pooled) pool.ensure((int)std::min<int64_t>(max_threads, nchunks));
+    int64_t filled = 624;                                            // words of x that hold final values
+    for (int64_t c = 0; c < nchunks; ++c) {
+      const int64_t upto = 624 + 4 * std::min<int64_t>(ncand, (c + 1) * chunk);
+      // the recurrence reads up to 624 words back and writes only beyond `filled`: extending the buffer in place
+      if (have_avx2) mt_fill_avx2_range(x, filled, upto);
+      else mt_fill_generic_range(x, filled, upto);
+      filled = upto;
+      if (pooled) pool.submit([&work, c] { work(c); });
+      else work(c);
     }
+    if (pooled) pool.wait();
+    std::memcpy(state, x + nwords, sizeof(state));     // the state after these words (a rare second round continues here)
     // concatenate in order; deviates beyond `total` belong to later draws of the stream and are dropped
     int64_t o = 2 * done_pairs;
-    for (int t = 0; t < nt && o < total; ++t) {
-      const std::vector<float>& d = dev[(size_t)t];
+    for (int64_t c = 0; c < nchunks && o < total; ++c) {
+      const std::vector<float>& d = dev[(size_t)c];
       const int64_t take = std::min<int64_t>((int64_t)d.size(), total - o);
       std::memcpy(out + o, d.data(), sizeof(float) * (size_t)take);
       o += take;
