@@ -437,9 +437,16 @@ def main():
             phase["pre"] += pre
             phase["svd"] += (c - a) - pre
             return mat, st, U, s, V
+        first = None
         if single:
             mat, st = engine.preprocess(ctx, Xraw, center=True, standardize=False, feature_weights=None,
                                         want_stats=False, **layout_kw)
+        elif args.layout == "inplace" and not args.two_step:
+            # every rank takes the statistics of its shard during its (local) first product X_g^T Omega
+            mat, st, first = sharded.sharded_fit_first(ctx, Xraw, comm, k, P, center=True, standardize=False,
+                                                       feature_weights=None, want_stats=False, n_oversamples=N_OVERSAMPLES,
+                                                       omega=omega)
+            phase["fused_steps"] += int(first is not None)
         else:   # + the global facts: valid-sample mask / isolated-NaN check, feature offsets, total variance
             mat, st = sharded.sharded_preprocess(ctx, Xraw, comm, center=True, standardize=False,
                                                  feature_weights=None, want_stats=False, **layout_kw)
@@ -450,7 +457,7 @@ def main():
         else:
             ops = sharded.HipPanelOps(ctx, mat)
             U, s, V = sharded.sharded_rsvd(ops, comm, k, P, lo, N_OVERSAMPLES, "auto", omega=omega.result(),
-                                           device_out=True)
+                                           device_out=True, first=first)
         torch.cuda.synchronize()
         c = time.perf_counter()
         phase["pre"] += b - a
@@ -681,9 +688,11 @@ def main():
                                    f"feature axis sharded over {world} GPU(s), n_iter={n_iter}, n_oversamples=10, "
                                    f"random_state=5",
                        "n_samples": n, "n_features": P, "n_modes": k, "passes": passes, "layout": args.layout,
-                       "field_reads_per_fit": passes if (one_call and phase["fused_steps"] == args.steps) else passes + 1,
+                       "field_reads_per_fit": passes if phase["fused_steps"] == args.steps else passes + 1,
                        "entry": "eofx_fit_f32 (statistics during the first pass)" if one_call else
-                                "eofx_preprocess_f32 + eofx_rsvd_f32" if single else "sharded_preprocess + sharded_rsvd (panel ABI + collectives)"},
+                                "eofx_preprocess_f32 + eofx_rsvd_f32" if single else
+                                "sharded_fit_first (eofx_fit_first_f32 per rank) + sharded_rsvd (panel ABI + collectives)"
+                                if phase["fused_steps"] else "sharded_preprocess + sharded_rsvd (panel ABI + collectives)"},
             "modes_per_s": round(k / (ms_step * 1e-3), 2),
             "phase_ms": {"preprocess": round(1e3 * phase["pre"] / args.steps, 3),
                          "svd": round(1e3 * phase["svd"] / args.steps, 3)},

@@ -209,7 +209,17 @@ int eofx_fit_f32(eofx_ctx *ctx, const float *X, int64_t n, int64_t P, int center
                  const float *omega, int64_t omega_rows, int flip, eofx_mat **out, double *mean, double *std,
                  uint8_t *valid_feature, uint8_t *valid_sample, int64_t *n_out, int64_t *p_out,
                  double *total_variance, float *U, float *s, float *V, int *fused);
-/* info3: [0] 1 when the last eofx_fit_f32 took the fused path, [1] milliseconds of its non-pass work (probe kernel,
+/* The statistics-carrying first pass on its own, for drivers that put collectives between the passes (the
+ * feature-sharded fit, SURVEY.md 8e: a rank's X_g^T Z needs no communication, so every rank takes the statistics of its
+ * shard while it computes it).  Yp [round_up(P, 512) x L] (device) = X'^T Zn for the device panel Zn [n_pad x L] whose
+ * first l < L columns are in use, plus everything eofx_preprocess_f32 returns (same arguments).  Same eligibility and
+ * fallback as eofx_fit_f32 (the fallback is eofx_preprocess_f32 + eofx_panel_tmul_f32; if it dropped samples, *n_out < n
+ * and Yp is NOT computed: the caller re-imports the rows of Z that survive).                                      */
+int eofx_fit_first_f32(eofx_ctx *ctx, const float *X, int64_t n, int64_t P, int center, int standardize,
+                       const double *feat_weights, int check_nans, const float *Zn, int L, int l, float *Yp,
+                       eofx_mat **out, double *mean, double *std, uint8_t *valid_feature, uint8_t *valid_sample,
+                       int64_t *n_out, int64_t *p_out, double *total_variance, int *fused);
+/* info3: [0] 1 when the last eofx_fit_f32 / eofx_fit_first_f32 took the fused path, [1] milliseconds of its non-pass work (probe kernel,
  * statistics finalisation, rank-one correction; HIP events, only while profiling is on), [2] why it did not: 0 fused,
  * -1 not eligible, 1 NaN / constant data in the sampled rows, 3 NaN or inf in the field, 4 provisional fp16 range
  * exceeded, 5 both.                                                                                              */

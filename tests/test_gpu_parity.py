@@ -357,6 +357,36 @@ def test_sharded_world1_equals_driver_bitwise(ctx):
         assert np.array_equal(a, b)
 
 
+def test_sharded_fused_first_pass_world1(ctx):
+    """The feature-sharded fit with the statistics taken during each rank's first product (`sharded_fit_first` ->
+    `eofx_fit_first_f32`, then `sharded_rsvd(first=...)`): at world size 1 the panel-level driver and the one-call engine
+    fit run the same sequence and must agree bit for bit; a shard with a NaN mask falls back on its own."""
+    import torch
+    from xeofs_amd import engine, sharded
+
+    n, p, k = 400, 3072, 12
+    X = torch.as_tensor(_field(n, p, rank=9, seed=21), device="cuda")
+    comm = sharded.Comm()
+    mat, st, first = sharded.sharded_fit_first(ctx, X, comm, k, p, random_state=9)
+    assert first is not None and st["fused"] and (st["p_total"], st["p_offset"]) == (p, 0)
+    U, s, V = sharded.sharded_rsvd(sharded.HipPanelOps(ctx, mat), comm, k, p, 0, random_state=9, first=first)
+    mat2, st2, U2, s2, V2 = engine.fit(ctx, X, k, random_state=9)
+    assert st2["fused"]
+    assert np.array_equal(s, s2) and np.array_equal(U, U2) and np.array_equal(V, V2)
+    assert np.array_equal(st["mean"], st2["mean"]) and st["total_variance"] == st2["total_variance"]
+    out = sharded.sharded_eof_fit(ctx, X, comm, k, random_state=9)
+    assert np.array_equal(out["components"], V2) and np.array_equal(out["norms"], s2.astype(np.float64))
+    mat.free(); mat2.free(); out["input_data"].free()
+    Xn = X.clone()
+    Xn[:, 100:140] = float("nan")
+    mat3, st3, first3 = sharded.sharded_fit_first(ctx, Xn, comm, k, p, random_state=9)
+    assert first3 is None and not st3["fused"] and st3["p_total"] == p - 40       # compacted: the driver redoes the product
+    U3, s3, V3 = sharded.sharded_rsvd(sharded.HipPanelOps(ctx, mat3), comm, k, st3["p_total"], 0, random_state=9)
+    ref = orc.eof_fit(Xn.cpu().numpy().astype(np.float64), k, random_state=9)
+    _check_factors(U3, s3, V3, ref, k)
+    mat3.free()
+
+
 def _check_factors(U, s, V, ref, k, tol=1e-5):
     assert np.all(np.abs(s - ref["norms"]) <= tol * ref["norms"][0]), (s, ref["norms"])
     sv = ref["norms"]

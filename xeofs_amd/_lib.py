@@ -61,6 +61,8 @@ SIGNATURES = {
     "eofx_mat_sumsq_f64": (_int, [_vp, _vp, _pd]),
     "eofx_fit_f32": (_int, [_vp, _vp, _i64, _i64, _int, _int, _vp, _int, _int, _int, _int, _vp, _i64, _int,
                             C.POINTER(_vp), _vp, _vp, _vp, _vp, _pi64, _pi64, _pd, _vp, _vp, _vp, C.POINTER(C.c_int)]),
+    "eofx_fit_first_f32": (_int, [_vp, _vp, _i64, _i64, _int, _int, _vp, _int, _vp, _int, _int, _vp, C.POINTER(_vp),
+                                  _vp, _vp, _vp, _vp, _pi64, _pi64, _pd, C.POINTER(C.c_int)]),
     "eofx_ctx_fit_info": (_int, [_vp, _pd]),
     "eofx_rsvd_c64": (_int, [_vp, _vp, _vp, _int, _int, _int, _vp, _int, _vp, _vp, _vp]),
     "eofx_orth_tall_rule": (_int, [_i64, _int, _int]),

@@ -1961,97 +1961,118 @@ extern "C" int eofx_rsvd_f32(eofx_ctx* ctx, const eofx_mat* m, int k, int n_over
 // The fused fit: Scaler.fit + Sanitizer + Decomposer.fit with the column statistics taken during the FIRST pass of
 // the randomized SVD (eofx_fit.hpp): 2 n_iter + 2 reads of the field instead of 2 n_iter + 3.
 // ------------------------------------------------------------------------------------
-static int fit_fused(eofx_ctx* ctx, const float* Xd, int64_t n, int64_t P, int center, int standardize,
-                     const double* feat_weights, int k, int l, int n_iter, const float* omega, int flip,
-                     eofx_mat** out, double* mean, double* std_, double* total_variance, float* U, float* s, float* V) {
-  const int L = (int)round_up(l, 32);
-  const int64_t p_pad = round_up(P, ATB_BM), n_pad = round_up(n, ATB_BM);
-  const int64_t K = round_up(n, ATB_KG);
-  const AtbPlan plan = atb_plan(p_pad, K, L);
-  const int S = plan.S;
-  const int NPART = 64;
-  size_t need = rsvd_scratch_bytes(p_pad, n_pad, l, k);
-  need += (size_t)S * p_pad * (8 + 4) + (size_t)P * (4 + 6 * 8) + (size_t)p_pad * 4 + (size_t)P * 8;
-  need += (size_t)(NPART + 1) * L * 8 + (size_t)S * p_pad * L * 4 + (1 << 20);
-  CHK(arena_reserve(ctx, need));
-  ArenaScope scope(ctx);
-  PreState ps;
-  ARENA(int, cnt, P);
-  ARENA(double, dmean, P);
-  ARENA(double, dstd, P);
-  ARENA(double, dshift, P);
-  ARENA(double, dscale, P);
-  ARENA(double, dm2, P);
-  ARENA(unsigned, dabsmax, 4);
-  ps = {cnt, dmean, dstd, dshift, dscale, dm2, dabsmax};
-  ARENA(double, dcorr, P);
-  ARENA(float, cshift, p_pad);
-  ARENA(double, st_sq, (size_t)S * p_pad);
-  ARENA(float, st_max, (size_t)S * p_pad);
-  ARENA(double, wpart, (size_t)NPART * L);
-  ARENA(double, wbar, L);
-  ARENA(int, dflags, 4);
-  double* wdev = nullptr;
-  if (feat_weights) {
-    wdev = arena_alloc<double>(ctx, P);
-    if (!wdev) return set_err(ctx, EOFX_ERR_NOMEM, "arena exhausted (weights)");
-    CHK(copy_in(ctx, wdev, feat_weights, sizeof(double) * P));
-  }
-  double* pin = nullptr;
-  CHK(pinned_scratch(ctx, &pin));
-  unsigned* hword = reinterpret_cast<unsigned*>(pin + EOFX_PINNED_DOUBLES - 8);   // 4 words beyond what rsvd_core uses
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-  struct EvGuard {
-    hipEvent_t* e;
-    ~EvGuard() {
-      for (int i = 0; i < 4; ++i)
-        if (e[i]) (void)hipEventDestroy(e[i]);
-    }
-  } evg{ev};
-  if (ctx->profile) {
-    for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreate(&ev[i]));
-    HIPCHK(hipEventRecord(ev[0], ctx->stream));
-  }
-  // provisional shift (first sample) and scale (sampled max |x - c|, with 2^6 of headroom: the lo fp16 term keeps
-  // 11 bits down to 2^-17 of the largest value, so a generous scale costs nothing; an underestimate is caught by the
-  // overflow flag and sends the fit back to the two-step path)
-  HIPCHK(hipMemsetAsync(dabsmax, 0, sizeof(unsigned) * 4, ctx->stream));
-  HIPCHK(hipMemsetAsync(dflags, 0, sizeof(int) * 4, ctx->stream));
-  hipLaunchKernelGGL(fit_probe_kernel, dim3((int)((p_pad / 4 + 255) / 256)), dim3(256), 0, ctx->stream, Xd, n, P, P, p_pad, cshift,
-                     dabsmax + 1, dflags);
-  KCHK();
-  HIPCHK(hipMemcpyAsync(hword, dabsmax + 1, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipMemcpyAsync(hword + 1, dflags, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  float est;
-  std::memcpy(&est, hword, sizeof(float));
-  if ((hword[1] & 1) || !(est > 0.f) || !std::isfinite(est)) {
-    ctx->fit_info[2] = 1.0;    // NaN in the sampled rows / constant or non-finite sample
-    return EOFX_FIT_FALLBACK;
-  }
-  int e2;
-  (void)std::frexp(est, &e2);
-  const float a_scale = std::ldexp(1.f, 14 - e2 - 6);
-
+// State of one statistics-carrying first pass.  prepare() carves its buffers from the arena (the caller has reserved
+// fit_first_bytes() on top of its own needs and holds the ArenaScope), runs the probe and creates the in-place matrix;
+// run() is the pass itself: Yt = X'^T Zs plus the Scaler's state.  Both may return EOFX_FIT_FALLBACK.
+struct FitFirst {
+  eofx_ctx* ctx = nullptr;
+  const float* Xd = nullptr;
+  int64_t n = 0, P = 0, p_pad = 0, n_pad = 0, K = 0;
+  int center = 1, standardize = 0, l = 0, L = 0, S = 1;
+  AtbPlan plan{1, 0};
+  PreState ps{};
+  double *dcorr = nullptr, *st_sq = nullptr, *wpart = nullptr, *wbar = nullptr, *wdev = nullptr;
+  float *cshift = nullptr, *st_max = nullptr;
+  int* dflags = nullptr;
+  unsigned* hword = nullptr;
+  float a_scale = 1.f;
   eofx_mat* m = nullptr;
-  CHK(mat_alloc(ctx, n, P, &m, false, false));
-  struct MatGuard {
-    eofx_ctx* c;
-    eofx_mat** m;
-    ~MatGuard() {
-      if (*m) eofx_mat_destroy(c, *m);
-    }
-  } mg{ctx, &m};
-  if (pool_malloc(ctx, (void**)&m->aff, sizeof(float) * 3 * (size_t)p_pad) != hipSuccess) {
-    (void)hipGetLastError();
-    m->aff = nullptr;
-    return set_err(ctx, EOFX_ERR_NOMEM, "cannot allocate the affine map");
-  }
-  m->raw = Xd;
-  m->raw_ld = P;
-  m->p_valid = P;
   FeatSummary fs;
-  FirstFwd first = [&](const float* Zs, float* Yt, int LL) -> int {
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  static constexpr int NPART = 64;
+  ~FitFirst() {
+    for (int i = 0; i < 4; ++i)
+      if (ev[i]) (void)hipEventDestroy(ev[i]);
+    if (m) eofx_mat_destroy(ctx, m);
+  }
+  static size_t bytes(int64_t n, int64_t P, int l) {
+    const int L = (int)round_up(l, 32);
+    const int64_t p_pad = round_up(P, ATB_BM);
+    const int S = atb_plan(p_pad, round_up(n, ATB_KG), L).S;
+    return (size_t)S * p_pad * (8 + 4) + (size_t)P * (4 + 6 * 8) + (size_t)p_pad * 4 + (size_t)P * 16 +
+           (size_t)(NPART + 1) * L * 8 + (size_t)S * p_pad * L * 4 + (1 << 20);
+  }
+  int prepare(eofx_ctx* c, const float* X, int64_t n_, int64_t P_, int center_, int standardize_, const double* feat_weights,
+              int l_) {
+    ctx = c;
+    Xd = X;
+    n = n_;
+    P = P_;
+    center = center_;
+    standardize = standardize_;
+    l = l_;
+    L = (int)round_up(l, 32);
+    p_pad = round_up(P, ATB_BM);
+    n_pad = round_up(n, ATB_BM);
+    K = round_up(n, ATB_KG);
+    plan = atb_plan(p_pad, K, L);
+    S = plan.S;
+    ARENA(int, cnt, P);
+    ARENA(double, dmean, P);
+    ARENA(double, dstd, P);
+    ARENA(double, dshift, P);
+    ARENA(double, dscale, P);
+    ARENA(double, dm2, P);
+    ARENA(unsigned, dabsmax, 4);
+    ps = {cnt, dmean, dstd, dshift, dscale, dm2, dabsmax};
+    ARENA(double, dcorr_, P);
+    ARENA(float, cshift_, p_pad);
+    ARENA(double, st_sq_, (size_t)S * p_pad);
+    ARENA(float, st_max_, (size_t)S * p_pad);
+    ARENA(double, wpart_, (size_t)NPART * L);
+    ARENA(double, wbar_, L);
+    ARENA(int, dflags_, 4);
+    dcorr = dcorr_;
+    cshift = cshift_;
+    st_sq = st_sq_;
+    st_max = st_max_;
+    wpart = wpart_;
+    wbar = wbar_;
+    dflags = dflags_;
+    if (feat_weights) {
+      wdev = arena_alloc<double>(ctx, P);
+      if (!wdev) return set_err(ctx, EOFX_ERR_NOMEM, "arena exhausted (weights)");
+      CHK(copy_in(ctx, wdev, feat_weights, sizeof(double) * P));
+    }
+    double* pin = nullptr;
+    CHK(pinned_scratch(ctx, &pin));
+    hword = reinterpret_cast<unsigned*>(pin + EOFX_PINNED_DOUBLES - 8);   // 4 words beyond what rsvd_core uses
+    if (ctx->profile) {
+      for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreate(&ev[i]));
+      HIPCHK(hipEventRecord(ev[0], ctx->stream));
+    }
+    // provisional shift (mean of nine sampled rows) and scale (sampled max |x - c|, with 2^6 of headroom: the lo fp16
+    // term keeps 11 bits down to 2^-17 of the largest value, so a generous scale costs nothing; an underestimate is
+    // caught by the overflow flag and sends the fit back to the two-step path)
+    HIPCHK(hipMemsetAsync(ps.absmax, 0, sizeof(unsigned) * 4, ctx->stream));
+    HIPCHK(hipMemsetAsync(dflags, 0, sizeof(int) * 4, ctx->stream));
+    hipLaunchKernelGGL(fit_probe_kernel, dim3((int)((p_pad / 4 + 255) / 256)), dim3(256), 0, ctx->stream, Xd, n, P, P, p_pad, cshift,
+                       ps.absmax + 1, dflags);
+    KCHK();
+    HIPCHK(hipMemcpyAsync(hword, ps.absmax + 1, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(hword + 1, dflags, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    float est;
+    std::memcpy(&est, hword, sizeof(float));
+    if ((hword[1] & 1) || !(est > 0.f) || !std::isfinite(est)) {
+      ctx->fit_info[2] = 1.0;    // NaN in the sampled rows / constant or non-finite sample
+      return EOFX_FIT_FALLBACK;
+    }
+    int e2;
+    (void)std::frexp(est, &e2);
+    a_scale = std::ldexp(1.f, 14 - e2 - 6);
+    CHK(mat_alloc(ctx, n, P, &m, false, false));
+    if (pool_malloc(ctx, (void**)&m->aff, sizeof(float) * 3 * (size_t)p_pad) != hipSuccess) {
+      (void)hipGetLastError();
+      m->aff = nullptr;
+      return set_err(ctx, EOFX_ERR_NOMEM, "cannot allocate the affine map");
+    }
+    m->raw = Xd;
+    m->raw_ld = P;
+    m->p_valid = P;
+    return EOFX_OK;
+  }
+  int run(const float* Zs, float* Yt, int LL) {
     // sum_i Omega[i, :] of the rank-one correction
     hipLaunchKernelGGL(panel_colsum_part_kernel, dim3(NPART), dim3(256), 0, ctx->stream, Zs, n, LL, wpart);
     KCHK();
@@ -2059,7 +2080,7 @@ static int fit_fused(eofx_ctx* ctx, const float* Xd, int64_t n, int64_t P, int c
     KCHK();
     const float* bmax = amax_get(ctx, Zs);
     if (!bmax) {
-      unsigned* bm = dabsmax + 2;
+      unsigned* bm = ps.absmax + 2;
       const int64_t total4 = n_pad * (LL / 4);
       hipLaunchKernelGGL(panel_absmax_kernel, dim3((int)std::max<int64_t>(1, std::min<int64_t>((total4 + 1023) / 1024, 1024))),
                          dim3(256), 0, ctx->stream, Zs, n_pad, LL, (int64_t)LL, bm);
@@ -2113,26 +2134,108 @@ static int fit_fused(eofx_ctx* ctx, const float* Xd, int64_t n, int64_t P, int c
     }
     std::memcpy(&m->absmax, hword + 3, sizeof(float));
     return EOFX_OK;
-  };
+  }
+  // mean / std to the caller, the event times of the non-pass work, and the matrix itself
+  int finish(double* mean, double* std_, double* total_variance, eofx_mat** out) {
+    if (mean) HIPCHK(hipMemcpyAsync(mean, ps.mean, sizeof(double) * P, hipMemcpyDeviceToHost, ctx->stream));
+    if (std_) HIPCHK(hipMemcpyAsync(std_, ps.stdv, sizeof(double) * P, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (total_variance) *total_variance = fs.tv;
+    if (ctx->profile) {
+      float t01 = 0.f, t23 = 0.f;
+      (void)hipEventElapsedTime(&t01, ev[0], ev[1]);
+      (void)hipEventElapsedTime(&t23, ev[2], ev[3]);
+      ctx->fit_info[1] = (double)t01 + (double)t23;
+    }
+    *out = m;
+    m = nullptr;
+    return EOFX_OK;
+  }
+};
+
+static bool fit_first_eligible(const eofx_ctx* ctx, const float* Xdev, int64_t n, int64_t P, int l) {
+  return ctx->keep_raw == 2 && ctx->prec_power == EOFX_PREC_F16X3 && n < P && l > 0 && l < n && round_up(l, 32) <= 64 &&
+         l % 32 != 0 && P % 4 == 0 && ((uintptr_t)Xdev % 16) == 0 && n < ((int64_t)1 << 31) && !std::getenv("EOFX_NO_FUSED_FIT");
+}
+
+// ------------------------------------------------------------------------------------
+// The fused fit: Scaler.fit + Sanitizer + Decomposer.fit with the column statistics taken during the FIRST pass of
+// the randomized SVD (eofx_fit.hpp): 2 n_iter + 2 reads of the field instead of 2 n_iter + 3.
+// ------------------------------------------------------------------------------------
+static int fit_fused(eofx_ctx* ctx, const float* Xd, int64_t n, int64_t P, int center, int standardize,
+                     const double* feat_weights, int k, int l, int n_iter, const float* omega, int flip,
+                     eofx_mat** out, double* mean, double* std_, double* total_variance, float* U, float* s, float* V) {
+  const int64_t p_pad = round_up(P, ATB_BM), n_pad = round_up(n, ATB_BM);
+  CHK(arena_reserve(ctx, rsvd_scratch_bytes(p_pad, n_pad, l, k) + FitFirst::bytes(n, P, l)));
+  ArenaScope scope(ctx);
+  FitFirst ff;
+  int rc = ff.prepare(ctx, Xd, n, P, center, standardize, feat_weights, l);
+  if (rc != EOFX_OK) return rc;
+  FirstFwd first = [&](const float* Zs, float* Yt, int LL) -> int { return ff.run(Zs, Yt, LL); };
+  const eofx_mat* m = ff.m;
   LinOp op = {P, n, p_pad, n_pad,
               [&](const float* z, float* y, int LL, int pr) { return panel_tmul(ctx, m, z, y, LL, pr); },
               [&](const float* y, float* w, int LL, int pr) { return panel_mul(ctx, m, y, w, LL, pr); }};
   RsvdOut ro;
-  int rc = rsvd_core(ctx, op, k, l, n_iter, omega, ro, &first);
+  rc = rsvd_core(ctx, op, k, l, n_iter, omega, ro, &first);
   if (rc != EOFX_OK) return rc;
   CHK(rsvd_finish(ctx, ro, true, n, P, k, flip, U, s, V));
-  if (mean) HIPCHK(hipMemcpyAsync(mean, ps.mean, sizeof(double) * P, hipMemcpyDeviceToHost, ctx->stream));
-  if (std_) HIPCHK(hipMemcpyAsync(std_, ps.stdv, sizeof(double) * P, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  if (total_variance) *total_variance = fs.tv;
-  if (ctx->profile) {
-    float t01 = 0.f, t23 = 0.f;
-    (void)hipEventElapsedTime(&t01, ev[0], ev[1]);
-    (void)hipEventElapsedTime(&t23, ev[2], ev[3]);
-    ctx->fit_info[1] = (double)t01 + (double)t23;
+  return ff.finish(mean, std_, total_variance, out);
+}
+
+// The first pass on its own, for drivers that put collectives between the passes (the feature-sharded fit: the product
+// X_g^T Z of a rank's shard needs no communication, so every rank takes its statistics while it computes it):
+// Yp [p_pad x L] = X'^T Zn for the device panel Zn [n_pad x L] whose first l columns are in use (l < L: the spare column
+// carries the ones), plus everything eofx_preprocess_f32 returns.  Falls back to eofx_preprocess_f32 + eofx_panel_tmul_f32
+// by itself (NaN fields, other precisions, ...); *fused tells which.  Yp must hold round_up(P, 512) rows; after a fallback
+// that compacted the field only the first (*out)->p_pad rows are meaningful.
+extern "C" int eofx_fit_first_f32(eofx_ctx* ctx, const float* X, int64_t n, int64_t P, int center, int standardize,
+                                  const double* feat_weights, int check_nans, const float* Zn, int L, int l, float* Yp,
+                                  eofx_mat** out, double* mean, double* std_, uint8_t* valid_feature, uint8_t* valid_sample,
+                                  int64_t* n_out, int64_t* p_out, double* total_variance, int* fused) {
+  if (!ctx || !X || !out || !Zn || !Yp || n <= 0 || P <= 0 || L <= 0 || L % 32 || l <= 0 || l > L)
+    return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  CHK(set_device(ctx));
+  if (fused) *fused = 0;
+  ctx->fit_info[0] = ctx->fit_info[1] = ctx->fit_info[2] = 0.0;
+  Staged st;
+  CHK(stage_input(ctx, X, (size_t)n * P, st));
+  if (fit_first_eligible(ctx, st.dev, n, P, l) && round_up(l, 32) == L) {
+    CHK(arena_reserve(ctx, FitFirst::bytes(n, P, l) + atb_scratch_bytes(round_up(P, ATB_BM), round_up(n, ATB_KG), L)));
+    ArenaScope scope(ctx);
+    FitFirst ff;
+    int rc = ff.prepare(ctx, st.dev, n, P, center, standardize, feat_weights, l);
+    if (rc == EOFX_OK) rc = ff.run(Zn, Yp, L);
+    if (rc < 0) return rc;
+    if (rc == EOFX_OK) {
+      CHK(ff.finish(mean, std_, total_variance, out));
+      adopt_staged(out, st, (size_t)n * P * sizeof(float));
+      if (valid_feature) std::memset(valid_feature, 1, (size_t)P);
+      if (valid_sample) std::memset(valid_sample, 1, (size_t)n);
+      if (n_out) *n_out = n;
+      if (p_out) *p_out = P;
+      if (fused) *fused = 1;
+      ctx->fit_info[0] = 1.0;
+      return EOFX_OK;
+    }
+  } else {
+    ctx->fit_info[2] = -1.0;
+  }
+  eofx_mat* m = nullptr;
+  int64_t ns = 0, pv = 0;
+  CHK(eofx_preprocess_f32(ctx, st.dev, n, P, center, standardize, feat_weights, check_nans, &m, mean, std_, valid_feature,
+                          valid_sample, &ns, &pv, total_variance));
+  adopt_staged(&m, st, (size_t)n * P * sizeof(float));
+  if (n_out) *n_out = ns;
+  if (p_out) *p_out = pv;
+  int rc = ns == n ? eofx_panel_tmul_f32(ctx, m, Zn, Yp, L, ctx->prec_power) : EOFX_OK;   // dropped samples: the caller re-imports Z
+  if (rc != EOFX_OK) {
+    const std::string keep = ctx->err;
+    eofx_mat_destroy(ctx, m);
+    ctx->err = keep;
+    return rc;
   }
   *out = m;
-  m = nullptr;
   return EOFX_OK;
 }
 
@@ -2151,9 +2254,7 @@ extern "C" int eofx_fit_f32(eofx_ctx* ctx, const float* X, int64_t n, int64_t P,
   const int l_req = k + n_oversamples;
   const int l = (int)std::min<int64_t>(l_req, std::min(n, P));
   const int iters = n_iter < 0 ? rsvd_auto_iters(k, n, P) : n_iter;
-  const bool eligible = ctx->keep_raw == 2 && ctx->prec_power == EOFX_PREC_F16X3 && n < P && k <= n && l == l_req && l < n &&
-                        round_up(l, 32) <= 64 && l % 32 != 0 && P % 4 == 0 && ((uintptr_t)st.dev % 16) == 0 && n < ((int64_t)1 << 31) &&
-                        omega_rows >= n && !is_device_ptr(omega) && !std::getenv("EOFX_NO_FUSED_FIT");
+  const bool eligible = fit_first_eligible(ctx, st.dev, n, P, l) && k <= n && l == l_req && omega_rows >= n && !is_device_ptr(omega);
   if (eligible) {
     const int rc = fit_fused(ctx, st.dev, n, P, center, standardize, feat_weights, k, l, iters, omega, flip, out, mean, std_,
                              total_variance, U, s, V);

@@ -408,6 +408,48 @@ def fit(ctx: Context, X, k: int, center=True, standardize=False, feature_weights
     return mat, stats, U, s, mat.compact_rows(V)
 
 
+def fit_first(ctx: Context, X, Zn, l: int, center=True, standardize=False, feature_weights=None, check_nans=True,
+              want_stats=True):
+    """The statistics-carrying first pass on its own (eofx_fit_first_f32): Yp = X'^T Zn for the device panel Zn
+    [n_pad, L] (first l < L columns in use) together with the preprocessing of X (in-place layout).
+    -> (ResidentMatrix, stats dict as `preprocess` plus `fused`, Yp [p_pad, L] device tensor or None when samples were
+    dropped and the caller has to redo the product with the surviving rows of Z)"""
+    torch = _torch()
+    X = _f32c(X)
+    n, P = X.shape
+    w = None if feature_weights is None else np.ascontiguousarray(feature_weights, dtype=np.float64)
+    if w is not None and w.shape != (P,):
+        raise ValueError("feature_weights must have one entry per stacked feature")
+    L = Zn.shape[1]
+    Yp = torch.empty(((P + 511) // 512 * 512, L), dtype=torch.float32, device=Zn.device)
+    mean = np.empty(P, np.float64) if want_stats else None
+    std = np.empty(P, np.float64) if want_stats else None
+    vf = np.empty(P, np.uint8)
+    vs = np.empty(n, np.uint8)
+    n_out, p_out = C.c_int64(), C.c_int64()
+    tv = C.c_double()
+    fused = C.c_int()
+    h = C.c_void_p()
+    ctx.lib.eofx_ctx_set_layout(ctx.handle, 2)
+    try:
+        rc = ctx.lib.eofx_fit_first_f32(ctx.handle, ptr(X), n, P, int(center), int(standardize), ptr(w), int(check_nans),
+                                        ptr(Zn), L, int(l), ptr(Yp), C.byref(h), ptr(mean), ptr(std), ptr(vf), ptr(vs),
+                                        C.byref(n_out), C.byref(p_out), C.byref(tv), C.byref(fused))
+    finally:
+        ctx.lib.eofx_ctx_set_layout(ctx.handle, 0)
+    raise_for(rc, ctx.handle)
+    mat = ResidentMatrix(ctx, h)
+    if hasattr(X, "data_ptr"):
+        mat._keepalive = X
+    stats = dict(mean=mean, std=std, valid_feature=vf.astype(bool), valid_sample=vs.astype(bool),
+                 n=n_out.value, p=p_out.value, total_variance=tv.value, fused=bool(fused.value))
+    if n_out.value != n:
+        Yp = None
+    elif mat.p_pad != Yp.shape[0]:
+        Yp = Yp[: mat.p_pad].contiguous()
+    return mat, stats, Yp
+
+
 def fit_info(ctx: Context):
     """-> dict(fused, preprocess_ms, reason) of the last `fit` on this context (include/eofx.h, eofx_ctx_fit_info)"""
     info = (C.c_double * 3)()

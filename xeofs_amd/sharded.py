@@ -194,17 +194,25 @@ def _prec_power(ops) -> str:
     return getattr(ctx, "precision", ("f16x3", "f16x3"))[0]
 
 
-def _rsvd_panels(la, to_tall, to_small, gram_small, gram_tall, Z, l, k, n_iter, orth_tall=False):
+def _rsvd_panels(la, to_tall, to_small, gram_small, gram_tall, Z, l, k, n_iter, orth_tall=False, first_tall=None):
     """The pass sequence of `rsvd_core` (csrc/eofx_abi.hip) on abstract products.
 
     `to_tall(P, final)` / `to_small(P, final)` apply A / A^T to a panel (including whatever reduction
     the sharding needs), `gram_*` return the globally reduced L x L float64 Gram matrix of a panel on
     that side, `la` supplies the matrix-independent steps (cholqr, matmul, eigh).  Returns the
     singular-vector panels (tall side, small side) and the k singular values (float64).
+    `first_tall`: the first product A Z when the caller already has it (the statistics-carrying first pass of the fused
+    fit, `engine.fit_first`): it replaces the first `to_tall` of the run.
     """
+    _first = [first_tall]
+
+    def tall(P):
+        y, _first[0] = _first[0], None
+        return y if y is not None else to_tall(P, False)
+
     orth_rest = bool(orth_tall)
     for it in range(int(n_iter)):
-        Yt = to_tall(Z, False)
+        Yt = tall(Z)
         if it == 0 or orth_rest:       # the first iteration always re-normalises the tall panel (rsvd_core)
             Yt = la.cholqr(Yt, l, gram_tall(Yt))
         W = to_small(Yt, False)
@@ -212,7 +220,7 @@ def _rsvd_panels(la, to_tall, to_small, gram_small, gram_tall, Z, l, k, n_iter, 
         if it == 0 and not orth_tall and int(n_iter) > 1:   # peaked spectrum?  same rule, same code as the C++ driver
             orth_rest = _peaked(Gs, l)
         Z = la.cholqr(W, l, Gs)
-    Yt = to_tall(Z, False)                       # range basis: a subspace only, power-pass precision
+    Yt = tall(Z)                                 # range basis: a subspace only, power-pass precision
     Q = la.cholqr(Yt, l, gram_tall(Yt))
     # CholeskyQR2 as in rsvd_core: the second factor R2 = chol(Q^T Q) is applied on the SMALL side, B^T = (A^T Q) R2^-1,
     # and folded into the final rotation of the tall panel -- one pass over the tall panel less
@@ -257,12 +265,15 @@ def _sign_from_extrema(comm, ops, Vp, rows, k):
 
 
 def sharded_rsvd(ops, comm: Comm, k: int, p_total: int, p_offset: int, n_oversamples: int = 10,
-                 n_iter="auto", random_state=None, flip: bool = True, omega=None, device_out: bool = False):
+                 n_iter="auto", random_state=None, flip: bool = True, omega=None, device_out: bool = False,
+                 first=None):
     """Randomized SVD of X = [X_0 | X_1 | ...] with the feature axis sharded over ranks.
 
     Returns (U[n, k] replicated, s[k] replicated, V_local[p_g, k]) as float32 numpy arrays.
     `omega` is the global sketch matrix (min(n, p_total) x (k + n_oversamples)), identical
     on every rank (same seed), drawn as scikit-learn does.
+    `first` = (Z panel, X_g^T Z panel) from `sharded_fit_first`: the sketch is already imported and the first product
+    already taken (with the statistics of the shard); only for the transposed case n < p_total.
     """
     n, p_loc = ops.n, ops.p
     omega, l = _resolve_sketch(k, min(n, p_total), n_oversamples, omega, random_state)
@@ -271,9 +282,15 @@ def sharded_rsvd(ops, comm: Comm, k: int, p_total: int, p_offset: int, n_oversam
     transposed = n < p_total   # A = X^T: tall side = features (sharded), small side = samples
 
     # side bookkeeping: "n" panels are replicated, "p" panels are sharded by rows
+    first_tall = None
+    if first is not None and not transposed:
+        raise ValueError("a precomputed first product needs the sketch on the sample side (n < p_total)")
     if transposed:
         small, tall = "n", "p"
-        Z = ops.import_panel(omega, "n")
+        if first is not None:
+            Z, first_tall = first
+        else:
+            Z = ops.import_panel(omega, "n")
     else:
         small, tall = "p", "n"
         Z = ops.import_panel(omega[p_offset:p_offset + p_loc], "p")
@@ -291,7 +308,7 @@ def sharded_rsvd(ops, comm: Comm, k: int, p_total: int, p_offset: int, n_oversam
 
     Tv, Sv, s = _rsvd_panels(ops, lambda P, f: to_side(P, tall, f), lambda P, f: to_side(P, small, f),
                              lambda P: gram(P, small), lambda P: gram(P, tall), Z, l, k, n_iter,
-                             _orth_tall(n if tall == "n" else p_total, Z.shape[1], _prec_power(ops)))
+                             _orth_tall(n if tall == "n" else p_total, Z.shape[1], _prec_power(ops)), first_tall=first_tall)
     Vp, Up = (Tv, Sv) if transposed else (Sv, Tv)
     sign = _sign_from_extrema(comm, ops, Vp, p_loc, k) if flip else None
     if device_out:   # results stay in HBM (torch tensors); nothing crosses PCIe
@@ -429,16 +446,64 @@ def sharded_preprocess(ctx, X_local, comm: Comm, center=True, standardize=False,
     return mat, st
 
 
+def sharded_fit_first(ctx, X_local, comm: Comm, k: int, p_total: int, center=True, standardize=False, feature_weights=None,
+                      check_nans=True, want_stats=True, n_oversamples: int = 10, omega=None, random_state=None):
+    """`sharded_preprocess` and the FIRST product of `sharded_rsvd` in one engine call per rank (engine.fit_first /
+    eofx_fit_first_f32): the statistics of the shard ride on X_g^T Omega, which is local to the rank -- no communication,
+    one read of the field less.  Only where the fused pass applies on EVERY shard's shape (n < p_total, sketch narrower than
+    its panel); the engine falls back by itself on a rank whose shard holds NaNs, and if that changed the global shape
+    (dropped features or samples) the precomputed product is discarded.
+    -> (ResidentMatrix, stats as `sharded_preprocess`, first = (Z, Yt) for `sharded_rsvd(..., first=first)` or None)"""
+    from . import engine
+
+    X_local = engine._f32c(X_local)
+    n, p_loc = X_local.shape
+    l_req = int(k) + int(n_oversamples)
+    usable = n < p_total and l_req < n and l_req % 32 != 0 and l_req < 64 and ctx.precision[0] == "f16x3"
+    if not usable:
+        mat, st = sharded_preprocess(ctx, X_local, comm, center, standardize, feature_weights, check_nans, want_stats)
+        return mat, st, None
+    if omega is None:
+        omega = engine.sketch_matrix(n, l_req, random_state)
+    elif hasattr(omega, "result"):
+        omega = omega.result()
+    n_pad = (n + 511) // 512 * 512
+    Z = engine.panel_import(ctx, np.ascontiguousarray(omega[:n], dtype=np.float32), n_pad, engine.panel_width(l_req))
+    mat, st, Yt = engine.fit_first(ctx, X_local, Z, l_req, center, standardize, feature_weights, check_nans, want_stats)
+    counts = _gather_counts(comm, mat.p)
+    st["p_total"] = int(counts.sum())
+    st["p_offset"] = int(counts[:comm.rank].sum())
+    vs_local = st["valid_sample"]
+    st["valid_sample"] = combine_sample_masks(comm, vs_local, mat.p, check_nans)
+    st["total_variance_local"] = st["total_variance"]
+    st["total_variance"] = _sum_scalar(comm, st["total_variance"])
+    # the precomputed product stands only if no rank dropped anything: same n everywhere, n still below the global p
+    ok = Yt is not None and mat.n == n and st["p_total"] > n
+    flag = _sum_scalar(comm, 0.0 if ok else 1.0)
+    first = (Z, Yt) if flag == 0.0 else None
+    return mat, st, first
+
+
 def sharded_eof_fit(ctx, X_local, comm: Comm, n_modes: int, center=True, standardize=False, feature_weights=None,
                     check_nans=True, random_state=None, n_oversamples: int = 10, n_iter="auto", omega=None,
                     device_out: bool = False):
     """`EOF.fit` (single/eof.py:85-118) with the space axis sharded: X_local is this rank's
     (n, P_g) slice of the stacked raw field.  Returns the DataContainer entries as a dict; `components`
-    holds this rank's rows, everything else is replicated."""
-    mat, st = sharded_preprocess(ctx, X_local, comm, center, standardize, feature_weights, check_nans)
+    holds this rank's rows, everything else is replicated.  Where the shapes allow, every rank takes the statistics of its
+    shard during the first product X_g^T Omega (`sharded_fit_first`: one read of the field less, no extra communication)."""
+    from . import engine
+
+    n = X_local.shape[0]
+    p_raw_total = int(_gather_counts(comm, X_local.shape[1]).sum())
+    if omega is None and n < p_raw_total:     # one draw for both steps (scikit-learn's stream for this seed)
+        omega = engine.sketch_matrix(n, int(n_modes) + int(n_oversamples), random_state)
+    mat, st, first = sharded_fit_first(ctx, X_local, comm, n_modes, p_raw_total, center, standardize, feature_weights,
+                                       check_nans, True, n_oversamples, omega, random_state)
     ops = HipPanelOps(ctx, mat)
+    if omega is not None and omega.shape[0] != min(mat.n, st["p_total"]):
+        omega = None                            # samples / features dropped: the driver draws for the compacted shape
     U, s, V = sharded_rsvd(ops, comm, n_modes, st["p_total"], st["p_offset"], n_oversamples, n_iter,
-                           random_state=random_state, omega=omega, device_out=device_out)
+                           random_state=random_state, omega=omega, device_out=device_out, first=first)
     s64 = np.asarray(s, dtype=np.float64)
     return dict(input_data=mat, components=V, scores=U * (s if not device_out else ops.e._torch().as_tensor(s, device=U.device)),
                 norms=s64, explained_variance=s64 ** 2 / (mat.n - 1), total_variance=st["total_variance"],
