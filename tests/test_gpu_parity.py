@@ -380,8 +380,9 @@ def test_sharded_fused_first_pass_world1(ctx):
     Xn = X.clone()
     Xn[:, 100:140] = float("nan")
     mat3, st3, first3 = sharded.sharded_fit_first(ctx, Xn, comm, k, p, random_state=9)
-    assert first3 is None and not st3["fused"] and st3["p_total"] == p - 40       # compacted: the driver redoes the product
-    U3, s3, V3 = sharded.sharded_rsvd(sharded.HipPanelOps(ctx, mat3), comm, k, st3["p_total"], 0, random_state=9)
+    # the engine fell back to the statistics pass + compaction by itself and still handed over the first product
+    assert not st3["fused"] and st3["p_total"] == p - 40 == mat3.p and first3 is not None and first3[1].shape[0] == mat3.p_pad
+    U3, s3, V3 = sharded.sharded_rsvd(sharded.HipPanelOps(ctx, mat3), comm, k, st3["p_total"], 0, random_state=9, first=first3)
     ref = orc.eof_fit(Xn.cpu().numpy().astype(np.float64), k, random_state=9)
     _check_factors(U3, s3, V3, ref, k)
     mat3.free()
