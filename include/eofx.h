@@ -66,6 +66,8 @@ int eofx_abi_version(void);
 int eofx_ctx_create(int device, void *stream, eofx_ctx **out);
 int eofx_ctx_destroy(eofx_ctx *ctx);
 int eofx_ctx_synchronize(eofx_ctx *ctx);
+/* Re-bind the context to another hipStream_t (work queued on the old stream is awaited first).                  */
+int eofx_ctx_set_stream(eofx_ctx *ctx, void *stream);
 const char *eofx_last_error(const eofx_ctx *ctx);
 /* Destroyed resident matrices leave their HBM buffers in a per-context cache (allocating
  * tens of GB costs more than a fit); eofx_ctx_trim returns that cache to the device. */

@@ -357,6 +357,29 @@ def test_sharded_world1_equals_driver_bitwise(ctx):
         assert np.array_equal(a, b)
 
 
+def test_context_on_a_non_default_stream():
+    """A context created inside `torch.cuda.stream(s)` runs on s (eofx_ctx_create takes torch's current stream), so torch
+    work issued on s between engine calls is ordered with the engine's kernels; `use_stream` re-binds.  Same results as on
+    the default stream, bit for bit."""
+    import torch
+    from xeofs_amd import engine
+
+    X = torch.as_tensor(_field(300, 2048, seed=31), device="cuda")
+    ref = engine.fit(engine.default_context(0), X, 6, random_state=1)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        c2 = engine.Context(0)
+        Y = X * 1.0                                   # produced on `side`: only ordered with a context that runs there
+        got = engine.fit(c2, Y, 6, random_state=1)
+        assert np.array_equal(got[3], ref[3]) and np.array_equal(got[4], ref[4])
+    c2.use_stream(torch.cuda.default_stream())
+    got2 = engine.fit(c2, X, 6, random_state=1)
+    assert np.array_equal(got2[3], ref[3])
+    for r in (ref, got, got2):
+        r[0].free()
+    c2.close()
+
+
 def test_sharded_fused_first_pass_world1(ctx):
     """The feature-sharded fit with the statistics taken during each rank's first product (`sharded_fit_first` ->
     `eofx_fit_first_f32`, then `sharded_rsvd(first=...)`): at world size 1 the panel-level driver and the one-call engine

@@ -30,6 +30,7 @@ SIGNATURES = {
     "eofx_ctx_create": (_int, [_int, _vp, C.POINTER(_vp)]),
     "eofx_ctx_destroy": (_int, [_vp]),
     "eofx_ctx_synchronize": (_int, [_vp]),
+    "eofx_ctx_set_stream": (_int, [_vp, _vp]),
     "eofx_last_error": (C.c_char_p, [_vp]),
     "eofx_ctx_trim": (_int, [_vp]),
     "eofx_ctx_set_precision": (_int, [_vp, _int, _int]),

@@ -229,6 +229,17 @@ extern "C" int eofx_ctx_destroy(eofx_ctx* ctx) {
   delete ctx;
   return EOFX_OK;
 }
+// Move the context to another HIP stream (everything already queued on the old one is awaited first).  The Python shell
+// binds a context to torch's CURRENT stream, so that torch operations between engine calls (collectives of the sharded
+// driver, the model classes' glue) are ordered with the engine's kernels on any stream, not only on the default one.
+extern "C" int eofx_ctx_set_stream(eofx_ctx* ctx, void* stream) {
+  if (!ctx) return EOFX_ERR_ARG;
+  CHK(set_device(ctx));
+  if ((hipStream_t)stream == ctx->stream) return EOFX_OK;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->stream = (hipStream_t)stream;
+  return EOFX_OK;
+}
 extern "C" int eofx_ctx_synchronize(eofx_ctx* ctx) {
   if (!ctx) return EOFX_ERR_ARG;
   CHK(set_device(ctx));

@@ -31,8 +31,19 @@ class Context:
     """One GPU + one HIP stream (eofx_ctx)."""
 
     def __init__(self, device: int = 0, stream: int | None = None):
+        """stream: a hipStream_t handle; None = torch's CURRENT stream on `device` at construction (the default stream
+        unless the caller is inside `torch.cuda.stream(...)`), so torch operations issued between engine calls stay ordered
+        with the engine's kernels.  `use_stream` re-binds later."""
         self.lib = _lib.load()
         h = C.c_void_p()
+        if stream is None:
+            try:
+                import torch
+
+                if torch.cuda.is_available():
+                    stream = int(torch.cuda.current_stream(int(device)).cuda_stream)
+            except Exception:
+                stream = None
         rc = self.lib.eofx_ctx_create(int(device), C.c_void_p(stream or 0), C.byref(h))
         if rc != 0:
             raise _lib.EofxError(
@@ -44,6 +55,13 @@ class Context:
 
     def synchronize(self):
         raise_for(self.lib.eofx_ctx_synchronize(self.handle), self.handle)
+
+    def use_stream(self, stream=None):
+        """bind the context to a hipStream_t handle / a torch.cuda.Stream (None: torch's current stream on this device)"""
+        if stream is None:
+            stream = _torch().cuda.current_stream(self.device)
+        handle = int(getattr(stream, "cuda_stream", stream) or 0)
+        raise_for(self.lib.eofx_ctx_set_stream(self.handle, C.c_void_p(handle)), self.handle)
 
     def set_precision(self, power="f16x3", final="f16x3"):
         """Arithmetic of the matrix passes: "f16x3" (scaled split-fp16 MFMA, default), "f32" (exact-f32
