@@ -352,16 +352,17 @@ int eofx_cpanel_combine_f32(eofx_ctx *ctx, const float *P1, const float *P2, int
 int eofx_panel_colargminmax_f32(eofx_ctx *ctx, const float *P, int64_t rows, int L, int64_t *amax,
                                 int64_t *amin);
 
-/* ---- rotation of loadings (EOFRotator: linalg/_numpy/_rotation.py:6-187), up to 64 modes ------
+/* ---- rotation of loadings (EOFRotator: linalg/_numpy/_rotation.py:6-187), up to 256 modes -----
  * eofx_panel_row_normalize_f32: Kaiser normalisation out[r,:] = P[r,:] / (||P[r,:]|| + eps).
  * eofx_panel_rot_step_f64: one pass over the normalised loadings X (rows_pad x L):
  *   per row b = x R (float64); mode 0 (one Varimax iteration, _rotation.py:166-176):
  *   G = X^T (b * (b^2 - aux)), aux[j] = alpha * sum_r b_rj^2;  mode 1 (Promax regression terms,
  *   _rotation.py:62-69): G = B^T ((b/aux) |b/aux|^(power-1)), aux[j] = max_r |b_rj|.
- *   R, aux, G are device float64 (L x L, L, L x L).
- *   modes 2 / 3: the same two steps for COMPLEX loadings held as a [Re (32) | Im (32)] panel (the rotation of
- *   ComplexEOF / HilbertEOF models, eof_rotator.py:294-400): R is the real 64 x 64 embedding [[Rr, Ri], [-Ri, Rr]] of the
- *   complex rotation matrix, aux[j] = aux[j + 32] the per-mode value, |b_j|^2 pairs column j with j + 32, and G holds
+ *   R, aux, G are device float64 (L x L, L, L x L); L = 32, 64 (one workgroup per row tile) or 128, 256 (G cut
+ *   into column blocks of 64, one workgroup each; aux must be padded with 0 (even modes) / 1 (odd modes)).
+ *   modes 2 / 3: the same two steps for COMPLEX loadings held as a [Re (L/2) | Im (L/2)] panel, L >= 64 (the rotation of
+ *   ComplexEOF / HilbertEOF models, eof_rotator.py:294-400): R is the real L x L embedding [[Rr, Ri], [-Ri, Rr]] of the
+ *   complex rotation matrix (L x L), aux[j] = aux[j + L/2] the per-mode value, |b_j|^2 pairs column j with j + L/2, and G holds
  *   the four real blocks of X^H T = (Xr^T Tr + Xi^T Ti) + i (Xr^T Ti - Xi^T Tr).
  * eofx_cpanel_colabsmax_f32: max over the rows of |column| for the L/2 complex columns of such a panel (device out). */
 int eofx_panel_row_normalize_f32(eofx_ctx *ctx, const float *P, int64_t rows_pad, int L, float *out);

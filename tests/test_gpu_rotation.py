@@ -22,13 +22,14 @@ def _loadings(seed, p, m):
     return L.astype(np.float32)
 
 
-@pytest.mark.parametrize("p,m", [(700, 3), (5000, 10), (70000, 33)])
+@pytest.mark.parametrize("p,m", [(700, 3), (5000, 10), (70000, 33), (9000, 100), (40000, 200), (777, 256)])
 def test_rot_step_matches_numpy(ctx, p, m):
+    """the step kernel (<= 64 columns) and its column-blocked variant (128 / 256-wide panels) against float64 numpy"""
     import torch
-    from xeofs_amd import engine
+    from xeofs_amd import engine, rotation
 
     Lh = _loadings(0, p, m)
-    L = engine.panel_width(m)
+    L = rotation._rot_width(m)
     rows_pad = (p + 511) // 512 * 512
     P = engine.panel_import(ctx, Lh, rows_pad, L)
     Xn = engine.panel_row_normalize(ctx, P)

@@ -3571,11 +3571,33 @@ extern "C" int eofx_cpanel_colabsmax_f32(eofx_ctx* ctx, const float* P, int64_t 
   return EOFX_OK;
 }
 
+template <int LW>
+static int launch_rot_step_wide(eofx_ctx* ctx, const float* X, int64_t rows_pad, const double* R, const double* aux, int mode,
+                                double power, double* G) {
+  constexpr size_t lds = sizeof(float) * 32 * (LW + 4) + sizeof(double) * 32 * (LW + 2) + sizeof(double) * 32 * 66;
+  auto kern = rot_step_wide_kernel<LW>;
+  HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  // one workgroup (two waves per SIMD) per CU: 256 / 512 workgroups in all
+  const int nbx = (int)std::max<int64_t>(1, std::min<int64_t>((rows_pad + 31) / 32, LW == 256 ? 64 : 256));
+  CHK(arena_reserve(ctx, (size_t)(nbx + 1) * LW * LW * sizeof(double) + 4096));
+  ArenaScope scope(ctx);
+  ARENA(double, part, (size_t)nbx * LW * LW);
+  hipLaunchKernelGGL(kern, dim3(nbx, LW / 64), dim3(512), lds, ctx->stream, X, rows_pad, R, aux, mode, power, part);
+  KCHK();
+  const int64_t count = (int64_t)LW * LW;
+  hipLaunchKernelGGL(f64_reduce_kernel, dim3((int)((count + 63) / 64)), dim3(256), 0, ctx->stream, part, G, count, nbx);
+  KCHK();
+  return EOFX_OK;
+}
+
 extern "C" int eofx_panel_rot_step_f64(eofx_ctx* ctx, const float* X, int64_t rows_pad, int L, const double* R,
                                        const double* aux, int mode, double power, double* G) {
-  if (!ctx || !X || !R || !aux || !G || L > 64 || L % 32 || mode < 0 || mode > 3 || (mode >= 2 && L != 64))
-    return set_err(ctx, EOFX_ERR_ARG, "bad argument (L <= 64; the complex modes 2 / 3 need the 32 | 32 panel)");
+  if (!ctx || !X || !R || !aux || !G || (L != 32 && L != 64 && L != 128 && L != 256) || mode < 0 || mode > 3 ||
+      (mode >= 2 && L < 64))
+    return set_err(ctx, EOFX_ERR_ARG, "bad argument (L = 32, 64, 128 or 256; the complex modes 2 / 3 need a [Re | Im] panel of L >= 64)");
   CHK(set_device(ctx));
+  if (L == 128) return launch_rot_step_wide<128>(ctx, X, rows_pad, R, aux, mode, power, G);
+  if (L == 256) return launch_rot_step_wide<256>(ctx, X, rows_pad, R, aux, mode, power, G);
   const int nbx = (int)std::max<int64_t>(1, std::min<int64_t>((rows_pad + 31) / 32, 512));
   CHK(arena_reserve(ctx, (size_t)(nbx + 1) * L * L * sizeof(double) + 4096));
   ArenaScope scope(ctx);

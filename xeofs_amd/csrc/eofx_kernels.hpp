@@ -2418,6 +2418,108 @@ __global__ __launch_bounds__(256) void rot_step_kernel(const float* __restrict__
     }
 }
 
+// The same step for 65 .. 256 modes (panels 128 / 256 wide; complex: 64 / 128 columns per half).  An LW x LW float64
+// accumulator does not fit one workgroup's registers, so G is cut into column blocks of 64: workgroup (x, cb) walks a
+// strided set of 32-row tiles like rot_step_kernel and owns G[:, 64 cb .. 64 cb + 63].  It needs t only for its own
+// columns, hence b = x R only there (plus the block holding the partner parts in the complex Varimax mode; the whole
+// width when the left factor is b, modes 1 / 3 -- the Promax regression, one step per rotation): the float64 matrix
+// work of an iteration stays 2 x rows x LW^2 multiply-adds over the launch.  R (up to 512 KB) is read from L2 in the
+// operand layout of v_mfma_f64_16x16x4_f64 (a k-row of 16 columns = one 128-byte line); 8 waves: b tile (w >> 2,
+// w & 3) of the block, G tile rows LW/128 per wave x 4 column tiles.
+template <int LW>
+__global__ __launch_bounds__(512) void rot_step_wide_kernel(const float* __restrict__ X, int64_t rows,
+                                                            const double* __restrict__ R,
+                                                            const double* __restrict__ aux, int mode, double power,
+                                                            double* __restrict__ Gpart) {
+  static_assert(LW == 128 || LW == 256, "128 / 256-wide panels");
+  constexpr int TR = 32, NCB = LW / 64, XP = LW + 4, DP = LW + 2, HALF = LW / 2, TRW = LW / 128;
+  extern __shared__ __attribute__((aligned(16))) unsigned char rot_smem[];
+  float (*Xs)[XP] = reinterpret_cast<float (*)[XP]>(rot_smem);
+  double (*Ls)[DP] = reinterpret_cast<double (*)[DP]>(rot_smem + sizeof(float) * TR * XP);
+  double (*Ts)[66] = reinterpret_cast<double (*)[66]>(rot_smem + sizeof(float) * TR * XP + sizeof(double) * TR * DP);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int cb = blockIdx.y;             // this workgroup's 64 columns of t and of G
+  const int pb = cb ^ (NCB / 2);         // complex modes: the block with the partner parts (column j pairs with j +- LW/2)
+  const int brow = tid >> 4, bq = 4 * (tid & 15);   // elementwise step: row brow, columns bq .. bq + 3 of the block
+  double auxr[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) auxr[e] = aux[64 * cb + bq + e];
+  const int rt = wave >> 2, ct = wave & 3;
+  f64x4 acc[TRW][4];
+#pragma unroll
+  for (int q = 0; q < TRW; ++q)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) acc[q][y] = f64x4{0.0, 0.0, 0.0, 0.0};
+  for (int64_t r0 = (int64_t)blockIdx.x * TR; r0 < rows; r0 += (int64_t)gridDim.x * TR) {
+    for (int i = tid; i < TR * (LW / 4); i += 512) {
+      const int rr = i / (LW / 4), c4 = (i % (LW / 4)) * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (r0 + rr < rows) v = *reinterpret_cast<const f32x4*>(X + (r0 + rr) * LW + c4);
+      *reinterpret_cast<f32x4*>(&Xs[rr][c4]) = v;
+    }
+    __syncthreads();
+    // b = x R on the column blocks this workgroup needs
+    for (int blk = 0; blk < NCB; ++blk) {
+      if (!((mode & 1) || blk == cb || (mode == 2 && blk == pb))) continue;
+      const double* Rc = R + 64 * blk + 16 * ct + li;
+      f64x4 bt = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+      for (int s = 0; s < LW / 4; ++s)
+        bt = __builtin_amdgcn_mfma_f64_16x16x4f64((double)Xs[16 * rt + li][4 * s + lk], Rc[(4 * s + lk) * LW], bt, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Ls[16 * rt + lk + 4 * r][64 * blk + 16 * ct + li] = bt[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int col = 64 * cb + bq + e;
+      const double b = Ls[brow][col];
+      double t;
+      if (mode >= 2) {
+        const int cr = col & (HALF - 1);
+        const double br_ = Ls[brow][cr], bi_ = Ls[brow][cr + HALF];
+        const double a2 = br_ * br_ + bi_ * bi_;
+        if (mode == 2) {
+          t = b * (a2 - auxr[e]);
+        } else {
+          const double za = sqrt(a2) / auxr[e];
+          t = (power == 1.0 || !(za > 0.0)) ? b / auxr[e] : (b / auxr[e]) * pow(za, power - 1.0);
+        }
+      } else if (mode == 0) {
+        t = b * (b * b - auxr[e]);
+      } else {
+        const double z = b / auxr[e];
+        t = (power == 1.0) ? z : z * pow(fabs(z), power - 1.0);
+      }
+      Ts[brow][bq + e] = t;
+    }
+    __syncthreads();
+    // G[:, block] += left^T t
+#pragma unroll
+    for (int s = 0; s < TR / 4; ++s) {
+#pragma unroll
+      for (int q = 0; q < TRW; ++q) {
+        const int lc_ = 16 * (TRW * wave + q) + li;
+        const double a = (mode & 1) ? Ls[4 * s + lk][lc_] : (double)Xs[4 * s + lk][lc_];
+#pragma unroll
+        for (int y = 0; y < 4; ++y)
+          acc[q][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Ts[4 * s + lk][16 * y + li], acc[q][y], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  double* G = Gpart + (int64_t)blockIdx.x * LW * LW;
+#pragma unroll
+  for (int q = 0; q < TRW; ++q)
+#pragma unroll
+    for (int y = 0; y < 4; ++y)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        G[(int64_t)(16 * (TRW * wave + q) + lk + 4 * r) * LW + 64 * cb + 16 * y + li] = acc[q][y][r];
+}
+
 // Kaiser normalisation: out[r,:] = P[r,:] / (||P[r,:]|| + eps)   (one wave per row quad)
 __global__ __launch_bounds__(256) void row_normalize_kernel(const float* __restrict__ P, int64_t rows, int L,
                                                             double eps, float* __restrict__ out) {

@@ -6,8 +6,8 @@ R = U VT`) is one fused pass over the panel (`eofx_panel_rot_step_f64`, float64 
 m x m SVD on the host; `W = diag(R^T (X^T X) R)` comes from the m x m Gram matrix computed once.
 Convergence test, error and outputs are the reference's.
 
-More than 64 modes (up to 256; rare) keep the same driver on 128 / 256-wide panels; the step is then three library
-products in float64 per block of rows (`_rot_step_wide`) instead of the fused kernel.
+More than 64 modes (up to 256; rare) keep the same driver on 128 / 256-wide panels: the same entry runs the
+column-blocked variant of the step kernel (`rot_step_wide_kernel`), still one pass over the panel per iteration.
 """
 
 from __future__ import annotations
@@ -17,7 +17,7 @@ import numpy as np
 from . import engine
 
 MAX_ROT_MODES = 256
-FUSED_ROT_MODES = 64      # widest panel of the fused step kernel
+FUSED_ROT_MODES = 64      # widest panel of the single-workgroup step kernel (wider ones: its column-blocked variant)
 
 
 def _dev(a, like):
@@ -37,28 +37,8 @@ def _rot_width(m):
     return engine.panel_width(m) if m <= FUSED_ROT_MODES else (128 if m <= 128 else 256)
 
 
-def _rot_step_wide(ctx, X, R, aux, mode, power=1.0, block=1 << 17):
-    """The step of `eofx_panel_rot_step_f64` for panels wider than the fused kernel takes (modes 0 / 1 of its contract:
-    G = X^T (b (b^2 - aux)) or G = b^T (z |z|^(power-1)), b = X R, z = b / aux), float64, block of rows by block of rows
-    through the library's GEMM."""
-    torch = engine._torch()
-    L = X.shape[1]
-    G = torch.zeros((L, L), dtype=torch.float64, device=X.device)
-    for r0 in range(0, X.shape[0], block):
-        x = X[r0:r0 + block].double()
-        b = x @ R
-        if mode == 0:
-            G += x.T @ (b * (b * b - aux))
-        else:
-            z = b / aux
-            G += b.T @ (z if power == 1.0 else z * z.abs().pow(power - 1.0))
-    return G
-
-
 def _rot_step(ctx, X, R, aux, mode, power=1.0):
-    if X.shape[1] <= FUSED_ROT_MODES:
-        return engine.panel_rot_step(ctx, X, R, aux, mode, power)
-    return _rot_step_wide(ctx, X, R, aux, mode, float(power))
+    return engine.panel_rot_step(ctx, X, R, aux, mode, power)
 
 
 def promax(ctx, loadings: np.ndarray, power: int = 1, max_iter: int = 1000, rtol: float = 1e-8):
@@ -153,7 +133,7 @@ MAX_CROT_MODES = 128
 
 
 def _cwidth(m):
-    """complex columns per panel half: 32 (fused step kernel), else 64 / 128 (library-GEMM step)"""
+    """complex columns per panel half: 32, 64 or 128 (panels of 64 / 128 / 256 real columns)"""
     return CH if m <= CH else (64 if m <= 64 else 128)
 
 
@@ -175,38 +155,21 @@ def _cblocks(G, m, ch=CH):
     return (rr + ii) + 1j * (ri - ir)
 
 
-def _crot_step(ctx, X, R, auxh, mode, power, ch, m, block=1 << 17):
+def _crot_step(ctx, X, R, auxh, mode, power, ch, m):
     """One step of the complex loop on the [Re | Im] panel X: the complex m x m matrix X^H (b (|b|^2 - aux)) (mode 2) or
-    b^H ((b / aux) (|b| / aux)^(power-1)) (mode 3), b = X R.  32 columns per half: the fused kernel (modes 2 / 3 of
-    `eofx_panel_rot_step_f64`); wider: complex128 library GEMMs block of rows by block of rows."""
-    if ch == CH:
-        aux = np.zeros(2 * ch) if mode == 2 else np.ones(2 * ch)
-        aux[:m] = aux[ch:ch + m] = auxh
-        G = engine.panel_rot_step(ctx, X, _dev(_cembed(R, ch), X), _dev(aux, X), mode, float(power))
-        return _cblocks(G.cpu().numpy(), m, ch)
-    torch = engine._torch()
-    Rc = torch.zeros((ch, ch), dtype=torch.complex128, device=X.device)
-    Rc[:m, :m] = torch.as_tensor(np.ascontiguousarray(R), device=X.device)
-    a = torch.zeros(ch, dtype=torch.float64, device=X.device) if mode == 2 else torch.ones(ch, dtype=torch.float64, device=X.device)
-    a[:m] = torch.as_tensor(np.asarray(auxh, dtype=np.float64), device=X.device)
-    G = torch.zeros((ch, ch), dtype=torch.complex128, device=X.device)
-    for r0 in range(0, X.shape[0], block):
-        x = torch.complex(X[r0:r0 + block, :ch].double(), X[r0:r0 + block, ch:].double())
-        b = x @ Rc
-        a2 = b.real * b.real + b.imag * b.imag
-        if mode == 2:
-            G += x.conj().T @ (b * (a2 - a))
-        else:
-            z = b / a
-            G += b.conj().T @ (z if power == 1 else z * (a2.sqrt() / a).pow(power - 1.0))
-    return G[:m, :m].cpu().numpy()
+    b^H ((b / aux) (|b| / aux)^(power-1)) (mode 3), b = X R -- modes 2 / 3 of `eofx_panel_rot_step_f64` with R in its real
+    embedding, for 32, 64 or 128 columns per half."""
+    aux = np.zeros(2 * ch) if mode == 2 else np.ones(2 * ch)
+    aux[:m] = aux[ch:ch + m] = auxh
+    G = engine.panel_rot_step(ctx, X, _dev(_cembed(R, ch), X), _dev(aux, X), mode, float(power))
+    return _cblocks(G.cpu().numpy(), m, ch)
 
 
 def cpromax_panel(ctx, loadings: np.ndarray, power: int = 1, max_iter: int = 1000, rtol: float = 1e-8, col_scale=None):
     """`promax_panel` for complex loadings [p, m]: -> ([Re | Im] panel on the device, p, m, complex rotation
     matrix, complex phi).  Up to 32 modes every step of the reference loop is the same fused pass
     (`eofx_panel_rot_step_f64`, modes 2 / 3) with the complex m x m matrices in their real embedding; 33 .. 128 modes
-    (rare) run the step as complex128 library GEMMs on 64 / 128-column halves (`_crot_step`)."""
+    (rare) use 64 / 128-column halves: the same entry, column-blocked kernel."""
     loadings = np.asarray(loadings)
     p, m = loadings.shape
     if m < 2:
