@@ -296,6 +296,71 @@ def test_engine_complex_rsvd_vs_exact(ctx, n, p, k, prec):
     A.free(); B.free()
 
 
+@pytest.mark.parametrize("n,p,k,both_in_place", [(300, 1536, 6, False), (1000, 700, 12, False), (260, 2500, 20, True),
+                                                  (640, 1024, 5, True)])
+def test_complex_rsvd_lean_layout(ctx, n, p, k, both_in_place):
+    """The lean layout of the complex path: Re = the raw field in place (Scaler map on the fly),
+    Im = the output of the Hilbert stage in its sample-contiguous layout only (or: both parts of a complex input in
+    place).  `eofx_rsvd_c64` then streams every part in a layout it has (atb_f16 / axb_f16 + cpanel_combine) instead of
+    the two-matrix launch over four written layouts.  Checked against the exact complex SVD of the same analytic
+    signal, against the written-layout path (same sketch), and that no layout got written on the way."""
+    from xeofs_amd import engine
+
+    rng = np.random.default_rng(7 * n + k)
+    t = np.arange(n)[:, None]
+    x = np.linspace(0, 2 * np.pi, p)[None, :]
+    X = 0.002 * rng.standard_normal((n, p))
+    for j in range(k + 4):          # k + 4 travelling waves with geometrically decaying amplitudes: every tested mode is signal
+        X += 6.0 * 0.85 ** j * np.cos((0.05 + 0.043 * j) * t - (1 + j % 7) * x + 0.3 * j)
+    X = (X + 3.0 + 0.5 * rng.standard_normal(p)).astype(np.float32)              # uncentred: the Scaler map centres
+    om = engine.sketch_matrix(min(n, p), k + 10, 3)
+    if both_in_place:
+        Y = np.ascontiguousarray(np.roll(X, 7, axis=0) * 0.7 + 1.0, dtype=np.float32)
+        A, _ = engine.preprocess(ctx, X, in_place=True)
+        B, _ = engine.preprocess(ctx, Y, in_place=True)
+        Aw, _ = engine.preprocess(ctx, X)
+        Bw, _ = engine.preprocess(ctx, Y)
+    else:
+        A, _ = engine.preprocess(ctx, X, in_place=True)
+        assert A.layout() == (False, True) and not A.has_sample_layout()
+        B, _ = engine.hilbert(ctx, A, "exp", 0.2)
+        assert not A.has_sample_layout()                       # built for the kernel only
+        assert B.layout()[0] is False and B.has_sample_layout()
+        Aw, _ = engine.preprocess(ctx, X)
+        Bw, _ = engine.hilbert(ctx, Aw, "exp", 0.2)
+        assert Bw.layout()[0] is True
+    U, s, V = engine.rsvd_c64(ctx, A, B, k, omega=om)
+    assert A.layout() == (False, True) and B.layout()[0] is False        # nothing was written for the passes
+    if not both_in_place:
+        assert not A.has_sample_layout()
+    Uw, sw, Vw = engine.rsvd_c64(ctx, Aw, Bw, k, omega=om)
+    U2, s2, V2 = engine.rsvd_c64(ctx, A, B, k, omega=om)
+    assert np.array_equal(s, s2) and np.array_equal(V, V2) and np.array_equal(U, U2)     # bitwise reproducible
+    Z = Aw.download().astype(np.float64) + 1j * Bw.download().astype(np.float64)
+    Ue, se, Vhe = np.linalg.svd(Z, full_matrices=False)
+    assert np.all(np.abs(s - se[:k]) <= 1e-5 * se[:k] + 2e-6 * se[0]), (s, se[:k])
+    assert np.all(np.abs(s - sw) <= 2e-6 * se[0])
+    gaps = np.minimum(np.abs(np.diff(se[:k + 1])), np.r_[np.inf, np.abs(np.diff(se[:k]))]) / se[:k]
+    for j in range(k):
+        if gaps[j] > 1e-2 and se[j] > 1e-3 * se[0]:
+            assert abs(np.vdot(Vhe[j].conj(), V[:, j])) >= 1 - 1e-5, j
+            assert abs(np.vdot(Ue[:, j], U[:, j])) >= 1 - 1e-5, j
+    assert np.abs(U.conj().T @ U - np.eye(k)).max() < 2e-5 and np.abs(V.conj().T @ V - np.eye(k)).max() < 2e-5
+    assert (orc.deterministic_sign_multiplier(V.conj().T) == 1).all()
+    # the panel-level driver (eofx_cmat_mul_f32) takes the same lean route
+    from xeofs_amd.complex_svd import complex_rsvd
+
+    Up, sp, Vp = complex_rsvd(ctx, A, B, k, random_state=3)
+    assert np.all(np.abs(sp - se[:k]) <= 1e-5 * se[:k] + 2e-6 * se[0])
+    assert A.layout() == (False, True) and B.layout()[0] is False
+    # consumers that want another layout of Im get it on demand
+    E = np.zeros((p, 2), np.float32); E[0, 0] = E[p - 1, 1] = 1.0
+    assert np.allclose(engine.project(ctx, B, E), Bw.download()[:, [0, p - 1]], atol=1e-5 * np.abs(Z.imag).max())
+    assert np.allclose(B.download(), Bw.download(), atol=1e-6 * np.abs(Z.imag).max())
+    for m in (A, B, Aw, Bw):
+        m.free()
+
+
 def test_complex_eof_standardize(ctx):
     """`ComplexEOF(standardize=True)` -- the reference's own docstring example (xeofs/single/eof.py:298): the Scaler
     divides the complex field by numpy's (real) std of a complex array, sqrt(var Re + var Im) (scaler.py:105-108)."""

@@ -333,10 +333,11 @@ def test_config5_hilbert_complex_full_size(ctx):
     n, nlat, nlon, k = 8000, 720, 1440, 20
     p = nlat * nlon
     X = _device_field(n, nlat, nlon)
-    A, st = engine.preprocess(ctx, X, want_stats=False)
+    A, st = engine.preprocess(ctx, X, want_stats=False, in_place=True)         # lean layout: Re in place, Im^T only
     del X
     torch.cuda.empty_cache()
     B, _ = engine.hilbert(ctx, A, "exp", 0.2)
+    assert A.layout() == (False, True) and not A.has_sample_layout() and B.layout()[0] is False
     cols = np.array([0, 1, 4097, p // 2, p - 1])
     E = np.zeros((p, len(cols)), np.float32)
     E[cols, np.arange(len(cols))] = 1.0
@@ -355,6 +356,7 @@ def test_config5_hilbert_complex_full_size(ctx):
     assert np.linalg.norm(ZV - Us) / np.linalg.norm(Us) < 2e-5
     U2, s2, V2 = engine.rsvd_c64(ctx, A, B, k, random_state=5)
     assert np.array_equal(s, s2) and np.array_equal(V, V2)
+    assert A.layout() == (False, True) and not A.has_sample_layout() and B.layout()[0] is False    # nothing written
     del U2, V2
     _, s3, _ = complex_rsvd(ctx, A, B, k, random_state=5)                      # the panel-level driver: same spectrum
     assert np.allclose(s3, s, rtol=2e-5)

@@ -2777,13 +2777,19 @@ extern "C" int eofx_hilbert_f32(eofx_ctx* ctx, const eofx_mat* a, int padding, d
   const float* hperm = nullptr;
   const float* u = nullptr;
   CHK(get_hilbert_setup(ctx, n, padding ? 1 : 0, padding ? decay_factor : 0.0, P, fused, &chat, &hperm, &u));
+  // An in-place input (the raw field through its Scaler map, no written layout) keeps the stage lean: its
+  // sample-contiguous copy exists only while the kernel runs, and the imaginary part is produced in that layout alone
+  // (eofx_rsvd_c64 streams the pair [raw field, Im^T] directly; any other consumer gets the feature-contiguous layout on
+  // demand through ensure_X).
+  const bool lean = a->raw && a->aff && !a->X && !a->masked;
+  const bool xt_transient = lean && !a->Xt;
   CHK(ensure_Xt(ctx, a));
   // features per FFT batch: real series + half spectrum of about 3 GB together
   int64_t Fc = std::max<int64_t>(1, std::min<int64_t>(p, (int64_t)(3.0e9 / (4.0 * (double)ldw + 8.0 * (double)nh))));
   eofx_mat *mi = nullptr, *mr = nullptr;
-  CHK(mat_alloc(ctx, n, p, &mi));
+  CHK(mat_alloc(ctx, n, p, &mi, !lean));
   int rc = EOFX_OK;
-  if (out_real) rc = mat_alloc(ctx, n, p, &mr);
+  if (out_real) rc = mat_alloc(ctx, n, p, &mr, !lean);
   float* work = nullptr;
   cfloat* spec = nullptr;
   float* coef = nullptr;
@@ -2849,8 +2855,8 @@ extern "C" int eofx_hilbert_f32(eofx_ctx* ctx, const eofx_mat* a, int padding, d
       }
     }
     dim3 grid((int)(n_pad / 64), (int)(p_pad / 64));
-    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, ctx->stream, mi->Xt, n_pad, mi->X, p_pad);
-    if (mr) hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, ctx->stream, mr->Xt, n_pad, mr->X, p_pad);
+    if (mi->X) hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, ctx->stream, mi->Xt, n_pad, mi->X, p_pad);
+    if (mr && mr->X) hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, ctx->stream, mr->Xt, n_pad, mr->X, p_pad);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(&mi->absmax, mi->absmax_dev, sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess && mr)
@@ -2862,6 +2868,11 @@ done:
   pool_give(ctx, work, work_bytes);
   pool_give(ctx, spec, spec_bytes);
   pool_give(ctx, coef, coef_bytes);
+  if (xt_transient && a->Xt) {   // (the stage ends with a stream synchronisation; same-stream reuse is ordered anyway)
+    eofx_mat* am = const_cast<eofx_mat*>(a);
+    pool_give(ctx, am->Xt, (size_t)n_pad * p_pad * sizeof(float));
+    am->Xt = nullptr;
+  }
   if (rc != EOFX_OK) {
     if (mi) eofx_mat_destroy(ctx, mi);
     if (mr) eofx_mat_destroy(ctx, mr);
@@ -3036,9 +3047,48 @@ struct CplxOps {
                        P1, P2, sgn, rows, LP, out);
     return hipGetLastError() == hipSuccess ? EOFX_OK : EOFX_ERR_HIP;
   }
+  // Lean layout (any part that is not held in both written layouts: Re as the raw field in place, Im in the
+  // sample-contiguous layout only -- what eofx_hilbert_f32 leaves for an in-place input -- or both parts of a complex
+  // input in place): every pass streams each part once in a layout it has.  A part whose contraction axis is its
+  // contiguous one goes through axb_f16 (rows streamed along their lines), the other way through atb_f16, and the two
+  // real products meet in cpanel_combine.  `ident` is the identity map (0, 0, 1) for the rows of a written Im^T.
+  bool lean = false;
+  const float* ident = nullptr;
+  int64_t ident_ld = 0;
+  static bool axb_fits(int64_t ld, int64_t cols, int L) {   // the 32-bit offsets of axb_f16 (launch_axb checks them too)
+    const int64_t K = round_up(cols, AXB_KG);
+    return K * (int64_t)L < ((int64_t)1 << 31) && 64 * ld + K < ((int64_t)1 << 30);
+  }
+  int t_part(const eofx_mat* M, const float* Wn, float* out, int prec) {      // M^T W  [p_pad x LP]
+    if (!M->X && M->raw && M->aff && prec == EOFX_PREC_F16X3) {
+      AffView av;
+      av.aff = M->aff;
+      av.ld = M->p_pad;
+      av.rows = (int)M->n;
+      av.cols = M->p;
+      av.masked = M->masked;
+      return launch_atb(ctx, M->raw, M->raw_ld, round_up(M->n, ATB_KG), M->p_pad, Wn, LP, LP, out, prec, M->absmax, nullptr, &av);
+    }
+    if (!M->X && M->Xt && prec == EOFX_PREC_F16X3 && ident && axb_fits(M->n_pad, M->n, LP))   // the rows of M^T times W
+      return launch_axb(ctx, M->Xt, M->n_pad, M->p, M->n, M->p_pad, ident, ident_ld, M->absmax, Wn, LP, out);
+    CHK(ensure_X(ctx, M));
+    return launch_atb(ctx, M->X, M->p_pad, round_up(M->n, ATB_KG), M->p_pad, Wn, LP, LP, out, prec, M->absmax);
+  }
+  int n_part(const eofx_mat* M, const float* Yp, float* out, int prec) {      // M Y  [n_pad x LP]
+    if (!M->Xt && M->raw && M->aff && prec == EOFX_PREC_F16X3 && axb_fits(M->raw_ld, M->p, LP))
+      return launch_axb(ctx, M->raw, M->raw_ld, M->n, M->p, M->n_pad, M->aff, M->p_pad, M->absmax, Yp, LP, out, M->masked);
+    CHK(ensure_Xt(ctx, M));
+    return launch_atb(ctx, M->Xt, M->n_pad, round_up(M->p, ATB_KG), M->n_pad, Yp, LP, LP, out, prec, M->absmax);
+  }
   // feature-side panel = Z^H W
   int zh_mul(const float* Wn, float* Yp, int prec) {
     const int64_t K = round_up(A->n, ATB_KG), M = A->p_pad;
+    if (lean) {
+      CHK(t_part(A, Wn, Yp, prec));
+      CHK(t_part(B, Wn, tmp, prec));
+      amax_forget(ctx, Yp);
+      return combine(Yp, tmp, 1.f, A->p_pad, Yp);
+    }
     if (prec == EOFX_PREC_F16X3) {
       CHK(rot_panel(Wn, 1.f, A->n_pad));
       return launch_atb(ctx, A->X, M, K, M, Wn, LP, LP, Yp, prec, absmax, nullptr, nullptr, B->X, rot);
@@ -3050,6 +3100,12 @@ struct CplxOps {
   // sample-side panel = Z Y
   int z_mul(const float* Yp, float* Wn, int prec) {
     const int64_t K = round_up(A->p, ATB_KG), M = A->n_pad;
+    if (lean) {
+      CHK(n_part(A, Yp, Wn, prec));
+      CHK(n_part(B, Yp, tmp, prec));
+      amax_forget(ctx, Wn);
+      return combine(Wn, tmp, -1.f, A->n_pad, Wn);
+    }
     if (prec == EOFX_PREC_F16X3) {
       CHK(rot_panel(Yp, -1.f, A->p_pad));
       return launch_atb(ctx, A->Xt, M, K, M, Yp, LP, LP, Wn, prec, absmax, nullptr, nullptr, B->Xt, rot);
@@ -3060,6 +3116,27 @@ struct CplxOps {
   }
 };
 
+// lean layout (see CplxOps): some part is not held in both written layouts -- every part is streamed in a layout it has
+// instead of writing the missing ones (64-column panels, split-fp16 passes)
+static bool cplx_lean(const eofx_mat* A, const eofx_mat* B, int LP, int prec_power, int prec_final) {
+  const bool all_written = A->X && A->Xt && B->X && B->Xt;
+  return !all_written && !A->masked && !B->masked && LP == 64 && prec_power == EOFX_PREC_F16X3 && prec_final == EOFX_PREC_F16X3;
+}
+// the identity map for the rows of a written sample-contiguous part (arena memory of the caller's scope)
+static int cplx_lean_setup(eofx_ctx* ctx, CplxOps& ops) {
+  const int64_t n = ops.A->n, il = round_up(n, AXB_KG);
+  float* ident = arena_alloc<float>(ctx, 3 * (size_t)il);
+  if (!ident) return set_err(ctx, EOFX_ERR_NOMEM, "arena exhausted (identity map)");
+  std::vector<float> h(3 * (size_t)il, 0.f);
+  for (int64_t i = 0; i < n; ++i) h[2 * (size_t)il + i] = 1.f;     // (shift hi, shift lo, scale) = (0, 0, 1); scale 0 beyond n
+  CHK(copy_in(ctx, ident, h.data(), sizeof(float) * h.size()));
+  HIPCHK(hipStreamSynchronize(ctx->stream));                         // h leaves scope
+  ops.lean = true;
+  ops.ident = ident;
+  ops.ident_ld = il;
+  return EOFX_OK;
+}
+
 // One pass of the complex operator on a [Re | Im] panel (the step the feature-sharded driver all-reduces around):
 // conj_left = 1: out [p_pad x L] = Z^H W for W [n_pad x L]; conj_left = 0: out [n_pad x L] = Z Y for Y [p_pad x L].
 // In the default precision this is ONE launch of the streaming kernel over both parts (as inside eofx_rsvd_c64).
@@ -3069,9 +3146,12 @@ extern "C" int eofx_cmat_mul_f32(eofx_ctx* ctx, const eofx_mat* A, const eofx_ma
   if (A->n != B->n || A->p != B->p) return set_err(ctx, EOFX_ERR_SHAPE, "real and imaginary parts must have the same shape");
   if (L != 64 && L != 128) return set_err(ctx, EOFX_ERR_ARG, "complex panels are 64 or 128 real columns wide");
   CHK(set_device(ctx));
-  CHK(ensure_X(ctx, A));
-  CHK(ensure_X(ctx, B));
   const int prec = final_pass ? ctx->prec_final : ctx->prec_power;
+  const bool lean = cplx_lean(A, B, L, prec, prec);
+  if (!lean) {
+    CHK(ensure_X(ctx, A));
+    CHK(ensure_X(ctx, B));
+  }
   const int64_t big = std::max(A->n_pad, A->p_pad);
   size_t need = (size_t)2 * big * L * 4 + (8 << 20);
   need += (size_t)2 * big * L * 4;   // the two partial results of a two-matrix launch that needs no split
@@ -3081,6 +3161,7 @@ extern "C" int eofx_cmat_mul_f32(eofx_ctx* ctx, const eofx_mat* A, const eofx_ma
   ARENA(float, rot, (size_t)big * L);
   ARENA(float, tmp, (size_t)big * L);
   CplxOps ops{ctx, A, B, L, rot, tmp, std::max(A->absmax, B->absmax)};
+  if (lean) CHK(cplx_lean_setup(ctx, ops));
   CHK(conj_left ? ops.zh_mul(Pin, Pout, prec) : ops.z_mul(Pin, Pout, prec));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return EOFX_OK;
@@ -3101,8 +3182,11 @@ extern "C" int eofx_rsvd_c64(eofx_ctx* ctx, const eofx_mat* A, const eofx_mat* B
   if (n_iter < 0) n_iter = k < 0.1 * (double)r ? 7 : 4;
   const int h = l <= 32 ? 32 : 64, LP = 2 * h;
   const int ko = (int)round_up(k, 16), Lo = 2 * ko;       // output panels [Re(ko) | Im(ko)]
-  CHK(ensure_X(ctx, A));   // (ensure_X builds the sample-contiguous layout first where that is missing too)
-  CHK(ensure_X(ctx, B));
+  const bool lean = cplx_lean(A, B, LP, ctx->prec_power, ctx->prec_final);
+  if (!lean) {
+    CHK(ensure_X(ctx, A));   // (ensure_X builds the sample-contiguous layout first where that is missing too)
+    CHK(ensure_X(ctx, B));
+  }
   const bool transposed = n < p;     // A_op = Z^H: tall side = features
   const int64_t small = transposed ? n : p;
   const int64_t small_pad = transposed ? A->n_pad : A->p_pad, tall_pad = transposed ? A->p_pad : A->n_pad;
@@ -3123,6 +3207,7 @@ extern "C" int eofx_rsvd_c64(eofx_ctx* ctx, const eofx_mat* A, const eofx_mat* B
   ARENA(double, G, (size_t)LP * LP);
   ARENA(double, Ed, (size_t)LP * LP);
   CplxOps ops{ctx, A, B, LP, rot, tmp, std::max(A->absmax, B->absmax)};
+  if (lean) CHK(cplx_lean_setup(ctx, ops));
   const int pp = ctx->prec_power, pf = ctx->prec_final;
   auto fwd = [&](const float* in, float* out, int prec) { return transposed ? ops.zh_mul(in, out, prec) : ops.z_mul(in, out, prec); };
   auto bwd = [&](const float* in, float* out, int prec) { return transposed ? ops.z_mul(in, out, prec) : ops.zh_mul(in, out, prec); };

@@ -190,8 +190,15 @@ class ComplexEOF(EOF):
         self.attrs.update({"model": "Complex EOF analysis", "padding": padding, "decay_factor": decay_factor})
         self._params.update({"padding": padding, "decay_factor": decay_factor})
         self.padding, self.decay_factor = padding, decay_factor
-        self.preprocessor_imag = Preprocessor(center, False, use_coslat, check_nans)
-        self.preprocessor.in_place = False      # the Hilbert transform works on the sample-contiguous layout
+        # both parts stay in place where the engine streams them as they lie (eofx_rsvd_c64's lean layout: sketches of up
+        # to 32 complex columns); wider sketches and the Hermitian-Gram route want the written layouts, built in one pass
+        lean = self._lean_ok()
+        self.preprocessor.in_place = lean
+        self.preprocessor_imag = Preprocessor(center, False, use_coslat, check_nans, in_place=lean)
+
+    def _lean_ok(self):
+        n_over = int(dict(self._solver_kwargs).get("n_oversamples", 10))
+        return isinstance(self.n_modes, (int, np.integer)) and int(self.n_modes) + n_over <= 32
 
     def _complex_parts(self, X, dim, weights):
         """preprocess Re and Im of a complex input with the same centring / weights"""
@@ -323,12 +330,20 @@ class HilbertEOF(ComplexEOF):
         self.ctx = self.ctx or engine.default_context()
         self.preprocessor.ctx = self.ctx
         omega = self._sketch_ahead(X, dim)          # drawn on a worker thread while the Hilbert stage runs
+        centred = bool(self._params["center"])
+        # A centred field stays in place (the raw field through the Scaler map): the Hilbert stage then builds the
+        # sample-contiguous layout it works on for the duration of its kernel only and leaves Im in that layout alone.
+        self.preprocessor.in_place = centred and self._lean_ok()
         A = self.preprocessor.fit_transform(X, dim, weights)
         self.sample_dims = self.preprocessor.sample_dims
-        centred = bool(self._params["center"])
         B, A2 = engine.hilbert(self.ctx, A, self.padding, self.decay_factor, want_real=not centred)
         if A2 is not None:          # eof.py:546-555: the analytic signal is re-centred per feature
             A.free()
             A = A2
-        tv = (A.sumsq() + B.sumsq()) / (A.n - 1)
+            tv_re = A.sumsq() / (A.n - 1)
+        elif A.layout()[1] and not A.layout()[0]:    # in place: the Scaler's statistics already hold it (no layout is built)
+            tv_re = float(self.preprocessor.total_variance)
+        else:
+            tv_re = A.sumsq() / (A.n - 1)
+        tv = tv_re + B.sumsq() / (A.n - 1)
         return self._fit_complex(A, B, tv, omega)
