@@ -698,7 +698,7 @@ static int launch_atb(eofx_ctx* ctx, const float* A, int64_t lda, int64_t K, int
   }
   if (best_s > 1) {
     const int64_t count4 = M * L / 4;
-    const int blocks = (int)std::min<int64_t>((count4 + 255) / 256, 4096);
+    const int blocks = (int)std::min<int64_t>((count4 + 255) / 256, amax_out ? 2048 : 4096);   // (one atomic per workgroup)
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, ctx->stream, out, C, count4,
                        best_s, amax_out);
     KCHK();
@@ -780,8 +780,8 @@ static int launch_axb(eofx_ctx* ctx, const float* raw, int64_t ld, int64_t rows,
   }
   if (plan.S > 1) {
     const int64_t count4 = rows_pad * L / 4;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)std::min<int64_t>((count4 + 255) / 256, 4096)), dim3(256), 0, ctx->stream,
-                       out, W, count4, plan.S, amax_out);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)std::min<int64_t>((count4 + 255) / 256, amax_out ? 2048 : 4096)), dim3(256), 0,
+                       ctx->stream, out, W, count4, plan.S, amax_out);
     KCHK();
   }
   return EOFX_OK;
@@ -930,7 +930,7 @@ static int import_panel(eofx_ctx* ctx, const float* src, int64_t rows, int l, fl
     dsrc = tmp;
   }
   const int64_t total = rows_pad * (L / 4);
-  const int blocks = (int)std::min<int64_t>((total + 255) / 256, 8192);
+  const int blocks = (int)std::min<int64_t>((total + 255) / 256, 2048);
   hipLaunchKernelGGL(panel_import_kernel, dim3(blocks), dim3(256), 0, ctx->stream, dsrc, rows, l, P,
                      rows_pad, L, amax_new(ctx, P));
   KCHK();
@@ -2134,7 +2134,7 @@ struct FitFirst {
     HIPCHK(hipMemcpyAsync(hword + 3, ps.absmax, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(m->absmax_dev, ps.absmax, sizeof(unsigned), hipMemcpyDeviceToDevice, ctx->stream));
     // the rank-one correction does not wait for the verdict on the statistics: it is queued behind them
-    hipLaunchKernelGGL(fit_reduce_kernel, dim3((int)std::min<int64_t>((p_pad * (LL / 4) + 255) / 256, 8192)), dim3(256), 0, ctx->stream,
+    hipLaunchKernelGGL(fit_reduce_kernel, dim3((int)std::min<int64_t>((p_pad * (LL / 4) + 255) / 256, 2048)), dim3(256), 0, ctx->stream,
                        part, Yt, p_pad, LL, l, S, P, dcorr, ps.scale, wbar, amax_new(ctx, Yt));
     KCHK();
     if (ctx->profile) HIPCHK(hipEventRecord(ev[3], ctx->stream));

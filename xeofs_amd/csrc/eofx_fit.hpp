@@ -453,11 +453,7 @@ __global__ __launch_bounds__(256) void fit_reduce_kernel(const float* part, floa
     }
     reinterpret_cast<f32x4*>(out)[i] = o;
   }
-  if (amax_out) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(amax_out, __float_as_uint(m));
-  }
+  if (amax_out) amax_commit(m, amax_out);
 }
 
 // ---------------------------------------------------------------------------------

@@ -34,6 +34,25 @@ __device__ __forceinline__ float aff_fma(float x, float sh_hi, float s, float nl
   return __builtin_fmaf(x - sh_hi, s, nls);
 }
 
+// One atomicMax per WORKGROUP for a running maximum kept per thread.  Atomics on one address retire one every ~12 ns
+// whatever the grid does meanwhile, so a kernel that lets every wave of a few thousand workgroups send its own becomes a
+// 0.2 - 0.4 ms kernel however little data it moves (measured: splitk_reduce 193 us with 16 K atomics for 100 MB,
+// fit_reduce 374 us at every size); callers also keep such grids at <= 1024 workgroups.  Every thread of the block
+// must call it (it synchronises).
+__device__ __forceinline__ void amax_commit(float mx, unsigned* __restrict__ amax_out) {
+  __shared__ float amax_red_[16];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if ((threadIdx.x & 63) == 0) amax_red_[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int nw = (int)(blockDim.x >> 6);
+    float m = amax_red_[0];
+    for (int w = 1; w < nw; ++w) m = fmaxf(m, amax_red_[w]);
+    if (m > 0.f) atomicMax(amax_out, __float_as_uint(m));
+  }
+}
+
 // ---------------------------------------------------------------------------------
 // atb_f32: C[M x L] = A[K x M]^T * B[K x L]        (the dominant kernel)
 //
@@ -594,10 +613,7 @@ __global__ __launch_bounds__(256, NB > 2 ? 1 : 2) void atb_f16_kernel(const floa
       for (int q = 0; q < NB; ++q)
 #pragma unroll
         for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fabsf(acc[j][q][r]));
-    mx *= out_scale;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    if (lane == 0 && mx > 0.f) atomicMax(amax_out, __float_as_uint(mx));
+    amax_commit(mx * out_scale, amax_out);
   }
 }
 
@@ -1042,11 +1058,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     reinterpret_cast<f32x4*>(out)[i] = o;
     mx = fmaxf(mx, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
   }
-  if (amax_out) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(amax_out, __float_as_uint(mx));
-  }
+  if (amax_out) amax_commit(mx, amax_out);
 }
 
 // ---------------------------------------------------------------------------------
@@ -1463,11 +1475,7 @@ __global__ __launch_bounds__(256) void panel_matmul_kernel(const float* __restri
       }
     }
   }
-  if (amax_out) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) amx = fmaxf(amx, __shfl_xor(amx, o));
-    if (lane == 0 && amx > 0.f) atomicMax(amax_out, __float_as_uint(amx));
-  }
+  if (amax_out) amax_commit(amx, amax_out);
 }
 
 // per-column max/min over rows [0, rows): partial per block, then a second tiny pass.
@@ -1594,11 +1602,7 @@ __global__ __launch_bounds__(256) void panel_import_kernel(const float* __restri
     reinterpret_cast<f32x4*>(P)[i] = v;
     mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
   }
-  if (amax_out) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(amax_out, __float_as_uint(mx));
-  }
+  if (amax_out) amax_commit(mx, amax_out);
 }
 
 // ---------------------------------------------------------------------------------
