@@ -244,6 +244,26 @@ def test_complex_cpcca_family_vs_oracle(ctx, cls, alpha):
     if not hil:      # transform of the training data reproduces the scores through PCA, whitener and singular vectors
         t1 = m.transform(X=X)
         assert np.abs(t1.values - s1.values).max() < 5e-3 * np.abs(s1.values).max()
+    # diagnostics for every alpha (cpcca.py:342-575 in complex algebra; the residual form of the SCF, the fractions of
+    # variance, the correlation coefficients of the scores) against the oracle's dense restatement
+    d = orc.cpcca_diagnostics(ref)
+    assert np.allclose(m.squared_covariance_fraction().values, d["squared_covariance_fraction"], atol=5e-3)
+    assert np.allclose(m.fraction_variance_X_explained_by_X().values, d["fraction_variance_X_explained_by_X"], atol=5e-3)
+    assert np.allclose(m.fraction_variance_Y_explained_by_Y().values, d["fraction_variance_Y_explained_by_Y"], atol=5e-3)
+    cc = m.cross_correlation_coefficients().values
+    assert np.allclose(np.real(cc), d["cross_correlation_coefficients"], atol=5e-3) and np.abs(np.imag(cc)).max() < 5e-3
+    cx = m.correlation_coefficients_X()
+    assert cx.dims == ("mode_x", "mode_y")
+    assert np.allclose(np.abs(cx.values), np.abs(d["correlation_coefficients_X"]), atol=5e-3)     # (phases are per mode)
+    assert np.allclose(np.abs(m.correlation_coefficients_Y().values), np.abs(d["correlation_coefficients_Y"]), atol=5e-3)
+    # inverse_transform of all scores = the rank-k reconstruction Xw_k T^-1 V^H, un-scaled (cpcca.py:254-271)
+    r1, r2 = m.inverse_transform(*m.scores())
+    for i, (r, F) in enumerate(((r1, A), (r2, B))):
+        Rk = orc._unwhiten(ref[f"scores{i + 1}"] @ ref[f"Q{i + 1}"].conj().T, ref["Tinv"][i]) @ ref["V"][i].conj().T
+        want = Rk + F.reshape(n, -1).mean(axis=0)                # (a Hilbert model: the real part carries the real mean)
+        got = r.values.reshape(n, -1)
+        assert r.dims == (("time", "lat", "lon") if i == 0 else ("time", "y", "x")) and np.iscomplexobj(got)
+        assert np.abs(got - want).max() < 1e-2 * np.abs(want).max(), (cls, i)
     # rotation of a whitened complex model (cpcca_rotator.py:472-600)
     Rot = xe.cross.HilbertCPCCARotator if hil else xe.cross.ComplexCPCCARotator
     rot = Rot(n_modes=3, power=1).fit(m)

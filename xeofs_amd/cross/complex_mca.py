@@ -178,8 +178,9 @@ class ComplexCPCCA(Deferred):
         if self._params["standardize"][i]:
             # scaler.py:105-108 on complex data: numpy's std of a complex array is the real sqrt(var Re + var Im)
             pr.standardize = False
-            s_re, s_im = pr.peek_std(re, dim), pi.peek_std(im, dim)
-            std_c = np.maximum(np.sqrt(s_re ** 2 + s_im ** 2), np.finfo(np.float32).eps)
+            eps = np.finfo(np.float32).eps       # peek_std clips each part at eps: undo that, combine, clip ONCE
+            s_re, s_im = (np.where(v <= eps, 0.0, v) for v in (pr.peek_std(re, dim), pi.peek_std(im, dim)))
+            std_c = np.maximum(np.sqrt(s_re ** 2 + s_im ** 2), eps)
         A = pr.fit_transform(re, dim, weights, std_override=std_c)
         B = pi.fit_transform(im, dim, weights, std_override=std_c)
         return A, B, pr.total_variance + pi.total_variance
@@ -259,6 +260,10 @@ class ComplexCPCCA(Deferred):
         def back(fld, Q, i):      # whitener.inverse_transform_components, then pca.inverse_transform_components
             return fld.back(Q if self.Tinv[i] is None else self.Tinv[i].conj().T @ Q)
 
+        for fld in (fx, fy):             # the resident parts are not read again (transform preprocesses new data and
+            fld.free()                   # projects through the PCA's own panel): give their HBM back
+        self._Su = (fx.S, fy.S)          # unwhitened analysis matrices (host): the diagnostics below work on them
+        self._back = lambda i, Q: back(self.field[i], Q, i)
         self.data = dict(Q1=Q1, Q2=Q2, components1=back(fx, Q1, 0), components2=back(fy, Q2, 1), scores1=scores1,
                          scores2=scores2, singular_values=s, squared_covariance=s ** 2,
                          total_squared_covariance=float((np.abs(Cu) ** 2).sum()), norm1=norm1, norm2=norm2)
@@ -324,13 +329,72 @@ class ComplexCPCCA(Deferred):
     def total_squared_covariance(self):
         return self.data["total_squared_covariance"]
 
+    # ---- diagnostics of cpcca.py:342-575 in complex algebra, in the n x m analysis space (a PCA basis has orthonormal
+    # columns, so Frobenius norms of feature-space residuals equal those of their PC-space coordinates)
+    def _rank_one_terms(self):
+        """mode j: the whitened reconstruction r_j q_j^H un-whitened (whitener.inverse_transform_data: . @ T^-1) is
+        r_j b_j^H with b_j = T^-H q_j"""
+        B = [self.data[f"Q{i + 1}"] if self.Tinv[i] is None else self.Tinv[i].conj().T @ self.data[f"Q{i + 1}"] for i in (0, 1)]
+        return self.data["scores1"], self.data["scores2"], B[0], B[1]
+
+    @staticmethod
+    def _deflated_norms(Sx, Sy, R1, R2, B1, B2, M2):
+        """||(Sx - r1 b1^H)^H (Sy - r2 b2^H)||_F^2 per mode without forming Sx^H Sy: with M = Sx^H Sy the product is
+        D = M - g1 b2^H - b1 g2^H + c b1 b2^H (g1 = Sx^H r2, g2 = Sy^H r1, c = r1^H r2) and ||D||^2 expands into inner
+        products of n-vectors (M2 = ||M||_F^2)."""
+        dot = lambda a, b: (a.conj() * b).sum(axis=0)            # column-wise <a, b>
+        G1, G2 = Sx.conj().T @ R2, Sy.conj().T @ R1              # (m1 x k), (m2 x k)
+        a1, a2b = Sx @ B1, Sy @ B2
+        a1g, a2g = Sx @ G1, Sy @ G2
+        c = dot(R1, R2)
+        nb1, nb2, ng1, ng2 = dot(B1, B1).real, dot(B2, B2).real, dot(G1, G1).real, dot(G2, G2).real
+        return (M2 + nb1 * ng2 + ng1 * nb2 + np.abs(c) ** 2 * nb1 * nb2
+                - 2 * dot(a2g, a1).real - 2 * dot(a2b, a1g).real + 2 * (c * dot(a2b, a1)).real
+                + 2 * (dot(B1, G1) * dot(B2, G2)).real - 2 * (c * nb1 * dot(B2, G2)).real - 2 * (c * dot(G1, B1) * nb2).real)
+
     def squared_covariance_fraction(self):
-        """cpcca.py:418-512 with alpha = 1: the residual form 1 - ||d_X^H d_Y||^2 / ||X^H Y||^2 of a rank-one deflation
-        equals sigma_i^2 / sum sigma^2 (the singular triplets are orthogonal)"""
-        if not all(np.isclose(a, 1.0) for a in self.alpha):
-            raise NotImplementedError("squared_covariance_fraction of the complex models is provided for alpha = 1 (MCA)")
-        scf = self.data["squared_covariance"] / self.data["total_squared_covariance"]
-        return self._mode_array(scf, "squared_covariance_fraction")
+        """cpcca.py:418-512: SCF_i = 1 - ||d_X,i^H d_Y,i||_F^2 / ||X^H Y||_F^2 with d the residual of the un-whitened data
+        after its reconstruction by mode i (clipped at 0) -- for every alpha; with alpha = 1 it equals sigma_i^2 / TSC."""
+        Sx, Sy = self._Su
+        n = Sx.shape[0]
+        R1, R2, B1, B2 = self._rank_one_terms()
+        M2 = self.data["total_squared_covariance"] * (n - 1) ** 2
+        scf = 1 - self._deflated_norms(Sx, Sy, R1, R2, B1, B2, M2) / M2
+        return self._mode_array(np.where(scf < 0, 0, scf), "squared_covariance_fraction")
+
+    def _fve_self(self, i):
+        """cpcca.py:514-639: 1 - ||S - r b^H||_F^2 / ||S||_F^2 per mode"""
+        S = self._Su[i]
+        R, B = self._rank_one_terms()[i], self._rank_one_terms()[2 + i]
+        tot = (np.abs(S) ** 2).sum()
+        res = tot - 2 * ((S @ B).conj() * R).sum(axis=0).real + (np.abs(R) ** 2).sum(0) * (np.abs(B) ** 2).sum(0)
+        return 1 - res / tot
+
+    def fraction_variance_X_explained_by_X(self):
+        return self._mode_array(self._fve_self(0), "fraction_variance_X_explained_by_X")
+
+    def fraction_variance_Y_explained_by_Y(self):
+        return self._mode_array(self._fve_self(1), "fraction_variance_Y_explained_by_Y")
+
+    @staticmethod
+    def _corr(A, B):
+        """cpcca.py:910-1022 method='correlation': columns divided by numpy's (real, population) std of a complex array,
+        then A^H B / (n - 1)"""
+        return (A / A.std(axis=0)).conj().T @ (B / B.std(axis=0)) / (A.shape[0] - 1)
+
+    def cross_correlation_coefficients(self):
+        return self._mode_array(np.diag(self._corr(self.data["scores1"], self.data["scores2"])), "cross_correlation_coefficients")
+
+    def _mode_matrix(self, M, name):
+        k = M.shape[0]
+        return labelled.pack(M, ("mode_x", "mode_y"), {"mode_x": np.arange(1, k + 1), "mode_y": np.arange(1, k + 1)}, name,
+                             dict(self.attrs), self.pre_re[0].fields[0].like)
+
+    def correlation_coefficients_X(self):
+        return self._mode_matrix(self._corr(self.data["scores1"], self.data["scores1"]), "correlation_coefficients_X")
+
+    def correlation_coefficients_Y(self):
+        return self._mode_matrix(self._corr(self.data["scores2"], self.data["scores2"]), "correlation_coefficients_Y")
 
     def covariance_fraction_CD95(self):
         """mca.py:127-189"""
@@ -367,6 +431,56 @@ class ComplexCPCCA(Deferred):
                 S = S / self.data[f"norm{i + 1}"]
             out.append(self.pre_re[i].inverse_transform_scores(S, "scores_" + "XY"[i], self.attrs, fields, vs))
         return out[0] if len(out) == 1 else out
+
+
+    def inverse_transform(self, X=None, Y=None):
+        """base_model_cross_set.py:376-425 + cpcca.py:254-271: scores (with a 'mode' dimension) back to the fields --
+        S conj(Q)^T in the analysis space, un-whitened, out of the PCA basis, then every part un-scaled by its own
+        Scaler (the imaginary part of a Hilbert model carries no mean)."""
+        if X is None and Y is None:
+            raise ValueError("Either X or Y must be provided.")
+        outs = []
+        for i, S in enumerate((X, Y)):
+            if S is None:
+                continue
+            pre = self.pre_re[i]
+            vals, dims, coords, _, _ = labelled.unpack(S)
+            if "mode" not in dims:
+                vals, dims = vals[None], ("mode",) + tuple(dims)
+                coords = dict(coords, mode=np.array([1]))
+            modes = np.asarray(coords["mode"]).astype(int)
+            order = [dims.index("mode")] + [j for j, d in enumerate(dims) if d != "mode"]
+            Sm = np.transpose(vals, order).reshape(len(modes), -1).T.astype(np.complex128)      # (n', k')
+            vs = ~np.isnan(Sm).all(axis=1)
+            Za = Sm[vs] @ self.data[f"Q{i + 1}"][:, modes - 1].conj().T                          # analysis space (n' x m)
+            rec = np.asarray(self._back(i, np.ascontiguousarray(Za.conj().T))).conj().T         # (V T^-H Za^H)^H = Za T^-1 V^H
+            f0 = pre.fields[0]
+            sample_shape = tuple(vals.shape[dims.index(d)] for d in f0.sample_dims)
+            fields = []
+            for f in pre.fields:
+                g = object.__new__(type(f))
+                g.__dict__.update(f.__dict__)
+                g.sample_shape = sample_shape
+                g.coords = dict(f.coords, **{d: coords[d] for d in f.sample_dims if d in coords})
+                fields.append(g)
+            re = pre.inverse_transform_data(rec.real, "reconstructed_data", fields, vs)
+            if self._hilbert:      # un-scale only: inverse(Im) - inverse(0)
+                im = pre.inverse_transform_data(rec.imag, "reconstructed_data", fields, vs)
+                zero = pre.inverse_transform_data(np.zeros_like(rec.imag), "reconstructed_data", fields, vs)
+            else:
+                im = self.pre_im[i].inverse_transform_data(rec.imag, "reconstructed_data", fields, vs)
+                zero = None
+
+            def join(a, b, z):
+                va, d_, c_, nm, at = labelled.unpack(a)
+                vb = labelled.unpack(b)[0] - (labelled.unpack(z)[0] if z is not None else 0.0)
+                return labelled.pack(va + 1j * vb, d_, c_, nm, at, a)
+
+            if isinstance(re, list):
+                outs.append([join(a, b, z) for a, b, z in zip(re, im, zero or [None] * len(re))])
+            else:
+                outs.append(join(re, im, zero))
+        return outs[0] if len(outs) == 1 else outs
 
 
 class HilbertCPCCA(ComplexCPCCA):

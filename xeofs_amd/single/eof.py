@@ -18,6 +18,15 @@ from ..preprocessing import Preprocessor
 
 
 class EOF(Deferred):
+    """Drop-in for xeofs.single.EOF (xeofs/single/eof.py:15-240).
+
+    Aliasing contract of the default in-place layout: when `fit` is handed a DEVICE tensor (a torch tensor in HBM), the
+    engine writes no copy of it -- the fitted model keeps a reference to that tensor and every later pass over the data
+    (`inverse_transform`, the rotators, the bootstrapper, `ResidentMatrix.download`) reads it again through the Scaler
+    map.  The tensor must therefore stay unmodified for as long as the model (or anything fitted on it) is in use;
+    `model.data["input_data"].release_raw()` builds the engine's own layouts and drops the reference.  Host inputs
+    (numpy / labelled arrays) are staged into HBM by the engine and owned by the model: nothing to observe there."""
+
     def __init__(self, n_modes: int = 2, center: bool = True, standardize: bool = False, use_coslat: bool = False,
                  check_nans=True, sample_name: str = "sample", feature_name: str = "feature", compute: bool = True,
                  random_state: int | None = None, solver: str = "auto", solver_kwargs: dict = {}, **kwargs):
@@ -211,8 +220,10 @@ class ComplexEOF(EOF):
             # scaler.py:105-108 on complex data: numpy's std of a complex array is the real
             # sqrt(mean |z - mean|^2) = sqrt(var Re + var Im); both parts are divided by it
             self.preprocessor.standardize = False
-            s_re, s_im = self.preprocessor.peek_std(re, dim), self.preprocessor_imag.peek_std(im, dim)
-            std_c = np.maximum(np.sqrt(s_re ** 2 + s_im ** 2), np.finfo(np.float32).eps)
+            eps = np.finfo(np.float32).eps       # peek_std clips each part at eps: undo that, combine, clip ONCE
+            s_re, s_im = (np.where(v <= eps, 0.0, v)
+                          for v in (self.preprocessor.peek_std(re, dim), self.preprocessor_imag.peek_std(im, dim)))
+            std_c = np.maximum(np.sqrt(s_re ** 2 + s_im ** 2), eps)
         A = self.preprocessor.fit_transform(re, dim, weights, std_override=std_c)
         B = self.preprocessor_imag.fit_transform(im, dim, weights, std_override=std_c)
         tv = self.preprocessor.total_variance + self.preprocessor_imag.total_variance
