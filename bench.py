@@ -423,8 +423,12 @@ def main():
 
     def step():
         a = time.perf_counter()
-        # the sketch (sklearn's RandomState stream, host) is drawn while the first kernels run
-        omega = engine.SketchFuture(min(n, P), k + N_OVERSAMPLES, 5)
+        if one_call:
+            # the sketch (sklearn's RandomState stream, host): the one engine call needs it for its first kernel, so it
+            # is drawn in line (a worker thread that is joined at once costs 0.7 ms more, profiles/r03_sketch_latency.txt)
+            omega = engine.sketch_matrix(min(n, P), k + N_OVERSAMPLES, 5)
+        else:   # drawn while the preprocess kernels run
+            omega = engine.SketchFuture(min(n, P), k + N_OVERSAMPLES, 5)
         if one_call:
             # Scaler statistics + Sanitizer + randomized SVD in ONE engine call: the statistics ride on the first pass
             mat, st, U, s, V = engine.fit(ctx, Xraw, k, center=True, standardize=False, feature_weights=None,

@@ -352,6 +352,17 @@ def _mask_worker(rank, world, port, out_dir):
     except ValueError as e:
         res["partial"] = str(e)
     res["partial_unchecked"] = sharded.combine_sample_masks(comm, other, 5, check_nans=False)
+    # the same facts through the single-collective form the sharded fit uses
+    counts, vs, tv, bad = sharded.global_facts(comm, 5 if rank == 0 else 7, base, True, 1.5 + rank, float(rank == 1))
+    res["gf_counts"], res["gf_vs"], res["gf_tv"], res["gf_bad"] = counts, vs, tv, bad
+    counts, vs, _, _ = sharded.global_facts(comm, 5 if rank == 0 else 0, base if rank == 0 else np.zeros(4, bool), True, 0.0)
+    res["gf_empty_counts"], res["gf_empty_vs"] = counts, vs
+    try:
+        sharded.global_facts(comm, 5, other, True, 0.0)
+        res["gf_partial"] = "no error"
+    except ValueError as e:
+        res["gf_partial"] = str(e)
+    res["gf_partial_unchecked"] = sharded.global_facts(comm, 5, other, False, 0.0)[1]
     np.savez(os.path.join(out_dir, f"m{rank}.npz"), **res)
     dist.barrier()
     dist.destroy_process_group()
@@ -367,3 +378,8 @@ def test_combine_sample_masks_two_ranks_gloo(tmp_path):
         assert m["empty_shard"].tolist() == [True, True, False, True]
         assert "partial NaN entries" in str(m["partial"])
         assert m["partial_unchecked"].tolist() == [True, True, False, True]
+        assert m["gf_counts"].tolist() == [5, 7] and m["gf_vs"].tolist() == [True, True, False, True]
+        assert float(m["gf_tv"]) == 4.0 and float(m["gf_bad"]) == 1.0
+        assert m["gf_empty_counts"].tolist() == [5, 0] and m["gf_empty_vs"].tolist() == [True, True, False, True]
+        assert "partial NaN entries" in str(m["gf_partial"])
+        assert m["gf_partial_unchecked"].tolist() == [True, True, False, True]

@@ -3538,7 +3538,7 @@ extern "C" int eofx_sketch_gaussian_f32(uint32_t seed, int64_t rows, int64_t col
     // The raw recurrence is sequential and runs on this thread, chunk by chunk; every finished chunk of candidates goes
     // to the pool at once, so tempering / accept test / log / sqrt of chunk c overlap the recurrence of chunk c + 1:
     // the call takes about as long as the recurrence alone (0.55 ns per word).
-    const int64_t chunk = 16384;                                    // candidates per task (64 K words, ~0.7 ms of deviate work)
+    const int64_t chunk = 4096;                                     // candidates per task (16 K words): the deviate work of the LAST chunk is the tail of the call
     const int64_t nchunks = (ncand + chunk - 1) / chunk;
     std::vector<std::vector<float>> dev((size_t)nchunks);          // deviates of each chunk, in stream order: (f b, f a) per accepted pair
     auto work = [&dev, raw, ncand, chunk](int64_t c) {
