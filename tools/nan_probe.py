@@ -20,3 +20,11 @@ for rep in range(6):
     torch.cuda.synchronize(); t2 = time.perf_counter()
     print(f"rep{rep} [{'masked in place' if mat.masked else 'compacted, two layouts'}]: valid features {st['p']} of {nlat*nlon}; preprocess {1e3*(t1-t0):.1f} ms, rsvd {1e3*(t2-t1):.1f} ms, s0={s[0]:.3f}")
     mat.free()
+# the one-call fit on the masked field: statistics during the first pass, masked in-place layout (round 3)
+for rep in range(3):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    mat, st, U, s, V = engine.fit(ctx, X, k, True, False, w, random_state=5, want_stats=False, device_out=True, allow_masked=True)
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    print(f"fit rep{rep} [{'one call, masked in place' if st['fused'] and mat.masked else 'fallback ' + str(engine.fit_info(ctx))}]: "
+          f"valid features {st['p']} of {nlat*nlon}; whole fit {1e3*(t1-t0):.1f} ms, s0={s[0]:.3f}")
+    mat.free()

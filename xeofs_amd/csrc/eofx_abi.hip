@@ -1987,6 +1987,7 @@ struct FitFirst {
   int* dflags = nullptr;
   unsigned* hword = nullptr;
   float a_scale = 1.f;
+  bool maybe_masked = false;
   eofx_mat* m = nullptr;
   FeatSummary fs;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -2065,7 +2066,10 @@ struct FitFirst {
     HIPCHK(hipStreamSynchronize(ctx->stream));
     float est;
     std::memcpy(&est, hword, sizeof(float));
-    if ((hword[1] & 1) || !(est > 0.f) || !std::isfinite(est)) {
+    // bit 1: some feature is NaN in all nine sampled rows -- an all-NaN grid point if the whole column is; the pass
+    // itself verifies that (eofx_fit.hpp) and the matrix takes the masked in-place layout, where the caller allows it
+    maybe_masked = (hword[1] & 2) != 0;
+    if ((hword[1] & 1) || (maybe_masked && !ctx->allow_masked) || !(est > 0.f) || !std::isfinite(est)) {
       ctx->fit_info[2] = 1.0;    // NaN in the sampled rows / constant or non-finite sample
       return EOFX_FIT_FALLBACK;
     }
@@ -2081,6 +2085,7 @@ struct FitFirst {
     m->raw = Xd;
     m->raw_ld = P;
     m->p_valid = P;
+    m->masked = maybe_masked;     // the MASK kernels from the second pass on (harmless if no feature turns out masked)
     return EOFX_OK;
   }
   int run(const float* Zs, float* Yt, int LL) {
@@ -2135,15 +2140,39 @@ struct FitFirst {
     HIPCHK(hipMemcpyAsync(m->absmax_dev, ps.absmax, sizeof(unsigned), hipMemcpyDeviceToDevice, ctx->stream));
     // the rank-one correction does not wait for the verdict on the statistics: it is queued behind them
     hipLaunchKernelGGL(fit_reduce_kernel, dim3((int)std::min<int64_t>((p_pad * (LL / 4) + 255) / 256, 2048)), dim3(256), 0, ctx->stream,
-                       part, Yt, p_pad, LL, l, S, P, dcorr, ps.scale, wbar, amax_new(ctx, Yt));
+                       part, Yt, p_pad, LL, l, S, P, dcorr, ps.scale, wbar, amax_new(ctx, Yt),
+                       maybe_masked ? ps.cnt : (const int*)nullptr);
     KCHK();
     if (ctx->profile) HIPCHK(hipEventRecord(ev[3], ctx->stream));
     CHK(run_feature_summary(ctx, ps, P, fs));       // total variance; synchronises
-    if (hword[2] != 0) {
-      ctx->fit_info[2] = 2.0 + (double)hword[2];   // 3: NaN / inf in the field, 4: fp16 overflow of the provisional scale, 5: both
-      return EOFX_FIT_FALLBACK;
+    if (hword[2] & 3) {
+      ctx->fit_info[2] = 2.0 + (double)(hword[2] & 3);   // 3: NaN / inf in the field, 4: fp16 overflow of the provisional scale
+      return EOFX_FIT_FALLBACK;                          //    (or a finite value in an all-NaN candidate), 5: both
+    }
+    if (fs.pv < P) {   // all-NaN grid points: the masked in-place layout, under the conditions of sanitize_and_apply
+      if (!(ctx->allow_masked && 10 * fs.pv >= 6 * P && n < fs.pv)) {
+        ctx->fit_info[2] = 6.0;                          // a mask outside the in-place range (too many points, n >= valid p)
+        return EOFX_FIT_FALLBACK;
+      }
+      m->p_valid = fs.pv;
+      m->masked = true;
+    } else {
+      m->masked = false;
     }
     std::memcpy(&m->absmax, hword + 3, sizeof(float));
+    return EOFX_OK;
+  }
+  // which features hold data (host bytes), after run()
+  int valid_features(uint8_t* valid_feature) {
+    if (!valid_feature) return EOFX_OK;
+    if (!m || !m->masked) {
+      std::memset(valid_feature, 1, (size_t)P);
+      return EOFX_OK;
+    }
+    std::vector<int> hc((size_t)P);
+    HIPCHK(hipMemcpyAsync(hc.data(), ps.cnt, sizeof(int) * P, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (int64_t c = 0; c < P; ++c) valid_feature[c] = hc[(size_t)c] > 0;
     return EOFX_OK;
   }
   // mean / std to the caller, the event times of the non-pass work, and the matrix itself
@@ -2175,7 +2204,8 @@ static bool fit_first_eligible(const eofx_ctx* ctx, const float* Xdev, int64_t n
 // ------------------------------------------------------------------------------------
 static int fit_fused(eofx_ctx* ctx, const float* Xd, int64_t n, int64_t P, int center, int standardize,
                      const double* feat_weights, int k, int l, int n_iter, const float* omega, int flip,
-                     eofx_mat** out, double* mean, double* std_, double* total_variance, float* U, float* s, float* V) {
+                     eofx_mat** out, double* mean, double* std_, double* total_variance, float* U, float* s, float* V,
+                     uint8_t* valid_feature, int64_t* p_valid) {
   const int64_t p_pad = round_up(P, ATB_BM), n_pad = round_up(n, ATB_BM);
   CHK(arena_reserve(ctx, rsvd_scratch_bytes(p_pad, n_pad, l, k) + FitFirst::bytes(n, P, l)));
   ArenaScope scope(ctx);
@@ -2191,6 +2221,8 @@ static int fit_fused(eofx_ctx* ctx, const float* Xd, int64_t n, int64_t P, int c
   rc = rsvd_core(ctx, op, k, l, n_iter, omega, ro, &first);
   if (rc != EOFX_OK) return rc;
   CHK(rsvd_finish(ctx, ro, true, n, P, k, flip, U, s, V));
+  CHK(ff.valid_features(valid_feature));
+  if (p_valid) *p_valid = ff.m->masked ? ff.m->p_valid : P;
   return ff.finish(mean, std_, total_variance, out);
 }
 
@@ -2219,12 +2251,13 @@ extern "C" int eofx_fit_first_f32(eofx_ctx* ctx, const float* X, int64_t n, int6
     if (rc == EOFX_OK) rc = ff.run(Zn, Yp, L);
     if (rc < 0) return rc;
     if (rc == EOFX_OK) {
+      CHK(ff.valid_features(valid_feature));
+      const int64_t pv_fused = ff.m->masked ? ff.m->p_valid : P;
       CHK(ff.finish(mean, std_, total_variance, out));
       adopt_staged(out, st, (size_t)n * P * sizeof(float));
-      if (valid_feature) std::memset(valid_feature, 1, (size_t)P);
       if (valid_sample) std::memset(valid_sample, 1, (size_t)n);
       if (n_out) *n_out = n;
-      if (p_out) *p_out = P;
+      if (p_out) *p_out = pv_fused;
       if (fused) *fused = 1;
       ctx->fit_info[0] = 1.0;
       return EOFX_OK;
@@ -2267,15 +2300,15 @@ extern "C" int eofx_fit_f32(eofx_ctx* ctx, const float* X, int64_t n, int64_t P,
   const int iters = n_iter < 0 ? rsvd_auto_iters(k, n, P) : n_iter;
   const bool eligible = fit_first_eligible(ctx, st.dev, n, P, l) && k <= n && l == l_req && omega_rows >= n && !is_device_ptr(omega);
   if (eligible) {
+    int64_t pv_fused = P;
     const int rc = fit_fused(ctx, st.dev, n, P, center, standardize, feat_weights, k, l, iters, omega, flip, out, mean, std_,
-                             total_variance, U, s, V);
+                             total_variance, U, s, V, valid_feature, &pv_fused);
     if (rc < 0) return rc;
     if (rc == EOFX_OK) {
       adopt_staged(out, st, (size_t)n * P * sizeof(float));
-      if (valid_feature) std::memset(valid_feature, 1, (size_t)P);
       if (valid_sample) std::memset(valid_sample, 1, (size_t)n);
       if (n_out) *n_out = n;
-      if (p_out) *p_out = P;
+      if (p_out) *p_out = pv_fused;
       if (fused) *fused = 1;
       ctx->fit_info[0] = 1.0;
       return EOFX_OK;
@@ -2342,7 +2375,8 @@ extern "C" int eofx_panel_bootstrap_f32(eofx_ctx* ctx, const float* P_in, int64_
 // [0] 1 when the last eofx_fit_f32 took the fused path, [1] milliseconds of its non-pass work (probe, finalize,
 // correction; measured with HIP events when profiling is on, else 0), [2] why not: 0 fused, -1 not eligible (shape,
 // precision, layout), 1 NaN / constant data in the sampled rows, 3 NaN or inf in the field, 4 fp16 range of the
-// provisional scale exceeded, 5 both
+// provisional scale exceeded (or a finite value in a column whose sampled rows were all NaN), 5 both, 6 all-NaN grid
+// points outside the range of the masked in-place layout
 extern "C" int eofx_ctx_fit_info(const eofx_ctx* ctx, double* info3) {
   if (!ctx || !info3) return EOFX_ERR_ARG;
   for (int i = 0; i < 3; ++i) info3[i] = ctx->fit_info[i];

@@ -25,13 +25,15 @@ namespace eofx {
 
 // Provisional shift c_j = mean of nine sampled rows (first, last, seven in between) and an estimate of max |x - c|
 // from the same rows.  One thread per four adjacent features (P % 4 == 0, 16-byte aligned rows).  flags bit 0: a NaN or
-// an infinity was seen in the sampled rows.
+// an infinity was seen in SOME of the sampled rows of a feature; bit 1: a feature is NaN in ALL nine -- a candidate for
+// an all-NaN grid point (land / sea mask).  Its shift is written as NaN, the marker the first pass and
+// fit_finalize_kernel read.
 __global__ __launch_bounds__(256) void fit_probe_kernel(const float* __restrict__ X, int64_t n, int64_t P, int64_t ld,
                                                          int64_t p_pad, float* __restrict__ cshift,
                                                          unsigned* __restrict__ est, int* __restrict__ flags) {
   const int64_t c = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
   float m = 0.f;
-  bool bad = false;
+  bool bad = false, cand = false;
   if (c < P) {
     f32x4 v[9];
 #pragma unroll
@@ -40,12 +42,20 @@ __global__ __launch_bounds__(256) void fit_probe_kernel(const float* __restrict_
       v[t] = *reinterpret_cast<const f32x4*>(X + (r < n ? r : n - 1) * ld + c);
     }
     f32x4 c0 = {0.f, 0.f, 0.f, 0.f};
+    int nn[4] = {0, 0, 0, 0};
 #pragma unroll
-    for (int t = 0; t < 9; ++t) c0 += v[t];
+    for (int t = 0; t < 9; ++t) {
+      c0 += v[t];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) nn[e] += v[t][e] != v[t][e];
+    }
     c0 *= (1.f / 9.f);
 #pragma unroll
     for (int e = 0; e < 4; ++e)
-      if (!(fabsf(c0[e]) < INFINITY)) {     // NaN or inf among the samples
+      if (nn[e] == 9) {                     // all-NaN candidate: marker
+        cand = true;
+        c0[e] = NAN;
+      } else if (!(fabsf(c0[e]) < INFINITY)) {     // NaN or inf among the samples
         bad = true;
         c0[e] = 0.f;
       }
@@ -59,10 +69,10 @@ __global__ __launch_bounds__(256) void fit_probe_kernel(const float* __restrict_
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  const bool anybad = __any(bad);
+  const int anybad = (__any(bad) ? 1 : 0) | (__any(cand) ? 2 : 0);
   if ((threadIdx.x & 63) == 0) {
-    if (m > 0.f) atomicMax(est, __float_as_uint(m));      // inf included: the host checks
-    if (anybad) atomicOr(flags, 1);
+    if (m > 0.f) atomicMax(est, __float_as_uint(m));      // inf included: the host checks  (NaN differences are skipped)
+    if (anybad) atomicOr(flags, anybad);
   }
 }
 
@@ -129,7 +139,14 @@ __global__ __launch_bounds__(256, 2) void atb_f16_fit_kernel(const float* __rest
   f32x4 cs_ = {0.f, 0.f, 0.f, 0.f};
   if (colok) cs_ = *reinterpret_cast<const f32x4*>(cshift + m0 + 4 * li);
   const float asc_ = colok ? a_scale : 0.f;      // 16-byte chunks beyond the field read chunk 0 and count as zeros
-  const f32x4 ncs_ = -cs_ * asc_;                // (x - c) a = fma(x, a, -c a): one rounding, one instruction (a = 2^k)
+  f32x4 ncs_ = -cs_ * asc_;                      // (x - c) a = fma(x, a, -c a): one rounding, one instruction (a = 2^k)
+  // All-NaN candidates (shift marker NaN, fit_probe_kernel): the addend +inf keeps a NaN a NaN -- confined to this
+  // feature's row of C, its sums and nothing else: the running maximum skips NaN operands -- and turns any FINITE value
+  // of the column into +inf, which the maximum does not skip: fit_finalize_kernel then sees an overflow and the caller
+  // takes the two-step path with its isolated-NaN policy.  No instruction in the hot loop changes.
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (cs_[e] != cs_[e]) ncs_[e] = INFINITY;
   float m1 = -1.f;   // opaque to the optimiser: x - (float)h stays ONE v_fma_mix_f32 instead of a conversion and a subtraction
   asm volatile("" : "+v"(m1));
   // B staging as in atb_f16_kernel: item = (column pair cp, parity lh, row pair tp), two 8-byte loads, one packed 4-byte
@@ -320,7 +337,8 @@ __global__ __launch_bounds__(256, 2) void atb_f16_fit_kernel(const float* __rest
 //        is padded with `extra` = K - n re-reads of the last row, whose squares are subtracted here.
 //   mean = cshift + S1 / n;  M2 = S2 / a^2 - S1^2 / n;  std = sqrt(M2 / n) clipped at eps        (scaler.py:101-108)
 //   shift = center ? mean : 0;  scale = (standardize ? 1 / std : 1) * weight                   (scaler.py:128-154)
-// flags: bit 0 a sum is not finite (NaN / inf in the data), bit 1 the provisional fp16 scaling overflowed.
+// flags: bit 0 a sum is not finite (NaN / inf in the data), bit 1 the provisional fp16 scaling overflowed (or a masked
+// candidate held a finite value), bit 2 all-NaN grid points are present (count 0, zero map: the masked in-place layout).
 // Also written: the float triples of the in-place view (aff_pack_kernel's layout), dcorr = shift - cshift for
 // fit_reduce_kernel, and max |(x - shift) * scale| (an upper bound within a factor of two) into *absmax.
 __global__ __launch_bounds__(256) void fit_finalize_kernel(
@@ -345,6 +363,21 @@ __global__ __launch_bounds__(256) void fit_finalize_kernel(
     }
     S1 *= unit;
     const float cs = cshift[c];
+    if (cs != cs) {       // an all-NaN grid point (no finite value: that would have set mx = inf): invalid feature, zero column
+      if (!(mx < 60000.f)) fl |= 2;
+      fl |= 4;
+      const double w = weights ? weights[c] : 1.0;
+      cnt[c] = 0;
+      mean[c] = NAN;
+      stdv[c] = NAN;
+      shift[c] = center ? NAN : 0.0;      // as colstats_finalize_kernel leaves a feature without data
+      scale[c] = (standardize ? NAN : 1.0) * w;
+      m2[c] = 0.0;
+      dcorr[c] = 0.0;
+      aff[c] = 0.f;
+      aff[p_pad + c] = 0.f;
+      aff[2 * p_pad + c] = 0.f;
+    } else {
     if (extra > 0) {
       const float v = __builtin_fmaf(X[(n - 1) * ld + c], a_scale, -cs * a_scale);    // the kernel's own expression
       q -= (double)extra * ((double)v * (double)v);
@@ -373,6 +406,7 @@ __global__ __launch_bounds__(256) void fit_finalize_kernel(
     aff[p_pad + c] = lo;
     aff[2 * p_pad + c] = (float)sc;
     amax = (float)(((double)mx * ia + fabs(sh - (double)cs)) * fabs(sc) * 1.000001);
+    }
   } else if (c < p_pad) {
     aff[c] = 0.f;
     aff[p_pad + c] = 0.f;
@@ -380,7 +414,7 @@ __global__ __launch_bounds__(256) void fit_finalize_kernel(
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
-  const int anyfl = __any(fl & 1) | (__any(fl & 2) << 1);
+  const int anyfl = (__any(fl & 1) ? 1 : 0) | (__any(fl & 2) ? 2 : 0) | (__any(fl & 4) ? 4 : 0);
   if ((threadIdx.x & 63) == 0) {
     if (amax > 0.f && amax < INFINITY) atomicMax(absmax, __float_as_uint(amax));
     if (anyfl) atomicOr(flags, anyfl);
@@ -415,13 +449,14 @@ __global__ __launch_bounds__(256) void panel_colsum_final_kernel(const double* _
 }
 
 // Y[j, c] = scale_j * (sum_splits part[s][j, c] - dcorr_j * wbar[c]) for j < P and c < l, 0 for the padding rows and
-// columns (the ones column of the first pass among them); float64 arithmetic, fixed order.  part may alias out when
+// columns (the ones column of the first pass among them) and for features without data (cnt[j] == 0); float64
+// arithmetic, fixed order.  part may alias out when
 // splits == 1.  amax_out (may be null): max |Y| by atomicMax on the float bits (order independent).
 __global__ __launch_bounds__(256) void fit_reduce_kernel(const float* part, float* out, int64_t rows_pad, int L, int l,
                                                           int splits, int64_t P, const double* __restrict__ dcorr,
                                                           const double* __restrict__ scale,
                                                           const double* __restrict__ wbar,
-                                                          unsigned* __restrict__ amax_out) {
+                                                          unsigned* __restrict__ amax_out, const int* __restrict__ cnt = nullptr) {
   // thread (row group, quad): quad = 4 adjacent columns, fixed for the thread, so its four wbar values are loaded once;
   // rows stride by the number of row slots of the grid.  L / 4 is 8 or 16: 32 or 16 rows per 256-thread workgroup.
   const int l4 = L / 4;
@@ -435,7 +470,7 @@ __global__ __launch_bounds__(256) void fit_reduce_kernel(const float* part, floa
   for (int64_t j = (int64_t)blockIdx.x * rper + rslot; j < rows_pad; j += (int64_t)gridDim.x * rper) {
     const int64_t i = j * l4 + quad;
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
-    if (j < P) {
+    if (j < P && !(cnt && cnt[j] == 0)) {      // (the partial sums of an all-NaN grid point are NaN: its row of Y is zero)
       double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
       for (int s = 0; s < splits; ++s) {
         const f32x4 v = reinterpret_cast<const f32x4*>(part)[(int64_t)s * count4 + i];
