@@ -316,6 +316,59 @@ def leg_extra_gates(ctx, device, orc, layout_kw):
     return res
 
 
+def measure_traffic(args, n, P):
+    """roofline.traffic counted in THIS run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes -- the
+    two counters do not fit one TCC pass, MI355X_MICROARCH.md) over two fits of the same command, per launch of the
+    streaming kernels; FETCH_SIZE doubled as the guide prescribes for gfx950's wide streaming reads, both in units of KB.
+    -> (bytes per launch | None, by-kernel dict, note)"""
+    import csv, glob, shutil, subprocess, tempfile
+
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, None, "rocprofv3 not on PATH"
+    if any(kk.startswith(("ROCPROF", "ROCP_")) for kk in os.environ):
+        return None, None, "this process already runs under a profiler"
+    me = os.path.abspath(__file__)
+    names = {"atb_f16_kernel<": "atb_f16_kernel<2,true>", "atb_f16_fit_kernel<": "atb_f16_fit_kernel<2>",
+             "axb_f16_kernel<": "axb_f16_kernel<4>"}
+    got = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="eofx_pmc_", dir="/tmp")
+        cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", d, "-o", "p", "--output-format", "csv", "--", sys.executable, me,
+               "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-configs", "--no-traffic",
+               "--nsamples", str(n), "--nlat", str(args.nlat), "--nlon", str(args.nlon), "--modes", str(args.modes),
+               "--layout", args.layout] + (["--two-step"] if args.two_step else [])
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+            vals = {}
+            for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+                with open(f) as fh:
+                    for r in csv.DictReader(fh):
+                        if r["Counter_Name"] != counter:
+                            continue
+                        for key, label in names.items():
+                            if key in r["Kernel_Name"]:
+                                vals.setdefault(label, []).append(float(r["Counter_Value"]))
+            if not vals:
+                return None, None, f"no {counter} rows for the streaming kernels"
+            got[counter] = {k: sum(v) / len(v) for k, v in vals.items()}
+        except Exception as e:      # a profiler problem must not cost the bench line
+            return None, None, f"rocprofv3 {counter} pass failed: {type(e).__name__}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    by = {}
+    for label in got["FETCH_SIZE"]:
+        by[label] = round((2.0 * got["FETCH_SIZE"][label] + got["WRITE_SIZE"].get(label, 0.0)) * 1000.0)
+    # mean over the 16 passes of a fit: 7 atb + 1 fit (or 8 atb in the two-step form) + 8 axb
+    a, f, x = by.get("atb_f16_kernel<2,true>"), by.get("atb_f16_fit_kernel<2>"), by.get("axb_f16_kernel<4>")
+    if a is None or x is None:
+        return None, by, "a streaming kernel is missing from the counter rows"
+    per = (7 * a + (f if f is not None else a) + 8 * x) / 16.0
+    return per, by, "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate passes over two fits " \
+                    "of this command; FETCH_SIZE x 2 (gfx950, MI355X_MICROARCH.md), KB units; mean over the 16 passes of a fit"
+
+
 def main():
     # Libraries (RCCL prints a version banner at communicator creation) must not pollute stdout: the
     # contract is ONE JSON line there.  Keep the real stdout aside and point fd 1 at stderr.
@@ -345,6 +398,9 @@ def main():
     ap.add_argument("--two-step", action="store_true",
                     help="statistics pass + decomposition as two engine calls (17 reads of the field) instead of the fused fit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="do not re-count roofline.traffic with rocprofv3 (two short PMC passes over this command, ~40 s); "
+                         "the committed profile is quoted instead, labelled from_profile")
     ap.add_argument("--no-f64-baseline", action="store_true",
                     help="skip the float64 CPU leg (config-2 shape: kernel level + whole oracle fit) and its 1e-5 parity gate")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs / the published workload")
@@ -526,11 +582,15 @@ def main():
     alg_flops_launch = 2.0 * n * (hi - lo) * (k + N_OVERSAMPLES)   # per pass, per rank
     launch_ms = prof["ms"] / max(prof["launches"], 1)
     achieved_tflops = alg_flops_launch / (launch_ms * 1e-3) / 1e12 if launch_ms > 0 else 0.0
-    pmc_traffic, traffic_src = None, None
+    pmc_traffic, traffic_src, traffic_by = None, None, None
+    if world == 1 and rank == 0 and not args.no_traffic and args.precision == "f16x3":
+        pmc_traffic, traffic_by, traffic_src = measure_traffic(args, n, P)
+        if pmc_traffic is None:
+            print(f"[bench] traffic not re-counted ({traffic_src}); quoting the committed profile", file=sys.stderr)
     tfile = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
     if not os.path.exists(tfile):
         tfile = os.path.join(ROOT, "profiles", "r02_stream_hbm_traffic.json")
-    if os.path.exists(tfile):
+    if pmc_traffic is None and os.path.exists(tfile):
         try:
             with open(tfile) as f:
                 tj = json.load(f)
@@ -575,7 +635,8 @@ def main():
                                              "GBps": round(alg_bytes_launch / (v["ms"] / v["launches"] * 1e-3) / 1e9, 1)}
                                  for kk, v in prof["by_kernel"].items()}
     roofline.update({
-        "traffic": pmc_traffic, "traffic_source": traffic_src, "launches_timed": prof["launches"],
+        "traffic": pmc_traffic, "traffic_source": traffic_src, "traffic_by_kernel": traffic_by,
+        "launches_timed": prof["launches"],
         "mean_launch_ms": round(launch_ms, 4),
         "alg_bytes_per_launch": alg_bytes_launch, "alg_flops_per_launch": alg_flops_launch,
         "alg_TFLOPs": round(achieved_tflops, 2),
