@@ -527,6 +527,45 @@ def test_fused_fit_with_land_mask(ctx, standardize, use_w):
     mat.free()
 
 
+@pytest.mark.parametrize("one_call", [False, True])
+def test_masked_in_place_skips_masked_runs(ctx, one_call):
+    """Masked grid points that come in RUNS (land in an ocean field): the MASK kernels do not read them -- a wave of
+    atb_f16 whose 128 features are all masked only helps staging B, a workgroup of four such waves leaves at once, and
+    axb_f16 walks the list of 64-feature slab pairs that hold at least one valid feature (eofx_mat::act).  Runs that
+    cover whole workgroups, single waves and single slab pairs, next to scattered masked points; results against the
+    oracle and the compacted matrix."""
+    from xeofs_amd import engine
+
+    n, P, k = 260, 4608, 7
+    rng = np.random.default_rng(12)
+    X = _field(n, P, seed=9)
+    dead = np.zeros(P, bool)
+    for a, b in ((0, 1024), (1500, 1700), (2048, 2176), (2240, 2304), (3000, 3300), (4544, 4608)):
+        dead[a:b] = True
+    dead[rng.choice(np.flatnonzero(~dead), 40, replace=False)] = True           # scattered points inside valid slabs
+    assert 0.6 * P < (~dead).sum()
+    X[:, dead] = np.nan
+    w = rng.uniform(0.5, 1.5, P)
+    ref = orc.eof_fit(X.astype(np.float64), k, True, False, w, random_state=3)
+    if one_call:
+        mat, st, U, s, V = engine.fit(ctx, X, k, feature_weights=w, random_state=3, allow_masked=True)
+        assert st["fused"]
+    else:
+        mat, st = engine.preprocess(ctx, X, True, False, w, in_place=True, allow_masked=True)
+        U, s, V = engine.rsvd(ctx, mat, k, random_state=3)
+    assert mat.masked and np.array_equal(st["valid_feature"], ~dead) and V.shape == (int((~dead).sum()), k)
+    _check_factors(U, s, V, ref, k)
+    mat2, st2 = engine.preprocess(ctx, X, True, False, w)                          # compacted, two layouts
+    U2, s2, V2 = engine.rsvd(ctx, mat2, k, random_state=3)
+    assert np.all(np.abs(s - s2) <= 2e-6 * s2[0])
+    P1, P2 = engine.project(ctx, mat, V2), engine.project(ctx, mat2, V2)         # one more axb pass over the list
+    assert np.abs(P1 - P2).max() <= 2e-6 * np.abs(P2).max()
+    U3, s3, V3 = engine.rsvd(ctx, mat, k, random_state=3)                         # reproducible bit for bit
+    if not one_call:
+        assert np.array_equal(s, s3) and np.array_equal(V, V3)
+    mat.free(); mat2.free()
+
+
 def test_fused_fit_falls_back(ctx):
     """NaN fields, sketches wider than 64 columns and n >= P take the two-step path inside the same call -- with the
     Sanitizer's policies and error messages -- and say so."""

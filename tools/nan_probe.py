@@ -7,7 +7,14 @@ import bench
 n, nlat, nlon, k = 10000, 720, 1440, 50
 ctx = engine.Context(0)
 X = bench.make_field(n, nlat, nlon, 0, nlat * nlon, torch.device("cuda:0"))
-mask = torch.rand(nlat * nlon, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1)) < 0.3
+if os.environ.get("MASK", "random") == "blobs":      # "continents": rectangles in lat x lon, ~30 % of the grid in long runs
+    m2 = torch.zeros((nlat, nlon), dtype=torch.bool, device="cuda")
+    for (a, b, c, d) in ((120, 400, 100, 420), (320, 620, 620, 860), (60, 250, 980, 1300), (520, 680, 1040, 1180), (0, 48, 0, 1440)):
+        m2[a:b, c:d] = True
+    mask = m2.reshape(-1)
+else:
+    mask = torch.rand(nlat * nlon, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1)) < 0.3
+print(f"mask: {os.environ.get('MASK', 'random')}, {float(mask.float().mean()):.3f} of the grid points")
 X[:, mask] = float("nan")
 lat = np.linspace(-89.75, 89.75, nlat)
 w = np.repeat(np.sqrt(np.cos(np.deg2rad(lat)).clip(0, 1)), nlon)

@@ -110,6 +110,10 @@ struct eofx_mat {
   // p_valid does not.  The host shell compacts / scatters the feature axis of the factors.
   bool masked = false;
   int64_t p_valid = 0;
+  // masked matrices: the 64-feature slab pairs of axb_f16 that hold at least one valid feature (device, ascending; built
+  // on first use by ensure_active_pairs; n_act < 0: not built yet, act == nullptr afterwards: every pair is active)
+  int* act = nullptr;
+  int64_t n_act = -1;
 };
 
 static int set_err(eofx_ctx* ctx, int code, const char* fmt, ...) {
@@ -715,10 +719,18 @@ static int launch_atb(eofx_ctx* ctx, const float* A, int64_t lda, int64_t K, int
 // W[n_pad x L] = X' Y with X' = the raw field [rows x cols] (ld) through the affine map, read in place (axb_f16_kernel).
 // Y: [>= round_up(cols, 64) x L] panel whose rows >= cols are zero.  L a multiple of 32.
 static int launch_axb(eofx_ctx* ctx, const float* raw, int64_t ld, int64_t rows, int64_t cols, int64_t rows_pad,
-                      const float* aff, int64_t aff_ld, float a_absmax, const float* Y, int L, float* W, bool masked = false) {
-  const int64_t K = round_up(cols, AXB_KG);
-  if (L % 32 || L <= 0 || rows_pad % AXB_BM || rows >= ((int64_t)1 << 31) || K * L >= ((int64_t)1 << 31) ||
-      64 * ld + K >= ((int64_t)1 << 30))     // the kernel's 32-bit offsets
+                      const float* aff, int64_t aff_ld, float a_absmax, const float* Y, int L, float* W, bool masked = false,
+                      const int* act = nullptr, int64_t n_act = 0) {
+  const int64_t K_all = round_up(cols, AXB_KG);
+  // masked matrix with an active list: the kernel walks n_act slab pairs instead of K_all / 64 (see axb_f16_kernel)
+  const int64_t K = (masked && act) ? n_act * AXB_KG : K_all;
+  if (K == 0) {   // nothing but masked grid points
+    HIPCHK(hipMemsetAsync(W, 0, sizeof(float) * (size_t)rows_pad * L, ctx->stream));
+    amax_forget(ctx, W);
+    return EOFX_OK;
+  }
+  if (L % 32 || L <= 0 || rows_pad % AXB_BM || rows >= ((int64_t)1 << 31) || K_all * L >= ((int64_t)1 << 31) ||
+      64 * ld + K_all >= ((int64_t)1 << 30))     // the kernel's 32-bit offsets
     return set_err(ctx, EOFX_ERR_ARG, "axb: bad geometry rows=%lld cols=%lld L=%d", (long long)rows, (long long)cols, L);
   const AtbPlan plan = axb_plan(rows_pad, K);
   const int rt = (int)(rows_pad / AXB_BM);
@@ -740,9 +752,9 @@ static int launch_axb(eofx_ctx* ctx, const float* raw, int64_t ld, int64_t rows,
     unsigned* bm = arena_alloc<unsigned>(ctx, 1);
     if (!bm) return set_err(ctx, EOFX_ERR_NOMEM, "arena exhausted (panel max)");
     HIPCHK(hipMemsetAsync(bm, 0, sizeof(unsigned), ctx->stream));
-    const int64_t total4 = K * (L / 4);
+    const int64_t total4 = K_all * (L / 4);
     hipLaunchKernelGGL(panel_absmax_kernel, dim3((int)std::max<int64_t>(1, std::min<int64_t>((total4 + 1023) / 1024, 1024))),
-                       dim3(256), 0, ctx->stream, Y, K, L, (int64_t)L, bm);
+                       dim3(256), 0, ctx->stream, Y, K_all, L, (int64_t)L, bm);
     KCHK();
     bmax = reinterpret_cast<const float*>(bm);
   }
@@ -757,7 +769,7 @@ static int launch_axb(eofx_ctx* ctx, const float* raw, int64_t ld, int64_t rows,
   if (nfull > 0) {
     if (masked)
       hipLaunchKernelGGL((axb_f16_kernel<4, 0, true>), dim3(gx, nfull), dim3(256), 0, ctx->stream, raw, ld, (int)rows, cols, aff, aff_ld, Y,
-                         L, out, L, rows_pad, K, plan.kps, plan.S, rt, 0, a_scale, bmax);
+                         L, out, L, rows_pad, K, plan.kps, plan.S, rt, 0, a_scale, bmax, act);
     else
       hipLaunchKernelGGL(axb_f16_kernel<4>, dim3(gx, nfull), dim3(256), 0, ctx->stream, raw, ld, (int)rows, cols, aff, aff_ld, Y, L, out,
                          L, rows_pad, K, plan.kps, plan.S, rt, 0, a_scale, bmax);
@@ -766,7 +778,7 @@ static int launch_axb(eofx_ctx* ctx, const float* raw, int64_t ld, int64_t rows,
   if (rem) {
     if (masked)
       hipLaunchKernelGGL((axb_f16_kernel<2, 0, true>), dim3(gx, 1), dim3(256), 0, ctx->stream, raw, ld, (int)rows, cols, aff, aff_ld, Y, L,
-                         out, L, rows_pad, K, plan.kps, plan.S, rt, nfull * 64, a_scale, bmax);
+                         out, L, rows_pad, K, plan.kps, plan.S, rt, nfull * 64, a_scale, bmax, act);
     else
       hipLaunchKernelGGL(axb_f16_kernel<2>, dim3(gx, 1), dim3(256), 0, ctx->stream, raw, ld, (int)rows, cols, aff, aff_ld, Y, L, out,
                          L, rows_pad, K, plan.kps, plan.S, rt, nfull * 64, a_scale, bmax);
@@ -1024,11 +1036,13 @@ extern "C" int eofx_mat_destroy(eofx_ctx* ctx, eofx_mat* m) {
     // same-stream reuse is ordered; nothing else touches these buffers
     if (m->X) pool_give(ctx, m->X, bytes);
     if (m->Xt) pool_give(ctx, m->Xt, bytes);
+    if (m->act) pool_give(ctx, m->act, sizeof(int) * (size_t)(round_up(m->p, AXB_KG) / AXB_KG));
     pool_give(ctx, m->absmax_dev, 256);
     if (m->raw_owned) pool_give(ctx, m->raw_owned, m->raw_owned_bytes);
   } else {
     if (m->X) (void)hipFree(m->X);
     if (m->Xt) (void)hipFree(m->Xt);
+    if (m->act) (void)hipFree(m->act);
     if (m->raw_owned) (void)hipFree(m->raw_owned);
   }
   if (m->aff) {
@@ -1582,11 +1596,41 @@ static int panel_tmul(eofx_ctx* ctx, const eofx_mat* m, const float* Zn, float* 
   CHK(ensure_X(ctx, m));
   return launch_atb(ctx, m->X, m->p_pad, round_up(m->n, ATB_KG), m->p_pad, Zn, L, L, Yp, prec, m->absmax);
 }
+// The active slab pairs of a masked in-place matrix (eofx_mat::act): one look at the map's scales, once per matrix.
+static int ensure_active_pairs(eofx_ctx* ctx, const eofx_mat* cm) {
+  eofx_mat* m = const_cast<eofx_mat*>(cm);
+  if (!m->masked || m->n_act >= 0 || !m->aff) return EOFX_OK;
+  const int64_t npairs = round_up(m->p, AXB_KG) / AXB_KG;
+  std::vector<float> sc((size_t)m->p_pad);
+  HIPCHK(hipMemcpyAsync(sc.data(), m->aff + 2 * m->p_pad, sizeof(float) * (size_t)m->p_pad, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  std::vector<int> list;
+  list.reserve((size_t)npairs);
+  for (int64_t q = 0; q < npairs; ++q) {
+    bool any = false;
+    for (int64_t c = q * AXB_KG; c < std::min<int64_t>((q + 1) * AXB_KG, m->p) && !any; ++c) any = sc[(size_t)c] != 0.f;
+    if (any) list.push_back((int)q);
+  }
+  m->n_act = (int64_t)list.size();
+  if (m->n_act == npairs || m->n_act == 0) return EOFX_OK;     // nothing to skip (or nothing at all): no list
+  if (pool_malloc(ctx, (void**)&m->act, sizeof(int) * (size_t)npairs) != hipSuccess) {
+    (void)hipGetLastError();
+    m->act = nullptr;
+    return EOFX_OK;                                              // (without the list every pair is read: still correct)
+  }
+  HIPCHK(hipMemcpyAsync(m->act, list.data(), sizeof(int) * list.size(), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));                     // `list` leaves scope
+  return EOFX_OK;
+}
+
 static int panel_mul(eofx_ctx* ctx, const eofx_mat* m, const float* Yp, float* Wn, int L, int prec) {
   if (!m->Xt && m->raw && m->aff && prec == EOFX_PREC_F16X3 &&
       round_up(m->p, AXB_KG) * (int64_t)L < ((int64_t)1 << 31) &&
-      64 * m->raw_ld + round_up(m->p, AXB_KG) < ((int64_t)1 << 30))   // in place: stream the raw field along its rows
-    return launch_axb(ctx, m->raw, m->raw_ld, m->n, m->p, m->n_pad, m->aff, m->p_pad, m->absmax, Yp, L, Wn, m->masked);
+      64 * m->raw_ld + round_up(m->p, AXB_KG) < ((int64_t)1 << 30)) {   // in place: stream the raw field along its rows
+    CHK(ensure_active_pairs(ctx, m));
+    return launch_axb(ctx, m->raw, m->raw_ld, m->n, m->p, m->n_pad, m->aff, m->p_pad, m->absmax, Yp, L, Wn, m->masked, m->act,
+                      m->n_act);
+  }
   CHK(ensure_Xt(ctx, m));
   return launch_atb(ctx, m->Xt, m->n_pad, round_up(m->p, ATB_KG), m->n_pad, Yp, L, L, Wn, prec, m->absmax);
 }

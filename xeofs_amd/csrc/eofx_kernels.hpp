@@ -452,6 +452,11 @@ __global__ __launch_bounds__(256, NB > 2 ? 1 : 2) void atb_f16_kernel(const floa
     sla_ = *reinterpret_cast<const f32x4*>(aff + 2 * aff_ld + m0 + 4 * li) * a_scale;   // exact: a power of two
   }
   const f32x4 nls_ = -(shl_ * sla_);
+  // MASK: a wave whose 128 features are ALL masked streams nothing -- it only takes its part in staging B (its rows of C
+  // stay zero) -- and a workgroup of four such waves leaves at once: where masked grid points come in runs (land in an
+  // ocean field) their 512-byte row segments drop out of the stream.  (Skipping per LANE inside the common loop made
+  // the slab registers conditional and the kernel spill.)
+  const bool wave_live = !(AFF && MASK) || __any(sla_[0] != 0.f || sla_[1] != 0.f || sla_[2] != 0.f || sla_[3] != 0.f);
   float m1 = -1.f;   // opaque to the optimiser (split_f16_mix)
   asm volatile("" : "+v"(m1));
   // B staging.  The MFMA fragment of a lane is Bs[plane][lh][column][0..7] = slab rows lh, lh + 2, .., lh + 14 of one
@@ -569,7 +574,22 @@ __global__ __launch_bounds__(256, NB > 2 ? 1 : 2) void atb_f16_kernel(const floa
     EOFX_MFMA_J(3, al_)                                                                          \
   } while (0)
 
-  if (nchunks > 0) {     // nchunks is even (K and k_per_split are multiples of ATB_KG = two slabs)
+  bool wg_live = true;
+  if constexpr (AFF && MASK) wg_live = __syncthreads_or(wave_live) != 0;
+  if (nchunks > 0 && wg_live && !wave_live) {   // (MASK) the B hand-over only: the same barriers as the streaming waves
+    EOFX_LOAD_B(0);
+    EOFX_STORE_B(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; c += 2) {
+      const int c2 = (c + 2 < nchunks) ? c + 2 : c;
+      EOFX_LOAD_B(c + 1);
+      EOFX_STORE_B(1);
+      __syncthreads();
+      EOFX_LOAD_B(c2);
+      EOFX_STORE_B(0);
+      __syncthreads();
+    }
+  } else if (nchunks > 0 && wg_live) {     // nchunks is even (K and k_per_split are multiples of ATB_KG = two slabs)
     EOFX_LOAD_B(0);
     EOFX_LOAD_A(a0, 0);
     EOFX_LOAD_A(a1, 1);
@@ -652,7 +672,8 @@ __global__ __launch_bounds__(256, 2) void axb_f16_kernel(const float* __restrict
                                                           const float* __restrict__ B, int ldb, float* __restrict__ C,
                                                           int ldc, int64_t c_rows, int64_t K, int64_t k_per_split,
                                                           int splits, int row_tiles, int col_base, float a_scale,
-                                                          const float* __restrict__ b_absmax) {
+                                                          const float* __restrict__ b_absmax,
+                                                          const int* __restrict__ act = nullptr) {
   __shared__ __attribute__((aligned(16))) _Float16 Bs[2][2][8][64][8];    // [buffer][plane][k-group of 8][column slot][8]
   __shared__ __attribute__((aligned(16))) _Float16 As[4][2][64][AXB_LDA];
   const int tid = threadIdx.x;
@@ -667,9 +688,16 @@ __global__ __launch_bounds__(256, 2) void axb_f16_kernel(const float* __restrict
   const bool full = r0 + 64 <= a_rows;
   const unsigned ldab = (unsigned)lda * 4u;   // row pitch in bytes
   const unsigned lrl = (unsigned)lr * ldab;   // this lane's row inside a group of 8
-  const int64_t kb = (int64_t)split * k_per_split;
-  const int64_t ke = (kb + k_per_split < K) ? kb + k_per_split : K;
-  const int nslab = (int)((ke - kb) / AXB_KC);
+  // MASK with an active list (`act`: the 64-feature slab pairs that hold at least one unmasked feature, ascending): K and
+  // k_per_split count ACTIVE features, the split walks its share of the list and the addresses come from the list
+  // entries -- slab pairs made of masked grid points only (land in an ocean field) are never read.
+  const bool listed = MASK && act != nullptr;
+  const int64_t kb_ = (int64_t)split * k_per_split;
+  const int64_t ke = (kb_ + k_per_split < K) ? kb_ + k_per_split : K;
+  const int nslab = (int)((ke - kb_) / AXB_KC);
+  const int64_t kb = (MASK && listed) ? 0 : kb_;           // address base of the split
+  const int* const actp = (MASK && listed) ? act + kb_ / AXB_KG : nullptr;
+#define EOFX_PAIR(i) (listed ? actp[(i)] : (i))            /* absolute pair id of the split's i-th pair (uniform) */
   const int bcol0 = col_base + blockIdx.y * 64;
   const float b_scale = f16_scale_for(*b_absmax);
   const float out_scale = 1.f / (a_scale * b_scale);   // exact: both are powers of two
@@ -831,36 +859,69 @@ __global__ __launch_bounds__(256, 2) void axb_f16_kernel(const float* __restrict
     }                                                                                                  \
   } while (0)
 
-  if (nslab > 0) {   // nslab is even (k_per_split and K are multiples of AXB_KG = 64 = one B slab = two A slabs)
+  // One pair = one 64-feature B slab (LDS buffer pb) = two A slabs.  The B slab of the NEXT pair goes to the other
+  // buffer half by half (8 registers in flight, not 16): its first half was requested during the previous pair, its
+  // second half is requested now and stored between the two slabs.  ONE workgroup barrier per pair: the B hand-over is
+  // the only shared state (with a barrier per slab the kernel ran 3 % slower).
+  if constexpr (!MASK) {
+    if (nslab > 0) {   // nslab is even (k_per_split and K are multiples of AXB_KG = 64 = one B slab = two A slabs)
+      const int npair = nslab / 2;
+      EOFX_LOAD_BH(0, 0);
+      EOFX_LOAD_F(fr, 0);
+      EOFX_LOAD_A(a0, 0, 0);
+      EOFX_LOAD_A(a0, 0, 4);
+      EOFX_STORE_BH(0, 0);
+      EOFX_LOAD_BH(0, 1);
+      EOFX_LOAD_A(a1, 1, 0);
+      EOFX_LOAD_A(a1, 1, 4);
+      EOFX_STORE_BH(0, 1);
+      EOFX_LOAD_BH(npair > 1 ? 1 : 0, 0);
+      __syncthreads();
+      for (int pr = 0; pr < npair; ++pr) {
+        const int pb = pr & 1;
+        const int c2 = pr + 1 < npair ? 2 * pr + 2 : 2 * pr;          // past the end: harmless re-reads of the last pair
+        const int p1 = pr + 1 < npair ? pr + 1 : npair - 1, p2 = pr + 2 < npair ? pr + 2 : npair - 1;
+        EOFX_STORE_BH(1 - pb, 0);
+        EOFX_LOAD_BH(p1, 1);
+        EOFX_SLAB(a0, pb, 0, 2 * pr + 1, c2);
+        EOFX_STORE_BH(1 - pb, 1);
+        EOFX_LOAD_BH(p2, 0);
+        EOFX_SLAB(a1, pb, 1, c2, c2 + 1);
+        __syncthreads();
+      }
+    }
+  } else if (nslab > 0) {   // the same schedule with the pair ids taken from the active list (or the identity)
     const int npair = nslab / 2;
-    EOFX_LOAD_BH(0, 0);
-    EOFX_LOAD_F(fr, 0);
-    EOFX_LOAD_A(a0, 0, 0);
-    EOFX_LOAD_A(a0, 0, 4);
-    EOFX_STORE_BH(0, 0);
-    EOFX_LOAD_BH(0, 1);
-    EOFX_LOAD_A(a1, 1, 0);
-    EOFX_LOAD_A(a1, 1, 4);
-    EOFX_STORE_BH(0, 1);
-    EOFX_LOAD_BH(npair > 1 ? 1 : 0, 0);
+    {
+      const int q0 = EOFX_PAIR(0), q1 = EOFX_PAIR(npair > 1 ? 1 : 0);
+      EOFX_LOAD_BH(q0, 0);
+      EOFX_LOAD_F(fr, 2 * q0);
+      EOFX_LOAD_A(a0, 2 * q0, 0);
+      EOFX_LOAD_A(a0, 2 * q0, 4);
+      EOFX_STORE_BH(0, 0);
+      EOFX_LOAD_BH(q0, 1);
+      EOFX_LOAD_A(a1, 2 * q0 + 1, 0);
+      EOFX_LOAD_A(a1, 2 * q0 + 1, 4);
+      EOFX_STORE_BH(0, 1);
+      EOFX_LOAD_BH(q1, 0);
+    }
     __syncthreads();
-    // One pair = one 64-feature B slab (LDS buffer pb) = two A slabs.  The B slab of the NEXT pair goes to the other
-    // buffer half by half (8 registers in flight, not 16): its first half was requested during the previous pair, its
-    // second half is requested now and stored between the two slabs.  ONE workgroup barrier per pair: the B hand-over is
-    // the only shared state (with a barrier per slab the kernel ran 3 % slower).
     for (int pr = 0; pr < npair; ++pr) {
       const int pb = pr & 1;
-      const int c2 = pr + 1 < npair ? 2 * pr + 2 : 2 * pr;          // past the end: harmless re-reads of the last pair
-      const int p1 = pr + 1 < npair ? pr + 1 : npair - 1, p2 = pr + 2 < npair ? pr + 2 : npair - 1;
+      // pair ids of this, the next and the next-but-one pair (past the end: harmless re-reads of the last pair)
+      const int q0 = EOFX_PAIR(pr), p1 = EOFX_PAIR(pr + 1 < npair ? pr + 1 : npair - 1);
+      const int p2 = EOFX_PAIR(pr + 2 < npair ? pr + 2 : npair - 1);
+      const int c2 = 2 * p1;
       EOFX_STORE_BH(1 - pb, 0);
       EOFX_LOAD_BH(p1, 1);
-      EOFX_SLAB(a0, pb, 0, 2 * pr + 1, c2);
+      EOFX_SLAB(a0, pb, 0, 2 * q0 + 1, c2);
       EOFX_STORE_BH(1 - pb, 1);
       EOFX_LOAD_BH(p2, 0);
       EOFX_SLAB(a1, pb, 1, c2, c2 + 1);
       __syncthreads();
     }
   }
+#undef EOFX_PAIR
 #undef EOFX_AXB_LD
 #undef EOFX_LOAD_BH
 #undef EOFX_LOAD_F
