@@ -802,10 +802,13 @@ static int launch_axb(eofx_ctx* ctx, const float* raw, int64_t ld, int64_t rows,
 // number of row-strided partial Gram matrices: >= 4 slabs of 32 rows per workgroup for the narrow
 // (sketch-width) panels; wide panels already expose (L/64)^2 sub-blocks, so fewer partials (<= 64 MB)
 static int gram_parts(int64_t rows, int L) {
-  // workgroups along the rows; every wave writes its own partial (4 per workgroup, each L x L float64):
+  // workgroups along the rows; every workgroup writes one partial (L x L float64):
   // >= 8 k-steps (32 rows) per wave, <= 64 MB of partials
-  const int64_t by_rows = std::min<int64_t>((rows + 127) / 128, 512);
-  const int64_t by_mem = ((int64_t)64 << 20) / ((int64_t)L * L * 8 * 4);
+  // (one workgroup per CU: the products run at the fp64 MFMA rate either way -- ~45 TFLOP/s here -- and every further
+  // partial is 8 L^2 bytes written and read again: 194 / 210 / 243 us for 256 / 512 / 1024 partials of a 1M x 64 panel)
+  const int64_t by_rows = std::min<int64_t>((rows + 127) / 128, 256);
+  const int64_t by_mem = ((int64_t)64 << 20) / ((int64_t)L * L * 8);
+  if (const char* ev = std::getenv("EOFX_GRAM_PARTS")) return std::max(1, atoi(ev));   // tuning hook (tools/small_kernel_probe.py)
   return (int)std::max<int64_t>(1, std::min(by_rows, std::max<int64_t>(by_mem, 1)));
 }
 
@@ -813,12 +816,12 @@ static int launch_gram(eofx_ctx* ctx, const float* P, int64_t rows, int L, doubl
   const int nb = (L + 63) / 64;
   const int nbx = gram_parts(rows, L);
   ArenaScope scope(ctx);
-  ARENA(double, part, (size_t)nbx * 4 * L * L);
+  ARENA(double, part, (size_t)nbx * L * L);
   hipLaunchKernelGGL(gram_mfma_kernel, dim3(nbx, nb * nb), dim3(256), 0, ctx->stream, P, rows, L, part);
   KCHK();
   const int64_t count = (int64_t)L * L;
   hipLaunchKernelGGL(f64_reduce_kernel, dim3((int)((count + 63) / 64)), dim3(256), 0, ctx->stream,
-                     part, G, count, nbx * 4);
+                     part, G, count, nbx);
   KCHK();
   return EOFX_OK;
 }

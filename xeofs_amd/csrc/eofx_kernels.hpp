@@ -1197,8 +1197,8 @@ __global__ __launch_bounds__(256) void gram_f64_kernel(const float* __restrict__
 
 // ---------------------------------------------------------------------------------
 // gram_mfma: the same float64 Gram matrix on the fp64 matrix cores (v_mfma_f64_16x16x4_f64).
-//   grid = (nbx, nb*nb); every WAVE writes its own partial (4 * nbx partials per 64x64 sub-block) so no
-//   cross-wave reduction is needed; the partials are summed in a fixed order by f64_reduce_kernel.
+//   grid = (nbx, nb*nb); every workgroup writes one partial of its 64x64 sub-block (its four waves meet in LDS in a fixed
+//   order); the nbx partials are summed in a fixed order by f64_reduce_kernel.
 //   Per k-step a wave reads 4 rows x 64 columns (lane (c = l % 16, k = l / 16) loads the float4 at
 //   P[row + k][64 b + 4 c ..]: one full 256 B row per 16 lanes), converts to float64 and issues the 16
 //   products a[qa] x b[qb]: lane c of "column group" q stands for column 4 c + q, so tile (qa, qb) holds
@@ -1259,21 +1259,41 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(const float* __restrict_
       }
     }
   }
-  double* G = Gpart + ((int64_t)blockIdx.x * 4 + wave) * (int64_t)L * L;
+  // The four waves add their tiles into ONE 64 x 64 block in LDS, wave after wave (fixed order), and the workgroup writes
+  // a single partial: a quarter of the partial traffic (one partial per WAVE made the write + the reduction as long as
+  // the products themselves: 67 MB of partials for a 265 MB panel, profiles/r03_small_kernel_probe.txt).
+  __shared__ double Gs[64][65];
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
 #pragma unroll
-  for (int x = 0; x < 4; ++x)
+      for (int x = 0; x < 4; ++x)
 #pragma unroll
-    for (int y = 0; y < 4; ++y)
+        for (int y = 0; y < 4; ++y) {
+          if (same && x > y) continue;                          // (tile (y, x) writes both triangles)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int i = lk + 4 * q, j = lc;                       // D[lane / 16 + 4 reg][lane % 16] (measured layout)
-        const int gi = 64 * bi + 4 * i + x, gj = 64 * bj + 4 * j + y;
-        if (same && x > y) continue;                            // (written by tile (y, x) below)
-        if (gi < L && gj < L) {
-          G[(int64_t)gi * L + gj] = acc[x][y][q];
-          if (!same || x < y) G[(int64_t)gj * L + gi] = acc[x][y][q];
+          for (int q = 0; q < 4; ++q) {
+            const int i = 4 * (lk + 4 * q) + x, j = 4 * lc + y; // D[lane / 16 + 4 reg][lane % 16] (measured layout)
+            if (w == 0) {
+              Gs[i][j] = acc[x][y][q];
+              if (same && x < y) Gs[j][i] = acc[x][y][q];
+            } else {
+              Gs[i][j] += acc[x][y][q];
+              if (same && x < y) Gs[j][i] += acc[x][y][q];
+            }
+          }
         }
-      }
+    }
+    __syncthreads();
+  }
+  double* G = Gpart + (int64_t)blockIdx.x * (int64_t)L * L;
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    const int i = e >> 6, j = e & 63;
+    const int gi = 64 * bi + i, gj = 64 * bj + j;
+    if (gi < L && gj < L) {
+      G[(int64_t)gi * L + gj] = Gs[i][j];
+      if (!same) G[(int64_t)gj * L + gi] = Gs[i][j];
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void f64_reduce_kernel(const double* __restrict__ part,
