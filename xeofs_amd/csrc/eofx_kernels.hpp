@@ -646,8 +646,8 @@ __global__ __launch_bounds__(256, NB > 2 ? 1 : 2) void atb_f16_kernel(const floa
 //      x one 128-byte line each: every line is touched exactly once and does not settle in L2, which stays free for
 //      the B slabs), maps + splits its 4 features per lane in registers -- a lane keeps the same 4 features of the slab
 //      for all 8 row groups, so its {shift hi, shift lo, scale} triples are three 16-byte loads per slab -- and
-//      transposes through a PRIVATE LDS region ([plane][row][32 halves], rows padded to 80 bytes: conflict-free
-//      16-byte reads in the operand layout of v_mfma_f32_16x16x32_f16).  Wave-private, so no workgroup barrier guards
+//      transposes through a PRIVATE LDS region ([plane][row][32 halves], 16-byte chunks XOR-swizzled by the row:
+//      conflict-free 8-byte stores and 16-byte reads in the operand layout of v_mfma_f32_16x16x32_f16).  Wave-private, so no workgroup barrier guards
 //      it.  (Loading in the operand layout directly -- one row per lane -- needs cached loads, the second touch of every
 //      line then relies on L1 and the stream evicts the B slabs from L2: 17 % more HBM traffic, measured.)
 //   B  32 x 64 slab through LDS as two fp16 planes [k-group][column][8], XOR-swizzled columns, written as packed
@@ -662,7 +662,7 @@ __global__ __launch_bounds__(256, NB > 2 ? 1 : 2) void atb_f16_kernel(const floa
 constexpr int AXB_KC = 32;    // features per slab
 constexpr int AXB_KG = 64;    // K granularity: slabs are consumed in pairs
 constexpr int AXB_BM = 256;   // rows per workgroup
-constexpr int AXB_LDA = 40;   // halves per staged row (32 + 8 of padding)
+constexpr int AXB_LDA = 32;   // halves per staged row: 64 bytes = four 16-byte chunks, chunk c of row r stored at c ^ ((r >> 1) & 3)
 
 // DBG (tools/probes/axb_probe.hip only): 1 no MFMA, 2 no conversion either, 4 no B / map loads, 8 cached A loads
 // MASK: as in atb_f16_kernel -- features with scale 0 (all-NaN grid points kept as zero columns) are ANDed to +0.
@@ -680,6 +680,13 @@ __global__ __launch_bounds__(256, 2) void axb_f16_kernel(const float* __restrict
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: scalar branches below
   const int ln = lane & 15, g = lane >> 4;
   const int lr = lane >> 3, lc = lane & 7;   // loader view: row inside a group of 8, 16-byte chunk of the 128-byte line
+  // A staging without bank conflicts on either side: rows are 64 bytes (no padding) and the 16-byte chunk c of row r sits
+  // at chunk c ^ ((r >> 1) & 3).  A store instruction (8-byte items, 16 lanes per LDS cycle = two adjacent rows x 64
+  // bytes) then covers all 32 banks once, and so does a 16-byte fragment read (8 lanes per cycle = 8 rows, one chunk
+  // each).  [Rows padded to 80 bytes were conflict-free for the reads only: every store took twice its cycles, 64 of the
+  // 113 bank-conflict cycles per slab and wave in profiles/r03_sq_counters.txt.]  Halves: column offsets in a row.
+  const int a_wc = 8 * ((lc >> 1) ^ ((lr >> 1) & 3)) + 4 * (lc & 1);   // store: halves 4 lc .. 4 lc + 3 of row 8 u + lr
+  const int a_rc = 8 * (g ^ ((ln >> 1) & 3));                          // read:  halves 8 g .. 8 g + 7 of row 16 t + ln
   const int slot_ = splits > 1 ? (int)blockIdx.x >> 3 : (int)blockIdx.x;
   const int split = splits > 1 ? ((int)blockIdx.x & 7) + 8 * (slot_ / row_tiles) : 0;
   if (split >= splits) return;
@@ -800,15 +807,15 @@ __global__ __launch_bounds__(256, 2) void axb_f16_kernel(const float* __restrict
         lo_[h] = __builtin_bit_cast(unsigned, q_);                                                     \
       }                                                                                                \
     }                                                                                                  \
-    *reinterpret_cast<u32x2*>(&As[wave][0][8 * u + lr][4 * lc]) = hi_;                                 \
-    *reinterpret_cast<u32x2*>(&As[wave][1][8 * u + lr][4 * lc]) = lo_;                                 \
+    *reinterpret_cast<u32x2*>(&As[wave][0][8 * u + lr][a_wc]) = hi_;                                   \
+    *reinterpret_cast<u32x2*>(&As[wave][1][8 * u + lr][a_wc]) = lo_;                                   \
   }
   // 32 rows (two 16-row tiles) x NQ column tiles: the three products ordered so that dependent MFMAs are 2 NQ apart
 #define EOFX_AXB_MFMA(jh, buf, hs)     /* hs: which half of the 64-feature B slab this A slab is */      \
   do {                                                                                                 \
     f16x8 af_[2][2], bf_[2][NQ];                                                                       \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int s = 0; s < 2; ++s)        \
-        af_[j][s] = *reinterpret_cast<const f16x8*>(&As[wave][s][16 * (2 * (jh) + j) + ln][8 * g]);    \
+        af_[j][s] = *reinterpret_cast<const f16x8*>(&As[wave][s][16 * (2 * (jh) + j) + ln][a_rc]);     \
     _Pragma("unroll") for (int q = 0; q < NQ; ++q) {                                                   \
       const int col_ = 16 * q + ln;                                                                    \
       const int sl_ = col_ ^ ((col_ >> 3) & 7);                                                        \
