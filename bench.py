@@ -175,9 +175,12 @@ def leg_configs(ctx, device, orc, layout_kw, quick=False):
     del F
 
     def c3(tsc):
+        # the 129 600 x 30 sketch (host, 6 ms of sklearn's RandomState stream) is drawn while the two preprocess passes run,
+        # as the model class does (xeofs_amd/cross/cpcca.py)
+        om = engine.SketchFuture(min(X.shape[1], Y.shape[1]), k + N_OVERSAMPLES, 5)
         mx, _ = engine.preprocess(ctx, X, want_stats=False)
         my, _ = engine.preprocess(ctx, Y, want_stats=False)
-        r = engine.crosscov_rsvd(ctx, mx, my, k, random_state=5, want_tsc=tsc)
+        r = engine.crosscov_rsvd(ctx, mx, my, k, random_state=5, want_tsc=tsc, omega=om.result())
         mx.free()
         my.free()
         return r

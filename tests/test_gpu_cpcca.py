@@ -70,6 +70,39 @@ def test_cpcca_fit_vs_oracle(ctx, alpha, use_pca):
     _check_fit(m, ref)
 
 
+def test_mca_matrix_free_sketch_drawn_ahead(ctx):
+    """MCA(use_pca=False) on fields wide enough for the sketch to be drawn ahead (cpcca.py::_sketch_ahead): the draw is as
+    tall as the RAW feature count of the narrower field and its leading rows are used -- numpy fills row by row, so they
+    are exactly what `RandomState(seed).normal(size=(valid features, l))` gives the oracle -- here with all-NaN grid
+    points dropped from the narrower field."""
+    import xeofs_amd as xe
+
+    rng = np.random.default_rng(4)
+    n, k = 60, 3
+    T = rng.standard_normal((n, 5)) * np.array([9.0, 6.0, 4.0, 1.0, 0.5])
+    A = (T @ rng.standard_normal((5, 64 * 60)) + 0.3 * rng.standard_normal((n, 64 * 60))).astype(np.float32)
+    B = (T @ rng.standard_normal((5, 50 * 70)) + 0.3 * rng.standard_normal((n, 50 * 70))).astype(np.float32)
+    B[:, rng.choice(B.shape[1], 100, replace=False)] = np.nan          # the narrower field loses 100 grid points
+    X = xe.DataArray(A.reshape(n, 64, 60), dims=("time", "lat", "lon"))
+    Y = xe.DataArray(B.reshape(n, 50, 70), dims=("time", "y", "x"))
+    m = xe.cross.MCA(n_modes=k, use_pca=False, random_state=11)
+    m._SKETCH_AHEAD_MIN = 2000                                          # (production: 20 000 features and more)
+    fut = m._sketch_ahead(X, Y, "time")
+    assert fut is not None and fut[0].result().shape == (3500, k + 10)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m.fit(X, Y, "time")
+        ref = orc.cpcca_fit(A.astype(np.float64), B.astype(np.float64), k, alpha=1.0, use_pca=False, random_state=11)
+    assert np.allclose(m.singular_values().values, ref["singular_values"], rtol=2e-5)
+    c1, c2 = m.components()
+    C2 = c2.values.reshape(k, -1).T
+    vf = ~np.isnan(B).all(axis=0)
+    assert np.isnan(C2[~vf]).all()
+    for j in range(k):
+        r = ref["components2"][:, j]
+        assert abs(np.dot(C2[vf, j].astype(np.float64), r)) / np.linalg.norm(C2[vf, j]) / np.linalg.norm(r) > 1 - 1e-5
+
+
 @pytest.mark.parametrize("cls_name,alpha", [("CCA", 0.0), ("RDA", [0.0, 1.0]), ("MCA", 1.0)])
 def test_named_models(ctx, cls_name, alpha):
     import xeofs_amd as xe

@@ -186,6 +186,7 @@ class CPCCA(Deferred):
     def _fit_now(self, X, Y, dim, weights_X=None, weights_Y=None):
         self.ctx = self.ctx or engine.default_context()
         self.preprocessor1.ctx = self.preprocessor2.ctx = self.ctx
+        ahead = self._sketch_ahead(X, Y, dim)       # drawn on a worker thread while the two fields are preprocessed
         mx = self.preprocessor1.fit_transform(X, dim, weights_X)
         my = self.preprocessor2.fit_transform(Y, dim, weights_Y)
         self.sample_dims = self.preprocessor1.sample_dims
@@ -214,8 +215,15 @@ class CPCCA(Deferred):
             n_over, n_iter = rank - k, 0
         n_over = min(n_over, rank - k)         # a sketch as wide as the rank is already exact
         identity = sx.Tinv is None and sy.Tinv is None
+        omega = None
+        if ahead is not None:
+            om, l_ahead = ahead
+            om = om.result()
+            small_ = min(sx.work.p, sy.work.p)
+            if l_ahead == k + n_over and om.shape[0] >= small_:      # numpy fills row by row: the leading rows ARE the draw
+                omega = np.ascontiguousarray(om[:small_])
         out = engine.crosscov_rsvd(self.ctx, sx.work, sy.work, k, n_over, n_iter, random_state=self.random_state,
-                                   want_tsc=identity)
+                                   want_tsc=identity, omega=omega)
         s = out["s"].astype(np.float64)
         self._q = [out["Q1"].astype(np.float64), out["Q2"].astype(np.float64)]     # in the analysis space
         tsc = out["total_squared_covariance"] if identity else self._unwhitened_tsc()
@@ -229,6 +237,30 @@ class CPCCA(Deferred):
             norm1=out["norm1"].astype(np.float64), norm2=out["norm2"].astype(np.float64),
         )
         return self
+
+    _SKETCH_AHEAD_MIN = 20000
+
+    def _sketch_ahead(self, X, Y, dim):
+        """The matrix-free path (no PCA pre-reduction) sketches on the smaller FEATURE side: min(p1, p2) x (k + oversamples)
+        normals of sklearn's RandomState stream, 6 ms at 129 600 x 30.  Its height depends on the NaN mask, but numpy
+        fills the array row by row, so a draw as tall as the raw feature count contains the one that is needed as its
+        leading rows: start it before the preprocessing.  -> (SketchFuture, width) or None"""
+        try:
+            if any(self._params["use_pca"]) or self.solver == "full" or not isinstance(self.random_state, (int, np.integer)):
+                return None
+            sd = (dim,) if isinstance(dim, str) else tuple(dim)
+            ps = []
+            for Z in (X, Y):
+                vals, dims, _, _, _ = labelled.unpack(Z)
+                n = int(np.prod([vals.shape[dims.index(d)] for d in sd]))
+                ps.append(int(np.prod(tuple(vals.shape), dtype=np.int64)) // max(n, 1))
+            kw = dict(self.solver_kwargs)
+            l = int(self.n_modes) + int(kw.get("n_oversamples", 10))
+            if min(ps) < self._SKETCH_AHEAD_MIN or l > min(ps):       # small draws are not worth a thread
+                return None
+            return engine.SketchFuture(min(ps), l, int(self.random_state)), l
+        except Exception:
+            return None
 
     def _unwhitened_tsc(self):
         """cpcca.py:991-1000: sum |Tinv1^T C Tinv2|^2 = || A1^T A2 ||_F^2 / (n-1)^2 on the unwhitened matrices"""
