@@ -343,7 +343,7 @@ def measure_traffic(args, n, P):
                "--nsamples", str(n), "--nlat", str(args.nlat), "--nlon", str(args.nlon), "--modes", str(args.modes),
                "--layout", args.layout] + (["--two-step"] if args.two_step else [])
         try:
-            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120, check=True)
             vals = {}
             for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
                 with open(f) as fh:
