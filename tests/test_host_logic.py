@@ -1,0 +1,86 @@
+"""Host-side logic of the path that needs no GPU (runs in the CPU suite): the rules that decide which engine route a call
+takes, and the pure-numpy algebra the model classes do on the host."""
+import numpy as np
+import pytest
+
+from oracle import eof_oracle as orc  # noqa: F401  (checker only)
+
+
+def test_sketch_leading_rows_are_the_shorter_draw():
+    """What `CPCCA._sketch_ahead` relies on: numpy fills `RandomState(seed).normal(size=(rows, l))` row by row, so the
+    sketch of a field that lost features to its NaN mask is the leading part of the draw for the raw feature count --
+    for the native generator as for numpy itself."""
+    from xeofs_amd import engine
+
+    for seed, rows, small, l in ((11, 3500, 3400, 13), (5, 20001, 17777, 30), (0, 700, 1, 64)):
+        tall = engine.sketch_matrix(rows, l, seed)
+        short = engine.sketch_matrix(small, l, seed)
+        assert np.array_equal(tall[:small], short)
+        assert np.array_equal(short, np.random.RandomState(seed).normal(size=(small, l)).astype(np.float32))
+        fut = engine.SketchFuture(rows, l, seed)
+        assert np.array_equal(fut.result(), tall)
+
+
+def test_fused_plan_and_lean_rules():
+    """Which calls may take the one-call fit (`Decomposer.fused_plan`: sketch narrower than its 32 / 64-column panel with a
+    spare column, n < P, randomized policy) and which complex models ask for the lean layout (sketches of at most 32
+    complex columns)."""
+    import xeofs_amd as xe
+    from xeofs_amd.linalg.decomposer import Decomposer
+
+    d = Decomposer(n_modes=50, random_state=1)
+    assert d.fused_plan(10000, 1036800) == (50, 10, "auto")           # (the engine resolves sklearn's 7 / 4 rule)
+    assert Decomposer(n_modes=22).fused_plan(5000, 20000) is None          # 32 columns: no spare column for the ones
+    assert Decomposer(n_modes=54).fused_plan(5000, 20000) is None          # 64 columns
+    assert Decomposer(n_modes=55).fused_plan(5000, 20000) is None          # wider than the fused panels
+    assert Decomposer(n_modes=10).fused_plan(3000, 2000) is None           # sketch on the feature side
+    assert Decomposer(n_modes=10).fused_plan(300, 400) is None             # small problem: the full solver
+    assert Decomposer(n_modes=0.9).fused_plan(5000, 20000) is None         # variance-based n_modes
+    assert Decomposer(n_modes=10, solver="full").fused_plan(5000, 20000) is None
+    plan = Decomposer(n_modes=800, random_state=1).fused_plan(10000, 1036800)
+    assert plan is None or plan[0] + plan[1] < 64
+    assert xe.single.HilbertEOF(n_modes=20)._lean_ok() and xe.single.ComplexEOF(n_modes=22)._lean_ok()
+    assert not xe.single.HilbertEOF(n_modes=23)._lean_ok()                 # 33 complex columns: written layouts
+    assert not xe.single.ComplexEOF(n_modes=0.9)._lean_ok()
+    assert xe.single.HilbertEOF(n_modes=28, solver_kwargs={"n_oversamples": 4})._lean_ok()
+
+
+def test_complex_deflated_norms_formula():
+    """`ComplexCPCCA._deflated_norms`: ||(Sx - r1 b1^H)^H (Sy - r2 b2^H)||_F^2 per mode from inner products of n-vectors,
+    against the dense expression (the residual form of the squared covariance fraction, cpcca.py:418-512)."""
+    from xeofs_amd.cross.complex_mca import ComplexCPCCA
+
+    rng = np.random.default_rng(0)
+    c = lambda *s: rng.standard_normal(s) + 1j * rng.standard_normal(s)
+    for n, m1, m2, k in ((50, 7, 9, 3), (31, 12, 4, 4)):
+        Sx, Sy, R1, R2, B1, B2 = c(n, m1), c(n, m2), c(n, k), c(n, k), c(m1, k), c(m2, k)
+        M = Sx.conj().T @ Sy
+        got = ComplexCPCCA._deflated_norms(Sx, Sy, R1, R2, B1, B2, (np.abs(M) ** 2).sum())
+        ref = [np.linalg.norm((Sx - np.outer(R1[:, j], B1[:, j].conj())).conj().T @ (Sy - np.outer(R2[:, j], B2[:, j].conj()))) ** 2
+               for j in range(k)]
+        assert np.allclose(got, ref, rtol=1e-10)
+    # real data is the special case the real CPCCA uses
+    Sx, Sy = rng.standard_normal((40, 6)), rng.standard_normal((40, 5))
+    U, s, Vt = np.linalg.svd(Sx.T @ Sy, full_matrices=False)
+    R1, R2 = Sx @ U[:, :2], Sy @ Vt[:2].T
+    got = ComplexCPCCA._deflated_norms(Sx, Sy, R1, R2, U[:, :2], Vt[:2].T, (s ** 2).sum())
+    assert np.allclose(got, (s ** 2).sum() - s[:2] ** 2, rtol=1e-10)       # alpha = 1: deflation removes sigma_i^2
+
+
+def test_cross_model_sketch_ahead_gate():
+    """`CPCCA._sketch_ahead`: only for the matrix-free path with an integer seed and wide fields; the draw is as tall as the
+    narrower RAW field."""
+    import xeofs_amd as xe
+
+    rng = np.random.default_rng(1)
+    X = xe.DataArray(rng.standard_normal((12, 40, 60)).astype(np.float32), dims=("time", "lat", "lon"))
+    Y = xe.DataArray(rng.standard_normal((12, 30, 70)).astype(np.float32), dims=("time", "y", "x"))
+    m = xe.cross.MCA(n_modes=3, use_pca=False, random_state=4)
+    assert m._sketch_ahead(X, Y, "time") is None                           # 2100 features: below the production gate
+    m._SKETCH_AHEAD_MIN = 1000
+    fut, l = m._sketch_ahead(X, Y, "time")
+    assert l == 13 and fut.result().shape == (2100, 13)
+    assert xe.cross.MCA(n_modes=3, use_pca=True, random_state=4)._sketch_ahead(X, Y, "time") is None
+    unseeded = xe.cross.MCA(n_modes=3, use_pca=False)
+    unseeded._SKETCH_AHEAD_MIN = 1000
+    assert unseeded._sketch_ahead(X, Y, "time") is None
