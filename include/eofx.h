@@ -223,8 +223,11 @@ int eofx_fit_first_f32(eofx_ctx *ctx, const float *X, int64_t n, int64_t P, int 
                        int64_t *n_out, int64_t *p_out, double *total_variance, int *fused);
 /* info3: [0] 1 when the last eofx_fit_f32 / eofx_fit_first_f32 took the fused path, [1] milliseconds of its non-pass work (probe kernel,
  * statistics finalisation, rank-one correction; HIP events, only while profiling is on), [2] why it did not: 0 fused,
- * -1 not eligible, 1 NaN / constant data in the sampled rows, 3 NaN or inf in the field, 4 provisional fp16 range
- * exceeded, 5 both.                                                                                              */
+ * -1 not eligible, 1 NaN / constant data in the sampled rows (a feature that is NaN in SOME of them; or in all of them
+ * while layout mode 3 is not selected), 3 NaN or inf in the field, 4 provisional fp16 range exceeded (or a finite value
+ * in a feature whose sampled rows were all NaN), 5 both, 6 all-NaN grid points outside the range of the masked in-place
+ * layout (40 % of the features or more, or n >= valid features).  In layout mode 3 a field whose NaNs are all-NaN grid
+ * points stays on the fused path: the first pass confines and verifies them by itself (xeofs_amd/csrc/eofx_fit.hpp).  */
 int eofx_ctx_fit_info(const eofx_ctx *ctx, double *info3);
 
 /* scores = X V (eof.py:129).  V host|device [p x k]; out host|device [n x k].   */
