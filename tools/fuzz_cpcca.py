@@ -25,7 +25,9 @@ for case in range(ncase):
         B[:, rng.choice(p2, size=max(1, p2 // 8), replace=False)] = np.nan
     std = bool(rng.integers(0, 2))
     use_pca = bool(rng.integers(0, 2))
-    alpha = float(rng.choice([1.0, 1.0, 0.5, 0.0])) if (use_pca or min(n, n) > max(p1, p2)) else 1.0
+    # whitening without PCA needs n well above p1 + p2: with n <= p1 + p2 the whitened cross-covariance has a whole
+    # subspace of canonical correlations equal to 1 and its leading singular vectors are not unique (seed 81, case 33)
+    alpha = float(rng.choice([1.0, 1.0, 0.5, 0.0])) if (use_pca or n > p1 + p2 + 5) else 1.0
     k = int(rng.integers(1, min(r, 4) + 1))
     npm = int(rng.integers(r + 1, r + 6)) if use_pca else 0.999
     seed = int(rng.integers(0, 1000))
