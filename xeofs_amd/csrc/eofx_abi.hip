@@ -491,7 +491,13 @@ struct AtbPlan {
 // workgroup slot, partial-sum traffic at ~4 TB/s.
 // 128-column tiles (atb_f16_kernel<4>, one workgroup per CU): the wide products (Gram matrices, PCA panels) and the
 // two-matrix form of a 128-column complex panel (33-64 complex columns: Re and Im are then streamed ONCE per pass)
-static bool atb_wide(int L, bool two_matrix = false) { return L >= 256 || (two_matrix && L >= 128); }
+// (round 3: also the single-matrix passes of sketches of 65 columns and more -- EOF with 55+ modes: one 128-column launch at
+// 4.3 TB/s beats two 64-column launches at 6.5 TB/s: 229.7 -> 205.6 ms per rSVD at k = 100, config-4 size)
+static bool atb_wide(int L, bool two_matrix = false) {
+  (void)two_matrix;
+  if (const char* ev = std::getenv("EOFX_ATB_WIDE_MIN")) return L >= atoi(ev);   // tuning hook (tools/wide_sketch_probe.py)
+  return L >= 128;
+}
 static AtbPlan atb_plan(int64_t M, int64_t K, int L, bool wide = false) {
   const int bx = (int)(M / ATB_BM);
   const int bz = wide ? (L + 127) / 128 : (L + 63) / 64;
