@@ -1633,6 +1633,18 @@ static int ensure_active_pairs(eofx_ctx* ctx, const eofx_mat* cm) {
 }
 
 static int panel_mul(eofx_ctx* ctx, const eofx_mat* m, const float* Yp, float* Wn, int L, int prec) {
+  // Wide panels (65 columns and more: EOF with 55+ modes) on an in-place matrix: axb_f16 takes 64 columns per launch, so
+  // every X Y pass would read the field L / 64 times, while the 128-column tile of atb_f16 over the sample-contiguous
+  // layout reads it once per 128.  Where HBM has room for that layout (one more copy of the field), build it once --
+  // 13 ms at config-4 size against ~5 ms saved in each of the 8 passes; the raw field stays the feature-side operand.
+  if (!m->Xt && m->raw && m->aff && !m->masked && prec == EOFX_PREC_F16X3 && L >= 128 && !std::getenv("EOFX_NO_WIDE_XT")) {
+    size_t free_b = 0, total_b = 0;
+    const size_t need_b = (size_t)m->n_pad * m->p_pad * sizeof(float);
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b + ctx->pool_bytes > need_b + need_b / 2 + ((size_t)8 << 30))
+      CHK(ensure_Xt(ctx, m));
+    else
+      (void)hipGetLastError();
+  }
   if (!m->Xt && m->raw && m->aff && prec == EOFX_PREC_F16X3 &&
       round_up(m->p, AXB_KG) * (int64_t)L < ((int64_t)1 << 31) &&
       64 * m->raw_ld + round_up(m->p, AXB_KG) < ((int64_t)1 << 30)) {   // in place: stream the raw field along its rows
