@@ -566,6 +566,38 @@ def test_masked_in_place_skips_masked_runs(ctx, one_call):
     mat.free(); mat2.free()
 
 
+def test_wide_sketch_on_an_in_place_matrix(ctx, monkeypatch):
+    """Sketches of 65+ columns (EOF with 55+ modes) on an in-place matrix: the X^T Z passes run in the 128-column tile over
+    the raw field; for the X Y passes the engine builds the sample-contiguous layout once where HBM has room (128-column
+    tile again) and otherwise (EOFX_NO_WIDE_XT=1 stands in for a full HBM) keeps streaming the field through axb_f16, 64
+    columns per launch.  Same factors either way, against the oracle."""
+    from xeofs_amd import engine
+
+    n, p, k = 400, 6000, 90                        # 100 sketch columns: a 128-column panel
+    X = _field(n, p, rank=110, seed=21)
+    ref = orc.eof_fit(X.astype(np.float64), k, random_state=6)
+    out = {}
+    for no_xt in ("1", None):
+        if no_xt:
+            monkeypatch.setenv("EOFX_NO_WIDE_XT", no_xt)
+        else:
+            monkeypatch.delenv("EOFX_NO_WIDE_XT", raising=False)
+        mat, st = engine.preprocess(ctx, X, in_place=True)
+        assert mat.layout() == (False, True) and not mat.has_sample_layout()
+        U, s, V = engine.rsvd(ctx, mat, k, random_state=6)
+        assert mat.has_sample_layout() == (no_xt is None)              # built only when allowed; the raw field stays the X^T operand
+        assert mat.layout() == (False, True)
+        _check_factors(U, s, V, ref, k)
+        out[no_xt] = s
+        mat.free()
+    assert np.all(np.abs(out["1"] - out[None]) <= 2e-6 * out[None][0])
+    # 64 columns and fewer never build anything
+    mat, st = engine.preprocess(ctx, X, in_place=True)
+    engine.rsvd(ctx, mat, 50, random_state=6)
+    assert not mat.has_sample_layout()
+    mat.free()
+
+
 def test_fused_fit_falls_back(ctx):
     """NaN fields, sketches wider than 64 columns and n >= P take the two-step path inside the same call -- with the
     Sanitizer's policies and error messages -- and say so."""
