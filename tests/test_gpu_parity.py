@@ -573,8 +573,20 @@ def test_wide_sketch_on_an_in_place_matrix(ctx, monkeypatch):
     columns per launch.  Same factors either way, against the oracle."""
     from xeofs_amd import engine
 
-    n, p, k = 400, 6000, 90                        # 100 sketch columns: a 128-column panel
+    n, p = 400, 6000
     X = _field(n, p, rank=110, seed=21)
+    for k in (70, 90, 200):        # 80 / 100 / 210 sketch columns: panels of 96 (one partial wide tile), 128, 224 (128 + partial)
+        _wide_case(ctx, monkeypatch, X, k)
+    # 64 columns and fewer never build anything
+    mat, st = engine.preprocess(ctx, X, in_place=True)
+    engine.rsvd(ctx, mat, 50, random_state=6)
+    assert not mat.has_sample_layout()
+    mat.free()
+
+
+def _wide_case(ctx, monkeypatch, X, k):
+    from xeofs_amd import engine
+
     ref = orc.eof_fit(X.astype(np.float64), k, random_state=6)
     out = {}
     for no_xt in ("1", None):
@@ -591,11 +603,6 @@ def test_wide_sketch_on_an_in_place_matrix(ctx, monkeypatch):
         out[no_xt] = s
         mat.free()
     assert np.all(np.abs(out["1"] - out[None]) <= 2e-6 * out[None][0])
-    # 64 columns and fewer never build anything
-    mat, st = engine.preprocess(ctx, X, in_place=True)
-    engine.rsvd(ctx, mat, 50, random_state=6)
-    assert not mat.has_sample_layout()
-    mat.free()
 
 
 def test_fused_fit_falls_back(ctx):
@@ -806,13 +813,16 @@ def test_raw_mode_equals_two_layout_mode(ctx, n, P, std, wts):
 
 @pytest.mark.parametrize("n,P,std,wts", [(300, 1024, False, False), (517, 2500, True, True), (1000, 7300, False, True),
                                          (96, 516, True, False), (2100, 640, True, True), (63, 100000, False, False)])
-def test_in_place_mode(ctx, n, P, std, wts):
+def test_in_place_mode(ctx, n, P, std, wts, monkeypatch):
     """eofx_ctx_set_layout(2): the preprocessor writes NO copy of the matrix; X^T Z streams the field through the Scaler
     map exactly as in raw mode and X Y streams it along its rows (axb_f16_kernel: another summation order, so equal to
     rounding, and checked against a float64 product); the randomized SVD built on them
     meets the float64 oracle at the usual 1e-5.  Row / column counts off every tile size; sketch widths 32, 64 and 96.
-    Layouts appear only when an entry point needs them and are bitwise what the apply kernel writes."""
+    Layouts appear only when an entry point needs them and are bitwise what the apply kernel writes.  (EOFX_NO_WIDE_XT:
+    panels of 96+ columns stay on axb_f16 here, as they do when HBM has no room for the sample-contiguous layout;
+    the other branch is test_wide_sketch_on_an_in_place_matrix.)"""
     import torch
+    monkeypatch.setenv("EOFX_NO_WIDE_XT", "1")
     from oracle import eof_oracle as orc
     from xeofs_amd import engine
 

@@ -496,7 +496,7 @@ struct AtbPlan {
 static bool atb_wide(int L, bool two_matrix = false) {
   (void)two_matrix;
   if (const char* ev = std::getenv("EOFX_ATB_WIDE_MIN")) return L >= atoi(ev);   // tuning hook (tools/wide_sketch_probe.py)
-  return L >= 128;
+  return L >= 96;       // (96 columns: one partial 128-column tile, see launch_atb)
 }
 static AtbPlan atb_plan(int64_t M, int64_t K, int L, bool wide = false) {
   const int bx = (int)(M / ATB_BM);
@@ -570,19 +570,22 @@ static void launch_atb_variant(int prec, dim3 grid, hipStream_t st, const float*
                                const float* B, int ldb, float* out, int L, int64_t M, int64_t K,
                                int64_t kps, int col_base, float a_scale, const float* b_absmax,
                                const AffView* aff = nullptr, const float* A2 = nullptr, const float* B2 = nullptr,
-                               int s_half = 0, int sym = 0, unsigned* amax_out = nullptr) {
+                               int s_half = 0, int sym = 0, unsigned* amax_out = nullptr, int l_valid = 128) {
   if (prec == EOFX_PREC_F16X3 && A2)
     hipLaunchKernelGGL(atb_f16_kernel<NB>, grid, dim3(256), 0, st, A, lda, B, ldb, out, L, M, K, kps, col_base,
-                       a_scale, b_absmax, (const float*)nullptr, (int64_t)0, 0, (int64_t)0, A2, B2, s_half, 0, amax_out);
+                       a_scale, b_absmax, (const float*)nullptr, (int64_t)0, 0, (int64_t)0, A2, B2, s_half, 0, amax_out, l_valid);
   else if (prec == EOFX_PREC_F16X3 && aff && aff->masked)
     hipLaunchKernelGGL((atb_f16_kernel<NB, true, true>), grid, dim3(256), 0, st, A, lda, B, ldb, out, L, M, K, kps, col_base,
-                       a_scale, b_absmax, aff->aff, aff->ld, aff->rows, aff->cols, (const float*)nullptr, (const float*)nullptr, 0, sym, amax_out);
+                       a_scale, b_absmax, aff->aff, aff->ld, aff->rows, aff->cols, (const float*)nullptr, (const float*)nullptr, 0, sym, amax_out,
+                       l_valid);
   else if (prec == EOFX_PREC_F16X3 && aff)
     hipLaunchKernelGGL((atb_f16_kernel<NB, true>), grid, dim3(256), 0, st, A, lda, B, ldb, out, L, M, K, kps, col_base,
-                       a_scale, b_absmax, aff->aff, aff->ld, aff->rows, aff->cols, (const float*)nullptr, (const float*)nullptr, 0, sym, amax_out);
+                       a_scale, b_absmax, aff->aff, aff->ld, aff->rows, aff->cols, (const float*)nullptr, (const float*)nullptr, 0, sym, amax_out,
+                       l_valid);
   else if (prec == EOFX_PREC_F16X3)
     hipLaunchKernelGGL(atb_f16_kernel<NB>, grid, dim3(256), 0, st, A, lda, B, ldb, out, L, M, K, kps, col_base,
-                       a_scale, b_absmax, (const float*)nullptr, (int64_t)0, 0, (int64_t)0, (const float*)nullptr, (const float*)nullptr, 0, sym, amax_out);
+                       a_scale, b_absmax, (const float*)nullptr, (int64_t)0, 0, (int64_t)0, (const float*)nullptr, (const float*)nullptr, 0, sym, amax_out,
+                       l_valid);
   else if constexpr (NB <= 2) {     // the 128-column tile exists for the split-fp16 kernel only
     if (prec == EOFX_PREC_BF16X3)
       hipLaunchKernelGGL((atb_bf16_kernel<NB, 2>), grid, dim3(256), 0, st, A, lda, B, ldb, out, L, M, K, kps, col_base);
@@ -609,7 +612,11 @@ static int launch_atb(eofx_ctx* ctx, const float* A, int64_t lda, int64_t K, int
   // wide products (Gram matrices, PCA panels) in 128-column tiles of the split-fp16 kernel, then 64 / 32-column rests
   const bool wide = atb_wide(L, A2 != nullptr) && prec == EOFX_PREC_F16X3;
   if (sym && !(wide && !aff && L == M)) sym = 0;
-  const int n4 = wide ? L / 128 : 0, cb4 = 128 * n4;
+  // wide panels: full 128-column tiles, then -- when 96 columns are left (panels of 96 / 224 columns) -- ONE partial wide tile
+  // instead of a 64- and a 32-column launch (each launch reads the field once)
+  const int n4 = wide ? L / 128 : 0;
+  const int part4 = (wide && L - 128 * n4 == 96) ? 96 : 0;
+  const int cb4 = 128 * n4 + part4;
   const int nfull = (L - cb4) / 64, rem = (L - cb4) % 64;
   const AtbPlan plan = atb_plan(M, K, L, wide);
   int best_s = plan.S;
@@ -690,6 +697,12 @@ static int launch_atb(eofx_ctx* ctx, const float* A, int64_t lda, int64_t K, int
     launch_atb_variant<4>(prec, grid, ctx->stream, A, lda, B, ldb, out, L, M, K, best_kps, 0, a_scale, b_absmax_dev, aff, A2, B2, s_half, sym, amax_direct);
     KCHK();
   }
+  if (part4) {
+    dim3 grid(bx, best_s, 1);
+    launch_atb_variant<4>(prec, grid, ctx->stream, A, lda, B, ldb, out, L, M, K, best_kps, 128 * n4, a_scale, b_absmax_dev, aff, A2, B2, s_half, sym,
+                          amax_direct, part4);
+    KCHK();
+  }
   if (nfull > 0) {
     dim3 grid(bx, best_s, nfull);
     launch_atb_variant<2>(prec, grid, ctx->stream, A, lda, B, ldb, out, L, M, K, best_kps, cb4, a_scale, b_absmax_dev, aff, A2, B2, s_half, sym, amax_direct);
@@ -704,7 +717,7 @@ static int launch_atb(eofx_ctx* ctx, const float* A, int64_t lda, int64_t K, int
     HIPCHK(hipEventRecord(ev1, ctx->stream));
     ctx->prof_events.emplace_back(ev0, ev1);
     ctx->prof_flops += 2.0 * (double)K * (double)M * (double)L * (A2 ? 2 : 1);
-    ctx->prof_bytes += (double)K * (double)M * 4.0 * (n4 + nfull + (rem ? 1 : 0)) * (A2 ? 2 : 1);
+    ctx->prof_bytes += (double)K * (double)M * 4.0 * (n4 + (part4 ? 1 : 0) + nfull + (rem ? 1 : 0)) * (A2 ? 2 : 1);
   }
   if (best_s > 1) {
     const int64_t count4 = M * L / 4;
@@ -1633,11 +1646,11 @@ static int ensure_active_pairs(eofx_ctx* ctx, const eofx_mat* cm) {
 }
 
 static int panel_mul(eofx_ctx* ctx, const eofx_mat* m, const float* Yp, float* Wn, int L, int prec) {
-  // Wide panels (65 columns and more: EOF with 55+ modes) on an in-place matrix: axb_f16 takes 64 columns per launch, so
+  // Wide panels (96 columns and more: EOF with 55+ modes) on an in-place matrix: axb_f16 takes 64 columns per launch, so
   // every X Y pass would read the field L / 64 times, while the 128-column tile of atb_f16 over the sample-contiguous
   // layout reads it once per 128.  Where HBM has room for that layout (one more copy of the field), build it once --
   // 13 ms at config-4 size against ~5 ms saved in each of the 8 passes; the raw field stays the feature-side operand.
-  if (!m->Xt && m->raw && m->aff && !m->masked && prec == EOFX_PREC_F16X3 && L >= 128 && !std::getenv("EOFX_NO_WIDE_XT")) {
+  if (!m->Xt && m->raw && m->aff && !m->masked && prec == EOFX_PREC_F16X3 && L >= 96 && !std::getenv("EOFX_NO_WIDE_XT")) {
     size_t free_b = 0, total_b = 0;
     const size_t need_b = (size_t)m->n_pad * m->p_pad * sizeof(float);
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b + ctx->pool_bytes > need_b + need_b / 2 + ((size_t)8 << 30))

@@ -411,7 +411,9 @@ __global__ __launch_bounds__(256, NB > 2 ? 1 : 2) void atb_f16_kernel(const floa
                                                           int64_t aff_ld = 0, int a_rows = 0, int64_t a_cols = 0,
                                                           const float* A2 = nullptr, const float* B2 = nullptr,
                                                           int s_half = 0, int sym = 0,
-                                                          unsigned* __restrict__ amax_out = nullptr) {
+                                                          unsigned* __restrict__ amax_out = nullptr, int l_valid = 128) {
+  // l_valid (NB = 4 only): columns of this 128-column tile that exist in B and C (96 for the tail of a 96 / 224-column
+  // panel: one partial wide tile instead of a 64- and a 32-column launch that would each read the field again).
   // Two-matrix form (complex passes, eofx_rsvd_c64): splits [s_half, 2 s_half) stream a second matrix A2 (same shape)
   // against its own panel B2 -- C = A^T B + A2^T B2 in one launch, summed by the split-K reduction.
   __shared__ __attribute__((aligned(16))) _Float16 Bs[2][2][2][32 * NB][8];
@@ -482,6 +484,7 @@ __global__ __launch_bounds__(256, NB > 2 ? 1 : 2) void atb_f16_kernel(const floa
     b_w1 = w_ + 16 * (1 - lh_);
   }
   const bool b_item0 = (((tid >> 2) & 3) | ((tid >> 5) << 2)) < CP;   // NB = 1: only the first 128 threads stage B
+  const int b_col0 = 2 * (((tid >> 2) & 3) | ((tid >> 5) << 2));      // first column (inside the tile) of this thread's item 0
   char* const Bsb = reinterpret_cast<char*>(&Bs[0][0][0][0][0]);
   constexpr int B_PLANE = 2 * 32 * NB * 8 * 2, B_BUF = 2 * B_PLANE;   // bytes per fp16 plane / per buffer
 
@@ -492,7 +495,7 @@ __global__ __launch_bounds__(256, NB > 2 ? 1 : 2) void atb_f16_kernel(const floa
 #define EOFX_LOAD_B(chunk)                                                                       \
   do {                                                                                           \
     _Pragma("unroll") for (int r = 0; r < BREP; ++r) {                                           \
-      if (b_item0) {                                                                             \
+      if (b_item0 && (NB < 4 || b_col0 + 64 * r < l_valid)) {   /* (columns beyond l_valid stay zero) */ \
         const float* bp_ = B + (kb + (int64_t)(chunk) * ATB_KC) * ldb + (b_off + 64 * r);         \
         const f32x2 lo_ = *reinterpret_cast<const f32x2*>(bp_);                                  \
         const f32x2 hi_ = *reinterpret_cast<const f32x2*>(bp_ + 2 * ldb);                        \
@@ -623,7 +626,7 @@ __global__ __launch_bounds__(256, NB > 2 ? 1 : 2) void atb_f16_kernel(const floa
       for (int r = 0; r < 16; ++r) {
         const int ii = (r & 3) + 8 * (r >> 2) + 4 * lh;
         const int64_t m = m0 + 4 * ii + j;
-        Cs[m * ldc + bcol0 + 32 * q + li] = acc[j][q][r] * out_scale;
+        if (NB < 4 || 32 * q + li < l_valid) Cs[m * ldc + bcol0 + 32 * q + li] = acc[j][q][r] * out_scale;
       }
   if (amax_out) {
     float mx = 0.f;
