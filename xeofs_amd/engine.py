@@ -216,6 +216,15 @@ class ResidentMatrix:
         self.ctx.lib.eofx_mat_layout(self.handle, C.byref(hx), None)
         return bool(hx.value & 2)
 
+    def ensure_sample_layout(self, only_if_room: bool = True) -> bool:
+        """Build the sample-contiguous layout ahead of repeated decompositions on this matrix (their X Y passes run
+        faster over it than over the raw field).  only_if_room: only when HBM holds one more copy of the field with 8 GB
+        to spare.  -> whether the layout exists afterwards (never for a masked in-place matrix)."""
+        built = C.c_int()
+        raise_for(self.ctx.lib.eofx_mat_ensure_sample_layout(self.ctx.handle, self.handle, int(only_if_room), C.byref(built)),
+                  self.ctx.handle)
+        return bool(built.value)
+
     def release_raw(self):
         """Drop the reference to the raw field (raw / in-place mode); missing layouts are built first / on demand."""
         raise_for(self.ctx.lib.eofx_mat_release_raw(self.ctx.handle, self.handle), self.ctx.handle)
