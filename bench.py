@@ -175,19 +175,21 @@ def leg_configs(ctx, device, orc, layout_kw, quick=False):
     del F
 
     def c3(tsc):
-        # the 129 600 x 30 sketch (host, 6 ms of sklearn's RandomState stream) is drawn while the two preprocess passes run,
-        # as the model class does (xeofs_amd/cross/cpcca.py)
+        # the 129 600 x 30 sketch (host, 5 ms of sklearn's RandomState stream) is drawn on a worker thread and joined by the
+        # engine when it first needs it (eofx_crosscov_rsvd_lazy_f32): behind the two statistics passes and, with the total
+        # squared covariance wanted, behind the two sample-space Gram matrices -- as the model class does (xeofs_amd/cross/cpcca.py).
+        # In-place layout: the fields are read where they lie, nothing is written.
         om = engine.SketchFuture(min(X.shape[1], Y.shape[1]), k + N_OVERSAMPLES, 5)
-        mx, _ = engine.preprocess(ctx, X, want_stats=False)
-        my, _ = engine.preprocess(ctx, Y, want_stats=False)
-        r = engine.crosscov_rsvd(ctx, mx, my, k, random_state=5, want_tsc=tsc, omega=om.result())
+        mx, _ = engine.preprocess(ctx, X, want_stats=False, in_place=True)
+        my, _ = engine.preprocess(ctx, Y, want_stats=False, in_place=True)
+        r = engine.crosscov_rsvd(ctx, mx, my, k, random_state=5, want_tsc=tsc, omega=om)
         mx.free()
         my.free()
         return r
 
     c3(True)
-    t_tsc, _, res = timed(lambda: c3(True), 2)
-    t_no, _, _ = timed(lambda: c3(False), 2)
+    t_tsc, _, res = timed(lambda: c3(True), 3)
+    t_no, _, _ = timed(lambda: c3(False), 3)
     alg3 = 16 * n * (X.shape[1] + Y.shape[1]) * 4.0        # 82.9 GB for the matrix-free operator
     S1, S2 = res["scores1"].astype(np.float64), res["scores2"].astype(np.float64)
     Cs = S1.T @ S2 / (n - 1)
@@ -196,9 +198,14 @@ def leg_configs(ctx, device, orc, layout_kw, quick=False):
     par3 = {"scores_cov_diag_relerr": float(np.max(np.abs(np.diag(Cs) - sv) / sv[0])),
             "scores_cov_offdiag_rel": float(np.max(np.abs(off)) / sv[0]),
             "scf_sum": float((sv ** 2).sum() / res["total_squared_covariance"])}
-    out["config3"] = {"what": f"MCA n_modes={k} on two {n}x(360x360) halves, matrix-free X^T(Y.), preprocess included",
+    # the whole call as the reference's fit runs it (cpcca.py:186-221: the total squared covariance is part of the fit):
+    # `frac` prices THAT time against SURVEY §8d's algorithmic bytes; the matrix-free time without the TSC is a sub-field
+    out["config3"] = {"what": f"MCA n_modes={k} on two {n}x(360x360) halves read in place, preprocess + rSVD of X^T Y + scores + "
+                              "total squared covariance (two 5000x5000 Gram matrices on the fp16 matrix cores; the power "
+                              "iterations run through them in sample space)",
                       "ms": round(t_tsc, 3), "ms_without_tsc": round(t_no, 3),
-                      "alg_GBps": round(alg3 / (t_no * 1e-3) / 1e9, 1), "frac": round(alg3 / (t_no * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
+                      "alg_GBps": round(alg3 / (t_tsc * 1e-3) / 1e9, 1), "frac": round(alg3 / (t_tsc * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
+                      "frac_without_tsc": round(alg3 / (t_no * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
                       "parity": par3}
     if not (par3["scores_cov_diag_relerr"] <= 1e-5 and par3["scores_cov_offdiag_rel"] <= 1e-5 and par3["scf_sum"] <= 1.0 + 1e-6):
         gate.append(f"config 3 covariance of the scores is not diag(s): {par3}")

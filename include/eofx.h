@@ -250,6 +250,16 @@ int eofx_crosscov_rsvd_f32(eofx_ctx *ctx, const eofx_mat *x, const eofx_mat *y, 
                            int n_oversamples, int n_iter, const float *omega, int flip, float *Q1,
                            float *s, float *Q2, float *scores1, float *scores2, float *norm1,
                            float *norm2, double *tsc);
+/* The same call with the sketch handed over by a callback that the engine invokes when it first needs the matrix --
+ * with tsc != NULL and both fields wider than long the two sample-space Gram matrices (which the total squared
+ * covariance needs, cpcca.py:991-1000, and through which the power iterations then run in sample space) are queued
+ * first, so a host generator (decomposer.py:142-145 passes random_state to scikit-learn, whose legacy stream takes
+ * ~5 ms for a 129 600 x 30 sketch) runs beside them.  omega_fn returns the matrix (host, layout as above; it must stay
+ * valid until the call returns) or NULL on failure; it is called at most once, on the calling thread.   */
+typedef const float *(*eofx_sketch_fn)(void *user);
+int eofx_crosscov_rsvd_lazy_f32(eofx_ctx *ctx, const eofx_mat *x, const eofx_mat *y, int k, int n_oversamples,
+                                int n_iter, eofx_sketch_fn omega_fn, void *omega_user, int flip, float *Q1, float *s,
+                                float *Q2, float *scores1, float *scores2, float *norm1, float *norm2, double *tsc);
 
 /* ---- panel-level steps (device pointers only) ---------------------------
  * Building blocks of eofx_rsvd_f32, exported so a host shell can insert

@@ -6,14 +6,16 @@ from xeofs_amd import engine
 import bench
 n, nlat, nlon, k = 5000, 360, 720, 20
 ctx = engine.Context(0)
+INPLACE = os.environ.get("LAYOUT", "inplace") == "inplace"
 F = bench.make_field(n, nlat, nlon, 0, nlat * nlon, torch.device("cuda:0")).reshape(n, nlat, nlon)
 X = F[:, :, :360].reshape(n, -1).contiguous(); Y = F[:, :, 360:].reshape(n, -1).contiguous()
 for rep in range(3):
     for tsc in (False, True):
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        mx, _ = engine.preprocess(ctx, X, want_stats=False); my, _ = engine.preprocess(ctx, Y, want_stats=False)
+        om = engine.SketchFuture(min(X.shape[1], Y.shape[1]), k + 10, 5)
+        mx, _ = engine.preprocess(ctx, X, want_stats=False, in_place=INPLACE); my, _ = engine.preprocess(ctx, Y, want_stats=False, in_place=INPLACE)
         torch.cuda.synchronize(); t1 = time.perf_counter()
-        out = engine.crosscov_rsvd(ctx, mx, my, k, random_state=5, want_tsc=tsc)
+        out = engine.crosscov_rsvd(ctx, mx, my, k, random_state=5, want_tsc=tsc, omega=om)
         torch.cuda.synchronize(); t2 = time.perf_counter()
         p1 = p2 = nlat * 360
         alg = 16 * n * (p1 + p2) * 4.0

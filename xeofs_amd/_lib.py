@@ -24,6 +24,9 @@ _int = C.c_int
 _pi64 = C.POINTER(C.c_int64)
 _pd = C.POINTER(C.c_double)
 
+# eofx_sketch_fn (include/eofx.h): const float *(*)(void *user)
+SKETCH_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p)
+
 # name -> (restype, argtypes); must list every symbol of include/eofx.h
 SIGNATURES = {
     "eofx_abi_version": (_int, []),
@@ -49,6 +52,8 @@ SIGNATURES = {
     "eofx_reconstruct_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _vp]),
     "eofx_crosscov_rsvd_f32": (_int, [_vp, _vp, _vp, _int, _int, _int, _vp, _int, _vp, _vp, _vp, _vp,
                                       _vp, _vp, _vp, _pd]),
+    "eofx_crosscov_rsvd_lazy_f32": (_int, [_vp, _vp, _vp, _int, _int, _int, SKETCH_FN, _vp, _int, _vp, _vp, _vp, _vp,
+                                           _vp, _vp, _vp, _pd]),
     "eofx_panel_tmul_f32": (_int, [_vp, _vp, _vp, _vp, _int, _int]),
     "eofx_panel_mul_f32": (_int, [_vp, _vp, _vp, _vp, _int, _int]),
     "eofx_panel_gram_f64": (_int, [_vp, _vp, _i64, _int, _vp]),

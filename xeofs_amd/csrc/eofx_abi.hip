@@ -4,6 +4,7 @@
 #include "eofx_hfft.hpp"
 #include "eofx_kernels.hpp"
 #include "eofx_fit.hpp"
+#include "eofx_gram.hpp"
 
 #if !defined(__HIP_DEVICE_COMPILE__)
 #include <immintrin.h>
@@ -85,6 +86,15 @@ struct eofx_ctx {
   std::vector<std::pair<const float*, const unsigned*>> amax_known;
   // page-locked host scratch for small asynchronous downloads (Gram matrices, flags)
   double* pinned = nullptr;
+  // cached work lists of gram_nt_kernel (eofx_gram.hpp): host plan + its device copy, keyed by the tile grid and stage count
+  struct GramPlanDev {
+    int nti = 0, ntj = 0, nst = 0;
+    bool sym = false;
+    GramPlan pl;
+    GramItem* items = nullptr;
+    int2* tiles = nullptr;
+  };
+  std::vector<GramPlanDev*> gram_plans;
   // the last eofx_fit_f32: [0] 1 when the statistics rode on the first pass, [1] ms of the non-pass work of the
   // fused preprocessor (probe, finalize, correction; HIP events, only with profiling on), [2] fallback reason
   double fit_info[4] = {0.0, 0.0, 0.0, 0.0};
@@ -225,6 +235,11 @@ extern "C" int eofx_ctx_destroy(eofx_ctx* ctx) {
     hipfftDestroy((hipfftHandle)e.second.first);
     hipfftDestroy((hipfftHandle)e.second.second);
   }
+  for (auto* g : ctx->gram_plans) {
+    if (g->items) (void)hipFree(g->items);
+    if (g->tiles) (void)hipFree(g->tiles);
+    delete g;
+  }
   for (auto& h : ctx->hsetups) {
     if (h.chat) (void)hipFree(h.chat);
     if (h.hperm) (void)hipFree(h.hperm);
@@ -242,6 +257,12 @@ extern "C" int eofx_ctx_set_stream(eofx_ctx* ctx, void* stream) {
   if ((hipStream_t)stream == ctx->stream) return EOFX_OK;
   HIPCHK(hipStreamSynchronize(ctx->stream));
   ctx->stream = (hipStream_t)stream;
+  // per-stream state cached in the context: the hipFFT plans of the Hilbert stage were bound to the old stream
+  for (auto& e : ctx->fft_plans) {
+    if (hipfftSetStream((hipfftHandle)e.second.first, ctx->stream) != HIPFFT_SUCCESS ||
+        hipfftSetStream((hipfftHandle)e.second.second, ctx->stream) != HIPFFT_SUCCESS)
+      return set_err(ctx, EOFX_ERR_HIP, "hipfftSetStream failed while moving the context to another stream");
+  }
   return EOFX_OK;
 }
 extern "C" int eofx_ctx_synchronize(eofx_ctx* ctx) {
@@ -1838,8 +1859,12 @@ static int launch_rinv(eofx_ctx* ctx, const double* G, int L, int l, double* Rin
 // column statistics, eofx_fit.hpp).  It may return EOFX_FIT_FALLBACK (> 0), which is passed through to the caller.
 constexpr int EOFX_FIT_FALLBACK = 1;
 typedef std::function<int(const float*, float*, int)> FirstFwd;
+// range (optional): replaces the power iterations AND the range product -- given the imported sketch Zs it returns
+// Yt = A (A^T A)^n_iter Zs (any column scaling), computed however the caller likes (the cross-covariance driver iterates
+// in sample space through the two Gram matrices, eofx_crosscov_rsvd_f32).
+typedef std::function<int(const float*, float*, int)> RangeFinder;
 static int rsvd_core(eofx_ctx* ctx, const LinOp& op, int k, int l, int n_iter, const float* omega,
-                     RsvdOut& out, const FirstFwd* first_fwd = nullptr) {
+                     RsvdOut& out, const FirstFwd* first_fwd = nullptr, const RangeFinder* range = nullptr) {
   const int L = (int)round_up(l, 32);
   const int Lo = (int)round_up(k, 32);
   AmaxScope amax_scope(ctx);
@@ -1885,7 +1910,7 @@ static int rsvd_core(eofx_ctx* ctx, const LinOp& op, int k, int l, int n_iter, c
   hipEvent_t peaked_ev = nullptr;
   bool peaked_pending = false;
   int rc = EOFX_OK;
-  for (int it = 0; it < n_iter && rc == EOFX_OK; ++it) {
+  for (int it = 0; it < (range ? 0 : n_iter) && rc == EOFX_OK; ++it) {
     rc = fwd(Zs, Yt, pp);
     if (rc != EOFX_OK) break;
     if (peaked_pending) {
@@ -1926,7 +1951,8 @@ static int rsvd_core(eofx_ctx* ctx, const LinOp& op, int k, int l, int n_iter, c
   // one pass over the tall panel less, and Q itself is never rounded to float32.
   // The range-basis pass only fixes a subspace: power-pass precision is enough; the projection B^T = A^T Q below
   // decides the singular values and uses the final one.
-  CHK(fwd(Zs, Yt, pp));
+  if (range) CHK((*range)(Zs, Yt, L));
+  else CHK(fwd(Zs, Yt, pp));
   CHK(launch_gram(ctx, Yt, op.tall_pad, L, G));
   CHK(launch_cholqr(ctx, Yt, op.tall_pad, L, l, G, Qt));      // Q1
   CHK(launch_gram(ctx, Qt, op.tall_pad, L, G));
@@ -2536,6 +2562,91 @@ static int mat_gram(eofx_ctx* ctx, const eofx_mat* m, int side, float* G) {
 }
 static int sample_gram(eofx_ctx* ctx, const eofx_mat* m, float* G) { return mat_gram(ctx, m, 0, G); }
 
+// ---- sample-space Gram matrix on the fp16 matrix cores (eofx_gram.hpp): planes once, then the tiled NT product ------
+constexpr int64_t EOFX_GRAM_MAX_SIDE = 32768;
+static int gram_plan_get(eofx_ctx* ctx, int nti, int ntj, bool sym, int nst, const eofx_ctx::GramPlanDev** out) {
+  for (auto* g : ctx->gram_plans)
+    if (g->nti == nti && g->ntj == ntj && g->sym == sym && g->nst == nst) {
+      *out = g;
+      return EOFX_OK;
+    }
+  auto* g = new eofx_ctx::GramPlanDev();
+  g->nti = nti;
+  g->ntj = ntj;
+  g->sym = sym;
+  g->nst = nst;
+  int S = 0;
+  if (const char* ev = std::getenv("EOFX_GRAM_SPLITS")) S = atoi(ev);     // tuning hook (tools/gram_probe.py)
+  gram_plan_build(nti, ntj, sym, nst, S, g->pl);
+  if (hipMalloc((void**)&g->items, sizeof(GramItem) * g->pl.items.size()) != hipSuccess ||
+      hipMalloc((void**)&g->tiles, sizeof(int2) * g->pl.tiles.size()) != hipSuccess ||
+      hipMemcpy(g->items, g->pl.items.data(), sizeof(GramItem) * g->pl.items.size(), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(g->tiles, g->pl.tiles.data(), sizeof(int2) * g->pl.tiles.size(), hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipGetLastError();
+    if (g->items) (void)hipFree(g->items);
+    if (g->tiles) (void)hipFree(g->tiles);
+    delete g;
+    return set_err(ctx, EOFX_ERR_NOMEM, "cannot allocate the work list of the Gram kernel");
+  }
+  ctx->gram_plans.push_back(g);
+  *out = g;
+  return EOFX_OK;
+}
+static int64_t gram_kpad(const eofx_mat* m) { return round_up(m->p, 2 * GR_BK); }
+// does the fast route take this matrix?  (sample side up to 32768; the 32-bit row offsets of the LDS-DMA loads)
+static bool gram_fast_ok(const eofx_mat* m) {
+  return m->n_pad % GR_BM == 0 && m->n_pad <= EOFX_GRAM_MAX_SIDE && (m->X || (m->raw && m->aff) || m->Xt) &&
+         gram_kpad(m) * 4 * GR_BM < ((int64_t)1 << 32) && !std::getenv("EOFX_NO_FAST_GRAM");
+}
+static size_t gram_fast_scratch(eofx_ctx* ctx, const eofx_mat* m) {
+  const eofx_ctx::GramPlanDev* g = nullptr;
+  const int nt = (int)(m->n_pad / GR_BM);
+  if (gram_plan_get(ctx, nt, nt, true, (int)(gram_kpad(m) / GR_BK), &g) != EOFX_OK) return 0;
+  return (size_t)m->n_pad * gram_kpad(m) * 4 + (size_t)g->pl.T * g->pl.S * GR_BM * GR_BM * sizeof(float) + 8192;
+}
+// the fp16 hi / lo planes of the preprocessed matrix (planes_split_kernel), from the raw field through the map (in-place and
+// masked in-place matrices) or from the feature-contiguous layout; *a_scale: the exact power of two they are scaled by
+static int mat_planes(eofx_ctx* ctx, const eofx_mat* m, _Float16* planes, int64_t kpad, float* a_scale) {
+  float sc = 1.f;
+  if (m->absmax > 0.f && std::isfinite(m->absmax)) {
+    int e;
+    (void)std::frexp(m->absmax, &e);
+    sc = std::ldexp(1.f, 14 - e);
+  }
+  *a_scale = sc;
+  const int rows_per_wg = 64;
+  dim3 grid((unsigned)((kpad + 2047) / 2048), (unsigned)((m->n_pad + rows_per_wg - 1) / rows_per_wg));
+  if (!m->X && m->raw && m->aff) {
+    hipLaunchKernelGGL(planes_split_kernel, grid, dim3(256), 0, ctx->stream, m->raw, m->raw_ld, m->n, m->p, (const float*)m->aff,
+                       m->p_pad, sc, planes, m->n_pad, kpad, rows_per_wg);
+  } else {
+    CHK(ensure_X(ctx, m));
+    hipLaunchKernelGGL(planes_split_kernel, grid, dim3(256), 0, ctx->stream, (const float*)m->X, m->p_pad, m->n, m->p,
+                       (const float*)nullptr, (int64_t)0, sc, planes, m->n_pad, kpad, rows_per_wg);
+  }
+  KCHK();
+  return EOFX_OK;
+}
+// G[n_pad x n_pad] = X' X'^T (float32, full symmetric matrix).  Arena: gram_fast_scratch(m) bytes.
+static int mat_gram_fast(eofx_ctx* ctx, const eofx_mat* m, float* G) {
+  const int64_t kpad = gram_kpad(m);
+  const int nt = (int)(m->n_pad / GR_BM);
+  const eofx_ctx::GramPlanDev* g = nullptr;
+  CHK(gram_plan_get(ctx, nt, nt, true, (int)(kpad / GR_BK), &g));
+  ArenaScope scope(ctx);
+  ARENA(_Float16, planes, (size_t)m->n_pad * kpad * 2);
+  ARENA(float, part, (size_t)g->pl.T * g->pl.S * GR_BM * GR_BM);
+  float sc = 1.f;
+  CHK(mat_planes(ctx, m, planes, kpad, &sc));
+  hipLaunchKernelGGL(gram_nt_kernel<2>, dim3(g->pl.grid), dim3(512), 0, ctx->stream, (const _Float16*)planes, (const _Float16*)planes,
+                     kpad * 4, (const GramItem*)g->items, part, 1.f / (sc * sc));
+  KCHK();
+  hipLaunchKernelGGL(gram_finish_kernel, dim3(g->pl.T, 16), dim3(256), 0, ctx->stream, (const float*)part, (const int2*)g->tiles, g->pl.S, G,
+                     m->n_pad);
+  KCHK();
+  return EOFX_OK;
+}
+
 // <a, b> over `count` floats, float64 accumulation, fixed reduction tree
 static int device_dot(eofx_ctx* ctx, const float* a, const float* b, int64_t count, double* out) {
   const int nb = 1024;
@@ -2593,11 +2704,11 @@ extern "C" int eofx_vec_dot_f64(eofx_ctx* ctx, const float* a, const float* b, i
 // ------------------------------------------------------------------------------------
 // cross-covariance path (MCA): matrix-free rSVD of C = X^T Y / (n-1)
 // ------------------------------------------------------------------------------------
-extern "C" int eofx_crosscov_rsvd_f32(eofx_ctx* ctx, const eofx_mat* x, const eofx_mat* y, int k,
-                                      int n_oversamples, int n_iter, const float* omega, int flip,
-                                      float* Q1, float* s, float* Q2, float* scores1, float* scores2,
-                                      float* norm1, float* norm2, double* tsc) {
-  if (!ctx || !x || !y || !omega || k <= 0) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+static int crosscov_impl(eofx_ctx* ctx, const eofx_mat* x, const eofx_mat* y, int k,
+                         int n_oversamples, int n_iter, const float* omega, eofx_sketch_fn omega_fn, void* omega_user, int flip,
+                         float* Q1, float* s, float* Q2, float* scores1, float* scores2,
+                         float* norm1, float* norm2, double* tsc) {
+  if (!ctx || !x || !y || (!omega && !omega_fn) || k <= 0) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
   CHK(set_device(ctx));
   if (x->n != y->n)
     return set_err(ctx, EOFX_ERR_SHAPE,
@@ -2615,12 +2726,33 @@ extern "C" int eofx_crosscov_rsvd_f32(eofx_ctx* ctx, const eofx_mat* x, const eo
   const int L = (int)round_up(l, 32);
   const bool transposed = p1 < p2;  // C is (p1 x p2): sklearn transposes when rows < cols
   const int64_t npad = x->n_pad;
+  // The total squared covariance needs the two sample-space Gram matrices (below).  With them resident the power
+  // iterations need not touch the fields at all: A = Ft^T Fs (Ft the field on the tall side), A Z = Ft^T (Fs Z) and
+  // (A^T A) Z = Fs^T Gt (Fs Z), so in terms of T = Fs Z (n x l) one iteration is T <- Gs (Gt T) -- two n x n x l products
+  // (tens of microseconds) instead of four passes over the fields.  Same subspace in exact arithmetic as scikit-learn's
+  // iteration on C (range of (C C^T)^q C Omega); the range basis and the projection that decides the singular values are
+  // still computed from the fields themselves.  Taken when the TSC is asked for and both fields are wider than long.
+  const bool gram_route = tsc && n < p1 && n < p2 && gram_fast_ok(x) && gram_fast_ok(y) && !std::getenv("EOFX_CROSS_NO_GRAM");
   size_t need = rsvd_scratch_bytes(std::max(x->p_pad, y->p_pad), std::max(x->p_pad, y->p_pad), l, k) +
                 (size_t)npad * L * 4 * 2 + atb_scratch_bytes(npad, std::max(x->p_pad, y->p_pad), L);
-  if (tsc) need += (size_t)npad * npad * 4 * 2 + atb_scratch_bytes(npad, std::max(x->p_pad, y->p_pad), (int)npad) + (1 << 20);
+  if (tsc) need += (size_t)npad * npad * 4 * 2 + (1 << 20);
+  if (gram_route)
+    need += std::max(gram_fast_scratch(ctx, x), gram_fast_scratch(ctx, y)) + (size_t)npad * L * 4 * 2 + atb_scratch_bytes(npad, npad, L);
+  else if (tsc)
+    need += atb_scratch_bytes(npad, std::max(x->p_pad, y->p_pad), (int)npad);
   CHK(arena_reserve(ctx, need));
   ArenaScope scope(ctx);
   ARENA(float, Tn, (size_t)npad * L);
+  float *Gx = nullptr, *Gy = nullptr;
+  if (tsc) {
+    Gx = arena_alloc<float>(ctx, (size_t)npad * npad);
+    Gy = arena_alloc<float>(ctx, (size_t)npad * npad);
+    if (!Gx || !Gy) return set_err(ctx, EOFX_ERR_NOMEM, "internal: arena exhausted (Gram matrices)");
+  }
+  if (gram_route) {
+    CHK(mat_gram_fast(ctx, x, Gx));
+    CHK(mat_gram_fast(ctx, y, Gy));
+  }
   // C   Z = X^T (Y Z);   C^T W = Y^T (X W)     (scaling by 1/(n-1) is applied to s at the end)
   auto C_mul = [&](const float* z2, float* out1, int LL, int pr) {
     CHK(panel_mul(ctx, y, z2, Tn, LL, pr));
@@ -2635,6 +2767,12 @@ extern "C" int eofx_crosscov_rsvd_f32(eofx_ctx* ctx, const eofx_mat* x, const eo
     op = {p2, p1, y->p_pad, x->p_pad, Ct_mul, C_mul};  // A = C^T (p2 x p1)
   else
     op = {p1, p2, x->p_pad, y->p_pad, C_mul, Ct_mul};  // A = C   (p1 x p2)
+  // the sketch is asked for only now: on the Gram route ~18 ms of matrix work are already queued behind which the caller's
+  // generator (scikit-learn's legacy stream: ~5 ms for 129 600 x 30 deviates) finishes unnoticed
+  if (!omega) {
+    omega = omega_fn(omega_user);
+    if (!omega) return set_err(ctx, EOFX_ERR_ARG, "the sketch callback returned no matrix");
+  }
   std::vector<float> om_eye;
   if (l == r) {   // full-width sketch: identity (see eofx_rsvd_f32)
     om_eye.assign((size_t)op.small * l, 0.f);
@@ -2642,7 +2780,37 @@ extern "C" int eofx_crosscov_rsvd_f32(eofx_ctx* ctx, const eofx_mat* x, const eo
     omega = om_eye.data();
   }
   RsvdOut ro;
-  CHK(rsvd_core(ctx, op, k, l, n_iter, omega, ro));
+  if (gram_route) {
+    const eofx_mat* ft = transposed ? y : x;     // field on the tall side of A
+    const eofx_mat* fs = transposed ? x : y;
+    const float* Gt = transposed ? Gy : Gx;
+    const float* Gs = transposed ? Gx : Gy;
+    RangeFinder range = [&](const float* Zs, float* Yt, int LL) -> int {
+      ArenaScope inner(ctx);
+      ARENA(float, T2, (size_t)npad * LL);
+      ARENA(double, Gd, (size_t)LL * LL);
+      auto orth = [&](const float* in, float* outp) -> int {     // Cholesky-QR of an n x l panel (float64 Gram matrix)
+        CHK(launch_gram(ctx, in, npad, LL, Gd));
+        return launch_cholqr(ctx, in, npad, LL, l, Gd, outp);
+      };
+      // exact-f32 MFMA products with the symmetric Gram matrices (G^T T = G T): 100 MB each, tens of microseconds
+      auto gmul = [&](const float* Gm, const float* in, float* outp) -> int {
+        return launch_atb(ctx, Gm, npad, npad, npad, in, LL, LL, outp, EOFX_PREC_F32);
+      };
+      CHK(panel_mul(ctx, fs, Zs, Tn, LL, ctx->prec_power));      // T = Fs Z
+      for (int it = 0; it < n_iter; ++it) {
+        CHK(orth(Tn, T2));
+        CHK(gmul(Gt, T2, Tn));
+        CHK(orth(Tn, T2));
+        CHK(gmul(Gs, T2, Tn));
+      }
+      CHK(orth(Tn, T2));
+      return panel_tmul(ctx, ft, T2, Yt, LL, ctx->prec_power);   // Yt = Ft^T T
+    };
+    CHK(rsvd_core(ctx, op, k, l, n_iter, omega, ro, nullptr, &range));
+  } else {
+    CHK(rsvd_core(ctx, op, k, l, n_iter, omega, ro));
+  }
   const float* Q1p = transposed ? ro.Svec : ro.Tvec;  // left vectors of C  (p1)
   const float* Q2p = transposed ? ro.Tvec : ro.Svec;  // right vectors of C (p2)
   std::vector<double> sign;
@@ -2678,18 +2846,33 @@ extern "C" int eofx_crosscov_rsvd_f32(eofx_ctx* ctx, const eofx_mat* x, const eo
       }
     }
   }
-  // total squared covariance ||X^T Y||_F^2/(n-1)^2 = <X X^T, Y Y^T>/(n-1)^2 : two n x n Grams
+  // total squared covariance ||X^T Y||_F^2/(n-1)^2 = <X X^T, Y Y^T>/(n-1)^2 : two n x n Grams (cpcca.py:197,991-1000)
   if (tsc) {
-    ARENA(float, Gx, (size_t)npad * npad);
-    ARENA(float, Gy, (size_t)npad * npad);
-    CHK(sample_gram(ctx, x, Gx));
-    CHK(sample_gram(ctx, y, Gy));
+    if (!gram_route) {
+      CHK(sample_gram(ctx, x, Gx));
+      CHK(sample_gram(ctx, y, Gy));
+    }
     double t = 0.0;
     CHK(device_dot(ctx, Gx, Gy, npad * npad, &t));
     *tsc = t / ((double)(n - 1) * (double)(n - 1));
   }
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return EOFX_OK;
+}
+
+extern "C" int eofx_crosscov_rsvd_f32(eofx_ctx* ctx, const eofx_mat* x, const eofx_mat* y, int k,
+                                      int n_oversamples, int n_iter, const float* omega, int flip,
+                                      float* Q1, float* s, float* Q2, float* scores1, float* scores2,
+                                      float* norm1, float* norm2, double* tsc) {
+  if (!omega) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  return crosscov_impl(ctx, x, y, k, n_oversamples, n_iter, omega, nullptr, nullptr, flip, Q1, s, Q2, scores1, scores2, norm1, norm2, tsc);
+}
+extern "C" int eofx_crosscov_rsvd_lazy_f32(eofx_ctx* ctx, const eofx_mat* x, const eofx_mat* y, int k,
+                                           int n_oversamples, int n_iter, eofx_sketch_fn omega_fn, void* omega_user, int flip,
+                                           float* Q1, float* s, float* Q2, float* scores1, float* scores2,
+                                           float* norm1, float* norm2, double* tsc) {
+  if (!omega_fn) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  return crosscov_impl(ctx, x, y, k, n_oversamples, n_iter, nullptr, omega_fn, omega_user, flip, Q1, s, Q2, scores1, scores2, norm1, norm2, tsc);
 }
 
 // ------------------------------------------------------------------------------------

@@ -1422,7 +1422,9 @@ __global__ __launch_bounds__(256) void chol_rinv_kernel(const double* __restrict
   {
     const int wave = tid >> 6, lane = tid & 63;
     const int c = wave * 16 + (lane >> 2), q = lane & 3;
-    for (int r = 63; r >= 0; --r) {
+    // rows / columns >= l are identity padding whose inverse nobody reads (the store below writes zeros there): a
+    // 30-column sketch walks 30 dependent steps, not 64
+    for (int r = l - 1; r >= 0; --r) {
       double s = 0.0;
 #pragma unroll 4
       for (int t = r + 1 + q; t <= c; t += 4) s += A[r][t] * X[t][c];
@@ -1436,7 +1438,7 @@ __global__ __launch_bounds__(256) void chol_rinv_kernel(const double* __restrict
   __syncthreads();
   for (int i = tid; i < 64 * 64; i += 256) {
     const int r = i >> 6, c = i & 63;
-    if (r < L && c < L) Rinv[(int64_t)r * L + c] = (r < l && c < l && !dead[c]) ? X[r][c] : 0.0;
+    if (r < L && c < L) Rinv[(int64_t)r * L + c] = (r <= c && c < l && !dead[c]) ? X[r][c] : 0.0;
   }
 }
 

@@ -566,20 +566,32 @@ def crosscov_rsvd(ctx: Context, x: ResidentMatrix, y: ResidentMatrix, k: int, n_
                   want_tsc: bool = True):
     """Matrix-free rSVD of C = X^T Y/(n-1) -> dict (cpcca.py:168-225 quantities)."""
     k = int(k)
-    if x.masked or y.masked:
-        raise NotImplementedError("cross-covariance of masked in-place matrices (preprocess without allow_masked)")
     small = min(x.p, y.p)
-    if omega is None:
-        omega = sketch_matrix(small, k + n_oversamples, random_state)
-    omega = np.ascontiguousarray(omega, dtype=np.float32)
-    if omega.shape != (small, k + n_oversamples):
-        raise ValueError(f"omega must have shape {(small, k + n_oversamples)}")
+    if (x.masked or y.masked) and k > small:
+        raise ValueError(f"n_modes must be less than or equal to the rank of the dataset (rank = {small}).")
+    if (x.masked or y.masked) and ((x.p < y.p) != (x.p_phys < y.p_phys) or min(x.p, y.p) <= x.n):
+        # the engine orients C by the PHYSICAL column counts; the reference by the valid ones (sklearn transposes when
+        # rows < cols): where the two disagree the sketch would live on the other side
+        raise NotImplementedError("cross-covariance of masked in-place matrices whose valid and physical widths order differently")
     if x.n != y.n:
         raise ValueError(f"Both data matrices must have the same number of samples but found {x.n} in the first and "
                          f"{y.n} in the second.")
+    small_mat = x if x.p_phys < y.p_phys else y
+
+    def sketch():
+        om = omega.result() if hasattr(omega, "result") else omega     # a SketchFuture is joined as late as possible
+        if om is None:
+            om = sketch_matrix(small, k + n_oversamples, random_state)
+        om = np.ascontiguousarray(om, dtype=np.float32)
+        if om.shape != (small, k + n_oversamples):
+            raise ValueError(f"omega must have shape {(small, k + n_oversamples)}")
+        # masked in-place matrices keep their all-NaN grid points as zero columns: the sketch gets zero rows there, the
+        # singular vectors come back with zero rows there (compacted below)
+        return np.ascontiguousarray(small_mat.scatter_rows(om))
+
     n = x.n
-    Q1 = np.empty((x.p, k), np.float32)
-    Q2 = np.empty((y.p, k), np.float32)
+    Q1 = np.empty((x.p_phys, k), np.float32)
+    Q2 = np.empty((y.p_phys, k), np.float32)
     s = np.empty(k, np.float32)
     s1 = np.empty((n, k), np.float32)
     s2 = np.empty((n, k), np.float32)
@@ -587,11 +599,26 @@ def crosscov_rsvd(ctx: Context, x: ResidentMatrix, y: ResidentMatrix, k: int, n_
     n2 = np.empty(k, np.float32)
     tsc = C.c_double(float("nan"))
     it = -1 if n_iter == "auto" else int(n_iter)
-    rc = ctx.lib.eofx_crosscov_rsvd_f32(ctx.handle, x.handle, y.handle, k, int(n_oversamples), it, ptr(omega),
-                                        int(flip), ptr(Q1), ptr(s), ptr(Q2), ptr(s1), ptr(s2), ptr(n1), ptr(n2),
-                                        C.byref(tsc) if want_tsc else None)
+    # the engine asks for the sketch when it first needs it (eofx_crosscov_rsvd_lazy_f32): with the total squared
+    # covariance wanted, the Gram matrices are queued before that and a SketchFuture finishes beside them
+    held = {}
+
+    def provide(_user):
+        try:
+            held["om"] = sketch()
+            return held["om"].ctypes.data
+        except BaseException as e:      # re-raised below, in the caller's frame
+            held["err"] = e
+            return None
+
+    cb = _lib.SKETCH_FN(provide)
+    rc = ctx.lib.eofx_crosscov_rsvd_lazy_f32(ctx.handle, x.handle, y.handle, k, int(n_oversamples), it, cb, None,
+                                             int(flip), ptr(Q1), ptr(s), ptr(Q2), ptr(s1), ptr(s2), ptr(n1), ptr(n2),
+                                             C.byref(tsc) if want_tsc else None)
+    if "err" in held:
+        raise held["err"]
     raise_for(rc, ctx.handle)
-    return dict(Q1=Q1, Q2=Q2, s=s, scores1=s1, scores2=s2, norm1=n1, norm2=n2,
+    return dict(Q1=x.compact_rows(Q1), Q2=y.compact_rows(Q2), s=s, scores1=s1, scores2=s2, norm1=n1, norm2=n2,
                 total_squared_covariance=tsc.value)
 
 
