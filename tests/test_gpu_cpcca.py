@@ -227,3 +227,57 @@ def test_cpcca_rotator_vs_oracle(ctx, alpha, use_pca, power):
     if power == 1:   # orthogonal rotation conserves the squared covariance of the rotated modes' subspace... of MCA
         assert np.abs(rot.rotation_matrix().T @ rot.rotation_matrix() - np.eye(3)).max() < 1e-8
     assert rot.squared_covariance_fraction().values.sum() <= 1 + 1e-5
+
+
+def test_whitener_identity_rule(ctx):
+    """preprocessing/whitener.py:54-60: the whitener is the identity iff (1 - alpha) < eps -- every alpha >= 1 is, alpha =
+    1 - 1e-9 is not (np.isclose would say it is)."""
+    from xeofs_amd.cross.cpcca import _whitener_is_identity
+
+    assert _whitener_is_identity(1.0) and _whitener_is_identity(1.5) and _whitener_is_identity(1.0 - 1e-17)
+    assert not _whitener_is_identity(1.0 - 1e-9) and not _whitener_is_identity(0.0)
+    m_one, ref, *_ = _models(1.0, True)
+    m_big, *_ = _models(1.5, True)
+    m_near, *_ = _models(1.0 - 1e-9, True)
+    assert all(sd.T is None for sd in m_one.side) and all(sd.T is None for sd in m_big.side)
+    assert all(sd.T is not None for sd in m_near.side)          # whitened (by an almost-identity matrix)
+    assert np.allclose(m_big.singular_values().values, m_one.singular_values().values, rtol=1e-6)
+    assert np.allclose(m_near.singular_values().values, ref["singular_values"], rtol=2e-4)
+
+
+@pytest.mark.parametrize("swap", [False, True])
+def test_mca_land_masks_in_place(ctx, swap):
+    """MCA(use_pca=False) on two fields with land / sea masks: both stay in place (layout mode 3: all-NaN grid points are
+    zero columns of the engine's matrices), the Gram route computes the total squared covariance and carries the power
+    iterations.  swap: the field that is narrower BY VALID features is the wider one physically -- the engine orients C by
+    physical widths, so the model compacts the fields and goes again (same results)."""
+    import xeofs_amd as xe
+
+    rng = np.random.default_rng(9)
+    n, k = 80, 4
+    T = rng.standard_normal((n, 6)) * np.array([9.0, 7.0, 5.0, 3.0, 1.0, 0.5])
+    A = (T @ rng.standard_normal((6, 40 * 50)) + 0.3 * rng.standard_normal((n, 40 * 50))).astype(np.float32)
+    B = (T @ rng.standard_normal((6, 30 * 60)) + 0.3 * rng.standard_normal((n, 30 * 60))).astype(np.float32)
+    A[:, rng.choice(A.shape[1], 500 if swap else 150, replace=False)] = np.nan      # swap: 1500 valid < B's 1600 valid, 2000 > 1800 physical
+    B[:, rng.choice(B.shape[1], 200, replace=False)] = np.nan
+    X = xe.DataArray(A.reshape(n, 40, 50), dims=("time", "lat", "lon"))
+    Y = xe.DataArray(B.reshape(n, 30, 60), dims=("time", "y", "x"))
+    m = xe.cross.MCA(n_modes=k, use_pca=False, random_state=2)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m.fit(X, Y, "time")
+        ref = orc.cpcca_fit(A.astype(np.float64), B.astype(np.float64), k, alpha=1.0, use_pca=False, random_state=2)
+    assert m.data["input_data1"].masked != swap and m.data["input_data2"].masked != swap
+    assert np.allclose(m.singular_values().values, ref["singular_values"], rtol=2e-5)
+    assert np.isclose(m.total_squared_covariance(), ref["total_squared_covariance"], rtol=1e-5)
+    for c, F, key in zip(m.components(), (A, B), ("components1", "components2")):
+        C = c.values.reshape(k, -1).T
+        vf = ~np.isnan(F).all(axis=0)
+        assert np.isnan(C[~vf]).all() and not np.isnan(C[vf]).any()
+        for j in range(k):
+            r = ref[key][:, j]
+            assert abs(np.dot(C[vf, j].astype(np.float64), r)) / np.linalg.norm(C[vf, j]) / np.linalg.norm(r) > 1 - 1e-5
+    s1, s2 = m.scores()
+    t1, t2 = m.transform(X=X, Y=Y)
+    assert np.allclose(t1.values, s1.values, atol=1e-4 * np.abs(s1.values).max())
+    assert np.allclose(t2.values, s2.values, atol=1e-4 * np.abs(s2.values).max())

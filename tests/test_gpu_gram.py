@@ -1,0 +1,73 @@
+"""The sample-space Gram matrix on the fp16 matrix cores (xeofs_amd/csrc/eofx_gram.hpp: planes_split_kernel ->
+gram_nt_kernel -> gram_finish_kernel) through the C ABI (eofx_mat_gram_f32) against float64 numpy on the oracle's
+preprocessed matrix: every layout (in place, masked in place, written layouts), shapes that leave partial tiles /
+stages / splits, and its two consumers -- the total squared covariance and the sample-space power iterations of
+eofx_crosscov_rsvd_f32 (xeofs/cross/cpcca.py:186-221, 991-1000)."""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import eof_oracle as orc  # noqa: E402  (checker only)
+
+
+@pytest.mark.parametrize("n,nlat,nlon,layout,std", [
+    (300, 20, 37, "inplace", False),       # P % 4 != 0: the scalar path of the split kernel
+    (300, 24, 40, "inplace", True),
+    (300, 24, 40, "masked", False),
+    (700, 30, 50, "copy", True),           # n_pad = 1024: 4 x 4 tiles, several splits
+    (1100, 16, 90, "inplace", False),      # n_pad = 1536
+])
+def test_sample_gram_vs_float64(ctx, n, nlat, nlon, layout, std):
+    from xeofs_amd import engine
+
+    X, lat = orc.synthetic_field(n, nlat, nlon, rank=10, seed=n)
+    w = np.repeat(orc.sqrt_cos_lat_weights(lat), nlon) if std else None
+    if layout == "masked":
+        rng = np.random.default_rng(0)
+        X[:, rng.choice(X.shape[1], X.shape[1] // 5, replace=False)] = np.nan
+    mat, st = engine.preprocess(ctx, X, True, std, w, in_place=layout != "copy", allow_masked=layout == "masked")
+    assert mat.masked == (layout == "masked")
+    ref = orc.preprocess(X.astype(np.float64), True, std, w)["X"]
+    Gref = ref @ ref.T
+    G = mat.gram(0)[:n, :n].double().cpu().numpy()
+    Gpad = mat.gram(0).cpu().numpy()
+    assert not Gpad[n:].any() and not Gpad[:, n:].any()            # padding rows / columns are exact zeros
+    assert np.array_equal(Gpad, Gpad.T)                               # mirrored, not recomputed
+    scale = np.sqrt(np.outer(np.diag(Gref), np.diag(Gref)))
+    assert np.max(np.abs(G - Gref) / scale) <= 3e-6, np.max(np.abs(G - Gref) / scale)
+    # bitwise reproducible (fixed split order, no atomics)
+    assert np.array_equal(mat.gram(0).cpu().numpy(), Gpad)
+    mat.free()
+
+
+def test_crosscov_gram_route_equals_matrix_free(ctx, monkeypatch):
+    """The same call with and without the Gram route (EOFX_CROSS_NO_GRAM=1 keeps the power iterations on the fields):
+    singular values / vectors / scores / TSC agree to float32 rounding, and both match the float64 oracle."""
+    from xeofs_amd import engine
+
+    n, k = 400, 6
+    F, _ = orc.synthetic_field(n, 30, 80, rank=15, seed=5)
+    F = F.reshape(n, 30, 80)
+    X = np.ascontiguousarray(F[:, :, :44].reshape(n, -1))
+    Y = np.ascontiguousarray(F[:, :, 44:].reshape(n, -1))
+    outs = []
+    for no_gram in ("", "1"):
+        if no_gram:
+            monkeypatch.setenv("EOFX_CROSS_NO_GRAM", "1")
+        mx, _ = engine.preprocess(ctx, X, in_place=True)
+        my, _ = engine.preprocess(ctx, Y, in_place=True)
+        outs.append(engine.crosscov_rsvd(ctx, mx, my, k, random_state=7))
+        mx.free(); my.free()
+    a, b = outs
+    ref = orc.mca_fit(X.astype(np.float64), Y.astype(np.float64), k, random_state=7, use_pca=False)
+    for o in (a, b):
+        assert np.all(np.abs(o["s"] - ref["singular_values"]) <= 1e-5 * ref["singular_values"][0])
+        assert abs(o["total_squared_covariance"] - ref["total_squared_covariance"]) <= 1e-5 * ref["total_squared_covariance"]
+        for j in range(k):
+            for key, rk in (("Q1", "components1"), ("Q2", "components2")):
+                assert abs(np.dot(o[key][:, j].astype(np.float64), ref[rk][:, j])) >= 1 - 1e-5
+    assert np.allclose(a["s"], b["s"], rtol=2e-6)
+    assert np.allclose(a["scores1"], b["scores1"], atol=2e-5 * np.abs(b["scores1"]).max())
+    assert np.isclose(a["total_squared_covariance"], b["total_squared_covariance"], rtol=1e-6)

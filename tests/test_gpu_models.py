@@ -325,3 +325,42 @@ def test_resident_torch_input(ctx):
     assert np.array_equal(mc.singular_values().values, md.singular_values().values)
     c1, c2 = xe.cross.MCA(n_modes=2, random_state=3, use_pca=False).fit(b, b, "time").components()
     assert c1.dims == ("mode", "lat", "lon") and not np.isnan(c2.values).any()
+
+
+@pytest.mark.parametrize("solver_kw", [dict(solver="full"), dict(n_modes=0.95)])
+def test_eof_wide_branch_on_a_land_mask(solver_kw):
+    """A land / sea mask keeps the field in place (layout mode 3) and solver='full' with more than 256 samples -- or a float
+    n_modes whose int(0.3 rank) + 10 exceeds the sketch kernels -- sends the decomposition through the exact Gram route
+    (xeofs_amd/pca.py), which has to compact / scatter the feature axis like every other consumer of a masked matrix:
+    components aligned with the grid, NaN exactly at the masked points, values against the oracle."""
+    import warnings
+
+    import xeofs_amd as xe
+
+    n, nlat, nlon = (900, 30, 50) if "n_modes" in solver_kw else (300, 24, 40)
+    vals, lat = orc.synthetic_field(n, nlat, nlon, rank=12, seed=3)
+    vals = vals.reshape(n, nlat, nlon)
+    land = np.zeros((nlat, nlon), bool)
+    land[3:9, 5:17] = True
+    land[15:20, 25:38] = True
+    land[0, 0] = land[-1, -1] = True
+    vals[:, land] = np.nan
+    kw = dict(n_modes=6, random_state=1)
+    kw.update(solver_kw)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = xe.single.EOF(**kw).fit(xe.DataArray(vals, dims=("time", "lat", "lon"), coords={"lat": lat}), "time")
+    assert m.data["input_data"].masked
+    c = m.components().values
+    k = c.shape[0]
+    assert np.isnan(c[:, land]).all() and not np.isnan(c[:, ~land]).any()
+    flat = vals.reshape(n, -1)[:, ~land.reshape(-1)].astype(np.float64)
+    ref = orc.eof_fit(flat, k, solver="full", random_state=1)
+    s = np.asarray(m.singular_values().values, dtype=np.float64)
+    assert np.all(np.abs(s - ref["norms"][:k]) <= 1e-5 * ref["norms"][0])
+    C = c[:, ~land].T.astype(np.float64)
+    for j in range(min(k, 6)):
+        assert np.dot(C[:, j], ref["components"][:, j]) > 1 - 1e-5
+    sc = m.scores().values
+    t = m.transform(xe.DataArray(vals, dims=("time", "lat", "lon"), coords={"lat": lat})).values
+    assert np.allclose(t, sc, atol=1e-4 * np.abs(sc).max())

@@ -40,6 +40,12 @@ def fractional_matrix_power(C, power):
     return (V[:, keep] * w[keep] ** power) @ V[:, keep].T
 
 
+def _whitener_is_identity(alpha) -> bool:
+    """preprocessing/whitener.py:54-60: `(1.0 - alpha) < eps` -- every alpha >= 1 (and those within one ulp below it) is the
+    identity transform; alpha = 1 - 1e-9 is NOT (np.isclose would call it one)."""
+    return (1.0 - float(alpha)) < np.finfo(np.float64).eps
+
+
 class _Side:
     """One field of the cross model: resident matrix, optional PCA, optional whitener, analysis matrix."""
 
@@ -47,7 +53,7 @@ class _Side:
         self.ctx, self.mat, self.pca, self.alpha = ctx, mat, pca, alpha
         self.T = self.Tinv = None
         self.Z = None if pca is None else pca.scores()          # analysis matrix on the host (n x m), or None
-        if not np.isclose(alpha, 1.0):                          # whitener.py:46-60: identity when alpha == 1
+        if not _whitener_is_identity(alpha):                     # whitener.py:54-60: identity when (1 - alpha) < eps
             if self.Z is None:
                 if mat.p > MAX_DENSE_WHITEN:
                     raise NotImplementedError(
@@ -115,7 +121,7 @@ class _Side:
         L = engine.panel_width(k)
         Rp = engine.panel_import(self.ctx, np.ascontiguousarray(R, dtype=np.float32), self.mat.n_pad, L)
         out = engine.panel_tmul(self.ctx, self.mat, Rp, prec=self.ctx.precision[1])
-        return engine.panel_export(self.ctx, out, self.mat.p, k).astype(np.float64)
+        return self.mat.compact_rows(engine.panel_export(self.ctx, out, self.mat.p_phys, k)).astype(np.float64)
 
     def A_sumsq(self):
         A = self.A_host()
@@ -165,8 +171,12 @@ class CPCCA(Deferred):
         self.solver, self.random_state, self.solver_kwargs = solver, random_state, dict(solver_kwargs)
         self.sample_name = sample_name
         # CPCCA always centres (cpcca.py:145)
-        self.preprocessor1 = Preprocessor(True, std[0], cos[0], chk[0])
-        self.preprocessor2 = Preprocessor(True, std[1], cos[1], chk[1])
+        # In-place layout: the fields are read where they lie (staged once when they come from the host), nothing is written;
+        # whatever needs a layout (PCA, dense whitening, download) builds it on demand.  Without PCA and whitening the
+        # resident matrices go straight to engine.crosscov_rsvd, which also takes land / sea masks in place (zero columns).
+        direct = [not self._params["use_pca"][i] and _whitener_is_identity(self.alpha[i]) for i in range(2)]
+        self.preprocessor1 = Preprocessor(True, std[0], cos[0], chk[0], in_place=True, masked_ok=direct[0])
+        self.preprocessor2 = Preprocessor(True, std[1], cos[1], chk[1], in_place=True, masked_ok=direct[1])
         self.attrs = {"model": self._model_name, "software": "xeofs_amd", "version": __version__,
                       "date": datetime.datetime.now().strftime("%Y-%m-%d %H:%M:%S")}
         self.ctx = None
@@ -217,13 +227,13 @@ class CPCCA(Deferred):
         identity = sx.Tinv is None and sy.Tinv is None
         omega = None
         if ahead is not None:
-            om, l_ahead = ahead
-            om = om.result()
+            fut, l_ahead = ahead
             small_ = min(sx.work.p, sy.work.p)
-            if l_ahead == k + n_over and om.shape[0] >= small_:      # numpy fills row by row: the leading rows ARE the draw
-                omega = np.ascontiguousarray(om[:small_])
-        out = engine.crosscov_rsvd(self.ctx, sx.work, sy.work, k, n_over, n_iter, random_state=self.random_state,
-                                   want_tsc=identity, omega=omega)
+            if l_ahead == k + n_over and fut.rows >= small_:      # numpy fills row by row: the leading rows ARE the draw
+                omega = engine.SketchSlice(fut, small_)           # joined by the engine when it first needs the sketch
+            else:
+                fut.result()
+        out = self._crosscov(sx, sy, k, n_over, n_iter, identity, omega)
         s = out["s"].astype(np.float64)
         self._q = [out["Q1"].astype(np.float64), out["Q2"].astype(np.float64)]     # in the analysis space
         tsc = out["total_squared_covariance"] if identity else self._unwhitened_tsc()
@@ -231,12 +241,30 @@ class CPCCA(Deferred):
         for sd in self.side:
             sd.free()
         self.data = dict(
-            input_data1=mx, input_data2=my, components1=comps[0], components2=comps[1],
+            input_data1=sx.mat, input_data2=sy.mat, components1=comps[0], components2=comps[1],
             scores1=out["scores1"], scores2=out["scores2"], singular_values=s, squared_covariance=s ** 2,
             total_squared_covariance=tsc, idx_modes_sorted=np.argsort(s)[::-1],
             norm1=out["norm1"].astype(np.float64), norm2=out["norm2"].astype(np.float64),
         )
         return self
+
+    def _crosscov(self, sx, sy, k, n_over, n_iter, identity, omega):
+        try:
+            return engine.crosscov_rsvd(self.ctx, sx.work, sy.work, k, n_over, n_iter, random_state=self.random_state,
+                                        want_tsc=identity, omega=omega)
+        except NotImplementedError:
+            # a masked in-place pair the engine cannot orient like the reference (valid and physical widths order
+            # differently, or fewer valid features than samples): compact the fields and go again
+            if not (sx.work.masked or sy.work.masked):
+                raise
+            import logging
+
+            logging.getLogger("xeofs_amd").info("cross-covariance: masked in-place matrices not usable here, compacting the fields")
+            for sd, pre in ((sx, self.preprocessor1), (sy, self.preprocessor2)):
+                if sd.work.masked:
+                    sd.work = sd.mat = pre.recompact(sd.mat)
+            return engine.crosscov_rsvd(self.ctx, sx.work, sy.work, k, n_over, n_iter, random_state=self.random_state,
+                                        want_tsc=identity, omega=omega)
 
     _SKETCH_AHEAD_MIN = 20000
 

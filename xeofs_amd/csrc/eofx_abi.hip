@@ -2669,6 +2669,11 @@ extern "C" int eofx_mat_gram_f32(eofx_ctx* ctx, const eofx_mat* m, int side, flo
   CHK(set_device(ctx));
   const int64_t d = side ? m->p_pad : m->n_pad, o = side ? m->n_pad : m->p_pad;
   if (d > (1 << 16)) return set_err(ctx, EOFX_ERR_ARG, "Gram side of %lld is too large", (long long)d);
+  // sample side, more features than samples: the MFMA-bound tiled kernel over the fp16 planes (eofx_gram.hpp)
+  if (side == 0 && m->p >= m->n && gram_fast_ok(m) && ctx->prec_final == EOFX_PREC_F16X3) {
+    CHK(arena_reserve(ctx, gram_fast_scratch(ctx, m) + (1 << 20)));
+    return mat_gram_fast(ctx, m, G);
+  }
   CHK(arena_reserve(ctx, atb_scratch_bytes(d, o, (int)d) + (1 << 20)));
   return mat_gram(ctx, m, side, G);
 }

@@ -383,14 +383,17 @@ __global__ __launch_bounds__(512, 2) void gram_nt_kernel(const _Float16* __restr
 }
 
 // G[n_pad x n_pad] (ld) from the split partials of the upper-triangle tiles: fixed-order sum over the S slots of a tile,
-// written to block (bi, bj) and, transposed, to block (bj, bi).  grid = (tiles, 16): one 64 x 64 sub-block per workgroup.
-// tiles: {bi, bj} per tile in slot order.
+// written to block (bi, bj) and, transposed, to block (bj, bi) -- G is symmetric bit for bit.  Inside a diagonal tile the
+// kernel's two triangles differ in the last bit (hl and lh meet the accumulator in another order), so only its upper
+// triangle is used there too.  grid = (tiles, 16): one 64 x 64 sub-block per workgroup.  tiles: {bi, bj} in slot order.
 __global__ __launch_bounds__(256) void gram_finish_kernel(const float* __restrict__ Cp, const int2* __restrict__ tiles, int S,
                                                            float* __restrict__ G, int64_t ld) {
   __shared__ float tr[64][65];
   const int tile = blockIdx.x, sb = blockIdx.y;
   const int bi = tiles[tile].x, bj = tiles[tile].y;
-  const int r0 = 64 * (sb >> 2), c0 = 64 * (sb & 3);
+  const int sr = sb >> 2, sc = sb & 3;
+  if (bi == bj && sr > sc) return;      // written as the mirror image of sub-block (sc, sr)   (uniform)
+  const int r0 = 64 * sr, c0 = 64 * sc;
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;     // float4 column, row (16 rows per sweep)
   const float* base = Cp + (int64_t)tile * S * (GR_BM * GR_BM);
 #pragma unroll
@@ -398,15 +401,20 @@ __global__ __launch_bounds__(256) void gram_finish_kernel(const float* __restric
     const int r = r0 + 16 * sweep + ty, c = c0 + 4 * tx;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     for (int s = 0; s < S; ++s) v += *reinterpret_cast<const f32x4*>(base + (int64_t)s * (GR_BM * GR_BM) + r * GR_BM + c);
-    *reinterpret_cast<f32x4*>(G + ((int64_t)bi * GR_BM + r) * ld + (int64_t)bj * GR_BM + c) = v;
     tr[16 * sweep + ty][4 * tx + 0] = v[0];
     tr[16 * sweep + ty][4 * tx + 1] = v[1];
     tr[16 * sweep + ty][4 * tx + 2] = v[2];
     tr[16 * sweep + ty][4 * tx + 3] = v[3];
   }
-  if (bi == bj) return;     // a diagonal tile holds both of its triangles already (uniform branch)
   __syncthreads();
+  const bool diag = bi == bj && sr == sc;     // the sub-block straddles the diagonal: element (r, c) with r > c := (c, r)
   const int qx = threadIdx.x & 63, qy = threadIdx.x >> 6;
+#pragma unroll
+  for (int sweep = 0; sweep < 16; ++sweep) {
+    const int rr = 4 * sweep + qy;
+    G[((int64_t)bi * GR_BM + r0 + rr) * ld + (int64_t)bj * GR_BM + c0 + qx] = (diag && rr > qx) ? tr[qx][rr] : tr[rr][qx];
+  }
+  if (diag) return;
 #pragma unroll
   for (int sweep = 0; sweep < 16; ++sweep) {
     const int cc = 4 * sweep + qy;      // column of the sub-block = row of the mirrored block

@@ -302,6 +302,7 @@ class SketchFuture:
     def __init__(self, rows, size, random_state=None):
         import threading
 
+        self.rows, self.size = int(rows), int(size)
         self._out = None
         self._err = None
 
@@ -319,6 +320,17 @@ class SketchFuture:
         if self._err is not None:
             raise self._err
         return self._out
+
+
+class SketchSlice:
+    """The leading `rows` rows of a SketchFuture (numpy fills the draw row by row, so they ARE the smaller draw); joined on
+    `.result()`, which engine.crosscov_rsvd calls as late as the engine allows."""
+
+    def __init__(self, future, rows):
+        self.future, self.rows = future, int(rows)
+
+    def result(self):
+        return np.ascontiguousarray(self.future.result()[:self.rows])
 
 
 def from_dense(ctx: Context, X) -> ResidentMatrix:

@@ -128,7 +128,9 @@ class ResidentPCA:
             Vp[:p, :m] = Small.float()
             self.Vp, U = Vp, Tall[:n, :m].double()
         # deterministic sign (utils/xarray_utils.py:273-301 on V), applied before the truncation in _svd.py:208-213
-        mx, mn = engine.panel_colminmax(ctx, self.Vp, p)
+        # (a masked in-place matrix -- layout mode 3 -- keeps its all-NaN grid points as zero columns: V has p_phys rows,
+        # zero at the masked features; zeros never change the sign rule, and every export below compacts the rows)
+        mx, mn = engine.panel_colminmax(ctx, self.Vp, mat.p_phys)
         if sharded:
             mx, mn = comm.max_(mx), comm.min_(mn)
         mx, mn = mx.double()[:m], mn.double()[:m]
@@ -137,6 +139,7 @@ class ResidentPCA:
             sign = torch.ones_like(sign)
         self.sign = sign.cpu().numpy()
         self.m, self.Lm, self.n, self.p, self.p_pad = m, Lm, n, p, mat.p_pad
+        self.p_phys, self._masked_index = mat.p_phys, (mat.valid_index if mat.masked else None)
         self.s = s.cpu().numpy()
         self.U = (U * sign).cpu().numpy()               # n x m float64
         self.singular_values_all = np.sqrt(lam_h)
@@ -148,9 +151,29 @@ class ResidentPCA:
         """X V = U s  (n x m), what `PCA.transform` returns for the training data (pca.py:125-134)."""
         return self.U * self.s
 
+    def _compact(self, V):
+        """rows of the valid features of an exported factor with p_phys rows"""
+        return V if self._masked_index is None else np.ascontiguousarray(V[self._masked_index])
+
+    def _vp_for(self, mat_new):
+        """V as a panel over the columns of `mat_new`: the fitted matrix may have been masked in place (V has p_phys rows)
+        while the new one is compacted, or the other way round"""
+        if self._masked_index is None and not mat_new.masked:
+            return self.Vp
+        if self._masked_index is not None and mat_new.masked and mat_new.p_phys == self.p_phys:
+            return self.Vp
+        torch = engine._torch()
+        idx = torch.as_tensor(self._masked_index if self._masked_index is not None else mat_new.valid_index, device=self.Vp.device)
+        out = torch.zeros((mat_new.p_pad, self.Lm), dtype=torch.float32, device=self.Vp.device)
+        if self._masked_index is not None:          # fitted masked, new data compacted: gather the valid rows
+            out[:self.p] = self.Vp.index_select(0, idx)
+        else:                                       # fitted compacted, new data masked in place: scatter
+            out.index_copy_(0, idx, self.Vp[:self.p])
+        return out
+
     def transform(self, mat_new):
         """X_new V (n' x m) for a resident matrix preprocessed with the fitted state."""
-        out = engine.panel_mul(self.ctx, mat_new, self.Vp, prec=self.ctx.precision[1])
+        out = engine.panel_mul(self.ctx, mat_new, self._vp_for(mat_new), prec=self.ctx.precision[1])
         return out[:mat_new.n, :self.m].double().cpu().numpy() * self.sign
 
     def back_project(self, Q):
@@ -161,11 +184,11 @@ class ResidentPCA:
         M = np.zeros((self.Lm, _round32(k)))
         M[:self.m, :k] = Q * self.sign[:, None]
         out = engine.panel_matmul(self.ctx, self.Vp, torch.as_tensor(M, device=self.Vp.device))
-        return engine.panel_export(self.ctx, out, self.p, k)
+        return self._compact(engine.panel_export(self.ctx, out, self.p_phys, k))
 
     def components(self):
         """V (p x m) float32 on the host."""
-        return engine.panel_export(self.ctx, self.Vp, self.p, self.m, self.sign)
+        return self._compact(engine.panel_export(self.ctx, self.Vp, self.p_phys, self.m, self.sign))
 
     def row_norms(self, M):
         """Euclidean norms of the rows of V diag(sign) M (p,), M: m x m -- the per-feature standard deviations
@@ -174,4 +197,4 @@ class ResidentPCA:
         Mp = np.zeros((self.Lm, self.Lm))
         Mp[:self.m, :self.m] = np.asarray(M, dtype=np.float64) * self.sign[:, None]
         out = engine.panel_matmul(self.ctx, self.Vp, torch.as_tensor(Mp, device=self.Vp.device))
-        return engine.panel_rownorm(self.ctx, out, self.p)
+        return self._compact(engine.panel_rownorm(self.ctx, out, self.p_phys))

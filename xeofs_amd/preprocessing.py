@@ -139,7 +139,20 @@ class Preprocessor:
         self.mean_, self.std_ = (st["mean"] if self.center else None), (st["std"] if self.standardize else None)
         self.valid_feature, self.valid_sample = st["valid_feature"], st["valid_sample"]
         self.total_variance = st["total_variance"]
+        self._stacked = M if mat.masked else None      # (a reference, not a copy) for recompact()
         return mat
+
+    def recompact(self, mat):
+        """The compacted matrix of a field that fit_transform left masked in place (layout mode 3), for a consumer that
+        cannot work with zero columns; frees `mat`.  Same statistics, same preprocessed values."""
+        ctx = self.ctx or engine.default_context()
+        M, self._stacked = self._stacked, None
+        if M is None:
+            raise RuntimeError("recompact: the stacked field is no longer held")
+        mat.free()
+        new, _ = engine.preprocess(ctx, M, self.center, self.standardize, self.feature_weights, self.check_nans,
+                                   want_stats=False, in_place=False, allow_masked=False)
+        return new
 
     def fit_transform_decompose(self, X, sample_dims, weights, decomposer, omega=None):
         """Preprocessor.fit_transform and Decomposer.fit in ONE engine call where the shape allows (engine.fit /
