@@ -234,6 +234,9 @@ int eofx_fit_first_f32(eofx_ctx *ctx, const float *X, int64_t n, int64_t P, int 
  * layout (40 % of the features or more, or n >= valid features).  In layout mode 3 a field whose NaNs are all-NaN grid
  * points stays on the fused path: the first pass confines and verifies them by itself (xeofs_amd/csrc/eofx_fit.hpp).  */
 int eofx_ctx_fit_info(const eofx_ctx *ctx, double *info3);
+/* power iterations the last eofx_rsvd_c64 on this context made (n_iter < 0 there = iterate until the Ritz values stand
+ * still: the reference's complex branch, scipy svds(solver="lobpcg"), converges to a tolerance -- decomposer.py:149-160) */
+int eofx_ctx_last_iterations(const eofx_ctx *ctx, int *iterations);
 
 /* scores = X V (eof.py:129).  V host|device [p x k]; out host|device [n x k].   */
 int eofx_project_f32(eofx_ctx *ctx, const eofx_mat *m, const float *V, int k, float *out);
@@ -345,7 +348,10 @@ int eofx_vec_dot_f64(eofx_ctx *ctx, const float *a, const float *b, int64_t coun
  * xarray_utils.py:273-301, with numpy's lexicographic complex max / min).  A pass over the data is one launch of the
  * streaming kernel in its two-matrix form; the l x l Hermitian factorisations run on the host in float64.
  * omega: host [min(n,p) x (k + n_oversamples)] REAL start matrix (the Gaussian numpy's RandomState draws; the
- * identity when k + n_oversamples >= min(n, p)); n_iter < 0 = scikit-learn's "auto".  U [n x k], V [p x k]:
+ * identity when k + n_oversamples >= min(n, p)); n_iter = -1: scikit-learn's "auto" count (7 or 4), n_iter = -2: iterate
+ * until the leading k Ritz values stand still (relative change <= 1e-6 twice in a row; 2 .. 20 iterations -- lobpcg
+ * converges to a tolerance, which matters when the wanted modes run into a flat noise bulk; eofx_ctx_last_iterations
+ * reports the count).  U [n x k], V [p x k]:
  * complex64, row-major, interleaved (re, im), host|device; s [k] float32.  k + n_oversamples <= 64
  * (EOFX_ERR_ARG beyond); vectors are defined up to a unit phase per mode, as in the reference.                   */
 int eofx_rsvd_c64(eofx_ctx *ctx, const eofx_mat *A, const eofx_mat *B, int k, int n_oversamples, int n_iter,

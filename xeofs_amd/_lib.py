@@ -70,6 +70,7 @@ SIGNATURES = {
     "eofx_fit_first_f32": (_int, [_vp, _vp, _i64, _i64, _int, _int, _vp, _int, _vp, _int, _int, _vp, C.POINTER(_vp),
                                   _vp, _vp, _vp, _vp, _pi64, _pi64, _pd, C.POINTER(C.c_int)]),
     "eofx_ctx_fit_info": (_int, [_vp, _pd]),
+    "eofx_ctx_last_iterations": (_int, [_vp, C.POINTER(_int)]),
     "eofx_rsvd_c64": (_int, [_vp, _vp, _vp, _int, _int, _int, _vp, _int, _vp, _vp, _vp]),
     "eofx_orth_tall_rule": (_int, [_i64, _int, _int]),
     "eofx_peaked_spectrum": (_int, [_vp, _int, _int]),

@@ -496,6 +496,13 @@ def fit_info(ctx: Context):
     return dict(fused=bool(info[0]), preprocess_ms=float(info[1]), reason=int(info[2]))
 
 
+def last_iterations(ctx: Context) -> int:
+    """power iterations of the last `rsvd_c64` on this context (its n_iter="auto" iterates until the Ritz values stand still)"""
+    out = C.c_int()
+    raise_for(ctx.lib.eofx_ctx_last_iterations(ctx.handle, C.byref(out)), ctx.handle)
+    return out.value
+
+
 def apply(ctx: Context, X, mean, std, feature_weights, valid_feature, check_nans=True, in_place=False, allow_masked=False):
     """Preprocessor.transform on new data with fitted state.  in_place: as in `preprocess` -- nothing is written, the
     projection that follows streams the (staged) field through the fitted map."""
@@ -748,12 +755,12 @@ def hilbert(ctx: Context, mat: ResidentMatrix, padding="exp", decay_factor: floa
     """Analytic signal along the sample axis (xeofs/utils/hilbert_transform.py:40-72).
     Returns (imag ResidentMatrix, real ResidentMatrix | None).  As in the reference only
     padding == "exp" pads; any other value means no padding."""
+    if mat.masked:      # (checked BEFORE the call: its two result matrices would leak)
+        raise NotImplementedError("Hilbert transform of a masked in-place matrix (preprocess without allow_masked)")
     hi, hr = C.c_void_p(), C.c_void_p()
     rc = ctx.lib.eofx_hilbert_f32(ctx.handle, mat.handle, int(padding == "exp"), float(decay_factor),
                                   C.byref(hi), C.byref(hr) if want_real else None)
     raise_for(rc, ctx.handle)
-    if mat.masked:
-        raise NotImplementedError("Hilbert transform of a masked in-place matrix (preprocess without allow_masked)")
     return ResidentMatrix(ctx, hi), (ResidentMatrix(ctx, hr) if want_real else None)
 
 
@@ -885,7 +892,8 @@ def rsvd_c64(ctx: Context, A: ResidentMatrix, B: ResidentMatrix, k: int, n_overs
         omega = np.ascontiguousarray(omega, dtype=np.float32)
         if omega.shape != (r, k + n_oversamples):
             raise ValueError(f"omega must have shape {(r, k + n_oversamples)}")
-    it = -1 if n_iter in ("auto", None) else int(n_iter)
+    # "auto": scikit-learn's count, as the real branch; "converge": until the Ritz values stand still (at most 20 iterations)
+    it = -1 if n_iter in ("auto", None) else -2 if n_iter == "converge" else int(n_iter)
     if device_out:
         torch = _torch()
         dev = f"cuda:{ctx.device}"
