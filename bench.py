@@ -546,6 +546,8 @@ def main():
     ap.add_argument("--two-layouts", action="store_true", help="same as --layout copy")
     ap.add_argument("--two-step", action="store_true",
                     help="statistics pass + decomposition as two engine calls (17 reads of the field) instead of the fused fit")
+    ap.add_argument("--no-native", action="store_true", help="multi-rank runs: the panel-level python driver instead of the "
+                    "engine's own sharded entry (eofx_fit_sharded_f32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true",
                     help="do not re-count roofline.traffic with rocprofv3 (two short PMC passes over this command, ~40 s); "
@@ -605,6 +607,9 @@ def main():
     ctx = engine.Context(local_rank)
     ctx.set_precision(*{"f16x3": ("f16x3", "f16x3"), "f32": ("f32", "f32"), "bf16": ("bf16x3", "bf16x6"), "f64": ("f64", "f64")}[args.precision])
     comm = sharded.Comm(force=args.force_sharded)
+    # the engine's own communicator (RCCL on the context's stream): eofx_fit_sharded_f32 issues the collectives of a fit
+    # itself, between its kernels; the panel-level driver (python + torch.distributed) stays as its fallback
+    native = (world > 1 or args.force_sharded) and not args.no_native and sharded.attach_native(ctx, comm)
 
     t0 = time.perf_counter()
     Xraw = make_field(n, args.nlat, args.nlon, lo, hi, device)
@@ -648,6 +653,20 @@ def main():
             phase["svd"] += (c - a) - pre
             return mat, st, U, s, V
         first = None
+        if native and args.layout == "inplace" and not args.two_step and n < P:
+            res = engine.fit_sharded(ctx, Xraw, k, P, center=True, standardize=False, feature_weights=None,
+                                     n_oversamples=N_OVERSAMPLES, n_iter="auto", omega=omega, want_stats=False,
+                                     device_out=True)
+            if res is not None:
+                torch.cuda.synchronize()
+                c = time.perf_counter()
+                info = engine.fit_info(ctx)
+                pre = info["preprocess_ms"] * 1e-3
+                phase["fused_steps"] += 1
+                phase["native_steps"] = phase.get("native_steps", 0) + 1
+                phase["pre"] += pre
+                phase["svd"] += (c - a) - pre
+                return res
         if single:
             mat, st = engine.preprocess(ctx, Xraw, center=True, standardize=False, feature_weights=None,
                                         want_stats=False, **layout_kw)
@@ -682,6 +701,9 @@ def main():
     comm.profile(True)
     phase["pre"] = phase["svd"] = 0.0
     phase["fused_steps"] = 0
+    phase["native_steps"] = 0
+    if native:
+        engine.comm_stats(ctx)      # (resets the counters: the warm-up fits are not part of the timed region)
     barrier()
     t0 = time.perf_counter()
     last = None
@@ -692,8 +714,11 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     prof = ctx.profile_read()
+    native_stats = engine.comm_stats(ctx) if native else None
     ctx.profile(False)
     comm_stats = comm.profile_read()
+    if native_stats and native_stats["calls"]:
+        comm_stats = native_stats
     tt = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -927,7 +952,9 @@ def main():
                                    f"random_state=5",
                        "n_samples": n, "n_features": P, "n_modes": k, "passes": passes, "layout": args.layout,
                        "field_reads_per_fit": passes if phase["fused_steps"] == args.steps else passes + 1,
-                       "entry": "eofx_fit_f32 (statistics during the first pass)" if one_call else
+                       "entry": "eofx_fit_sharded_f32 (one engine call per rank; statistics during the first pass; collectives "
+                                "issued by the engine on its own stream)" if phase.get("native_steps", 0) == args.steps else
+                                "eofx_fit_f32 (statistics during the first pass)" if one_call else
                                 "eofx_preprocess_f32 + eofx_rsvd_f32" if single else
                                 "sharded_fit_first (eofx_fit_first_f32 per rank) + sharded_rsvd (panel ABI + collectives)"
                                 if phase["fused_steps"] else "sharded_preprocess + sharded_rsvd (panel ABI + collectives)"},
@@ -945,6 +972,9 @@ def main():
                             "allreduce_calls_per_fit": round(comm_stats["calls"] / args.steps, 1),
                             "allreduce_bytes_per_fit": round(comm_stats["bytes"] / args.steps),
                             "allreduce_ms_per_fit": round(comm_stats["ms"] / args.steps, 3),
+                            "binding": ("engine-owned RCCL communicator, ncclAllReduce on the context's stream" if args.backend == "nccl"
+                                        else "host callback over torch.distributed") if phase.get("native_steps", 0) else
+                                       "torch.distributed all_reduce from the python driver",
                             "timing": "events on the collective's stream around every all_reduce of the timed fits (rank 0)"}
         print(json.dumps(line), file=real_stdout, flush=True)
     if world > 1 or args.force_sharded:

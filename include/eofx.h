@@ -234,6 +234,38 @@ int eofx_fit_first_f32(eofx_ctx *ctx, const float *X, int64_t n, int64_t P, int 
  * layout (40 % of the features or more, or n >= valid features).  In layout mode 3 a field whose NaNs are all-NaN grid
  * points stays on the fused path: the first pass confines and verifies them by itself (xeofs_amd/csrc/eofx_fit.hpp).  */
 int eofx_ctx_fit_info(const eofx_ctx *ctx, double *info3);
+/* ---- feature-sharded fit: one process per GPU, the space axis split over the ranks ---------------------
+ * Rank g holds X_g = X[:, p_g] (all n samples, its slice of the stacked feature axis).  With a communicator attached to
+ * the context, eofx_fit_sharded_f32 is eofx_fit_f32 on that slice: the statistics of the slice ride on its
+ * (communication-free) first product X_g^T Omega, every later sample-side product X_g Y_g is followed by ONE all-reduce of
+ * the n x L float32 panel, every Gram matrix of a feature-side panel by one of L x L float64, the sign rule by one of 2 k
+ * extrema, the total variance by one scalar -- all enqueued on the context's stream between the kernels, no host round
+ * trip and no second stream.  Results: U, s replicated (bit-identical on every rank), V = this rank's rows.
+ *
+ * Two bindings of the collective.  RCCL: rank 0 calls eofx_comm_unique_id and hands the 128 bytes to every rank (any side
+ * channel: torch.distributed, MPI, a file); every rank then calls eofx_ctx_comm_init_rccl (ncclCommInitRank; the library
+ * is opened at run time -- an already loaded librccl.so.1 is reused, e.g. PyTorch's --, nothing links against it).
+ * Callback: `fn` must all-reduce `count` elements of the DEVICE buffer in place, ordered after the work already queued on
+ * `stream` and before what is queued next (e.g. synchronise, reduce through a host library, copy back): for tests and for
+ * hosts that own their communicator.  dtype: 0 float32, 1 float64, 2 int32; op: 0 sum, 1 max, 2 min; returns 0 on success. */
+typedef int (*eofx_allreduce_fn)(void *user, void *device_buf, int64_t count, int dtype, int op, void *stream);
+int eofx_comm_unique_id(char *id128);
+int eofx_ctx_comm_init_rccl(eofx_ctx *ctx, const char *id128, int world, int rank);
+int eofx_ctx_comm_set_callback(eofx_ctx *ctx, eofx_allreduce_fn fn, void *user, int world, int rank);
+int eofx_ctx_comm_clear(eofx_ctx *ctx);
+/* collectives issued on this context since the last call, their bytes, and (while eofx_ctx_profile is on) their
+ * milliseconds from events on the context's stream; resets the counters */
+int eofx_ctx_comm_stats(eofx_ctx *ctx, int64_t *calls, int64_t *bytes, double *ms);
+/* eofx_fit_f32 on this rank's slice [n x P_local] of a field with P_total features (arguments as there; omega: the global
+ * sketch [n x (k + n_oversamples)], identical on every rank; needs n < P_total, i.e. the sketch on the sample side).
+ * total_variance is the global one; mean / std / valid_feature / V are those of the slice.  Returns 0, or 1 when the
+ * fused path is not available on SOME rank (NaN fields, shapes outside eofx_fit_first_f32's range -- the ranks agree on
+ * this by a vote): nothing is built then and the caller takes the panel-level route (xeofs_amd/sharded.py). */
+int eofx_fit_sharded_f32(eofx_ctx *ctx, const float *X, int64_t n, int64_t P_local, int64_t P_total, int center,
+                         int standardize, const double *feat_weights, int k, int n_oversamples, int n_iter,
+                         const float *omega, int64_t omega_rows, int flip, eofx_mat **out, double *mean, double *std,
+                         uint8_t *valid_feature, double *total_variance, float *U, float *s, float *V);
+
 /* power iterations the last eofx_rsvd_c64 on this context made (n_iter < 0 there = iterate until the Ritz values stand
  * still: the reference's complex branch, scipy svds(solver="lobpcg"), converges to a tolerance -- decomposer.py:149-160) */
 int eofx_ctx_last_iterations(const eofx_ctx *ctx, int *iterations);

@@ -178,9 +178,22 @@ def test_two_rank_sharded_path_on_one_gpu(ctx):
     d2 = json.loads(two.stdout.strip().splitlines()[-1])
     d1 = json.loads(one.stdout.strip().splitlines()[-1])
     assert d2["n_gpus"] == 2 and d1["n_gpus"] == 1
+    # the two ranks went through the engine's own sharded entry (collectives issued by the engine; here through the
+    # host-callback binding, gloo underneath), not through the python driver
+    assert d2["config"]["entry"].startswith("eofx_fit_sharded_f32"), d2["config"]["entry"]
+    assert d2["comm"]["allreduce_calls_per_fit"] >= 15 and "callback" in d2["comm"]["binding"]
     assert len(two.stdout.strip().splitlines()) == 1 and len(one.stdout.strip().splitlines()) == 1  # ONE JSON line
     assert np.allclose(d2["parity"]["s_head"], d1["parity"]["s_head"], rtol=2e-6)
     assert d2["parity"]["XV_eq_Us_relerr"] < 1e-5 and d2["parity"]["orth_V_maxabs"] < 1e-6
+    # the panel-level python driver (torch.distributed collectives between engine calls) is still there and agrees
+    py2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29518", os.path.join(root, "bench.py"),
+                          "--gpus", "2", "--backend", "gloo", "--same-gpu", "--no-native"] + common,
+                         capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    assert py2.returncode == 0, py2.stderr[-2000:]
+    dp = json.loads(py2.stdout.strip().splitlines()[-1])
+    assert dp["config"]["entry"].startswith("sharded_fit_first")
+    assert np.allclose(dp["parity"]["s_head"], d2["parity"]["s_head"], rtol=1e-6)
     # the same job without an external launcher: `bench.py --gpus 2` starts its own two ranks
     env_nl = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     self2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo",

@@ -27,6 +27,9 @@ _pd = C.POINTER(C.c_double)
 # eofx_sketch_fn (include/eofx.h): const float *(*)(void *user)
 SKETCH_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p)
 
+# eofx_allreduce_fn (include/eofx.h): int (*)(void *user, void *device_buf, int64_t count, int dtype, int op, void *stream)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p)
+
 # name -> (restype, argtypes); must list every symbol of include/eofx.h
 SIGNATURES = {
     "eofx_abi_version": (_int, []),
@@ -71,6 +74,13 @@ SIGNATURES = {
                                   _vp, _vp, _vp, _vp, _pi64, _pi64, _pd, C.POINTER(C.c_int)]),
     "eofx_ctx_fit_info": (_int, [_vp, _pd]),
     "eofx_ctx_last_iterations": (_int, [_vp, C.POINTER(_int)]),
+    "eofx_comm_unique_id": (_int, [C.c_char_p]),
+    "eofx_ctx_comm_init_rccl": (_int, [_vp, C.c_char_p, _int, _int]),
+    "eofx_ctx_comm_set_callback": (_int, [_vp, ALLREDUCE_FN, _vp, _int, _int]),
+    "eofx_ctx_comm_clear": (_int, [_vp]),
+    "eofx_ctx_comm_stats": (_int, [_vp, _pi64, _pi64, _pd]),
+    "eofx_fit_sharded_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _int, _int, _vp, _int, _int, _int, _vp, _i64, _int,
+                                    C.POINTER(_vp), _vp, _vp, _vp, _pd, _vp, _vp, _vp]),
     "eofx_rsvd_c64": (_int, [_vp, _vp, _vp, _int, _int, _int, _vp, _int, _vp, _vp, _vp]),
     "eofx_orth_tall_rule": (_int, [_i64, _int, _int]),
     "eofx_peaked_spectrum": (_int, [_vp, _int, _int]),

@@ -24,15 +24,41 @@
 #include <memory>
 #include <vector>
 
+#include <dlfcn.h>
 #include <hipfft/hipfft.h>
 
 #include "eofx.h"
 
 using namespace eofx;
 
+struct ncclUniqueIdCompat {      // rccl.h: typedef struct { char internal[128]; } ncclUniqueId  (passed BY VALUE to ncclCommInitRank)
+  char internal[128];
+};
+
 // ------------------------------------------------------------------------------------
 // context, arena, helpers
 // ------------------------------------------------------------------------------------
+// Communicator of the feature-sharded entry points: one process per GPU, every rank holds its slice of the
+// feature axis, the only traffic is all-reduces of sample-side panels (n x L float32), L x L float64 Gram matrices and a
+// few scalars.  Two bindings: RCCL (ncclAllReduce enqueued on the context's own stream -- no host round trip, no second
+// stream, no Python between the passes; the library is opened at run time, nothing links against it) and a host callback
+// (tests: torch.distributed / gloo between two processes that share one GPU).
+struct EofxComm {
+  int world = 1, rank = 0;
+  // RCCL binding
+  void* lib = nullptr;
+  void* comm = nullptr;    // ncclComm_t
+  int (*p_allreduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*p_destroy)(void*) = nullptr;
+  const char* (*p_errstr)(int) = nullptr;
+  // callback binding
+  eofx_allreduce_fn fn = nullptr;
+  void* user = nullptr;
+  // bookkeeping (eofx_ctx_comm_stats): collectives issued, bytes, milliseconds (events, only while profiling is on)
+  int64_t calls = 0, bytes = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+};
+
 struct eofx_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -99,6 +125,7 @@ struct eofx_ctx {
   // fused preprocessor (probe, finalize, correction; HIP events, only with profiling on), [2] fallback reason
   double fit_info[4] = {0.0, 0.0, 0.0, 0.0};
   int last_iters = 0;   // power iterations of the last eofx_rsvd_c64 (its adaptive rule decides the count)
+  EofxComm* comm = nullptr;   // feature-sharded entry points (eofx_fit_sharded_f32)
 };
 constexpr int EOFX_AMAX_SLOTS = 1024;
 constexpr size_t EOFX_PINNED_DOUBLES = 2 * 256 * 256 + 64;
@@ -236,6 +263,7 @@ extern "C" int eofx_ctx_destroy(eofx_ctx* ctx) {
     hipfftDestroy((hipfftHandle)e.second.first);
     hipfftDestroy((hipfftHandle)e.second.second);
   }
+  (void)eofx_ctx_comm_clear(ctx);
   for (auto* g : ctx->gram_plans) {
     if (g->items) (void)hipFree(g->items);
     if (g->tiles) (void)hipFree(g->tiles);
@@ -1790,6 +1818,9 @@ struct LinOp {
   int64_t tall, small, tall_pad, small_pad;
   std::function<int(const float*, float*, int, int)> fwd;  // tall panel  = A   * small panel (.., L, prec)
   std::function<int(const float*, float*, int, int)> bwd;  // small panel = A^T * tall panel
+  // rows of the tall side sharded over ranks (eofx_fit_sharded_f32): every L x L float64 Gram matrix of a tall panel is
+  // summed over the ranks by this hook (count doubles, device, in place, stream order); bwd then includes its own reduction
+  std::function<int(double*, int64_t)> reduce_tall_gram;
 };
 
 struct RsvdOut {
@@ -1894,6 +1925,10 @@ static int rsvd_core(eofx_ctx* ctx, const LinOp& op, int k, int l, int n_iter, c
     first_done = true;
     return op.fwd(z, y, L, prec);
   };
+  auto gram_tall = [&](const float* Pn, double* Gout) -> int {
+    CHK(launch_gram(ctx, Pn, op.tall_pad, L, Gout));
+    return op.reduce_tall_gram ? op.reduce_tall_gram(Gout, (int64_t)L * L) : EOFX_OK;
+  };
   // power iterations: Z <- orth(A^T (A Z)).  Only the small-side panel is orthonormalised
   // (Cholesky-QR with a float64 Gram matrix); the tall panel is never factorised here.
   const int pp = ctx->prec_power, pf = ctx->prec_final;
@@ -1921,7 +1956,7 @@ static int rsvd_core(eofx_ctx* ctx, const LinOp& op, int k, int l, int n_iter, c
       if (rc != EOFX_OK) break;
     }
     if (it == 0 || orth_rest) {
-      if ((rc = launch_gram(ctx, Yt, op.tall_pad, L, G)) != EOFX_OK) break;
+      if ((rc = gram_tall(Yt, G)) != EOFX_OK) break;
       if ((rc = launch_cholqr(ctx, Yt, op.tall_pad, L, l, G, Qt)) != EOFX_OK) break;
       rc = op.bwd(Qt, Ws, L, pp);
     } else {
@@ -1954,9 +1989,9 @@ static int rsvd_core(eofx_ctx* ctx, const LinOp& op, int k, int l, int n_iter, c
   // decides the singular values and uses the final one.
   if (range) CHK((*range)(Zs, Yt, L));
   else CHK(fwd(Zs, Yt, pp));
-  CHK(launch_gram(ctx, Yt, op.tall_pad, L, G));
+  CHK(gram_tall(Yt, G));
   CHK(launch_cholqr(ctx, Yt, op.tall_pad, L, l, G, Qt));      // Q1
-  CHK(launch_gram(ctx, Qt, op.tall_pad, L, G));
+  CHK(gram_tall(Qt, G));
   CHK(launch_rinv(ctx, G, L, l, R2));                          // R2^-1
   // B^T = A^T Q  (small x l);  B B^T = (B^T)^T (B^T)
   CHK(op.bwd(Qt, Zs, L, pf));                                  // A^T Q1 (Zs is free now)
@@ -2464,6 +2499,249 @@ extern "C" int eofx_fit_f32(eofx_ctx* ctx, const float* X, int64_t n, int64_t P,
     return rc;
   }
   *out = m;
+  return EOFX_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// communicator of the feature-sharded entry (include/eofx.h)
+// ------------------------------------------------------------------------------------
+struct RcclApi {
+  void* lib = nullptr;
+  int (*get_unique_id)(void*) = nullptr;
+  int (*comm_init_rank)(void**, int, ncclUniqueIdCompat, int) = nullptr;
+  int (*allreduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*comm_destroy)(void*) = nullptr;
+  const char* (*errstr)(int) = nullptr;
+};
+static int rccl_open(eofx_ctx* ctx, RcclApi& api) {
+  static RcclApi cached;
+  if (!cached.lib) {
+    void* h = nullptr;
+    // an instance already in the process first (PyTorch ships its own librccl: two instances would not share communicators)
+    for (const char* name : {"librccl.so.1", "librccl.so"})
+      if (!h) h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+    if (!h)
+      if (const char* ev = std::getenv("EOFX_RCCL_LIB")) h = dlopen(ev, RTLD_NOW | RTLD_GLOBAL);
+    for (const char* name : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"})
+      if (!h) h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return set_err(ctx, EOFX_ERR_HIP, "cannot open librccl (%s); set EOFX_RCCL_LIB", dlerror());
+    cached.lib = h;
+    cached.get_unique_id = reinterpret_cast<int (*)(void*)>(dlsym(h, "ncclGetUniqueId"));
+    cached.comm_init_rank = reinterpret_cast<int (*)(void**, int, ncclUniqueIdCompat, int)>(dlsym(h, "ncclCommInitRank"));
+    cached.allreduce = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, void*, hipStream_t)>(dlsym(h, "ncclAllReduce"));
+    cached.comm_destroy = reinterpret_cast<int (*)(void*)>(dlsym(h, "ncclCommDestroy"));
+    cached.errstr = reinterpret_cast<const char* (*)(int)>(dlsym(h, "ncclGetErrorString"));
+    if (!cached.get_unique_id || !cached.comm_init_rank || !cached.allreduce || !cached.comm_destroy) {
+      cached = RcclApi();
+      return set_err(ctx, EOFX_ERR_HIP, "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy");
+    }
+  }
+  api = cached;
+  return EOFX_OK;
+}
+extern "C" int eofx_comm_unique_id(char* id128) {
+  if (!id128) return EOFX_ERR_ARG;
+  RcclApi api;
+  CHK(rccl_open(nullptr, api));
+  ncclUniqueIdCompat id;
+  if (api.get_unique_id(&id) != 0) return EOFX_ERR_HIP;
+  std::memcpy(id128, id.internal, 128);
+  return EOFX_OK;
+}
+extern "C" int eofx_ctx_comm_clear(eofx_ctx* ctx) {
+  if (!ctx) return EOFX_ERR_ARG;
+  if (!ctx->comm) return EOFX_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto& e : ctx->comm->events) {
+    (void)hipEventDestroy(e.first);
+    (void)hipEventDestroy(e.second);
+  }
+  if (ctx->comm->comm && ctx->comm->p_destroy) (void)ctx->comm->p_destroy(ctx->comm->comm);
+  delete ctx->comm;
+  ctx->comm = nullptr;
+  return EOFX_OK;
+}
+extern "C" int eofx_ctx_comm_init_rccl(eofx_ctx* ctx, const char* id128, int world, int rank) {
+  if (!ctx || !id128 || world < 1 || rank < 0 || rank >= world) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  CHK(set_device(ctx));
+  CHK(eofx_ctx_comm_clear(ctx));
+  RcclApi api;
+  CHK(rccl_open(ctx, api));
+  ncclUniqueIdCompat id;
+  std::memcpy(id.internal, id128, 128);
+  void* comm = nullptr;
+  const int rc = api.comm_init_rank(&comm, world, id, rank);
+  if (rc != 0 || !comm)
+    return set_err(ctx, EOFX_ERR_HIP, "ncclCommInitRank(world %d, rank %d) failed: %s", world, rank, api.errstr ? api.errstr(rc) : "?");
+  auto* c = new EofxComm();
+  c->world = world;
+  c->rank = rank;
+  c->lib = api.lib;
+  c->comm = comm;
+  c->p_allreduce = api.allreduce;
+  c->p_destroy = api.comm_destroy;
+  c->p_errstr = api.errstr;
+  ctx->comm = c;
+  return EOFX_OK;
+}
+extern "C" int eofx_ctx_comm_set_callback(eofx_ctx* ctx, eofx_allreduce_fn fn, void* user, int world, int rank) {
+  if (!ctx || !fn || world < 1 || rank < 0 || rank >= world) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  CHK(eofx_ctx_comm_clear(ctx));
+  auto* c = new EofxComm();
+  c->world = world;
+  c->rank = rank;
+  c->fn = fn;
+  c->user = user;
+  ctx->comm = c;
+  return EOFX_OK;
+}
+extern "C" int eofx_ctx_comm_stats(eofx_ctx* ctx, int64_t* calls, int64_t* bytes, double* ms) {
+  if (!ctx) return EOFX_ERR_ARG;
+  double t = 0.0;
+  if (ctx->comm) {
+    CHK(set_device(ctx));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (auto& e : ctx->comm->events) {
+      float dt = 0.f;
+      (void)hipEventElapsedTime(&dt, e.first, e.second);
+      t += dt;
+      (void)hipEventDestroy(e.first);
+      (void)hipEventDestroy(e.second);
+    }
+    ctx->comm->events.clear();
+  }
+  if (calls) *calls = ctx->comm ? ctx->comm->calls : 0;
+  if (bytes) *bytes = ctx->comm ? ctx->comm->bytes : 0;
+  if (ms) *ms = t;
+  if (ctx->comm) ctx->comm->calls = ctx->comm->bytes = 0;
+  return EOFX_OK;
+}
+// all-reduce `count` elements of a device buffer in place, in stream order.  dtype: 0 f32, 1 f64, 2 i32; op: 0 sum, 1 max, 2 min
+static int comm_allreduce(eofx_ctx* ctx, void* buf, int64_t count, int dtype, int op) {
+  EofxComm* c = ctx->comm;
+  if (!c) return EOFX_OK;
+  static const int esize[3] = {4, 8, 4};
+  c->calls += 1;
+  c->bytes += count * esize[dtype];
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (ctx->profile) {
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, ctx->stream));
+  }
+  if (c->fn) {
+    if (c->fn(c->user, buf, count, dtype, op, (void*)ctx->stream) != 0)
+      return set_err(ctx, EOFX_ERR_HIP, "the all-reduce callback failed");
+  } else {
+    static const int nccl_type[3] = {7, 8, 2};     // ncclFloat32, ncclFloat64, ncclInt32 (rccl.h)
+    static const int nccl_op[3] = {0, 2, 3};       // ncclSum, ncclMax, ncclMin
+    const int rc = c->p_allreduce(buf, buf, (size_t)count, nccl_type[dtype], nccl_op[op], c->comm, ctx->stream);
+    if (rc != 0) return set_err(ctx, EOFX_ERR_HIP, "ncclAllReduce failed: %s", c->p_errstr ? c->p_errstr(rc) : "?");
+  }
+  if (ctx->profile) {
+    HIPCHK(hipEventRecord(e1, ctx->stream));
+    c->events.emplace_back(e0, e1);
+  }
+  return EOFX_OK;
+}
+// the ranks agree on the worst of their local verdicts (0 go on, 1 fall back, 2 error); one int32 all-reduce + a host read
+static int comm_vote(eofx_ctx* ctx, int local, int* global) {
+  *global = local;
+  if (!ctx->comm) return EOFX_OK;
+  ArenaScope scope(ctx);
+  ARENA(int, d, 4);
+  HIPCHK(hipMemcpyAsync(d, &local, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  CHK(comm_allreduce(ctx, d, 1, 2, 1));
+  HIPCHK(hipMemcpyAsync(global, d, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return EOFX_OK;
+}
+
+extern "C" int eofx_fit_sharded_f32(eofx_ctx* ctx, const float* X, int64_t n, int64_t P, int64_t P_total, int center,
+                                    int standardize, const double* feat_weights, int k, int n_oversamples, int n_iter,
+                                    const float* omega, int64_t omega_rows, int flip, eofx_mat** out, double* mean,
+                                    double* std_, uint8_t* valid_feature, double* total_variance, float* U, float* s,
+                                    float* V) {
+  if (!ctx || !X || !out || !omega || n <= 0 || P <= 0 || P_total < P || k <= 0 || n_oversamples < 0)
+    return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  if (!ctx->comm) return set_err(ctx, EOFX_ERR_ARG, "no communicator attached (eofx_ctx_comm_init_rccl / eofx_ctx_comm_set_callback)");
+  if (!(n < P_total)) return set_err(ctx, EOFX_ERR_ARG, "the sharded fit needs the sketch on the sample side (n < P_total)");
+  CHK(set_device(ctx));
+  ctx->fit_info[0] = ctx->fit_info[1] = ctx->fit_info[2] = 0.0;
+  Staged st;
+  CHK(stage_input(ctx, X, (size_t)n * P, st));
+  const int l_req = k + n_oversamples;
+  const int l = (int)std::min<int64_t>(l_req, n);
+  const int iters = n_iter < 0 ? rsvd_auto_iters(k, n, P_total) : n_iter;
+  const bool eligible = fit_first_eligible(ctx, st.dev, n, P, l) && k <= n && l == l_req && omega_rows >= n && !is_device_ptr(omega);
+  const int64_t p_pad = round_up(P, ATB_BM), n_pad = round_up(n, ATB_BM);
+  CHK(arena_reserve(ctx, rsvd_scratch_bytes(p_pad, n_pad, l, k) + FitFirst::bytes(n, P, l) + (1 << 16)));
+  ArenaScope scope(ctx);
+  FitFirst ff;
+  int rc = eligible ? ff.prepare(ctx, st.dev, n, P, center, standardize, feat_weights, l) : EOFX_FIT_FALLBACK;
+  if (!eligible) ctx->fit_info[2] = -1.0;
+  const std::string err_local = rc < 0 ? ctx->err : std::string();
+  int verdict = 0;
+  CHK(comm_vote(ctx, rc < 0 ? 2 : rc > 0 ? 1 : 0, &verdict));
+  if (verdict == 2) return rc < 0 ? (ctx->err = err_local, rc) : set_err(ctx, EOFX_ERR_HIP, "the sharded fit failed on another rank");
+  if (verdict == 1) return EOFX_FIT_FALLBACK;
+  // the first product + the statistics of the slice; then the ranks agree on whether every slice passed
+  FirstFwd first = [&](const float* Zs, float* Yt, int LL) -> int {
+    const int r1 = ff.run(Zs, Yt, LL);
+    const std::string e1 = r1 < 0 ? ctx->err : std::string();
+    int v = 0;
+    CHK(comm_vote(ctx, r1 < 0 ? 2 : r1 > 0 ? 1 : 0, &v));
+    if (v == 2) return r1 < 0 ? (ctx->err = e1, r1) : set_err(ctx, EOFX_ERR_HIP, "the sharded fit failed on another rank");
+    return v == 1 ? EOFX_FIT_FALLBACK : EOFX_OK;
+  };
+  const eofx_mat* m = ff.m;
+  LinOp op = {P, n, p_pad, n_pad,
+              // feature-side panel of this slice: local
+              [&](const float* z, float* y, int LL, int pr) { return panel_tmul(ctx, m, z, y, LL, pr); },
+              // sample-side panel: the partial sum over this slice's features, then the sum over the slices
+              [&](const float* y, float* w, int LL, int pr) {
+                CHK(panel_mul(ctx, m, y, w, LL, pr));
+                amax_forget(ctx, w);            // (the recorded maximum is that of the partial sum)
+                return comm_allreduce(ctx, w, (int64_t)n_pad * LL, 0, 0);
+              }};
+  op.reduce_tall_gram = [&](double* G, int64_t count) { return comm_allreduce(ctx, G, count, 1, 0); };
+  RsvdOut ro;
+  rc = rsvd_core(ctx, op, k, l, iters, omega, ro, &first);
+  if (rc != EOFX_OK) return rc;       // (EOFX_FIT_FALLBACK: every rank leaves here together)
+  // sign rule over all slices: one all-reduce(max) of [max | -min]
+  std::vector<double> sign(k, 1.0);
+  if (flip) {
+    ARENA(float, ext, 2 * (size_t)ro.Lo);
+    CHK(launch_colminmax(ctx, ro.Tvec, P, ro.Lo, ext, ext + ro.Lo));
+    hipLaunchKernelGGL(negate_kernel, dim3(1), dim3(256), 0, ctx->stream, ext + ro.Lo, ro.Lo);
+    KCHK();
+    CHK(comm_allreduce(ctx, ext, 2 * (int64_t)ro.Lo, 0, 1));
+    std::vector<float> h(2 * (size_t)ro.Lo);
+    HIPCHK(hipMemcpyAsync(h.data(), ext, sizeof(float) * h.size(), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (int j = 0; j < k; ++j) sign[j] = (std::fabs(h[j]) >= std::fabs(-h[ro.Lo + j])) ? 1.0 : -1.0;
+  }
+  CHK(export_panel(ctx, ro.Svec, n, ro.Lo, k, flip ? sign.data() : nullptr, U));
+  CHK(export_panel(ctx, ro.Tvec, P, ro.Lo, k, flip ? sign.data() : nullptr, V));
+  if (s) {
+    std::vector<float> hs(k);
+    for (int j = 0; j < k; ++j) hs[j] = (float)ro.s[j];
+    HIPCHK(hipMemcpy(s, hs.data(), sizeof(float) * k, hipMemcpyDefault));
+  }
+  CHK(ff.valid_features(valid_feature));
+  double tv_local = 0.0;
+  CHK(ff.finish(mean, std_, &tv_local, out));
+  adopt_staged(out, st, (size_t)n * P * sizeof(float));
+  {   // total variance = sum over the slices
+    ARENA(double, dtv, 2);
+    HIPCHK(hipMemcpyAsync(dtv, &tv_local, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    CHK(comm_allreduce(ctx, dtv, 1, 1, 0));
+    HIPCHK(hipMemcpyAsync(&tv_local, dtv, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
+  if (total_variance) *total_variance = tv_local;
+  ctx->fit_info[0] = 1.0;
   return EOFX_OK;
 }
 

@@ -956,6 +956,11 @@ __global__ __launch_bounds__(256, 2) void axb_f16_kernel(const float* __restrict
     }
 }
 
+// v <- -v (the sharded sign rule all-reduces [max | -min] with ONE max collective)
+__global__ void negate_kernel(float* __restrict__ v, int count) {
+  for (int i = threadIdx.x; i < count; i += blockDim.x) v[i] = -v[i];
+}
+
 // max |v| over a (rows x cols) block with leading dimension ld -> *out (float bits, atomicMax on the
 // unsigned view: order-independent, hence deterministic).  *out must be zeroed first.
 __global__ __launch_bounds__(256) void panel_absmax_kernel(const float* __restrict__ P, int64_t rows,

@@ -447,6 +447,104 @@ def fit(ctx: Context, X, k: int, center=True, standardize=False, feature_weights
     return mat, stats, U, s, mat.compact_rows(V)
 
 
+# ---- communicator of the native feature-sharded fit (include/eofx.h: eofx_fit_sharded_f32) -------------------------------
+def comm_unique_id() -> bytes:
+    """128 bytes from ncclGetUniqueId (rank 0 draws them and hands them to every rank)"""
+    buf = C.create_string_buffer(128)
+    raise_for(_lib.load().eofx_comm_unique_id(buf))
+    return buf.raw
+
+
+def comm_init_rccl(ctx: Context, unique_id: bytes, world: int, rank: int):
+    """attach an RCCL communicator to the context: its collectives are enqueued on the context's own stream"""
+    raise_for(ctx.lib.eofx_ctx_comm_init_rccl(ctx.handle, C.c_char_p(bytes(unique_id)), int(world), int(rank)), ctx.handle)
+    ctx._comm_cb = None
+
+
+def comm_set_callback(ctx: Context, fn, world: int, rank: int):
+    """attach a host callback as the collective: fn(ptr, count, dtype, op, stream) -> 0, all-reducing `count` elements of the
+    device buffer in place (dtype 0 f32 / 1 f64 / 2 i32, op 0 sum / 1 max / 2 min), in stream order"""
+    def tramp(_user, buf, count, dtype, op, stream):
+        try:
+            return int(fn(buf, int(count), int(dtype), int(op), stream) or 0)
+        except BaseException as e:        # must not propagate through the C frames
+            ctx._comm_err = e
+            return 1
+
+    cb = _lib.ALLREDUCE_FN(tramp)
+    raise_for(ctx.lib.eofx_ctx_comm_set_callback(ctx.handle, cb, None, int(world), int(rank)), ctx.handle)
+    ctx._comm_cb = cb      # keep the trampoline alive
+
+
+def comm_clear(ctx: Context):
+    raise_for(ctx.lib.eofx_ctx_comm_clear(ctx.handle), ctx.handle)
+    ctx._comm_cb = None
+
+
+def comm_stats(ctx: Context):
+    """-> dict(calls, bytes, ms) of the collectives of the native sharded fit since the last call (ms: while profiling)"""
+    calls, nbytes, ms = C.c_int64(), C.c_int64(), C.c_double()
+    raise_for(ctx.lib.eofx_ctx_comm_stats(ctx.handle, C.byref(calls), C.byref(nbytes), C.byref(ms)), ctx.handle)
+    return dict(calls=calls.value, bytes=nbytes.value, ms=ms.value)
+
+
+def fit_sharded(ctx: Context, X, k: int, p_total: int, center=True, standardize=False, feature_weights=None,
+                n_oversamples: int = 10, n_iter: int | str = "auto", random_state=None, flip: bool = True, omega=None,
+                want_stats=True, device_out: bool = False, allow_masked: bool = False):
+    """`fit` on this rank's slice X [n, p_local] of a field with `p_total` features, the ranks joined by the communicator
+    attached to the context (eofx_fit_sharded_f32: every collective is issued by the engine on its own stream).
+    -> (ResidentMatrix, stats, U[n, k] replicated, s[k], V[p_local, k]) or None when some rank cannot take the fused path
+    (the ranks agree on that; nothing has been built -- use the panel-level driver, xeofs_amd.sharded)."""
+    X = _f32c(X)
+    n, P = X.shape
+    k = int(k)
+    w = None if feature_weights is None else np.ascontiguousarray(feature_weights, dtype=np.float64)
+    if w is not None and w.shape != (P,):
+        raise ValueError("feature_weights must have one entry per stacked feature of the slice")
+    if omega is None:
+        omega = sketch_matrix(n, k + n_oversamples, random_state)
+    elif hasattr(omega, "result"):
+        omega = omega.result()
+    omega = np.ascontiguousarray(omega, dtype=np.float32)
+    if omega.ndim != 2 or omega.shape[1] != k + n_oversamples or omega.shape[0] < n:
+        raise ValueError(f"omega must have shape {(n, k + n_oversamples)}")
+    mean = np.empty(P, np.float64) if want_stats else None
+    std = np.empty(P, np.float64) if want_stats else None
+    vf = np.empty(P, np.uint8)
+    tv = C.c_double()
+    h = C.c_void_p()
+    if device_out:
+        torch = _torch()
+        U = torch.empty((n, k), dtype=torch.float32, device=f"cuda:{ctx.device}")
+        V = torch.empty((P, k), dtype=torch.float32, device=f"cuda:{ctx.device}")
+    else:
+        U = _host_out((n, k))
+        V = _host_out((P, k))
+    s = np.empty(k, np.float32)
+    it = -1 if n_iter == "auto" else int(n_iter)
+    ctx._comm_err = None
+    ctx.lib.eofx_ctx_set_layout(ctx.handle, _layout_mode(False, True, allow_masked))
+    try:
+        rc = ctx.lib.eofx_fit_sharded_f32(ctx.handle, ptr(X), n, P, int(p_total), int(center), int(standardize), ptr(w), k,
+                                          int(n_oversamples), it, ptr(omega), omega.shape[0], int(flip), C.byref(h),
+                                          ptr(mean), ptr(std), ptr(vf), C.byref(tv), ptr(U), ptr(s), ptr(V))
+    finally:
+        ctx.lib.eofx_ctx_set_layout(ctx.handle, 0)
+    if getattr(ctx, "_comm_err", None) is not None:
+        raise ctx._comm_err
+    if rc == 1:
+        return None
+    raise_for(rc, ctx.handle)
+    mat = ResidentMatrix(ctx, h)
+    if hasattr(X, "data_ptr"):
+        mat._keepalive = X
+    stats = dict(mean=mean, std=std, valid_feature=vf.astype(bool), valid_sample=np.ones(n, bool), n=n,
+                 p=mat.p, total_variance=tv.value, fused=True)
+    if mat.masked:
+        mat.set_valid(stats["valid_feature"])
+    return mat, stats, U, s, mat.compact_rows(V)
+
+
 def fit_first(ctx: Context, X, Zn, l: int, center=True, standardize=False, feature_weights=None, check_nans=True,
               want_stats=True):
     """The statistics-carrying first pass on its own (eofx_fit_first_f32): Yp = X'^T Zn for the device panel Zn

@@ -87,6 +87,48 @@ class Comm:
         return self._reduce(t, self.dist.ReduceOp.MIN)
 
 
+class _DeviceView:
+    """a raw device pointer as something torch.as_tensor accepts (zero copy)"""
+
+    def __init__(self, ptr, count, typestr):
+        self.__cuda_array_interface__ = {"data": (int(ptr), False), "shape": (int(count),), "typestr": typestr, "version": 2}
+
+
+def attach_native(ctx, comm: Comm) -> bool:
+    """Give the engine context its own communicator over the ranks of `comm`, so that `engine.fit_sharded`
+    (eofx_fit_sharded_f32) issues every collective itself, on its own stream, between its kernels.
+    nccl backend: an RCCL communicator of the engine's own -- rank 0 draws the unique id, torch.distributed carries the 128
+    bytes (the one thing it is used for), every rank calls ncclCommInitRank.  Other backends (gloo: CPU tests, two processes
+    on one GPU): a host callback that synchronises, reduces a host copy through torch.distributed and copies back.
+    -> whether a communicator was attached (False without an initialised process group)."""
+    import torch
+    from . import engine
+
+    dist = comm.dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    world, rank = comm.world, comm.rank
+    if dist.get_backend(comm.group) == "nccl":
+        box = [engine.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=comm.group)
+        engine.comm_init_rccl(ctx, box[0], world, rank)
+        return True
+    ops = {0: dist.ReduceOp.SUM, 1: dist.ReduceOp.MAX, 2: dist.ReduceOp.MIN}
+    types = {0: "<f4", 1: "<f8", 2: "<i4"}
+
+    def allreduce(buf, count, dtype, op, _stream):
+        torch.cuda.synchronize()
+        t = torch.as_tensor(_DeviceView(buf, count, types[dtype]), device=f"cuda:{ctx.device}")
+        h = t.cpu()
+        dist.all_reduce(h, op=ops[op], group=comm.group)
+        t.copy_(h)
+        torch.cuda.synchronize()
+        return 0
+
+    engine.comm_set_callback(ctx, allreduce, world, rank)
+    return True
+
+
 class HipPanelOps:
     """Panel steps on this rank's ResidentMatrix through the C ABI (include/eofx.h)."""
 
