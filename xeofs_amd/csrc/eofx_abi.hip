@@ -2923,7 +2923,7 @@ static int mat_gram_fast(eofx_ctx* ctx, const eofx_mat* m, float* G) {
   ARENA(float, part, (size_t)g->pl.T * g->pl.S * GR_BM * GR_BM);
   float sc = 1.f;
   CHK(mat_planes(ctx, m, planes, kpad, &sc));
-  hipLaunchKernelGGL(gram_nt_kernel<2>, dim3(g->pl.grid), dim3(512), 0, ctx->stream, (const _Float16*)planes, (const _Float16*)planes,
+  hipLaunchKernelGGL(gram_nt_kernel, dim3(g->pl.grid), dim3(512), 0, ctx->stream, (const _Float16*)planes, (const _Float16*)planes,
                      kpad * 4, (const GramItem*)g->items, part, 1.f / (sc * sc));
   KCHK();
   hipLaunchKernelGGL(gram_finish_kernel, dim3(g->pl.T, 16), dim3(256), 0, ctx->stream, (const float*)part, (const int2*)g->tiles, g->pl.S, G,

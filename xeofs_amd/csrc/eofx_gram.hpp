@@ -14,7 +14,8 @@
 //                         LDS-DMA (global_load_lds_dwordx4, no VGPRs, no VALU) of 8 rows x 128 B per instruction into a
 //                         lane-linear image whose 16-byte chunks are XOR-swizzled on the SOURCE side, conflict-free
 //                         ds_read_b128 fragments for v_mfma_f32_32x32x16_f16, two 64 KiB stages, one barrier per stage
-//                         (= 48 MFMAs per wave: the three products triple the matrix work per staged byte).
+//                         (= 48 MFMAs per wave: the three products triple the matrix work per staged byte), fragment
+//                         reads a quarter-stage ahead of their MFMAs with hand-counted waits.
 //                         Work items = (tile, K split) dealt so that each XCD owns a compact patch of the tile triangle
 //                         and walks the splits in order: a row block's lines are fetched once per XCD and shared in L2.
 //   gram_finish_kernel    fixed-order sum of the split partials, mirrored into the full symmetric matrix.
@@ -106,7 +107,6 @@ struct GramItem {
 // C_slot[256 x 256] = A_tile (256 rows of PA from row 256 bi) . B_tile^T (256 rows of PB from row 256 bj) over the item's
 // stages.  pitch: bytes per row of the planes (= 4 kpad).  Cp: [slots][256][256] float32.
 // out_scale: exact inverse of the two operands' power-of-two scales.
-template <int VAR>
 __global__ __launch_bounds__(512, 2) void gram_nt_kernel(const _Float16* __restrict__ PA, const _Float16* __restrict__ PB,
                                                           int64_t pitch, const GramItem* __restrict__ items,
                                                           float* __restrict__ Cp, float out_scale) {
@@ -158,130 +158,14 @@ __global__ __launch_bounds__(512, 2) void gram_nt_kernel(const _Float16* __restr
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[rt][ct][r] = 0.f;
 
-#define GR_COMPUTE(buf)                                                                                           \
-  do {                                                                                                            \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                            \
-      f16x8 af_[4][2], bf_[2][2];                                                                                 \
-      _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) {                                                          \
-        _Pragma("unroll") for (int ct = 0; ct < 2; ++ct) bf_[ct][pl] = *reinterpret_cast<const f16x8*>(           \
-            lds + (buf) * GR_STAGE_BYTES + ct * 4096 + (b_lane ^ (64 * pl + 32 * ks)));                           \
-        _Pragma("unroll") for (int rt = 0; rt < 4; ++rt) af_[rt][pl] = *reinterpret_cast<const f16x8*>(           \
-            lds + (buf) * GR_STAGE_BYTES + rt * 4096 + (a_lane ^ (64 * pl + 32 * ks)));                           \
-      }                                                                                                           \
-      _Pragma("unroll") for (int rt = 0; rt < 4; ++rt) _Pragma("unroll") for (int ct = 0; ct < 2; ++ct)           \
-          acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af_[rt][1], bf_[ct][0], acc[rt][ct], 0, 0, 0);     \
-      _Pragma("unroll") for (int rt = 0; rt < 4; ++rt) _Pragma("unroll") for (int ct = 0; ct < 2; ++ct)           \
-          acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af_[rt][0], bf_[ct][1], acc[rt][ct], 0, 0, 0);     \
-      _Pragma("unroll") for (int rt = 0; rt < 4; ++rt) _Pragma("unroll") for (int ct = 0; ct < 2; ++ct)           \
-          acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af_[rt][0], bf_[ct][0], acc[rt][ct], 0, 0, 0);     \
-    }                                                                                                             \
-  } while (0)
-#define GR_SYNC()                                  \
-  do {                                             \
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
-    __syncthreads();                               \
-  } while (0)
-
-  // fragment sets: F0 = k-step 0 of a stage, F1 = k-step 1.  VAR 1: each set is read one half-stage AHEAD of its MFMAs
-  // (F1 of stage t under the MFMAs of F0, F0 of stage t + 1 -- the other buffer, right after the barrier -- under the
-  // MFMAs of F1), so the matrix pipe never waits for an LDS read it has just issued.
-#define GR_READ(F, buf, ks)                                                                                       \
-  do {                                                                                                            \
-    _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) {                                                            \
-      _Pragma("unroll") for (int ct = 0; ct < 2; ++ct) F##b[ct][pl] = *reinterpret_cast<const f16x8*>(            \
-          lds + (buf) * GR_STAGE_BYTES + ct * 4096 + (b_lane ^ (64 * pl + 32 * (ks))));                           \
-      _Pragma("unroll") for (int rt = 0; rt < 4; ++rt) F##a[rt][pl] = *reinterpret_cast<const f16x8*>(            \
-          lds + (buf) * GR_STAGE_BYTES + rt * 4096 + (a_lane ^ (64 * pl + 32 * (ks))));                           \
-    }                                                                                                             \
-  } while (0)
-#define GR_MFMA(F)                                                                                                \
-  do {                                                                                                            \
-    _Pragma("unroll") for (int rt = 0; rt < 4; ++rt) _Pragma("unroll") for (int ct = 0; ct < 2; ++ct)             \
-        acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F##a[rt][1], F##b[ct][0], acc[rt][ct], 0, 0, 0);     \
-    _Pragma("unroll") for (int rt = 0; rt < 4; ++rt) _Pragma("unroll") for (int ct = 0; ct < 2; ++ct)             \
-        acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F##a[rt][0], F##b[ct][1], acc[rt][ct], 0, 0, 0);     \
-    _Pragma("unroll") for (int rt = 0; rt < 4; ++rt) _Pragma("unroll") for (int ct = 0; ct < 2; ++ct)             \
-        acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F##a[rt][0], F##b[ct][0], acc[rt][ct], 0, 0, 0);     \
-  } while (0)
-  if constexpr (VAR == 0) {
-    GR_ISSUE(0, 0);
-    GR_SYNC();
-    int t = 0;
-    for (; t + 2 <= nst; t += 2) {
-      GR_ISSUE(t + 1, 1);
-      GR_COMPUTE(0);
-      GR_SYNC();
-      if (t + 2 < nst) GR_ISSUE(t + 2, 0);
-      GR_COMPUTE(1);
-      GR_SYNC();
-    }
-    if (t < nst) GR_COMPUTE(0);
-  } else if constexpr (VAR == 1) {
-    // VAR 1: every fragment set is read one quarter-stage AHEAD of its 12 MFMAs (a quarter = one k-step x two of the four
-    // row tiles), the first quarter of the next stage right after the barrier, under the last quarter's MFMAs: the matrix
-    // pipe never waits for an LDS read it has just issued.  A sets: 2 x 16 registers, B sets: 2 x 16.
-    f16x8 Aa[2][2], Ab[2][2], Ba[2][2], Bb[2][2];
-#define GR_RA(D, buf, ks, half)                                                                                   \
-  _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) _Pragma("unroll") for (int r = 0; r < 2; ++r)                  \
-      D[r][pl] = *reinterpret_cast<const f16x8*>(lds + (buf) * GR_STAGE_BYTES + (2 * (half) + r) * 4096 +         \
-                                                 (a_lane ^ (64 * pl + 32 * (ks))))
-#define GR_RB(D, buf, ks)                                                                                         \
-  _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) _Pragma("unroll") for (int ct = 0; ct < 2; ++ct)               \
-      D[ct][pl] = *reinterpret_cast<const f16x8*>(lds + (buf) * GR_STAGE_BYTES + ct * 4096 +                      \
-                                                  (b_lane ^ (64 * pl + 32 * (ks))))
-#define GR_MM(A_, B_, half)                                                                                       \
-  do {                                                                                                            \
-    _Pragma("unroll") for (int r = 0; r < 2; ++r) _Pragma("unroll") for (int ct = 0; ct < 2; ++ct)                \
-        acc[2 * (half) + r][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_[r][1], B_[ct][0], acc[2 * (half) + r][ct], 0, 0, 0); \
-    _Pragma("unroll") for (int r = 0; r < 2; ++r) _Pragma("unroll") for (int ct = 0; ct < 2; ++ct)                \
-        acc[2 * (half) + r][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_[r][0], B_[ct][1], acc[2 * (half) + r][ct], 0, 0, 0); \
-    _Pragma("unroll") for (int r = 0; r < 2; ++r) _Pragma("unroll") for (int ct = 0; ct < 2; ++ct)                \
-        acc[2 * (half) + r][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_[r][0], B_[ct][0], acc[2 * (half) + r][ct], 0, 0, 0); \
-  } while (0)
-#define GR_FENCE() __builtin_amdgcn_sched_barrier(0)
-#define GR_STAGE(buf, tnext)                                         \
-  do {                                                               \
-    GR_ISSUE(tnext, 1 - (buf));                                      \
-    GR_RA(Ab, buf, 0, 1);                                            \
-    GR_FENCE();                                                      \
-    GR_MM(Aa, Ba, 0);                                                \
-    GR_FENCE();                                                      \
-    GR_RA(Aa, buf, 1, 0);                                            \
-    GR_RB(Bb, buf, 1);                                               \
-    GR_FENCE();                                                      \
-    GR_MM(Ab, Ba, 1);                                                \
-    GR_FENCE();                                                      \
-    GR_RA(Ab, buf, 1, 1);                                            \
-    GR_FENCE();                                                      \
-    GR_MM(Aa, Bb, 0);                                                \
-    GR_FENCE();                                                      \
-    GR_SYNC();                                                       \
-    GR_RA(Aa, 1 - (buf), 0, 0);                                      \
-    GR_RB(Ba, 1 - (buf), 0);                                         \
-    GR_FENCE();                                                      \
-    GR_MM(Ab, Bb, 1);                                                \
-    GR_FENCE();                                                      \
-  } while (0)
-    GR_ISSUE(0, 0);
-    GR_SYNC();
-    GR_RA(Aa, 0, 0, 0);
-    GR_RB(Ba, 0, 0);
-    // nst is even (the plan's splits are); past the end the prefetch re-reads the last stage (harmless), so the body has
-    // no data-dependent control flow
-    for (int t = 0; t < nst; t += 2) {
-      GR_STAGE(0, t + 1);
-      GR_STAGE(1, (t + 2 < nst ? t + 2 : nst - 1));
-    }
-#undef GR_STAGE
-#undef GR_RA
-#undef GR_RB
-#undef GR_MM
-#undef GR_FENCE
-  }
-  if constexpr (VAR == 2) {
-    // VAR 2: the schedule of VAR 1 with the fragment reads and their waits written by hand.  hipcc waits lgkmcnt(0) in
-    // front of every MFMA group -- it loses count of the reads across the loop edge -- and so waits for the reads it has
-    // JUST issued; here the wait in front of a group leaves exactly the younger reads in flight (LDS returns in order).
+  {
+    // Every fragment set is read one quarter-stage AHEAD of its 12 MFMAs (a quarter = one k-step x two of the four row
+    // tiles), the first quarter of the next stage right after the barrier, under the last quarter's MFMAs.  The reads and
+    // their waits are written by hand: hipcc waits lgkmcnt(0) in front of every MFMA group -- it loses count of the reads
+    // across the loop edge -- and so waits for the reads it has JUST issued; here the wait in front of a group leaves exactly
+    // the younger reads in flight (LDS returns in order).  [Measured, config-3 Gram, same box: compiler-scheduled reads
+    // 8.87 ms, quarter-stage prefetch with the compiler's waits 8.49 ms, this 8.15 ms; s_setprio around the MFMA groups: no
+    // difference -- profiles/r04_gram_probe.txt.]
     f16x8 Aa[2][2], Ab[2][2], Ba[2][2], Bb[2][2];
     int ax[2][2], bx[2][2];     // [plane][k-step] byte addresses of this lane's fragments in buffer 0
 #pragma unroll
@@ -363,11 +247,7 @@ __global__ __launch_bounds__(512, 2) void gram_nt_kernel(const _Float16* __restr
 #undef GR_FENCE
 #undef GR_LGKM
   }
-#undef GR_READ
-#undef GR_MFMA
 #undef GR_ISSUE
-#undef GR_COMPUTE
-#undef GR_SYNC
 
   // D of the 32x32 MFMA: column = lane % 32, row = (r % 4) + 8 (r / 4) + 4 (lane / 32)
   float* out = Cp + (int64_t)it.slot * (GR_BM * GR_BM);
