@@ -14,6 +14,6 @@ X = F[:, :, :360].reshape(n, -1).contiguous(); Y = F[:, :, 360:].reshape(n, -1).
 for rep in range(5):
     om = engine.SketchFuture(X.shape[1], k + 10, 5)
     mx, _ = engine.preprocess(ctx, X, want_stats=False, in_place=INPLACE); my, _ = engine.preprocess(ctx, Y, want_stats=False, in_place=INPLACE)
-    out = engine.crosscov_rsvd(ctx, mx, my, k, random_state=5, want_tsc=TSC, omega=om.result())
+    out = engine.crosscov_rsvd(ctx, mx, my, k, random_state=5, want_tsc=TSC, omega=om)
     mx.free(); my.free()
 torch.cuda.synchronize()
