@@ -71,3 +71,32 @@ def test_crosscov_gram_route_equals_matrix_free(ctx, monkeypatch):
     assert np.allclose(a["s"], b["s"], rtol=2e-6)
     assert np.allclose(a["scores1"], b["scores1"], atol=2e-5 * np.abs(b["scores1"]).max())
     assert np.isclose(a["total_squared_covariance"], b["total_squared_covariance"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("n,P,L,layout", [(700, 3000, 512, "inplace"), (1100, 2500, 672, "copy"), (600, 2050, 1024, "masked")])
+def test_wide_feature_side_product_through_the_nt_kernel(ctx, n, P, L, layout, monkeypatch):
+    """eofx_panel_tmul_f32 with 512 columns and more goes through transposed fp16 planes + gram_nt_kernel (the PCA
+    pre-reduction's wide panel): against float64 numpy on the oracle's preprocessed matrix, and against the streaming
+    kernel's result for the same call (EOFX_NO_TMUL_NT=1)."""
+    import torch
+    from xeofs_amd import engine
+
+    X, _ = orc.synthetic_field(n, 1, P, rank=10, seed=P)
+    if layout == "masked":
+        X[:, np.random.default_rng(1).choice(P, P // 6, replace=False)] = np.nan
+    mat, st = engine.preprocess(ctx, X, True, True, None, in_place=layout != "copy", allow_masked=layout == "masked")
+    ref = orc.preprocess(X.astype(np.float64), True, True, None)["X"]
+    rng = np.random.default_rng(2)
+    Z = np.zeros((mat.n_pad, L), np.float32)
+    Z[:n] = rng.standard_normal((n, L)) * (1.0 + rng.random(L))
+    Zd = torch.as_tensor(Z, device="cuda")
+    Y = engine.panel_tmul(ctx, mat, Zd, prec="f16x3")
+    Yh = mat.compact_rows(Y[:mat.p_phys].cpu().numpy()).astype(np.float64)
+    want = ref.T @ Z[:n].astype(np.float64)
+    scale = np.sqrt((ref ** 2).sum(0))[:, None] * np.sqrt((Z[:n].astype(np.float64) ** 2).sum(0))[None, :]
+    assert np.max(np.abs(Yh - want) / scale) <= 3e-6
+    assert not Y[mat.p_phys:].any()
+    monkeypatch.setenv("EOFX_NO_TMUL_NT", "1")
+    Y2 = engine.panel_tmul(ctx, mat, Zd, prec="f16x3")
+    assert np.max(np.abs((Y - Y2).cpu().numpy()[:mat.p_phys]) / np.maximum(scale.max(), 1e-30)) <= 3e-6
+    mat.free()

@@ -34,6 +34,13 @@ for rep in range(2):
     sync(); print(f"  TOTAL default-args MCA fit: {1e3 * (time.perf_counter() - t00):.1f} ms; s[:3]={out['s'][:3]}", flush=True)
     # the two dominant steps inside ResidentPCA.fit, timed on their own (NOT part of the total above)
     G = T("[inside PCA.fit] gram X X^T (5120^2, f16x3)", lambda: mx.gram(0))
+    if getattr(p1, "solver_used", "") == "randomized":
+        pr = ResidentPCA(ctx, 0.999)
+        Qr, GQ, Gm = T("[inside PCA.fit] randomized range finder on G: 5 x (G Q, Gram, blocked Cholesky-QR) + G Q", lambda: pr._range_randomized(G, n, 1510))
+        Bw = T("[inside PCA.fit] B = X^T Q (129600 x 1536, NT kernel over transposed planes)", lambda: engine.panel_tmul(ctx, mx, Qr, prec="f16x3"))
+        Mw = T("[inside PCA.fit] Gram of B (fp64 MFMA)", lambda: engine.panel_gram(ctx, Bw))
+        T("[inside PCA.fit] eigh of order 1510 (rocSOLVER: the one library call)", lambda: torch.linalg.eigh(Mw[:1510, :1510]))
+        Gm.free(); del Qr, GQ, Bw, Mw
     lam = T("[inside PCA.fit] eigh n x n fp64 (rocSOLVER)", lambda: torch.linalg.eigh(G[:n, :n].double()))
     del G, lam
     ref = engine.crosscov_rsvd(ctx, mx, my, k, random_state=5)

@@ -894,7 +894,6 @@ static int launch_gram(eofx_ctx* ctx, const float* P, int64_t rows, int L, doubl
   KCHK();
   return EOFX_OK;
 }
-
 static int launch_matmul(eofx_ctx* ctx, const float* P, int64_t rows, int L, const double* Mx, int Lo,
                          float* out) {
   const int KW = (int)std::min<int64_t>(round_up(L, 64), 256);      // rows of Mx held in LDS at a time
@@ -952,6 +951,7 @@ static void host_chol_rinv(const double* G, int L, int l, double* Rinv, double t
 
 // out = P R^-1 with G = R^T R (leading l x l block)
 static int launch_rinv(eofx_ctx* ctx, const double* G, int L, int l, double* Rinv);
+static size_t rinv_blocked_bytes(int l);
 static int launch_cholqr(eofx_ctx* ctx, const float* P, int64_t rows, int L, int l, const double* G,
                          float* out) {
   ArenaScope scope(ctx);
@@ -1677,7 +1677,13 @@ extern "C" int eofx_resample_f32(eofx_ctx* ctx, const eofx_mat* src, const int64
 // ------------------------------------------------------------------------------------
 // panel-level ABI
 // ------------------------------------------------------------------------------------
+static bool tmul_nt_ok(const eofx_mat* m, int L);
+static size_t tmul_nt_scratch(const eofx_mat* m, int L);
+static int mat_tmul_nt(eofx_ctx* ctx, const eofx_mat* m, const float* Zn, float* Yp, int L);
 static int panel_tmul(eofx_ctx* ctx, const eofx_mat* m, const float* Zn, float* Yp, int L, int prec) {
+  // panels of 512 columns and more (PCA pre-reduction): the MFMA-bound NT kernel over transposed fp16 planes (eofx_gram.hpp)
+  if (prec == EOFX_PREC_F16X3 && tmul_nt_ok(m, L) && ctx->arena_size - ctx->arena_off >= tmul_nt_scratch(m, L))
+    return mat_tmul_nt(ctx, m, Zn, Yp, L);
   if (!m->X && m->raw && prec == EOFX_PREC_F16X3) {   // raw mode: stream the raw field through the affine map
     AffView av;
     av.aff = m->aff;
@@ -1755,7 +1761,9 @@ extern "C" int eofx_panel_tmul_f32(eofx_ctx* ctx, const eofx_mat* m, const float
                                    int prec) {
   if (!ctx || !m || !Zn || !Yp || !valid_prec(prec)) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
   CHK(set_device(ctx));
-  CHK(arena_reserve(ctx, atb_scratch_bytes(m->p_pad, round_up(m->n, ATB_KG), L)));
+  size_t need = atb_scratch_bytes(m->p_pad, round_up(m->n, ATB_KG), L);
+  if (prec == EOFX_PREC_F16X3 && tmul_nt_ok(m, L)) need = std::max(need, tmul_nt_scratch(m, L));
+  CHK(arena_reserve(ctx, need));
   return panel_tmul(ctx, m, Zn, Yp, L, prec);
 }
 extern "C" int eofx_panel_mul_f32(eofx_ctx* ctx, const eofx_mat* m, const float* Yp, float* Wn, int L,
@@ -1775,12 +1783,13 @@ extern "C" int eofx_panel_cholqr_f32(eofx_ctx* ctx, const float* P, int64_t rows
                                      const double* G, float* out) {
   if (!ctx || !P || !G || !out || P == out) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
   CHK(set_device(ctx));
-  CHK(arena_reserve(ctx, (size_t)2 * L * L * sizeof(double)));
+  CHK(arena_reserve(ctx, (size_t)2 * L * L * sizeof(double) + (l > 64 ? rinv_blocked_bytes(l) : 0)));
   return launch_cholqr(ctx, P, rows_pad, L, l, G, out);
 }
 extern "C" int eofx_panel_rinv_f64(eofx_ctx* ctx, const double* G, int L, int l, double* Rinv) {
   if (!ctx || !G || !Rinv || L <= 0 || l <= 0 || l > L || G == Rinv) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
   CHK(set_device(ctx));
+  if (l > 64) CHK(arena_reserve(ctx, rinv_blocked_bytes(l)));
   return launch_rinv(ctx, G, L, l, Rinv);
 }
 extern "C" int eofx_panel_matmul_f32(eofx_ctx* ctx, const float* P, int64_t rows_pad, int L,
@@ -1872,10 +1881,62 @@ extern "C" int eofx_peaked_spectrum(const double* G, int ld, int l) {
 
 // R^-1 (device, L x L float64, leading l x l block) of the Cholesky factor of G: the device kernel up to one
 // wavefront's 64 columns, the host beyond
+// Blocked right-looking Cholesky factorisation + triangular inverse on the device for sketches wider than one wavefront
+// (the PCA pre-reduction's int(0.3 rank) + 10 columns: l = 1510): 64-column blocks, the diagonal blocks through
+// chol_rinv_kernel (same pivots, same dependency rule against the ORIGINAL diagonal), row panels / trailing updates /
+// the inverse's block columns through dgemm64_kernel.  ~5 launches per block, everything in float64, fixed order.
+// Arena: 2 Lb^2 + Lb 64 + Lb doubles.
+static size_t rinv_blocked_bytes(int l) {
+  const size_t Lb = (size_t)round_up(l, 64);
+  return (2 * Lb * Lb + Lb * 64 + Lb) * sizeof(double) + 4096;
+}
+static int launch_rinv_blocked(eofx_ctx* ctx, const double* G, int L, int l, double* Rinv) {
+  const int Lb = (int)round_up(l, 64), nb = Lb / 64;
+  ArenaScope scope(ctx);
+  ARENA(double, S, (size_t)Lb * Lb);      // the matrix; R's off-diagonal blocks end up in its upper triangle
+  ARENA(double, X, (size_t)Lb * Lb);      // R^-1
+  ARENA(double, T, (size_t)Lb * 64);
+  ARENA(double, d0, Lb);
+  hipLaunchKernelGGL(chol_blocked_init_kernel, dim3(512), dim3(256), 0, ctx->stream, G, L, l, S, Lb, d0);
+  KCHK();
+  HIPCHK(hipMemsetAsync(X, 0, sizeof(double) * (size_t)Lb * Lb, ctx->stream));
+  for (int j = 0; j < nb; ++j) {
+    const int64_t dj = (int64_t)64 * j * Lb + 64 * j;      // the diagonal block
+    const int lj = std::min(64, l - 64 * j);
+    hipLaunchKernelGGL(chol_rinv_kernel, dim3(1), dim3(256), 0, ctx->stream, (const double*)(S + dj), Lb, lj, X + dj, 1e-13,
+                       (const double*)(d0 + 64 * j));
+    KCHK();
+    const int rest = nb - 1 - j;
+    if (rest > 0) {
+      double* row = S + dj + 64;                            // S[j, j+1 ..] -> R[j, j+1 ..] = X_jj^T S[j, j+1 ..]
+      hipLaunchKernelGGL(dgemm64_kernel<true>, dim3(rest, 1), dim3(256), 0, ctx->stream, (const double*)(X + dj), Lb,
+                         (const double*)row, Lb, row, Lb, 64, 1.0, 0.0, 0);
+      KCHK();
+      double* trail = S + dj + (int64_t)64 * Lb + 64;       // S[j+1 .., j+1 ..] -= R[j, j+1 ..]^T R[j, j+1 ..]  (upper tiles)
+      hipLaunchKernelGGL(dgemm64_kernel<true>, dim3(rest, rest), dim3(256), 0, ctx->stream, (const double*)row, Lb,
+                         (const double*)row, Lb, trail, Lb, 64, -1.0, 1.0, 1);
+      KCHK();
+    }
+  }
+  // R^-1 block column by block column: X[0:j, j] = -X[0:j, 0:j] (R[0:j, j] X_jj)
+  for (int j = 1; j < nb; ++j) {
+    hipLaunchKernelGGL(dgemm64_kernel<false>, dim3(1, j), dim3(256), 0, ctx->stream, (const double*)(S + 64 * j), Lb,
+                       (const double*)(X + (int64_t)64 * j * Lb + 64 * j), Lb, T, 64, 64, 1.0, 0.0, 0);
+    KCHK();
+    hipLaunchKernelGGL(dgemm64_kernel<false>, dim3(1, j), dim3(256), 0, ctx->stream, (const double*)X, Lb, (const double*)T, 64,
+                       X + 64 * j, Lb, 64 * j, -1.0, 0.0, 0);
+    KCHK();
+  }
+  hipLaunchKernelGGL(chol_blocked_export_kernel, dim3(512), dim3(256), 0, ctx->stream, (const double*)X, Lb, l, Rinv, L);
+  KCHK();
+  return EOFX_OK;
+}
 static int launch_rinv(eofx_ctx* ctx, const double* G, int L, int l, double* Rinv) {
   if (l <= 64) {
-    hipLaunchKernelGGL(chol_rinv_kernel, dim3(1), dim3(256), 0, ctx->stream, G, L, l, Rinv, 1e-13);
+    hipLaunchKernelGGL(chol_rinv_kernel, dim3(1), dim3(256), 0, ctx->stream, G, L, l, Rinv, 1e-13, (const double*)nullptr);
     KCHK();
+  } else if (ctx->arena_size - ctx->arena_off >= rinv_blocked_bytes(l) && !std::getenv("EOFX_HOST_RINV")) {
+    CHK(launch_rinv_blocked(ctx, G, L, l, Rinv));
   } else {
     std::vector<double> hG((size_t)L * L), hR((size_t)L * L);
     HIPCHK(hipMemcpyAsync(hG.data(), G, sizeof(double) * L * L, hipMemcpyDeviceToHost, ctx->stream));
@@ -2045,6 +2106,7 @@ static size_t rsvd_scratch_bytes(int64_t tall_pad, int64_t small_pad, int l, int
   b += atb_scratch_bytes(small_pad, tall_pad, (int)Lo);
   b += (size_t)(4 * gram_parts(std::max(tall_pad, small_pad), (int)L) + 8) * L * L * 8 + 2 * L * Lo * 8 + 4096;  // gram partials, Rinv, G0, R2, M1, M2
   b += (size_t)std::max(tall_pad, small_pad) * (Lo + L) * 4;  // export / import staging
+  if (l > 64) b += rinv_blocked_bytes(l);                     // blocked device Cholesky of a wide sketch
   b += 4 << 20;
   return b;
 }
@@ -2929,6 +2991,76 @@ static int mat_gram_fast(eofx_ctx* ctx, const eofx_mat* m, float* G) {
   hipLaunchKernelGGL(gram_finish_kernel, dim3(g->pl.T, 16), dim3(256), 0, ctx->stream, (const float*)part, (const int2*)g->tiles, g->pl.S, G,
                      m->n_pad);
   KCHK();
+  return EOFX_OK;
+}
+
+// ---- wide feature-side products Yp [p_pad x L] = X'^T Zn through the same NT kernel (L in the hundreds: the PCA
+// pre-reduction's 1500-column panel took 83 ms through the 128-column streaming tiles, the field re-read 12 times at a third of
+// the matrix cores' rate; here: transposed planes of the field once, planes of Zn^T, one MFMA-bound product)
+static bool tmul_nt_ok(const eofx_mat* m, int L) {
+  const int64_t kpad = round_up(m->n, 2 * GR_BK);
+  return L >= 512 && m->p_pad % GR_BM == 0 && (m->X || (m->raw && m->aff)) && kpad * 4 * GR_BM < ((int64_t)1 << 32) &&
+         m->n >= 512 && !std::getenv("EOFX_NO_TMUL_NT");
+}
+static size_t tmul_nt_scratch(const eofx_mat* m, int L) {
+  const int64_t kpad = round_up(m->n, 2 * GR_BK), Lp = round_up(L, GR_BM);
+  return (size_t)(m->p_pad + Lp) * kpad * 4 + (size_t)m->p_pad * Lp * 4 + (1 << 16);
+}
+static int mat_tmul_nt(eofx_ctx* ctx, const eofx_mat* m, const float* Zn, float* Yp, int L) {
+  const int64_t kpad = round_up(m->n, 2 * GR_BK), Lp = round_up(L, GR_BM);
+  const int nti = (int)(m->p_pad / GR_BM), ntj = (int)(Lp / GR_BM);
+  const eofx_ctx::GramPlanDev* g = nullptr;
+  CHK(gram_plan_get(ctx, nti, ntj, false, (int)(kpad / GR_BK), &g));
+  ArenaScope scope(ctx);
+  ARENA(_Float16, pa, (size_t)m->p_pad * kpad * 2);
+  ARENA(_Float16, pb, (size_t)Lp * kpad * 2);
+  ARENA(float, part, (size_t)g->pl.T * g->pl.S * GR_BM * GR_BM);
+  ARENA(unsigned, zmax, 4);
+  float sa = 1.f;
+  if (m->absmax > 0.f && std::isfinite(m->absmax)) {
+    int e;
+    (void)std::frexp(m->absmax, &e);
+    sa = std::ldexp(1.f, 14 - e);
+  }
+  // max |Zn| for its power-of-two scale (one small read + a host word)
+  const float* zm = amax_get(ctx, Zn);
+  if (!zm) {
+    HIPCHK(hipMemsetAsync(zmax, 0, sizeof(unsigned), ctx->stream));
+    const int64_t total4 = m->n_pad * (int64_t)(L / 4);
+    hipLaunchKernelGGL(panel_absmax_kernel, dim3((int)std::max<int64_t>(1, std::min<int64_t>((total4 + 1023) / 1024, 1024))), dim3(256), 0,
+                       ctx->stream, Zn, m->n_pad, L, (int64_t)L, zmax);
+    KCHK();
+    zm = reinterpret_cast<const float*>(zmax);
+  }
+  float hz = 0.f;
+  HIPCHK(hipMemcpyAsync(&hz, zm, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  float sb = 1.f;
+  if (hz > 0.f && std::isfinite(hz)) {
+    int e;
+    (void)std::frexp(hz, &e);
+    sb = std::ldexp(1.f, 14 - e);
+  }
+  const dim3 ga((unsigned)(m->p_pad / 64), (unsigned)(kpad / 64)), gb((unsigned)(Lp / 64), (unsigned)(kpad / 64));
+  if (!m->X && m->raw && m->aff) {
+    hipLaunchKernelGGL(planes_split_t_kernel, ga, dim3(256), 0, ctx->stream, m->raw, m->raw_ld, m->n, m->p, (const float*)m->aff, m->p_pad,
+                       sa, pa, kpad);
+  } else {
+    CHK(ensure_X(ctx, m));
+    hipLaunchKernelGGL(planes_split_t_kernel, ga, dim3(256), 0, ctx->stream, (const float*)m->X, m->p_pad, m->n, m->p, (const float*)nullptr,
+                       (int64_t)0, sa, pa, kpad);
+  }
+  KCHK();
+  hipLaunchKernelGGL(planes_split_t_kernel, gb, dim3(256), 0, ctx->stream, Zn, (int64_t)L, m->n, (int64_t)L, (const float*)nullptr, (int64_t)0,
+                     sb, pb, kpad);
+  KCHK();
+  hipLaunchKernelGGL(gram_nt_kernel, dim3(g->pl.grid), dim3(512), 0, ctx->stream, (const _Float16*)pa, (const _Float16*)pb, kpad * 4,
+                     (const GramItem*)g->items, part, 1.f / (sa * sb));
+  KCHK();
+  hipLaunchKernelGGL(nt_finish_kernel, dim3(g->pl.T, 16), dim3(256), 0, ctx->stream, (const float*)part, (const int2*)g->tiles, g->pl.S, Yp,
+                     (int64_t)L, m->p_pad, L);
+  KCHK();
+  amax_forget(ctx, Yp);
   return EOFX_OK;
 }
 

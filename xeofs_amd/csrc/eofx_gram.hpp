@@ -95,6 +95,66 @@ __global__ __launch_bounds__(256) void planes_split_kernel(const float* __restri
   }
 }
 
+// Planes of the TRANSPOSED matrix: row f of the planes = feature (column) f of src, the K axis = the rows of src (samples).
+// For the wide products X'^T Z (hundreds of columns: the PCA pre-reduction's p x 1500 panel) through gram_nt_kernel, whose
+// operands are both K-contiguous.  src [rows x cols] (ld) through the map as above (aff may be null); planes
+// [cols_pad][kpad / 32][2][32], cols_pad % 64 == 0, kpad = round_up(rows, 64).  grid = (cols_pad / 64, kpad / 64): a workgroup
+// reads a 64 x 64 tile with 256-byte row segments, turns it in LDS and writes 32-byte pieces of the features' lines.
+__global__ __launch_bounds__(256) void planes_split_t_kernel(const float* __restrict__ src, int64_t ld, int64_t rows,
+                                                              int64_t cols, const float* __restrict__ aff, int64_t aff_ld,
+                                                              float a_scale, _Float16* __restrict__ planes, int64_t kpad) {
+  __shared__ float tile[64][65];      // [sample][feature]
+  const int64_t f0 = (int64_t)blockIdx.x * 64, s0 = (int64_t)blockIdx.y * 64;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int64_t f = f0 + 4 * tx;
+  float sh[4], sc[4], nls[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const bool in = f + e < cols;
+    sh[e] = (in && aff) ? aff[f + e] : 0.f;
+    sc[e] = in ? (aff ? aff[2 * aff_ld + f + e] * a_scale : a_scale) : 0.f;
+    nls[e] = (in && aff) ? -(aff[aff_ld + f + e] * sc[e]) : 0.f;
+  }
+  const bool vec = f + 4 <= cols && (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0;
+#pragma unroll
+  for (int sweep = 0; sweep < 4; ++sweep) {
+    const int64_t r = s0 + ty + 16 * sweep;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (r < rows) {
+      const float* p = src + r * ld + f;
+      if (vec) {
+        const f32x4 x = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+        v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = f + e < cols ? p[e] : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = sc[e] != 0.f ? aff_fma(v[e], sh[e], sc[e], nls[e]) : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tile[ty + 16 * sweep][4 * tx + e] = v[e];
+  }
+  __syncthreads();
+  float m1 = -1.f;
+  asm volatile("" : "+v"(m1));
+  const int fl = threadIdx.x >> 2, q = threadIdx.x & 3;      // feature of the tile, quarter of its 64 samples
+  u32x4 hi[2], lo[2];
+#pragma unroll
+  for (int h = 0; h < 8; ++h) {
+    const float a0 = tile[16 * q + 2 * h][fl], a1 = tile[16 * q + 2 * h + 1][fl];
+    const fp16x2_t a = __builtin_amdgcn_cvt_pkrtz(a0, a1);
+    const fp16x2_t b = __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf((float)a[0], m1, a0), __builtin_fmaf((float)a[1], m1, a1));
+    hi[h >> 2][h & 3] = __builtin_bit_cast(unsigned, a);
+    lo[h >> 2][h & 3] = __builtin_bit_cast(unsigned, b);
+  }
+  char* line = reinterpret_cast<char*>(planes) + (f0 + fl) * (4 * kpad) + ((s0 >> 5) + (q >> 1)) * 128 + 32 * (q & 1);
+  *reinterpret_cast<u32x4*>(line) = hi[0];
+  *reinterpret_cast<u32x4*>(line + 16) = hi[1];
+  *reinterpret_cast<u32x4*>(line + 64) = lo[0];
+  *reinterpret_cast<u32x4*>(line + 80) = lo[1];
+}
+
 // work item of gram_nt_kernel: tile (bi, bj), first stage, number of stages (EVEN), output slot (tile-major: slot = tile * S + split)
 struct GramItem {
   int bi, bj, st0, nst, slot, pad0, pad1, pad2;
@@ -299,6 +359,33 @@ __global__ __launch_bounds__(256) void gram_finish_kernel(const float* __restric
   for (int sweep = 0; sweep < 16; ++sweep) {
     const int cc = 4 * sweep + qy;      // column of the sub-block = row of the mirrored block
     G[((int64_t)bj * GR_BM + c0 + cc) * ld + (int64_t)bi * GR_BM + r0 + qx] = tr[qx][cc];
+  }
+}
+
+// C[nrows x ncols] (ldc) from the tile partials of a general (non-symmetric) NT product: fixed-order sum over the S slots of a
+// tile.  grid = (tiles, 16): one 64 x 64 sub-block per workgroup.
+__global__ __launch_bounds__(256) void nt_finish_kernel(const float* __restrict__ Cp, const int2* __restrict__ tiles, int S,
+                                                         float* __restrict__ C, int64_t ldc, int64_t nrows, int ncols) {
+  const int tile = blockIdx.x, sb = blockIdx.y;
+  const int bi = tiles[tile].x, bj = tiles[tile].y;
+  const int r0 = 64 * (sb >> 2), c0 = 64 * (sb & 3);
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const float* base = Cp + (int64_t)tile * S * (GR_BM * GR_BM);
+#pragma unroll
+  for (int sweep = 0; sweep < 4; ++sweep) {
+    const int r = r0 + 16 * sweep + ty, c = c0 + 4 * tx;
+    const int64_t gr = (int64_t)bi * GR_BM + r;
+    const int gc = bj * GR_BM + c;
+    if (gr >= nrows || gc >= ncols) continue;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < S; ++s) v += *reinterpret_cast<const f32x4*>(base + (int64_t)s * (GR_BM * GR_BM) + r * GR_BM + c);
+    if (gc + 4 <= ncols) {
+      *reinterpret_cast<f32x4*>(C + gr * ldc + gc) = v;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (gc + e < ncols) C[gr * ldc + gc + e] = v[e];
+    }
   }
 }
 

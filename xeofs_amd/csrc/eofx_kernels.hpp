@@ -1349,8 +1349,12 @@ __device__ __forceinline__ double rl_f64(double v, int lane) {   // broadcast of
 //   phase 2: back substitution for X = R^-1 (R X = I), bottom row first; each wave owns 16 columns, lane
 //            (c, q) sums every fourth term, partials meet through quad shuffles -- no barriers at all.
 // Rows / columns >= l are padded with the identity.  All sums run in a fixed order (deterministic).
+// d0_ext (optional): the ORIGINAL diagonal the dependency rule refers to, when G is a diagonal block of a blocked
+// factorisation (its own diagonal is a Schur complement by then); G / Rinv may then point into a larger matrix of leading
+// dimension L.
 __global__ __launch_bounds__(256) void chol_rinv_kernel(const double* __restrict__ G, int L, int l,
-                                                         double* __restrict__ Rinv, double tol) {
+                                                         double* __restrict__ Rinv, double tol,
+                                                         const double* __restrict__ d0_ext = nullptr) {
   __shared__ double A[64][65];     // upper triangle: R[r][c], r < c (the diagonal is kept as 1/R[j][j] in pivs)
   __shared__ double X[64][65];     // R^-1 (upper triangle)
   __shared__ double d0s[64], pivs[64];
@@ -1363,7 +1367,7 @@ __global__ __launch_bounds__(256) void chol_rinv_kernel(const double* __restrict
     A[r][c] = v;
   }
   if (tid < 64) {
-    d0s[tid] = (tid < l) ? G[(int64_t)tid * L + tid] : 1.0;
+    d0s[tid] = (tid < l) ? (d0_ext ? d0_ext[tid] : G[(int64_t)tid * L + tid]) : 1.0;
     pivs[tid] = 1.0;
     dead[tid] = 0;
   }
@@ -1444,6 +1448,85 @@ __global__ __launch_bounds__(256) void chol_rinv_kernel(const double* __restrict
   for (int i = tid; i < 64 * 64; i += 256) {
     const int r = i >> 6, c = i & 63;
     if (r < L && c < L) Rinv[(int64_t)r * L + c] = (r <= c && c < l && !dead[c]) ? X[r][c] : 0.0;
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// dgemm64: C[M x N] = alpha op(A) B + beta C in float64, row-major, M, N, K multiples of 64 -- the small dense products of
+// the blocked Cholesky factorisation / triangular inverse of wide sketches (launch_rinv for l > 64: the PCA pre-reduction's
+// 1536-column panels).  One 64 x 64 tile of C per workgroup (16 x 16 threads, 4 x 4 outputs each), K in steps of 16
+// through LDS.  TA: op(A) = A^T with A stored [K x M].  upper: tiles strictly below the block diagonal are skipped.
+// C may alias B when K == 64 and the tile of B a workgroup reads is the tile of C it writes (the row-panel solve).
+// ---------------------------------------------------------------------------------
+template <bool TA>
+__global__ __launch_bounds__(256) void dgemm64_kernel(const double* __restrict__ A, int lda, const double* B, int ldb,
+                                                       double* C, int ldc, int K, double alpha, double beta, int upper) {
+  __shared__ double As[16][65], Bs[16][65];
+  const int bx = blockIdx.x, by = blockIdx.y;
+  if (upper && by > bx) return;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  double acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    // stage op(A)[64 by .. +64][k0 .. +16] as As[k][m] and B[k0 .. +16][64 bx .. +64] as Bs[k][n]
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int idx = threadIdx.x + 256 * e;     // 0 .. 1023
+      if (TA) {
+        const int k = idx >> 6, m = idx & 63;
+        As[k][m] = A[(int64_t)(k0 + k) * lda + 64 * by + m];
+      } else {
+        const int m = idx >> 4, k = idx & 15;
+        As[k][m] = A[(int64_t)(64 * by + m) * lda + k0 + k];
+      }
+      const int kb = idx >> 6, n = idx & 63;
+      Bs[kb][n] = B[(int64_t)(k0 + kb) * ldb + 64 * bx + n];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      double a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = As[k][4 * ty + i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = Bs[k][4 * tx + j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_fma(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      double* c = C + (int64_t)(64 * by + 4 * ty + i) * ldc + 64 * bx + 4 * tx + j;
+      *c = beta == 0.0 ? alpha * acc[i][j] : alpha * acc[i][j] + beta * *c;
+    }
+}
+
+// S <- [leading l x l block of G, identity beyond] as an Lb x Lb matrix; d0 <- its diagonal (the dependency rule's reference)
+__global__ void chol_blocked_init_kernel(const double* __restrict__ G, int L, int l, double* __restrict__ S, int Lb,
+                                          double* __restrict__ d0) {
+  const int64_t total = (int64_t)Lb * Lb;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / Lb), c = (int)(i % Lb);
+    double v = (r == c) ? 1.0 : 0.0;
+    if (r < l && c < l) v = G[(int64_t)r * L + c];
+    S[i] = v;
+    if (r == c) d0[r] = v;
+  }
+}
+// Rinv (L x L) <- leading l x l block of X (Lb x Lb, upper triangular), zero elsewhere
+__global__ void chol_blocked_export_kernel(const double* __restrict__ X, int Lb, int l, double* __restrict__ Rinv, int L) {
+  const int64_t total = (int64_t)L * L;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / L), c = (int)(i % L);
+    Rinv[i] = (r <= c && c < l) ? X[(int64_t)r * Lb + c] : 0.0;
   }
 }
 

@@ -32,8 +32,18 @@ def _round32(m):
 
 
 class ResidentPCA:
-    def __init__(self, ctx, n_modes=0.999, init_rank_reduction: float = 0.3, flip_signs: bool = True):
+    def __init__(self, ctx, n_modes=0.999, init_rank_reduction: float = 0.3, flip_signs: bool = True, solver: str = "auto",
+                 random_state=None, n_iter: int = 4, n_oversamples: int = 10):
+        """solver: "randomized" = the reference's own algorithm (scikit-learn's randomized_svd: n_oversamples = 10, 4 power
+        iterations at this width, re-normalised every step) carried out on the RESIDENT sample-space Gram matrix -- every
+        product n x n x l, no pass over the field inside the iteration, no order-n eigen-decomposition; "exact": the
+        eigen-decomposition of the Gram matrix (rounds 1-3; rocSOLVER through torch, 0.2 s at n = 5000); "auto":
+        randomized where the eigen-decomposition is the expensive step (n <= p, n >= 1024, sketch narrower than 0.6 n), else exact.  random_state: seed of the
+        Gaussian start (the reference's is unseeded; None here means a fixed seed, so refits are bitwise reproducible)."""
         self.ctx = ctx
+        self.solver = solver
+        self.random_state = random_state
+        self.n_iter, self.n_oversamples = int(n_iter), int(n_oversamples)
         self.flip_signs = flip_signs
         self.n_modes = n_modes
         self.init_rank_reduction = init_rank_reduction
@@ -78,55 +88,92 @@ class ResidentPCA:
         Gf = mat.gram(side)
         if sharded:
             Gf = comm.sum_(Gf)                          # X X^T = sum over the feature shards
-        G = Gf[:r, :r].double()
-        del Gf
-        G = 0.5 * (G + G.T)
-        if not bool(torch.isfinite(G).all()):
-            raise np.linalg.LinAlgError("SVD failed. This may be due to isolated NaN values in the data.")
-        lam, E = torch.linalg.eigh(G)                   # ascending
-        lam = torch.flip(lam, (0,)).clamp_min(0.0)
-        E = torch.flip(E, (1,))
-        lam_h = lam.cpu().numpy()
-        if total_variance is None:
-            total_variance = float(lam_h.sum()) / (n - 1)
-        m = n_pre
-        if self.is_based_on_variance:                   # _svd.py:215-241
-            cum = np.cumsum(lam_h[:n_pre] / (n - 1) / total_variance)
-            m = n_pre - int((cum >= self.n_modes).sum()) + 1
-            if m > n_pre:
-                warnings.warn(f"Dataset has {n_pre} components, explaining {cum[-1]:.2%} of the variance. However, "
-                              f"{self.n_modes:.2%} explained variance was requested. Please consider increasing "
-                              "`init_rank_reduction`.")
-                m = n_pre
-        Lm = _round32(m)
-        rows_small = mat.n_pad if side == 0 else mat.p_pad
-        Es = torch.zeros((rows_small, Lm), dtype=torch.float32, device=G.device)
-        Es[:r, :m] = E[:, :m].float()
-        # tall-side panel B = A^T E (A = X for side 0): columns ~ s_j v_j
-        B = engine.panel_tmul(ctx, mat, Es, prec=ctx.precision[1]) if side == 0 else \
-            engine.panel_mul(ctx, mat, Es, prec=ctx.precision[1])
-        M = engine.panel_gram(ctx, B)
-        if sharded:
-            M = comm.sum_(M)
-        M = M[:m, :m]
-        M = 0.5 * (M + M.T)
-        th, W = torch.linalg.eigh(M)
-        th = torch.flip(th, (0,)).clamp_min(0.0)
-        W = torch.flip(W, (1,))
-        s = torch.sqrt(th)
-        tiny = float(th[0]) * 1e-14 if m else 0.0
-        inv = torch.where(th > tiny, 1.0 / torch.sqrt(th.clamp_min(1e-300)), torch.zeros_like(th))
-        Wt = torch.zeros((Lm, Lm), dtype=torch.float64, device=G.device)
-        Wt[:m, :m] = W * inv                            # B W theta^-1/2 : orthonormal tall-side vectors
-        Tall = engine.panel_matmul(ctx, B, Wt)
-        del B
-        Small = (E[:, :m] @ W)                          # r x m float64, orthonormal small-side vectors
-        if side == 0:
-            self.Vp, U = Tall, Small                    # V: p_pad x Lm panel (device), U: n x m
-        else:                                           # features are the small side: V = E W, U = tall side
-            Vp = torch.zeros((mat.p_pad, Lm), dtype=torch.float32, device=G.device)
-            Vp[:p, :m] = Small.float()
-            self.Vp, U = Vp, Tall[:n, :m].double()
+        ell = min(n_pre + self.n_oversamples, r)
+        # "auto": the order-r eigen-decomposition is a few milliseconds up to r ~ 1000 and 0.2 s at 5000 (cubic): the exact route
+        # below that size, the reference's randomized algorithm on the resident Gram matrix above it
+        randomized = self.solver == "randomized" or (self.solver == "auto" and side == 0 and not sharded and
+                                                     ell <= 0.6 * r and r >= 1024)
+        if randomized and (side != 0 or ell >= r):
+            randomized = False
+        if self.solver not in ("auto", "randomized", "exact"):
+            raise ValueError(f"Unrecognized solver '{self.solver}'. Valid options are 'auto', 'randomized', and 'exact'.")
+        self.solver_used = "randomized" if randomized else "exact"
+        dev = Gf.device
+        if randomized:
+            # ---- the reference's randomized solver on the resident Gram matrix (see _range_randomized) -----------------------
+            if total_variance is None:
+                total_variance = float(Gf.diagonal()[:r].double().sum()) / (n - 1)
+            Q, GQ, Gm = self._range_randomized(Gf, r, ell)
+            del Gf
+            try:
+                Le = Q.shape[1]
+                # B = X^T Q (p x ell: the one wide product over the field) and the Rayleigh-Ritz step on B^T B = Q^T G Q,
+                # accumulated in float64 from exact products of the field -- as in the exact route below
+                B = engine.panel_tmul(ctx, mat, Q, prec=ctx.precision[1])
+                M = engine.panel_gram(ctx, B)[:ell, :ell]
+                M = 0.5 * (M + M.T)
+                th, W = torch.linalg.eigh(M)                # order ell: the one library call of this route
+                th = torch.flip(th, (0,)).clamp_min(0.0)
+                W = torch.flip(W, (1,))
+                lam_h = th.cpu().numpy()
+                m = self._truncate(lam_h, n_pre, n, total_variance)
+                Lm = _round32(m)
+                th, W = th[:m], W[:, :m]
+                s = torch.sqrt(th)
+                tiny = float(th[0]) * 1e-14 if m else 0.0
+                inv = torch.where(th > tiny, 1.0 / torch.sqrt(th.clamp_min(1e-300)), torch.zeros_like(th))
+                Wt = torch.zeros((Le, Lm), dtype=torch.float64, device=dev)
+                Wt[:ell, :m] = W * inv
+                self.Vp = engine.panel_matmul(ctx, B, Wt)   # V = B W theta^-1/2
+                del B
+                # The subspace of a randomized solver is not invariant, so U s and X V differ for the unconverged modes; the
+                # reference keeps V and defines the scores as X V (preprocessing/pca.py:120-131).  X V = X X^T Q W theta^-1/2
+                # = (G Q) W theta^-1/2, and G Q is at hand from the range finder's last product: no further pass.
+                U = engine.panel_matmul(ctx, GQ, Wt)[:n, :m].double() * inv
+            finally:
+                Gm.free()
+        else:
+            G = Gf[:r, :r].double()
+            del Gf
+            G = 0.5 * (G + G.T)
+            if not bool(torch.isfinite(G).all()):
+                raise np.linalg.LinAlgError("SVD failed. This may be due to isolated NaN values in the data.")
+            lam, E = torch.linalg.eigh(G)                   # ascending
+            lam = torch.flip(lam, (0,)).clamp_min(0.0)
+            E = torch.flip(E, (1,))
+            lam_h = lam.cpu().numpy()
+            if total_variance is None:
+                total_variance = float(lam_h.sum()) / (n - 1)
+            m = self._truncate(lam_h, n_pre, n, total_variance)
+            Lm = _round32(m)
+            rows_small = mat.n_pad if side == 0 else mat.p_pad
+            Es = torch.zeros((rows_small, Lm), dtype=torch.float32, device=dev)
+            Es[:r, :m] = E[:, :m].float()
+            # tall-side panel B = A^T E (A = X for side 0): columns ~ s_j v_j
+            B = engine.panel_tmul(ctx, mat, Es, prec=ctx.precision[1]) if side == 0 else \
+                engine.panel_mul(ctx, mat, Es, prec=ctx.precision[1])
+            M = engine.panel_gram(ctx, B)
+            if sharded:
+                M = comm.sum_(M)
+            M = M[:m, :m]
+            M = 0.5 * (M + M.T)
+            th, W = torch.linalg.eigh(M)
+            th = torch.flip(th, (0,)).clamp_min(0.0)
+            W = torch.flip(W, (1,))
+            s = torch.sqrt(th)
+            tiny = float(th[0]) * 1e-14 if m else 0.0
+            inv = torch.where(th > tiny, 1.0 / torch.sqrt(th.clamp_min(1e-300)), torch.zeros_like(th))
+            Wt = torch.zeros((Lm, Lm), dtype=torch.float64, device=dev)
+            Wt[:m, :m] = W * inv                            # B W theta^-1/2 : orthonormal tall-side vectors
+            Tall = engine.panel_matmul(ctx, B, Wt)
+            del B
+            Small = (E[:, :m] @ W)                          # r x m float64, orthonormal small-side vectors
+            if side == 0:
+                self.Vp, U = Tall, Small                    # V: p_pad x Lm panel (device), U: n x m
+            else:                                           # features are the small side: V = E W, U = tall side
+                Vp = torch.zeros((mat.p_pad, Lm), dtype=torch.float32, device=dev)
+                Vp[:p, :m] = Small.float()
+                self.Vp, U = Vp, Tall[:n, :m].double()
         # deterministic sign (utils/xarray_utils.py:273-301 on V), applied before the truncation in _svd.py:208-213
         # (a masked in-place matrix -- layout mode 3 -- keeps its all-NaN grid points as zero columns: V has p_phys rows,
         # zero at the masked features; zeros never change the sign rule, and every export below compacts the rows)
@@ -145,6 +192,51 @@ class ResidentPCA:
         self.singular_values_all = np.sqrt(lam_h)
         self.total_variance = total_variance
         return self
+
+    def _truncate(self, lam_h, n_pre, n, total_variance):
+        """number of modes kept (linalg/_numpy/_svd.py:215-241): the first n_pre eigenvalue estimates against the target"""
+        m = n_pre
+        if self.is_based_on_variance:
+            cum = np.cumsum(lam_h[:n_pre] / (n - 1) / total_variance)
+            m = n_pre - int((cum >= self.n_modes).sum()) + 1
+            if m > n_pre:
+                warnings.warn(f"Dataset has {n_pre} components, explaining {cum[-1]:.2%} of the variance. However, "
+                              f"{self.n_modes:.2%} explained variance was requested. Please consider increasing "
+                              "`init_rank_reduction`.")
+                m = n_pre
+        return m
+
+    def _range_randomized(self, Gf, r, ell):
+        """Orthonormal basis Q (n x ell) of the reference's randomized range finder (linalg/_numpy/_svd.py:170-186 -> sklearn
+        randomized_svd: Gaussian start, n_iter power iterations each followed by a re-normalisation) run IN SAMPLE SPACE on
+        the resident Gram matrix G = X X^T: range((X X^T)^q X Omega) = range(G^q Y0).  The start Y0 = G Omega' (Omega' Gaussian
+        n x ell) stands in for X Omega -- both are a Gaussian combination of the field's columns pushed once through X.  Per
+        step: one product G Q (the split-fp16 streaming kernel over the 100 MB matrix), the float64 Gram matrix of the n x ell
+        panel, its blocked Cholesky factor + triangular inverse on the device (eofx_abi.hip::launch_rinv_blocked) and the
+        product with it -- engine kernels only, nothing of order n is factorised.
+        -> (Q [n_pad, round32(ell)] float32, G Q (same shape), the Gram matrix as a ResidentMatrix: the caller frees it)"""
+        torch = engine._torch()
+        ctx = self.ctx
+        dev = Gf.device
+        if not bool(torch.isfinite(Gf[:r, :r]).all()):
+            raise np.linalg.LinAlgError("SVD failed. This may be due to isolated NaN values in the data.")
+        Gm = engine.from_dense(ctx, Gf[:r, :r].contiguous())          # the Gram matrix as a resident (r x r) matrix
+        try:
+            L = _round32(ell)
+            gen = torch.Generator(device=dev)
+            gen.manual_seed(0x5EED if self.random_state is None else int(self.random_state))
+            Q = torch.zeros((Gm.n_pad, L), dtype=torch.float32, device=dev)
+            Q[:r, :ell] = torch.randn((r, ell), generator=gen, device=dev, dtype=torch.float32)
+            prec = ctx.precision[1]
+            for _ in range(self.n_iter + 1):
+                Y = engine.panel_tmul(ctx, Gm, Q, prec=prec)           # G Q (G symmetric); [p_pad == n_pad, L]
+                S = engine.panel_gram(ctx, Y)
+                Q = engine.panel_cholqr(ctx, Y, ell, S)
+            Y = engine.panel_tmul(ctx, Gm, Q, prec=prec)
+        except BaseException:
+            Gm.free()
+            raise
+        return Q, Y, Gm
 
     # ------------------------------------------------------------------ PC-space views
     def scores(self):
