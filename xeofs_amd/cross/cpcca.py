@@ -52,32 +52,82 @@ class _Side:
     def __init__(self, ctx, mat, pca, alpha):
         self.ctx, self.mat, self.pca, self.alpha = ctx, mat, pca, alpha
         self.T = self.Tinv = None
-        self.Z = None if pca is None else pca.scores()          # analysis matrix on the host (n x m), or None
+        # the analysis matrix (n x m): PC scores, whitened -- on the DEVICE (float32 tensor) where a PCA produced it, and on
+        # the host (float64, downloaded on first use) for the m x m / n x k diagnostics algebra
+        self._Zdev = pca.scores_device() if (pca is not None and hasattr(pca, "scores_device")) else None
+        self._Zhost = None if (pca is None or self._Zdev is not None) else pca.scores()
         if not _whitener_is_identity(alpha):                     # whitener.py:54-60: identity when (1 - alpha) < eps
-            if self.Z is None:
-                if mat.p > MAX_DENSE_WHITEN:
-                    raise NotImplementedError(
-                        f"alpha < 1 without PCA needs the {mat.p} x {mat.p} feature covariance; use use_pca=True")
-                self.Z = mat.download().astype(np.float64)
-            n, m = self.Z.shape
-            if n < m:                                           # whitener.py:101-104
-                warnings.warn(f"The number of samples ({n}) is smaller than the number of features ({m}), leading to "
-                              "an ill-conditioned problem. This may cause unstable results. Consider using PCA to "
-                              "reduce dimensionality and stabilize the problem by setting `use_pca=True`.")
-            Cm = self.Z.T @ self.Z / n
-            self.T = fractional_matrix_power(Cm, (alpha - 1) / 2)
-            try:
-                self.Tinv = np.linalg.inv(self.T)
-            except np.linalg.LinAlgError:
-                self.Tinv = np.linalg.pinv(self.T)
-            self.Z = self.Z @ self.T
-        self.work = mat if self.Z is None else engine.from_dense(ctx, self.Z.astype(np.float32))
-        self.n, self.m = mat.n, (mat.p if self.Z is None else self.Z.shape[1])
+            if self._Zdev is not None:
+                self._whiten_on_device(alpha)
+            else:
+                if self._Zhost is None:
+                    if mat.p > MAX_DENSE_WHITEN:
+                        raise NotImplementedError(
+                            f"alpha < 1 without PCA needs the {mat.p} x {mat.p} feature covariance; use use_pca=True")
+                    self._Zhost = mat.download().astype(np.float64)
+                n, m = self._Zhost.shape
+                self._warn_ill_conditioned(n, m)
+                Cm = self._Zhost.T @ self._Zhost / n
+                self.T = fractional_matrix_power(Cm, (alpha - 1) / 2)
+                try:
+                    self.Tinv = np.linalg.inv(self.T)
+                except np.linalg.LinAlgError:
+                    self.Tinv = np.linalg.pinv(self.T)
+                self._Zhost = self._Zhost @ self.T
+        if self._Zdev is not None:
+            self.work = engine.from_dense(ctx, self._Zdev)       # device tensor in: nothing crosses PCIe
+        else:
+            self.work = mat if self._Zhost is None else engine.from_dense(ctx, self._Zhost.astype(np.float32))
+        self.n, self.m = mat.n, (mat.p if not self.has_Z else
+                                 (self._Zdev.shape[1] if self._Zdev is not None else self._Zhost.shape[1]))
+
+    @staticmethod
+    def _warn_ill_conditioned(n, m):
+        if n < m:                                               # whitener.py:101-104
+            warnings.warn(f"The number of samples ({n}) is smaller than the number of features ({m}), leading to "
+                          "an ill-conditioned problem. This may cause unstable results. Consider using PCA to "
+                          "reduce dimensionality and stabilize the problem by setting `use_pca=True`.")
+
+    def _whiten_on_device(self, alpha):
+        """Whitener.fit / transform (preprocessing/whitener.py:86-133) on the resident PC scores: C = Z^T Z / n through the
+        float64 Gram kernel, T = C^((alpha - 1) / 2) from its eigen-decomposition (linalg/_numpy/_utils.py:6-33: eigenvalues
+        <= eps dropped; order m <= int(0.3 rank), the one library call), Z T through panel_matmul.  T and its inverse go
+        to the host (m x m) for the back-transforms; the n x m matrix never leaves HBM."""
+        torch = engine._torch()
+        ctx = self.ctx
+        Zd = self._Zdev
+        n, m = Zd.shape
+        self._warn_ill_conditioned(n, m)
+        Lm = (m + 31) // 32 * 32
+        Zp = torch.zeros((self.mat.n_pad, Lm), dtype=torch.float32, device=Zd.device)
+        Zp[:n, :m] = Zd
+        Cm = engine.panel_gram(ctx, Zp)[:m, :m] / n
+        w, V = torch.linalg.eigh(0.5 * (Cm + Cm.T))
+        keep = w > torch.finfo(w.dtype).eps
+        Vk, wk = V[:, keep], w[keep]
+        T = (Vk * wk ** ((alpha - 1) / 2)) @ Vk.T
+        # np.linalg.inv(T) where T is regular (all eigenvalues kept), its pseudo-inverse otherwise (whitener.py:117-123)
+        Tinv = (Vk * wk ** ((1 - alpha) / 2)) @ Vk.T
+        Tp = torch.zeros((Lm, Lm), dtype=torch.float64, device=Zd.device)
+        Tp[:m, :m] = T
+        self._Zdev = engine.panel_matmul(ctx, Zp, Tp)[:n, :m].contiguous()
+        self.T, self.Tinv = T.cpu().numpy(), Tinv.cpu().numpy()
+
+    @property
+    def has_Z(self):
+        return self._Zdev is not None or self._Zhost is not None
+
+    @property
+    def Z(self):
+        """the analysis matrix on the host (float64), or None when the field itself is the analysis matrix"""
+        if self._Zhost is None and self._Zdev is not None:
+            self._Zhost = self._Zdev.double().cpu().numpy()
+        return self._Zhost
 
     # --- analysis-space <-> feature-space maps ------------------------------------------------
     def to_analysis(self, mat_new):
         """preprocessed new data (resident) -> analysis space: pca.transform, whitener.transform"""
-        if self.Z is None:
+        if not self.has_Z:
             return None                                          # stays resident
         Z = self.pca.transform(mat_new) if self.pca is not None else mat_new.download().astype(np.float64)
         return Z if self.T is None else Z @ self.T
@@ -101,7 +151,7 @@ class _Side:
 
     # --- unwhitened analysis matrix A (= input_data after whitener.inverse_transform_data) ------
     def A_host(self):
-        if self.Z is None:
+        if not self.has_Z:
             return None
         return self.Z if self.Tinv is None else self.Z @ self.Tinv
 
@@ -138,7 +188,7 @@ class _Side:
             w, E = np.linalg.eigh(0.5 * (S + S.T))
             half = (E * np.sqrt(np.clip(w, 0, None))) @ E.T
             std = self.pca.row_norms(half) / np.sqrt(n)
-        elif self.Z is not None:
+        elif self.has_Z:
             A = self.A_host()
             num, std = A.T @ R, np.sqrt((A * A).sum(axis=0) / n)
         else:
@@ -146,7 +196,7 @@ class _Side:
         return num, std
 
     def free(self):
-        if self.Z is not None and self.work is not None:
+        if self.has_Z and self.work is not None:
             self.work.free()
         self.work = None
 
@@ -294,6 +344,22 @@ class CPCCA(Deferred):
         """cpcca.py:991-1000: sum |Tinv1^T C Tinv2|^2 = || A1^T A2 ||_F^2 / (n-1)^2 on the unwhitened matrices"""
         sx, sy = self.side
         n = sx.n
+        if sx._Zdev is not None and sy._Zdev is not None:
+            # A1^T A2 = Tinv1^T (Z1^T Z2) Tinv2 with Z1^T Z2 the off-diagonal block of the float64 Gram matrix of the panel
+            # [Z1 | Z2] (gram kernel on the resident analysis matrices); the m x m products on the host
+            torch = engine._torch()
+            Z1, Z2 = sx._Zdev, sy._Zdev
+            m1, m2 = Z1.shape[1], Z2.shape[1]
+            L1, L2 = (m1 + 31) // 32 * 32, (m2 + 31) // 32 * 32
+            P = torch.zeros((sx.mat.n_pad, L1 + L2), dtype=torch.float32, device=Z1.device)
+            P[:n, :m1] = Z1
+            P[:n, L1:L1 + m2] = Z2
+            C12 = engine.panel_gram(self.ctx, P)[:m1, L1:L1 + m2].cpu().numpy()
+            if sx.Tinv is not None:
+                C12 = sx.Tinv.T @ C12
+            if sy.Tinv is not None:
+                C12 = C12 @ sy.Tinv
+            return float((C12 ** 2).sum()) / (n - 1) ** 2
         A1, A2 = sx.A_host(), sy.A_host()
         if A1 is not None and A2 is not None:
             return float(((A1.T @ A2) ** 2).sum()) / (n - 1) ** 2

@@ -31,6 +31,19 @@ def _round32(m):
     return (int(m) + 31) // 32 * 32
 
 
+# Seeds of unseeded randomized fits: the reference's PCA draws from numpy's global, unseeded generator, so the two fields
+# of a cross model start from INDEPENDENT Gaussian matrices.  A fixed seed shared by both would correlate the two sample-space
+# starts -- and with them the noise ends of the two PC spaces (the total squared covariance of a default-argument MCA at
+# config 3 came out 28 % high that way).  One process-wide counter: every unseeded fit gets the next stream; a process that
+# makes the same calls in the same order gets the same results.
+_unseeded_fits = [0]
+
+
+def _next_seed():
+    _unseeded_fits[0] += 1
+    return 0x5EED0000 + _unseeded_fits[0]
+
+
 class ResidentPCA:
     def __init__(self, ctx, n_modes=0.999, init_rank_reduction: float = 0.3, flip_signs: bool = True, solver: str = "auto",
                  random_state=None, n_iter: int = 4, n_oversamples: int = 10):
@@ -39,7 +52,8 @@ class ResidentPCA:
         product n x n x l, no pass over the field inside the iteration, no order-n eigen-decomposition; "exact": the
         eigen-decomposition of the Gram matrix (rounds 1-3; rocSOLVER through torch, 0.2 s at n = 5000); "auto":
         randomized where the eigen-decomposition is the expensive step (n <= p, n >= 1024, sketch narrower than 0.6 n), else exact.  random_state: seed of the
-        Gaussian start (the reference's is unseeded; None here means a fixed seed, so refits are bitwise reproducible)."""
+        Gaussian start (the reference's is unseeded; None here takes the next stream of a process-wide counter: independent starts for
+        the two fields of a cross model, the same results for the same sequence of calls)."""
         self.ctx = ctx
         self.solver = solver
         self.random_state = random_state
@@ -188,7 +202,9 @@ class ResidentPCA:
         self.m, self.Lm, self.n, self.p, self.p_pad = m, Lm, n, p, mat.p_pad
         self.p_phys, self._masked_index = mat.p_phys, (mat.valid_index if mat.masked else None)
         self.s = s.cpu().numpy()
-        self.U = (U * sign).cpu().numpy()               # n x m float64
+        Ud = U * sign                                   # n x m float64 (device)
+        self._U_dev, self._U_host = Ud, None            # downloaded on first use (60 MB at config 3)
+        self._scores_dev = (Ud * s).float().contiguous()   # X V on the device: the analysis matrix of the cross models
         self.singular_values_all = np.sqrt(lam_h)
         self.total_variance = total_variance
         return self
@@ -224,7 +240,7 @@ class ResidentPCA:
         try:
             L = _round32(ell)
             gen = torch.Generator(device=dev)
-            gen.manual_seed(0x5EED if self.random_state is None else int(self.random_state))
+            gen.manual_seed(_next_seed() if self.random_state is None else int(self.random_state))
             Q = torch.zeros((Gm.n_pad, L), dtype=torch.float32, device=dev)
             Q[:r, :ell] = torch.randn((r, ell), generator=gen, device=dev, dtype=torch.float32)
             prec = ctx.precision[1]
@@ -237,6 +253,21 @@ class ResidentPCA:
             Gm.free()
             raise
         return Q, Y, Gm
+
+    @property
+    def U(self):
+        """left singular vectors (n x m float64, host): X V / s"""
+        if getattr(self, "_U_host", None) is None:
+            self._U_host = self._U_dev.cpu().numpy()
+        return self._U_host
+
+    @U.setter
+    def U(self, value):      # (the complex subclass assigns its host array directly)
+        self._U_host = value
+
+    def scores_device(self):
+        """X V (n x m float32) as a device tensor: stays in HBM for the cross models' analysis"""
+        return self._scores_dev
 
     # ------------------------------------------------------------------ PC-space views
     def scores(self):
