@@ -276,6 +276,26 @@ def leg_configs(ctx, device, orc, layout_kw, quick=False):
             g3["right"]["min_abs_cos"] >= 1 - 1e-5 and g3["left"]["sign_ok"] and g3["right"]["sign_ok"]):
         gate.append(f"config 3 oracle gate: {g3}")
     del Xg, Yg, rg, refg
+    # the same two fields through the model class with the REFERENCE'S DEFAULT ARGUMENTS (use_pca=True, n_pca_modes=0.999,
+    # init_rank_reduction=0.3: SURVEY §8f row N1): PCA pre-reduction of both fields (the reference's randomized solver on the
+    # resident sample-space Gram matrix), analysis on the 5000 x 1500 PC scores, components projected back
+    Xd = xe.DataArray(X.reshape(n, nlat, 360), dims=("time", "lat", "lon"))
+    Yd = xe.DataArray(Y.reshape(n, nlat, 360), dims=("time", "lat", "lon"))
+
+    def c3_default():
+        import warnings
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")     # "Dataset has 1500 components, explaining 35 % ..." (the reference warns too)
+            return xe.cross.MCA(n_modes=k, random_state=5).fit(Xd, Yd, "time")
+
+    c3_default()
+    t_def, _, md = timed(c3_default, 2)
+    out["config3"]["default_arguments"] = {
+        "what": "xe.cross.MCA(n_modes=20, random_state=5).fit(X, Y, 'time') -- use_pca=True, n_pca_modes=0.999 -- model level, "
+                "fields resident", "ms": round(t_def, 1), "pca_modes": [int(md.pca[0].m), int(md.pca[1].m)],
+        "pca_solver": md.pca[0].solver_used, "s_head": [float(x) for x in np.asarray(md.singular_values().values)[:3]]}
+    del Xd, Yd, md
     del X, Y, res
     torch.cuda.empty_cache()
 
