@@ -52,12 +52,15 @@ int main(int argc, char** argv) {
     CK(hipDeviceSynchronize());
   }
   const float one = 1.f; CK(hipMemcpy(bmax, &one, 4, hipMemcpyHostToDevice));
-  for (int S : {64, 96, 128}) {
+  for (int S : {96}) {
     run<0>(A, ld, n, aff, B, C, rows_pad, S, bmax);
     run<1>(A, ld, n, aff, B, C, rows_pad, S, bmax);
     run<3>(A, ld, n, aff, B, C, rows_pad, S, bmax);
     run<7>(A, ld, n, aff, B, C, rows_pad, S, bmax);
     run<8>(A, ld, n, aff, B, C, rows_pad, S, bmax);
+    run<16>(A, ld, n, aff, B, C, rows_pad, S, bmax);
+    run<20>(A, ld, n, aff, B, C, rows_pad, S, bmax);
+    run<0>(A, ld, n, aff, B, C, rows_pad, S, bmax);
   }
   return 0;
 }

@@ -798,7 +798,7 @@ static int launch_axb(eofx_ctx* ctx, const float* raw, int64_t ld, int64_t rows,
     amax_forget(ctx, W);
     return EOFX_OK;
   }
-  if (L % 32 || L <= 0 || rows_pad % AXB_BM || rows >= ((int64_t)1 << 31) || K_all * L >= ((int64_t)1 << 31) ||
+  if (L % 32 || L <= 0 || rows_pad % AXB_BM || rows >= ((int64_t)1 << 31) || K_all * L >= ((int64_t)1 << 30) ||
       64 * ld + K_all >= ((int64_t)1 << 30))     // the kernel's 32-bit offsets
     return set_err(ctx, EOFX_ERR_ARG, "axb: bad geometry rows=%lld cols=%lld L=%d", (long long)rows, (long long)cols, L);
   const AtbPlan plan = axb_plan(rows_pad, K);
@@ -3796,7 +3796,7 @@ struct CplxOps {
   int64_t ident_ld = 0;
   static bool axb_fits(int64_t ld, int64_t cols, int L) {   // the 32-bit offsets of axb_f16 (launch_axb checks them too)
     const int64_t K = round_up(cols, AXB_KG);
-    return K * (int64_t)L < ((int64_t)1 << 31) && 64 * ld + K < ((int64_t)1 << 30);
+    return K * (int64_t)L < ((int64_t)1 << 30) && 64 * ld + K < ((int64_t)1 << 30);   // BYTE offsets in 32 bits
   }
   int t_part(const eofx_mat* M, const float* Wn, float* out, int prec) {      // M^T W  [p_pad x LP]
     if (!M->X && M->raw && M->aff && prec == EOFX_PREC_F16X3) {

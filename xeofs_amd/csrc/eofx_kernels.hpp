@@ -667,7 +667,8 @@ constexpr int AXB_KG = 64;    // K granularity: slabs are consumed in pairs
 constexpr int AXB_BM = 256;   // rows per workgroup
 constexpr int AXB_LDA = 32;   // halves per staged row: 64 bytes = four 16-byte chunks, chunk c of row r stored at c ^ ((r >> 1) & 3)
 
-// DBG (tools/probes/axb_probe.hip only): 1 no MFMA, 2 no conversion either, 4 no B / map loads, 8 cached A loads
+// DBG (tools/probes/axb_probe.hip only): 1 no MFMA, 2 no conversion either, 4 no B / map loads, 8 cached A loads,
+// 16 no B conversion / staging stores
 // MASK: as in atb_f16_kernel -- features with scale 0 (all-NaN grid points kept as zero columns) are ANDed to +0.
 template <int NQ, int DBG = 0, bool MASK = false>   // 16-column tiles per workgroup column block: 4 (64 columns) or 2 (a 32-column remainder)
 __global__ __launch_bounds__(256, 2) void axb_f16_kernel(const float* __restrict__ A, int64_t lda, int a_rows,
@@ -721,7 +722,7 @@ __global__ __launch_bounds__(256, 2) void axb_f16_kernel(const float* __restrict
   // A: uniform base of the wave's row block + 32-bit byte offsets (the launcher guarantees 64 lda + K < 2^30 elements)
   const char* const Ab = reinterpret_cast<const char*>(A + (int64_t)(live ? r0 : 0) * lda);
   const int arow0 = live ? r0 : 0;     // dead waves stream the first rows (their results are discarded)
-  // 32-bit offsets from uniform bases for the small streams (the launcher guarantees K * ldb < 2^31)
+  // 32-bit BYTE offsets from uniform bases for the small streams (the launcher guarantees K * ldb < 2^30)
   const float* const aff1 = aff + aff_ld;
   const float* const aff2 = aff + 2 * aff_ld;
   const int fo = (int)kb + 4 * lc;
@@ -742,16 +743,18 @@ __global__ __launch_bounds__(256, 2) void axb_f16_kernel(const float* __restrict
 #define EOFX_LOAD_BH(pair, hb)   /* B slab = 64 features = TWO A slabs; half hb: rows bk, bk + 1 of that half */ \
   do {                                                                                                 \
     if (!(DBG & 4)) {                                                                                  \
-      bn[0] = *reinterpret_cast<const f32x4*>(B + (bo + ((pair) * AXB_KG + 32 * (hb)) * ldb));         \
-      bn[1] = *reinterpret_cast<const f32x4*>(B + (bo + ((pair) * AXB_KG + 32 * (hb) + 1) * ldb));     \
+      const unsigned bb_ = (unsigned)(bo + ((pair) * AXB_KG + 32 * (hb)) * ldb) * 4u;   /* K ldb < 2^30 */ \
+      bn[0] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(B) + bb_);                 \
+      bn[1] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(B) + (bb_ + (unsigned)ldb * 4u)); \
     }                                                                                                  \
   } while (0)
 #define EOFX_LOAD_F(freg, chunk)                                                                       \
   do {                                                                                                 \
     if (!(DBG & 4)) {                                                                                  \
-      freg[0] = *reinterpret_cast<const f32x4*>(aff + (fo + (chunk) * AXB_KC));                        \
-      freg[1] = *reinterpret_cast<const f32x4*>(aff1 + (fo + (chunk) * AXB_KC));                       \
-      freg[2] = *reinterpret_cast<const f32x4*>(aff2 + (fo + (chunk) * AXB_KC));                       \
+      const unsigned fb_ = (unsigned)(fo + (chunk) * AXB_KC) * 4u;   /* K < 2^30: scalar base + 32-bit offset */ \
+      freg[0] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(aff) + fb_);             \
+      freg[1] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(aff1) + fb_);            \
+      freg[2] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(aff2) + fb_);            \
     }                                                                                                  \
   } while (0)
   // row groups u0 .. u0+3 (32 rows) of slab `chunk`
@@ -778,7 +781,7 @@ __global__ __launch_bounds__(256, 2) void axb_f16_kernel(const float* __restrict
   } while (0)
 #define EOFX_STORE_BH(buf, hb)                                                                         \
   do {                                                                                                 \
-    if (b_loader) _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                      \
+    if (b_loader && !(DBG & 16)) _Pragma("unroll") for (int e = 0; e < 4; ++e) {                       \
       const int col_ = 4 * bc4 + e;                                                                    \
       const int sl_ = col_ ^ ((col_ >> 3) & 7);                                                        \
       const float v0_ = bn[0][e] * b_scale, v1_ = bn[1][e] * b_scale;                                  \
@@ -802,7 +805,10 @@ __global__ __launch_bounds__(256, 2) void axb_f16_kernel(const float* __restrict
         /* aff_map on a pair (packed float32 arithmetic: the same three roundings per element) */       \
         const f32x2 x_ = {MASK ? __uint_as_float(__float_as_uint(areg[u][2 * h]) & mk_[2 * h]) : areg[u][2 * h],           \
                           MASK ? __uint_as_float(__float_as_uint(areg[u][2 * h + 1]) & mk_[2 * h + 1]) : areg[u][2 * h + 1]}; \
-        const f32x2 v_ = __builtin_elementwise_fma(x_ + fh_[h], fs_[h], fl_[h]);   /* aff_fma: fh_ = -hi, fl_ = -(lo s) */ \
+        f32x2 t_;   /* x - hi as ONE packed add with negated second source (no v_pk_sub_f32 exists) */            \
+        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(t_) : "v"(x_), "v"(fh_[h]));     \
+        f32x2 v_;   /* aff_fma: (x - hi) s - lo s, packed (the optimiser splits half of these otherwise) */       \
+        asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(v_) : "v"(t_), "v"(fs_[h]), "v"(fl_[h])); \
         const fp16x2_t p_ = __builtin_amdgcn_cvt_pkrtz(v_[0], v_[1]);                                  \
         const fp16x2_t q_ = __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf((float)p_[0], m1, v_[0]),        \
                                                        __builtin_fmaf((float)p_[1], m1, v_[1]));        \
@@ -846,11 +852,9 @@ __global__ __launch_bounds__(256, 2) void axb_f16_kernel(const float* __restrict
     if (live) {                                                                                        \
       f32x2 fh_[2], fl_[2], fs_[2];                                                                    \
       _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                  \
-        fh_[h] = -f32x2{fr[0][2 * h], fr[0][2 * h + 1]};   /* x - s == x + (-s) exactly: packed adds */  \
-        fl_[h] = -f32x2{fr[1][2 * h], fr[1][2 * h + 1]};                                               \
-        asm volatile("" : "+v"(fh_[h]), "+v"(fl_[h]));   /* keep them additions (v_pk_add_f32) */         \
+        fh_[h] = f32x2{fr[0][2 * h], fr[0][2 * h + 1]};                                                \
         fs_[h] = f32x2{fr[2][2 * h], fr[2][2 * h + 1]} * a_scale;   /* exact: a power of two */         \
-        fl_[h] = fl_[h] * fs_[h];                                   /* -(lo * s), as aff_fma wants it */  \
+        fl_[h] = f32x2{fr[1][2 * h], fr[1][2 * h + 1]} * fs_[h];    /* lo * s; aff_fma subtracts it */   \
       }                                                                                                \
       unsigned mk_[4];                                                                                 \
       _Pragma("unroll") for (int e = 0; e < 4; ++e) mk_[e] = (MASK && fr[2][e] == 0.f) ? 0u : 0xffffffffu; \
@@ -887,18 +891,26 @@ __global__ __launch_bounds__(256, 2) void axb_f16_kernel(const float* __restrict
       EOFX_STORE_BH(0, 1);
       EOFX_LOAD_BH(npair > 1 ? 1 : 0, 0);
       __syncthreads();
-      for (int pr = 0; pr < npair; ++pr) {
-        const int pb = pr & 1;
-        const int c2 = pr + 1 < npair ? 2 * pr + 2 : 2 * pr;          // past the end: harmless re-reads of the last pair
-        const int p1 = pr + 1 < npair ? pr + 1 : npair - 1, p2 = pr + 2 < npair ? pr + 2 : npair - 1;
-        EOFX_STORE_BH(1 - pb, 0);
-        EOFX_LOAD_BH(p1, 1);
-        EOFX_SLAB(a0, pb, 0, 2 * pr + 1, c2);
-        EOFX_STORE_BH(1 - pb, 1);
-        EOFX_LOAD_BH(p2, 0);
-        EOFX_SLAB(a1, pb, 1, c2, c2 + 1);
-        __syncthreads();
+      // the B buffer index is a compile-time constant in each copy of the body (two pairs per trip): its LDS addresses are
+      // instruction offsets instead of 11 address computations per slab
+#define EOFX_AXB_PAIR(pr_, pb)                                                                          \
+      do {                                                                                              \
+        const int c2 = (pr_) + 1 < npair ? 2 * (pr_) + 2 : 2 * (pr_);   /* past the end: harmless re-reads of the last pair */ \
+        const int p1 = (pr_) + 1 < npair ? (pr_) + 1 : npair - 1, p2 = (pr_) + 2 < npair ? (pr_) + 2 : npair - 1; \
+        EOFX_STORE_BH(1 - (pb), 0);                                                                     \
+        EOFX_LOAD_BH(p1, 1);                                                                            \
+        EOFX_SLAB(a0, pb, 0, 2 * (pr_) + 1, c2);                                                        \
+        EOFX_STORE_BH(1 - (pb), 1);                                                                     \
+        EOFX_LOAD_BH(p2, 0);                                                                            \
+        EOFX_SLAB(a1, pb, 1, c2, c2 + 1);                                                               \
+        __syncthreads();                                                                                \
+      } while (0)
+      for (int pr = 0; pr < npair; pr += 2) {
+        EOFX_AXB_PAIR(pr, 0);
+        if (pr + 1 >= npair) break;
+        EOFX_AXB_PAIR(pr + 1, 1);
       }
+#undef EOFX_AXB_PAIR
     }
   } else if (nslab > 0) {   // the same schedule with the pair ids taken from the active list (or the identity)
     const int npair = nslab / 2;
@@ -916,20 +928,26 @@ __global__ __launch_bounds__(256, 2) void axb_f16_kernel(const float* __restrict
       EOFX_LOAD_BH(q1, 0);
     }
     __syncthreads();
-    for (int pr = 0; pr < npair; ++pr) {
-      const int pb = pr & 1;
-      // pair ids of this, the next and the next-but-one pair (past the end: harmless re-reads of the last pair)
-      const int q0 = EOFX_PAIR(pr), p1 = EOFX_PAIR(pr + 1 < npair ? pr + 1 : npair - 1);
-      const int p2 = EOFX_PAIR(pr + 2 < npair ? pr + 2 : npair - 1);
-      const int c2 = 2 * p1;
-      EOFX_STORE_BH(1 - pb, 0);
-      EOFX_LOAD_BH(p1, 1);
-      EOFX_SLAB(a0, pb, 0, 2 * q0 + 1, c2);
-      EOFX_STORE_BH(1 - pb, 1);
-      EOFX_LOAD_BH(p2, 0);
-      EOFX_SLAB(a1, pb, 1, c2, c2 + 1);
-      __syncthreads();
+#define EOFX_AXB_PAIR(pr_, pb)                                                                          \
+    do {                                                                                                \
+      /* pair ids of this, the next and the next-but-one pair (past the end: harmless re-reads of the last pair) */ \
+      const int q0 = EOFX_PAIR(pr_), p1 = EOFX_PAIR((pr_) + 1 < npair ? (pr_) + 1 : npair - 1);         \
+      const int p2 = EOFX_PAIR((pr_) + 2 < npair ? (pr_) + 2 : npair - 1);                              \
+      const int c2 = 2 * p1;                                                                            \
+      EOFX_STORE_BH(1 - (pb), 0);                                                                       \
+      EOFX_LOAD_BH(p1, 1);                                                                              \
+      EOFX_SLAB(a0, pb, 0, 2 * q0 + 1, c2);                                                             \
+      EOFX_STORE_BH(1 - (pb), 1);                                                                       \
+      EOFX_LOAD_BH(p2, 0);                                                                              \
+      EOFX_SLAB(a1, pb, 1, c2, c2 + 1);                                                                 \
+      __syncthreads();                                                                                  \
+    } while (0)
+    for (int pr = 0; pr < npair; pr += 2) {
+      EOFX_AXB_PAIR(pr, 0);
+      if (pr + 1 >= npair) break;
+      EOFX_AXB_PAIR(pr + 1, 1);
     }
+#undef EOFX_AXB_PAIR
   }
 #undef EOFX_PAIR
 #undef EOFX_AXB_LD
