@@ -60,6 +60,7 @@ int main(int argc, char** argv) {
     run<8>(A, ld, n, aff, B, C, rows_pad, S, bmax);
     run<16>(A, ld, n, aff, B, C, rows_pad, S, bmax);
     run<20>(A, ld, n, aff, B, C, rows_pad, S, bmax);
+    run<32>(A, ld, n, aff, B, C, rows_pad, S, bmax);
     run<0>(A, ld, n, aff, B, C, rows_pad, S, bmax);
   }
   return 0;

@@ -668,7 +668,7 @@ constexpr int AXB_BM = 256;   // rows per workgroup
 constexpr int AXB_LDA = 32;   // halves per staged row: 64 bytes = four 16-byte chunks, chunk c of row r stored at c ^ ((r >> 1) & 3)
 
 // DBG (tools/probes/axb_probe.hip only): 1 no MFMA, 2 no conversion either, 4 no B / map loads, 8 cached A loads,
-// 16 no B conversion / staging stores
+// 16 no B conversion / staging stores, 32 B staged as raw bits (loads, waits and stores without the arithmetic)
 // MASK: as in atb_f16_kernel -- features with scale 0 (all-NaN grid points kept as zero columns) are ANDed to +0.
 template <int NQ, int DBG = 0, bool MASK = false>   // 16-column tiles per workgroup column block: 4 (64 columns) or 2 (a 32-column remainder)
 __global__ __launch_bounds__(256, 2) void axb_f16_kernel(const float* __restrict__ A, int64_t lda, int a_rows,
@@ -785,10 +785,14 @@ __global__ __launch_bounds__(256, 2) void axb_f16_kernel(const float* __restrict
       const int col_ = 4 * bc4 + e;                                                                    \
       const int sl_ = col_ ^ ((col_ >> 3) & 7);                                                        \
       const float v0_ = bn[0][e] * b_scale, v1_ = bn[1][e] * b_scale;                                  \
-      const fp16x2_t h_ = __builtin_amdgcn_cvt_pkrtz(v0_, v1_);                                        \
-      fp16x2_t l_;                                                                                     \
-      l_[0] = (__fp16)__builtin_fmaf((float)h_[0], m1, v0_);                                           \
-      l_[1] = (__fp16)__builtin_fmaf((float)h_[1], m1, v1_);                                           \
+      fp16x2_t h_, l_;                                                                                 \
+      if (DBG & 32) {   /* raw bits: the loads, the waits and the LDS stores without the arithmetic */   \
+        h_ = __builtin_bit_cast(fp16x2_t, bn[0][e]); l_ = __builtin_bit_cast(fp16x2_t, bn[1][e]);      \
+      } else {                                                                                         \
+        h_ = __builtin_amdgcn_cvt_pkrtz(v0_, v1_);                                                     \
+        l_[0] = (__fp16)__builtin_fmaf((float)h_[0], m1, v0_);                                         \
+        l_[1] = (__fp16)__builtin_fmaf((float)h_[1], m1, v1_);                                         \
+      }                                                                                                \
       *reinterpret_cast<unsigned*>(&Bs[buf][0][wave + 4 * (hb)][sl_][bt]) = __builtin_bit_cast(unsigned, h_); \
       *reinterpret_cast<unsigned*>(&Bs[buf][1][wave + 4 * (hb)][sl_][bt]) = __builtin_bit_cast(unsigned, l_); \
     }                                                                                                  \
@@ -891,26 +895,18 @@ __global__ __launch_bounds__(256, 2) void axb_f16_kernel(const float* __restrict
       EOFX_STORE_BH(0, 1);
       EOFX_LOAD_BH(npair > 1 ? 1 : 0, 0);
       __syncthreads();
-      // the B buffer index is a compile-time constant in each copy of the body (two pairs per trip): its LDS addresses are
-      // instruction offsets instead of 11 address computations per slab
-#define EOFX_AXB_PAIR(pr_, pb)                                                                          \
-      do {                                                                                              \
-        const int c2 = (pr_) + 1 < npair ? 2 * (pr_) + 2 : 2 * (pr_);   /* past the end: harmless re-reads of the last pair */ \
-        const int p1 = (pr_) + 1 < npair ? (pr_) + 1 : npair - 1, p2 = (pr_) + 2 < npair ? (pr_) + 2 : npair - 1; \
-        EOFX_STORE_BH(1 - (pb), 0);                                                                     \
-        EOFX_LOAD_BH(p1, 1);                                                                            \
-        EOFX_SLAB(a0, pb, 0, 2 * (pr_) + 1, c2);                                                        \
-        EOFX_STORE_BH(1 - (pb), 1);                                                                     \
-        EOFX_LOAD_BH(p2, 0);                                                                            \
-        EOFX_SLAB(a1, pb, 1, c2, c2 + 1);                                                               \
-        __syncthreads();                                                                                \
-      } while (0)
-      for (int pr = 0; pr < npair; pr += 2) {
-        EOFX_AXB_PAIR(pr, 0);
-        if (pr + 1 >= npair) break;
-        EOFX_AXB_PAIR(pr + 1, 1);
+      for (int pr = 0; pr < npair; ++pr) {
+        const int pb = pr & 1;
+        const int c2 = pr + 1 < npair ? 2 * pr + 2 : 2 * pr;          // past the end: harmless re-reads of the last pair
+        const int p1 = pr + 1 < npair ? pr + 1 : npair - 1, p2 = pr + 2 < npair ? pr + 2 : npair - 1;
+        EOFX_STORE_BH(1 - pb, 0);
+        EOFX_LOAD_BH(p1, 1);
+        EOFX_SLAB(a0, pb, 0, 2 * pr + 1, c2);
+        EOFX_STORE_BH(1 - pb, 1);
+        EOFX_LOAD_BH(p2, 0);
+        EOFX_SLAB(a1, pb, 1, c2, c2 + 1);
+        __syncthreads();
       }
-#undef EOFX_AXB_PAIR
     }
   } else if (nslab > 0) {   // the same schedule with the pair ids taken from the active list (or the identity)
     const int npair = nslab / 2;
@@ -928,26 +924,20 @@ __global__ __launch_bounds__(256, 2) void axb_f16_kernel(const float* __restrict
       EOFX_LOAD_BH(q1, 0);
     }
     __syncthreads();
-#define EOFX_AXB_PAIR(pr_, pb)                                                                          \
-    do {                                                                                                \
-      /* pair ids of this, the next and the next-but-one pair (past the end: harmless re-reads of the last pair) */ \
-      const int q0 = EOFX_PAIR(pr_), p1 = EOFX_PAIR((pr_) + 1 < npair ? (pr_) + 1 : npair - 1);         \
-      const int p2 = EOFX_PAIR((pr_) + 2 < npair ? (pr_) + 2 : npair - 1);                              \
-      const int c2 = 2 * p1;                                                                            \
-      EOFX_STORE_BH(1 - (pb), 0);                                                                       \
-      EOFX_LOAD_BH(p1, 1);                                                                              \
-      EOFX_SLAB(a0, pb, 0, 2 * q0 + 1, c2);                                                             \
-      EOFX_STORE_BH(1 - (pb), 1);                                                                       \
-      EOFX_LOAD_BH(p2, 0);                                                                              \
-      EOFX_SLAB(a1, pb, 1, c2, c2 + 1);                                                                 \
-      __syncthreads();                                                                                  \
-    } while (0)
-    for (int pr = 0; pr < npair; pr += 2) {
-      EOFX_AXB_PAIR(pr, 0);
-      if (pr + 1 >= npair) break;
-      EOFX_AXB_PAIR(pr + 1, 1);
+    for (int pr = 0; pr < npair; ++pr) {
+      const int pb = pr & 1;
+      // pair ids of this, the next and the next-but-one pair (past the end: harmless re-reads of the last pair)
+      const int q0 = EOFX_PAIR(pr), p1 = EOFX_PAIR(pr + 1 < npair ? pr + 1 : npair - 1);
+      const int p2 = EOFX_PAIR(pr + 2 < npair ? pr + 2 : npair - 1);
+      const int c2 = 2 * p1;
+      EOFX_STORE_BH(1 - pb, 0);
+      EOFX_LOAD_BH(p1, 1);
+      EOFX_SLAB(a0, pb, 0, 2 * q0 + 1, c2);
+      EOFX_STORE_BH(1 - pb, 1);
+      EOFX_LOAD_BH(p2, 0);
+      EOFX_SLAB(a1, pb, 1, c2, c2 + 1);
+      __syncthreads();
     }
-#undef EOFX_AXB_PAIR
   }
 #undef EOFX_PAIR
 #undef EOFX_AXB_LD
