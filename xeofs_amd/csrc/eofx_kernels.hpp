@@ -1354,18 +1354,23 @@ __device__ __forceinline__ double rl_f64(double v, int lane) {   // broadcast of
 //   phase 1: blocked right-looking Cholesky (upper form A = R^T R), 8 rows per block: wave 0 factors the
 //            8-row panel in registers (v_readlane broadcasts, no barriers), then all four waves apply the rank-8 update to
 //            the trailing rows -- two barriers per block instead of two per column;
-//   phase 2: back substitution for X = R^-1 (R X = I), bottom row first; each wave owns 16 columns, lane
-//            (c, q) sums every fourth term, partials meet through quad shuffles -- no barriers at all.
+//   phase 2: X = R^-1 by 16 x 16 blocks: the four diagonal blocks by back substitution (wave 0, a column per lane in
+//            registers), then the blocks above the diagonal as small products, one block diagonal at a time
+//            (six barriers).  Round 4: 64 dependent steps took 29 of the kernel's 64 us (tools/probes/rinv_phase_probe.hip).
 // Rows / columns >= l are padded with the identity.  All sums run in a fixed order (deterministic).
 // d0_ext (optional): the ORIGINAL diagonal the dependency rule refers to, when G is a diagonal block of a blocked
 // factorisation (its own diagonal is a Schur complement by then); G / Rinv may then point into a larger matrix of leading
 // dimension L.
 __global__ __launch_bounds__(256) void chol_rinv_kernel(const double* __restrict__ G, int L, int l,
                                                          double* __restrict__ Rinv, double tol,
-                                                         const double* __restrict__ d0_ext = nullptr) {
+                                                         const double* __restrict__ d0_ext = nullptr,
+                                                         unsigned long long* __restrict__ prof = nullptr) {
+#define EOFX_RINV_T(i) do { if (prof && threadIdx.x == 0) prof[i] = wall_clock64(); } while (0)   /* tools/probes/rinv_phase_probe.hip */
+  EOFX_RINV_T(0);
   __shared__ double A[64][65];     // upper triangle: R[r][c], r < c (the diagonal is kept as 1/R[j][j] in pivs)
   __shared__ double X[64][65];     // R^-1 (upper triangle)
   __shared__ double d0s[64], pivs[64];
+  __shared__ double Tm[3][16][17];   // phase 2b: the inner sums of one block diagonal
   __shared__ int dead[64];
   const int tid = threadIdx.x;
   for (int i = tid; i < 64 * 64; i += 256) {
@@ -1380,83 +1385,111 @@ __global__ __launch_bounds__(256) void chol_rinv_kernel(const double* __restrict
     dead[tid] = 0;
   }
   __syncthreads();
+  EOFX_RINV_T(1);
+  // rows / columns >= l are identity padding: factoring them is harmless (pivot 1, zero row), so the panels are always
+  // full -- 8 rows, no bounds inside: straight-line code the scheduler can overlap across columns
   for (int jb = 0; jb < l; jb += 8) {
-    const int je = (jb + 8 < l) ? jb + 8 : l;
+    const int je = jb + 8;
+    unsigned long long tp0 = prof ? wall_clock64() : 0;
     if (tid < 64) {   // wave 0 factors rows jb .. je-1 of R in registers: lane c holds a[u] = A[jb+u][c];
                       // values cross lanes with v_readlane (uniform lane index), no LDS round trips
       const int c = tid;
       double a[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) a[u] = (jb + u < je) ? A[jb + u][c] : 0.0;
+      for (int u = 0; u < 8; ++u) a[u] = A[jb + u][c];
       const double d0c = d0s[c];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int j = jb + u;
-        if (j < je) {                                   // uniform
-          const double d = rl_f64(a[u], j);             // A[j][j] after the updates of all earlier rows
-          const double d0 = rl_f64(d0c, j);
-          const bool dj = !(d > tol * d0) || !(d0 > 0.0);   // numerically dependent column
-          double piv = __builtin_amdgcn_rsq(dj ? 1.0 : d);  // 1/sqrt(d): estimate + two Newton steps
-          piv = piv * (1.5 - 0.5 * d * piv * piv);
-          piv = piv * (1.5 - 0.5 * d * piv * piv);
-          if (dj) piv = 0.0;
-          if (c == j) {
-            dead[j] = dj;
-            pivs[j] = dj ? 1.0 : piv;
-          }
-          a[u] = (c > j) ? a[u] * piv : 0.0;            // R[j][c]
+        const double d = rl_f64(a[u], j);             // A[j][j] after the updates of all earlier rows
+        const double d0 = rl_f64(d0c, j);
+        const bool dj = !(d > tol * d0) || !(d0 > 0.0);   // numerically dependent column
+        double piv = __builtin_amdgcn_rsq(dj ? 1.0 : d);  // 1/sqrt(d): estimate + two Newton steps
+        piv = piv * (1.5 - 0.5 * d * piv * piv);
+        piv = piv * (1.5 - 0.5 * d * piv * piv);
+        if (dj) piv = 0.0;
+        if (c == j) {
+          dead[j] = dj;
+          pivs[j] = dj ? 1.0 : piv;
+        }
+        a[u] = (c > j) ? a[u] * piv : 0.0;            // R[j][c]
 #pragma unroll
-          for (int u2 = u + 1; u2 < 8; ++u2) {
-            const int r = jb + u2;
-            if (r < je) {
-              const double rjr = rl_f64(a[u], r);       // R[j][r] lives in lane r
-              if (c >= r) a[u2] -= rjr * a[u];
-            }
-          }
+        for (int u2 = u + 1; u2 < 8; ++u2) {
+          const double rjr = rl_f64(a[u], jb + u2);   // R[j][r] lives in lane r
+          if (c >= jb + u2) a[u2] -= rjr * a[u];
         }
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u)
-        if (jb + u < je && c > jb + u) A[jb + u][c] = a[u];
+        if (c > jb + u) A[jb + u][c] = a[u];
     }
     __syncthreads();
-    {                                                  // rank-(je-jb) update of the trailing rows r >= je
+    if (prof && tid == 0) prof[5] += wall_clock64() - tp0;
+    {                                                  // rank-8 update of the trailing rows r >= je: every wave walks the
+                                                       // same number of rows (uniform loop, unrolled: the LDS round trips of
+                                                       // four rows overlap); entries below the diagonal are not stored
       const int c = tid & 63;
-      if (c >= je) {
-        double rc[8];
+      double rc[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) rc[u] = (jb + u < je) ? A[jb + u][c] : 0.0;
-        for (int r = je + (tid >> 6); r <= c; r += 4) {
-          double s = 0.0;
+      for (int u = 0; u < 8; ++u) rc[u] = A[jb + u][c];
+#pragma unroll 4
+      for (int r = je + (tid >> 6); r < 64; r += 4) {
+        double s = 0.0;
 #pragma unroll
-          for (int u = 0; u < 8; ++u) s += ((jb + u < je) ? A[jb + u][r] : 0.0) * rc[u];
-          A[r][c] -= s;
-        }
+        for (int u = 0; u < 8; ++u) s += A[jb + u][r] * rc[u];
+        if (r <= c) A[r][c] -= s;
       }
     }
     __syncthreads();
   }
-  {
-    const int wave = tid >> 6, lane = tid & 63;
-    const int c = wave * 16 + (lane >> 2), q = lane & 3;
-    // rows / columns >= l are identity padding whose inverse nobody reads (the store below writes zeros there): a
-    // 30-column sketch walks 30 dependent steps, not 64
-    for (int r = l - 1; r >= 0; --r) {
+  EOFX_RINV_T(2);
+  if (tid < 64) {   // phase 2a: the four 16 x 16 diagonal blocks of X = R^-1 by back substitution, all in wave 0: lane (b, cc)
+                    // keeps column cc of block b in registers (fully unrolled: static indices), R comes from LDS as
+                    // broadcasts -- no shuffles, no fences; entries below the diagonal come out as exact zeros (2b reads them)
+    const int b16 = (tid >> 4) * 16, cc = tid & 15;
+    double x[16];
+#pragma unroll
+    for (int r = 15; r >= 0; --r) {
       double s = 0.0;
-#pragma unroll 4
-      for (int t = r + 1 + q; t <= c; t += 4) s += A[r][t] * X[t][c];
-      const double s1 = s + __shfl_xor(s, 1);          // (q0 + q1), (q2 + q3)
-      const double tot = s1 + __shfl_xor(s1, 2);       // ((q0 + q1) + (q2 + q3)) in every lane of the quad
-      if (q == 0) X[r][c] = (r <= c) ? (((r == c) ? 1.0 : 0.0) - tot) * pivs[r] : 0.0;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int t = r + 1; t < 16; ++t) s += A[b16 + r][b16 + t] * x[t];
+      x[r] = (r <= cc) ? (((r == cc) ? 1.0 : 0.0) - s) * pivs[b16 + r] : 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) X[b16 + r][b16 + cc] = x[r];
+  }
+  __syncthreads();
+  {   // phase 2b: the blocks above the diagonal, by distance d from it: X_ij = -X_ii (sum_{k = i+1 .. j} R_ik X_kj), every
+      // block a 16 x 16 x 16 product per term with one output per thread -- 64 dependent steps become 16 + six products
+    const int rr = tid >> 4, cc = tid & 15;
+    for (int d = 1; d < 4; ++d) {
+      for (int i = 0; i + d < 4; ++i) {
+        const int j = i + d;
+        double t = 0.0;
+        for (int k = i + 1; k <= j; ++k)
+#pragma unroll 16
+          for (int m = 0; m < 16; ++m) t += A[16 * i + rr][16 * k + m] * X[16 * k + m][16 * j + cc];
+        Tm[i][rr][cc] = t;
+      }
+      __syncthreads();
+      for (int i = 0; i + d < 4; ++i) {
+        const int j = i + d;
+        double x = 0.0;
+#pragma unroll 16
+        for (int m = 0; m < 16; ++m) x += X[16 * i + rr][16 * i + m] * Tm[i][m][cc];   // X_ii is upper triangular, zeros stored
+        X[16 * i + rr][16 * j + cc] = -x;
+      }
+      __syncthreads();
     }
   }
   __syncthreads();
+  EOFX_RINV_T(3);
   for (int i = tid; i < 64 * 64; i += 256) {
     const int r = i >> 6, c = i & 63;
     if (r < L && c < L) Rinv[(int64_t)r * L + c] = (r <= c && c < l && !dead[c]) ? X[r][c] : 0.0;
   }
+  EOFX_RINV_T(4);
+#undef EOFX_RINV_T
 }
 
 // ---------------------------------------------------------------------------------
