@@ -184,6 +184,9 @@ int eofx_mat_layout(const eofx_mat *m, int *layouts, int *has_raw);
  * run faster over it).  only_if_room: do nothing unless HBM holds one more copy of the field with 8 GB to spare;
  * *built (may be NULL) = 1 when the layout exists afterwards.  Masked in-place matrices are left as they are.        */
 int eofx_mat_ensure_sample_layout(eofx_ctx *ctx, eofx_mat *m, int only_if_room, int *built);
+/* The inverse: drop that layout again when the matrix can rebuild it (in-place / raw mode keeps the raw field and its
+ * map); the memory returns to the context's pool.  No-op for a matrix whose only data is that layout. */
+int eofx_mat_release_sample_layout(eofx_ctx *ctx, eofx_mat *m);
 
 /* ---- randomized SVD (the decomposer seam) ------------------------------
  * Replaces randomized_svd(X, n_components=k, random_state) at decomposer.py:146.

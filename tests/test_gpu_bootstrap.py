@@ -38,6 +38,7 @@ def test_eof_bootstrapper_vs_oracle(ctx):
     vals = orc.synthetic_field(120, 8, 10, rank=6, seed=3)[0].reshape(120, 8, 10)
     X = xe.DataArray(vals, dims=("time", "lat", "lon"))
     model = xe.single.EOF(n_modes=3, random_state=1).fit(X, "time")
+    had_layout = model.data["input_data"].has_sample_layout()
     bs = xe.validation.EOFBootstrapper(n_bootstraps=5, seed=11).fit(model, random_state=0)
     Xs = vals.reshape(120, -1).astype(np.float64)
     eof = orc.eof_fit(Xs, 3, random_state=1)
@@ -62,6 +63,8 @@ def test_eof_bootstrapper_vs_oracle(ctx):
     bs2 = xe.validation.EOFBootstrapper(n_bootstraps=5, seed=11).fit(model, random_state=0)
     assert np.array_equal(bs2.data["scores"], bs.data["scores"])
     assert (bs.explained_variance_ratio().values <= 1).all()
+    # the sample-contiguous copy the members run over is released again: the model's matrix keeps its footprint
+    assert model.data["input_data"].has_sample_layout() == had_layout
 
 
 def test_bootstrap_member_operator(ctx):

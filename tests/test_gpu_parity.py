@@ -399,7 +399,10 @@ def test_sharded_fused_first_pass_world1(ctx):
     assert np.array_equal(st["mean"], st2["mean"]) and st["total_variance"] == st2["total_variance"]
     out = sharded.sharded_eof_fit(ctx, X, comm, k, random_state=9)
     assert np.array_equal(out["components"], V2) and np.array_equal(out["norms"], s2.astype(np.float64))
-    mat.free(); mat2.free(); out["input_data"].free()
+    # a sketch handed over as a future (drawn on a worker thread) is the same fit
+    outf = sharded.sharded_eof_fit(ctx, X, comm, k, random_state=9, omega=engine.SketchFuture(n, k + 10, 9))
+    assert np.array_equal(outf["components"], V2) and np.array_equal(outf["norms"], out["norms"])
+    mat.free(); mat2.free(); out["input_data"].free(); outf["input_data"].free()
     Xn = X.clone()
     Xn[:, 100:140] = float("nan")
     mat3, st3, first3 = sharded.sharded_fit_first(ctx, Xn, comm, k, p, random_state=9)

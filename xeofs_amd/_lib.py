@@ -87,6 +87,7 @@ SIGNATURES = {
     "eofx_ctx_set_layout": (_int, [_vp, _int]),
     "eofx_mat_release_raw": (_int, [_vp, _vp]),
     "eofx_mat_ensure_sample_layout": (_int, [_vp, _vp, _int, _vp]),
+    "eofx_mat_release_sample_layout": (_int, [_vp, _vp]),
     "eofx_mat_masked": (_int, [_vp, C.POINTER(C.c_int), _pi64]),
     "eofx_mat_layout": (_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "eofx_panel_rownorm_f64": (_int, [_vp, _vp, _i64, _int, _vp]),

@@ -1268,6 +1268,17 @@ extern "C" int eofx_mat_ensure_sample_layout(eofx_ctx* ctx, eofx_mat* m, int onl
   if (built) *built = 1;
   return EOFX_OK;
 }
+// Drop the sample-contiguous layout of a matrix that can rebuild it (in-place / raw mode: the raw field and its map stay).
+// The memory goes back to the context's pool.  A matrix whose only data is that layout keeps it (EOFX_OK, nothing done).
+extern "C" int eofx_mat_release_sample_layout(eofx_ctx* ctx, eofx_mat* m) {
+  if (!ctx || !m) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  CHK(set_device(ctx));
+  if (!m->Xt || !(m->X || (m->raw && m->aff))) return EOFX_OK;
+  HIPCHK(hipStreamSynchronize(ctx->stream));   // kernels that read it may still be in flight
+  pool_give(ctx, m->Xt, (size_t)m->n_pad * m->p_pad * sizeof(float));
+  m->Xt = nullptr;
+  return EOFX_OK;
+}
 extern "C" int eofx_mat_masked(const eofx_mat* m, int* masked, int64_t* p_valid) {
   if (!m) return EOFX_ERR_ARG;
   if (masked) *masked = m->masked ? 1 : 0;

@@ -225,6 +225,11 @@ class ResidentMatrix:
                   self.ctx.handle)
         return bool(built.value)
 
+    def release_sample_layout(self):
+        """Drop the sample-contiguous layout again (a matrix that still holds the raw field and its map, or the other
+        layout, rebuilds it on demand); the memory returns to the context's pool."""
+        raise_for(self.ctx.lib.eofx_mat_release_sample_layout(self.ctx.handle, self.handle), self.ctx.handle)
+
     def release_raw(self):
         """Drop the reference to the raw field (raw / in-place mode); missing layouts are built first / on demand."""
         raise_for(self.ctx.lib.eofx_mat_release_raw(self.ctx.handle, self.handle), self.ctx.handle)

@@ -573,8 +573,10 @@ def sharded_eof_fit(ctx, X_local, comm: Comm, n_modes: int, center=True, standar
     mat, st, first = sharded_fit_first(ctx, X_local, comm, n_modes, p_raw_total, center, standardize, feature_weights,
                                        check_nans, True, n_oversamples, omega, random_state)
     ops = HipPanelOps(ctx, mat)
-    if omega is not None and omega.shape[0] != min(mat.n, st["p_total"]):
-        omega = None                            # samples / features dropped: the driver draws for the compacted shape
+    if omega is not None:     # an array or a SketchFuture (rows / size): its row count must match the compacted problem
+        om_rows = omega.rows if hasattr(omega, "result") else omega.shape[0]
+        if om_rows != min(mat.n, st["p_total"]):
+            omega = None                        # samples / features dropped: the driver draws for the compacted shape
     U, s, V = sharded_rsvd(ops, comm, n_modes, st["p_total"], st["p_offset"], n_oversamples, n_iter,
                            random_state=random_state, omega=omega, device_out=device_out, first=first)
     s64 = np.asarray(s, dtype=np.float64)

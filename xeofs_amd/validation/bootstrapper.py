@@ -42,7 +42,9 @@ class BootstrapOps(HipPanelOps):
     """Panel products of the bootstrap member X_b = H X on the resident X (H = G - 1 c^T / n, see the module docstring).
     Sample-side panels are indexed by draw; H and H^T are applied by two small HIP kernels (`eofx_panel_bootstrap_f32`:
     row gather / segment sums over the sorted draw + a rank-one term, float64 sums in draw order, no atomics), so a member
-    is reproducible bit for bit and its trace holds no library GEMM."""
+    is reproducible bit for bit ON A GIVEN LAYOUT of the matrix and its trace holds no library GEMM.  (The in-place route
+    maps the field with a fused multiply-add, the sample-contiguous copy was written with a multiply: one ulp apart when the
+    scale is not a power of two.  The bootstrapper builds that copy only where HBM has room, and releases it afterwards.)"""
 
     def __init__(self, ctx, mat, idx):
         super().__init__(ctx, mat)
@@ -110,21 +112,27 @@ class EOFBootstrapper(EOF):
         comps = np.empty((n_boot, p, k), np.float32)
         scores = np.empty((n_boot, n, k), np.float32)
         r2 = engine.sample_norms(ctx, mat) ** 2                        # |x_r|^2, once
+        built_here = False
         if n_boot >= 2:      # every member is a full decomposition of the same matrix: where HBM has room for the
-            mat.ensure_sample_layout(only_if_room=True)    # sample-contiguous layout, its X Y passes run 13 % faster over it
+            had = mat.has_sample_layout()                  # sample-contiguous layout, its X Y passes run 13 % faster over it
+            built_here = mat.ensure_sample_layout(only_if_room=True) and not had
         comm = _Solo()
-        for b in range(n_boot):
-            idx = rng.choice(n, n, replace=True)                       # bootstrapper.py:79
-            ops = BootstrapOps(ctx, mat, idx)
-            U, s, V = sharded_rsvd(ops, comm, k, p, 0, random_state=None if random_state is None else random_state + b)
-            s64 = s.astype(np.float64)
-            expvar[b] = s64 ** 2 / (n - 1)                             # eof.py:104
-            c = ops.counts.cpu().numpy()
-            totvar[b] = (float(c @ r2) - n * ops.mean_sumsq()) / (n - 1)
-            comps[b] = V
-            # bst_model.transform(input_data): centre with the member's mean, project (eof.py:123-132)
-            proj = engine.project(ctx, mat, V).astype(np.float64)
-            scores[b] = proj - (c @ proj) / n
+        try:
+            for b in range(n_boot):
+                idx = rng.choice(n, n, replace=True)                       # bootstrapper.py:79
+                ops = BootstrapOps(ctx, mat, idx)
+                U, s, V = sharded_rsvd(ops, comm, k, p, 0, random_state=None if random_state is None else random_state + b)
+                s64 = s.astype(np.float64)
+                expvar[b] = s64 ** 2 / (n - 1)                             # eof.py:104
+                c = ops.counts.cpu().numpy()
+                totvar[b] = (float(c @ r2) - n * ops.mean_sumsq()) / (n - 1)
+                comps[b] = V
+                # bst_model.transform(input_data): centre with the member's mean, project (eof.py:123-132)
+                proj = engine.project(ctx, mat, V).astype(np.float64)
+                scores[b] = proj - (c @ proj) / n
+        finally:
+            if built_here:   # the model's matrix goes back to the footprint it had; the layout is rebuilt on demand
+                mat.release_sample_layout()
         # sign of each member's modes from the correlation with the model's scores (bootstrapper.py:112-121)
         ms = np.asarray(model.data["scores"], dtype=np.float64)[:, :k]
         sc = scores.astype(np.float64)
