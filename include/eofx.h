@@ -259,6 +259,9 @@ int eofx_ctx_comm_clear(eofx_ctx *ctx);
 /* collectives issued on this context since the last call, their bytes, and (while eofx_ctx_profile is on) their
  * milliseconds from events on the context's stream; resets the counters */
 int eofx_ctx_comm_stats(eofx_ctx *ctx, int64_t *calls, int64_t *bytes, double *ms);
+/* one round of every collective the sharded fit uses (float32 sum / max / min, float64 sum, int32 max) on known values;
+ * *ok = 1 when all results are what `world` ranks must produce.  Collective: every rank of the communicator calls it. */
+int eofx_ctx_comm_selftest(eofx_ctx *ctx, int *ok);
 /* eofx_fit_f32 on this rank's slice [n x P_local] of a field with P_total features (arguments as there; omega: the global
  * sketch [n x (k + n_oversamples)], identical on every rank; needs n < P_total, i.e. the sketch on the sample side).
  * total_variance is the global one; mean / std / valid_feature / V are those of the slice.  Returns 0, or 1 when the

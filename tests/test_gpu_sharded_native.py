@@ -72,3 +72,24 @@ def test_sharded_entry_needs_a_communicator(ctx):
 
     with pytest.raises((EofxError, ValueError)):
         engine.fit_sharded(ctx, _field(), 4, 40 * 64, random_state=0)
+
+
+def test_comm_selftest(ctx):
+    """eofx_ctx_comm_selftest: every collective the sharded fit uses, on known values.  World 1 over RCCL passes; a callback
+    that reduces nothing passes at world 1 too (identity), one that claims two ranks without reducing is caught."""
+    from xeofs_amd import engine
+    from xeofs_amd._lib import EofxError
+
+    with pytest.raises((EofxError, ValueError)):
+        engine.comm_selftest(ctx)                    # nothing attached
+    engine.comm_init_rccl(ctx, engine.comm_unique_id(), 1, 0)
+    try:
+        assert engine.comm_selftest(ctx)
+        assert engine.comm_stats(ctx)["calls"] == 5
+    finally:
+        engine.comm_clear(ctx)
+    engine.comm_set_callback(ctx, lambda buf, count, dtype, op, stream: 0, 2, 0)    # "two ranks", no reduction
+    try:
+        assert not engine.comm_selftest(ctx)
+    finally:
+        engine.comm_clear(ctx)

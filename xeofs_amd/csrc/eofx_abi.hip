@@ -2731,6 +2731,45 @@ static int comm_vote(eofx_ctx* ctx, int local, int* global) {
   return EOFX_OK;
 }
 
+// One round of each collective the sharded fit uses, on known values: sum / max / min of float32, sum of float64, max of
+// int32 over {rank + 1}.  *ok = 1 when every result is what `world` ranks must produce.  Collective: every rank calls it.
+extern "C" int eofx_ctx_comm_selftest(eofx_ctx* ctx, int* ok) {
+  if (!ctx || !ok) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  *ok = 0;
+  if (!ctx->comm) return set_err(ctx, EOFX_ERR_ARG, "no communicator attached");
+  CHK(set_device(ctx));
+  CHK(arena_reserve(ctx, 4096));
+  ArenaScope scope(ctx);
+  ARENA(double, d, 8);
+  const int world = ctx->comm->world, rank = ctx->comm->rank;
+  const float vf = (float)(rank + 1);
+  const double vd = (double)(rank + 1);
+  const int vi = rank + 1;
+  float* f = reinterpret_cast<float*>(d);          // f[0] sum, f[1] max, f[2] min
+  double* dd = d + 2;                               // dd[0] sum
+  int* ii = reinterpret_cast<int*>(d + 4);         // ii[0] max
+  const float hf[3] = {vf, vf, vf};
+  HIPCHK(hipMemcpyAsync(f, hf, sizeof(hf), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(dd, &vd, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ii, &vi, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));       // the host sources are on this frame
+  CHK(comm_allreduce(ctx, f, 1, 0, 0));
+  CHK(comm_allreduce(ctx, f + 1, 1, 0, 1));
+  CHK(comm_allreduce(ctx, f + 2, 1, 0, 2));
+  CHK(comm_allreduce(ctx, dd, 1, 1, 0));
+  CHK(comm_allreduce(ctx, ii, 1, 2, 1));
+  float rf[3];
+  double rd;
+  int ri;
+  HIPCHK(hipMemcpyAsync(rf, f, sizeof(rf), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(&rd, dd, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(&ri, ii, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  const double tri = 0.5 * world * (world + 1);
+  *ok = rf[0] == (float)tri && rf[1] == (float)world && rf[2] == 1.f && rd == tri && ri == world;
+  return EOFX_OK;
+}
+
 extern "C" int eofx_fit_sharded_f32(eofx_ctx* ctx, const float* X, int64_t n, int64_t P, int64_t P_total, int center,
                                     int standardize, const double* feat_weights, int k, int n_oversamples, int n_iter,
                                     const float* omega, int64_t omega_rows, int flip, eofx_mat** out, double* mean,

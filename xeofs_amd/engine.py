@@ -486,6 +486,13 @@ def comm_clear(ctx: Context):
     ctx._comm_cb = None
 
 
+def comm_selftest(ctx: Context) -> bool:
+    """One round of every collective the sharded fit uses on known values (collective: every rank calls it)."""
+    ok = C.c_int()
+    raise_for(ctx.lib.eofx_ctx_comm_selftest(ctx.handle, C.byref(ok)), ctx.handle)
+    return bool(ok.value)
+
+
 def comm_stats(ctx: Context):
     """-> dict(calls, bytes, ms) of the collectives of the native sharded fit since the last call (ms: while profiling)"""
     calls, nbytes, ms = C.c_int64(), C.c_int64(), C.c_double()

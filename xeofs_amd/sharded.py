@@ -108,11 +108,37 @@ def attach_native(ctx, comm: Comm) -> bool:
     if not (dist.is_available() and dist.is_initialized()):
         return False
     world, rank = comm.world, comm.rank
+
+    def agreed(ok_local: bool) -> bool:      # every rank attaches, or none does: the fit's control flow is collective
+        flag = torch.tensor([1 if ok_local else 0], dtype=torch.int32,
+                            device=f"cuda:{ctx.device}" if dist.get_backend(comm.group) == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=comm.group)
+        return bool(int(flag.item()))
+
     if dist.get_backend(comm.group) == "nccl":
-        box = [engine.comm_unique_id() if rank == 0 else None]
+        try:
+            uid = engine.comm_unique_id() if rank == 0 else None
+        except Exception as e:              # librccl not loadable: the same on every rank of a node, the vote covers the rest
+            uid, err = None, e
+        box = [uid]
         dist.broadcast_object_list(box, src=0, group=comm.group)
-        engine.comm_init_rccl(ctx, box[0], world, rank)
-        return True
+        ok = False
+        if box[0] is not None:
+            try:
+                engine.comm_init_rccl(ctx, box[0], world, rank)
+                ok = engine.comm_selftest(ctx)
+            except Exception as e:
+                import warnings
+
+                warnings.warn(f"xeofs_amd: the engine's RCCL communicator is not usable ({e}); "
+                              "the sharded fit takes the panel-level driver over torch.distributed")
+        if agreed(ok):
+            return True
+        try:
+            engine.comm_clear(ctx)
+        except Exception:
+            pass
+        return False
     ops = {0: dist.ReduceOp.SUM, 1: dist.ReduceOp.MAX, 2: dist.ReduceOp.MIN}
     types = {0: "<f4", 1: "<f8", 2: "<i4"}
 
@@ -126,7 +152,10 @@ def attach_native(ctx, comm: Comm) -> bool:
         return 0
 
     engine.comm_set_callback(ctx, allreduce, world, rank)
-    return True
+    if agreed(engine.comm_selftest(ctx)):
+        return True
+    engine.comm_clear(ctx)
+    return False
 
 
 class HipPanelOps:
@@ -208,6 +237,8 @@ def _resolve_sketch(k, r, n_oversamples, omega, random_state):
     l = min(l_req, r)
     if omega is None:
         omega = sketch_matrix(r, l_req, random_state)
+    elif hasattr(omega, "result"):          # an engine.SketchFuture: joined here
+        omega = omega.result()
     omega = np.ascontiguousarray(omega[:, :l], dtype=np.float32)
     if l == r:
         omega = np.eye(r, dtype=np.float32)
