@@ -1748,7 +1748,7 @@ static int panel_mul(eofx_ctx* ctx, const eofx_mat* m, const float* Yp, float* W
       (void)hipGetLastError();
   }
   if (!m->Xt && m->raw && m->aff && prec == EOFX_PREC_F16X3 &&
-      round_up(m->p, AXB_KG) * (int64_t)L < ((int64_t)1 << 31) &&
+      round_up(m->p, AXB_KG) * (int64_t)L < ((int64_t)1 << 30) &&       // the kernel's 32-bit BYTE offsets into the panel
       64 * m->raw_ld + round_up(m->p, AXB_KG) < ((int64_t)1 << 30)) {   // in place: stream the raw field along its rows
     CHK(ensure_active_pairs(ctx, m));
     return launch_axb(ctx, m->raw, m->raw_ld, m->n, m->p, m->n_pad, m->aff, m->p_pad, m->absmax, Yp, L, Wn, m->masked, m->act,
