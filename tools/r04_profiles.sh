@@ -5,7 +5,8 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r04final; rm -rf $O; mkdir -p $O
 export TMPDIR=/tmp
-S=$(date +%s); python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_full_driver_command.json 2> $O/bench_full.err; echo "bench rc=$? wall=$(( $(date +%s) - S ))s" | tee $O/summary.txt
+timeout 2400 python -m pytest tests -x -q -m gpu > $O/pytest_gpu.txt 2>&1; echo "pytest rc=$?" | tee $O/summary.txt; grep -h "passed\|failed" $O/pytest_gpu.txt | tail -2
+S=$(date +%s); python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_full_driver_command.json 2> $O/bench_full.err; echo "bench rc=$? wall=$(( $(date +%s) - S ))s" | tee -a $O/summary.txt
 cd /tmp
 timeout 900 rocprofv3 --kernel-trace --stats -d $O/trace -o p --output-format csv -- python $R/bench.py --no-traffic --no-cpu-baseline --no-configs --steps 4 --warmup 2 > $O/bench_under_rocprof.json 2> $O/trace.err
 cd $R
@@ -38,4 +39,6 @@ for set in "FETCH_SIZE" "WRITE_SIZE" \
   rm -rf $O/pmc$i $O/pmc${i}_full.txt
 done
 python $R/tools/pca_probe.py > $O/pca_probe.txt 2>&1
+python $R/bench.py --nlon 180 --no-traffic --no-cpu-baseline --no-configs --steps 20 --warmup 5 > $O/eighth.json 2> $O/eighth.err
+$R/build/rinv_phase_probe > $O/rinv_phases_now.txt 2>&1
 ls -la $O
