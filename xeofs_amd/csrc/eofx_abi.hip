@@ -5,6 +5,10 @@
 #include "eofx_kernels.hpp"
 #include "eofx_fit.hpp"
 #include "eofx_gram.hpp"
+#include "eofx_axb_dma.hpp"
+#ifndef EOFX_AXB_DMA_DEFAULT
+#define EOFX_AXB_DMA_DEFAULT 0
+#endif
 
 #if !defined(__HIP_DEVICE_COMPILE__)
 #include <immintrin.h>
@@ -121,6 +125,10 @@ struct eofx_ctx {
     int2* tiles = nullptr;
   };
   std::vector<GramPlanDev*> gram_plans;
+  // fp16 planes of the panel an in-place X Y product reads (eofx_axb_dma.hpp): one grow-only buffer per context
+  _Float16* axb_planes = nullptr;
+  size_t axb_planes_bytes = 0;
+  int axb_dma = -1;   // -1 not decided, 0 off, 1 on (EOFX_AXB_DMA)
   // the last eofx_fit_f32: [0] 1 when the statistics rode on the first pass, [1] ms of the non-pass work of the
   // fused preprocessor (probe, finalize, correction; HIP events, only with profiling on), [2] fallback reason
   double fit_info[4] = {0.0, 0.0, 0.0, 0.0};
@@ -264,6 +272,7 @@ extern "C" int eofx_ctx_destroy(eofx_ctx* ctx) {
     hipfftDestroy((hipfftHandle)e.second.second);
   }
   (void)eofx_ctx_comm_clear(ctx);
+  if (ctx->axb_planes) (void)hipFree(ctx->axb_planes);
   for (auto* g : ctx->gram_plans) {
     if (g->items) (void)hipFree(g->items);
     if (g->tiles) (void)hipFree(g->tiles);
@@ -835,7 +844,49 @@ static int launch_axb(eofx_ctx* ctx, const float* raw, int64_t ld, int64_t rows,
     HIPCHK(hipEventRecord(ev0, ctx->stream));
   }
   const int gx = plan.S > 1 ? 8 * rt * ((plan.S + 7) / 8) : rt;
-  if (nfull > 0) {
+  if (ctx->axb_dma < 0) {
+    const char* ev = std::getenv("EOFX_AXB_DMA");
+    ctx->axb_dma = ev ? (atoi(ev) != 0) : EOFX_AXB_DMA_DEFAULT;
+  }
+  if (ctx->axb_dma) {   // the B panel as fp16 planes, moved by LDS-DMA (eofx_axb_dma.hpp); same bits in W
+    const int ncb = nfull + (rem ? 1 : 0);
+    const size_t need = (size_t)ncb * (size_t)(K_all / AXB_KG) * AXB_PAIR_BYTES;
+    if (ctx->axb_planes_bytes < need) {
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      if (ctx->axb_planes) (void)hipFree(ctx->axb_planes);
+      ctx->axb_planes = nullptr;
+      ctx->axb_planes_bytes = 0;
+      if (hipMalloc((void**)&ctx->axb_planes, need) != hipSuccess) {
+        (void)hipGetLastError();
+        return set_err(ctx, EOFX_ERR_NOMEM, "cannot allocate the panel planes of the in-place product (%.2f GB)", need / 1e9);
+      }
+      ctx->axb_planes_bytes = need;
+    }
+    hipLaunchKernelGGL(axb_bsplit_kernel, dim3((unsigned)((K_all + 31) / 32), ncb), dim3(256), 0, ctx->stream, Y, L, L, K_all, bmax,
+                       ctx->axb_planes);
+    KCHK();
+    const int64_t pairs_all = K_all / AXB_KG;
+    if (nfull > 0) {
+      if (masked)
+        hipLaunchKernelGGL((axb_f16_dma_kernel<4, 0, true>), dim3(gx, nfull), dim3(256), 0, ctx->stream, raw, ld, (int)rows, cols, aff,
+                           aff_ld, ctx->axb_planes, pairs_all, out, L, rows_pad, K, plan.kps, plan.S, rt, 0, a_scale, bmax, act);
+      else
+        hipLaunchKernelGGL((axb_f16_dma_kernel<4, 0, false>), dim3(gx, nfull), dim3(256), 0, ctx->stream, raw, ld, (int)rows, cols, aff,
+                           aff_ld, ctx->axb_planes, pairs_all, out, L, rows_pad, K, plan.kps, plan.S, rt, 0, a_scale, bmax,
+                           (const int*)nullptr);
+      KCHK();
+    }
+    if (rem) {
+      if (masked)
+        hipLaunchKernelGGL((axb_f16_dma_kernel<2, 0, true>), dim3(gx, 1), dim3(256), 0, ctx->stream, raw, ld, (int)rows, cols, aff,
+                           aff_ld, ctx->axb_planes, pairs_all, out, L, rows_pad, K, plan.kps, plan.S, rt, nfull * 64, a_scale, bmax, act);
+      else
+        hipLaunchKernelGGL((axb_f16_dma_kernel<2, 0, false>), dim3(gx, 1), dim3(256), 0, ctx->stream, raw, ld, (int)rows, cols, aff,
+                           aff_ld, ctx->axb_planes, pairs_all, out, L, rows_pad, K, plan.kps, plan.S, rt, nfull * 64, a_scale, bmax,
+                           (const int*)nullptr);
+      KCHK();
+    }
+  } else if (nfull > 0) {
     if (masked)
       hipLaunchKernelGGL((axb_f16_kernel<4, 0, true>), dim3(gx, nfull), dim3(256), 0, ctx->stream, raw, ld, (int)rows, cols, aff, aff_ld, Y,
                          L, out, L, rows_pad, K, plan.kps, plan.S, rt, 0, a_scale, bmax, act);
@@ -844,7 +895,7 @@ static int launch_axb(eofx_ctx* ctx, const float* raw, int64_t ld, int64_t rows,
                          L, rows_pad, K, plan.kps, plan.S, rt, 0, a_scale, bmax);
     KCHK();
   }
-  if (rem) {
+  if (!ctx->axb_dma && rem) {
     if (masked)
       hipLaunchKernelGGL((axb_f16_kernel<2, 0, true>), dim3(gx, 1), dim3(256), 0, ctx->stream, raw, ld, (int)rows, cols, aff, aff_ld, Y, L,
                          out, L, rows_pad, K, plan.kps, plan.S, rt, nfull * 64, a_scale, bmax, act);
