@@ -14,7 +14,7 @@ On one GPU that is ONE engine call (eofx_fit_f32): the statistics ride on the fi
 value = algorithmic SVD bytes (16 * n * p * 4 B, the reference's 16 GEMM passes) / step time.
 
 One JSON line on rank 0; see the task contract for the fields.  Extra objects:
-  roofline      the streaming kernels (atb_f16_kernel / atb_f16_fit_kernel for X^T Z, axb_f16_kernel for X Y):
+  roofline      the streaming kernels (atb_f16_kernel / atb_f16_fit_kernel for X^T Z, axb_f16_dma_kernel for X Y):
                 algorithmic bytes per launch (n p_local 4 B) / mean launch duration from HIP events on the launch stream.
   cpu_baseline  the oracle's sklearn-restated randomized_svd (oracle/, "port") timed on the host cores on a
                 bounded sample (the workload's n and k on half of its grid, fp32); "f64": the same kernel in
@@ -499,7 +499,8 @@ def measure_traffic(args, n, P):
         return None, None, "this process already runs under a profiler"
     me = os.path.abspath(__file__)
     names = {"atb_f16_kernel<": "atb_f16_kernel<2,true>", "atb_f16_fit_kernel<": "atb_f16_fit_kernel<2>",
-             "axb_f16_kernel<": "axb_f16_kernel<4>"}
+             "axb_f16_kernel<": "axb_f16_kernel<4>", "axb_f16_dma_kernel<": "axb_f16_dma_kernel<4>",
+             "axb_bsplit_kernel": "axb_bsplit_kernel"}
     got = {}
     env = dict(os.environ, TMPDIR="/tmp")
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -531,6 +532,8 @@ def measure_traffic(args, n, P):
         by[label] = round((2.0 * got["FETCH_SIZE"][label] + got["WRITE_SIZE"].get(label, 0.0)) * 1000.0)
     # mean over the 16 passes of a fit: 7 atb + 1 fit (or 8 atb in the two-step form) + 8 axb
     a, f, x = by.get("atb_f16_kernel<2,true>"), by.get("atb_f16_fit_kernel<2>"), by.get("axb_f16_kernel<4>")
+    if by.get("axb_f16_dma_kernel<4>") is not None:     # the X Y pass = the split of the panel into fp16 planes + the kernel
+        x = by["axb_f16_dma_kernel<4>"] + by.get("axb_bsplit_kernel", 0)
     if a is None or x is None:
         return None, by, "a streaming kernel is missing from the counter rows"
     per = (7 * a + (f if f is not None else a) + 8 * x) / 16.0
@@ -808,7 +811,8 @@ def main():
         roofline = {
             "kernel": ({"inplace": "the streaming kernels of the in-place layout, mean over all 16 passes: atb_f16_kernel<2,true> "
                                    "(X^T Z, 8 passes; the first one is atb_f16_fit_kernel<2>, which also takes the column "
-                                   "statistics) and axb_f16_kernel<4> (X Y, 8 passes), both over the raw field through "
+                                   "statistics) and axb_f16_dma_kernel<4> (X Y, 8 passes; its launch time includes axb_bsplit_kernel, "
+                                   "the panel's split into fp16 planes), both over the raw field through "
                                    "the Scaler map, scaled split-fp16 MFMA; per kernel in `by_kernel`",
                         "raw": "atb_f16_kernel<2, true|false> (C = A^T B, scaled split-fp16 MFMA 32x32x16, all 16 passes: 8 over "
                                "the raw field through the Scaler map, 8 over the sample-contiguous layout; mean over all)",
@@ -824,7 +828,7 @@ def main():
         }
     if prof.get("by_kernel"):
         names = {"atb": "atb_f16_kernel (X^T Z" + ("" if args.layout == "inplace" else " and X Y") + ")",
-                 "axb": "axb_f16_kernel (X Y, in place)"}
+                 "axb": "axb_f16_dma_kernel + axb_bsplit_kernel (X Y, in place)"}
         roofline["by_kernel"] = {names[kk]: {"launches": v["launches"], "mean_launch_ms": round(v["ms"] / v["launches"], 4),
                                              "GBps": round(alg_bytes_launch / (v["ms"] / v["launches"] * 1e-3) / 1e9, 1)}
                                  for kk, v in prof["by_kernel"].items()}

@@ -1,0 +1,141 @@
+"""axb_f16_dma_kernel (xeofs_amd/csrc/eofx_axb_dma.hpp) keeps its loads and LDS traffic out of the compiler's sight: they are
+inline assembly with hand-counted waits, and the loads land in registers above amdgpu_num_vgpr(176).  That contract can be
+checked without a GPU, on the assembly hipcc emits for gfx950:
+
+* the compiler's own code never names v176 or above (the landing registers are the kernel's alone),
+* inside the pair loop the compiler issues no memory instruction of its own apart from the LDS-DMA builtin, and no vmcnt
+  wait (every wait is one of the hand-written ones, with the counts the header derives),
+* no scratch, no AccVGPRs, 253 registers in the kernel descriptor (two workgroups per CU).
+
+A compiler that starts doing any of this differently would corrupt data silently on the GPU; here it fails loudly first
+(the bit-for-bit GPU test against axb_f16_kernel is the other half)."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+SRC = r'''
+#include <hip/hip_runtime.h>
+#include "eofx_kernels.hpp"
+#include "eofx_axb_dma.hpp"
+#define INST(NQ, MASK) template __global__ void eofx::axb_f16_dma_kernel<NQ, 0, MASK>(const float*, int64_t, int, int64_t, \
+    const float*, int64_t, const _Float16*, int64_t, float*, int, int64_t, int64_t, int64_t, int, int, int, float, const float*, const int*);
+INST(4, false) INST(4, true) INST(2, false) INST(2, true)
+'''
+
+
+@pytest.fixture(scope="module")
+def kernels(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("no hipcc")
+    d = tmp_path_factory.mktemp("axb_dma_isa")
+    (d / "t.hip").write_text(SRC)
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-I",
+           os.path.join(ROOT, "xeofs_amd", "csrc"), "-S", "--cuda-device-only", str(d / "t.hip"), "-o", str(d / "t.s")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    text = (d / "t.s").read_text().split("\n")
+    out = {}
+    starts = [i for i, l in enumerate(text) if re.match(r"^_ZN4eofx18axb_f16_dma_kernel\w+:", l)]
+    assert len(starts) == 4
+    for st in starts:
+        en = next(i for i in range(st, len(text)) if text[i].strip().startswith(".amdhsa_kernel"))
+        desc_end = next(i for i in range(en, len(text)) if text[i].strip().startswith(".end_amdhsa_kernel"))
+        out[text[st].rstrip(":").split()[0]] = (text[st:en], text[en:desc_end])
+    return out
+
+
+def _walk(lines):
+    """-> list of (text, in_asm, in_loop) for every instruction line"""
+    res, in_asm, in_loop = [], False, False
+    for l in lines:
+        s = l.strip()
+        if "Inner Loop Header" in l:
+            in_loop = True
+        if "ASMSTART" in s:
+            in_asm = True
+            continue
+        if "ASMEND" in s:
+            in_asm = False
+            continue
+        if not s or s.startswith(";") or s.startswith("."):
+            continue
+        res.append((s, in_asm, in_loop))
+    return res
+
+
+def test_the_compiler_stays_out_of_the_landing_registers(kernels):
+    for name, (body, _) in kernels.items():
+        for s, in_asm, _loop in _walk(body):
+            if in_asm:
+                continue
+            for m in re.finditer(r"v\[(\d+):(\d+)\]|\bv(\d+)\b", s):
+                hi = int(m.group(2)) if m.group(2) else int(m.group(3))
+                assert hi < 176, (name, s)
+            assert "accvgpr" not in s and "scratch_" not in s, (name, s)
+
+
+def test_no_compiler_memory_traffic_or_vmcnt_wait_in_the_pair_loop(kernels):
+    for name, (body, _) in kernels.items():
+        ins = _walk(body)
+        loop = [(s, a) for s, a, lp in ins if lp]
+        assert loop, name
+        # the pair loop ends at the hand-written drain (the last vmcnt wait in front of the epilogue's stores)
+        first_store = next(i for i, (s, a) in enumerate(loop) if s.startswith("global_store"))
+        end = max(i for i, (s, a) in enumerate(loop[:first_store]) if a and s.startswith("s_waitcnt vmcnt")) + 1
+        mine = []
+        for s, in_asm in loop[:end]:
+            if in_asm:
+                if s.startswith("s_waitcnt vmcnt"):
+                    mine.append(int(re.search(r"vmcnt\((\d+)\)", s).group(1)))
+                continue
+            assert not s.startswith("s_waitcnt vmcnt"), (name, s)
+            if s.startswith(("global_load", "buffer_", "flat_", "s_load", "s_buffer_load")):
+                assert s.startswith("global_load_lds_dwordx4"), (name, s)
+        # the hand-written waits of one pair: triples 13 / 8, the four half-slabs 23, the barrier 22 (0 for a wave without rows),
+        # and the final drain
+        assert sorted(set(mine)) == [0, 8, 13, 22, 23], (name, mine)
+        assert mine.count(23) == 4 and mine.count(13) == 1 and mine.count(8) == 1, (name, mine)
+
+
+def test_register_budget(kernels):
+    for name, (_, desc) in kernels.items():
+        d = "\n".join(desc)
+        assert re.search(r"\.amdhsa_next_free_vgpr\s+253\b", d), name        # v0 .. v252: two workgroups of 256 per CU
+        assert re.search(r"\.amdhsa_accum_offset\s+25[36]\b", d), name       # no AccVGPRs behind them
+        assert re.search(r"\.amdhsa_private_segment_fixed_size\s+0\b", d), name
+        assert re.search(r"\.amdhsa_group_segment_fixed_size\s+65536\b", d), name
+
+
+def test_no_fragment_register_is_touched_between_its_read_and_its_wait(kernels):
+    """ds_read_b128 results (inline assembly) are only valid after the hand-written lgkmcnt wait that names them: no
+    compiler-generated instruction may read or move such a register in between."""
+    def regs(tok):
+        out = set()
+        for m in re.finditer(r"v\[(\d+):(\d+)\]|\bv(\d+)\b", tok):
+            out |= set(range(int(m.group(1)), int(m.group(2)) + 1)) if m.group(1) else {int(m.group(3))}
+        return out
+
+    for name, (body, _) in kernels.items():
+        pending = set()
+        nreads = 0
+        for s, in_asm, in_loop in _walk(body):
+            if not in_loop:
+                continue
+            if in_asm and s.startswith("ds_read_b128"):
+                pending |= regs(s.split(",")[0])
+                nreads += 1
+            elif in_asm and s.startswith("s_waitcnt lgkmcnt(0)"):
+                pending.clear()
+            elif in_asm and s.startswith("s_waitcnt lgkmcnt"):
+                pass          # the first set is released; the check stays conservative and keeps all of them pending
+            elif not in_asm and pending:
+                ops = s.split(None, 1)
+                if len(ops) == 2 and not s.startswith("v_mfma"):
+                    assert not (regs(ops[1]) & pending), (name, s)
+        assert nreads >= 24, (name, nreads)

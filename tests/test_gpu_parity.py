@@ -902,3 +902,39 @@ def test_peaked_spectrum_float64_passes(ctx, peak):
     # the default split-fp16 passes stay inside the tolerance too: the drivers detect the peaked spectrum after the
     # first iteration and keep re-normalising the tall panel (eofx_peaked_spectrum)
     assert err_def <= 1e-5, (so[0] / so[-1], err64, err_def)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,P,L,masked", [(1000, 4096, 64, False), (700, 3000, 96, False), (515, 8200, 32, False),
+                                          (900, 6400, 64, True), (333, 5000, 96, True)])
+def test_axb_dma_kernel_equals_the_register_path_bit_for_bit(monkeypatch, n, P, L, masked):
+    """The in-place X Y product with the B slab moved by LDS-DMA (eofx_axb_dma.hpp: every load and LDS access of its pair
+    loop is hand-scheduled inline assembly) against axb_f16_kernel, which leaves the scheduling to the compiler: same
+    arithmetic in the same order, so the SAME BITS -- full and partial row tiles, a 32-column remainder, feature counts that
+    are not multiples of 64, and a land mask (zero columns + the active-pair list)."""
+    import torch
+    from xeofs_amd import engine
+
+    rng = np.random.default_rng(n + P)
+    X = (280.0 + 5.0 * rng.standard_normal((n, P))).astype(np.float32)
+    if masked:
+        land = np.zeros(P, bool)
+        land[500:1900] = True            # whole 64-feature pairs without a valid feature, and ragged edges
+        land[rng.integers(0, P, 200)] = True
+        X[:, land] = np.nan
+    Xd = torch.as_tensor(X, device="cuda")
+    outs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("EOFX_AXB_DMA", flag)
+        c = engine.Context(0)            # the switch is read by a context at its first in-place product
+        mat, st = engine.preprocess(c, Xd, in_place=True, allow_masked=masked)
+        assert mat.masked == masked
+        Y = torch.zeros((mat.p_pad, L), dtype=torch.float32, device="cuda")
+        Yh = rng.standard_normal((mat.p, L)).astype(np.float32)
+        Y[: mat.p_phys if masked else mat.p] = torch.as_tensor(mat.scatter_rows(Yh) if masked else Yh, device="cuda")
+        W = engine.panel_mul(c, mat, Y, prec="f16x3")
+        torch.cuda.synchronize()
+        outs.append(W.cpu().numpy().view(np.uint32).copy())
+        mat.free()
+    assert np.array_equal(outs[0], outs[1])
+    assert np.isfinite(outs[1].view(np.float32)).all() and np.abs(outs[1].view(np.float32)[:n]).max() > 0

@@ -39,6 +39,7 @@ __global__ void fill_kernel(float* p, size_t n, float lo, float hi, unsigned see
 }
 
 // the LDS-DMA variant (eofx_axb_dma.hpp): split pass + kernel, timed apart; C compared bit for bit with axb_f16_kernel's
+template <int DD>
 static void run_dma(const float* A, int64_t ld, int n, const float* aff, const float* B, float* C, float* Cref, int64_t rows_pad, int S,
                     const float* bmax, _Float16* planes) {
   const int64_t K = ld;
@@ -55,7 +56,7 @@ static void run_dma(const float* A, int64_t ld, int n, const float* aff, const f
     CK(hipEventRecord(e0));
     hipLaunchKernelGGL(axb_bsplit_kernel, dim3((unsigned)((K + 31) / 32), 1), dim3(256), 0, 0, B, 64, 64, K, bmax, planes);
     CK(hipEventRecord(e1));
-    hipLaunchKernelGGL((axb_f16_dma_kernel<4, 0, false>), grid, dim3(256), 0, 0, A, ld, n, ld, aff, ld, (const _Float16*)planes, K / 64, C, 64, rows_pad, K,
+    hipLaunchKernelGGL((axb_f16_dma_kernel<4, DD, false>), grid, dim3(256), 0, 0, A, ld, n, ld, aff, ld, (const _Float16*)planes, K / 64, C, 64, rows_pad, K,
                        kps, s_eff, rt, 0, 512.0f, bmax, (const int*)nullptr);
     CK(hipEventRecord(e2)); CK(hipEventSynchronize(e2));
     float a, b; CK(hipEventElapsedTime(&a, e0, e1)); CK(hipEventElapsedTime(&b, e1, e2));
@@ -65,7 +66,7 @@ static void run_dma(const float* A, int64_t ld, int n, const float* aff, const f
   std::vector<unsigned> h0(cn), h1(cn);
   CK(hipMemcpy(h0.data(), Cref, cn * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(h1.data(), C, cn * 4, hipMemcpyDeviceToHost));
   size_t diff = 0; for (size_t i = 0; i < cn; ++i) diff += h0[i] != h1[i];
-  printf("DMA     splits %3d: split pass %.3f ms + kernel %.3f ms = %.3f ms -> %.0f GB/s | words that differ from axb_f16_kernel: %zu of %zu\n", s_eff,
+  printf("DMA %3d splits %3d: split pass %.3f ms + kernel %.3f ms = %.3f ms -> %.0f GB/s | words that differ from axb_f16_kernel: %zu of %zu\n", DD, s_eff,
          best_s, best_k, best_s + best_k, (double)n * ld * 4 / (best_s + best_k) / 1e6, diff, cn);
 }
 
@@ -89,7 +90,7 @@ int main(int argc, char** argv) {
   const float one = 1.f; CK(hipMemcpy(bmax, &one, 4, hipMemcpyHostToDevice));
   for (int S : {96}) {
     run<0>(A, ld, n, aff, B, C, rows_pad, S, bmax);
-    run_dma(A, ld, n, aff, B, C, Cref, rows_pad, S, bmax, planes);
+    run_dma<0>(A, ld, n, aff, B, C, Cref, rows_pad, S, bmax, planes);
     run<1>(A, ld, n, aff, B, C, rows_pad, S, bmax);
     run<3>(A, ld, n, aff, B, C, rows_pad, S, bmax);
     run<7>(A, ld, n, aff, B, C, rows_pad, S, bmax);
@@ -98,7 +99,7 @@ int main(int argc, char** argv) {
     run<20>(A, ld, n, aff, B, C, rows_pad, S, bmax);
     run<32>(A, ld, n, aff, B, C, rows_pad, S, bmax);
     run<0>(A, ld, n, aff, B, C, rows_pad, S, bmax);
-    run_dma(A, ld, n, aff, B, C, Cref, rows_pad, S, bmax, planes);
+    run_dma<0>(A, ld, n, aff, B, C, Cref, rows_pad, S, bmax, planes);
   }
   return 0;
 }

@@ -7,7 +7,7 @@
 #include "eofx_gram.hpp"
 #include "eofx_axb_dma.hpp"
 #ifndef EOFX_AXB_DMA_DEFAULT
-#define EOFX_AXB_DMA_DEFAULT 0
+#define EOFX_AXB_DMA_DEFAULT 1
 #endif
 
 #if !defined(__HIP_DEVICE_COMPILE__)

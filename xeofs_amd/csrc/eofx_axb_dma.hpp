@@ -304,38 +304,40 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(176))) void 
   // 32 rows x NQ column tiles.  Reads in two sets (lo A + hi B first: the first MFMA group needs only those), each wait
   // names the registers it releases so that no MFMA can be scheduled above it.  LDS operations of a wave complete in
   // order: lgkmcnt(2 + NQ) after both sets = the first set has landed (an outstanding scalar load only makes it stricter).
+#define EOFX_AXB_BHI(boff, hs)       /* the hi-plane B fragments (issuing them ahead of the conversion was slower: 7.24 vs 7.13 ms) */ \
+  _Pragma("unroll") for (int q = 0; q < NQ; ++q) { const unsigned ad_ = bs_r[q] + (boff); EOFX_DSR128(bfh_[q], ad_, 4096 * (hs)); }
 #define EOFX_AXB_MFMA(jh, boff, hs)                                                                    \
   do {                                                                                                 \
-    f16x8 af_[2][2], bf_[2][NQ];                                                                       \
+    f16x8 af_[2][2], bfh_[NQ], bfl_[NQ];                                                                       \
     EOFX_DSR128(af_[0][1], as_r, 4096 + 1024 * (2 * (jh)));                                            \
     EOFX_DSR128(af_[1][1], as_r, 4096 + 1024 * (2 * (jh) + 1));                                        \
-    _Pragma("unroll") for (int q = 0; q < NQ; ++q) { const unsigned ad_ = bs_r[q] + (boff); EOFX_DSR128(bf_[0][q], ad_, 4096 * (hs)); } \
+    EOFX_AXB_BHI(boff, hs)                                                                             \
     EOFX_DSR128(af_[0][0], as_r, 1024 * (2 * (jh)));                                                   \
     EOFX_DSR128(af_[1][0], as_r, 1024 * (2 * (jh) + 1));                                               \
-    _Pragma("unroll") for (int q = 0; q < NQ; ++q) { const unsigned ad_ = bs_r[q] + (boff); EOFX_DSR128(bf_[1][q], ad_, 8192 + 4096 * (hs)); } \
+    _Pragma("unroll") for (int q = 0; q < NQ; ++q) { const unsigned ad_ = bs_r[q] + (boff); EOFX_DSR128(bfl_[q], ad_, 8192 + 4096 * (hs)); } \
     if constexpr (NQ == 4)                                                                             \
-      asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(af_[0][1]), "+v"(af_[1][1]), "+v"(bf_[0][0]), "+v"(bf_[0][1]), "+v"(bf_[0][2]), "+v"(bf_[0][3]) : : "memory"); \
+      asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(af_[0][1]), "+v"(af_[1][1]), "+v"(bfh_[0]), "+v"(bfh_[1]), "+v"(bfh_[2]), "+v"(bfh_[3]) : : "memory"); \
     else                                                                                               \
-      asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(af_[0][1]), "+v"(af_[1][1]), "+v"(bf_[0][0]), "+v"(bf_[0][1]) : : "memory"); \
+      asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(af_[0][1]), "+v"(af_[1][1]), "+v"(bfh_[0]), "+v"(bfh_[1]) : : "memory"); \
     if (DBG & 1) {                                                                                     \
       if constexpr (NQ == 4)                                                                           \
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af_[0][0]), "+v"(af_[1][0]), "+v"(bf_[1][0]), "+v"(bf_[1][1]), "+v"(bf_[1][2]), "+v"(bf_[1][3]) : : "memory"); \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af_[0][0]), "+v"(af_[1][0]), "+v"(bfl_[0]), "+v"(bfl_[1]), "+v"(bfl_[2]), "+v"(bfl_[3]) : : "memory"); \
       else                                                                                             \
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af_[0][0]), "+v"(af_[1][0]), "+v"(bf_[1][0]), "+v"(bf_[1][1]) : : "memory"); \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af_[0][0]), "+v"(af_[1][0]), "+v"(bfl_[0]), "+v"(bfl_[1]) : : "memory"); \
       _Pragma("unroll") for (int q = 0; q < NQ; ++q) _Pragma("unroll") for (int j = 0; j < 2; ++j)     \
           _Pragma("unroll") for (int r = 0; r < 4; ++r) acc[2 * (jh) + j][q][r] +=                     \
-              (float)af_[j][0][r] + (float)af_[j][1][r + 4] + (float)bf_[0][q][r] + (float)bf_[1][q][r]; \
+              (float)af_[j][0][r] + (float)af_[j][1][r + 4] + (float)bfh_[q][r] + (float)bfl_[q][r]; \
     } else {                                                                                           \
       _Pragma("unroll") for (int q = 0; q < NQ; ++q) _Pragma("unroll") for (int j = 0; j < 2; ++j)     \
-          acc[2 * (jh) + j][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af_[j][1], bf_[0][q], acc[2 * (jh) + j][q], 0, 0, 0); \
+          acc[2 * (jh) + j][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af_[j][1], bfh_[q], acc[2 * (jh) + j][q], 0, 0, 0); \
       if constexpr (NQ == 4)                                                                           \
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af_[0][0]), "+v"(af_[1][0]), "+v"(bf_[1][0]), "+v"(bf_[1][1]), "+v"(bf_[1][2]), "+v"(bf_[1][3]) : : "memory"); \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af_[0][0]), "+v"(af_[1][0]), "+v"(bfl_[0]), "+v"(bfl_[1]), "+v"(bfl_[2]), "+v"(bfl_[3]) : : "memory"); \
       else                                                                                             \
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af_[0][0]), "+v"(af_[1][0]), "+v"(bf_[1][0]), "+v"(bf_[1][1]) : : "memory"); \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af_[0][0]), "+v"(af_[1][0]), "+v"(bfl_[0]), "+v"(bfl_[1]) : : "memory"); \
       _Pragma("unroll") for (int q = 0; q < NQ; ++q) _Pragma("unroll") for (int j = 0; j < 2; ++j)     \
-          acc[2 * (jh) + j][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af_[j][0], bf_[1][q], acc[2 * (jh) + j][q], 0, 0, 0); \
+          acc[2 * (jh) + j][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af_[j][0], bfl_[q], acc[2 * (jh) + j][q], 0, 0, 0); \
       _Pragma("unroll") for (int q = 0; q < NQ; ++q) _Pragma("unroll") for (int j = 0; j < 2; ++j)     \
-          acc[2 * (jh) + j][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af_[j][0], bf_[0][q], acc[2 * (jh) + j][q], 0, 0, 0); \
+          acc[2 * (jh) + j][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af_[j][0], bfh_[q], acc[2 * (jh) + j][q], 0, 0, 0); \
     }                                                                                                  \
   } while (0)
 #define EOFX_SLAB(set, boff, hs, next_f, next_a, WF)                                                   \
@@ -437,6 +439,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(176))) void 
 #undef EOFX_AXB_CONV1
 #undef EOFX_AXB_CONV_TAIL
 #undef EOFX_AXB_MFMA
+#undef EOFX_AXB_BHI
 #undef EOFX_SLAB
 #undef EOFX_PAIR_BARRIER
 
