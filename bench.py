@@ -500,6 +500,7 @@ def measure_traffic(args, n, P):
     me = os.path.abspath(__file__)
     names = {"atb_f16_kernel<": "atb_f16_kernel<2,true>", "atb_f16_fit_kernel<": "atb_f16_fit_kernel<2>",
              "axb_f16_kernel<": "axb_f16_kernel<4>", "axb_f16_dma_kernel<": "axb_f16_dma_kernel<4>",
+             "axb_f16_dma_kernelILi4": "axb_f16_dma_kernel<4>",      # rocprofv3 leaves this one mangled (_Float16 in the signature)
              "axb_bsplit_kernel": "axb_bsplit_kernel"}
     got = {}
     env = dict(os.environ, TMPDIR="/tmp")

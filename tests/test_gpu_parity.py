@@ -930,7 +930,7 @@ def test_axb_dma_kernel_equals_the_register_path_bit_for_bit(monkeypatch, n, P, 
         mat, st = engine.preprocess(c, Xd, in_place=True, allow_masked=masked)
         assert mat.masked == masked
         Y = torch.zeros((mat.p_pad, L), dtype=torch.float32, device="cuda")
-        Yh = rng.standard_normal((mat.p, L)).astype(np.float32)
+        Yh = np.random.default_rng(7).standard_normal((mat.p, L)).astype(np.float32)     # the same panel both times
         Y[: mat.p_phys if masked else mat.p] = torch.as_tensor(mat.scatter_rows(Yh) if masked else Yh, device="cuda")
         W = engine.panel_mul(c, mat, Y, prec="f16x3")
         torch.cuda.synchronize()

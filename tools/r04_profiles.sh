@@ -35,10 +35,13 @@ for set in "FETCH_SIZE" "WRITE_SIZE" \
            "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS"; do
   i=$((i+1))
   timeout 600 rocprofv3 --kernel-trace --pmc $set -d $O/pmc$i -o p --output-format csv -- python $R/bench.py --no-traffic --no-cpu-baseline --no-configs --steps 2 --warmup 1 > $O/pmc$i.json 2> $O/pmc$i.err
-  (cd $R && python tools/prof_summary.py $O/pmc$i > $O/pmc${i}_full.txt 2>&1; awk '/^# PMC/{p=1} p' $O/pmc${i}_full.txt | grep -A 9 "atb_f16_fit_kernel\|atb_f16_kernel<2, true\|axb_f16_kernel<4\|axb_f16_dma_kernel<4\|axb_bsplit\|^# PMC" > $O/pmc${i}_summary.txt)
+  (cd $R && python tools/prof_summary.py $O/pmc$i > $O/pmc${i}_full.txt 2>&1; awk '/^# PMC/{p=1} p' $O/pmc${i}_full.txt | grep -A 9 "atb_f16_fit_kernel\|atb_f16_kernel<2, true\|axb_f16_kernel<4\|axb_f16_dma_kernel\|axb_bsplit\|^# PMC" > $O/pmc${i}_summary.txt)
   rm -rf $O/pmc$i $O/pmc${i}_full.txt
 done
 python $R/tools/pca_probe.py > $O/pca_probe.txt 2>&1
 python $R/bench.py --nlon 180 --no-traffic --no-cpu-baseline --no-configs --steps 20 --warmup 5 > $O/eighth.json 2> $O/eighth.err
+EOFX_AXB_DMA=0 python $R/bench.py --nlon 180 --no-traffic --no-cpu-baseline --no-configs --steps 20 --warmup 5 > $O/eighth_register_path.json 2>/dev/null
+EOFX_AXB_DMA=0 python $R/bench.py --no-traffic --no-cpu-baseline --no-configs --steps 10 --warmup 3 > $O/bench_register_path.json 2>/dev/null
+python $R/bench.py --no-traffic --no-cpu-baseline --no-configs --steps 10 --warmup 3 > $O/bench_dma_path.json 2>/dev/null
 $R/build/rinv_phase_probe > $O/rinv_phases_now.txt 2>&1
 ls -la $O

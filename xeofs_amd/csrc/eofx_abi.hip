@@ -848,8 +848,9 @@ static int launch_axb(eofx_ctx* ctx, const float* raw, int64_t ld, int64_t rows,
     const char* ev = std::getenv("EOFX_AXB_DMA");
     ctx->axb_dma = ev ? (atoi(ev) != 0) : EOFX_AXB_DMA_DEFAULT;
   }
-  if (ctx->axb_dma) {   // the B panel as fp16 planes, moved by LDS-DMA (eofx_axb_dma.hpp); same bits in W
-    const int ncb = nfull + (rem ? 1 : 0);
+  bool dma = ctx->axb_dma != 0;
+  const int ncb = nfull + (rem ? 1 : 0);
+  if (dma) {            // the panel's fp16 planes: one grow-only buffer per context (K_all x 64 ncb x 4 bytes)
     const size_t need = (size_t)ncb * (size_t)(K_all / AXB_KG) * AXB_PAIR_BYTES;
     if (ctx->axb_planes_bytes < need) {
       HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -858,10 +859,14 @@ static int launch_axb(eofx_ctx* ctx, const float* raw, int64_t ld, int64_t rows,
       ctx->axb_planes_bytes = 0;
       if (hipMalloc((void**)&ctx->axb_planes, need) != hipSuccess) {
         (void)hipGetLastError();
-        return set_err(ctx, EOFX_ERR_NOMEM, "cannot allocate the panel planes of the in-place product (%.2f GB)", need / 1e9);
+        ctx->axb_planes = nullptr;
+        dma = false;    // no room for the planes: the register path needs none (same bits)
+      } else {
+        ctx->axb_planes_bytes = need;
       }
-      ctx->axb_planes_bytes = need;
     }
+  }
+  if (dma) {   // the B panel as fp16 planes, moved by LDS-DMA (eofx_axb_dma.hpp); same bits in W
     hipLaunchKernelGGL(axb_bsplit_kernel, dim3((unsigned)((K_all + 31) / 32), ncb), dim3(256), 0, ctx->stream, Y, L, L, K_all, bmax,
                        ctx->axb_planes);
     KCHK();
@@ -895,7 +900,7 @@ static int launch_axb(eofx_ctx* ctx, const float* raw, int64_t ld, int64_t rows,
                          L, rows_pad, K, plan.kps, plan.S, rt, 0, a_scale, bmax);
     KCHK();
   }
-  if (!ctx->axb_dma && rem) {
+  if (!dma && rem) {
     if (masked)
       hipLaunchKernelGGL((axb_f16_kernel<2, 0, true>), dim3(gx, 1), dim3(256), 0, ctx->stream, raw, ld, (int)rows, cols, aff, aff_ld, Y, L,
                          out, L, rows_pad, K, plan.kps, plan.S, rt, nfull * 64, a_scale, bmax, act);
@@ -1123,6 +1128,12 @@ extern "C" int eofx_ctx_trim(eofx_ctx* ctx) {
   if (!ctx) return EOFX_ERR_ARG;
   (void)hipSetDevice(ctx->device);
   pool_trim(ctx);
+  if (ctx->axb_planes) {      // the panel planes of the in-place product are a cache as well
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(ctx->axb_planes);
+    ctx->axb_planes = nullptr;
+    ctx->axb_planes_bytes = 0;
+  }
   return EOFX_OK;
 }
 
