@@ -128,7 +128,7 @@ struct eofx_ctx {
   // fp16 planes of the panel an in-place X Y product reads (eofx_axb_dma.hpp): one grow-only buffer per context
   _Float16* axb_planes = nullptr;
   size_t axb_planes_bytes = 0;
-  int axb_dma = -1;   // -1 not decided, 0 off, 1 on (EOFX_AXB_DMA)
+  int axb_dma = -1;   // -1 not decided, 0 off, 1 by size, 2 always (EOFX_AXB_DMA)
   // the last eofx_fit_f32: [0] 1 when the statistics rode on the first pass, [1] ms of the non-pass work of the
   // fused preprocessor (probe, finalize, correction; HIP events, only with profiling on), [2] fallback reason
   double fit_info[4] = {0.0, 0.0, 0.0, 0.0};
@@ -844,11 +844,14 @@ static int launch_axb(eofx_ctx* ctx, const float* raw, int64_t ld, int64_t rows,
     HIPCHK(hipEventRecord(ev0, ctx->stream));
   }
   const int gx = plan.S > 1 ? 8 * rt * ((plan.S + 7) / 8) : rt;
-  if (ctx->axb_dma < 0) {
+  if (ctx->axb_dma < 0) {      // 0 never, 1 by size (the default), 2 always (EOFX_AXB_DMA=1: the tests run small shapes over it)
     const char* ev = std::getenv("EOFX_AXB_DMA");
-    ctx->axb_dma = ev ? (atoi(ev) != 0) : EOFX_AXB_DMA_DEFAULT;
+    ctx->axb_dma = ev ? (atoi(ev) != 0 ? 2 : 0) : EOFX_AXB_DMA_DEFAULT;
   }
-  bool dma = ctx->axb_dma != 0;
+  // The LDS-DMA kernel costs a second launch and the split pass (~20 us together) and wins 3-5 % of the kernel: it pays from
+  // about 16 GB of field per pass on (config 4 and 5; measured on one box each: 10000 x 1 036 800 -2.8 %, 10000 x 129 600
+  // +0.9 %, 5000 x 259 200 +4.4 %, profiles/r04_axb_dma_ab.txt)
+  bool dma = ctx->axb_dma == 2 || (ctx->axb_dma == 1 && (double)rows_pad * (double)K_all >= 4.0e9);
   const int ncb = nfull + (rem ? 1 : 0);
   if (dma) {            // the panel's fp16 planes: one grow-only buffer per context (K_all x 64 ncb x 4 bytes)
     const size_t need = (size_t)ncb * (size_t)(K_all / AXB_KG) * AXB_PAIR_BYTES;
