@@ -25,10 +25,9 @@ namespace eofx {
 //   * axb_f16_dma_kernel moves a pair's 16 KiB with 16 LDS-DMA instructions per workgroup (global_load_lds_dwordx4: no
 //     VGPRs, no VALU, no LDS store instructions), one pair ahead.
 // Everything else is axb_f16_kernel: same A stream, same map, same split, same MFMA order -> the SAME BITS in C.
-// The compiler makes every LDS access it can see wait for an LDS-DMA in flight (it cannot prove them disjoint), which
-// would drain the A prefetch; so this kernel has ONE LDS object and touches it only from inline assembly (as
-// gram_nt_kernel does): stores of the converted A, fragment reads, and their lgkmcnt waits are written by hand.  The A loads
-// stay ordinary loads, and the DMA is the builtin, so the compiler's vmcnt bookkeeping stays exact.
+// ONE LDS object, touched only from inline assembly (stores of the converted A, fragment reads, their lgkmcnt waits); the A
+// and map-triple loads are inline assembly into v176 .. v251, the pair id of a masked matrix into v252; the DMA itself is
+// the builtin (with nothing else of the compiler's in flight it adds no waits of its own).  See the file header for why.
 // ---------------------------------------------------------------------------------
 constexpr int AXB_PAIR_BYTES = 2 * 8 * 64 * 16;   // one feature pair (64 features) x 64 columns, two fp16 planes
 
@@ -128,11 +127,9 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(176))) void 
   float m1 = -1.f;
   asm volatile("" : "+v"(m1));
   // ---- A and the map triples land in v[176 .. 251] (a0[u] = v[176 + 4u ..], a1[u] = v[208 + 4u ..], triples v[240 .. 251]) ----
-  // An asynchronous load into a register the compiler manages is not expressible: it copies "defined" values wherever it likes,
-  // also between the load and its wait (seen in the assembly of the first version of this variant).  The kernel is compiled
-  // with amdgpu_num_vgpr(176): the allocator never touches v176 and above, the loads name them in their text (and list them
-  // as clobbers, which is what puts them into the kernel's register count), and four v_mov after the wait hand a row group
-  // to ordinary registers.
+  // The loads name these registers in their text and list them as clobbers (which is what puts them into the kernel's
+  // register count); the conversion's first instruction reads a row group in place, the masked variant and the triples
+  // take four v_mov after the wait.
 #define EOFX_ALD_(lo, hi, c0, c1, c2, c3, voff, sbase, mod)                                                    \
   asm volatile("global_load_dwordx4 v[" #lo ":" #hi "], %0, %1" mod : : "v"(voff), "s"(sbase) : "memory", c0, c1, c2, c3)
 #define EOFX_ARD_(dst, r0, r1, r2, r3)                                                                          \
