@@ -935,6 +935,11 @@ def test_axb_dma_kernel_equals_the_register_path_bit_for_bit(monkeypatch, n, P, 
         W = engine.panel_mul(c, mat, Y, prec="f16x3")
         torch.cuda.synchronize()
         outs.append(W.cpu().numpy().view(np.uint32).copy())
+        if flag == "1":      # the panel planes are a per-context cache: trimming it and running again changes nothing
+            c.trim()
+            W2 = engine.panel_mul(c, mat, Y, prec="f16x3")
+            torch.cuda.synchronize()
+            assert np.array_equal(W2.cpu().numpy().view(np.uint32), outs[-1])
         mat.free()
     assert np.array_equal(outs[0], outs[1])
     assert np.isfinite(outs[1].view(np.float32)).all() and np.abs(outs[1].view(np.float32)[:n]).max() > 0
