@@ -100,3 +100,25 @@ def test_wide_feature_side_product_through_the_nt_kernel(ctx, n, P, L, layout, m
     Y2 = engine.panel_tmul(ctx, mat, Zd, prec="f16x3")
     assert np.max(np.abs((Y - Y2).cpu().numpy()[:mat.p_phys]) / np.maximum(scale.max(), 1e-30)) <= 3e-6
     mat.free()
+
+
+@pytest.mark.parametrize("rows,L,Lo", [(2048, 768, 512), (1280, 1536, 1504), (1024, 512, 260)])
+def test_wide_panel_matmul_through_the_nt_kernel(ctx, rows, L, Lo, monkeypatch):
+    """eofx_panel_matmul_f32 with a wide panel and a wide matrix (the PCA pre-reduction's V = B W) runs on the fp16 matrix
+    cores (fp16 {hi, lo} planes of both operands, gram_nt_kernel): against float64, and against the float64 VALU kernel it
+    replaces there (EOFX_NO_MATMUL_NT=1)."""
+    import torch
+    from xeofs_amd import engine
+
+    rng = np.random.default_rng(rows + L)
+    P = torch.as_tensor((rng.standard_normal((rows, L)) * np.exp(rng.uniform(-3, 3, size=L))).astype(np.float32), device="cuda")
+    M = torch.as_tensor(rng.standard_normal((L, Lo)) / np.sqrt(L), device="cuda")
+    ref = (P.double() @ M).cpu().numpy()
+    out = engine.panel_matmul(ctx, P, M).cpu().numpy()
+    scale = np.abs(ref).max()
+    assert out.shape == ref.shape
+    assert np.abs(out - ref).max() <= 3e-6 * scale                      # 22-bit operands, float32 accumulation over L terms
+    monkeypatch.setenv("EOFX_NO_MATMUL_NT", "1")
+    old = engine.panel_matmul(ctx, P, M).cpu().numpy()
+    assert np.abs(old - ref).max() <= 1e-6 * scale
+    assert np.abs(out - old).max() <= 3e-6 * scale

@@ -1868,10 +1868,20 @@ extern "C" int eofx_panel_rinv_f64(eofx_ctx* ctx, const double* G, int L, int l,
   if (l > 64) CHK(arena_reserve(ctx, rinv_blocked_bytes(l)));
   return launch_rinv(ctx, G, L, l, Rinv);
 }
+static bool matmul_nt_ok(int64_t rows, int L, int Lo);
+static size_t matmul_nt_scratch(eofx_ctx* ctx, int64_t rows, int L, int Lo);
+static int launch_matmul_nt(eofx_ctx* ctx, const float* P, int64_t rows, int L, const double* Mx, int Lo, float* out);
 extern "C" int eofx_panel_matmul_f32(eofx_ctx* ctx, const float* P, int64_t rows_pad, int L,
                                      const double* M, int Lo, float* out) {
   if (!ctx || !P || !M || !out || P == out) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
   CHK(set_device(ctx));
+  // a wide panel times a wide matrix (the PCA pre-reduction's V = B W: 129 600 x 1536 by 1536 x 1504, 0.6 TFLOP) belongs on the
+  // matrix cores: fp16 planes of both operands and the tiled NT kernel of eofx_gram.hpp (2.4 ms instead of 22 ms in the float64
+  // VALU kernel below, which is made for panels of up to 256 columns)
+  if (matmul_nt_ok(rows_pad, L, Lo)) {
+    const size_t need = matmul_nt_scratch(ctx, rows_pad, L, Lo);
+    if (need && arena_reserve(ctx, need) == EOFX_OK) return launch_matmul_nt(ctx, P, rows_pad, L, M, Lo, out);
+  }
   return launch_matmul(ctx, P, rows_pad, L, M, Lo, out);
 }
 extern "C" int eofx_panel_colminmax_f32(eofx_ctx* ctx, const float* P, int64_t rows, int L, float* mx,
@@ -3176,6 +3186,80 @@ static int mat_tmul_nt(eofx_ctx* ctx, const eofx_mat* m, const float* Zn, float*
                      (int64_t)L, m->p_pad, L);
   KCHK();
   amax_forget(ctx, Yp);
+  return EOFX_OK;
+}
+
+// out[rows x Lo] = P[rows x L] Mx[L x Lo] for WIDE operands, on the fp16 matrix cores: both operands as {hi, lo} fp16 planes
+// (22 bits, exact power-of-two scales from their maxima), the tiled NT kernel, float32 accumulation -- the arithmetic of
+// every other pass.  Mx (float64 on the device) is rounded to float32 first.
+static bool matmul_nt_ok(int64_t rows, int L, int Lo) {
+  const int64_t kpad = round_up(L, 2 * GR_BK);
+  return L >= 512 && Lo >= 256 && Lo % 4 == 0 && L % 4 == 0 && rows >= 1024 && rows % GR_BM == 0 &&
+         kpad * 4 * GR_BM < ((int64_t)1 << 32) && !std::getenv("EOFX_NO_MATMUL_NT");
+}
+static size_t matmul_nt_scratch(eofx_ctx* ctx, int64_t rows, int L, int Lo) {
+  const int64_t kpad = round_up(L, 2 * GR_BK), Lop = round_up(Lo, GR_BM);
+  const eofx_ctx::GramPlanDev* g = nullptr;
+  if (gram_plan_get(ctx, (int)(rows / GR_BM), (int)(Lop / GR_BM), false, (int)(kpad / GR_BK), &g) != EOFX_OK) return 0;
+  return (size_t)(rows + Lop) * kpad * 4 + (size_t)g->pl.T * g->pl.S * GR_BM * GR_BM * sizeof(float) + (size_t)L * Lo * 4 + (1 << 16);
+}
+__global__ __launch_bounds__(256) void f64_to_f32_kernel(const double* __restrict__ a, float* __restrict__ b, int64_t count) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) b[i] = (float)a[i];
+}
+static int launch_matmul_nt(eofx_ctx* ctx, const float* P, int64_t rows, int L, const double* Mx, int Lo, float* out) {
+  const int64_t kpad = round_up(L, 2 * GR_BK), Lop = round_up(Lo, GR_BM);
+  const int nti = (int)(rows / GR_BM), ntj = (int)(Lop / GR_BM);
+  const eofx_ctx::GramPlanDev* g = nullptr;
+  CHK(gram_plan_get(ctx, nti, ntj, false, (int)(kpad / GR_BK), &g));
+  ArenaScope scope(ctx);
+  ARENA(_Float16, pa, (size_t)rows * kpad * 2);
+  ARENA(_Float16, pb, (size_t)Lop * kpad * 2);
+  ARENA(float, part, (size_t)g->pl.T * g->pl.S * GR_BM * GR_BM);
+  ARENA(float, m32, (size_t)L * Lo);
+  ARENA(unsigned, mx, 4);
+  hipLaunchKernelGGL(f64_to_f32_kernel, dim3((unsigned)std::min<int64_t>(((int64_t)L * Lo + 255) / 256, 4096)), dim3(256), 0, ctx->stream, Mx, m32,
+                     (int64_t)L * Lo);
+  KCHK();
+  HIPCHK(hipMemsetAsync(mx, 0, 2 * sizeof(unsigned), ctx->stream));
+  const float* pm = amax_get(ctx, P);
+  if (!pm) {
+    const int64_t total4 = rows * (int64_t)(L / 4);
+    hipLaunchKernelGGL(panel_absmax_kernel, dim3((int)std::max<int64_t>(1, std::min<int64_t>((total4 + 1023) / 1024, 1024))), dim3(256), 0,
+                       ctx->stream, P, rows, L, (int64_t)L, mx);
+    KCHK();
+    pm = reinterpret_cast<const float*>(mx);
+  }
+  {
+    const int64_t total4 = (int64_t)L * (Lo / 4);
+    hipLaunchKernelGGL(panel_absmax_kernel, dim3((int)std::max<int64_t>(1, std::min<int64_t>((total4 + 1023) / 1024, 1024))), dim3(256), 0,
+                       ctx->stream, (const float*)m32, (int64_t)L, Lo, (int64_t)Lo, mx + 1);
+    KCHK();
+  }
+  float hp = 0.f, hm = 0.f;
+  HIPCHK(hipMemcpyAsync(&hp, pm, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(&hm, mx + 1, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  auto pow2 = [](float v) {
+    if (!(v > 0.f) || !std::isfinite(v)) return 1.f;
+    int e;
+    (void)std::frexp(v, &e);
+    return std::ldexp(1.f, 14 - e);
+  };
+  const float sa = pow2(hp), sb = pow2(hm);
+  const int rows_per_wg = 64;
+  hipLaunchKernelGGL(planes_split_kernel, dim3((unsigned)((kpad + 2047) / 2048), (unsigned)((rows + rows_per_wg - 1) / rows_per_wg)), dim3(256), 0,
+                     ctx->stream, P, (int64_t)L, rows, (int64_t)L, (const float*)nullptr, (int64_t)0, sa, pa, rows, kpad, rows_per_wg);
+  KCHK();
+  hipLaunchKernelGGL(planes_split_t_kernel, dim3((unsigned)(Lop / 64), (unsigned)(kpad / 64)), dim3(256), 0, ctx->stream, (const float*)m32,
+                     (int64_t)Lo, (int64_t)L, (int64_t)Lo, (const float*)nullptr, (int64_t)0, sb, pb, kpad);
+  KCHK();
+  hipLaunchKernelGGL(gram_nt_kernel, dim3(g->pl.grid), dim3(512), 0, ctx->stream, (const _Float16*)pa, (const _Float16*)pb, kpad * 4,
+                     (const GramItem*)g->items, part, 1.f / (sa * sb));
+  KCHK();
+  hipLaunchKernelGGL(nt_finish_kernel, dim3(g->pl.T, 16), dim3(256), 0, ctx->stream, (const float*)part, (const int2*)g->tiles, g->pl.S, out,
+                     (int64_t)Lo, rows, Lo);
+  KCHK();
+  amax_forget(ctx, out);
   return EOFX_OK;
 }
 
