@@ -1011,11 +1011,17 @@ static void host_chol_rinv(const double* G, int L, int l, double* Rinv, double t
 // out = P R^-1 with G = R^T R (leading l x l block)
 static int launch_rinv(eofx_ctx* ctx, const double* G, int L, int l, double* Rinv);
 static size_t rinv_blocked_bytes(int l);
+static bool matmul_nt_ok(int64_t rows, int L, int Lo);
+static size_t matmul_nt_scratch(eofx_ctx* ctx, int64_t rows, int L, int Lo);
+static int launch_matmul_nt(eofx_ctx* ctx, const float* P, int64_t rows, int L, const double* Mx, int Lo, float* out);
 static int launch_cholqr(eofx_ctx* ctx, const float* P, int64_t rows, int L, int l, const double* G,
                          float* out) {
   ArenaScope scope(ctx);
   ARENA(double, Rinv, (size_t)L * L);
   CHK(launch_rinv(ctx, G, L, l, Rinv));
+  // (Also for wide sketches the product with R^-1 stays in the float64 kernel: through fp16 planes -- 22-bit operands against the
+  // matrix' largest entry, and R^-1 spans orders of magnitude -- Q lost orthonormality, 1.5e-6 instead of 4e-9 at 1510 columns,
+  // for 0.75 ms per factorisation.)
   return launch_matmul(ctx, P, rows, L, Rinv, L, out);
 }
 
@@ -1868,9 +1874,6 @@ extern "C" int eofx_panel_rinv_f64(eofx_ctx* ctx, const double* G, int L, int l,
   if (l > 64) CHK(arena_reserve(ctx, rinv_blocked_bytes(l)));
   return launch_rinv(ctx, G, L, l, Rinv);
 }
-static bool matmul_nt_ok(int64_t rows, int L, int Lo);
-static size_t matmul_nt_scratch(eofx_ctx* ctx, int64_t rows, int L, int Lo);
-static int launch_matmul_nt(eofx_ctx* ctx, const float* P, int64_t rows, int L, const double* Mx, int Lo, float* out);
 extern "C" int eofx_panel_matmul_f32(eofx_ctx* ctx, const float* P, int64_t rows_pad, int L,
                                      const double* M, int Lo, float* out) {
   if (!ctx || !P || !M || !out || P == out) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
@@ -1974,14 +1977,14 @@ extern "C" int eofx_peaked_spectrum(const double* G, int ld, int l) {
 // Arena: 2 Lb^2 + Lb 64 + Lb doubles.
 static size_t rinv_blocked_bytes(int l) {
   const size_t Lb = (size_t)round_up(l, 64);
-  return (2 * Lb * Lb + Lb * 64 + Lb) * sizeof(double) + 4096;
+  return (2 * Lb * Lb + Lb * Lb / 2 + 64 * 64 + Lb) * sizeof(double) + 8192;
 }
 static int launch_rinv_blocked(eofx_ctx* ctx, const double* G, int L, int l, double* Rinv) {
   const int Lb = (int)round_up(l, 64), nb = Lb / 64;
   ArenaScope scope(ctx);
   ARENA(double, S, (size_t)Lb * Lb);      // the matrix; R's off-diagonal blocks end up in its upper triangle
   ARENA(double, X, (size_t)Lb * Lb);      // R^-1
-  ARENA(double, T, (size_t)Lb * 64);
+  ARENA(double, T, (size_t)Lb * Lb / 2 + 64 * 64);   // the inner products of one merge level of the inverse (<= half the matrix)
   ARENA(double, d0, Lb);
   hipLaunchKernelGGL(chol_blocked_init_kernel, dim3(512), dim3(256), 0, ctx->stream, G, L, l, S, Lb, d0);
   KCHK();
@@ -2004,14 +2007,44 @@ static int launch_rinv_blocked(eofx_ctx* ctx, const double* G, int L, int l, dou
       KCHK();
     }
   }
-  // R^-1 block column by block column: X[0:j, j] = -X[0:j, 0:j] (R[0:j, j] X_jj)
-  for (int j = 1; j < nb; ++j) {
-    hipLaunchKernelGGL(dgemm64_kernel<false>, dim3(1, j), dim3(256), 0, ctx->stream, (const double*)(S + 64 * j), Lb,
-                       (const double*)(X + (int64_t)64 * j * Lb + 64 * j), Lb, T, 64, 64, 1.0, 0.0, 0);
-    KCHK();
-    hipLaunchKernelGGL(dgemm64_kernel<false>, dim3(1, j), dim3(256), 0, ctx->stream, (const double*)X, Lb, (const double*)T, 64,
-                       X + 64 * j, Lb, 64 * j, -1.0, 0.0, 0);
-    KCHK();
+  // R^-1 by merging inverted diagonal segments pairwise, level by level: for [A B; 0 C] with A^-1, C^-1 at hand the block above
+  // the diagonal is -A^-1 (B C^-1) -- two products with plenty of tiles each, all pairs of a level in ONE batched launch.
+  // 24 blocks: 3 batched levels (1+1, 2+2, 4+4 blocks) and two single merges (8+8, 16+8) = 10 launches; the block column by
+  // block column form this replaces took 46, the last ones with a K of 1472 on a handful of workgroups (2.5 of the 3.3 ms).
+  {
+    std::vector<int> seg((size_t)nb, 1);      // sizes (in 64-blocks) of the inverted segments along the diagonal
+    while (seg.size() > 1) {
+      std::vector<int> next;
+      const size_t npairs = seg.size() / 2;
+      bool uniform = true;
+      for (size_t i = 0; i < 2 * npairs; ++i) uniform = uniform && seg[i] == seg[0];
+      auto merge = [&](int64_t off, int m1, int m2, int batch, int64_t diag_stride) {   // off, m1, m2 in elements
+        // T = R12 X22 ; X12 = -X11 T
+        hipLaunchKernelGGL(dgemm64_kernel<false>, dim3(m2 / 64, m1 / 64, batch), dim3(256), 0, ctx->stream,
+                           (const double*)(S + off * Lb + off + m1), Lb, (const double*)(X + (off + m1) * Lb + off + m1), Lb, T, m2, m2, 1.0,
+                           0.0, 0, diag_stride, diag_stride, (int64_t)m1 * m2);
+        hipLaunchKernelGGL(dgemm64_kernel<false>, dim3(m2 / 64, m1 / 64, batch), dim3(256), 0, ctx->stream,
+                           (const double*)(X + off * Lb + off), Lb, (const double*)T, m2, X + off * Lb + off + m1, Lb, m1, -1.0, 0.0, 0,
+                           diag_stride, (int64_t)m1 * m2, diag_stride);
+      };
+      if (uniform && npairs > 0) {
+        const int m = 64 * seg[0];
+        merge(0, m, m, (int)npairs, (int64_t)2 * m * (Lb + 1));
+        KCHK();
+        for (size_t i = 0; i < npairs; ++i) next.push_back(2 * seg[0]);
+      } else {
+        int64_t off = 0;
+        for (size_t i = 0; i < npairs; ++i) {
+          const int m1 = 64 * seg[2 * i], m2 = 64 * seg[2 * i + 1];
+          merge(off, m1, m2, 1, 0);
+          KCHK();
+          off += m1 + m2;
+          next.push_back(seg[2 * i] + seg[2 * i + 1]);
+        }
+      }
+      if (seg.size() & 1) next.push_back(seg.back());
+      seg.swap(next);
+    }
   }
   hipLaunchKernelGGL(chol_blocked_export_kernel, dim3(512), dim3(256), 0, ctx->stream, (const double*)X, Lb, l, Rinv, L);
   KCHK();

@@ -1498,13 +1498,18 @@ __global__ __launch_bounds__(256) void chol_rinv_kernel(const double* __restrict
 // 1536-column panels).  One 64 x 64 tile of C per workgroup (16 x 16 threads, 4 x 4 outputs each), K in steps of 16
 // through LDS.  TA: op(A) = A^T with A stored [K x M].  upper: tiles strictly below the block diagonal are skipped.
 // C may alias B when K == 64 and the tile of B a workgroup reads is the tile of C it writes (the row-panel solve).
+// blockIdx.z: batch index, operands advance by sA / sB / sC elements per problem.
 // ---------------------------------------------------------------------------------
 template <bool TA>
 __global__ __launch_bounds__(256) void dgemm64_kernel(const double* __restrict__ A, int lda, const double* B, int ldb,
-                                                       double* C, int ldc, int K, double alpha, double beta, int upper) {
+                                                       double* C, int ldc, int K, double alpha, double beta, int upper,
+                                                       int64_t sA = 0, int64_t sB = 0, int64_t sC = 0) {
   __shared__ double As[16][65], Bs[16][65];
   const int bx = blockIdx.x, by = blockIdx.y;
   if (upper && by > bx) return;
+  A += (int64_t)blockIdx.z * sA;      // batched form (the level-wise triangular inverse): element strides between the problems
+  B += (int64_t)blockIdx.z * sB;
+  C += (int64_t)blockIdx.z * sC;
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   double acc[4][4];
 #pragma unroll
