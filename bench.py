@@ -295,7 +295,20 @@ def leg_configs(ctx, device, orc, layout_kw, quick=False):
         "what": "xe.cross.MCA(n_modes=20, random_state=5).fit(X, Y, 'time') -- use_pca=True, n_pca_modes=0.999 -- model level, "
                 "fields resident", "ms": round(t_def, 1), "pca_modes": [int(md.pca[0].m), int(md.pca[1].m)],
         "pca_solver": md.pca[0].solver_used, "s_head": [float(x) for x in np.asarray(md.singular_values().values)[:3]]}
-    del Xd, Yd, md
+
+    def c3_cca():      # the whitened member of the family (alpha = 0): PCA pre-reduction + whitener + rSVD + unwhitened TSC
+        import warnings
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            return xe.cross.CCA(n_modes=k, random_state=5).fit(Xd, Yd, "time")
+
+    c3_cca()
+    t_cca, _, mc = timed(c3_cca, 2)
+    out["config3"]["default_arguments_cca"] = {
+        "what": "xe.cross.CCA(n_modes=20, random_state=5).fit(X, Y, 'time'), model level, fields resident", "ms": round(t_cca, 1),
+        "s_head": [float(x) for x in np.asarray(mc.singular_values().values)[:3]]}
+    del Xd, Yd, md, mc
     del X, Y, res
     torch.cuda.empty_cache()
 
