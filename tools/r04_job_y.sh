@@ -1,7 +1,7 @@
 #!/bin/bash
-# round 4: the lean Hilbert stage, copy chunks and transforms on two streams: tests, then config 5 (probe) with and without
+# round 4: the Rayleigh-Ritz matrix of the randomized PCA from Q^T (G Q): tests, PCA probe, CCA probe
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=$GRAFT_REPO_ROOT/gpurun_out/r04y; rm -rf $O; mkdir -p $O
-timeout 1500 python -m pytest tests/test_gpu_complex.py tests/test_gpu_complex_cross.py tests/test_gpu_golden.py -x -q > $O/pytest.txt 2>&1; grep -h "passed\|failed\|^E " $O/pytest.txt | tail -6
-python tools/complex_probe.py 8000 720 1440 20 > $O/cplx.txt 2>&1; grep "^rep1" $O/cplx.txt | cut -c1-200
-EOFX_HILBERT_UNPIPED=1 python tools/complex_probe.py 8000 720 1440 20 > $O/cplx_unpiped.txt 2>&1; grep "^rep1" $O/cplx_unpiped.txt | cut -c1-200
+timeout 1500 python -m pytest tests/test_gpu_pca.py tests/test_gpu_cpcca.py tests/test_gpu_models.py tests/test_gpu_complex_cross.py tests/test_gpu_golden.py -x -q > $O/pytest.txt 2>&1; grep -h "passed\|failed\|^E " $O/pytest.txt | tail -6
+python tools/pca_probe.py > $O/pca_probe.txt 2>&1; grep -A14 "^rep 1" $O/pca_probe.txt | grep "fit\|TOTAL\|kept"
+python tools/cca_probe.py > $O/cca_probe.txt 2>&1; grep "fit " $O/cca_probe.txt
