@@ -29,6 +29,8 @@
 #include <vector>
 
 #include <dlfcn.h>
+#include <pthread.h>
+#include <sched.h>
 #include <hipfft/hipfft.h>
 
 #include "eofx.h"
@@ -4465,6 +4467,39 @@ struct SketchPool {
     std::lock_guard<std::mutex> lk(mu);
     while ((int)threads.size() < n) threads.emplace_back([this] { loop(); });
   }
+  // Keep the workers on the cores that share the calling thread's L3 (EOFX_SKETCH_PIN=1; Linux): the stream buffer then moves
+  // between the producer and its consumers inside one cache instead of across the socket.
+  int pinned_cpu = -1;
+  int domain_threads = 0;     // hardware threads that share the caller's L3 (0: unknown / not pinned)
+  void pin_near_caller() {
+#if defined(__linux__) && !defined(__HIP_DEVICE_COMPILE__)
+    const int cpu = sched_getcpu();
+    if (cpu < 0 || cpu == pinned_cpu) return;
+    char path[128];
+    snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu);
+    FILE* f = fopen(path, "r");
+    if (!f) return;
+    char buf[512] = {0};
+    const bool ok = fgets(buf, sizeof(buf), f) != nullptr;
+    fclose(f);
+    if (!ok) return;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    int count = 0;
+    for (char* tok = strtok(buf, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
+      int a = 0, b = 0;
+      const int got = sscanf(tok, "%d-%d", &a, &b);
+      if (got == 1) b = a;
+      if (got < 1) continue;
+      for (int c = a; c <= b && c < CPU_SETSIZE; ++c) { CPU_SET(c, &set); ++count; }
+    }
+    if (count < 2) return;
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto& t : threads) (void)pthread_setaffinity_np(t.native_handle(), sizeof(set), &set);
+    pinned_cpu = cpu;
+    domain_threads = count;
+#endif
+  }
   void loop() {
     for (;;) {
       std::function<void()> job;
@@ -4516,7 +4551,9 @@ extern "C" int eofx_sketch_gaussian_f32(uint32_t seed, int64_t rows, int64_t col
   if (total == 0) return EOFX_OK;
   const int64_t npairs = (total + 1) / 2;
   const int hw = (int)std::thread::hardware_concurrency();
-  int max_threads = std::max(1, std::min(16, hw > 1 ? hw - 1 : 1));
+  // eight workers: the producer thread is the bound from four on (profiles/r04_sketch_probe.txt), and eight fit the physical cores
+  // of one L3 domain, where the workers are kept (SketchPool::pin_near_caller)
+  int max_threads = std::max(1, std::min(8, hw > 1 ? hw - 1 : 1));
   if (const char* ev = getenv("EOFX_SKETCH_THREADS")) max_threads = std::max(1, atoi(ev));
   static const bool have_avx2 = __builtin_cpu_supports("avx2");
   std::lock_guard<std::mutex> call_lock(g_sketch_call);
@@ -4570,7 +4607,11 @@ extern "C" int eofx_sketch_gaussian_f32(uint32_t seed, int64_t rows, int64_t col
     };
     const bool pooled = max_threads > 1 && nchunks > 1;
     SketchPool& pool = sketch_pool();
-    if (pooled) pool.ensure((int)std::min<int64_t>(max_threads, nchunks));
+    if (pooled) {
+      pool.ensure((int)std::min<int64_t>(max_threads, nchunks));
+      static const bool pin = !(getenv("EOFX_SKETCH_PIN") && atoi(getenv("EOFX_SKETCH_PIN")) == 0);
+      if (pin) pool.pin_near_caller();
+    }
     int64_t filled = 624;                                            // words of x that hold final values
     for (int64_t c = 0; c < nchunks; ++c) {
       const int64_t upto = 624 + 4 * std::min<int64_t>(ncand, (c + 1) * chunk);
