@@ -14,6 +14,7 @@
 #include <immintrin.h>
 #endif
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <complex>
 #include <cstdarg>
@@ -4543,6 +4544,17 @@ SketchPool& sketch_pool() {
   return *pool;
 }
 std::mutex g_sketch_call;    // one generation at a time (the pool's completion counter is per call)
+// spin politely: a few thousand pauses (the waits here are microseconds), then give the core away -- on a host with fewer free
+// cores than workers a pure spin would keep the producer off its core
+struct SpinWait {
+  int spins = 0;
+  void operator()() {
+#if !defined(__HIP_DEVICE_COMPILE__)
+    if (++spins < 4000) _mm_pause();
+    else std::this_thread::yield();
+#endif
+  }
+};
 }  // namespace
 
 extern "C" int eofx_sketch_gaussian_f32(uint32_t seed, int64_t rows, int64_t cols, float* out) {
@@ -4581,17 +4593,27 @@ extern "C" int eofx_sketch_gaussian_f32(uint32_t seed, int64_t rows, int64_t col
     uint32_t* x = xbuf.get();
     std::memcpy(x, state, sizeof(state));
     const uint32_t* raw = x + 624;
-    // The raw recurrence is sequential and runs on this thread, chunk by chunk; every finished chunk of candidates goes
-    // to the pool at once, so tempering / accept test / log / sqrt of chunk c overlap the recurrence of chunk c + 1:
-    // the call takes about as long as the recurrence alone (0.55 ns per word).
-    const int64_t chunk = 4096;                                     // candidates per task (16 K words): the deviate work of the LAST chunk is the tail of the call
+    // The raw recurrence is sequential and runs on this thread, chunk by chunk.  The workers are woken ONCE per call and
+    // then claim chunks from an atomic counter, spinning (politely) for the few microseconds until the chunk they hold has
+    // been produced: a mutex + condition-variable hand-over per 16 K-word chunk cost more than the chunk's recurrence.
+    // Deviates go to one grow-only buffer at their chunk's place; once every chunk is done the same workers copy them to
+    // their final offsets.
+    const int64_t chunk = 4096;                                     // candidates per chunk (16 K words): the deviate work of the LAST chunk is the tail of the call
     const int64_t nchunks = (ncand + chunk - 1) / chunk;
-    std::vector<std::vector<float>> dev((size_t)nchunks);          // deviates of each chunk, in stream order: (f b, f a) per accepted pair
-    auto work = [&dev, raw, ncand, chunk](int64_t c) {
+    static std::unique_ptr<float[]> dbuf;                          // [nchunks][2 chunk]: (f b, f a) per accepted pair, in stream order
+    static size_t dcap = 0;
+    if (dcap < (size_t)(2 * chunk * nchunks)) {
+      dbuf.reset(new float[(size_t)(2 * chunk * nchunks)]);
+      dcap = (size_t)(2 * chunk * nchunks);
+    }
+    float* const dev = dbuf.get();
+    std::vector<int64_t> cnt((size_t)nchunks, 0), off((size_t)nchunks + 1, 0);
+    std::atomic<int64_t> produced{0}, claim{0}, finished{0}, claim2{0};
+    std::atomic<int> phase2{0};
+    auto work = [&](int64_t c) {
       const int64_t lo = c * chunk, hi = std::min<int64_t>(ncand, lo + chunk);
-      std::vector<float>& d = dev[(size_t)c];
-      d.resize((size_t)(2 * std::max<int64_t>(hi - lo, 0)));
-      size_t q = 0;
+      float* d = dev + 2 * chunk * c;
+      int64_t q = 0;
       for (int64_t i = lo; i < hi; ++i) {
         const uint32_t w0 = mt_temper(raw[4 * i]) >> 5, w1 = mt_temper(raw[4 * i + 1]) >> 6;
         const uint32_t w2 = mt_temper(raw[4 * i + 2]) >> 5, w3 = mt_temper(raw[4 * i + 3]) >> 6;
@@ -4603,14 +4625,37 @@ extern "C" int eofx_sketch_gaussian_f32(uint32_t seed, int64_t rows, int64_t col
         d[q++] = (float)(f * b);      // returned first
         d[q++] = (float)(f * a);      // the cached deviate
       }
-      d.resize(q);
+      cnt[(size_t)c] = q;
     };
-    const bool pooled = max_threads > 1 && nchunks > 1;
+    const int64_t obase = 2 * done_pairs;
+    auto copy_out = [&](int64_t c) {     // deviates beyond `total` belong to later draws of the stream and are dropped
+      const int64_t o = obase + off[(size_t)c];
+      if (o >= total) return;
+      const int64_t take = std::min<int64_t>(cnt[(size_t)c], total - o);
+      std::memcpy(out + o, dev + 2 * chunk * c, sizeof(float) * (size_t)take);
+    };
+    auto worker = [&] {
+      for (;;) {
+        const int64_t c = claim.fetch_add(1, std::memory_order_relaxed);
+        if (c >= nchunks) break;
+        for (SpinWait sw; produced.load(std::memory_order_acquire) <= c;) sw();
+        work(c);
+        finished.fetch_add(1, std::memory_order_release);
+      }
+      for (SpinWait sw; !phase2.load(std::memory_order_acquire);) sw();
+      for (;;) {
+        const int64_t c = claim2.fetch_add(1, std::memory_order_relaxed);
+        if (c >= nchunks) break;
+        copy_out(c);
+      }
+    };
+    const int nworkers = (max_threads > 1 && nchunks > 1) ? (int)std::min<int64_t>(max_threads, nchunks) : 0;
     SketchPool& pool = sketch_pool();
-    if (pooled) {
-      pool.ensure((int)std::min<int64_t>(max_threads, nchunks));
+    if (nworkers) {
+      pool.ensure(nworkers);
       static const bool pin = !(getenv("EOFX_SKETCH_PIN") && atoi(getenv("EOFX_SKETCH_PIN")) == 0);
       if (pin) pool.pin_near_caller();
+      for (int w = 0; w < nworkers; ++w) pool.submit(worker);
     }
     int64_t filled = 624;                                            // words of x that hold final values
     for (int64_t c = 0; c < nchunks; ++c) {
@@ -4619,19 +4664,25 @@ extern "C" int eofx_sketch_gaussian_f32(uint32_t seed, int64_t rows, int64_t col
       if (have_avx2) mt_fill_avx2_range(x, filled, upto);
       else mt_fill_generic_range(x, filled, upto);
       filled = upto;
-      if (pooled) pool.submit([&work, c] { work(c); });
-      else work(c);
+      produced.store(c + 1, std::memory_order_release);
     }
-    if (pooled) pool.wait();
+    for (;;) {                                                        // this thread takes chunks too once the stream stands
+      const int64_t c = claim.fetch_add(1, std::memory_order_relaxed);
+      if (c >= nchunks) break;
+      work(c);
+      finished.fetch_add(1, std::memory_order_release);
+    }
+    for (SpinWait sw; finished.load(std::memory_order_acquire) < nchunks;) sw();
+    for (int64_t c = 0; c < nchunks; ++c) off[(size_t)c + 1] = off[(size_t)c] + cnt[(size_t)c];
+    phase2.store(1, std::memory_order_release);
+    for (;;) {
+      const int64_t c = claim2.fetch_add(1, std::memory_order_relaxed);
+      if (c >= nchunks) break;
+      copy_out(c);
+    }
+    if (nworkers) pool.wait();
     std::memcpy(state, x + nwords, sizeof(state));     // the state after these words (a rare second round continues here)
-    // concatenate in order; deviates beyond `total` belong to later draws of the stream and are dropped
-    int64_t o = 2 * done_pairs;
-    for (int64_t c = 0; c < nchunks && o < total; ++c) {
-      const std::vector<float>& d = dev[(size_t)c];
-      const int64_t take = std::min<int64_t>((int64_t)d.size(), total - o);
-      std::memcpy(out + o, d.data(), sizeof(float) * (size_t)take);
-      o += take;
-    }
+    const int64_t o = std::min<int64_t>(total, obase + off[(size_t)nchunks]);
     done_pairs = (o + 1) / 2;
     if (o >= total) break;
   }
