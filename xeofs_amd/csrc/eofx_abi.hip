@@ -2212,16 +2212,20 @@ static int rsvd_core(eofx_ctx* ctx, const LinOp& op, int k, int l, int n_iter, c
   eofx_host_eigh_f64(Gl.data(), l, w.data(), Uh.data());
   out.s.assign(k, 0.0);
   std::vector<double> M1((size_t)L * Lo, 0.0), M2((size_t)L * Lo, 0.0);
+  std::vector<double> invs(k);
   for (int j = 0; j < k; ++j) {
     const double sv = std::sqrt(std::max(w[j], 0.0));
     out.s[j] = sv;
-    const double inv = sv > 0.0 ? 1.0 / sv : 0.0;
-    for (int i = 0; i < l; ++i) {
-      double t = 0.0;                                          // (R2^-1 Uh)[i][j]
-      for (int q = 0; q < l; ++q) t += hR2[(size_t)i * L + q] * Uh[(size_t)q * l + j];
-      M1[(size_t)i * Lo + j] = t;
-      M2[(size_t)i * Lo + j] = Uh[(size_t)i * l + j] * inv;
+    invs[j] = sv > 0.0 ? 1.0 / sv : 0.0;
+  }
+  for (int i = 0; i < l; ++i) {                                // M1 = R2^-1 Uh[:, :k] (rows accumulated over q in the same order
+    double* m1 = &M1[(size_t)i * Lo];                          // as before: contiguous in j), M2 = Uh[:, :k] / s
+    for (int q = 0; q < l; ++q) {
+      const double r = hR2[(size_t)i * L + q];
+      const double* uq = &Uh[(size_t)q * l];
+      for (int j = 0; j < k; ++j) m1[j] += r * uq[j];
     }
+    for (int j = 0; j < k; ++j) M2[(size_t)i * Lo + j] = Uh[(size_t)i * l + j] * invs[j];
   }
   HIPCHK(hipMemcpyAsync(Md, M1.data(), sizeof(double) * L * Lo, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(Md2, M2.data(), sizeof(double) * L * Lo, hipMemcpyHostToDevice, ctx->stream));
