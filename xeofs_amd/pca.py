@@ -88,6 +88,22 @@ class ResidentPCA:
         in all); the n x n Gram matrix and the m x m Rayleigh-Ritz Gram matrix are all-reduced, V stays
         sharded by rows, scores / singular values are replicated.  `total_variance` must then be the global
         one."""
+        steps = self.fit_steps(mat, total_variance, comm, p_total)
+        try:
+            M = next(steps)
+        except StopIteration:
+            return self
+        try:
+            steps.send(engine._torch().linalg.eigh(M))
+        except StopIteration:
+            pass
+        return self
+
+    def fit_steps(self, mat, total_variance: float | None = None, comm=None, p_total: int | None = None):
+        """`fit` as a generator: the randomized route YIELDS its order-ell Rayleigh-Ritz matrix and expects
+        `torch.linalg.eigh` of it to be sent back (the one library call of the route: 36 of 85 ms at config 3, launch-bound) --
+        a caller with two fields lets one field's eigen-problem run on a second stream under the other field's kernels
+        (xeofs_amd/cross/cpcca.py).  The exact route never yields."""
         torch = engine._torch()
         ctx = self.ctx
         n, p = mat.n, mat.p
@@ -126,7 +142,7 @@ class ResidentPCA:
                 B = engine.panel_tmul(ctx, mat, Q, prec=ctx.precision[1])
                 M = engine.panel_gram(ctx, B)[:ell, :ell]
                 M = 0.5 * (M + M.T)
-                th, W = torch.linalg.eigh(M)                # order ell: the one library call of this route
+                th, W = yield M                             # order ell: the one library call of this route (see fit)
                 th = torch.flip(th, (0,)).clamp_min(0.0)
                 W = torch.flip(W, (1,))
                 lam_h = th.cpu().numpy()
@@ -207,7 +223,6 @@ class ResidentPCA:
         self._scores_dev = (Ud * s).float().contiguous()   # X V on the device: the analysis matrix of the cross models
         self.singular_values_all = np.sqrt(lam_h)
         self.total_variance = total_variance
-        return self
 
     def _truncate(self, lam_h, n_pre, n, total_variance):
         """number of modes kept (linalg/_numpy/_svd.py:215-241): the first n_pre eigenvalue estimates against the target"""
