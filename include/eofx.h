@@ -444,6 +444,12 @@ int eofx_sketch_gaussian_f32(uint32_t seed, int64_t rows, int64_t cols, float *o
  * A[n x n] row-major ->
  * eigenvalues w[n] descending, eigenvectors as columns of Vec[n x n].          */
 int eofx_host_eigh_f64(const double *A, int n, double *w, double *Vec);
+/* leading `nev` eigenpairs of the complex Hermitian matrix Hr + i Hi (row-major m x m, float64): Householder reduction to a
+ * real tridiagonal matrix, QL eigenvalues, inverse iteration, back-transformation (xeofs_amd/csrc/eofx_hosteig.hpp).  The
+ * Rayleigh-Ritz step of the block-Krylov complex decomposition (eofx_rsvd_c64; the reference's counterpart is the dense
+ * eigen-problem inside scipy's lobpcg, reached from xeofs/linalg/decomposer.py:149-160).
+ * w[nev] descending, Xr / Xi [m x nev] row-major with orthonormal columns.     */
+int eofx_host_zheigh_top_f64(const double *Hr, const double *Hi, int m, int nev, double *w, double *Xr, double *Xi);
 
 #ifdef __cplusplus
 }

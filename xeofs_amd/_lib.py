@@ -107,6 +107,7 @@ SIGNATURES = {
     "eofx_cpanel_colabsmax_f32": (_int, [_vp, _vp, _i64, _int, _vp]),
     "eofx_sketch_gaussian_f32": (_int, [C.c_uint32, _i64, _i64, _vp]),
     "eofx_host_eigh_f64": (_int, [_vp, _int, _vp, _vp]),
+    "eofx_host_zheigh_top_f64": (_int, [_vp, _vp, _int, _int, _vp, _vp, _vp]),
 }
 
 PREC = {"f32": 0, "bf16x3": 1, "bf16x6": 2, "f16x3": 3, "f64": 4}

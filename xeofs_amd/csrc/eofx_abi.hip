@@ -6,6 +6,7 @@
 #include "eofx_fit.hpp"
 #include "eofx_gram.hpp"
 #include "eofx_axb_dma.hpp"
+#include "eofx_hosteig.hpp"
 #ifndef EOFX_AXB_DMA_DEFAULT
 #define EOFX_AXB_DMA_DEFAULT 1
 #endif
@@ -432,6 +433,10 @@ static inline double hypot_fast(double a, double b) {
   const double q = a * a + b * b;
   if (q > 1e-280 && q < 1e280) return std::sqrt(q);
   return std::hypot(a, b);
+}
+extern "C" int eofx_host_zheigh_top_f64(const double* Hr, const double* Hi, int m, int nev, double* w, double* Xr, double* Xi) {
+  if (!Hr || !Hi || !w || !Xr || !Xi || m <= 0 || nev <= 0 || nev > m) return EOFX_ERR_ARG;
+  return hosteig::zheigh_top(Hr, Hi, m, nev, w, Xr, Xi) == 0 ? EOFX_OK : EOFX_ERR_LINALG;
 }
 extern "C" int eofx_host_eigh_f64(const double* Ain, int n, double* w, double* Vec) {
   if (!Ain || !w || !Vec || n <= 0) return EOFX_ERR_ARG;
@@ -977,13 +982,45 @@ static int launch_matmul(eofx_ctx* ctx, const float* P, int64_t rows, int L, con
   const size_t smem = (size_t)KW * PMM_LD * sizeof(double);         // 33 .. 132 KB
   static size_t attr_smem = 0;    // opt in to more than 64 KB of dynamic LDS when a wide panel asks for it
   if (smem > 64 * 1024 && smem > attr_smem) {
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_matmul_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_matmul_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr_smem = smem;
   }
   const int64_t units = (rows + 127) / 128;        // 4 waves x 32 rows
   const int64_t gx = L <= KW ? std::min<int64_t>(units, 1024) : units;   // windowed form: one group per wave
   dim3 grid((int)std::max<int64_t>(1, gx), (Lo + 63) / 64);
-  hipLaunchKernelGGL(panel_matmul_kernel, grid, dim3(256), smem, ctx->stream, P, rows, L, Mx, Lo, out, KW, amax_new(ctx, out));
+  hipLaunchKernelGGL(panel_matmul_kernel<false>, grid, dim3(256), smem, ctx->stream, P, rows, L, Mx, Lo, out, KW, amax_new(ctx, out),
+                     (int64_t)0, (int64_t)0, 1, (const float*)nullptr);
+  KCHK();
+  return EOFX_OK;
+}
+// out [rows x Lo] = (sub -) sum over the 64-column chunks c of P: chunk c at P + (c / cpb) * slab + (c % cpb) * 64, row stride ldp
+// (see panel_matmul_kernel<true>); L = 64 x chunks.  out must not alias P (it may alias sub).
+static int launch_matmul_gen(eofx_ctx* ctx, const float* P, int64_t ldp, int64_t slab, int cpb, int64_t rows, int L, const double* Mx, int Lo,
+                             const float* sub, float* out) {
+  const int KW = (int)std::min<int64_t>(round_up(L, 64), 256);
+  const size_t smem = (size_t)KW * PMM_LD * sizeof(double);
+  static size_t attr_smem = 0;
+  if (smem > 64 * 1024 && smem > attr_smem) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_matmul_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    attr_smem = smem;
+  }
+  const int64_t units = (rows + 127) / 128;
+  const int64_t gx = L <= KW ? std::min<int64_t>(units, 1024) : units;
+  dim3 grid((int)std::max<int64_t>(1, gx), (Lo + 63) / 64);
+  hipLaunchKernelGGL(panel_matmul_kernel<true>, grid, dim3(256), smem, ctx->stream, P, rows, L, Mx, Lo, out, KW, amax_new(ctx, out), ldp,
+                     slab, cpb, sub);
+  KCHK();
+  return EOFX_OK;
+}
+// C [La x Lb] (float64, device) = Pa^T Pb over `rows` rows; La, Lb multiples of 64
+static int launch_xgram(eofx_ctx* ctx, const float* Pa, int64_t lda, int La, const float* Pb, int64_t ldb, int Lb, int64_t rows, double* C) {
+  const int nbx = (int)std::max<int64_t>(1, std::min<int64_t>((rows + 127) / 128, std::max<int64_t>(1, ((int64_t)32 << 20) / ((int64_t)La * Lb * 8))));
+  ArenaScope scope(ctx);
+  ARENA(double, part, (size_t)nbx * La * Lb);
+  hipLaunchKernelGGL(xgram_mfma_kernel, dim3(nbx, (La / 64) * (Lb / 64)), dim3(256), 0, ctx->stream, Pa, lda, Pb, ldb, rows, La, Lb, part);
+  KCHK();
+  const int64_t count = (int64_t)La * Lb;
+  hipLaunchKernelGGL(f64_reduce_kernel, dim3((int)((count + 63) / 64)), dim3(256), 0, ctx->stream, part, C, count, nbx);
   KCHK();
   return EOFX_OK;
 }
@@ -3936,14 +3973,15 @@ static void hermitian_from_real(const std::vector<double>& G, int LP, int l, std
 }
 // T (l x l upper triangular) with (P T)^H (P T) = I for H = P^H P; dependent columns -> zero columns (same rule as the
 // real driver's chol_rinv: pivot below tol * original diagonal)
-static void host_zchol_rinv(const std::vector<zdouble>& Hin, int l, std::vector<zdouble>& T, double tol) {
+static void host_zchol_rinv(const std::vector<zdouble>& Hin, int l, std::vector<zdouble>& T, double tol,
+                            std::vector<zdouble>* Rout = nullptr, int* n_live = nullptr, const double* dref = nullptr, double tolref = 0.0) {
   std::vector<zdouble> A(Hin);
   std::vector<double> d0(l);
   std::vector<char> dead(l, 0);
   for (int j = 0; j < l; ++j) d0[j] = Hin[(size_t)j * l + j].real();
   for (int j = 0; j < l; ++j) {        // H = R^H R, R upper triangular, stored in the upper part of A
     const double d = A[(size_t)j * l + j].real();
-    const bool dj = !(d > tol * d0[j]) || !(d0[j] > 0.0);
+    const bool dj = !(d > tol * d0[j]) || !(d0[j] > 0.0) || (dref && !(d > tolref * dref[j]));   // (dref: see eofx_rsvd_c64)
     dead[j] = dj;
     const double rjj = dj ? 1.0 : std::sqrt(d);
     const double piv = dj ? 0.0 : 1.0 / rjj;
@@ -3954,6 +3992,15 @@ static void host_zchol_rinv(const std::vector<zdouble>& Hin, int l, std::vector<
       if (f == zdouble(0.0, 0.0)) continue;
       for (int c = r; c < l; ++c) A[(size_t)r * l + c] -= f * A[(size_t)j * l + c];
     }
+  }
+  if (Rout) {                          // P = Q R (a dependent column keeps its coefficients on the earlier columns of Q)
+    Rout->assign((size_t)l * l, zdouble(0.0, 0.0));
+    for (int r = 0; r < l; ++r)
+      for (int c = r; c < l; ++c) (*Rout)[(size_t)r * l + c] = (r == c && dead[r]) ? zdouble(0.0, 0.0) : A[(size_t)r * l + c];
+  }
+  if (n_live) {
+    *n_live = 0;
+    for (int j = 0; j < l; ++j) *n_live += dead[j] ? 0 : 1;
   }
   T.assign((size_t)l * l, zdouble(0.0, 0.0));
   for (int c = 0; c < l; ++c) {        // T = R^-1 column by column
@@ -4162,6 +4209,24 @@ extern "C" int eofx_cmat_mul_f32(eofx_ctx* ctx, const eofx_mat* A, const eofx_ma
 
 // U [n x k] and V [p x k] are complex64, row-major, interleaved (re, im); s [k] float32; all host|device.
 // omega: [min(n, p) x (k + n_oversamples)] REAL Gaussian start (host), as the reference's random_state would draw.
+//
+// Round 5: BLOCK KRYLOV.  The reference's complex branch is scipy's svds(solver="lobpcg") (linalg/decomposer.py:149-160): a
+// block Krylov-class eigen-solver on Z^H Z.  Plain subspace iteration with scikit-learn's count (rounds 1-4) reads the field
+// the same number of times but leaves modes inside a flat noise bulk 1e-3 .. 4e-2 short.  The passes over the field are now
+// the steps of a block Lanczos recurrence on the small side, M = A_op^H A_op:
+//     P_i = A_op Z_i (tall, KEPT),  W_i = A_op^H P_i = M Z_i,  Z_{i+1} = orth(W_i - K (K^H W_i)),  K = [Z_0 .. Z_i]
+// (full re-orthogonalisation, twice: a few small-side kernels on min(n, p) x 64 panels), and after the same q products a
+// Rayleigh-Ritz step over the WHOLE Krylov space K = [Z_0 .. Z_q] picks the sketch-width subspace: H = K^H M K is assembled
+// from the products already made (K^H W_i; the last diagonal block is P_q^H P_q), its leading eigenvectors y come from the
+// host (hosteig::zheigh_top, order (q + 1) l = 240 at config 5), and the tall basis A_op K y is a linear combination of the kept
+// panels P_i -- no extra pass.  The final stage (CholeskyQR2, one projection pass, l x l Hermitian problem) is unchanged and
+// still fixes the values, so the Rayleigh-Ritz matrix only has to identify the subspace.  Same 2 q + 2 passes as before;
+// on the bench's config-5 sample the worst mode goes from 8.7e-3 to 6e-7 (tools/probes/krylov_rr_prototype.py).
+//   n_iter >= 0: that many products;  -1: scikit-learn's count (7 if k < 0.1 min(n, p) else 4);
+//   -2 ("converge"): restarted cycles of that count, each starting from the Ritz block of the previous one, until the leading k
+//        values move by <= 1e-6 (relative, squared values) or 20 products have been made (lobpcg's own limit under svds).
+// Sketches whose Krylov space would exceed order 384 (k + n_oversamples > 48 at q = 7) keep the subspace iteration of rounds 1-4
+// (EOFX_C64_KRYLOV=0 forces it, for comparisons).
 extern "C" int eofx_rsvd_c64(eofx_ctx* ctx, const eofx_mat* A, const eofx_mat* B, int k, int n_oversamples, int n_iter,
                              const float* omega, int flip_signs, float* U, float* s, float* V) {
   if (!ctx || !A || !B || !omega || !s || k <= 0 || n_oversamples < 0)
@@ -4172,19 +4237,11 @@ extern "C" int eofx_rsvd_c64(eofx_ctx* ctx, const eofx_mat* A, const eofx_mat* B
   if (k > r) return set_err(ctx, EOFX_ERR_RANK, "n_modes must be less than or equal to the rank of the dataset (rank = %lld).", (long long)r);
   const int l = (int)std::min<int64_t>(k + n_oversamples, r);
   if (l > 64) return set_err(ctx, EOFX_ERR_ARG, "complex sketch width %d > 64 is not supported (n_modes + n_oversamples <= 64)", l);
-  // n_iter == -1: scikit-learn's count (7 if k < 0.1 min(n, p) else 4), as the real branch uses.
-  // n_iter == -2: iterate until the Ritz values stand still.  The reference's complex branch is scipy's
-  // svds(solver="lobpcg") (linalg/decomposer.py:149-160), which iterates to a residual tolerance: on a spectrum with
-  // clear gaps a handful of power iterations reach the same values, but where the wanted modes run into a flat noise
-  // bulk a fixed count leaves them short (config 5's synthetic field: sigma_3 = 2601.5 after 7 iterations, 2646.35
-  // after 20 and after 50).  Rule: after every iteration the leading k eigenvalues of the Rayleigh quotient B B^H
-  // (already on the host for the Cholesky factor) are compared with the previous iteration's; two consecutive relative
-  // changes <= 1e-6 (5e-7 on the singular values) end the loop, after at least 2 and at most 20 iterations (lobpcg's own
-  // limit under svds).
   const bool adaptive = n_iter == -2;
-  if (n_iter == -1) n_iter = k < 0.1 * (double)r ? 7 : 4;
-  const int it_min = 2, it_max = adaptive ? 20 : n_iter;
-  if (adaptive) n_iter = it_max;
+  const int auto_count = k < 0.1 * (double)r ? 7 : 4;
+  if (n_iter == -1) n_iter = auto_count;
+  const int it_min = 2, it_cap = 20;
+  if (adaptive) n_iter = it_cap;
   if (n_iter < 0) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
   const int h = l <= 32 ? 32 : 64, LP = 2 * h;
   const int ko = (int)round_up(k, 16), Lo = 2 * ko;       // output panels [Re(ko) | Im(ko)]
@@ -4197,9 +4254,19 @@ extern "C" int eofx_rsvd_c64(eofx_ctx* ctx, const eofx_mat* A, const eofx_mat* B
   const int64_t small = transposed ? n : p;
   const int64_t small_pad = transposed ? A->n_pad : A->p_pad, tall_pad = transposed ? A->p_pad : A->n_pad;
   const int64_t big = std::max(A->n_pad, A->p_pad);
+  // block Krylov: products per cycle, blocks, order of the Rayleigh-Ritz problem
+  const int q_cycle = adaptive ? auto_count : n_iter;
+  constexpr int KRYLOV_MAX_ORDER = 384;
+  const char* kenv = std::getenv("EOFX_C64_KRYLOV");
+  const bool krylov = q_cycle >= 1 && (q_cycle + 1) * l <= KRYLOV_MAX_ORDER && !(kenv && atoi(kenv) == 0);
+  const int nbmax = krylov ? q_cycle + 1 : 0;
+  const int64_t ldk = (int64_t)nbmax * LP;
   size_t need = (size_t)(2 * small_pad + 2 * tall_pad + 2 * big) * LP * 4 + (size_t)(small_pad + tall_pad) * Lo * 4;
   need += 2 * atb_scratch_bytes(A->p_pad, round_up(n, ATB_KG), LP) + 2 * atb_scratch_bytes(A->n_pad, round_up(p, ATB_KG), LP);
   need += (size_t)(4 * gram_parts(big, LP) + 8) * LP * LP * 8 + (size_t)big * (Lo + LP) * 4 + (8 << 20);
+  if (krylov)
+    need += (size_t)nbmax * (small_pad + tall_pad) * LP * 4 + (size_t)small_pad * LP * 4 + (size_t)(3 + q_cycle) * nbmax * LP * LP * 8 +
+            ((size_t)40 << 20);
   CHK(arena_reserve(ctx, need));
   ArenaScope scope(ctx);
   ARENA(float, Zs, (size_t)small_pad * LP);
@@ -4212,6 +4279,18 @@ extern "C" int eofx_rsvd_c64(eofx_ctx* ctx, const eofx_mat* A, const eofx_mat* B
   ARENA(float, Sv, (size_t)small_pad * Lo);
   ARENA(double, G, (size_t)LP * LP);
   ARENA(double, Ed, (size_t)LP * LP);
+  float *Kw = nullptr, *Pt = nullptr, *Vs = nullptr;
+  double *Cd = nullptr, *Ecd = nullptr, *Eall = nullptr, *Hd = nullptr;
+  if (krylov) {
+    Kw = arena_alloc<float>(ctx, (size_t)small_pad * ldk);               // the Krylov blocks Z_0 .. Z_q side by side
+    Pt = arena_alloc<float>(ctx, (size_t)nbmax * tall_pad * LP);         // the tall panels P_i = A_op Z_i (or their Q factors)
+    Vs = arena_alloc<float>(ctx, (size_t)small_pad * LP);
+    Cd = arena_alloc<double>(ctx, (size_t)nbmax * LP * LP);
+    Ecd = arena_alloc<double>(ctx, (size_t)nbmax * LP * LP);
+    Eall = arena_alloc<double>(ctx, (size_t)nbmax * LP * LP);
+    Hd = arena_alloc<double>(ctx, (size_t)q_cycle * nbmax * LP * LP);
+    if (!Kw || !Pt || !Vs || !Cd || !Ecd || !Eall || !Hd) return set_err(ctx, EOFX_ERR_NOMEM, "arena exhausted (block Krylov panels)");
+  }
   CplxOps ops{ctx, A, B, LP, rot, tmp, std::max(A->absmax, B->absmax)};
   if (lean) CHK(cplx_lean_setup(ctx, ops));
   const int pp = ctx->prec_power, pf = ctx->prec_final;
@@ -4248,56 +4327,277 @@ extern "C" int eofx_rsvd_c64(eofx_ctx* ctx, const eofx_mat* A, const eofx_mat* B
       for (int j = 0; j < l; ++j) host[(size_t)i * LP + j] = omega[(size_t)i * (k + n_oversamples) + j];
     CHK(import_panel(ctx, host.data(), small, LP, Zs, small_pad, LP));
   }
-  // (adaptive: the tall panel is orthonormalised in every iteration -- only then is W^H W the Rayleigh quotient whose
-  // eigenvalues are compared; 1-2 ms against the ~25 ms of the two products at config-5 size)
-  const bool orth_always = adaptive || orth_tall_rule(tall_pad, LP, pp);
-  bool orth_rest = orth_always;
-  std::vector<double> ritz_prev;
-  int calm = 0;
+  // (adaptive subspace iteration: the tall panel is orthonormalised in every iteration -- only then is W^H W the Rayleigh
+  // quotient whose eigenvalues are compared)
+  const bool orth_always = (adaptive && !krylov) || orth_tall_rule(tall_pad, LP, pp);
+  const bool trace = std::getenv("EOFX_C64_TRACE") != nullptr;
   ctx->last_iters = 0;
-  for (int it = 0; it < n_iter; ++it) {
-    CHK(fwd(Zs, Yt, pp));
-    if (it == 0 || orth_rest) {
-      CHK(orth(Yt, tall_pad, Qt));
-      CHK(bwd(Qt, Ws, pp));
-    } else {
-      CHK(bwd(Yt, Ws, pp));
+
+  // ---- one cycle of the block Lanczos recurrence: Zs (orthonormal start block) -> Yt = A_op K y, the tall Ritz panel
+  auto cplx_block = [&](const double* g, std::vector<zdouble>& out) {      // complex l x l block of a real LP x LP cross-Gram block
+    out.assign((size_t)l * l, zdouble(0.0, 0.0));
+    for (int i = 0; i < l; ++i)
+      for (int j = 0; j < l; ++j)
+        out[(size_t)i * l + j] = zdouble(g[(size_t)i * LP + j] + g[(size_t)(h + i) * LP + h + j], g[(size_t)i * LP + h + j] - g[(size_t)(h + i) * LP + j]);
+  };
+  auto zmatmul = [&](const std::vector<zdouble>& X, const std::vector<zdouble>& Y) {    // l x l
+    std::vector<zdouble> Z((size_t)l * l, zdouble(0.0, 0.0));
+    for (int i = 0; i < l; ++i)
+      for (int t = 0; t < l; ++t) {
+        const zdouble x = X[(size_t)i * l + t];
+        if (x == zdouble(0.0, 0.0)) continue;
+        for (int j = 0; j < l; ++j) Z[(size_t)i * l + j] += x * Y[(size_t)t * l + j];
+      }
+    return Z;
+  };
+  auto copy_block = [&](const float* src, int blk) -> int {
+    HIPCHK(hipMemcpy2DAsync(Kw + (size_t)blk * LP, sizeof(float) * ldk, src, sizeof(float) * LP, sizeof(float) * LP, (size_t)small_pad,
+                            hipMemcpyDeviceToDevice, ctx->stream));
+    return EOFX_OK;
+  };
+  std::vector<double> hC;
+  // out = Win - K (K^H Win) over the first nbk blocks; the real cross-Gram K^T Win stays in Cd (and in hC when asked for)
+  auto project = [&](const float* Win, int nbk, float* out, bool to_host) -> int {
+    CHK(launch_xgram(ctx, Kw, ldk, nbk * LP, Win, LP, LP, small_pad, Cd));
+    if (to_host) {
+      hC.resize((size_t)nbk * LP * LP);
+      HIPCHK(hipMemcpyAsync(hC.data(), Cd, sizeof(double) * hC.size(), hipMemcpyDeviceToHost, ctx->stream));
     }
-    CHK(gram_h(Ws, small_pad));
-    ctx->last_iters = it + 1;
-    if (it == 0 && !orth_always && n_iter > 1) {   // peaked spectrum?  the Hermitian Gram matrix is on the host already
-      std::vector<zdouble> V0;
-      std::vector<double> w0;
-      orth_rest = host_heigh(H, l, w0, V0) != EOFX_OK || !(w0[l - 1] > 0.0) || std::sqrt(w0[0] / w0[l - 1]) > EOFX_PEAKED_RATIO;
-    }
-    bool done = false;
-    if (adaptive) {
-      std::vector<zdouble> V0;
-      std::vector<double> w0;
-      if (host_heigh(H, l, w0, V0) == EOFX_OK) {
-        double worst = 0.0;
-        if (ritz_prev.size() == (size_t)k)
-          for (int j = 0; j < k; ++j) worst = std::max(worst, std::fabs(w0[j] - ritz_prev[j]) / std::max(w0[j], 1e-300));
-        else
-          worst = 1.0;
-        ritz_prev.assign(w0.begin(), w0.begin() + k);
-        calm = worst <= 1e-6 ? calm + 1 : 0;
-        if (std::getenv("EOFX_C64_TRACE")) fprintf(stderr, "[eofx_rsvd_c64] iteration %d: max relative change of the leading %d Ritz values %.3e\n", it + 1, k, worst);
-        done = calm >= 2 && it + 1 >= it_min;
+    hipLaunchKernelGGL(cproj_embed_kernel, dim3((unsigned)std::min<int64_t>(((int64_t)nbk * h * h + 255) / 256, 1024)), dim3(256), 0, ctx->stream,
+                       (const double*)Cd, nbk, LP, Ecd);
+    KCHK();
+    return launch_matmul_gen(ctx, Kw, ldk, 64, 1 << 20, small_pad, nbk * LP, Ecd, LP, Win, out);
+  };
+  // Cholesky-QR with the dependency rules of a Lanczos block: a column dies when what is left of it after the columns before it
+  // falls below 1e-13 of its own squared norm (as everywhere), or below tolref x dref[j] (its squared norm BEFORE the projection:
+  // a residual below 1e-5 of the product is rounding noise of a converged direction; a re-projected unit column that kept less
+  // than half its length lay inside the blocks already there)
+  auto orth_block = [&](const float* P, float* out, const double* dref, double tolref, int* live) -> int {
+    CHK(gram_h(P, small_pad));
+    host_zchol_rinv(H, l, T, 1e-13, nullptr, live, dref, tolref);
+    return right_mul(P, small_pad, T, l, LP, out);
+  };
+  auto krylov_cycle = [&](int q) -> int {
+    std::vector<std::vector<double>> Hc(q);         // real cross-Gram [Z_0 .. Z_{i+1}]^T W_i
+    std::vector<std::vector<zdouble>> Rf(q + 1);    // M Z_i = W_i Rf[i] (empty = identity: the tall panel was not orthonormalised)
+    std::vector<zdouble> Hqq;
+    int nb = 1, nW = 0;
+    bool exhausted = false, orth_rest = orth_always;
+    std::vector<double> dref(l), ones(l, 1.0);
+    std::vector<zdouble> blk;
+    CHK(copy_block(Zs, 0));
+    for (int it = 0; it < q; ++it) {
+      float* slot = Pt + (size_t)it * tall_pad * LP;
+      if (it == 0 || orth_rest) {
+        CHK(fwd(Zs, Yt, pp));
+        CHK(gram_h(Yt, tall_pad));
+        host_zchol_rinv(H, l, T, 1e-13, &Rf[it]);
+        CHK(right_mul(Yt, tall_pad, T, l, LP, slot));
+      } else {
+        CHK(fwd(Zs, slot, pp));
+      }
+      CHK(bwd(slot, Ws, pp));
+      ++ctx->last_iters;
+      CHK(project(Ws, nb, Vs, true));
+      CHK(gram_h(Vs, small_pad));                    // (synchronises: hC is on the host)
+      // |W_j|^2 = |V_j|^2 + |K^H W_j|^2
+      for (int j = 0; j < l; ++j) dref[j] = H[(size_t)j * l + j].real();
+      for (int b = 0; b < nb; ++b) {
+        cplx_block(&hC[(size_t)b * LP * LP], blk);
+        for (int i = 0; i < l; ++i)
+          for (int j = 0; j < l; ++j) dref[j] += std::norm(blk[(size_t)i * l + j]);
+      }
+      if (it == 0 && !orth_always && q > 1) {        // peaked spectrum?  H_00 = Z_0^H M Z_0 is on the host
+        cplx_block(hC.data(), blk);
+        std::vector<zdouble> H00 = Rf[0].empty() ? blk : zmatmul(blk, Rf[0]), V0;
+        for (int i = 0; i < l; ++i)
+          for (int j = i; j < l; ++j) {
+            const zdouble v = 0.5 * (H00[(size_t)i * l + j] + std::conj(H00[(size_t)j * l + i]));
+            H00[(size_t)i * l + j] = v;
+            H00[(size_t)j * l + i] = std::conj(v);
+          }
+        std::vector<double> w0;
+        orth_rest = host_heigh(H00, l, w0, V0) != EOFX_OK || !(w0[l - 1] > 0.0) || std::sqrt(w0[0] / w0[l - 1]) > EOFX_PEAKED_RATIO;
+      }
+      int live = 0;
+      host_zchol_rinv(H, l, T, 1e-13, nullptr, &live, dref.data(), 1e-10);
+      CHK(right_mul(Vs, small_pad, T, l, LP, Zs));
+      if (live > 0) {
+        CHK(project(Zs, nb, Vs, false));
+        CHK(orth_block(Vs, Zs, ones.data(), 0.25, &live));
+      }
+      if (live > 0) {
+        CHK(copy_block(Zs, nb));
+        ++nb;
+      }
+      double* Hdi = Hd + (size_t)it * nbmax * LP * LP;
+      CHK(launch_xgram(ctx, Kw, ldk, nb * LP, Ws, LP, LP, small_pad, Hdi));
+      Hc[it].resize((size_t)nb * LP * LP);
+      HIPCHK(hipMemcpyAsync(Hc[it].data(), Hdi, sizeof(double) * Hc[it].size(), hipMemcpyDeviceToHost, ctx->stream));
+      nW = it + 1;
+      if (trace) fprintf(stderr, "[eofx_rsvd_c64] Lanczos step %d: %d live columns in the new block (%d blocks)\n", it + 1, live, nb);
+      if (live == 0) {
+        exhausted = true;      // the Krylov space is invariant: every product of its blocks is known
+        break;
       }
     }
-    host_zchol_rinv(H, l, T, 1e-13);
-    CHK(right_mul(Ws, small_pad, T, l, LP, Zs));
-    if (done) break;
-  }
-  CHK(fwd(Zs, Yt, pp));
-  CHK(orth(Yt, tall_pad, Qt));
-  CHK(orth(Qt, tall_pad, Yt));                     // Q in Yt (CholeskyQR2)
-  CHK(bwd(Yt, Ws, pf));                            // B^H, B = Q^H A_op
-  CHK(gram_h(Ws, small_pad));                      // B B^H
+    if (!exhausted) {          // the last block's panel: its diagonal block of H is P_q^H P_q
+      float* slot = Pt + (size_t)(nb - 1) * tall_pad * LP;
+      if (orth_rest || q == 0) {
+        CHK(fwd(Zs, Yt, pp));
+        CHK(gram_h(Yt, tall_pad));
+        Hqq = H;
+        host_zchol_rinv(H, l, T, 1e-13, &Rf[nb - 1]);
+        CHK(right_mul(Yt, tall_pad, T, l, LP, slot));
+      } else {
+        CHK(fwd(Zs, slot, pp));
+        CHK(gram_h(slot, tall_pad));
+        Hqq = H;
+      }
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    // ---- H = K^H M K (order nb l), Hermitian, from the columns K^H W_i Rf[i]
+    const int m = nb * l;
+    std::vector<std::vector<zdouble>> raw((size_t)nb * nb);
+    for (int i = 0; i < nW; ++i) {
+      const int rows_b = (int)(Hc[i].size() / ((size_t)LP * LP));
+      for (int j = 0; j < rows_b && j < nb; ++j) {
+        cplx_block(&Hc[i][(size_t)j * LP * LP], blk);
+        raw[(size_t)j * nb + i] = Rf[i].empty() ? blk : zmatmul(blk, Rf[i]);
+      }
+    }
+    if (!exhausted) raw[(size_t)(nb - 1) * nb + nb - 1] = Hqq;
+    std::vector<double> Hr((size_t)m * m, 0.0), Hi((size_t)m * m, 0.0);
+    for (int a = 0; a < nb; ++a)
+      for (int b = a; b < nb; ++b) {
+        const std::vector<zdouble>& u = raw[(size_t)a * nb + b];     // block (a, b)
+        const std::vector<zdouble>& v = raw[(size_t)b * nb + a];     // block (b, a): its conjugate transpose is another reading of (a, b)
+        if (u.empty() && v.empty()) continue;
+        const double wu = u.empty() ? 0.0 : (v.empty() ? 1.0 : 0.5), wv = v.empty() ? 0.0 : (u.empty() ? 1.0 : 0.5);
+        for (int i = 0; i < l; ++i)
+          for (int j = 0; j < l; ++j) {
+            zdouble val(0.0, 0.0);
+            if (!u.empty()) val += wu * u[(size_t)i * l + j];
+            if (!v.empty()) val += wv * std::conj(v[(size_t)j * l + i]);
+            const size_t ij = (size_t)(a * l + i) * m + b * l + j, ji = (size_t)(b * l + j) * m + a * l + i;
+            Hr[ij] = val.real();
+            Hi[ij] = val.imag();
+            if (a != b) {
+              Hr[ji] = val.real();
+              Hi[ji] = -val.imag();
+            }
+          }
+      }
+    for (double v : Hr)
+      if (!std::isfinite(v)) return set_err(ctx, EOFX_ERR_LINALG, "SVD failed. This may be due to isolated NaN values in the data.");
+    std::vector<double> wv(l), Xr((size_t)m * l), Xi((size_t)m * l);
+    if (hosteig::zheigh_top(Hr.data(), Hi.data(), m, l, wv.data(), Xr.data(), Xi.data()) != 0) {
+      // general-purpose route (real symmetric embedding): slower, no assumptions
+      std::vector<zdouble> Hz((size_t)m * m), Vz;
+      for (size_t e = 0; e < Hz.size(); ++e) Hz[e] = zdouble(Hr[e], Hi[e]);
+      std::vector<double> wz;
+      if (host_heigh(Hz, m, wz, Vz) != EOFX_OK) return set_err(ctx, EOFX_ERR_LINALG, "complex SVD: Rayleigh-Ritz eigen-solver failed");
+      for (int i = 0; i < m; ++i)
+        for (int j = 0; j < l; ++j) {
+          Xr[(size_t)i * l + j] = Vz[(size_t)i * m + j].real();
+          Xi[(size_t)i * l + j] = Vz[(size_t)i * m + j].imag();
+        }
+    }
+    if (trace) fprintf(stderr, "[eofx_rsvd_c64] Rayleigh-Ritz over %d blocks (order %d): leading Ritz values %.6e %.6e ... %.6e\n", nb, m, wv[0], l > 1 ? wv[1] : 0.0, wv[l - 1]);
+    // ---- tall Ritz panel A_op K y = sum_b slot_b (Rf[b] y_b)
+    std::vector<double> hEall((size_t)nb * LP * LP, 0.0), eb;
+    std::vector<zdouble> yb((size_t)l * l);
+    for (int b = 0; b < nb; ++b) {
+      for (int i = 0; i < l; ++i)
+        for (int j = 0; j < l; ++j) yb[(size_t)i * l + j] = zdouble(Xr[(size_t)(b * l + i) * l + j], Xi[(size_t)(b * l + i) * l + j]);
+      const std::vector<zdouble> cb = Rf[b].empty() ? yb : zmatmul(Rf[b], yb);
+      embed_right(cb, l, l, LP, LP, eb);
+      std::copy(eb.begin(), eb.end(), hEall.begin() + (size_t)b * LP * LP);
+    }
+    HIPCHK(hipMemcpyAsync(Eall, hEall.data(), sizeof(double) * hEall.size(), hipMemcpyHostToDevice, ctx->stream));
+    CHK(launch_matmul_gen(ctx, Pt, LP, tall_pad * LP, LP / 64, tall_pad, nb * LP, Eall, LP, nullptr, Yt));
+    HIPCHK(hipStreamSynchronize(ctx->stream));     // hEall leaves scope
+    return EOFX_OK;
+  };
+
   std::vector<double> w;
   std::vector<zdouble> Uh;
-  if (host_heigh(H, l, w, Uh) != EOFX_OK) return set_err(ctx, EOFX_ERR_LINALG, "complex SVD: Hermitian eigen-solver failed");
+  if (krylov) {
+    CHK(orth(Zs, small_pad, Vs));                    // Z_0: the orthonormalised start panel
+    std::swap(Zs, Vs);
+    std::vector<double> w_prev;
+    for (;;) {
+      const int q = std::min(q_cycle, n_iter - ctx->last_iters);
+      CHK(krylov_cycle(q));
+      CHK(orth(Yt, tall_pad, Qt));
+      CHK(orth(Qt, tall_pad, Yt));                   // Q in Yt (CholeskyQR2)
+      CHK(bwd(Yt, Ws, pf));                          // B^H, B = Q^H A_op
+      CHK(gram_h(Ws, small_pad));                    // B B^H
+      if (host_heigh(H, l, w, Uh) != EOFX_OK) return set_err(ctx, EOFX_ERR_LINALG, "complex SVD: Hermitian eigen-solver failed");
+      if (!adaptive) break;
+      double worst = 1.0;
+      if (w_prev.size() == (size_t)k) {
+        worst = 0.0;
+        for (int j = 0; j < k; ++j) worst = std::max(worst, std::fabs(w[j] - w_prev[j]) / std::max(w[j], 1e-300));
+      }
+      w_prev.assign(w.begin(), w.begin() + k);
+      if (trace) fprintf(stderr, "[eofx_rsvd_c64] cycle ends after %d products: max relative change of the leading %d Ritz values %.3e\n", ctx->last_iters, k, worst);
+      if ((worst <= 1e-6 && ctx->last_iters >= it_min) || ctx->last_iters >= n_iter) break;
+      // restart from the small-side Ritz block B^H Uh diag(1 / s), all l columns
+      std::vector<zdouble> Mr((size_t)l * l);
+      for (int j = 0; j < l; ++j) {
+        const double sv = std::sqrt(std::max(w[j], 0.0)), inv = sv > 0.0 ? 1.0 / sv : 0.0;
+        for (int i = 0; i < l; ++i) Mr[(size_t)i * l + j] = Uh[(size_t)i * l + j] * inv;
+      }
+      CHK(right_mul(Ws, small_pad, Mr, l, LP, Vs));
+      CHK(orth(Vs, small_pad, Zs));
+    }
+  } else {
+    bool orth_rest = orth_always;
+    std::vector<double> ritz_prev;
+    int calm = 0;
+    for (int it = 0; it < n_iter; ++it) {
+      CHK(fwd(Zs, Yt, pp));
+      if (it == 0 || orth_rest) {
+        CHK(orth(Yt, tall_pad, Qt));
+        CHK(bwd(Qt, Ws, pp));
+      } else {
+        CHK(bwd(Yt, Ws, pp));
+      }
+      CHK(gram_h(Ws, small_pad));
+      ctx->last_iters = it + 1;
+      if (it == 0 && !orth_always && n_iter > 1) {   // peaked spectrum?  the Hermitian Gram matrix is on the host already
+        std::vector<zdouble> V0;
+        std::vector<double> w0;
+        orth_rest = host_heigh(H, l, w0, V0) != EOFX_OK || !(w0[l - 1] > 0.0) || std::sqrt(w0[0] / w0[l - 1]) > EOFX_PEAKED_RATIO;
+      }
+      bool done = false;
+      if (adaptive) {
+        std::vector<zdouble> V0;
+        std::vector<double> w0;
+        if (host_heigh(H, l, w0, V0) == EOFX_OK) {
+          double worst = 0.0;
+          if (ritz_prev.size() == (size_t)k)
+            for (int j = 0; j < k; ++j) worst = std::max(worst, std::fabs(w0[j] - ritz_prev[j]) / std::max(w0[j], 1e-300));
+          else
+            worst = 1.0;
+          ritz_prev.assign(w0.begin(), w0.begin() + k);
+          calm = worst <= 1e-6 ? calm + 1 : 0;
+          if (trace) fprintf(stderr, "[eofx_rsvd_c64] iteration %d: max relative change of the leading %d Ritz values %.3e\n", it + 1, k, worst);
+          done = calm >= 2 && it + 1 >= it_min;
+        }
+      }
+      host_zchol_rinv(H, l, T, 1e-13);
+      CHK(right_mul(Ws, small_pad, T, l, LP, Zs));
+      if (done) break;
+    }
+    CHK(fwd(Zs, Yt, pp));
+    CHK(orth(Yt, tall_pad, Qt));
+    CHK(orth(Qt, tall_pad, Yt));                     // Q in Yt (CholeskyQR2)
+    CHK(bwd(Yt, Ws, pf));                            // B^H, B = Q^H A_op
+    CHK(gram_h(Ws, small_pad));                      // B B^H
+    if (host_heigh(H, l, w, Uh) != EOFX_OK) return set_err(ctx, EOFX_ERR_LINALG, "complex SVD: Hermitian eigen-solver failed");
+  }
   std::vector<zdouble> M1((size_t)l * k), M2((size_t)l * k);
   std::vector<float> hs(k);
   for (int j = 0; j < k; ++j) {

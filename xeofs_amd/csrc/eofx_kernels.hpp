@@ -1338,6 +1338,95 @@ __global__ __launch_bounds__(256) void f64_reduce_kernel(const double* __restric
 }
 
 // ---------------------------------------------------------------------------------
+// xgram_mfma (round 5): the float64 cross-Gram matrix C = Pa^T Pb of two row-major float32 panels with their own leading
+// dimensions (Pa: La columns, Pb: Lb columns; both multiples of 64) on the fp64 matrix cores -- the projection
+// coefficients K^H W and the columns of the Rayleigh-Ritz matrix of the complex block-Krylov decomposition.
+//   grid = (nbx, (La / 64) * (Lb / 64)); same wave layout, prefetch depth and fixed-order wave merge as gram_mfma_kernel
+//   (its bi != bj case); partial b of sub-block (bi, bj) lands in part[b][La x Lb]; f64_reduce_kernel sums the partials.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void xgram_mfma_kernel(const float* __restrict__ Pa, int64_t lda, const float* __restrict__ Pb,
+                                                          int64_t ldb, int64_t rows, int La, int Lb, double* __restrict__ part) {
+  const int nbj = Lb / 64;
+  const int bi = blockIdx.y / nbj, bj = blockIdx.y % nbj;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lc = lane & 15, lk = lane >> 4;
+  const int ca = 64 * bi + 4 * lc, cb = 64 * bj + 4 * lc;
+  f64x4 acc[4][4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) acc[x][y] = f64x4{0.0, 0.0, 0.0, 0.0};
+  const int64_t wstride = (int64_t)gridDim.x * 4 * 4;
+  auto fetch = [&](int64_t r0, f32x4& va, f32x4& vb) {
+    const int64_t r = r0 + lk;
+    va = f32x4{0.f, 0.f, 0.f, 0.f};
+    vb = va;
+    if (r < rows) {
+      va = *reinterpret_cast<const f32x4*>(Pa + r * lda + ca);
+      vb = *reinterpret_cast<const f32x4*>(Pb + r * ldb + cb);
+    }
+  };
+  constexpr int XG_PF = 4;
+  int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * 4;
+  f32x4 pa[XG_PF], pb[XG_PF];
+#pragma unroll
+  for (int d = 0; d < XG_PF; ++d) fetch(r0 + d * wstride, pa[d], pb[d]);
+  for (; r0 < rows; r0 += XG_PF * wstride) {
+#pragma unroll
+    for (int d = 0; d < XG_PF; ++d) {
+      const f32x4 va = pa[d], vb = pb[d];
+      fetch(r0 + (XG_PF + d) * wstride, pa[d], pb[d]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y)
+          acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)va[x], (double)vb[y], acc[x][y], 0, 0, 0);
+    }
+  }
+  __shared__ double Gs[64][65];
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int i = 4 * (lk + 4 * q) + x, j = 4 * lc + y;    // D[lane / 16 + 4 reg][lane % 16], as in gram_mfma_kernel
+            if (w == 0) Gs[i][j] = acc[x][y][q];
+            else Gs[i][j] += acc[x][y][q];
+          }
+    }
+    __syncthreads();
+  }
+  double* G = part + (int64_t)blockIdx.x * (int64_t)La * Lb;
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    const int i = e >> 6, j = e & 63;
+    G[(int64_t)(64 * bi + i) * Lb + 64 * bj + j] = Gs[i][j];
+  }
+}
+
+// The real cross-Gram matrix C [(nb LP) x LP] of complex panels held as [Re(h) | Im(h)] (LP = 2 h) -> the real matrix
+// E [(nb LP) x LP] with [Kr | Ki] E = [Re(K c) | Im(K c)] for the complex coefficients c = K^H W of every block:
+//   c = (rr + ii) + i (ri - ir),   E_b = [[Re c, Im c], [-Im c, Re c]]
+__global__ __launch_bounds__(256) void cproj_embed_kernel(const double* __restrict__ C, int nb, int LP, double* __restrict__ E) {
+  const int h = LP / 2;
+  const int64_t total = (int64_t)nb * h * h;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(t / (h * h)), i = (int)(t / h % h), j = (int)(t % h);
+    const double* Cb = C + (int64_t)b * LP * LP;
+    double* Eb = E + (int64_t)b * LP * LP;
+    const double rr = Cb[i * LP + j], ii = Cb[(h + i) * LP + h + j], ri = Cb[i * LP + h + j], ir = Cb[(h + i) * LP + j];
+    const double cr = rr + ii, ci = ri - ir;
+    Eb[i * LP + j] = cr;
+    Eb[(h + i) * LP + j] = -ci;
+    Eb[i * LP + h + j] = ci;
+    Eb[(h + i) * LP + h + j] = cr;
+  }
+}
+
+// ---------------------------------------------------------------------------------
 // chol_rinv: single workgroup.  G (L x L float64, leading l x l block used) -> Rinv with
 // G = R^T R, Rinv = R^-1 (upper triangular), zero outside l x l.  A pivot that falls below
 // tol * G[j][j] marks column j as linearly dependent: its Q column becomes exactly zero.
@@ -1591,11 +1680,18 @@ __global__ void chol_blocked_export_kernel(const double* __restrict__ X, int Lb,
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 constexpr int PMM_LD = 66;   // doubles per staged row of Mx
 
+// GEN (round 5, the block-Krylov steps of eofx_rsvd_c64): the inner dimension is a list of 64-column chunks, chunk c at
+// P + (c / cpb) * slab + (c % cpb) * 64 with row stride ldp (a wide row-major panel: cpb = all its chunks, ldp = its width; a
+// stack of separate panels of cpb chunks each: slab = rows_pad * 64 cpb, ldp = 64 cpb), and with `sub` the kernel writes
+// sub - P Mx (a projection step).
+template <bool GEN = false>
 __global__ __launch_bounds__(256) void panel_matmul_kernel(const float* __restrict__ P,
                                                            int64_t rows, int L,
                                                            const double* __restrict__ Mx, int Lo,
                                                            float* __restrict__ out, int KW,
-                                                           unsigned* __restrict__ amax_out = nullptr) {
+                                                           unsigned* __restrict__ amax_out = nullptr,
+                                                           int64_t ldp = 0, int64_t slab = 0, int cpb = 1,
+                                                           const float* __restrict__ sub = nullptr) {
   extern __shared__ __attribute__((aligned(16))) double Ms[];
   float amx = 0.f;   // [KW][PMM_LD]: KW = multiple of 64, the K window in LDS
   const int tid = threadIdx.x;
@@ -1618,8 +1714,12 @@ __global__ __launch_bounds__(256) void panel_matmul_kernel(const float* __restri
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt) {
         const int k = kc + 16 * tt + 4 * lk;
-        a[t][tt] = (valid && r < rows && k < L) ? *reinterpret_cast<const f32x4*>(P + r * L + k)
-                                               : f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (GEN)
+          a[t][tt] = (valid && r < rows && k < L) ? *reinterpret_cast<const f32x4*>(P + (int64_t)((k >> 6) / cpb) * slab + ((k >> 6) % cpb) * 64 + r * ldp + (k & 63))
+                                                 : f32x4{0.f, 0.f, 0.f, 0.f};
+        else
+          a[t][tt] = (valid && r < rows && k < L) ? *reinterpret_cast<const f32x4*>(P + r * L + k)
+                                                 : f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
   };
@@ -1656,7 +1756,10 @@ __global__ __launch_bounds__(256) void panel_matmul_kernel(const float* __restri
           for (int q = 0; q < 4; ++q) {
             const int col = c0 + 16 * q + li;
             if (col < Lo) {
-              const float o_ = (float)acc[t][q][r];
+              float o_ = (float)acc[t][q][r];
+              if constexpr (GEN) {
+                if (sub) o_ = (float)((double)sub[row * Lo + col] - acc[t][q][r]);
+              }
               out[row * Lo + col] = o_;
               amx = fmaxf(amx, fabsf(o_));
             }
