@@ -420,28 +420,41 @@ def leg_configs(ctx, device, orc, layout_kw, quick=False):
         del X, U, V, Pn, ZV, ZVc, Us
         torch.cuda.empty_cache()
         ctx.trim()
-        # oracle gate of the same path at 2000 x (40 x 80): scipy-equivalent Hilbert transform (padding "exp") + EXACT complex SVD
+        # oracle gate of the same path at 2000 x (40 x 80): scipy-equivalent Hilbert transform (padding "exp") + EXACT complex SVD,
+        # and the REFERENCE'S OWN solver on the same matrix (scipy svds(lobpcg), xeofs/linalg/decomposer.py:149-160) beside it.
+        # Gated: the engine's DEFAULT rule (n_iter="auto": scikit-learn's count, block Krylov since round 5) -- per mode
+        # |s - s_exact| / s_exact <= max(1e-5, the reference solver's own error); `n_iter="converge"` is reported beside it.
         n5, nlat5, nlon5 = 2000, 40, 80
         X5 = make_field(n5, nlat5, nlon5, 0, nlat5 * nlon5, device, seed=51_000)
         A5, _ = engine.preprocess(ctx, X5, want_stats=False, in_place=True)
         B5, _ = engine.hilbert(ctx, A5, "exp", 0.2)
-        # the reference's complex solver (lobpcg) converges to a tolerance: the gate runs the engine's "converge" rule; the
-        # fixed scikit-learn-style count the timing above uses (n_iter="auto") is reported beside it, not gated -- this
-        # sample's spectrum runs into its noise bulk, where seven power iterations stop short (complex branch)
-        U5, s5, V5 = engine.rsvd_c64(ctx, A5, B5, k, random_state=5, n_iter="converge")
+        U5, s5, V5 = engine.rsvd_c64(ctx, A5, B5, k, random_state=5)
         its_g = engine.last_iterations(ctx)
-        _, s5a, _ = engine.rsvd_c64(ctx, A5, B5, k, random_state=5)
+        _, s5c, _ = engine.rsvd_c64(ctx, A5, B5, k, random_state=5, n_iter="converge")
+        its_c = engine.last_iterations(ctx)
         A5.free(); B5.free()
         x64 = X5.cpu().numpy().astype(np.float64)
         z = orc.hilbert_transform(x64 - x64.mean(axis=0), padding="exp", decay_factor=0.2)
         _, sz, vhz = np.linalg.svd(z, full_matrices=False)
-        g5 = {"sample": f"{n5} x ({nlat5}x{nlon5}), oracle = Hilbert transform restatement (padding 'exp') + exact complex SVD, float64",
+        import warnings as _w
+        with _w.catch_warnings():
+            _w.simplefilter("ignore")      # (lobpcg reports the modes it did not converge)
+            _, s_lob, _ = orc.complex_svds(z, k, random_state=5)
+        e_eng = np.abs(np.asarray(s5, dtype=np.float64) - sz[:k]) / sz[:k]
+        e_lob = np.abs(s_lob - sz[:k]) / sz[:k]
+        e_conv = np.abs(np.asarray(s5c, dtype=np.float64) - sz[:k]) / sz[:k]
+        g5 = {"sample": f"{n5} x ({nlat5}x{nlon5}), oracle = Hilbert transform restatement (padding 'exp') + exact complex SVD, float64; "
+                        "reference solver = scipy svds(lobpcg) on the same matrix",
+              "rule": "n_iter='auto' (the timed rule)",
               "sv_relerr": float(np.max(np.abs(np.asarray(s5, dtype=np.float64) - sz[:k]) / sz[0])),
+              "sv_relerr_per_mode_max": float(e_eng.max()),
+              "reference_solver_relerr_per_mode_max": float(e_lob.max()),
+              "per_mode_le_max_1e-5_or_reference": bool(np.all(e_eng <= np.maximum(1e-5, e_lob))),
               "right": vector_gate(sz[:k], np.asarray(V5), vhz[:k].conj().T, complex_phase=True),
               "power_iterations": its_g,
-              "sv_relerr_with_n_iter_auto": float(np.max(np.abs(np.asarray(s5a, dtype=np.float64) - sz[:k]) / sz[0]))}
+              "sv_relerr_per_mode_max_with_n_iter_converge": float(e_conv.max()), "power_iterations_converge": its_c}
         out["config5"]["parity"]["oracle_gate"] = g5
-        if not (g5["sv_relerr"] <= 1e-5 and g5["right"]["min_abs_cos"] >= 1 - 1e-5):
+        if not (g5["sv_relerr"] <= 1e-5 and g5["per_mode_le_max_1e-5_or_reference"] and g5["right"]["min_abs_cos"] >= 1 - 1e-5):
             gate.append(f"config 5 oracle gate: {g5}")
         del X5, x64, z, vhz
     return out, gate

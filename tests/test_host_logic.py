@@ -84,3 +84,54 @@ def test_cross_model_sketch_ahead_gate():
     unseeded = xe.cross.MCA(n_modes=3, use_pca=False)
     unseeded._SKETCH_AHEAD_MIN = 1000
     assert unseeded._sketch_ahead(X, Y, "time") is None
+
+
+@pytest.mark.parametrize("m,nev", [(1, 1), (2, 2), (7, 3), (60, 30), (150, 30), (240, 30), (256, 32), (96, 96)])
+def test_host_hermitian_top_eigensolver(m, nev):
+    """eofx_host_zheigh_top_f64 (the Rayleigh-Ritz step of the block-Krylov complex decomposition; Householder reduction to a
+    real tridiagonal matrix + QL values + inverse iteration + back-transformation, csrc/eofx_hosteig.hpp) against numpy:
+    values to 1e-12 of the norm, residual and orthonormality of the returned basis -- on a random Hermitian matrix, on
+    one with exactly repeated and nearly repeated leading eigenvalues, and on a block-tridiagonal one with zero rows
+    (dead Lanczos columns)."""
+    from xeofs_amd import _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(m + nev)
+
+    def run(A):
+        Hr, Hi = np.ascontiguousarray(A.real), np.ascontiguousarray(A.imag)
+        w = np.zeros(nev)
+        Xr, Xi = np.zeros((m, nev)), np.zeros((m, nev))
+        rc = lib.eofx_host_zheigh_top_f64(Hr.ctypes.data, Hi.ctypes.data, m, nev, w.ctypes.data, Xr.ctypes.data, Xi.ctypes.data)
+        assert rc == 0
+        X = Xr + 1j * Xi
+        we = np.linalg.eigvalsh(A)[::-1][:nev]
+        scale = max(np.abs(np.linalg.eigvalsh(A)).max(), 1e-300)
+        assert np.abs(w - we).max() <= 1e-12 * scale
+        assert np.abs(X.conj().T @ X - np.eye(nev)).max() <= 1e-11
+        # the basis spans the leading invariant subspace: the projected matrix reproduces the values
+        assert np.abs(np.linalg.eigvalsh(X.conj().T @ A @ X)[::-1] - we).max() <= 1e-10 * scale
+        return w, X
+
+    A = rng.standard_normal((m, m)) + 1j * rng.standard_normal((m, m))
+    A = A + A.conj().T
+    w, X = run(A)
+    assert np.abs(A @ X - X * w).max() <= 1e-10 * np.abs(w).max()
+    if m >= 60:
+        Q, _ = np.linalg.qr(A)
+        lam = np.concatenate([np.full(5, 9.0), np.full(5, 9.0 - 1e-13), np.linspace(8, -3, m - 10)])
+        run((Q * lam) @ Q.conj().T)
+        # block tridiagonal with dead columns (zero rows / columns)
+        b = 30
+        T = np.zeros((m, m), complex)
+        for i in range(0, m, b):
+            D = rng.standard_normal((min(b, m - i),) * 2) + 1j * rng.standard_normal((min(b, m - i),) * 2)
+            T[i:i + b, i:i + b] = D @ D.conj().T
+            if i + b < m:
+                R = np.triu(rng.standard_normal((b, min(b, m - i - b))) + 1j * rng.standard_normal((b, min(b, m - i - b))))
+                T[i:i + b, i + b:i + 2 * b] = R
+                T[i + b:i + 2 * b, i:i + b] = R.conj().T
+        dead = rng.choice(m, size=m // 10, replace=False)
+        T[dead, :] = 0
+        T[:, dead] = 0
+        run(T)

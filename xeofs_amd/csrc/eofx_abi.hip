@@ -4255,18 +4255,19 @@ extern "C" int eofx_rsvd_c64(eofx_ctx* ctx, const eofx_mat* A, const eofx_mat* B
   const int64_t small_pad = transposed ? A->n_pad : A->p_pad, tall_pad = transposed ? A->p_pad : A->n_pad;
   const int64_t big = std::max(A->n_pad, A->p_pad);
   // block Krylov: products per cycle, blocks, order of the Rayleigh-Ritz problem
-  const int q_cycle = adaptive ? auto_count : n_iter;
+  // blocks kept before a thick restart: the Rayleigh-Ritz problem stays below order 384 (the host solves it: ~10 ms at 240)
   constexpr int KRYLOV_MAX_ORDER = 384;
   const char* kenv = std::getenv("EOFX_C64_KRYLOV");
-  const bool krylov = q_cycle >= 1 && (q_cycle + 1) * l <= KRYLOV_MAX_ORDER && !(kenv && atoi(kenv) == 0);
-  const int nbmax = krylov ? q_cycle + 1 : 0;
+  const int nb_fit = KRYLOV_MAX_ORDER / l;
+  const bool krylov = n_iter >= 1 && nb_fit >= 3 && !(kenv && atoi(kenv) == 0);
+  const int nbmax = krylov ? std::min(n_iter + 1, nb_fit) : 0;
   const int64_t ldk = (int64_t)nbmax * LP;
   size_t need = (size_t)(2 * small_pad + 2 * tall_pad + 2 * big) * LP * 4 + (size_t)(small_pad + tall_pad) * Lo * 4;
   need += 2 * atb_scratch_bytes(A->p_pad, round_up(n, ATB_KG), LP) + 2 * atb_scratch_bytes(A->n_pad, round_up(p, ATB_KG), LP);
   need += (size_t)(4 * gram_parts(big, LP) + 8) * LP * LP * 8 + (size_t)big * (Lo + LP) * 4 + (8 << 20);
   if (krylov)
-    need += (size_t)nbmax * (small_pad + tall_pad) * LP * 4 + (size_t)small_pad * LP * 4 + (size_t)(3 + q_cycle) * nbmax * LP * LP * 8 +
-            ((size_t)40 << 20);
+    need += (size_t)nbmax * (2 * small_pad + tall_pad) * LP * 4 + (size_t)small_pad * LP * 4 + (size_t)(3 + nbmax) * nbmax * LP * LP * 8 +
+            ((size_t)48 << 20);
   CHK(arena_reserve(ctx, need));
   ArenaScope scope(ctx);
   ARENA(float, Zs, (size_t)small_pad * LP);
@@ -4279,17 +4280,18 @@ extern "C" int eofx_rsvd_c64(eofx_ctx* ctx, const eofx_mat* A, const eofx_mat* B
   ARENA(float, Sv, (size_t)small_pad * Lo);
   ARENA(double, G, (size_t)LP * LP);
   ARENA(double, Ed, (size_t)LP * LP);
-  float *Kw = nullptr, *Pt = nullptr, *Vs = nullptr;
-  double *Cd = nullptr, *Ecd = nullptr, *Eall = nullptr, *Hd = nullptr;
+  float *Kw = nullptr, *Ww = nullptr, *Pt = nullptr, *Vs = nullptr;
+  double *Cd = nullptr, *Ecd = nullptr, *Eall = nullptr, *Cf = nullptr;
   if (krylov) {
     Kw = arena_alloc<float>(ctx, (size_t)small_pad * ldk);               // the Krylov blocks Z_0 .. Z_q side by side
+    Ww = arena_alloc<float>(ctx, (size_t)small_pad * ldk);               // their products W_i = A_op^H (A_op Z_i)
     Pt = arena_alloc<float>(ctx, (size_t)nbmax * tall_pad * LP);         // the tall panels P_i = A_op Z_i (or their Q factors)
     Vs = arena_alloc<float>(ctx, (size_t)small_pad * LP);
     Cd = arena_alloc<double>(ctx, (size_t)nbmax * LP * LP);
     Ecd = arena_alloc<double>(ctx, (size_t)nbmax * LP * LP);
     Eall = arena_alloc<double>(ctx, (size_t)nbmax * LP * LP);
-    Hd = arena_alloc<double>(ctx, (size_t)q_cycle * nbmax * LP * LP);
-    if (!Kw || !Pt || !Vs || !Cd || !Ecd || !Eall || !Hd) return set_err(ctx, EOFX_ERR_NOMEM, "arena exhausted (block Krylov panels)");
+    Cf = arena_alloc<double>(ctx, (size_t)nbmax * nbmax * LP * LP);
+    if (!Kw || !Ww || !Pt || !Vs || !Cd || !Ecd || !Eall || !Cf) return set_err(ctx, EOFX_ERR_NOMEM, "arena exhausted (block Krylov panels)");
   }
   CplxOps ops{ctx, A, B, LP, rot, tmp, std::max(A->absmax, B->absmax)};
   if (lean) CHK(cplx_lean_setup(ctx, ops));
@@ -4333,12 +4335,14 @@ extern "C" int eofx_rsvd_c64(eofx_ctx* ctx, const eofx_mat* A, const eofx_mat* B
   const bool trace = std::getenv("EOFX_C64_TRACE") != nullptr;
   ctx->last_iters = 0;
 
-  // ---- one cycle of the block Lanczos recurrence: Zs (orthonormal start block) -> Yt = A_op K y, the tall Ritz panel
-  auto cplx_block = [&](const double* g, std::vector<zdouble>& out) {      // complex l x l block of a real LP x LP cross-Gram block
+  // ---- block Lanczos state: blocks Z_0 .. Z_{nb-1} side by side in Kw (orthonormal, dead columns zero); block b < nW has
+  //      been multiplied: slot b of Pt holds A_op Z_b (or its Q factor, then Rf[b] is the triangular factor) and block b of Ww
+  //      holds W_b with M Z_b = W_b Rf[b]
+  auto cplx_block = [&](const double* g, int64_t ldc, std::vector<zdouble>& out) {   // complex l x l block of a real LP x LP cross-Gram block
     out.assign((size_t)l * l, zdouble(0.0, 0.0));
     for (int i = 0; i < l; ++i)
       for (int j = 0; j < l; ++j)
-        out[(size_t)i * l + j] = zdouble(g[(size_t)i * LP + j] + g[(size_t)(h + i) * LP + h + j], g[(size_t)i * LP + h + j] - g[(size_t)(h + i) * LP + j]);
+        out[(size_t)i * l + j] = zdouble(g[(size_t)i * ldc + j] + g[(size_t)(h + i) * ldc + h + j], g[(size_t)i * ldc + h + j] - g[(size_t)(h + i) * ldc + j]);
   };
   auto zmatmul = [&](const std::vector<zdouble>& X, const std::vector<zdouble>& Y) {    // l x l
     std::vector<zdouble> Z((size_t)l * l, zdouble(0.0, 0.0));
@@ -4350,8 +4354,8 @@ extern "C" int eofx_rsvd_c64(eofx_ctx* ctx, const eofx_mat* A, const eofx_mat* B
       }
     return Z;
   };
-  auto copy_block = [&](const float* src, int blk) -> int {
-    HIPCHK(hipMemcpy2DAsync(Kw + (size_t)blk * LP, sizeof(float) * ldk, src, sizeof(float) * LP, sizeof(float) * LP, (size_t)small_pad,
+  auto copy_block = [&](float* wide, const float* src, int blk) -> int {
+    HIPCHK(hipMemcpy2DAsync(wide + (size_t)blk * LP, sizeof(float) * ldk, src, sizeof(float) * LP, sizeof(float) * LP, (size_t)small_pad,
                             hipMemcpyDeviceToDevice, ctx->stream));
     return EOFX_OK;
   };
@@ -4368,121 +4372,107 @@ extern "C" int eofx_rsvd_c64(eofx_ctx* ctx, const eofx_mat* A, const eofx_mat* B
     KCHK();
     return launch_matmul_gen(ctx, Kw, ldk, 64, 1 << 20, small_pad, nbk * LP, Ecd, LP, Win, out);
   };
-  // Cholesky-QR with the dependency rules of a Lanczos block: a column dies when what is left of it after the columns before it
-  // falls below 1e-13 of its own squared norm (as everywhere), or below tolref x dref[j] (its squared norm BEFORE the projection:
-  // a residual below 1e-5 of the product is rounding noise of a converged direction; a re-projected unit column that kept less
-  // than half its length lay inside the blocks already there)
-  auto orth_block = [&](const float* P, float* out, const double* dref, double tolref, int* live) -> int {
-    CHK(gram_h(P, small_pad));
-    host_zchol_rinv(H, l, T, 1e-13, nullptr, live, dref, tolref);
-    return right_mul(P, small_pad, T, l, LP, out);
-  };
-  auto krylov_cycle = [&](int q) -> int {
-    std::vector<std::vector<double>> Hc(q);         // real cross-Gram [Z_0 .. Z_{i+1}]^T W_i
-    std::vector<std::vector<zdouble>> Rf(q + 1);    // M Z_i = W_i Rf[i] (empty = identity: the tall panel was not orthonormalised)
-    std::vector<zdouble> Hqq;
-    int nb = 1, nW = 0;
-    bool exhausted = false, orth_rest = orth_always;
-    std::vector<double> dref(l), ones(l, 1.0);
-    std::vector<zdouble> blk;
-    CHK(copy_block(Zs, 0));
-    for (int it = 0; it < q; ++it) {
-      float* slot = Pt + (size_t)it * tall_pad * LP;
-      if (it == 0 || orth_rest) {
-        CHK(fwd(Zs, Yt, pp));
-        CHK(gram_h(Yt, tall_pad));
-        host_zchol_rinv(H, l, T, 1e-13, &Rf[it]);
-        CHK(right_mul(Yt, tall_pad, T, l, LP, slot));
-      } else {
-        CHK(fwd(Zs, slot, pp));
-      }
-      CHK(bwd(slot, Ws, pp));
-      ++ctx->last_iters;
-      CHK(project(Ws, nb, Vs, true));
-      CHK(gram_h(Vs, small_pad));                    // (synchronises: hC is on the host)
-      // |W_j|^2 = |V_j|^2 + |K^H W_j|^2
-      for (int j = 0; j < l; ++j) dref[j] = H[(size_t)j * l + j].real();
-      for (int b = 0; b < nb; ++b) {
-        cplx_block(&hC[(size_t)b * LP * LP], blk);
-        for (int i = 0; i < l; ++i)
-          for (int j = 0; j < l; ++j) dref[j] += std::norm(blk[(size_t)i * l + j]);
-      }
-      if (it == 0 && !orth_always && q > 1) {        // peaked spectrum?  H_00 = Z_0^H M Z_0 is on the host
-        cplx_block(hC.data(), blk);
-        std::vector<zdouble> H00 = Rf[0].empty() ? blk : zmatmul(blk, Rf[0]), V0;
-        for (int i = 0; i < l; ++i)
-          for (int j = i; j < l; ++j) {
-            const zdouble v = 0.5 * (H00[(size_t)i * l + j] + std::conj(H00[(size_t)j * l + i]));
-            H00[(size_t)i * l + j] = v;
-            H00[(size_t)j * l + i] = std::conj(v);
-          }
-        std::vector<double> w0;
-        orth_rest = host_heigh(H00, l, w0, V0) != EOFX_OK || !(w0[l - 1] > 0.0) || std::sqrt(w0[0] / w0[l - 1]) > EOFX_PEAKED_RATIO;
-      }
-      int live = 0;
-      host_zchol_rinv(H, l, T, 1e-13, nullptr, &live, dref.data(), 1e-10);
+  int nb = 0, nW = 0;
+  bool exhausted = false, orth_rest = orth_always;
+  std::vector<std::vector<zdouble>> Rf(nbmax);      // (empty = identity: the tall panel was not orthonormalised)
+  std::vector<zdouble> Hqq, blk;
+  std::vector<double> dref(l), ones(l, 1.0);
+  // multiply the newest block (b = nb - 1 = nW): slot b, W_b; then the next block = what is left of W_b after two rounds of
+  // (project on all blocks, Cholesky-QR).  A column of the new block dies when what is left of it after the columns before it
+  // falls below 1e-13 of its own squared norm (as everywhere), or -- first round -- below 1e-10 of its squared norm BEFORE the
+  // projection (a residual below 1e-5 of the product is the rounding noise of a converged direction), or -- second round --
+  // when the re-projected unit column kept less than half its length (it lay inside the blocks already there).
+  auto lanczos_step = [&]() -> int {
+    const int b = nW;
+    float* slot = Pt + (size_t)b * tall_pad * LP;
+    Rf[b].clear();
+    if (ctx->last_iters == 0 || orth_rest) {
+      CHK(fwd(Zs, Yt, pp));
+      CHK(gram_h(Yt, tall_pad));
+      host_zchol_rinv(H, l, T, 1e-13, &Rf[b]);
+      CHK(right_mul(Yt, tall_pad, T, l, LP, slot));
+    } else {
+      CHK(fwd(Zs, slot, pp));
+    }
+    CHK(bwd(slot, Ws, pp));
+    const bool first = ctx->last_iters == 0;
+    ++ctx->last_iters;
+    CHK(copy_block(Ww, Ws, b));
+    nW = b + 1;
+    CHK(project(Ws, nb, Vs, true));
+    CHK(gram_h(Vs, small_pad));                      // (synchronises: hC is on the host)
+    for (int j = 0; j < l; ++j) dref[j] = H[(size_t)j * l + j].real();      // |W_j|^2 = |V_j|^2 + |K^H W_j|^2
+    for (int c = 0; c < nb; ++c) {
+      cplx_block(&hC[(size_t)c * LP * LP], LP, blk);
+      for (int i = 0; i < l; ++i)
+        for (int j = 0; j < l; ++j) dref[j] += std::norm(blk[(size_t)i * l + j]);
+    }
+    if (first && !orth_always && n_iter > 1) {       // peaked spectrum?  H_00 = Z_0^H M Z_0 is on the host
+      cplx_block(hC.data(), LP, blk);
+      std::vector<zdouble> H00 = Rf[0].empty() ? blk : zmatmul(blk, Rf[0]), V0;
+      for (int i = 0; i < l; ++i)
+        for (int j = i; j < l; ++j) {
+          const zdouble v = 0.5 * (H00[(size_t)i * l + j] + std::conj(H00[(size_t)j * l + i]));
+          H00[(size_t)i * l + j] = v;
+          H00[(size_t)j * l + i] = std::conj(v);
+        }
+      std::vector<double> w0;
+      orth_rest = host_heigh(H00, l, w0, V0) != EOFX_OK || !(w0[l - 1] > 0.0) || std::sqrt(w0[0] / w0[l - 1]) > EOFX_PEAKED_RATIO;
+    }
+    int live = 0;
+    host_zchol_rinv(H, l, T, 1e-13, nullptr, &live, dref.data(), 1e-10);
+    CHK(right_mul(Vs, small_pad, T, l, LP, Zs));
+    if (live > 0) {
+      CHK(project(Zs, nb, Vs, false));
+      CHK(gram_h(Vs, small_pad));
+      host_zchol_rinv(H, l, T, 1e-13, nullptr, &live, ones.data(), 0.25);
       CHK(right_mul(Vs, small_pad, T, l, LP, Zs));
-      if (live > 0) {
-        CHK(project(Zs, nb, Vs, false));
-        CHK(orth_block(Vs, Zs, ones.data(), 0.25, &live));
-      }
-      if (live > 0) {
-        CHK(copy_block(Zs, nb));
-        ++nb;
-      }
-      double* Hdi = Hd + (size_t)it * nbmax * LP * LP;
-      CHK(launch_xgram(ctx, Kw, ldk, nb * LP, Ws, LP, LP, small_pad, Hdi));
-      Hc[it].resize((size_t)nb * LP * LP);
-      HIPCHK(hipMemcpyAsync(Hc[it].data(), Hdi, sizeof(double) * Hc[it].size(), hipMemcpyDeviceToHost, ctx->stream));
-      nW = it + 1;
-      if (trace) fprintf(stderr, "[eofx_rsvd_c64] Lanczos step %d: %d live columns in the new block (%d blocks)\n", it + 1, live, nb);
-      if (live == 0) {
-        exhausted = true;      // the Krylov space is invariant: every product of its blocks is known
-        break;
-      }
     }
-    if (!exhausted) {          // the last block's panel: its diagonal block of H is P_q^H P_q
-      float* slot = Pt + (size_t)(nb - 1) * tall_pad * LP;
-      if (orth_rest || q == 0) {
-        CHK(fwd(Zs, Yt, pp));
-        CHK(gram_h(Yt, tall_pad));
-        Hqq = H;
-        host_zchol_rinv(H, l, T, 1e-13, &Rf[nb - 1]);
-        CHK(right_mul(Yt, tall_pad, T, l, LP, slot));
-      } else {
-        CHK(fwd(Zs, slot, pp));
-        CHK(gram_h(slot, tall_pad));
-        Hqq = H;
-      }
+    if (trace) fprintf(stderr, "[eofx_rsvd_c64] product %d: %d live columns in the next block (%d blocks)\n", ctx->last_iters, live, nb + (live > 0));
+    if (live == 0) {
+      exhausted = true;        // the Krylov space is invariant: every product of its blocks is known
+      return EOFX_OK;
     }
+    CHK(copy_block(Kw, Zs, nb));
+    ++nb;
+    return EOFX_OK;
+  };
+  // Rayleigh-Ritz over the first nbr blocks: H = K^H M K from the columns K^H W_i Rf[i] (i < nW) and, when the newest block has no
+  // product yet, P^H P of its tall panel (Hqq).  -> leading l eigenvectors X (order nbr l), values wv; res[j] (with_res): the
+  // norm of the part of M K y_j outside the first nbr blocks, read off the coupling to block nbr.
+  std::vector<double> Xr, Xi, wv, hCf;
+  auto rayleigh_ritz = [&](int nbr, bool with_last, std::vector<double>* res) -> int {
+    const int nWr = std::min(nW, nbr);
+    const int nrow = res ? std::min(nb, nbr + 1) : nbr;         // one more block row: the coupling
+    CHK(launch_xgram(ctx, Kw, ldk, nrow * LP, Ww, ldk, nWr * LP, small_pad, Cf));
+    hCf.resize((size_t)nrow * LP * nWr * LP);
+    HIPCHK(hipMemcpyAsync(hCf.data(), Cf, sizeof(double) * hCf.size(), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    // ---- H = K^H M K (order nb l), Hermitian, from the columns K^H W_i Rf[i]
-    const int m = nb * l;
-    std::vector<std::vector<zdouble>> raw((size_t)nb * nb);
-    for (int i = 0; i < nW; ++i) {
-      const int rows_b = (int)(Hc[i].size() / ((size_t)LP * LP));
-      for (int j = 0; j < rows_b && j < nb; ++j) {
-        cplx_block(&Hc[i][(size_t)j * LP * LP], blk);
-        raw[(size_t)j * nb + i] = Rf[i].empty() ? blk : zmatmul(blk, Rf[i]);
+    const int64_t ldc = (int64_t)nWr * LP;
+    const int m = nbr * l;
+    std::vector<std::vector<zdouble>> raw((size_t)nrow * nbr);
+    for (int i = 0; i < nWr; ++i)
+      for (int j = 0; j < nrow; ++j) {
+        cplx_block(&hCf[(size_t)j * LP * ldc + (size_t)i * LP], ldc, blk);
+        raw[(size_t)j * nbr + i] = Rf[i].empty() ? blk : zmatmul(blk, Rf[i]);
       }
-    }
-    if (!exhausted) raw[(size_t)(nb - 1) * nb + nb - 1] = Hqq;
+    if (with_last) raw[(size_t)(nbr - 1) * nbr + nbr - 1] = Hqq;
     std::vector<double> Hr((size_t)m * m, 0.0), Hi((size_t)m * m, 0.0);
-    for (int a = 0; a < nb; ++a)
-      for (int b = a; b < nb; ++b) {
-        const std::vector<zdouble>& u = raw[(size_t)a * nb + b];     // block (a, b)
-        const std::vector<zdouble>& v = raw[(size_t)b * nb + a];     // block (b, a): its conjugate transpose is another reading of (a, b)
+    for (int a = 0; a < nbr; ++a)
+      for (int c = a; c < nbr; ++c) {
+        const std::vector<zdouble>& u = raw[(size_t)a * nbr + c];     // block (a, c)
+        const std::vector<zdouble>& v = raw[(size_t)c * nbr + a];     // block (c, a): its conjugate transpose is another reading of (a, c)
         if (u.empty() && v.empty()) continue;
-        const double wu = u.empty() ? 0.0 : (v.empty() ? 1.0 : 0.5), wv = v.empty() ? 0.0 : (u.empty() ? 1.0 : 0.5);
+        const double wu = u.empty() ? 0.0 : (v.empty() ? 1.0 : 0.5), wvv = v.empty() ? 0.0 : (u.empty() ? 1.0 : 0.5);
         for (int i = 0; i < l; ++i)
           for (int j = 0; j < l; ++j) {
             zdouble val(0.0, 0.0);
             if (!u.empty()) val += wu * u[(size_t)i * l + j];
-            if (!v.empty()) val += wv * std::conj(v[(size_t)j * l + i]);
-            const size_t ij = (size_t)(a * l + i) * m + b * l + j, ji = (size_t)(b * l + j) * m + a * l + i;
+            if (!v.empty()) val += wvv * std::conj(v[(size_t)j * l + i]);
+            const size_t ij = (size_t)(a * l + i) * m + c * l + j, ji = (size_t)(c * l + j) * m + a * l + i;
             Hr[ij] = val.real();
             Hi[ij] = val.imag();
-            if (a != b) {
+            if (a != c) {
               Hr[ji] = val.real();
               Hi[ji] = -val.imag();
             }
@@ -4490,7 +4480,9 @@ extern "C" int eofx_rsvd_c64(eofx_ctx* ctx, const eofx_mat* A, const eofx_mat* B
       }
     for (double v : Hr)
       if (!std::isfinite(v)) return set_err(ctx, EOFX_ERR_LINALG, "SVD failed. This may be due to isolated NaN values in the data.");
-    std::vector<double> wv(l), Xr((size_t)m * l), Xi((size_t)m * l);
+    wv.assign(l, 0.0);
+    Xr.assign((size_t)m * l, 0.0);
+    Xi.assign((size_t)m * l, 0.0);
     if (hosteig::zheigh_top(Hr.data(), Hi.data(), m, l, wv.data(), Xr.data(), Xi.data()) != 0) {
       // general-purpose route (real symmetric embedding): slower, no assumptions
       std::vector<zdouble> Hz((size_t)m * m), Vz;
@@ -4502,21 +4494,63 @@ extern "C" int eofx_rsvd_c64(eofx_ctx* ctx, const eofx_mat* A, const eofx_mat* B
           Xr[(size_t)i * l + j] = Vz[(size_t)i * m + j].real();
           Xi[(size_t)i * l + j] = Vz[(size_t)i * m + j].imag();
         }
+      std::copy(wz.begin(), wz.begin() + l, wv.begin());
     }
-    if (trace) fprintf(stderr, "[eofx_rsvd_c64] Rayleigh-Ritz over %d blocks (order %d): leading Ritz values %.6e %.6e ... %.6e\n", nb, m, wv[0], l > 1 ? wv[1] : 0.0, wv[l - 1]);
-    // ---- tall Ritz panel A_op K y = sum_b slot_b (Rf[b] y_b)
-    std::vector<double> hEall((size_t)nb * LP * LP, 0.0), eb;
+    if (res) {
+      res->assign(l, 0.0);
+      if (nrow > nbr)
+        for (int j = 0; j < l; ++j) {
+          double r2 = 0.0;
+          for (int i2 = 0; i2 < l; ++i2) {           // row i2 of block nbr of M K y_j
+            zdouble acc(0.0, 0.0);
+            for (int c = 0; c < nWr; ++c) {
+              const std::vector<zdouble>& cb = raw[(size_t)nbr * nbr + c];
+              if (cb.empty()) continue;
+              for (int t = 0; t < l; ++t) acc += cb[(size_t)i2 * l + t] * zdouble(Xr[(size_t)(c * l + t) * l + j], Xi[(size_t)(c * l + t) * l + j]);
+            }
+            r2 += std::norm(acc);
+          }
+          (*res)[j] = std::sqrt(r2);
+        }
+    }
+    return EOFX_OK;
+  };
+  // coefficient stack for a linear combination of per-block panels: block b gets Rf[b] y_b (with_rf) or y_b
+  std::vector<double> hEall;
+  auto coeff_stack = [&](int nbr, bool with_rf) -> int {
+    hEall.assign((size_t)nbr * LP * LP, 0.0);
+    std::vector<double> eb;
     std::vector<zdouble> yb((size_t)l * l);
-    for (int b = 0; b < nb; ++b) {
+    for (int b = 0; b < nbr; ++b) {
       for (int i = 0; i < l; ++i)
         for (int j = 0; j < l; ++j) yb[(size_t)i * l + j] = zdouble(Xr[(size_t)(b * l + i) * l + j], Xi[(size_t)(b * l + i) * l + j]);
-      const std::vector<zdouble> cb = Rf[b].empty() ? yb : zmatmul(Rf[b], yb);
+      const std::vector<zdouble> cb = (with_rf && !Rf[b].empty()) ? zmatmul(Rf[b], yb) : yb;
       embed_right(cb, l, l, LP, LP, eb);
       std::copy(eb.begin(), eb.end(), hEall.begin() + (size_t)b * LP * LP);
     }
     HIPCHK(hipMemcpyAsync(Eall, hEall.data(), sizeof(double) * hEall.size(), hipMemcpyHostToDevice, ctx->stream));
-    CHK(launch_matmul_gen(ctx, Pt, LP, tall_pad * LP, LP / 64, tall_pad, nb * LP, Eall, LP, nullptr, Yt));
-    HIPCHK(hipStreamSynchronize(ctx->stream));     // hEall leaves scope
+    return EOFX_OK;
+  };
+  // thick restart when the space is full: blocks 0 .. nb-2 (all multiplied) collapse to their leading Ritz block X = K y, with
+  // A_op X and M X as the same combination of the kept panels; the newest block (not yet multiplied) follows it
+  auto compress = [&]() -> int {
+    const int nbr = nb - 1;
+    CHK(rayleigh_ritz(nbr, false, nullptr));
+    if (trace) fprintf(stderr, "[eofx_rsvd_c64] thick restart after %d products: %d blocks -> Ritz block + newest block\n", ctx->last_iters, nb);
+    CHK(coeff_stack(nbr, false));
+    CHK(launch_matmul_gen(ctx, Kw, ldk, 64, 1 << 20, small_pad, nbr * LP, Eall, LP, nullptr, Vs));        // X
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    CHK(coeff_stack(nbr, true));
+    CHK(launch_matmul_gen(ctx, Ww, ldk, 64, 1 << 20, small_pad, nbr * LP, Eall, LP, nullptr, Ws));        // M X
+    CHK(launch_matmul_gen(ctx, Pt, LP, tall_pad * LP, LP / 64, tall_pad, nbr * LP, Eall, LP, nullptr, Yt)); // A_op X
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpyAsync(Pt, Yt, sizeof(float) * (size_t)tall_pad * LP, hipMemcpyDeviceToDevice, ctx->stream));
+    CHK(copy_block(Kw, Vs, 0));
+    CHK(copy_block(Ww, Ws, 0));
+    CHK(copy_block(Kw, Zs, 1));
+    for (auto& rf : Rf) rf.clear();
+    nb = 2;
+    nW = 1;
     return EOFX_OK;
   };
 
@@ -4525,33 +4559,51 @@ extern "C" int eofx_rsvd_c64(eofx_ctx* ctx, const eofx_mat* A, const eofx_mat* B
   if (krylov) {
     CHK(orth(Zs, small_pad, Vs));                    // Z_0: the orthonormalised start panel
     std::swap(Zs, Vs);
-    std::vector<double> w_prev;
-    for (;;) {
-      const int q = std::min(q_cycle, n_iter - ctx->last_iters);
-      CHK(krylov_cycle(q));
-      CHK(orth(Yt, tall_pad, Qt));
-      CHK(orth(Qt, tall_pad, Yt));                   // Q in Yt (CholeskyQR2)
-      CHK(bwd(Yt, Ws, pf));                          // B^H, B = Q^H A_op
-      CHK(gram_h(Ws, small_pad));                    // B B^H
-      if (host_heigh(H, l, w, Uh) != EOFX_OK) return set_err(ctx, EOFX_ERR_LINALG, "complex SVD: Hermitian eigen-solver failed");
-      if (!adaptive) break;
-      double worst = 1.0;
-      if (w_prev.size() == (size_t)k) {
-        worst = 0.0;
-        for (int j = 0; j < k; ++j) worst = std::max(worst, std::fabs(w[j] - w_prev[j]) / std::max(w[j], 1e-300));
+    CHK(copy_block(Kw, Zs, 0));
+    nb = 1;
+    // "converge": relative residual |M x - theta x| / theta of every wanted Ritz pair <= 3e-5 (the value is then good to
+    // ~1e-9 / relative gap), checked from scikit-learn's count on after every second product
+    const double res_tol = 3e-5;
+    while (ctx->last_iters < n_iter && !exhausted) {
+      if (nb == nbmax) CHK(compress());
+      CHK(lanczos_step());
+      if (adaptive && !exhausted && ctx->last_iters >= std::max(auto_count, it_min) && ctx->last_iters < n_iter &&
+          ((ctx->last_iters - auto_count) % 2 == 0 || nb == nbmax)) {
+        std::vector<double> res;
+        CHK(rayleigh_ritz(nb - 1, false, &res));
+        double worst = 0.0;
+        for (int j = 0; j < k; ++j) worst = std::max(worst, res[j] / std::max(wv[j], 1e-300));
+        if (trace) fprintf(stderr, "[eofx_rsvd_c64] after %d products: largest relative residual of the leading %d Ritz pairs %.3e\n", ctx->last_iters, k, worst);
+        if (worst <= res_tol) break;
       }
-      w_prev.assign(w.begin(), w.begin() + k);
-      if (trace) fprintf(stderr, "[eofx_rsvd_c64] cycle ends after %d products: max relative change of the leading %d Ritz values %.3e\n", ctx->last_iters, k, worst);
-      if ((worst <= 1e-6 && ctx->last_iters >= it_min) || ctx->last_iters >= n_iter) break;
-      // restart from the small-side Ritz block B^H Uh diag(1 / s), all l columns
-      std::vector<zdouble> Mr((size_t)l * l);
-      for (int j = 0; j < l; ++j) {
-        const double sv = std::sqrt(std::max(w[j], 0.0)), inv = sv > 0.0 ? 1.0 / sv : 0.0;
-        for (int i = 0; i < l; ++i) Mr[(size_t)i * l + j] = Uh[(size_t)i * l + j] * inv;
-      }
-      CHK(right_mul(Ws, small_pad, Mr, l, LP, Vs));
-      CHK(orth(Vs, small_pad, Zs));
     }
+    bool with_last = false;
+    if (!exhausted) {          // the newest block's panel: its diagonal block of H is P^H P
+      const int b = nb - 1;
+      float* slot = Pt + (size_t)b * tall_pad * LP;
+      Rf[b].clear();
+      if (orth_rest || ctx->last_iters == 0) {
+        CHK(fwd(Zs, Yt, pp));
+        CHK(gram_h(Yt, tall_pad));
+        Hqq = H;
+        host_zchol_rinv(H, l, T, 1e-13, &Rf[b]);
+        CHK(right_mul(Yt, tall_pad, T, l, LP, slot));
+      } else {
+        CHK(fwd(Zs, slot, pp));
+        CHK(gram_h(slot, tall_pad));
+        Hqq = H;
+      }
+      with_last = true;
+    }
+    CHK(rayleigh_ritz(nb, with_last, nullptr));
+    if (trace) fprintf(stderr, "[eofx_rsvd_c64] Rayleigh-Ritz over %d blocks (order %d) after %d products: leading Ritz values %.6e %.6e ... %.6e\n", nb, nb * l, ctx->last_iters, wv[0], l > 1 ? wv[1] : 0.0, wv[l - 1]);
+    CHK(coeff_stack(nb, true));
+    CHK(launch_matmul_gen(ctx, Pt, LP, tall_pad * LP, LP / 64, tall_pad, nb * LP, Eall, LP, nullptr, Yt));   // A_op K y
+    CHK(orth(Yt, tall_pad, Qt));
+    CHK(orth(Qt, tall_pad, Yt));                     // Q in Yt (CholeskyQR2)
+    CHK(bwd(Yt, Ws, pf));                            // B^H, B = Q^H A_op
+    CHK(gram_h(Ws, small_pad));                      // B B^H
+    if (host_heigh(H, l, w, Uh) != EOFX_OK) return set_err(ctx, EOFX_ERR_LINALG, "complex SVD: Hermitian eigen-solver failed");
   } else {
     bool orth_rest = orth_always;
     std::vector<double> ritz_prev;
