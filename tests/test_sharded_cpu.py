@@ -216,6 +216,9 @@ class NumpyComplexOps:
 
         return self.torch.from_numpy((P.numpy().astype(np.float64) @ _embed_right(M)).astype(np.float32))
 
+    def matmul_real(self, P, E):
+        return self.torch.from_numpy((P.numpy().astype(np.float64) @ np.asarray(E, dtype=np.float64)).astype(np.float32))
+
     def argminmax(self, P, rows):
         a = P.numpy()[:rows]
         return self.torch.from_numpy(a.argmax(axis=0)), self.torch.from_numpy(a.argmin(axis=0))
@@ -251,8 +254,10 @@ def _cworker(rank, world, port, n, p, k, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n,p,k", [(90, 400, 4), (420, 80, 3)])
+@pytest.mark.parametrize("n,p,k", [(90, 400, 4), (420, 80, 3), (90, 400, 12), (420, 300, 14)])
 def test_sharded_complex_rsvd_two_ranks_gloo(tmp_path, n, p, k):
+    """(k = 12, 14: most wanted modes are noise modes -- the block Lanczos recurrence of round 5 resolves them, and on the
+    90-sample field its Krylov space exhausts the sample space after two products)"""
     import torch.multiprocessing as mp
 
     from oracle import eof_oracle as orc
@@ -266,6 +271,8 @@ def test_sharded_complex_rsvd_two_ranks_gloo(tmp_path, n, p, k):
     Ue, se, Vhe = np.linalg.svd(Z, full_matrices=False)
     assert np.all(np.abs(s - se[:k]) <= 2e-5 * se[:k] + 2e-6 * se[0])
     for j in range(k):
+        if min(se[j - 1] - se[j] if j else np.inf, se[j] - se[j + 1]) < 2e-2 * se[j]:
+            continue                       # (noise modes without a gap: the pair is defined up to a rotation)
         assert abs(np.vdot(Vhe[j].conj(), V[:, j])) >= 1 - 1e-4
         assert abs(np.vdot(Ue[:, j], U[:, j])) >= 1 - 1e-4
     # global (cross-rank) sign rule of the reference: already satisfied by the assembled V

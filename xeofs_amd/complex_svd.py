@@ -86,11 +86,141 @@ class ComplexOps:
         torch = engine._torch()
         return engine.panel_matmul(self.ctx, P, torch.as_tensor(_embed_right(M, self.half), device=P.device))
 
+    def matmul_real(self, P, E):             # P [rows x L] (any multiple of 64 columns) times the real matrix E [L x Lo]
+        torch = engine._torch()
+        return engine.panel_matmul(self.ctx, P, torch.as_tensor(np.ascontiguousarray(E, dtype=np.float64), device=P.device))
+
     def argminmax(self, P, rows):
         return engine.panel_colargminmax(self.ctx, P, rows)
 
     def export(self, P, rows, sign):
         return engine.panel_export(self.ctx, P, rows, 2 * self.half, sign)
+
+
+KRYLOV_MAX_ORDER = 8 * 64       # (numpy solves the Rayleigh-Ritz problem here: every sketch width up to 64 at 7 products)
+
+
+def _block_krylov(ops, comm, Z0, q, l, half, small, tall, fwd, bwd, gram, orth, orth_tall):
+    """The q products of the decomposition as a block Lanczos recurrence on the small side with a Rayleigh-Ritz step over the
+    whole Krylov space (the engine entry `eofx_rsvd_c64` does the same on one GPU, csrc/eofx_abi.hip; round 5: the reference's
+    complex branch is a block Krylov-class solver, scipy svds(lobpcg), decomposer.py:149-160).  Returns the tall Ritz panel
+    A_op K y -- a linear combination of the tall panels of the products, no extra pass.  Sharded: the small-side Gram matrices
+    are all-reduced when the small side is the feature side; everything else is local or replicated."""
+    torch = engine._torch()
+    lp = 2 * half
+
+    def real_gram(P, side):
+        G = ops.gram_real(P)
+        if side == "p":
+            G = comm.sum_(G)
+        return G.detach().cpu().numpy() if torch.is_tensor(G) else np.asarray(G)
+
+    def cblock(G, r0, c0):                       # complex l x l block of a real Gram matrix at (r0, c0)
+        rr, ri = G[r0:r0 + l, c0:c0 + l], G[r0:r0 + l, c0 + half:c0 + half + l]
+        ir, ii = G[r0 + half:r0 + half + l, c0:c0 + l], G[r0 + half:r0 + half + l, c0 + half:c0 + half + l]
+        return (rr + ii) + 1j * (ri - ir)
+
+    def cholqr(P, side, dref=None, tolref=0.0):
+        """Cholesky-QR with the dependency rules of eofx_rsvd_c64 -> (Q, R, live columns)"""
+        Hm = cblock(real_gram(P, side), 0, 0)
+        Hm = 0.5 * (Hm + Hm.conj().T)
+        d0 = Hm.diagonal().real.copy()
+        A = Hm.copy()
+        dead = np.zeros(l, bool)
+        for j in range(l):
+            d = A[j, j].real
+            dj = not (d > 1e-13 * d0[j]) or not (d0[j] > 0.0) or (dref is not None and not (d > tolref * dref[j]))
+            dead[j] = dj
+            rjj = 1.0 if dj else np.sqrt(d)
+            A[j, j] = rjj
+            A[j, j + 1:] *= 0.0 if dj else 1.0 / rjj
+            if not dj and j + 1 < l:
+                A[j + 1:, j + 1:] -= np.outer(A[j, j + 1:].conj(), A[j, j + 1:])
+        R = np.triu(A)
+        R[dead, dead] = 0.0
+        T = np.zeros((l, l), complex)
+        live = ~dead
+        if live.any():
+            T[np.ix_(live, live)] = np.linalg.inv(np.triu(A)[np.ix_(live, live)])
+        return ops.right_mul(P, T), R, int(live.sum()), d0
+
+    def embed_stack(blocks):                     # real (len(blocks) lp) x lp matrix applying complex l x l blocks on the right
+        return np.concatenate([_embed_right(c, half) for c in blocks], axis=0)
+
+    K, W, slots, Rf = [], [], [], []
+    Zb, _, _, _ = cholqr(Z0, small)
+    K.append(Zb)
+    orth_rest = orth_tall
+    exhausted = False
+    for it in range(q):
+        Y = fwd(K[-1])
+        if it == 0 or orth_rest:
+            Y, R, _, _ = cholqr(Y, tall)
+            Rf.append(R)
+        else:
+            Rf.append(None)
+        slots.append(Y)
+        Wb = bwd(Y)
+        W.append(Wb)
+        nbk = len(K)
+        Kc = torch.cat(K, dim=1)
+        G = real_gram(torch.cat([Kc, Wb], dim=1), small)
+        c = [cblock(G, b * lp, nbk * lp) for b in range(nbk)]
+        if it == 0 and not orth_tall and q > 1:
+            H00 = c[0] if Rf[0] is None else c[0] @ Rf[0]
+            wv = np.linalg.eigvalsh(0.5 * (H00 + H00.conj().T))
+            orth_rest = not (wv[0] > 0.0) or np.sqrt(wv[-1] / wv[0]) > 30.0
+        V1 = ops.matmul_real(torch.cat([Kc, Wb], dim=1), np.concatenate([-embed_stack(c), np.eye(lp)], axis=0))
+        Gv = cblock(real_gram(V1, small), 0, 0)
+        dref = Gv.diagonal().real + sum((np.abs(cb) ** 2).sum(axis=0) for cb in c)
+        Zn, _, live, _ = cholqr(V1, small, dref, 1e-10)
+        if live > 0:
+            G2 = real_gram(torch.cat([Kc, Zn], dim=1), small)
+            c2 = [cblock(G2, b * lp, nbk * lp) for b in range(nbk)]
+            V2 = ops.matmul_real(torch.cat([Kc, Zn], dim=1), np.concatenate([-embed_stack(c2), np.eye(lp)], axis=0))
+            Zn, _, live, _ = cholqr(V2, small, np.ones(l), 0.25)
+        if live == 0:
+            exhausted = True
+            break
+        K.append(Zn)
+    nb, nW = len(K), len(W)
+    Hqq = None
+    if not exhausted:
+        Y = fwd(K[-1])
+        Gq = cblock(real_gram(Y, tall), 0, 0)
+        Hqq = 0.5 * (Gq + Gq.conj().T)
+        if orth_rest:
+            Y, R, _, _ = cholqr(Y, tall)
+            Rf.append(R)
+        else:
+            Rf.append(None)
+        slots.append(Y)
+    G = real_gram(torch.cat(K + W, dim=1), small)
+    m = nb * l
+    raw = {}
+    for i in range(nW):
+        for j in range(nb):
+            cb = cblock(G, j * lp, (nb + i) * lp)
+            raw[(j, i)] = cb if Rf[i] is None else cb @ Rf[i]
+    if Hqq is not None:
+        raw[(nb - 1, nb - 1)] = Hqq
+    Hm = np.zeros((m, m), complex)
+    for a in range(nb):
+        for b in range(a, nb):
+            u, v = raw.get((a, b)), raw.get((b, a))
+            if u is None and v is None:
+                continue
+            val = u if v is None else (v.conj().T if u is None else 0.5 * (u + v.conj().T))
+            Hm[a * l:(a + 1) * l, b * l:(b + 1) * l] = val
+            if a != b:
+                Hm[b * l:(b + 1) * l, a * l:(a + 1) * l] = val.conj().T
+    wv, y = np.linalg.eigh(0.5 * (Hm + Hm.conj().T))
+    y = y[:, ::-1][:, :l]
+    coeff = []
+    for b in range(nb):
+        yb = y[b * l:(b + 1) * l]
+        coeff.append(yb if Rf[b] is None else Rf[b] @ yb)
+    return ops.matmul_real(torch.cat(slots, dim=1), embed_stack(coeff))
 
 
 class _NoComm:
@@ -167,16 +297,21 @@ def complex_rsvd(ctx, A, B, k: int, n_oversamples: int = 10, n_iter="auto", rand
 
     orth_tall = _orth_tall(tall_total, lp, getattr(ctx, "precision", ("f16x3",))[0])
     orth_rest = orth_tall
-    for it in range(int(n_iter)):
-        Yt = fwd(Z)
-        if it == 0 or orth_rest:           # the first iteration always re-normalises the tall panel (rsvd_core)
-            Yt = orth(Yt, tall)
-        Wp = bwd(Yt)
-        if it == 0 and not orth_tall and int(n_iter) > 1:      # peaked spectrum: keep the step (eofx_peaked_spectrum's rule)
-            wv = np.linalg.eigvalsh(gram(Wp, small))
-            orth_rest = not (wv[0] > 0.0) or np.sqrt(wv[-1] / wv[0]) > 30.0
-        Z = orth(Wp, small)
-    Q = orth(orth(fwd(Z), tall), tall)                  # range basis: a subspace only, power-pass precision
+    q = int(n_iter)
+    if q >= 1 and (q + 1) * l <= KRYLOV_MAX_ORDER and hasattr(ops, "matmul_real"):
+        Yx = _block_krylov(ops, comm, Z, q, l, half, small, tall, fwd, bwd, gram, orth, orth_tall)
+        Q = orth(orth(Yx, tall), tall)
+    else:
+        for it in range(q):
+            Yt = fwd(Z)
+            if it == 0 or orth_rest:           # the first iteration always re-normalises the tall panel (rsvd_core)
+                Yt = orth(Yt, tall)
+            Wp = bwd(Yt)
+            if it == 0 and not orth_tall and q > 1:      # peaked spectrum: keep the step (eofx_peaked_spectrum's rule)
+                wv = np.linalg.eigvalsh(gram(Wp, small))
+                orth_rest = not (wv[0] > 0.0) or np.sqrt(wv[-1] / wv[0]) > 30.0
+            Z = orth(Wp, small)
+        Q = orth(orth(fwd(Z), tall), tall)                  # range basis: a subspace only, power-pass precision
     Bt = bwd(Q, True)                                   # = B^H with B = Q^H A_op
     w, Uh = np.linalg.eigh(gram(Bt, small))             # B B^H = Uh diag(w) Uh^H
     order = np.argsort(w)[::-1][:k]
