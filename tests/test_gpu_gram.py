@@ -122,3 +122,24 @@ def test_wide_panel_matmul_through_the_nt_kernel(ctx, rows, L, Lo, monkeypatch):
     old = engine.panel_matmul(ctx, P, M).cpu().numpy()
     assert np.abs(old - ref).max() <= 1e-6 * scale
     assert np.abs(out - old).max() <= 3e-6 * scale
+
+
+@pytest.mark.parametrize("n,P,L", [(700, 3000, 512), (2000, 4096, 608)])
+def test_wide_feature_side_product_on_a_fresh_context(n, P, L):
+    """the NT route's scratch estimate left out the plan's split-K factor (700 x 3000 with 512 columns
+    plans S = 3, 2000 x 4096 with 608 plans S = 4), so a context whose grow-only arena had not been enlarged by earlier calls
+    ran out of it.  A FRESH context per case: the first engine call it sees is this product."""
+    import torch
+    from xeofs_amd import engine
+
+    ctx2 = engine.Context(0)
+    rng = np.random.default_rng(n)
+    X = rng.standard_normal((n, P)).astype(np.float32)
+    mat = engine.from_dense(ctx2, X)
+    Z = np.zeros((mat.n_pad, L), np.float32)
+    Z[:n] = rng.standard_normal((n, L))
+    Y = engine.panel_tmul(ctx2, mat, torch.as_tensor(Z, device="cuda"), prec="f16x3")
+    want = X.astype(np.float64).T @ Z[:n].astype(np.float64)
+    assert np.abs(Y[:P].cpu().numpy() - want).max() <= 3e-6 * np.sqrt(n) * 4.0 * 4.0
+    mat.free()
+    del ctx2

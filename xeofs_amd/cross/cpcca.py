@@ -345,7 +345,12 @@ class CPCCA(Deferred):
         n_over, n_iter = int(kw.pop("n_oversamples", 10)), kw.pop("n_iter", "auto")
         # PCA pre-reduction and whitening (base_model_cross_set.py:307-313)
         mats, pres = (mx, my), (self.preprocessor1, self.preprocessor2)
-        pcas = [ResidentPCA(self.ctx, self._params["n_pca_modes"][i], self._params["pca_init_rank_reduction"][i])
+        # (the reference's PCA is unseeded; here a model built with an integer random_state seeds the two pre-reductions with
+        # random_state + i -- distinct starts for the two fields, the same fit for the same seed -- and an unseeded model takes
+        # the process-wide counter of xeofs_amd.pca)
+        rs = self.random_state
+        seeds = [int(rs) + 1000003 * (i + 1) if isinstance(rs, (int, np.integer)) else None for i in range(2)]
+        pcas = [ResidentPCA(self.ctx, self._params["n_pca_modes"][i], self._params["pca_init_rank_reduction"][i], random_state=seeds[i])
                 if self._params["use_pca"][i] else None for i in range(2)]
         _fit_two_pcas(pcas, mats, [pre.total_variance for pre in pres])
         for i in range(2):

@@ -1815,11 +1815,12 @@ extern "C" int eofx_resample_f32(eofx_ctx* ctx, const eofx_mat* src, const int64
 // panel-level ABI
 // ------------------------------------------------------------------------------------
 static bool tmul_nt_ok(const eofx_mat* m, int L);
-static size_t tmul_nt_scratch(const eofx_mat* m, int L);
+static size_t tmul_nt_scratch(eofx_ctx* ctx, const eofx_mat* m, int L);
 static int mat_tmul_nt(eofx_ctx* ctx, const eofx_mat* m, const float* Zn, float* Yp, int L);
 static int panel_tmul(eofx_ctx* ctx, const eofx_mat* m, const float* Zn, float* Yp, int L, int prec) {
   // panels of 512 columns and more (PCA pre-reduction): the MFMA-bound NT kernel over transposed fp16 planes (eofx_gram.hpp)
-  if (prec == EOFX_PREC_F16X3 && tmul_nt_ok(m, L) && ctx->arena_size - ctx->arena_off >= tmul_nt_scratch(m, L))
+  if (prec == EOFX_PREC_F16X3 && tmul_nt_ok(m, L) && tmul_nt_scratch(ctx, m, L) > 0 &&
+      ctx->arena_size - ctx->arena_off >= tmul_nt_scratch(ctx, m, L))   // (too little arena: the streaming tiles below, same result)
     return mat_tmul_nt(ctx, m, Zn, Yp, L);
   if (!m->X && m->raw && prec == EOFX_PREC_F16X3) {   // raw mode: stream the raw field through the affine map
     AffView av;
@@ -1899,7 +1900,7 @@ extern "C" int eofx_panel_tmul_f32(eofx_ctx* ctx, const eofx_mat* m, const float
   if (!ctx || !m || !Zn || !Yp || !valid_prec(prec)) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
   CHK(set_device(ctx));
   size_t need = atb_scratch_bytes(m->p_pad, round_up(m->n, ATB_KG), L);
-  if (prec == EOFX_PREC_F16X3 && tmul_nt_ok(m, L)) need = std::max(need, tmul_nt_scratch(m, L));
+  if (prec == EOFX_PREC_F16X3 && tmul_nt_ok(m, L)) need = std::max(need, tmul_nt_scratch(ctx, m, L));
   CHK(arena_reserve(ctx, need));
   return panel_tmul(ctx, m, Zn, Yp, L, prec);
 }
@@ -2948,18 +2949,22 @@ extern "C" int eofx_fit_sharded_f32(eofx_ctx* ctx, const float* X, int64_t n, in
   if (!(n < P_total)) return set_err(ctx, EOFX_ERR_ARG, "the sharded fit needs the sketch on the sample side (n < P_total)");
   CHK(set_device(ctx));
   ctx->fit_info[0] = ctx->fit_info[1] = ctx->fit_info[2] = 0.0;
+  // A failure of THIS rank before the first vote (staging the slice, growing the arena) must not return here: the other ranks
+  // would wait in the vote's all-reduce for ever.  It becomes this rank's verdict (2) and every rank leaves together.
   Staged st;
-  CHK(stage_input(ctx, X, (size_t)n * P, st));
+  int rc = stage_input(ctx, X, (size_t)n * P, st);
   const int l_req = k + n_oversamples;
   const int l = (int)std::min<int64_t>(l_req, n);
   const int iters = n_iter < 0 ? rsvd_auto_iters(k, n, P_total) : n_iter;
-  const bool eligible = fit_first_eligible(ctx, st.dev, n, P, l) && k <= n && l == l_req && omega_rows >= n && !is_device_ptr(omega);
   const int64_t p_pad = round_up(P, ATB_BM), n_pad = round_up(n, ATB_BM);
-  CHK(arena_reserve(ctx, rsvd_scratch_bytes(p_pad, n_pad, l, k) + FitFirst::bytes(n, P, l) + (1 << 16)));
+  if (rc == EOFX_OK) rc = arena_reserve(ctx, rsvd_scratch_bytes(p_pad, n_pad, l, k) + FitFirst::bytes(n, P, l) + (1 << 16));
   ArenaScope scope(ctx);
   FitFirst ff;
-  int rc = eligible ? ff.prepare(ctx, st.dev, n, P, center, standardize, feat_weights, l) : EOFX_FIT_FALLBACK;
-  if (!eligible) ctx->fit_info[2] = -1.0;
+  if (rc == EOFX_OK) {
+    const bool eligible = fit_first_eligible(ctx, st.dev, n, P, l) && k <= n && l == l_req && omega_rows >= n && !is_device_ptr(omega);
+    rc = eligible ? ff.prepare(ctx, st.dev, n, P, center, standardize, feat_weights, l) : EOFX_FIT_FALLBACK;
+    if (!eligible) ctx->fit_info[2] = -1.0;
+  }
   const std::string err_local = rc < 0 ? ctx->err : std::string();
   int verdict = 0;
   CHK(comm_vote(ctx, rc < 0 ? 2 : rc > 0 ? 1 : 0, &verdict));
@@ -3219,9 +3224,13 @@ static bool tmul_nt_ok(const eofx_mat* m, int L) {
   return L >= 512 && m->p_pad % GR_BM == 0 && (m->X || (m->raw && m->aff)) && kpad * 4 * GR_BM < ((int64_t)1 << 32) &&
          m->n >= 512 && !std::getenv("EOFX_NO_TMUL_NT");
 }
-static size_t tmul_nt_scratch(const eofx_mat* m, int L) {
+// (the partial tiles follow the plan's split-K factor S -- as matmul_nt_scratch and gram_fast_scratch count them; the estimate
+// p_pad Lp 4 of round 4 covered S = 1 only: 700 x 3000 with L = 512 plans S = 3, and a fresh context ran out of arena)
+static size_t tmul_nt_scratch(eofx_ctx* ctx, const eofx_mat* m, int L) {
   const int64_t kpad = round_up(m->n, 2 * GR_BK), Lp = round_up(L, GR_BM);
-  return (size_t)(m->p_pad + Lp) * kpad * 4 + (size_t)m->p_pad * Lp * 4 + (1 << 16);
+  const eofx_ctx::GramPlanDev* g = nullptr;
+  if (gram_plan_get(ctx, (int)(m->p_pad / GR_BM), (int)(Lp / GR_BM), false, (int)(kpad / GR_BK), &g) != EOFX_OK) return 0;
+  return (size_t)(m->p_pad + Lp) * kpad * 4 + (size_t)g->pl.T * g->pl.S * GR_BM * GR_BM * sizeof(float) + (1 << 16);
 }
 static int mat_tmul_nt(eofx_ctx* ctx, const eofx_mat* m, const float* Zn, float* Yp, int L) {
   const int64_t kpad = round_up(m->n, 2 * GR_BK), Lp = round_up(L, GR_BM);

@@ -123,8 +123,8 @@ class ResidentPCA:
         # below that size, the reference's randomized algorithm on the resident Gram matrix above it
         randomized = self.solver == "randomized" or (self.solver == "auto" and side == 0 and not sharded and
                                                      ell <= 0.6 * r and r >= 1024)
-        if randomized and (side != 0 or ell >= r):
-            randomized = False
+        if randomized and (side != 0 or ell >= r or sharded):
+            randomized = False          # (the randomized route has no collectives: a feature-sharded fit takes the exact one)
         if self.solver not in ("auto", "randomized", "exact"):
             raise ValueError(f"Unrecognized solver '{self.solver}'. Valid options are 'auto', 'randomized', and 'exact'.")
         self.solver_used = "randomized" if randomized else "exact"

@@ -94,8 +94,13 @@ class EOFBootstrapper(EOF):
     def get_params(self):
         return dict(self._params)
 
-    def fit(self, model: EOF, random_state=None):
-        """`random_state` seeds the members' randomized SVDs (the reference leaves them unseeded)."""
+    def fit(self, model: EOF, random_state=None, sample_layout="auto"):
+        """`random_state` seeds the members' randomized SVDs (the reference leaves them unseeded).
+        `sample_layout`: "auto" builds the sample-contiguous copy of the model's matrix for the members' X Y passes where HBM
+        has room (13 % faster) and releases it afterwards; True / False force the choice.  With a seed the members are
+        reproducible bit for bit FOR A GIVEN CHOICE; between the two layouts the Scaler map is a multiply or a fused
+        multiply-add, i.e. results agree to one float32 ulp of the field (pass True / False where runs on machines
+        with different free memory must agree bit for bit)."""
         getattr(model, "compute", lambda: None)()      # a deferred fit runs now: ctx / preprocessor / data are read below
         self.model = model
         self.ctx = ctx = model.ctx
@@ -115,7 +120,10 @@ class EOFBootstrapper(EOF):
         built_here = False
         if n_boot >= 2:      # every member is a full decomposition of the same matrix: where HBM has room for the
             had = mat.has_sample_layout()                  # sample-contiguous layout, its X Y passes run 13 % faster over it
-            built_here = mat.ensure_sample_layout(only_if_room=True) and not had
+            if sample_layout == "auto":
+                built_here = mat.ensure_sample_layout(only_if_room=True) and not had
+            elif sample_layout:
+                built_here = mat.ensure_sample_layout(only_if_room=False) and not had
         comm = _Solo()
         try:
             for b in range(n_boot):
