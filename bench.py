@@ -660,6 +660,19 @@ def main():
     # the engine's own communicator (RCCL on the context's stream): eofx_fit_sharded_f32 issues the collectives of a fit
     # itself, between its kernels; the panel-level driver (python + torch.distributed) stays as its fallback
     native = (world > 1 or args.force_sharded) and not args.no_native and sharded.attach_native(ctx, comm)
+    # self-diagnosis of the engine's communicator, before anything is timed (RCCL has only ever run at world
+    # size 1 here): the rank count it really reduces over and the cost of each collective of a sharded fit
+    comm_probe = None
+    if native:
+        n_pad_c, l_c = (n + 511) // 512 * 512, 64
+        cases = [(n_pad_c * l_c, "f32"), (l_c * l_c, "f64"), (2 * l_c, "f32"), (1, "i32")]
+        try:
+            seen, us = engine.comm_probe(ctx, cases, reps=20)
+            comm_probe = {"ranks_seen": seen, "ranks_expected": world,
+                          "allreduce_latency_us": {"sample_panel_n_pad_x_64_f32": round(us[0], 1), "gram_64x64_f64": round(us[1], 1),
+                                                   "sign_rule_128_f32": round(us[2], 1), "vote_1_i32": round(us[3], 1)}}
+        except Exception as e:      # (never fatal: the probe is a diagnosis)
+            comm_probe = {"ranks_seen": None, "probe_error": str(e)[:200]}
 
     t0 = time.perf_counter()
     Xraw = make_field(n, args.nlat, args.nlon, lo, hi, device)
@@ -1027,6 +1040,8 @@ def main():
                                         else "host callback over torch.distributed") if phase.get("native_steps", 0) else
                                        "torch.distributed all_reduce from the python driver",
                             "timing": "events on the collective's stream around every all_reduce of the timed fits (rank 0)"}
+            if comm_probe is not None:
+                line["comm"].update(comm_probe)
         print(json.dumps(line), file=real_stdout, flush=True)
     if world > 1 or args.force_sharded:
         dist.barrier()

@@ -262,6 +262,12 @@ int eofx_ctx_comm_stats(eofx_ctx *ctx, int64_t *calls, int64_t *bytes, double *m
 /* one round of every collective the sharded fit uses (float32 sum / max / min, float64 sum, int32 max) on known values;
  * *ok = 1 when all results are what `world` ranks must produce.  Collective: every rank of the communicator calls it. */
 int eofx_ctx_comm_selftest(eofx_ctx *ctx, int *ok);
+/* Self-diagnosis of the attached communicator (collective): ranks_seen = all-reduce(sum) of 1.0 per rank, us[i] = mean
+ * microseconds (HIP events, `reps` calls after a warm-up) of an all-reduce(sum) of counts[i] elements of dtypes[i]
+ * (0 float32, 1 float64, 2 int32) -- the collectives of one sharded fit (n x l float32 per pass, l x l
+ * float64 Gram matrices, one int32 vote).  bench.py --gpus N prints both on its JSON line (`comm.ranks_seen`). */
+int eofx_ctx_comm_probe(eofx_ctx *ctx, int ncases, const int64_t *counts, const int *dtypes, int reps, double *ranks_seen,
+                        double *us);
 /* eofx_fit_f32 on this rank's slice [n x P_local] of a field with P_total features (arguments as there; omega: the global
  * sketch [n x (k + n_oversamples)], identical on every rank; needs n < P_total, i.e. the sketch on the sample side).
  * total_variance is the global one; mean / std / valid_feature / V are those of the slice.  Returns 0, or 1 when the

@@ -80,6 +80,7 @@ SIGNATURES = {
     "eofx_ctx_comm_clear": (_int, [_vp]),
     "eofx_ctx_comm_stats": (_int, [_vp, _pi64, _pi64, _pd]),
     "eofx_ctx_comm_selftest": (_int, [_vp, C.POINTER(C.c_int)]),
+    "eofx_ctx_comm_probe": (_int, [_vp, _int, _vp, _vp, _int, _vp, _vp]),
     "eofx_fit_sharded_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _int, _int, _vp, _int, _int, _int, _vp, _i64, _int,
                                     C.POINTER(_vp), _vp, _vp, _vp, _pd, _vp, _vp, _vp]),
     "eofx_rsvd_c64": (_int, [_vp, _vp, _vp, _int, _int, _int, _vp, _int, _vp, _vp, _vp]),

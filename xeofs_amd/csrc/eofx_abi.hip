@@ -2938,6 +2938,51 @@ extern "C" int eofx_ctx_comm_selftest(eofx_ctx* ctx, int* ok) {
   return EOFX_OK;
 }
 
+// What the first real multi-GPU run needs to diagnose itself: how many ranks the attached communicator
+// really reduces over, and what each collective of a sharded fit costs there.  ranks_seen = all-reduce(sum) of 1.0 per rank;
+// us[i] = mean time (HIP events on the context's stream, `reps` back-to-back calls after one warm-up) of an all-reduce(sum) of
+// counts[i] elements of dtypes[i] (0 float32, 1 float64, 2 int32).  Collective: every rank calls it with the same arguments.
+extern "C" int eofx_ctx_comm_probe(eofx_ctx* ctx, int ncases, const int64_t* counts, const int* dtypes, int reps, double* ranks_seen,
+                                   double* us) {
+  if (!ctx || !counts || !dtypes || !ranks_seen || !us || ncases < 0 || reps <= 0) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  if (!ctx->comm) return set_err(ctx, EOFX_ERR_ARG, "no communicator attached");
+  CHK(set_device(ctx));
+  int64_t most = 8;
+  for (int i = 0; i < ncases; ++i) {
+    if (counts[i] <= 0 || dtypes[i] < 0 || dtypes[i] > 2) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+    most = std::max<int64_t>(most, counts[i] * 8);
+  }
+  CHK(arena_reserve(ctx, (size_t)most + 4096));
+  ArenaScope scope(ctx);
+  ARENA(char, buf, (size_t)most);
+  HIPCHK(hipMemsetAsync(buf, 0, (size_t)most, ctx->stream));
+  const float one = 1.f;
+  HIPCHK(hipMemcpyAsync(buf, &one, sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  CHK(comm_allreduce(ctx, buf, 1, 0, 0));
+  float seen = 0.f;
+  HIPCHK(hipMemcpyAsync(&seen, buf, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  *ranks_seen = (double)seen;
+  HIPCHK(hipMemsetAsync(buf, 0, (size_t)most, ctx->stream));
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0));
+  HIPCHK(hipEventCreate(&e1));
+  for (int i = 0; i < ncases; ++i) {
+    CHK(comm_allreduce(ctx, buf, counts[i], dtypes[i], 0));
+    HIPCHK(hipEventRecord(e0, ctx->stream));
+    for (int r = 0; r < reps; ++r) CHK(comm_allreduce(ctx, buf, counts[i], dtypes[i], 0));
+    HIPCHK(hipEventRecord(e1, ctx->stream));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    us[i] = 1e3 * (double)ms / reps;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return EOFX_OK;
+}
+
 extern "C" int eofx_fit_sharded_f32(eofx_ctx* ctx, const float* X, int64_t n, int64_t P, int64_t P_total, int center,
                                     int standardize, const double* feat_weights, int k, int n_oversamples, int n_iter,
                                     const float* omega, int64_t omega_rows, int flip, eofx_mat** out, double* mean,

@@ -493,6 +493,18 @@ def comm_selftest(ctx: Context) -> bool:
     return bool(ok.value)
 
 
+def comm_probe(ctx: Context, cases, reps: int = 20):
+    """eofx_ctx_comm_probe (collective): cases = [(count, "f32" | "f64" | "i32"), ...] -> (ranks the communicator reduces over,
+    [mean microseconds of an all-reduce(sum) per case])"""
+    codes = {"f32": 0, "f64": 1, "i32": 2}
+    counts = np.ascontiguousarray([int(c) for c, _ in cases], dtype=np.int64)
+    dtypes = np.ascontiguousarray([codes[d] for _, d in cases], dtype=np.int32)
+    seen = np.zeros(1, np.float64)
+    us = np.zeros(len(cases), np.float64)
+    raise_for(ctx.lib.eofx_ctx_comm_probe(ctx.handle, len(cases), ptr(counts), ptr(dtypes), int(reps), ptr(seen), ptr(us)), ctx.handle)
+    return float(seen[0]), [float(x) for x in us]
+
+
 def comm_stats(ctx: Context):
     """-> dict(calls, bytes, ms) of the collectives of the native sharded fit since the last call (ms: while profiling)"""
     calls, nbytes, ms = C.c_int64(), C.c_int64(), C.c_double()
