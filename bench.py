@@ -359,7 +359,7 @@ def leg_configs(ctx, device, orc, layout_kw, quick=False):
         def c5():
             t = {}
             _sync(); a = time.perf_counter()
-            A, _ = engine.preprocess(ctx, X, want_stats=False, in_place=True)      # lean layout: Re in place, Im^T only
+            A, _ = engine.preprocess(ctx, X, want_stats=False, in_place=True, for_hilbert=True)   # lean layout: Re in place, Im^T only
             _sync(); b = time.perf_counter()
             B, _ = engine.hilbert(ctx, A, "exp", 0.2)
             _sync(); c = time.perf_counter()

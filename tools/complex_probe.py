@@ -13,7 +13,8 @@ X = bench.make_field(n, nlat, nlon, 0, nlat * nlon, torch.device("cuda:0"))
 torch.cuda.synchronize()
 for rep in range(2):
     t0 = time.perf_counter()
-    A, st = engine.preprocess(ctx, X, want_stats=False, in_place=os.environ.get("LAYOUT", "lean") != "written")
+    A, st = engine.preprocess(ctx, X, want_stats=False, in_place=os.environ.get("LAYOUT", "lean") != "written",
+                              for_hilbert=not os.environ.get("NO_RAWT"))
     torch.cuda.synchronize(); t1 = time.perf_counter()
     B, _ = engine.hilbert(ctx, A, "exp", 0.2)
     torch.cuda.synchronize(); t2 = time.perf_counter()

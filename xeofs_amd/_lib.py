@@ -87,6 +87,7 @@ SIGNATURES = {
     "eofx_orth_tall_rule": (_int, [_i64, _int, _int]),
     "eofx_peaked_spectrum": (_int, [_vp, _int, _int]),
     "eofx_ctx_set_layout": (_int, [_vp, _int]),
+    "eofx_ctx_set_sample_raw": (_int, [_vp, _int]),
     "eofx_mat_release_raw": (_int, [_vp, _vp]),
     "eofx_mat_ensure_sample_layout": (_int, [_vp, _vp, _int, _vp]),
     "eofx_mat_release_sample_layout": (_int, [_vp, _vp]),

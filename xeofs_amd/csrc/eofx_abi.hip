@@ -100,6 +100,9 @@ struct eofx_ctx {
   // layout mode 3: in place, and a field with all-NaN grid points (land / sea mask) keeps them as ZERO columns instead of
   // being compacted (eofx_mat::masked); only for callers that compact / scatter the feature axis of the factors themselves
   bool allow_masked = false;
+  bool want_rawT = false;          // eofx_ctx_set_sample_raw: the next in-place preprocess also writes the transposed raw field
+  float* pending_rawT = nullptr;   // ... produced by run_colstats, adopted by the matrix (or returned to the pool)
+  size_t pending_rawT_bytes = 0;
   // optional per-launch timing of the dominant kernel (atb_f32) with HIP events on `stream`
   bool profile = false;
   struct ProfEvent {
@@ -164,6 +167,10 @@ struct eofx_mat {
   // on first use by ensure_active_pairs; n_act < 0: not built yet, act == nullptr afterwards: every pair is active)
   int* act = nullptr;
   int64_t n_act = -1;
+  // in-place matrix about to be Hilbert-transformed (eofx_ctx_set_sample_raw): the RAW field in the sample-contiguous layout
+  // [p_pad x n_pad], written by the statistics pass on its way (colstats4_tr_kernel); eofx_hilbert_f32 reads it through the
+  // Scaler map and returns it to the pool.  Rows >= p and samples >= n are not initialised (the consumer never reads them).
+  float* rawT = nullptr;
 };
 
 static int set_err(eofx_ctx* ctx, int code, const char* fmt, ...) {
@@ -1237,11 +1244,13 @@ extern "C" int eofx_mat_destroy(eofx_ctx* ctx, eofx_mat* m) {
     if (m->act) pool_give(ctx, m->act, sizeof(int) * (size_t)(round_up(m->p, AXB_KG) / AXB_KG));
     pool_give(ctx, m->absmax_dev, 256);
     if (m->raw_owned) pool_give(ctx, m->raw_owned, m->raw_owned_bytes);
+    if (m->rawT) pool_give(ctx, m->rawT, bytes);
   } else {
     if (m->X) (void)hipFree(m->X);
     if (m->Xt) (void)hipFree(m->Xt);
     if (m->act) (void)hipFree(m->act);
     if (m->raw_owned) (void)hipFree(m->raw_owned);
+    if (m->rawT) (void)hipFree(m->rawT);
   }
   if (m->aff) {
     const size_t abytes = sizeof(float) * 3 * (size_t)m->p_pad;
@@ -1361,6 +1370,11 @@ extern "C" int eofx_ctx_set_layout(eofx_ctx* ctx, int keep_raw) {
   ctx->keep_raw = keep_raw;
   return EOFX_OK;
 }
+extern "C" int eofx_ctx_set_sample_raw(eofx_ctx* ctx, int on) {
+  if (!ctx) return EOFX_ERR_ARG;
+  ctx->want_rawT = on != 0;
+  return EOFX_OK;
+}
 extern "C" int eofx_mat_release_raw(eofx_ctx* ctx, eofx_mat* m) {
   if (!ctx || !m) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
   CHK(set_device(ctx));
@@ -1477,7 +1491,8 @@ static int run_colstats(eofx_ctx* ctx, const float* Xd, int64_t n, int64_t P, in
   const int gx = vec4 ? (int)((P / 4 + 255) / 256) : gxs;
   int64_t RS = std::max<int64_t>(1, (2048 + gx - 1) / gx);
   RS = std::min<int64_t>(RS, std::max<int64_t>(1, n / 64));
-  const int64_t rps = (n + RS - 1) / RS;
+  int64_t rps = (n + RS - 1) / RS;
+  if (ctx->want_rawT && ctx->keep_raw == 2 && !row_map) rps = round_up(rps, 64);   // (the transposing variant moves 64 x 64 tiles)
   RS = (n + rps - 1) / rps;
   ArenaScope scope(ctx);
   ARENA(int, cnt_p, (size_t)RS * P);
@@ -1485,7 +1500,21 @@ static int run_colstats(eofx_ctx* ctx, const float* Xd, int64_t n, int64_t P, in
   ARENA(double, sq_p, (size_t)RS * P);
   ARENA(float, mn_p, (size_t)RS * P);
   ARENA(float, mx_p, (size_t)RS * P);
-  if (vec4)
+  // the Hilbert stage follows (eofx_ctx_set_sample_raw) and its one-kernel route takes this length two features at a time:
+  // the pass also writes the raw field in the sample-contiguous layout (instead of a separate transposing copy behind the statistics pass)
+  if (vec4 && !row_map && ctx->want_rawT && ctx->keep_raw == 2 && !ctx->pending_rawT && round_up(n, ATB_BM) <= 8192 && rps % 64 == 0) {
+    const int64_t n_pad_t = round_up(n, ATB_BM), p_pad_t = round_up(P, ATB_BM);
+    const size_t tb = (size_t)n_pad_t * p_pad_t * sizeof(float);
+    if (pool_malloc(ctx, (void**)&ctx->pending_rawT, tb) == hipSuccess) ctx->pending_rawT_bytes = tb;
+    else {
+      (void)hipGetLastError();
+      ctx->pending_rawT = nullptr;
+    }
+  }
+  if (vec4 && ctx->pending_rawT && !row_map && ctx->want_rawT)
+    hipLaunchKernelGGL(colstats_tr_kernel, dim3((unsigned)((P + 63) / 64), (int)RS), dim3(256), 0, ctx->stream, Xd, n, P, ld, rps, cnt_p,
+                       sum_p, sq_p, mn_p, mx_p, ctx->pending_rawT, round_up(n, ATB_BM));
+  else if (vec4)
     hipLaunchKernelGGL(colstats4_kernel, dim3(gx, (int)RS), dim3(256), 0, ctx->stream, Xd, n, P, ld, row_map, rps,
                        cnt_p, sum_p, sq_p, mn_p, mx_p);
   else
@@ -1696,12 +1725,31 @@ extern "C" int eofx_preprocess_f32(eofx_ctx* ctx, const float* X, int64_t n, int
     if (!wdev) return set_err(ctx, EOFX_ERR_NOMEM, "arena exhausted (weights)");
     CHK(copy_in(ctx, wdev, feat_weights, sizeof(double) * P));
   }
-  CHK(run_colstats(ctx, st.dev, n, P, center, standardize, wdev, ps));
+  {
+    const int rc_cs = run_colstats(ctx, st.dev, n, P, center, standardize, wdev, ps);
+    if (rc_cs != EOFX_OK) {
+      if (ctx->pending_rawT) pool_give(ctx, ctx->pending_rawT, ctx->pending_rawT_bytes);
+      ctx->pending_rawT = nullptr;
+      ctx->pending_rawT_bytes = 0;
+      return rc_cs;
+    }
+  }
   std::vector<int> hcnt;
   int64_t ns = 0, pv = 0;
   FeatSummary fs;
-  CHK(sanitize_and_apply(ctx, st.dev, n, P, ps, true, nullptr, check_nans, out, valid_feature, valid_sample, &ns,
-                         &pv, hcnt, &fs));
+  const int rc_sa = sanitize_and_apply(ctx, st.dev, n, P, ps, true, nullptr, check_nans, out, valid_feature, valid_sample, &ns,
+                                       &pv, hcnt, &fs);
+  if (ctx->pending_rawT) {     // the transposed raw field of the statistics pass: to the in-place matrix, or back to the pool
+    eofx_mat* m = (rc_sa == EOFX_OK && out) ? *out : nullptr;
+    if (m && m->raw && m->aff && !m->X && !m->Xt && !m->masked && m->n == n && m->p == P &&
+        (size_t)m->n_pad * m->p_pad * sizeof(float) == ctx->pending_rawT_bytes)
+      m->rawT = ctx->pending_rawT;
+    else
+      pool_give(ctx, ctx->pending_rawT, ctx->pending_rawT_bytes);
+    ctx->pending_rawT = nullptr;
+    ctx->pending_rawT_bytes = 0;
+  }
+  CHK(rc_sa);
   adopt_staged(out, st, (size_t)n * P * sizeof(float));
   if (n_out) *n_out = ns;
   if (p_out) *p_out = pv;
@@ -3827,7 +3875,7 @@ static int get_hilbert_setup(eofx_ctx* ctx, int64_t n, int padding, double decay
 template <int L, int MODE>
 static hipError_t launch_hilbert_fused(eofx_ctx* ctx, const float* Xt, int64_t n_pad, int64_t n, int64_t p, int padding,
                                        const float* hperm, const float* u, float* Bt, float* At, unsigned* bmax,
-                                       unsigned* amax) {
+                                       unsigned* amax, const float* aff = nullptr, int64_t aff_ld = 0) {
   using PL = hfft::plan<L>;
   auto kern = hfft::hilbert_fft_kernel<L, MODE>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PL::lds);
@@ -3843,7 +3891,7 @@ static hipError_t launch_hilbert_fused(eofx_ctx* ctx, const float* Xt, int64_t n
   }
   const int grid = (int)std::min<int64_t>(groups, (int64_t)cu_count * per_cu);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(PL::WG), PL::lds, ctx->stream, Xt, n_pad, (int)n, p, padding, hperm, u, Bt, At,
-                     bmax, amax);
+                     bmax, amax, aff, aff_ld);
   return hipGetLastError();
 }
 
@@ -3866,8 +3914,12 @@ extern "C" int eofx_hilbert_f32(eofx_ctx* ctx, const eofx_mat* a, int padding, d
   // (eofx_rsvd_c64 streams the pair [raw field, Im^T] directly; any other consumer gets the feature-contiguous layout on
   // demand through ensure_X).
   const bool lean = a->raw && a->aff && !a->X && !a->masked;
-  const bool xt_transient = lean && !a->Xt;
-  CHK(ensure_Xt(ctx, a));
+  // round 5: the statistics pass of the in-place preprocess already wrote the RAW field in the sample-contiguous layout
+  // (eofx_ctx_set_sample_raw, colstats4_tr_kernel); the one-kernel route reads it through the Scaler map -- the same
+  // expression apply_kernel would have written, so the transform is bit-identical to the transient-copy route below
+  const bool from_rawT = lean && a->rawT && !a->Xt && fused && L <= 14 && !out_real;
+  const bool xt_transient = lean && !a->Xt && !from_rawT;
+  if (!from_rawT) CHK(ensure_Xt(ctx, a));
   // features per FFT batch: real series + half spectrum of about 3 GB together
   int64_t Fc = std::max<int64_t>(1, std::min<int64_t>(p, (int64_t)(3.0e9 / (4.0 * (double)ldw + 8.0 * (double)nh))));
   eofx_mat *mi = nullptr, *mr = nullptr;
@@ -3887,7 +3939,8 @@ extern "C" int eofx_hilbert_f32(eofx_ctx* ctx, const eofx_mat* a, int padding, d
     unsigned* amax = mr ? mr->absmax_dev : nullptr;
     switch (L) {
 #define EOFX_HF(LL) \
-  case LL: e = launch_hilbert_fused<LL, 0>(ctx, a->Xt, n_pad, n, p, padding ? 1 : 0, hperm, u, mi->Xt, At, mi->absmax_dev, amax); break;
+  case LL: e = launch_hilbert_fused<LL, 0>(ctx, from_rawT ? a->rawT : a->Xt, n_pad, n, p, padding ? 1 : 0, hperm, u, mi->Xt, At, mi->absmax_dev, amax, \
+                                           from_rawT ? a->aff : nullptr, a->p_pad); break;
       EOFX_HF(10) EOFX_HF(11) EOFX_HF(12) EOFX_HF(13) EOFX_HF(14)
 #undef EOFX_HF
       case 15:   // 8193 .. 16384 samples: one feature per workgroup, half-length transform of its even / odd samples
@@ -3952,6 +4005,11 @@ done:
   pool_give(ctx, work, work_bytes);
   pool_give(ctx, spec, spec_bytes);
   pool_give(ctx, coef, coef_bytes);
+  if (a->rawT) {                 // consumed (or not usable by this call): back to the pool either way
+    eofx_mat* am = const_cast<eofx_mat*>(a);
+    pool_give(ctx, am->rawT, (size_t)n_pad * p_pad * sizeof(float));
+    am->rawT = nullptr;
+  }
   if (xt_transient && a->Xt) {   // (the stage ends with a stream synchronisation; same-stream reuse is ordered anyway)
     eofx_mat* am = const_cast<eofx_mat*>(a);
     pool_give(ctx, am->Xt, (size_t)n_pad * p_pad * sizeof(float));

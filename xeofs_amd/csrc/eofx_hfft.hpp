@@ -408,7 +408,9 @@ __global__ __launch_bounds__(plan<L>::WG, HFFT_WAVES) void hilbert_fft_kernel(co
                                                                               const float* __restrict__ u,
                                                                               float* __restrict__ Bt, float* __restrict__ At,
                                                                               unsigned* __restrict__ bmax,
-                                                                              unsigned* __restrict__ amax) {
+                                                                              unsigned* __restrict__ amax,
+                                                                              const float* __restrict__ aff = nullptr,
+                                                                              int64_t aff_ld = 0) {
   using PL = plan<L>;
   constexpr int P = PL::P, NT = PL::NT, RL = PL::RL, NW = PL::NW, NIN = PL::NIN, SA = PL::SA, SB = PL::SB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -479,6 +481,18 @@ __global__ __launch_bounds__(plan<L>::WG, HFFT_WAVES) void hilbert_fft_kernel(co
     cf* const row = data + phys(16 * t);
     const int64_t fa = MODE ? pair : 2 * pair, fb = fa + 1;
     const bool hb = MODE ? false : fb < p;
+    if constexpr (MODE == 0) {
+      if (aff) {   // rows of the RAW field (eofx_hilbert_f32, from_rawT): the Scaler map ((x - hi) - lo) * scale of apply_kernel
+        const float ha = aff[fa], la = aff[aff_ld + fa], sa_ = aff[2 * aff_ld + fa];
+        const float hb_ = hb ? aff[fb] : 0.f, lb = hb ? aff[aff_ld + fb] : 0.f, sb_ = hb ? aff[2 * aff_ld + fb] : 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const bool in = tb4 + (unsigned)(c * NT * 4) < nb;      // (samples beyond n were read as zeros and stay zeros)
+          ya[c] = in ? ((ya[c] - ha) - la) * sa_ : 0.f;
+          yb[c] = in ? ((yb[c] - hb_) - lb) * sb_ : 0.f;
+        }
+      }
+    }
     // ---- linear fit and pad amplitudes (float64 sums over the group)
     double sa = 0.0, ta = 0.0, sb = 0.0, tb = 0.0;
     if (sums) {

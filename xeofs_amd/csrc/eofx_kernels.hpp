@@ -2053,6 +2053,112 @@ __global__ __launch_bounds__(256) void colstats4_kernel(const float* __restrict_
   }
 }
 
+// The column statistics of colstats4_kernel + the sample-contiguous RAW field on the way (round 5: the Hilbert stage of an
+// in-place matrix needs whole series per feature and paid a 14 ms transposing copy behind the 5.5 ms statistics pass).
+// The tiling of apply_kernel<true>: a workgroup walks a strip of 64 features down its row split in 64 x 64 tiles -- thread
+// (tq = t % 16, tr = t / 16) loads the float4 of features 4 tq .. of rows tr + 16 q, takes them into its statistics, stages
+// them in LDS and writes 4 consecutive samples of one feature (256 contiguous bytes per feature and wave instruction) into
+// Xt [P][n_pad].  At the end the 16 row groups of a feature meet in LDS in a fixed order: one partial per (split, feature),
+// as colstats4_kernel leaves them.  P % 4 == 0, rows_per_split % 64 == 0.  The values written are the RAW ones.
+__global__ __launch_bounds__(256) void colstats_tr_kernel(const float* __restrict__ X, int64_t n, int64_t P, int64_t ld,
+                                                           int64_t rows_per_split, int* __restrict__ cnt, double* __restrict__ sum,
+                                                           double* __restrict__ sumsq, float* __restrict__ vmin,
+                                                           float* __restrict__ vmax, float* __restrict__ Xt, int64_t n_pad) {
+  __shared__ float T[64][65];
+  __shared__ double Sd[16][64];
+  __shared__ float Sf[16][64];
+  const int tid = threadIdx.x, tq = tid & 15, tr = tid >> 4;
+  const int64_t c0 = (int64_t)blockIdx.x * 64, cb = c0 + 4 * tq;
+  const bool live = cb < P;
+  const int64_t rs0 = (int64_t)blockIdx.y * rows_per_split;
+  const int64_t rs1 = (rs0 + rows_per_split < n) ? rs0 + rows_per_split : n;
+  int k[4] = {0, 0, 0, 0};
+  double s[4] = {0.0, 0.0, 0.0, 0.0}, qq[4] = {0.0, 0.0, 0.0, 0.0};
+  float lo[4] = {INFINITY, INFINITY, INFINITY, INFINITY}, hi[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  for (int64_t r0 = rs0; r0 < rs1; r0 += 64) {
+    f32x4 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int64_t r = r0 + tr + 16 * q;
+      v[q] = (live && r < rs1) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(X + r * ld + cb)) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const bool in = live && r0 + tr + 16 * q < rs1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float x = v[q][e];
+        T[tr + 16 * q][4 * tq + e] = x;
+        if (in) {
+          lo[e] = fminf(lo[e], x);      // fminf / fmaxf skip NaN
+          hi[e] = fmaxf(hi[e], x);
+          if (x == x) {
+            const double d = (double)x;
+            ++k[e];
+            s[e] += d;
+            qq[e] += d * d;
+          }
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int cc = tr + 16 * q;
+      if (c0 + cc < P) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = T[4 * tq + e][cc];
+        *reinterpret_cast<f32x4*>(Xt + (c0 + cc) * n_pad + r0 + 4 * tq) = o;
+      }
+    }
+    __syncthreads();
+  }
+  // the 16 row groups of every feature, added in the order tr = 0 .. 15
+  const int64_t o = (int64_t)blockIdx.y * P + c0 + tid;
+  const bool writer = tid < 64 && c0 + tid < P;
+#define EOFX_CTR_RED_D(arr, dst)                                         \
+  {                                                                      \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) Sd[tr][4 * tq + e] = arr[e]; \
+    __syncthreads();                                                     \
+    if (writer) {                                                        \
+      double a = Sd[0][tid];                                             \
+      for (int g = 1; g < 16; ++g) a += Sd[g][tid];                      \
+      dst[o] = a;                                                        \
+    }                                                                    \
+    __syncthreads();                                                     \
+  }
+  EOFX_CTR_RED_D(s, sum)
+  EOFX_CTR_RED_D(qq, sumsq)
+#undef EOFX_CTR_RED_D
+#pragma unroll
+  for (int e = 0; e < 4; ++e) Sf[tr][4 * tq + e] = lo[e];
+  __syncthreads();
+  if (writer) {
+    float a = Sf[0][tid];
+    for (int g = 1; g < 16; ++g) a = fminf(a, Sf[g][tid]);
+    vmin[o] = a;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 4; ++e) Sf[tr][4 * tq + e] = hi[e];
+  __syncthreads();
+  if (writer) {
+    float a = Sf[0][tid];
+    for (int g = 1; g < 16; ++g) a = fmaxf(a, Sf[g][tid]);
+    vmax[o] = a;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 4; ++e) Sf[tr][4 * tq + e] = __int_as_float(k[e]);
+  __syncthreads();
+  if (writer) {
+    int a = 0;
+    for (int g = 0; g < 16; ++g) a += __float_as_int(Sf[g][tid]);
+    cnt[o] = a;
+  }
+}
+
 // One thread per feature.  weights may be null (ones).  Outputs per (uncompacted) feature.
 __global__ __launch_bounds__(256) void colstats_finalize_kernel(
     const int* __restrict__ cnt_p, const double* __restrict__ sum_p,

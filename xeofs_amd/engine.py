@@ -351,7 +351,8 @@ def _layout_mode(keep_raw, in_place, allow_masked):
 
 
 def preprocess(ctx: Context, X, center=True, standardize=False, feature_weights=None,
-               check_nans=True, want_stats=True, build=True, keep_raw=False, in_place=False, allow_masked=False):
+               check_nans=True, want_stats=True, build=True, keep_raw=False, in_place=False, allow_masked=False,
+               for_hilbert=False):
     """Scaler + Sanitizer + total variance on the stacked raw (n, P) field.
     Returns (ResidentMatrix | None, stats dict).  keep_raw: raw mode (include/eofx.h, eofx_ctx_set_layout) -- the
     feature-contiguous layout is not written, the products read the raw field through the Scaler map; in_place:
@@ -360,7 +361,9 @@ def preprocess(ctx: Context, X, center=True, standardize=False, feature_weights=
     `release_raw()` / `free()` (the matrix holds a reference to it); a host field is staged and owned.
     allow_masked (with in_place): a field whose NaN pattern is a mask of all-NaN grid points stays in place as well -- the
     masked features become zero columns of the engine's matrix (layout mode 3, include/eofx.h) and this module
-    compacts / scatters the feature axis of every factor, so `mat.p` and the factors have the valid features only."""
+    compacts / scatters the feature axis of every factor, so `mat.p` and the factors have the valid features only.
+    for_hilbert (with in_place): `hilbert(ctx, mat, ...)` is the next call on this matrix -- the statistics pass also writes the
+    raw field in the sample-contiguous layout (eofx_ctx_set_sample_raw) and the Hilbert stage saves its transposing copy."""
     X = _f32c(X)
     n, P = X.shape
     w = None if feature_weights is None else np.ascontiguousarray(feature_weights, dtype=np.float64)
@@ -374,12 +377,14 @@ def preprocess(ctx: Context, X, center=True, standardize=False, feature_weights=
     tv = C.c_double()
     h = C.c_void_p()
     ctx.lib.eofx_ctx_set_layout(ctx.handle, _layout_mode(keep_raw, in_place, allow_masked))
+    ctx.lib.eofx_ctx_set_sample_raw(ctx.handle, int(bool(for_hilbert and in_place and build)))
     try:
         rc = ctx.lib.eofx_preprocess_f32(ctx.handle, ptr(X), n, P, int(center), int(standardize), ptr(w),
                                          int(check_nans), C.byref(h) if build else None, ptr(mean), ptr(std),
                                          ptr(vf), ptr(vs), C.byref(n_out), C.byref(p_out), C.byref(tv))
     finally:
         ctx.lib.eofx_ctx_set_layout(ctx.handle, 0)
+        ctx.lib.eofx_ctx_set_sample_raw(ctx.handle, 0)
     raise_for(rc, ctx.handle)
     stats = dict(mean=mean, std=std, valid_feature=vf.astype(bool), valid_sample=vs.astype(bool),
                  n=n_out.value, p=p_out.value, total_variance=tv.value)

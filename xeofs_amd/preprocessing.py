@@ -135,7 +135,8 @@ class Preprocessor:
             self.total_variance = mat.sumsq() / (mat.n - 1)
             return mat
         mat, st = engine.preprocess(ctx, M, self.center, self.standardize, self.feature_weights, self.check_nans,
-                                    in_place=self.in_place, allow_masked=self.masked_ok)
+                                    in_place=self.in_place, allow_masked=self.masked_ok,
+                                    for_hilbert=bool(getattr(self, "for_hilbert", False)) and self.in_place)
         self.mean_, self.std_ = (st["mean"] if self.center else None), (st["std"] if self.standardize else None)
         self.valid_feature, self.valid_sample = st["valid_feature"], st["valid_sample"]
         self.total_variance = st["total_variance"]

@@ -345,6 +345,7 @@ class HilbertEOF(ComplexEOF):
         # A centred field stays in place (the raw field through the Scaler map): the Hilbert stage then builds the
         # sample-contiguous layout it works on for the duration of its kernel only and leaves Im in that layout alone.
         self.preprocessor.in_place = centred and self._lean_ok()
+        self.preprocessor.for_hilbert = True        # (the statistics pass writes the sample-contiguous raw field on its way)
         A = self.preprocessor.fit_transform(X, dim, weights)
         self.sample_dims = self.preprocessor.sample_dims
         B, A2 = engine.hilbert(self.ctx, A, self.padding, self.decay_factor, want_real=not centred)
