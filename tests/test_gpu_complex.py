@@ -568,3 +568,77 @@ def test_hilbert_reads_the_raw_layout_of_the_statistics_pass(ctx, n, p, std, use
     assert np.array_equal(B2.download(), b1) or np.abs(B2.download() - b1).max() <= 2e-6 * np.abs(b1).max()
     for m in (A0, B0, A1, B1, B2):
         m.free()
+
+
+@pytest.mark.parametrize("for_hilbert", [False, True])
+@pytest.mark.parametrize("n,P,k", [(300, 1600, 6), (520, 4096, 12)])
+def test_masked_field_through_hilbert_and_complex_rsvd_in_place(ctx, n, P, k, for_hilbert):
+    """VERDICT r04 item 7 (sanitizer.py:80-126 ahead of eof.py:546-555): a field with a 30 % land mask (all-NaN grid points)
+    stays IN PLACE through the Hilbert stage and the complex decomposition -- zero columns in the real part (the MASK forms of
+    the streaming kernels), zero columns in the written imaginary part, the sign rule over the valid features only -- and gives
+    the factors of the compaction route (which writes the compacted matrix in both layouts: 3x the field) to 2e-6."""
+    from xeofs_amd import engine
+
+    rng = np.random.default_rng(P)
+    X = _waves(n, P, seed=n, noise=0.2) + 11.0
+    dead = rng.choice(P, size=int(0.3 * P), replace=False)
+    X[:, dead] = np.nan
+    w = rng.uniform(0.4, 1.3, size=P)
+    A0, st0 = engine.preprocess(ctx, X, True, False, w)                         # compacted, written layouts
+    assert not A0.masked and A0.p == P - dead.size
+    B0, _ = engine.hilbert(ctx, A0, "exp", 0.2)
+    U0, s0, V0 = engine.rsvd_c64(ctx, A0, B0, k, random_state=3)
+    A1, st1 = engine.preprocess(ctx, X, True, False, w, in_place=True, allow_masked=True, for_hilbert=for_hilbert)
+    assert A1.masked and A1.p == A0.p and A1.p_phys == P and A1.layout() == (False, True)
+    B1, _ = engine.hilbert(ctx, A1, "exp", 0.2)
+    assert B1.p == P and not B1.masked
+    U1, s1, V1 = engine.rsvd_c64(ctx, A1, B1, k, random_state=3)
+    assert A1.layout() == (False, True) and not B1.layout()[0]                   # nothing else was written
+    b1 = B1.download()                                                           # (builds B1's other layout: after the check)
+    assert not b1[:, dead].any()
+    b0 = B0.download()
+    assert np.abs(b1[:, np.setdiff1d(np.arange(P), dead)] - b0).max() <= 2e-6 * np.abs(b0).max()
+    assert V1.shape == V0.shape == (A0.p, k)
+    assert np.all(np.abs(s1 - s0) <= 2e-6 * s0[0])
+    for j in range(k):
+        if min(s0[j - 1] - s0[j] if j else np.inf, s0[j] - (s0[j + 1] if j + 1 < k else 0.0)) > 1e-3 * s0[0]:
+            assert abs(np.vdot(V0[:, j], V1[:, j])) >= 1 - 1e-5, j        # (a complex mode is defined up to a unit phase)
+            assert abs(np.vdot(U0[:, j], U1[:, j])) >= 1 - 1e-5, j
+    assert (orc.deterministic_sign_multiplier(V1.conj().T) == 1).all()
+    for m in (A0, B0, A1, B1):
+        m.free()
+
+
+def test_hilbert_eof_model_on_a_land_masked_field(ctx):
+    """xe.single.HilbertEOF on a field with a land mask: the masked in-place route (round 5) against the compaction route of
+    the same model, and against the oracle's analytic signal -- components carry NaN at the masked grid points either way."""
+    import xeofs_amd as xe
+
+    n, ny, nx, k = 260, 24, 50, 4
+    rng = np.random.default_rng(5)
+    X = (_waves(n, ny * nx, seed=3, noise=0.2) + 4.0).reshape(n, ny, nx)
+    land = rng.random((ny, nx)) < 0.3
+    X[:, land] = np.nan
+    da = xe.DataArray(X, dims=("time", "lat", "lon"), coords={"lat": np.linspace(-60, 60, ny)})
+    ms = []
+    for masked_ok in (True, False):
+        m = xe.single.HilbertEOF(n_modes=k, use_coslat=True, random_state=2, padding="exp")
+        m.ctx = ctx
+        m._hilbert_masked_ok = masked_ok
+        m.fit(da, "time")
+        assert m.data["input_data"][0].masked == masked_ok
+        ms.append(m)
+    s1, s0 = (np.asarray(m.singular_values().values, dtype=np.float64) for m in ms)
+    assert np.all(np.abs(s1 - s0) <= 2e-6 * s0[0])
+    c1, c0 = (np.asarray(m.components().values) for m in ms)
+    assert c1.shape == c0.shape == (k, ny, nx)
+    assert np.isnan(c1[:, land]).all() and not np.isnan(c1[:, ~land]).any()
+    for j in range(k):
+        a, b = c0[j][~land], c1[j][~land]
+        assert abs(np.vdot(a, b)) >= (1 - 1e-5) * np.linalg.norm(a) * np.linalg.norm(b)
+    # against the oracle: Scaler / Sanitizer restatement + Hilbert transform + exact complex SVD of the compacted matrix
+    w = np.repeat(orc.sqrt_cos_lat_weights(np.linspace(-60, 60, ny)), nx)
+    pre = orc.preprocess(X.reshape(n, -1).astype(np.float64), True, False, w)
+    Z = pre["X"] + 1j * orc.hilbert_transform(pre["X"], padding="exp", decay_factor=0.2).imag
+    se = np.linalg.svd(Z, compute_uv=False)[:k]
+    assert np.all(np.abs(s1 - se) <= 1e-5 * se)

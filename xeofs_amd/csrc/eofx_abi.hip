@@ -1741,7 +1741,7 @@ extern "C" int eofx_preprocess_f32(eofx_ctx* ctx, const float* X, int64_t n, int
                                        &pv, hcnt, &fs);
   if (ctx->pending_rawT) {     // the transposed raw field of the statistics pass: to the in-place matrix, or back to the pool
     eofx_mat* m = (rc_sa == EOFX_OK && out) ? *out : nullptr;
-    if (m && m->raw && m->aff && !m->X && !m->Xt && !m->masked && m->n == n && m->p == P &&
+    if (m && m->raw && m->aff && !m->X && !m->Xt && m->n == n && m->p == P &&
         (size_t)m->n_pad * m->p_pad * sizeof(float) == ctx->pending_rawT_bytes)
       m->rawT = ctx->pending_rawT;
     else
@@ -3875,7 +3875,7 @@ static int get_hilbert_setup(eofx_ctx* ctx, int64_t n, int padding, double decay
 template <int L, int MODE>
 static hipError_t launch_hilbert_fused(eofx_ctx* ctx, const float* Xt, int64_t n_pad, int64_t n, int64_t p, int padding,
                                        const float* hperm, const float* u, float* Bt, float* At, unsigned* bmax,
-                                       unsigned* amax, const float* aff = nullptr, int64_t aff_ld = 0) {
+                                       unsigned* amax, const float* aff = nullptr, int64_t aff_ld = 0, const float* oscale = nullptr) {
   using PL = hfft::plan<L>;
   auto kern = hfft::hilbert_fft_kernel<L, MODE>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PL::lds);
@@ -3891,7 +3891,7 @@ static hipError_t launch_hilbert_fused(eofx_ctx* ctx, const float* Xt, int64_t n
   }
   const int grid = (int)std::min<int64_t>(groups, (int64_t)cu_count * per_cu);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(PL::WG), PL::lds, ctx->stream, Xt, n_pad, (int)n, p, padding, hperm, u, Bt, At,
-                     bmax, amax, aff, aff_ld);
+                     bmax, amax, aff, aff_ld, oscale);
   return hipGetLastError();
 }
 
@@ -3913,7 +3913,9 @@ extern "C" int eofx_hilbert_f32(eofx_ctx* ctx, const eofx_mat* a, int padding, d
   // sample-contiguous copy exists only while the kernel runs, and the imaginary part is produced in that layout alone
   // (eofx_rsvd_c64 streams the pair [raw field, Im^T] directly; any other consumer gets the feature-contiguous layout on
   // demand through ensure_X).
-  const bool lean = a->raw && a->aff && !a->X && !a->masked;
+  // (round 5: a MASKED in-place field -- all-NaN grid points kept as zero columns, sanitizer.py:80-126 -- takes the lean route
+  // too: its series are zeros, so is their transform, and Im carries the same zero columns as a plain written matrix)
+  const bool lean = a->raw && a->aff && !a->X;
   // round 5: the statistics pass of the in-place preprocess already wrote the RAW field in the sample-contiguous layout
   // (eofx_ctx_set_sample_raw, colstats4_tr_kernel); the one-kernel route reads it through the Scaler map -- the same
   // expression apply_kernel would have written, so the transform is bit-identical to the transient-copy route below
@@ -3940,7 +3942,7 @@ extern "C" int eofx_hilbert_f32(eofx_ctx* ctx, const eofx_mat* a, int padding, d
     switch (L) {
 #define EOFX_HF(LL) \
   case LL: e = launch_hilbert_fused<LL, 0>(ctx, from_rawT ? a->rawT : a->Xt, n_pad, n, p, padding ? 1 : 0, hperm, u, mi->Xt, At, mi->absmax_dev, amax, \
-                                           from_rawT ? a->aff : nullptr, a->p_pad); break;
+                                           from_rawT ? a->aff : nullptr, a->p_pad, a->masked ? a->aff + 2 * a->p_pad : nullptr); break;
       EOFX_HF(10) EOFX_HF(11) EOFX_HF(12) EOFX_HF(13) EOFX_HF(14)
 #undef EOFX_HF
       case 15:   // 8193 .. 16384 samples: one feature per workgroup, half-length transform of its even / odd samples
@@ -4036,8 +4038,12 @@ extern "C" int eofx_cpanel_combine_f32(eofx_ctx* ctx, const float* P1, const flo
   return EOFX_OK;
 }
 
+static int panel_colargminmax(eofx_ctx* ctx, const float* P, int64_t rows, int L, int64_t* amax, int64_t* amin, const float* rowscale);
 extern "C" int eofx_panel_colargminmax_f32(eofx_ctx* ctx, const float* P, int64_t rows, int L, int64_t* amax,
                                            int64_t* amin) {
+  return panel_colargminmax(ctx, P, rows, L, amax, amin, nullptr);
+}
+static int panel_colargminmax(eofx_ctx* ctx, const float* P, int64_t rows, int L, int64_t* amax, int64_t* amin, const float* rowscale) {
   if (!ctx || !P || !amax || !amin) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
   CHK(set_device(ctx));
   const int nparts = (int)std::max<int64_t>(1, std::min<int64_t>((rows + 3) / 4, 512));
@@ -4048,7 +4054,7 @@ extern "C" int eofx_panel_colargminmax_f32(eofx_ctx* ctx, const float* P, int64_
   ARENA(int64_t, imx, (size_t)nparts * L);
   ARENA(int64_t, imn, (size_t)nparts * L);
   hipLaunchKernelGGL(colargminmax_part_kernel, dim3(nparts, (L + 63) / 64), dim3(256), 0, ctx->stream, P, rows, L,
-                     pmx, imx, pmn, imn);
+                     pmx, imx, pmn, imn, rowscale);
   KCHK();
   hipLaunchKernelGGL(colargminmax_final_kernel, dim3((L + 63) / 64), dim3(64), 0, ctx->stream, pmx, imx, pmn, imn,
                      nparts, L, amax, amin);
@@ -4272,7 +4278,9 @@ struct CplxOps {
 // instead of writing the missing ones (64-column panels, split-fp16 passes)
 static bool cplx_lean(const eofx_mat* A, const eofx_mat* B, int LP, int prec_power, int prec_final) {
   const bool all_written = A->X && A->Xt && B->X && B->Xt;
-  return !all_written && !A->masked && !B->masked && LP == 64 && prec_power == EOFX_PREC_F16X3 && prec_final == EOFX_PREC_F16X3;
+  // (a masked real part -- zero columns in place, the MASK forms of the streaming kernels -- is streamed where it lies as well;
+  // the imaginary part of such a field is a written matrix whose columns there are zeros)
+  return !all_written && !B->masked && LP == 64 && prec_power == EOFX_PREC_F16X3 && prec_final == EOFX_PREC_F16X3;
 }
 // the identity map for the rows of a written sample-contiguous part (arena memory of the caller's scope)
 static int cplx_lean_setup(eofx_ctx* ctx, CplxOps& ops) {
@@ -4345,10 +4353,11 @@ extern "C" int eofx_rsvd_c64(eofx_ctx* ctx, const eofx_mat* A, const eofx_mat* B
     return set_err(ctx, EOFX_ERR_ARG, "bad argument");
   if (A->n != B->n || A->p != B->p) return set_err(ctx, EOFX_ERR_SHAPE, "real and imaginary parts must have the same shape");
   CHK(set_device(ctx));
-  const int64_t n = A->n, p = A->p, r = std::min(n, p);
+  const int64_t n = A->n, p = A->p, r = std::min(n, A->masked ? A->p_valid : p);
   if (k > r) return set_err(ctx, EOFX_ERR_RANK, "n_modes must be less than or equal to the rank of the dataset (rank = %lld).", (long long)r);
   const int l = (int)std::min<int64_t>(k + n_oversamples, r);
   if (l > 64) return set_err(ctx, EOFX_ERR_ARG, "complex sketch width %d > 64 is not supported (n_modes + n_oversamples <= 64)", l);
+  if (A->masked && !(n < A->p_valid)) return set_err(ctx, EOFX_ERR_ARG, "masked in-place matrix with fewer valid features than samples");
   const bool adaptive = n_iter == -2;
   const int auto_count = k < 0.1 * (double)r ? 7 : 4;
   if (n_iter == -1) n_iter = auto_count;
@@ -4782,7 +4791,7 @@ extern "C" int eofx_rsvd_c64(eofx_ctx* ctx, const eofx_mat* A, const eofx_mat* B
     // VT = conj(V)^T; numpy's max / min of complex numbers are lexicographic (real part, then imaginary part)
     ARENA(int64_t, amax, Lo);
     ARENA(int64_t, amin, Lo);
-    CHK(eofx_panel_colargminmax_f32(ctx, Vp, p, Lo, amax, amin));
+    CHK(panel_colargminmax(ctx, Vp, p, Lo, amax, amin, A->masked ? A->aff + 2 * A->p_pad : nullptr));   // (scale plane: 0 at masked features)
     ARENA(float, picks, 4 * (size_t)k);
     hipLaunchKernelGGL(cpanel_pick_kernel, dim3((k + 63) / 64), dim3(64), 0, ctx->stream, Vp, Lo, k, amax, amin, picks);
     KCHK();

@@ -410,7 +410,8 @@ __global__ __launch_bounds__(plan<L>::WG, HFFT_WAVES) void hilbert_fft_kernel(co
                                                                               unsigned* __restrict__ bmax,
                                                                               unsigned* __restrict__ amax,
                                                                               const float* __restrict__ aff = nullptr,
-                                                                              int64_t aff_ld = 0) {
+                                                                              int64_t aff_ld = 0,
+                                                                              const float* __restrict__ oscale = nullptr) {
   using PL = plan<L>;
   constexpr int P = PL::P, NT = PL::NT, RL = PL::RL, NW = PL::NW, NIN = PL::NIN, SA = PL::SA, SB = PL::SB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -488,8 +489,8 @@ __global__ __launch_bounds__(plan<L>::WG, HFFT_WAVES) void hilbert_fft_kernel(co
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
           const bool in = tb4 + (unsigned)(c * NT * 4) < nb;      // (samples beyond n were read as zeros and stay zeros)
-          ya[c] = in ? ((ya[c] - ha) - la) * sa_ : 0.f;
-          yb[c] = in ? ((yb[c] - hb_) - lb) * sb_ : 0.f;
+          ya[c] = (in && sa_ != 0.f) ? ((ya[c] - ha) - la) * sa_ : 0.f;      // (scale 0: an all-NaN grid point kept as a zero column)
+          yb[c] = (in && sb_ != 0.f) ? ((yb[c] - hb_) - lb) * sb_ : 0.f;
         }
       }
     }
@@ -683,6 +684,9 @@ __global__ __launch_bounds__(plan<L>::WG, HFFT_WAVES) void hilbert_fft_kernel(co
       const rsrc_t ru = row_rsrc(u, padding ? 4u * nb : 0u);   // [n][4]: 16 bytes per sample
       const rsrc_t wa_ = row_rsrc(Bt + fa * n_pad, npb);
       const rsrc_t wb_ = row_rsrc(Bt + fb * n_pad, hb ? npb : 0u);
+      // oscale (masked in-place input): a feature whose Scaler scale is 0 is an all-NaN grid point kept as a zero column -- its
+      // output row is written as exact zeros (sharing a complex transform with a live feature leaves rounding noise in it)
+      const bool za = oscale && oscale[fa] == 0.f, zb = oscale && hb && oscale[fb] == 0.f;
       constexpr int UB = 2;                                    // sample groups per batch of table loads
 #pragma unroll
       for (int c0 = 0; c0 < 8; c0 += UB) {
@@ -711,8 +715,8 @@ __global__ __launch_bounds__(plan<L>::WG, HFFT_WAVES) void hilbert_fft_kernel(co
           } else {
             float xa = va[c] + (a1a * ue[q].x + a2a * ue[q].y + a3a * ue[q].z + a4a * ue[q].w) - m0;
             float xb = vb[c] + (a1b * ue[q].x + a2b * ue[q].y + a3b * ue[q].z + a4b * ue[q].w) - m1;
-            xa = (o < nb) ? xa : 0.f;
-            xb = (o < nb) ? xb : 0.f;
+            xa = (o < nb && !za) ? xa : 0.f;
+            xb = (o < nb && !zb) ? xb : 0.f;
             st_nt(xa, wa_, o);
             st_nt(xb, wb_, o);
             run_mx = max(run_mx, max(absbits(xa), absbits(xb)));   // (idle rows carry zeros)

@@ -2690,7 +2690,10 @@ __global__ __launch_bounds__(256) void colargminmax_part_kernel(const float* __r
                                                                  int L, float* __restrict__ pmx,
                                                                  int64_t* __restrict__ imx,
                                                                  float* __restrict__ pmn,
-                                                                 int64_t* __restrict__ imn) {
+                                                                 int64_t* __restrict__ imn,
+                                                                 const float* __restrict__ rowscale = nullptr) {
+  // rowscale (may be null): rows r with rowscale[r] == 0 are skipped -- the masked features of an in-place matrix, whose
+  // rows of V are exact zeros and must not take part in the sign rule of the compacted matrix
   __shared__ float smx[4][64], smn[4][64];
   __shared__ int64_t sax[4][64], san[4][64];
   const int tid = threadIdx.x;
@@ -2700,6 +2703,7 @@ __global__ __launch_bounds__(256) void colargminmax_part_kernel(const float* __r
   int64_t ax = -1, an = -1;
   if (c < L)
     for (int64_t r = (int64_t)blockIdx.x * 4 + rl; r < rows; r += (int64_t)gridDim.x * 4) {
+      if (rowscale && rowscale[r] == 0.f) continue;
       const float v = P[r * L + c];
       if (v > mx) { mx = v; ax = r; }
       if (v < mn) { mn = v; an = r; }

@@ -882,13 +882,16 @@ def hilbert(ctx: Context, mat: ResidentMatrix, padding="exp", decay_factor: floa
     """Analytic signal along the sample axis (xeofs/utils/hilbert_transform.py:40-72).
     Returns (imag ResidentMatrix, real ResidentMatrix | None).  As in the reference only
     padding == "exp" pads; any other value means no padding."""
-    if mat.masked:      # (checked BEFORE the call: its two result matrices would leak)
-        raise NotImplementedError("Hilbert transform of a masked in-place matrix (preprocess without allow_masked)")
+    if mat.masked and want_real:      # (checked BEFORE the call: its two result matrices would leak)
+        raise NotImplementedError("re-centred real part of a masked in-place matrix (preprocess with center=True)")
     hi, hr = C.c_void_p(), C.c_void_p()
     rc = ctx.lib.eofx_hilbert_f32(ctx.handle, mat.handle, int(padding == "exp"), float(decay_factor),
                                   C.byref(hi), C.byref(hr) if want_real else None)
     raise_for(rc, ctx.handle)
-    return ResidentMatrix(ctx, hi), (ResidentMatrix(ctx, hr) if want_real else None)
+    B = ResidentMatrix(ctx, hi)
+    # a masked in-place input (all-NaN grid points kept as zero columns): Im is a plain written matrix over the SAME physical
+    # columns, zeros at the masked ones; `rsvd_c64(ctx, mat, B, ...)` compacts the feature axis of its factors through `mat`
+    return B, (ResidentMatrix(ctx, hr) if want_real else None)
 
 
 def cmat_mul(ctx: Context, A: ResidentMatrix, B: ResidentMatrix, P, conj_left: bool, final: bool = False):
@@ -1004,8 +1007,10 @@ def rsvd_c64(ctx: Context, A: ResidentMatrix, B: ResidentMatrix, k: int, n_overs
     """complex randomized SVD of Z = A + iB (eofx_rsvd_c64) -> (U[n,k] complex64, s[k] float32, V[p,k] complex64);
     device_out: U and V stay on the device as torch complex64 tensors (V is 8 p k bytes: 166 MB at config 5)"""
     k = int(k)
-    if A.masked or B.masked:
-        raise NotImplementedError("complex rSVD of masked in-place matrices (preprocess without allow_masked)")
+    if B.masked:
+        raise NotImplementedError("complex rSVD with a masked imaginary part (only the real part may be a masked in-place matrix)")
+    if A.masked and (B.p_phys != A.p_phys or A.p < A.n):
+        raise NotImplementedError("masked in-place real part: the imaginary part must cover the same physical columns and n < p")
     r = min(A.n, A.p)
     if k > r:
         raise ValueError(f"n_modes must be less than or equal to the rank of the dataset (rank = {r}).")
@@ -1025,11 +1030,11 @@ def rsvd_c64(ctx: Context, A: ResidentMatrix, B: ResidentMatrix, k: int, n_overs
         torch = _torch()
         dev = f"cuda:{ctx.device}"
         U = torch.empty((A.n, k), dtype=torch.complex64, device=dev)
-        V = torch.empty((A.p, k), dtype=torch.complex64, device=dev)
+        V = torch.empty((A.p_phys, k), dtype=torch.complex64, device=dev)
     else:
         U = _host_out((A.n, k), np.complex64)
-        V = _host_out((A.p, k), np.complex64)
+        V = _host_out((A.p_phys, k), np.complex64)
     s = np.empty(k, np.float32)
     raise_for(ctx.lib.eofx_rsvd_c64(ctx.handle, A.handle, B.handle, k, int(n_oversamples), it, ptr(omega), int(flip),
                                     ptr(U), ptr(s), ptr(V)), ctx.handle)
-    return U, s, V
+    return U, s, A.compact_rows(V)       # (masked real part: the rows of the valid features)

@@ -346,6 +346,9 @@ class HilbertEOF(ComplexEOF):
         # sample-contiguous layout it works on for the duration of its kernel only and leaves Im in that layout alone.
         self.preprocessor.in_place = centred and self._lean_ok()
         self.preprocessor.for_hilbert = True        # (the statistics pass writes the sample-contiguous raw field on its way)
+        # a land / sea mask (all-NaN grid points) stays in place too: zero columns through the Hilbert stage and the passes
+        # of the decomposition (round 5; `_hilbert_masked_ok = False` forces the compaction route, for comparisons)
+        self.preprocessor.masked_ok = self.preprocessor.in_place and getattr(self, "_hilbert_masked_ok", True)
         A = self.preprocessor.fit_transform(X, dim, weights)
         self.sample_dims = self.preprocessor.sample_dims
         B, A2 = engine.hilbert(self.ctx, A, self.padding, self.decay_factor, want_real=not centred)
