@@ -350,7 +350,10 @@ class CPCCA(Deferred):
         # the process-wide counter of xeofs_amd.pca)
         rs = self.random_state
         seeds = [int(rs) + 1000003 * (i + 1) if isinstance(rs, (int, np.integer)) else None for i in range(2)]
-        pcas = [ResidentPCA(self.ctx, self._params["n_pca_modes"][i], self._params["pca_init_rank_reduction"][i], random_state=seeds[i])
+        # (alpha = 1: no whitener reads the PC spectrum and the model's outputs are invariant to a rotation inside the PC space --
+        # the pre-reduction may skip its order-ell eigen-decomposition when it keeps every mode anyway, pca.py `basis_only`)
+        pcas = [ResidentPCA(self.ctx, self._params["n_pca_modes"][i], self._params["pca_init_rank_reduction"][i], random_state=seeds[i],
+                            basis_only=_whitener_is_identity(self.alpha[i]))
                 if self._params["use_pca"][i] else None for i in range(2)]
         _fit_two_pcas(pcas, mats, [pre.total_variance for pre in pres])
         for i in range(2):

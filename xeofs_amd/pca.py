@@ -46,7 +46,7 @@ def _next_seed():
 
 class ResidentPCA:
     def __init__(self, ctx, n_modes=0.999, init_rank_reduction: float = 0.3, flip_signs: bool = True, solver: str = "auto",
-                 random_state=None, n_iter: int = 4, n_oversamples: int = 10):
+                 random_state=None, n_iter: int = 4, n_oversamples: int = 10, basis_only: bool = False):
         """solver: "randomized" = the reference's own algorithm (scikit-learn's randomized_svd: n_oversamples = 10, 4 power
         iterations at this width, re-normalised every step) carried out on the RESIDENT sample-space Gram matrix -- every
         product n x n x l, no pass over the field inside the iteration, no order-n eigen-decomposition; "exact": the
@@ -56,6 +56,11 @@ class ResidentPCA:
         the two fields of a cross model, the same results for the same sequence of calls)."""
         self.ctx = ctx
         self.solver = solver
+        # basis_only (round 5, VERDICT r04 item 5): the caller needs the PC SUBSPACE, not its individual modes (a cross model
+        # with alpha = 1: MCA's outputs are invariant to a rotation inside the PC space).  When the variance target is then
+        # out of reach of all the computed directions -- decided from trace(B^T B) alone -- every mode is kept and the order-ell
+        # eigen-decomposition of the randomized route (36 of 85 ms at config 3) is skipped: see `_basis_without_spectrum`.
+        self.basis_only = bool(basis_only)
         self.random_state = random_state
         self.n_iter, self.n_oversamples = int(n_iter), int(n_oversamples)
         self.flip_signs = flip_signs
@@ -128,6 +133,7 @@ class ResidentPCA:
         if self.solver not in ("auto", "randomized", "exact"):
             raise ValueError(f"Unrecognized solver '{self.solver}'. Valid options are 'auto', 'randomized', and 'exact'.")
         self.solver_used = "randomized" if randomized else "exact"
+        self.spectrum_known = True
         dev = Gf.device
         if randomized:
             # ---- the reference's randomized solver on the resident Gram matrix (see _range_randomized) -----------------------
@@ -140,26 +146,44 @@ class ResidentPCA:
                 # B = X^T Q (p x ell: the one wide product over the field) and the Rayleigh-Ritz step on B^T B = Q^T G Q,
                 # accumulated in float64 from exact products of the field -- as in the exact route below
                 B = engine.panel_tmul(ctx, mat, Q, prec=ctx.precision[1])
-                M = engine.panel_gram(ctx, B)[:ell, :ell]
+                Mfull = engine.panel_gram(ctx, B)
+                M = Mfull[:ell, :ell]
                 M = 0.5 * (M + M.T)
-                th, W = yield M                             # order ell: the one library call of this route (see fit)
-                th = torch.flip(th, (0,)).clamp_min(0.0)
-                W = torch.flip(W, (1,))
-                lam_h = th.cpu().numpy()
-                m = self._truncate(lam_h, n_pre, n, total_variance)
-                Lm = _round32(m)
-                th, W = th[:m], W[:, :m]
-                s = torch.sqrt(th)
-                tiny = float(th[0]) * 1e-14 if m else 0.0
-                inv = torch.where(th > tiny, 1.0 / torch.sqrt(th.clamp_min(1e-300)), torch.zeros_like(th))
-                Wt = torch.zeros((Le, Lm), dtype=torch.float64, device=dev)
-                Wt[:ell, :m] = W * inv
-                self.Vp = engine.panel_matmul(ctx, B, Wt)   # V = B W theta^-1/2
-                del B
-                # The subspace of a randomized solver is not invariant, so U s and X V differ for the unconverged modes; the
-                # reference keeps V and defines the scores as X V (preprocessing/pca.py:120-131).  X V = X X^T Q W theta^-1/2
-                # = (G Q) W theta^-1/2, and G Q is at hand from the range finder's last product: no further pass.
-                U = engine.panel_matmul(ctx, GQ, Wt)[:n, :m].double() * inv
+                fast = None
+                if self.basis_only and self.is_based_on_variance and n_pre <= ell and \
+                        float(M.diagonal().sum()) / (n - 1) / total_variance < self.n_modes:
+                    fast = self._basis_without_spectrum(M, Mfull, ell, n_pre, n, total_variance)
+                if fast is not None:
+                    Wm, lam_h = fast                        # ell x n_pre: B Wm is an orthonormal basis of the kept subspace
+                    m = n_pre
+                    Lm = _round32(m)
+                    Wt = torch.zeros((Le, Lm), dtype=torch.float64, device=dev)
+                    Wt[:ell, :m] = Wm
+                    self.Vp = engine.panel_matmul(ctx, B, Wt)
+                    del B
+                    Sc = engine.panel_matmul(ctx, GQ, Wt)[:n, :m].double()     # X V = (G Q) Wm
+                    s = torch.sqrt((Sc * Sc).sum(dim=0)).clamp_min(1e-300)     # column norms: scores = U s stays X V
+                    U = Sc / s
+                    self.spectrum_known = False
+                else:
+                    th, W = yield M                         # order ell: the one library call of this route (see fit)
+                    th = torch.flip(th, (0,)).clamp_min(0.0)
+                    W = torch.flip(W, (1,))
+                    lam_h = th.cpu().numpy()
+                    m = self._truncate(lam_h, n_pre, n, total_variance)
+                    Lm = _round32(m)
+                    th, W = th[:m], W[:, :m]
+                    s = torch.sqrt(th)
+                    tiny = float(th[0]) * 1e-14 if m else 0.0
+                    inv = torch.where(th > tiny, 1.0 / torch.sqrt(th.clamp_min(1e-300)), torch.zeros_like(th))
+                    Wt = torch.zeros((Le, Lm), dtype=torch.float64, device=dev)
+                    Wt[:ell, :m] = W * inv
+                    self.Vp = engine.panel_matmul(ctx, B, Wt)   # V = B W theta^-1/2
+                    del B
+                    # The subspace of a randomized solver is not invariant, so U s and X V differ for the unconverged modes; the
+                    # reference keeps V and defines the scores as X V (preprocessing/pca.py:120-131).  X V = X X^T Q W theta^-1/2
+                    # = (G Q) W theta^-1/2, and G Q is at hand from the range finder's last product: no further pass.
+                    U = engine.panel_matmul(ctx, GQ, Wt)[:n, :m].double() * inv
             finally:
                 Gm.free()
         else:
@@ -223,6 +247,78 @@ class ResidentPCA:
         self._scores_dev = (Ud * s).float().contiguous()   # X V on the device: the analysis matrix of the cross models
         self.singular_values_all = np.sqrt(lam_h)
         self.total_variance = total_variance
+
+    def _basis_without_spectrum(self, M, Mfull, ell, n_pre, n, total_variance):
+        """The randomized route when only the kept SUBSPACE matters and every computed mode is kept (`basis_only`, variance
+        target out of reach): the reference keeps the leading n_pre of the ell = n_pre + n_oversamples Ritz directions of
+        M = B^T B (linalg/_numpy/_svd.py:215-241 after sklearn's truncation) -- i.e. it drops the span of the n_oversamples
+        SMALLEST ones.  Those few are found without the order-ell eigen-decomposition: the blocked device Cholesky factor of M
+        (engine.panel_rinv, 4.7 ms at 1510) gives M^-1 = R^-1 R^-T, a 32-column inverse subspace iteration converges on the bottom
+        of the spectrum, and the kept subspace is the orthogonal complement of B w_bottom inside span(B):
+        B R^-1 N with N an orthonormal basis of the complement of R w_bottom (a 10-column Householder QR).  No individual
+        mode is formed; `s` / `singular_values_all` are then not the spectrum (spectrum_known = False).
+        -> (ell x n_pre float64 device matrix Wm with (B Wm)^T (B Wm) = I, host array of per-mode variances as far as known)
+        or None when the Cholesky factor is not usable (dependent columns): the caller takes the eigen-decomposition."""
+        torch = engine._torch()
+        ctx = self.ctx
+        dev = M.device
+        nb = ell - n_pre
+        import os, time
+        trace = bool(os.environ.get("EOFX_PCA_TRACE"))
+        def tick(label, t0=[None]):
+            if trace:
+                torch.cuda.synchronize()
+                now = time.perf_counter()
+                if t0[0] is not None:
+                    print(f"[pca fast path] {label}: {1e3 * (now - t0[0]):.2f} ms")
+                t0[0] = now
+        tick("start")
+        Ri = engine.panel_rinv(ctx, Mfull.contiguous(), ell)[:ell, :ell]      # upper triangular, M^-1 = Ri Ri^T
+        tick("panel_rinv")
+        d = Ri.diagonal()
+        if not bool(torch.isfinite(Ri).all()) or bool((d <= 0).any()):
+            return None
+        if nb == 0:
+            Wm, lam_bottom = Ri, np.zeros(0)
+        else:
+            blk = min(ell, nb + 22)
+            gen = torch.Generator(device=dev)
+            gen.manual_seed(0x5EED)
+            Y = torch.randn((ell, blk), generator=gen, device=dev, dtype=torch.float64)
+            RiT = Ri.T.contiguous()
+
+            def cholqr(Z):      # (two small library calls; torch.linalg.qr of a 1510 x 32 panel costs milliseconds)
+                Lc = torch.linalg.cholesky(Z.T @ Z)
+                return torch.linalg.solve_triangular(Lc, Z.T, upper=False).T
+
+            # (the bottom of the sketch's spectrum decays smoothly: the iteration is stopped after 20 steps whether or not the Ritz
+            # values stand still -- the dropped subspace then differs from the exact bottom one by directions whose variance is
+            # within a fraction of a per cent of it, far inside what the reference's unseeded sketch varies by from run to run)
+            prev = None
+            for outer in range(4):
+                for _ in range(5):                                            # five inverse steps between orthonormalisations
+                    Y = Ri @ (RiT @ Y)
+                    Y = Y / Y.norm(dim=0, keepdim=True)
+                Y = cholqr(cholqr(Y))
+                T = (Y.T @ (M @ Y)).cpu().numpy()                             # 32 x 32: the host solves it
+                tv_h, Ws_h = np.linalg.eigh(0.5 * (T + T.T))                  # ascending: the bottom of the spectrum first
+                cur = tv_h[:nb]
+                if prev is not None and np.all(np.abs(cur - prev) <= 1e-3 * np.abs(cur)):
+                    break
+                prev = cur
+            tick(f"inverse subspace iteration ({outer + 1} x 5 steps)")
+            Wb = Y @ torch.as_tensor(Ws_h[:, :nb], device=dev)
+            lam_bottom = np.maximum(tv_h[:nb], 0.0)
+            D = torch.linalg.solve_triangular(Ri, Wb, upper=True)             # R w_bottom
+            Qf, _ = torch.linalg.qr(D, mode="complete")
+            Wm = Ri @ Qf[:, nb:]
+            tick("complement basis (QR complete + product)")
+        kept = float(M.diagonal().sum()) - float(lam_bottom.sum())
+        warnings.warn(f"Dataset has {n_pre} components, explaining {kept / (n - 1) / total_variance:.2%} of the variance. However, "
+                      f"{self.n_modes:.2%} explained variance was requested. Please consider increasing "
+                      "`init_rank_reduction`.")
+        lam_h = np.full(n_pre, kept / max(n_pre, 1))       # (not the spectrum: its sum is right, the modes are not separated)
+        return Wm, lam_h
 
     def _truncate(self, lam_h, n_pre, n, total_variance):
         """number of modes kept (linalg/_numpy/_svd.py:215-241): the first n_pre eigenvalue estimates against the target"""
