@@ -1,6 +1,7 @@
 // eofx_abi.hip -- C ABI (include/eofx.h) of the MI355X-native EOF / randomized-SVD engine:
 // launch logic, the randomized-SVD drivers and the small host-side linear algebra.
 // Kernels live in eofx_kernels.hpp.  gfx950 only.
+#include <chrono>
 #include "eofx_hfft.hpp"
 #include "eofx_kernels.hpp"
 #include "eofx_fit.hpp"
@@ -4604,7 +4605,11 @@ extern "C" int eofx_rsvd_c64(eofx_ctx* ctx, const eofx_mat* A, const eofx_mat* B
     wv.assign(l, 0.0);
     Xr.assign((size_t)m * l, 0.0);
     Xi.assign((size_t)m * l, 0.0);
-    if (hosteig::zheigh_top(Hr.data(), Hi.data(), m, l, wv.data(), Xr.data(), Xi.data()) != 0) {
+    const auto t_rr0 = std::chrono::steady_clock::now();
+    const int rc_rr = hosteig::zheigh_top(Hr.data(), Hi.data(), m, l, wv.data(), Xr.data(), Xi.data());
+    if (trace) fprintf(stderr, "[eofx_rsvd_c64] host Rayleigh-Ritz solve, order %d: %.2f ms\n", m,
+                       1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_rr0).count());
+    if (rc_rr != 0) {
       // general-purpose route (real symmetric embedding): slower, no assumptions
       std::vector<zdouble> Hz((size_t)m * m), Vz;
       for (size_t e = 0; e < Hz.size(); ++e) Hz[e] = zdouble(Hr[e], Hi[e]);
