@@ -714,7 +714,7 @@ def test_masked_in_place_layout(ctx, opts):
 
 
 def test_documented_size_limits_fail_loudly(ctx):
-    """The limits DESIGN.md §13 lists raise instead of degrading silently."""
+    """The limits DESIGN.md §10 lists raise instead of degrading silently."""
     import torch
     from xeofs_amd import engine, rotation
     from xeofs_amd.complex_svd import complex_rsvd
