@@ -50,7 +50,7 @@ template <int L, int MODE> static void launch(const float* Xt, int64_t n_pad, in
   const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(163840 / PL::lds, 2048 / PL::WG));
   const int64_t groups = MODE ? p : (p + 1) / 2;
   const int grid = (int)std::min<int64_t>(groups, (int64_t)cus * per_cu);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(PL::WG), PL::lds, 0, Xt, n_pad, n, p, padding, hperm, u, Bt, At, bmax, amax);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(PL::WG), PL::lds, 0, Xt, n_pad, n, p, padding, hperm, u, Bt, At, bmax, amax, (const float*)nullptr, (int64_t)0, (const float*)nullptr);
 }
 
 int main(int argc, char** argv) {

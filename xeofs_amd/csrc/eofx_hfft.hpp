@@ -648,19 +648,28 @@ __global__ __launch_bounds__(plan<L>::WG, HFFT_WAVES) void hilbert_fft_kernel(co
       // 16-byte table loads in flight (one load at a time is an exposed L2 round trip per sample group).
       float va[8], vb[8];
       double ua = 0.0, ub = 0.0;
+      if constexpr (MODE == 0) {
+        // (round 5: the kernel is bound by instruction issue, DESIGN.md section 6 -- the pair (feature a, feature b) of a sample
+        // is one packed float2 from here on: a float32 partial sum of the thread's 8 samples per feature, then float64 across threads)
+        cf acc2 = cf{0.f, 0.f};
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const unsigned o = tb4 + (unsigned)(c * NT * 4);
-        float xa = e[c].x, xb = e[c].y;
-        if constexpr (MODE == 1) {      // samples 2 j, 2 j + 1: byte offsets 2 o, 2 o + 4
+        for (int c = 0; c < 8; ++c) {
+          const unsigned o = tb4 + (unsigned)(c * NT * 4);
+          e[c] = (o < nb) ? e[c] : cf{0.f, 0.f};
+          acc2 += e[c];
+        }
+        ua = (double)acc2.x;
+        ub = (double)acc2.y;
+      } else {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const unsigned o = tb4 + (unsigned)(c * NT * 4);
+          float xa = e[c].x, xb = e[c].y;    // samples 2 j, 2 j + 1: byte offsets 2 o, 2 o + 4
           xa = (2u * o < nb) ? xa : 0.f;
           xb = (2u * o + 4u < nb) ? xb : 0.f;
-        } else {
-          xa = (o < nb) ? xa : 0.f;
-          xb = (o < nb) ? xb : 0.f;
+          ua += (double)xa; ub += (double)xb;
+          va[c] = xa; vb[c] = xb;
         }
-        ua += (double)xa; ub += (double)xb;
-        va[c] = xa; vb[c] = xb;
       }
       if constexpr (NW > 1) {
         const double k = reduce2(ua, ub, lane);
@@ -713,10 +722,14 @@ __global__ __launch_bounds__(plan<L>::WG, HFFT_WAVES) void hilbert_fft_kernel(co
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, cf{xa, xb}), wa_, 2u * o, 0, 2);
             run_mx = max(run_mx, max(absbits(xa), absbits(xb)));
           } else {
-            float xa = va[c] + (a1a * ue[q].x + a2a * ue[q].y + a3a * ue[q].z + a4a * ue[q].w) - m0;
-            float xb = vb[c] + (a1b * ue[q].x + a2b * ue[q].y + a3b * ue[q].z + a4b * ue[q].w) - m1;
-            xa = (o < nb && !za) ? xa : 0.f;
-            xb = (o < nb && !zb) ? xb : 0.f;
+            // both features of the pair at once: x = (e - mean) + a1 u1 + a2 u2 + a3 u3 + a4 u4 (packed float2 arithmetic)
+            cf x = e[c] - cf{m0, m1};
+            x = __builtin_elementwise_fma(cf{a1a, a1b}, cf{ue[q].x, ue[q].x}, x);
+            x = __builtin_elementwise_fma(cf{a2a, a2b}, cf{ue[q].y, ue[q].y}, x);
+            x = __builtin_elementwise_fma(cf{a3a, a3b}, cf{ue[q].z, ue[q].z}, x);
+            x = __builtin_elementwise_fma(cf{a4a, a4b}, cf{ue[q].w, ue[q].w}, x);
+            const float xa = (o < nb && !za) ? x.x : 0.f;
+            const float xb = (o < nb && !zb) ? x.y : 0.f;
             st_nt(xa, wa_, o);
             st_nt(xb, wb_, o);
             run_mx = max(run_mx, max(absbits(xa), absbits(xb)));   // (idle rows carry zeros)
