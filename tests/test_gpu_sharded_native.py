@@ -93,3 +93,24 @@ def test_comm_selftest(ctx):
         assert not engine.comm_selftest(ctx)
     finally:
         engine.comm_clear(ctx)
+
+
+@pytest.mark.parametrize("binding", ["rccl", "callback"])
+def test_comm_probe_reports_ranks_and_latencies(ctx, binding):
+    """eofx_ctx_comm_probe (what `bench.py --gpus N` prints as `comm.ranks_seen` before anything is timed): the rank count the
+    attached communicator really reduces over and a latency per collective of a fit -- world size 1 here, through RCCL itself
+    and through the host callback."""
+    from xeofs_amd import engine
+
+    if binding == "rccl":
+        engine.comm_init_rccl(ctx, engine.comm_unique_id(), 1, 0)
+    else:
+        engine.comm_set_callback(ctx, lambda buf, count, dtype, op, stream: 0, 1, 0)
+    try:
+        seen, us = engine.comm_probe(ctx, [(10240 * 64, "f32"), (64 * 64, "f64"), (1, "i32")], reps=5)
+    finally:
+        engine.comm_clear(ctx)
+    assert seen == 1.0
+    assert len(us) == 3 and all(u >= 0.0 and np.isfinite(u) for u in us)
+    with pytest.raises(Exception):
+        engine.comm_probe(ctx, [(1, "f32")])          # no communicator attached any more
