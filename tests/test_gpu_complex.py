@@ -467,7 +467,7 @@ def test_complex_rsvd_default_rule_vs_reference_solver_and_exact(ctx, n, p, k, n
 def test_complex_rsvd_flat_bulk_vs_reference_solver_and_exact(ctx, n, p, k, monkeypatch):
     """Row R9 at its hardest: all but four of the k wanted modes are noise modes at the edge of a flat bulk.  The reference's
     lobpcg spends its full 20 iterations there; the engine's "converge" rule (block Lanczos with thick restarts until the
-    residual of every wanted Ritz pair is below 3e-5 of its value, at most 20 products) must be as accurate per mode:
+    residual of every wanted Ritz pair is below 1e-5 of its value, at most 20 products) must be as accurate per mode:
     |s - s_exact| / s_exact <= max(1e-5, the reference solver's error).  The default rule (7 products) is an order of
     magnitude or more ahead of the subspace iteration it replaced at the same number of passes."""
     X = _bulk_field(n, p, seed=n + k)

@@ -58,7 +58,8 @@ for case in range(ncase):
         # deficient -- n / 2 + 1 non-negative frequencies --, and the Gram-based finish returns such values with an ABSOLUTE error of
         # sqrt(eps_f32) s_1 = 3e-4 s_1, as the reference's own float32 Gram route would)
         e_eng = np.abs(s - se) / np.maximum(se, 3e-3 * se[0])
-        le = bool(np.all(e_eng <= np.maximum(1e-5, e_ref) + 1e-6))
+        # (+ 2e-7 s_1 absolute: the float32 class of the arithmetic -- a mode 200x below the leading one cannot be relatively better than 4e-5)
+        le = bool(np.all(np.abs(s - se) <= (np.maximum(1e-5, e_ref) + 1e-6) * np.maximum(se, 3e-3 * se[0]) + 2e-7 * se[0]))
         n_le += le
         worst_eng, worst_ref = max(worst_eng, float(e_eng.max())), max(worst_ref, float(e_ref.max()))
         ratios.append(float(np.max(e_eng / np.maximum(1e-5, e_ref))))
@@ -71,7 +72,8 @@ for case in range(ncase):
         rec = (U.astype(np.complex128) * s) @ V.astype(np.complex128).conj().T
         Ue, sf, Vhe = np.linalg.svd(Z, full_matrices=False)
         best = (Ue[:, :k] * sf[:k]) @ Vhe[:k]
-        ok &= np.linalg.norm(Z - rec) <= np.linalg.norm(Z - best) * (1 + (1e-4 if clear.all() else 5e-2)) + 1e-6 * np.linalg.norm(Z)
+        tiny = int((se < 3e-3 * se[0]).sum())        # numerically zero modes come back with sqrt(eps_f32) s_1 of absolute noise (Gram-based finish)
+        ok &= np.linalg.norm(Z - rec) <= np.linalg.norm(Z - best) * (1 + (1e-4 if clear.all() else 5e-2)) + 1e-6 * np.linalg.norm(Z) + 1e-3 * se[0] * np.sqrt(tiny)
         ok &= bool(lean) and (kept == (k + 10 <= 32))
         if bulk_mode:
             ok &= le

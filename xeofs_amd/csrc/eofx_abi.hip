@@ -4687,9 +4687,9 @@ extern "C" int eofx_rsvd_c64(eofx_ctx* ctx, const eofx_mat* A, const eofx_mat* B
     std::swap(Zs, Vs);
     CHK(copy_block(Kw, Zs, 0));
     nb = 1;
-    // "converge": relative residual |M x - theta x| / theta of every wanted Ritz pair <= 3e-5 (the value is then good to
+    // "converge": relative residual |M x - theta x| / theta of every wanted Ritz pair <= 1e-5 (the value is then good to
     // ~1e-9 / relative gap), checked from scikit-learn's count on after every second product
-    const double res_tol = 3e-5;
+    const double res_tol = 1e-5;
     while (ctx->last_iters < n_iter && !exhausted) {
       if (nb == nbmax) CHK(compress());
       CHK(lanczos_step());
