@@ -17,14 +17,15 @@ One JSON line on rank 0; see the task contract for the fields.  Extra objects:
   roofline      the streaming kernels (atb_f16_kernel / atb_f16_fit_kernel for X^T Z, axb_f16_dma_kernel for X Y):
                 algorithmic bytes per launch (n p_local 4 B) / mean launch duration from HIP events on the launch stream.
   cpu_baseline  the oracle's sklearn-restated randomized_svd (oracle/, "port") timed on the host cores on a
-                bounded sample (the workload's n and k on half of its grid, fp32); "f64": the same kernel in
+                bounded sample (the workload itself where the host holds it, else its n and k on half of its grid, fp32); "f64": the same kernel in
                 float64 and the whole oracle fit on the config-2 shape (what xeofs itself computes in).
   parity        size-independent checks at full size + singular values of the samples vs the CPU runs;
                 the float64 comparisons are a gate: above 1e-5 the run exits non-zero.
   configs       every other BASELINE.json config on one GPU (after the timed region, like the CPU leg): config 1 at
                 model level, config 2, config 3 (MCA with the total squared covariance), config 5 (Hilbert + complex
-                rSVD), and the reference's own published workload (docs/perf/xeofs_timings.py:18-57), whose ratio to
-                the published 39.5 s is `vs_baseline`.
+                rSVD), and the reference's own published workload (docs/perf/xeofs_timings.py:18-57) with its ratio to
+                the published 39.5 s (`configs.published.speedup`; `vs_baseline` is null: no published number
+                exists for the headline metric itself).
   comm          (N > 1) the collectives of one fit: count, bytes, milliseconds between events around them.
 """
 
@@ -1008,12 +1009,13 @@ def main():
                 configs["f64_mode"] = f64_mode
 
     if rank == 0:
+        # BASELINE.md holds no published number for THIS metric (GB/s at n_modes=50 on the 1M grid; `published` is {}): null.
+        # The one workload the reference does publish a time for is measured as `configs.published` (its own `speedup` field).
         vs_baseline, vs_note = None, None
         if configs and "published" in configs:
-            vs_baseline = configs["published"]["speedup"]
-            vs_note = ("reference seconds / ours on the ONE workload the reference publishes a number for (configs.published: "
-                       "EOF(n_modes=2) on 10000 x 100000 fp32, whole fit from host memory, 39.5 s on a laptop, BASELINE.md row 1); "
-                       "no published number exists for the headline metric (GB/s at n_modes=50 on the 1M grid)")
+            vs_note = ("null: no published number exists for the headline metric; the reference's one published grid point "
+                       "(EOF(n_modes=2) on 10000 x 100000 fp32 from host memory, 39.5 s on a laptop, BASELINE.md row 1) is measured as "
+                       f"configs.published: {configs['published']['speedup']}x")
         line = {
             "metric": "EOF randomized-SVD GB/s (algorithmic: 16 passes x n x p x 4 B per fit / fit time)",
             "value": round(alg_bytes / (ms_step * 1e-3) / 1e9, 2), "unit": "GB/s",
