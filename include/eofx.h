@@ -407,6 +407,21 @@ int eofx_vec_dot_f64(eofx_ctx *ctx, const float *a, const float *b, int64_t coun
 int eofx_rsvd_c64(eofx_ctx *ctx, const eofx_mat *A, const eofx_mat *B, int k, int n_oversamples, int n_iter,
                   const float *omega, int flip_signs, float *U, float *s, float *V);
 
+/* The same decomposition for the ANALYTIC SIGNAL of a resident real matrix -- Z = A + i H(A), H the Hilbert stage of
+ * eofx_hilbert_f32 (padding / decay_factor as there; reference single/eof.py:433-447 -> utils/hilbert_transform.py:10-44
+ * -> decomposer.py:149-160) -- without writing the imaginary part.  The stage is linear along the samples, Im = Hc A
+ * with one n x n matrix Hc per (n, padding, decay) (built in float64 on the host, resident in both layouts, cached on
+ * the context), so Z^H W = A^T (W - i Hc^T W) and Z Y = (I + i Hc)(A Y): every product streams the REAL field once
+ * and applies Hc to the sample-side panel -- half the bytes per pass of the two-part form, no second resident field.
+ * Arguments, rules, outputs and errors as eofx_rsvd_c64 on (A, eofx_hilbert_f32(A)); n <= 16384 (EOFX_ERR_ARG beyond:
+ * use the two calls).  A may be an in-place or masked in-place matrix.                                             */
+int eofx_rsvd_hilbert_c64(eofx_ctx *ctx, const eofx_mat *A, int padding, double decay_factor, int k, int n_oversamples,
+                          int n_iter, const float *omega, int flip_signs, float *U, float *s, float *V);
+/* sum of squares of the imaginary part eofx_hilbert_f32 would write for `a` (total variance of the analytic signal =
+ * (eofx_mat_sumsq_f64(a) + this) / (n - 1); reference single/eof.py:93 on the complex field), computed by the same
+ * kernel with its stores switched off; consumes the transposed raw layout of eofx_ctx_set_sample_raw like the stage. */
+int eofx_hilbert_sumsq_f64(eofx_ctx *ctx, const eofx_mat *a, int padding, double decay_factor, double *out);
+
 /* One pass of the complex operator Z = A + iB on a [Re | Im] panel of L = 64 or 128 real columns (device pointers):
  *   conj_left = 1: out [p_pad x L] = Z^H W, W [n_pad x L];   conj_left = 0: out [n_pad x L] = Z Y, Y [p_pad x L].
  * One launch of the streaming kernel over both parts in the default precision (the step a feature-sharded driver

@@ -93,6 +93,14 @@ struct eofx_ctx {
     float* u = nullptr;    // device float[4 n]: [4][n] (hipFFT route) or [n][4] (one-kernel route)
   };
   std::vector<HilbertSetup> hsetups;
+  // cached operators of the Hilbert stage as resident n x n matrices (eofx_rsvd_hilbert_c64): Im = Hc y along the samples
+  struct HilbertOp {
+    int64_t n = 0;
+    int padding = 0;
+    double decay = 0.0;
+    eofx_mat* m = nullptr;
+  };
+  std::vector<HilbertOp> hops;
   // cached hipFFT plans of the Hilbert stage: key = (P, batch) -> (R2C plan, C2R plan)
   std::vector<std::pair<std::pair<int64_t, int64_t>, std::pair<void*, void*>>> fft_plans;
   // layout policy of the next preprocess / apply (eofx_ctx_set_layout): 0 = write both layouts, 1 = keep a reference to
@@ -144,6 +152,7 @@ struct eofx_ctx {
   EofxComm* comm = nullptr;   // feature-sharded entry points (eofx_fit_sharded_f32)
 };
 constexpr int EOFX_AMAX_SLOTS = 1024;
+constexpr int EOFX_HILBERT_OP_MAX_N = 16384;   // resident n x n Hilbert operator (two layouts): 2 GB at the limit
 constexpr size_t EOFX_PINNED_DOUBLES = 2 * 256 * 256 + 64;
 
 struct eofx_mat {
@@ -290,6 +299,8 @@ extern "C" int eofx_ctx_destroy(eofx_ctx* ctx) {
     if (g->tiles) (void)hipFree(g->tiles);
     delete g;
   }
+  for (auto& h : ctx->hops) (void)eofx_mat_destroy(ctx, h.m);
+  ctx->hops.clear();
   for (auto& h : ctx->hsetups) {
     if (h.chat) (void)hipFree(h.chat);
     if (h.hperm) (void)hipFree(h.hperm);
@@ -3772,6 +3783,35 @@ static int64_t hilbert_length(int64_t n, int* log2_out) {
 }
 static const int HFFT_MAX_LOG2 = 15;   // 2^14 complex points in LDS: two features up to P = 2^14, one feature (even / odd samples) at P = 2^15
 
+// The four correction vectors of the padded transform, float64 [4][n] (threaded):
+// u1 = K_pre e_rev, u2 = K_pos e, u3 = (K_pre + K_pos) 1, u4 = K_pre (t - n) + K_pos (t + n)
+// with K_pre[t][s] = kappa((n + t) - s), K_pos[t][s] = kappa((n + t) - (2n + s)), e[t] = exp(-t / n / decay)
+static void hilbert_pad_vectors(int64_t n, int64_t N, double decay, std::vector<double>& u) {
+  std::vector<double> e((size_t)n), kap((size_t)(4 * n + 1));
+  for (int64_t t = 0; t < n; ++t) e[t] = std::exp(-(double)t / (double)n / decay);
+  for (int64_t d = -2 * n; d <= 2 * n; ++d) kap[(size_t)(d + 2 * n)] = hilbert_kappa(N, d);
+  u.assign((size_t)4 * n, 0.0);
+  auto work = [&](int64_t lo, int64_t hi) {
+    for (int64_t t = lo; t < hi; ++t) {
+      double a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+      for (int64_t sidx = 0; sidx < n; ++sidx) {
+        const double kp = kap[(size_t)((n + t - sidx) + 2 * n)];
+        const double kq = kap[(size_t)((t - n - sidx) + 2 * n)];
+        a1 += kp * e[n - 1 - sidx];
+        a2 += kq * e[sidx];
+        a3 += kp + kq;
+        a4 += kp * (double)(sidx - n) + kq * (double)(sidx + n);
+      }
+      u[(size_t)t] = a1; u[(size_t)(n + t)] = a2; u[(size_t)(2 * n + t)] = a3; u[(size_t)(3 * n + t)] = a4;
+    }
+  };
+  const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(16, n / 256));
+  std::vector<std::thread> th;
+  const int64_t step = (n + nt - 1) / nt;
+  for (int t = 0; t < nt; ++t) th.emplace_back(work, t * step, std::min<int64_t>(n, (t + 1) * step));
+  for (auto& t : th) t.join();
+}
+
 // kernel spectrum and correction vectors for series length n (cached per context)
 static int get_hilbert_setup(eofx_ctx* ctx, int64_t n, int padding, double decay, int64_t P, bool fused,
                              const cfloat** chat_out, const float** hperm_out, const float** u_out) {
@@ -3827,35 +3867,15 @@ static int get_hilbert_setup(eofx_ctx* ctx, int64_t n, int padding, double decay
     (void)hipFree(cdev);
   }
   if (padding) {
-    // u1 = K_pre e_rev, u2 = K_pos e, u3 = (K_pre + K_pos) 1, u4 = K_pre (t - n) + K_pos (t + n)
-    // with K_pre[t][s] = kappa((n + t) - s), K_pos[t][s] = kappa((n + t) - (2n + s)); float64, threaded
-    std::vector<double> e((size_t)n), kap((size_t)(4 * n + 1));
-    for (int64_t t = 0; t < n; ++t) e[t] = std::exp(-(double)t / (double)n / decay);
-    for (int64_t d = -2 * n; d <= 2 * n; ++d) kap[(size_t)(d + 2 * n)] = hilbert_kappa(N, d);
+    std::vector<double> ud;
+    hilbert_pad_vectors(n, N, decay, ud);
     std::vector<float> hu((size_t)4 * n + 4, 0.f);   // (+ the four means over the samples, one-kernel route)
-    auto work = [&](int64_t lo, int64_t hi) {
-      for (int64_t t = lo; t < hi; ++t) {
-        double a1 = 0, a2 = 0, a3 = 0, a4 = 0;
-        for (int64_t sidx = 0; sidx < n; ++sidx) {
-          const double kp = kap[(size_t)((n + t - sidx) + 2 * n)];
-          const double kq = kap[(size_t)((t - n - sidx) + 2 * n)];
-          a1 += kp * e[n - 1 - sidx];
-          a2 += kq * e[sidx];
-          a3 += kp + kq;
-          a4 += kp * (double)(sidx - n) + kq * (double)(sidx + n);
-        }
-        if (fused) {   // the one-kernel route reads the four vectors interleaved per sample
-          hu[4 * t] = (float)a1; hu[4 * t + 1] = (float)a2; hu[4 * t + 2] = (float)a3; hu[4 * t + 3] = (float)a4;
-        } else {
-          hu[t] = (float)a1; hu[n + t] = (float)a2; hu[2 * n + t] = (float)a3; hu[3 * n + t] = (float)a4;
-        }
+    for (int64_t t = 0; t < n; ++t)
+      for (int k = 0; k < 4; ++k) {
+        const float v = (float)ud[(size_t)k * n + t];
+        if (fused) hu[(size_t)(4 * t + k)] = v;      // the one-kernel route reads the four vectors interleaved per sample
+        else hu[(size_t)k * n + t] = v;
       }
-    };
-    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(16, n / 256));
-    std::vector<std::thread> th;
-    const int64_t step = (n + nt - 1) / nt;
-    for (int t = 0; t < nt; ++t) th.emplace_back(work, t * step, std::min<int64_t>(n, (t + 1) * step));
-    for (auto& t : th) t.join();
     if (fused)       // means of the (float32-rounded) vectors: the kernel adds coefficient * mean to the output's mean
       for (int k = 0; k < 4; ++k) {
         double m = 0.0;
@@ -3872,11 +3892,13 @@ static int get_hilbert_setup(eofx_ctx* ctx, int64_t n, int padding, double decay
   return EOFX_OK;
 }
 
+constexpr int HILBERT_SQ_PARTIALS = 16384;
 // launch of the one-kernel route for one plan (L = log2 of the circular length)
 template <int L, int MODE>
 static hipError_t launch_hilbert_fused(eofx_ctx* ctx, const float* Xt, int64_t n_pad, int64_t n, int64_t p, int padding,
                                        const float* hperm, const float* u, float* Bt, float* At, unsigned* bmax,
-                                       unsigned* amax, const float* aff = nullptr, int64_t aff_ld = 0, const float* oscale = nullptr) {
+                                       unsigned* amax, const float* aff = nullptr, int64_t aff_ld = 0, const float* oscale = nullptr,
+                                       double* sqpart = nullptr) {
   using PL = hfft::plan<L>;
   auto kern = hfft::hilbert_fft_kernel<L, MODE>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PL::lds);
@@ -3891,8 +3913,10 @@ static hipError_t launch_hilbert_fused(eofx_ctx* ctx, const float* Xt, int64_t n
     cu_count = prop.multiProcessorCount;
   }
   const int grid = (int)std::min<int64_t>(groups, (int64_t)cu_count * per_cu);
+  // (sqpart: one float64 partial per wave, grid * NW <= CUs * 2048 / 64 of them -- HILBERT_SQ_PARTIALS bounds it)
+  if (sqpart && (int64_t)grid * PL::NW > HILBERT_SQ_PARTIALS) return hipErrorInvalidValue;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(PL::WG), PL::lds, ctx->stream, Xt, n_pad, (int)n, p, padding, hperm, u, Bt, At,
-                     bmax, amax, aff, aff_ld, oscale);
+                     bmax, amax, aff, aff_ld, oscale, sqpart);
   return hipGetLastError();
 }
 
@@ -4025,6 +4049,75 @@ done:
   }
   *out_imag = mi;
   if (out_real) *out_real = mr;
+  return EOFX_OK;
+}
+
+// Sum of squares of the imaginary part eofx_hilbert_f32 would produce for `a` (so total variance of the analytic signal =
+// (sumsq(a) + this) / (n - 1), reference single/eof.py:93 on the complex field) WITHOUT writing it: the one-kernel route with
+// zero-sized output descriptors and one float64 partial per wave, summed on the host in a fixed order.  Consumes the
+// transposed raw layout of an in-place matrix exactly as eofx_hilbert_f32 does.  Series longer than the one-kernel
+// route (or its one-feature-per-workgroup form) materialise the part, sum it and return it to the pool.
+extern "C" int eofx_hilbert_sumsq_f64(eofx_ctx* ctx, const eofx_mat* a, int padding, double decay_factor, double* out) {
+  if (!ctx || !a || !out) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  if (padding && !(decay_factor > 0.0)) return set_err(ctx, EOFX_ERR_ARG, "decay_factor must be positive");
+  CHK(set_device(ctx));
+  const int64_t n = a->n, p = a->p, n_pad = a->n_pad, p_pad = a->p_pad;
+  int L = 0;
+  const int64_t P = hilbert_length(n, &L);
+  const bool fused = L <= 14 && n_pad <= P / 2;
+  if (!fused) {
+    eofx_mat* mi = nullptr;
+    CHK(eofx_hilbert_f32(ctx, a, padding, decay_factor, &mi, nullptr));
+    const int rc = eofx_mat_sumsq_f64(ctx, mi, out);
+    eofx_mat_destroy(ctx, mi);
+    return rc;
+  }
+  const cfloat* chat = nullptr;
+  const float *hperm = nullptr, *u = nullptr;
+  CHK(get_hilbert_setup(ctx, n, padding ? 1 : 0, decay_factor, P, true, &chat, &hperm, &u));
+  const bool lean = a->raw && a->aff && !a->X;
+  const bool from_rawT = lean && a->rawT && !a->Xt;
+  const bool xt_transient = lean && !a->Xt && !from_rawT;
+  if (!from_rawT) CHK(ensure_Xt(ctx, a));
+  int rc = EOFX_OK;
+  double* sq = nullptr;
+  unsigned* bmax = nullptr;
+  std::vector<double> hsq((size_t)HILBERT_SQ_PARTIALS);
+  const size_t sq_bytes = sizeof(double) * HILBERT_SQ_PARTIALS + 256;
+  if (pool_malloc(ctx, (void**)&sq, sq_bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    rc = set_err(ctx, EOFX_ERR_NOMEM, "cannot allocate the partial sums");
+  }
+  if (rc == EOFX_OK) {
+    bmax = reinterpret_cast<unsigned*>(sq + HILBERT_SQ_PARTIALS);
+    hipError_t e = hipMemsetAsync(sq, 0, sq_bytes, ctx->stream);
+    if (e == hipSuccess) switch (L) {
+#define EOFX_HF(LL) \
+  case LL: e = launch_hilbert_fused<LL, 0>(ctx, from_rawT ? a->rawT : a->Xt, n_pad, n, p, padding ? 1 : 0, hperm, u, nullptr, nullptr, bmax, nullptr, \
+                                           from_rawT ? a->aff : nullptr, a->p_pad, a->masked ? a->aff + 2 * a->p_pad : nullptr, sq); break;
+      EOFX_HF(10) EOFX_HF(11) EOFX_HF(12) EOFX_HF(13) EOFX_HF(14)
+#undef EOFX_HF
+      default: e = hipErrorInvalidValue;
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(hsq.data(), sq, sizeof(double) * HILBERT_SQ_PARTIALS, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) rc = set_err(ctx, EOFX_ERR_HIP, "hilbert stage failed: %s", hipGetErrorString(e));
+  }
+  pool_give(ctx, sq, sq_bytes);
+  if (a->rawT) {                 // consumed (or not usable by this call): back to the pool either way
+    eofx_mat* am = const_cast<eofx_mat*>(a);
+    pool_give(ctx, am->rawT, (size_t)n_pad * p_pad * sizeof(float));
+    am->rawT = nullptr;
+  }
+  if (xt_transient && a->Xt) {
+    eofx_mat* am = const_cast<eofx_mat*>(a);
+    pool_give(ctx, am->Xt, (size_t)n_pad * p_pad * sizeof(float));
+    am->Xt = nullptr;
+  }
+  if (rc != EOFX_OK) return rc;
+  double t = 0.0;
+  for (double v : hsq) t += v;
+  *out = t;
   return EOFX_OK;
 }
 
@@ -4187,6 +4280,77 @@ static void embed_right(const std::vector<zdouble>& M, int l, int mcols, int LP,
 }
 }  // namespace
 
+// The Hilbert stage as ONE linear map along the samples: for a series y [n] (padding "exp": linear fit, exponential pads,
+// transform of the 3n-long series, middle third -- reference utils/hilbert_transform.py:47-92; no padding: the circular
+// transform of the series itself), minus the mean over the samples,
+//   Im = Hc y,   Hc = C (T + u1 (e_0 - a0)^T + u2 (e_{n-1} - a0 - (n-1) a1)^T + u3 a0^T + u4 a1^T),   C = I - 1 1^T / n
+// with T[t][s] = kappa(N, t - s), a0^T y = c0 and a1^T y = c1 the coefficients of the linear fit, and u1..u4 the
+// correction vectors of get_hilbert_setup.  Built in float64 on the host, held as a resident n x n matrix (both layouts)
+// per (n, padding, decay): eofx_rsvd_hilbert_c64 applies it to the SAMPLE-side panels instead of materialising Im.
+static int get_hilbert_operator(eofx_ctx* ctx, int64_t n, int padding, double decay, const eofx_mat** out) {
+  for (auto& h : ctx->hops)
+    if (h.n == n && h.padding == padding && (!padding || h.decay == decay)) {
+      *out = h.m;
+      return EOFX_OK;
+    }
+  const int64_t N = padding ? 3 * n : n;
+  std::vector<double> kap((size_t)(2 * n + 1)), pre((size_t)(2 * n + 2), 0.0);   // kappa(N, d), d = -n .. n, and its prefix sums
+  for (int64_t d = -n; d <= n; ++d) kap[(size_t)(d + n)] = hilbert_kappa(N, d);
+  for (size_t i = 0; i < kap.size(); ++i) pre[i + 1] = pre[i] + kap[i];
+  std::vector<double> u, rowv((size_t)4 * n, 0.0), ubar(4, 0.0);
+  if (padding) {
+    hilbert_pad_vectors(n, N, decay, u);
+    const double tbar = 0.5 * (double)(n - 1), stt = (double)n * ((double)n * (double)n - 1.0) / 12.0;
+    for (int64_t sidx = 0; sidx < n; ++sidx) {
+      const double a1 = n > 1 ? ((double)sidx - tbar) / stt : 0.0, a0 = 1.0 / (double)n - tbar * a1;
+      rowv[(size_t)sidx] = (sidx == 0 ? 1.0 : 0.0) - a0;                                      // amp_pre = y[0] - c0
+      rowv[(size_t)(n + sidx)] = (sidx == n - 1 ? 1.0 : 0.0) - a0 - (double)(n - 1) * a1;    // amp_pos = y[n-1] - fit(n-1)
+      rowv[(size_t)(2 * n + sidx)] = a0;
+      rowv[(size_t)(3 * n + sidx)] = a1;
+    }
+    for (int k = 0; k < 4; ++k) {
+      double m = 0.0;
+      for (int64_t t = 0; t < n; ++t) m += u[(size_t)k * n + t];
+      ubar[k] = m / (double)n;
+    }
+  }
+  std::vector<float> hc;
+  try {
+    hc.resize((size_t)n * n);
+  } catch (const std::bad_alloc&) {
+    return set_err(ctx, EOFX_ERR_NOMEM, "cannot allocate the %lld x %lld Hilbert operator on the host", (long long)n, (long long)n);
+  }
+  auto work = [&](int64_t lo, int64_t hi) {
+    for (int64_t t = lo; t < hi; ++t) {
+      float* row = hc.data() + (size_t)t * n;
+      double ut[4] = {0, 0, 0, 0};
+      if (padding)
+        for (int k = 0; k < 4; ++k) ut[k] = u[(size_t)k * n + t] - ubar[k];
+      for (int64_t sidx = 0; sidx < n; ++sidx) {
+        // column mean of T: (1/n) sum_t kappa(t - s) = (pre[n - s + n] - pre[-s + n]) / n
+        const double cm = (pre[(size_t)(2 * n - sidx)] - pre[(size_t)(n - sidx)]) / (double)n;
+        double v = kap[(size_t)(t - sidx + n)] - cm;
+        if (padding)
+          v += ut[0] * rowv[(size_t)sidx] + ut[1] * rowv[(size_t)(n + sidx)] + ut[2] * rowv[(size_t)(2 * n + sidx)] +
+               ut[3] * rowv[(size_t)(3 * n + sidx)];
+        row[sidx] = (float)v;
+      }
+    }
+  };
+  const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(16, n / 256));
+  std::vector<std::thread> th;
+  const int64_t step = (n + nt - 1) / nt;
+  for (int t = 0; t < nt; ++t) th.emplace_back(work, t * step, std::min<int64_t>(n, (t + 1) * step));
+  for (auto& t : th) t.join();
+  eofx_mat* m = nullptr;
+  CHK(eofx_mat_from_dense_f32(ctx, hc.data(), n, n, n, &m));
+  eofx_ctx::HilbertOp h;
+  h.n = n; h.padding = padding; h.decay = decay; h.m = m;
+  ctx->hops.push_back(h);
+  *out = m;
+  return EOFX_OK;
+}
+
 struct CplxOps {
   eofx_ctx* ctx;
   const eofx_mat *A, *B;
@@ -4214,6 +4378,10 @@ struct CplxOps {
   bool lean = false;
   const float* ident = nullptr;
   int64_t ident_ld = 0;
+  // Operator mode (eofx_rsvd_hilbert_c64): B is absent and Z = (I + i Hc) A with the n x n Hilbert operator Hc resident
+  // (get_hilbert_operator).  Z^H W = A^T (W - i Hc^T W) and Z Y = (I + i Hc)(A Y): ONE real pass over the field per
+  // product plus an n x n x LP product on the sample side -- the imaginary part is never written or read.
+  const eofx_mat* Hop = nullptr;
   static bool axb_fits(int64_t ld, int64_t cols, int L) {   // the 32-bit offsets of axb_f16 (launch_axb checks them too)
     const int64_t K = round_up(cols, AXB_KG);
     return K * (int64_t)L < ((int64_t)1 << 30) && 64 * ld + K < ((int64_t)1 << 30);   // BYTE offsets in 32 bits
@@ -4242,6 +4410,12 @@ struct CplxOps {
   // feature-side panel = Z^H W
   int zh_mul(const float* Wn, float* Yp, int prec) {
     const int64_t K = round_up(A->n, ATB_KG), M = A->p_pad;
+    if (Hop) {
+      CHK(launch_atb(ctx, Hop->X, Hop->p_pad, K, Hop->p_pad, Wn, LP, LP, tmp, prec, Hop->absmax));   // Hc^T [Wr | Wi]
+      amax_forget(ctx, rot);
+      CHK(combine(Wn, tmp, 1.f, A->n_pad, rot));                                                      // W - i Hc^T W
+      return t_part(A, rot, Yp, prec);
+    }
     if (lean) {
       CHK(t_part(A, Wn, Yp, prec));
       CHK(t_part(B, Wn, tmp, prec));
@@ -4259,6 +4433,12 @@ struct CplxOps {
   // sample-side panel = Z Y
   int z_mul(const float* Yp, float* Wn, int prec) {
     const int64_t K = round_up(A->p, ATB_KG), M = A->n_pad;
+    if (Hop) {
+      CHK(n_part(A, Yp, tmp, prec));                                                                  // T = A [Yr | Yi]
+      CHK(launch_atb(ctx, Hop->Xt, Hop->n_pad, round_up(A->n, ATB_KG), Hop->n_pad, tmp, LP, LP, rot, prec, Hop->absmax));   // Hc T
+      amax_forget(ctx, Wn);
+      return combine(tmp, rot, -1.f, A->n_pad, Wn);                                                   // T + i Hc T
+    }
     if (lean) {
       CHK(n_part(A, Yp, Wn, prec));
       CHK(n_part(B, Yp, tmp, prec));
@@ -4348,11 +4528,12 @@ extern "C" int eofx_cmat_mul_f32(eofx_ctx* ctx, const eofx_mat* A, const eofx_ma
 //        values move by <= 1e-6 (relative, squared values) or 20 products have been made (lobpcg's own limit under svds).
 // Sketches whose Krylov space would exceed order 384 (k + n_oversamples > 48 at q = 7) keep the subspace iteration of rounds 1-4
 // (EOFX_C64_KRYLOV=0 forces it, for comparisons).
-extern "C" int eofx_rsvd_c64(eofx_ctx* ctx, const eofx_mat* A, const eofx_mat* B, int k, int n_oversamples, int n_iter,
-                             const float* omega, int flip_signs, float* U, float* s, float* V) {
-  if (!ctx || !A || !B || !omega || !s || k <= 0 || n_oversamples < 0)
+// B != nullptr: Z = A + i B (both resident).  B == nullptr: Z = (I + i Hc) A with the resident Hilbert operator Hop.
+static int rsvd_c64_impl(eofx_ctx* ctx, const eofx_mat* A, const eofx_mat* B, const eofx_mat* Hop, int k, int n_oversamples,
+                         int n_iter, const float* omega, int flip_signs, float* U, float* s, float* V) {
+  if (!ctx || !A || (!B && !Hop) || !omega || !s || k <= 0 || n_oversamples < 0)
     return set_err(ctx, EOFX_ERR_ARG, "bad argument");
-  if (A->n != B->n || A->p != B->p) return set_err(ctx, EOFX_ERR_SHAPE, "real and imaginary parts must have the same shape");
+  if (B && (A->n != B->n || A->p != B->p)) return set_err(ctx, EOFX_ERR_SHAPE, "real and imaginary parts must have the same shape");
   CHK(set_device(ctx));
   const int64_t n = A->n, p = A->p, r = std::min(n, A->masked ? A->p_valid : p);
   if (k > r) return set_err(ctx, EOFX_ERR_RANK, "n_modes must be less than or equal to the rank of the dataset (rank = %lld).", (long long)r);
@@ -4367,8 +4548,8 @@ extern "C" int eofx_rsvd_c64(eofx_ctx* ctx, const eofx_mat* A, const eofx_mat* B
   if (n_iter < 0) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
   const int h = l <= 32 ? 32 : 64, LP = 2 * h;
   const int ko = (int)round_up(k, 16), Lo = 2 * ko;       // output panels [Re(ko) | Im(ko)]
-  const bool lean = cplx_lean(A, B, LP, ctx->prec_power, ctx->prec_final);
-  if (!lean) {
+  const bool lean = B && cplx_lean(A, B, LP, ctx->prec_power, ctx->prec_final);
+  if (B && !lean) {
     CHK(ensure_X(ctx, A));   // (ensure_X builds the sample-contiguous layout first where that is missing too)
     CHK(ensure_X(ctx, B));
   }
@@ -4415,7 +4596,8 @@ extern "C" int eofx_rsvd_c64(eofx_ctx* ctx, const eofx_mat* A, const eofx_mat* B
     Cf = arena_alloc<double>(ctx, (size_t)nbmax * nbmax * LP * LP);
     if (!Kw || !Ww || !Pt || !Vs || !Cd || !Ecd || !Eall || !Cf) return set_err(ctx, EOFX_ERR_NOMEM, "arena exhausted (block Krylov panels)");
   }
-  CplxOps ops{ctx, A, B, LP, rot, tmp, std::max(A->absmax, B->absmax)};
+  CplxOps ops{ctx, A, B, LP, rot, tmp, B ? std::max(A->absmax, B->absmax) : A->absmax};
+  ops.Hop = B ? nullptr : Hop;
   if (lean) CHK(cplx_lean_setup(ctx, ops));
   const int pp = ctx->prec_power, pf = ctx->prec_final;
   auto fwd = [&](const float* in, float* out, int prec) { return transposed ? ops.zh_mul(in, out, prec) : ops.z_mul(in, out, prec); };
@@ -4832,6 +5014,31 @@ extern "C" int eofx_rsvd_c64(eofx_ctx* ctx, const eofx_mat* A, const eofx_mat* B
   if (is_device_ptr(s)) HIPCHK(hipMemcpy(s, hs.data(), sizeof(float) * k, hipMemcpyHostToDevice));
   else std::memcpy(s, hs.data(), sizeof(float) * k);
   return EOFX_OK;
+}
+
+extern "C" int eofx_rsvd_c64(eofx_ctx* ctx, const eofx_mat* A, const eofx_mat* B, int k, int n_oversamples, int n_iter,
+                             const float* omega, int flip_signs, float* U, float* s, float* V) {
+  if (!B) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  return rsvd_c64_impl(ctx, A, B, nullptr, k, n_oversamples, n_iter, omega, flip_signs, U, s, V);
+}
+
+// The decomposition of the ANALYTIC SIGNAL of a resident real matrix without writing its imaginary part:
+// Z = A + i H(A) = (I + i Hc) A with Hc the n x n operator of the Hilbert stage along the samples (padding, decay as in
+// eofx_hilbert_f32; get_hilbert_operator).  Same arguments, rules and outputs as eofx_rsvd_c64 on (A, eofx_hilbert_f32(A));
+// every product streams the real field once and applies Hc on the sample side (CplxOps operator mode), so a pass moves
+// half the bytes of the two-part form and the field needs no second resident copy.
+extern "C" int eofx_rsvd_hilbert_c64(eofx_ctx* ctx, const eofx_mat* A, int padding, double decay_factor, int k,
+                                     int n_oversamples, int n_iter, const float* omega, int flip_signs, float* U, float* s,
+                                     float* V) {
+  if (!ctx || !A) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  if (padding && !(decay_factor > 0.0)) return set_err(ctx, EOFX_ERR_ARG, "decay_factor must be positive");
+  if (A->n > EOFX_HILBERT_OP_MAX_N)
+    return set_err(ctx, EOFX_ERR_ARG, "the resident Hilbert operator is limited to %d samples (got %lld): use eofx_hilbert_f32 + eofx_rsvd_c64",
+                   EOFX_HILBERT_OP_MAX_N, (long long)A->n);
+  CHK(set_device(ctx));
+  const eofx_mat* Hop = nullptr;
+  CHK(get_hilbert_operator(ctx, A->n, padding ? 1 : 0, decay_factor, &Hop));
+  return rsvd_c64_impl(ctx, A, nullptr, Hop, k, n_oversamples, n_iter, omega, flip_signs, U, s, V);
 }
 
 // sum of squares of the resident matrix in float64 (fixed tree); for zero-mean columns

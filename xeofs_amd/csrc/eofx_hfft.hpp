@@ -411,7 +411,8 @@ __global__ __launch_bounds__(plan<L>::WG, HFFT_WAVES) void hilbert_fft_kernel(co
                                                                               unsigned* __restrict__ amax,
                                                                               const float* __restrict__ aff = nullptr,
                                                                               int64_t aff_ld = 0,
-                                                                              const float* __restrict__ oscale = nullptr) {
+                                                                              const float* __restrict__ oscale = nullptr,
+                                                                              double* __restrict__ sqpart = nullptr) {
   using PL = plan<L>;
   constexpr int P = PL::P, NT = PL::NT, RL = PL::RL, NW = PL::NW, NIN = PL::NIN, SA = PL::SA, SB = PL::SB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -443,6 +444,9 @@ __global__ __launch_bounds__(plan<L>::WG, HFFT_WAVES) void hilbert_fft_kernel(co
   const unsigned nb = (unsigned)n * 4u, npb = (unsigned)n_pad * 4u;
 
   unsigned run_mx = 0u, run_my = 0u;   // running absmax of this thread's outputs (one atomic per wave at the end)
+  // sqpart (MODE 0): the sum of squares of the outputs, one float64 partial per wave in a fixed order (total variance of
+  // the imaginary part -- eofx_hilbert_sumsq_f64); with Bt == nullptr the rows are not written at all (zero-sized descriptors)
+  double run_sq = 0.0;
   float ya[8], yb[8];
   auto load_pair = [&](int64_t pr, unsigned tb4) {
     if constexpr (MODE == 1) {   // (the padded tail of a row is zero: whole 8-byte pairs up to n_pad)
@@ -691,8 +695,9 @@ __global__ __launch_bounds__(plan<L>::WG, HFFT_WAVES) void hilbert_fft_kernel(co
         m1 += a1b * b1 + a2b * b2 + a3b * b3 + a4b * b4;
       }
       const rsrc_t ru = row_rsrc(u, padding ? 4u * nb : 0u);   // [n][4]: 16 bytes per sample
-      const rsrc_t wa_ = row_rsrc(Bt + fa * n_pad, npb);
-      const rsrc_t wb_ = row_rsrc(Bt + fb * n_pad, hb ? npb : 0u);
+      const rsrc_t wa_ = row_rsrc(Bt + fa * n_pad, Bt ? npb : 0u);
+      const rsrc_t wb_ = row_rsrc(Bt + fb * n_pad, (Bt && hb) ? npb : 0u);
+      cf sq2 = cf{0.f, 0.f};
       // oscale (masked in-place input): a feature whose Scaler scale is 0 is an all-NaN grid point kept as a zero column -- its
       // output row is written as exact zeros (sharing a complex transform with a live feature leaves rounding noise in it)
       const bool za = oscale && oscale[fa] == 0.f, zb = oscale && hb && oscale[fb] == 0.f;
@@ -732,10 +737,12 @@ __global__ __launch_bounds__(plan<L>::WG, HFFT_WAVES) void hilbert_fft_kernel(co
             const float xb = (o < nb && !zb) ? x.y : 0.f;
             st_nt(xa, wa_, o);
             st_nt(xb, wb_, o);
+            if (sqpart) sq2 = __builtin_elementwise_fma(cf{xa, xb}, cf{xa, xb}, sq2);
             run_mx = max(run_mx, max(absbits(xa), absbits(xb)));   // (idle rows carry zeros)
           }
         }
       }
+      run_sq += (double)sq2.x + (double)sq2.y;
       if (At) {   // the re-centred input (only asked for when the field was not centred before): second read of y
         const float ma = coef[4], mb = coef[10];
         const rsrc_t ra = row_rsrc(Xt + fa * n_pad, nb);
@@ -767,6 +774,11 @@ __global__ __launch_bounds__(plan<L>::WG, HFFT_WAVES) void hilbert_fft_kernel(co
   if (lane == 0) {   // bit patterns of non-negative floats order like the floats
     if (run_mx) atomicMax(bmax, run_mx);
     if (At && run_my) atomicMax(amax, run_my);
+  }
+  if (sqpart) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) run_sq += __shfl_xor(run_sq, o);
+    if (lane == 0) sqpart[(size_t)blockIdx.x * NW + wave] = run_sq;
   }
 }
 

@@ -1002,15 +1002,8 @@ def sample_norms(ctx: Context, mat: ResidentMatrix) -> np.ndarray:
     return out
 
 
-def rsvd_c64(ctx: Context, A: ResidentMatrix, B: ResidentMatrix, k: int, n_oversamples: int = 10, n_iter="auto",
-             random_state=None, flip: bool = True, omega=None, device_out: bool = False):
-    """complex randomized SVD of Z = A + iB (eofx_rsvd_c64) -> (U[n,k] complex64, s[k] float32, V[p,k] complex64);
-    device_out: U and V stay on the device as torch complex64 tensors (V is 8 p k bytes: 166 MB at config 5)"""
-    k = int(k)
-    if B.masked:
-        raise NotImplementedError("complex rSVD with a masked imaginary part (only the real part may be a masked in-place matrix)")
-    if A.masked and (B.p_phys != A.p_phys or A.p < A.n):
-        raise NotImplementedError("masked in-place real part: the imaginary part must cover the same physical columns and n < p")
+def _c64_arguments(ctx: Context, A: ResidentMatrix, k: int, n_oversamples: int, n_iter, random_state, omega, device_out: bool):
+    """the start matrix, the iteration rule and the output buffers shared by the two complex decompositions"""
     r = min(A.n, A.p)
     if k > r:
         raise ValueError(f"n_modes must be less than or equal to the rank of the dataset (rank = {r}).")
@@ -1034,7 +1027,46 @@ def rsvd_c64(ctx: Context, A: ResidentMatrix, B: ResidentMatrix, k: int, n_overs
     else:
         U = _host_out((A.n, k), np.complex64)
         V = _host_out((A.p_phys, k), np.complex64)
-    s = np.empty(k, np.float32)
+    return omega, it, U, np.empty(k, np.float32), V
+
+
+def rsvd_c64(ctx: Context, A: ResidentMatrix, B: ResidentMatrix, k: int, n_oversamples: int = 10, n_iter="auto",
+             random_state=None, flip: bool = True, omega=None, device_out: bool = False):
+    """complex randomized SVD of Z = A + iB (eofx_rsvd_c64) -> (U[n,k] complex64, s[k] float32, V[p,k] complex64);
+    device_out: U and V stay on the device as torch complex64 tensors (V is 8 p k bytes: 166 MB at config 5)"""
+    k = int(k)
+    if B.masked:
+        raise NotImplementedError("complex rSVD with a masked imaginary part (only the real part may be a masked in-place matrix)")
+    if A.masked and (B.p_phys != A.p_phys or A.p < A.n):
+        raise NotImplementedError("masked in-place real part: the imaginary part must cover the same physical columns and n < p")
+    omega, it, U, s, V = _c64_arguments(ctx, A, k, n_oversamples, n_iter, random_state, omega, device_out)
     raise_for(ctx.lib.eofx_rsvd_c64(ctx.handle, A.handle, B.handle, k, int(n_oversamples), it, ptr(omega), int(flip),
                                     ptr(U), ptr(s), ptr(V)), ctx.handle)
     return U, s, A.compact_rows(V)       # (masked real part: the rows of the valid features)
+
+
+HILBERT_OPERATOR_MAX_SAMPLES = 16384      # eofx_rsvd_hilbert_c64 holds the n x n operator resident (2 GB at the limit)
+
+
+def rsvd_hilbert_c64(ctx: Context, A: ResidentMatrix, k: int, padding="exp", decay_factor: float = 0.2, n_oversamples: int = 10,
+                     n_iter="auto", random_state=None, flip: bool = True, omega=None, device_out: bool = False):
+    """complex randomized SVD of the analytic signal Z = A + i H(A) WITHOUT its imaginary part in memory
+    (eofx_rsvd_hilbert_c64): the Hilbert stage is one n x n matrix along the samples, applied to the sample-side panels,
+    and every product streams the real field once.  Same results as `rsvd_c64(ctx, A, hilbert(ctx, A)[0], ...)`
+    (reference single/eof.py:433-447 + decomposer.py:149-160)."""
+    k = int(k)
+    if A.masked and A.p < A.n:
+        raise NotImplementedError("masked in-place matrix with fewer valid features than samples")
+    omega, it, U, s, V = _c64_arguments(ctx, A, k, n_oversamples, n_iter, random_state, omega, device_out)
+    raise_for(ctx.lib.eofx_rsvd_hilbert_c64(ctx.handle, A.handle, int(padding == "exp"), float(decay_factor), k,
+                                            int(n_oversamples), it, ptr(omega), int(flip), ptr(U), ptr(s), ptr(V)), ctx.handle)
+    return U, s, A.compact_rows(V)
+
+
+def hilbert_sumsq(ctx: Context, A: ResidentMatrix, padding="exp", decay_factor: float = 0.2) -> float:
+    """sum of squares of the imaginary part `hilbert(ctx, A)` would hold, without writing it (eofx_hilbert_sumsq_f64):
+    total variance of the analytic signal = (A.sumsq() + this) / (n - 1)  (reference single/eof.py:93)"""
+    out = C.c_double()
+    raise_for(ctx.lib.eofx_hilbert_sumsq_f64(ctx.handle, A.handle, int(padding == "exp"), float(decay_factor), C.byref(out)),
+              ctx.handle)
+    return float(out.value)
