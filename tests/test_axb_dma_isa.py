@@ -139,3 +139,15 @@ def test_no_fragment_register_is_touched_between_its_read_and_its_wait(kernels):
                 if len(ops) == 2 and not s.startswith("v_mfma"):
                     assert not (regs(ops[1]) & pending), (name, s)
         assert nreads >= 24, (name, nreads)
+
+
+def test_the_split_rounds_to_nearest(kernels):
+    """Round 5: the hi / lo split of the scaled split-fp16 products must round to nearest (v_cvt_pk_f16_f32).  A truncating
+    split (v_cvt_pkrtz_f16_f32) makes every residual carry the sign of its value; the cross terms of a coherent sum then all
+    push the same way, are swamped in the long float32 accumulation chains of these kernels, and the leading singular value
+    of a field with a dominant mode comes out 2e-5 low (tools/split_precision_probe.py; the GPU half of this check is
+    tests/test_gpu_fullsize.py::test_dominant_mode_field_with_known_singular_values)."""
+    for name, (body, _) in kernels.items():
+        text = "\n".join(s for s, _a, _l in _walk(body))
+        assert "v_cvt_pkrtz" not in text, name
+        assert text.count("v_cvt_pk_f16_f32") >= 16, name

@@ -408,3 +408,51 @@ def test_hilbert_of_the_config4_field_full_size(ctx):
     assert 0.5 * A.sumsq() < ssq < 1.5 * A.sumsq()
     A.free(); B2.free()
     ctx.trim()
+
+
+def test_dominant_mode_field_with_known_singular_values(ctx):
+    """A full-size field whose singular values are known exactly: X = T W S^T with T [8000 x 60] red-noise series, geometric
+    weights W and S [1 036 800 x 60] Gaussian -- one mode dominates, every sum of the passes is coherent.  The singular values
+    of the centred field (and of its analytic signal: the Hilbert stage acts on T alone) follow from two small QR
+    factorisations in float64.  Round 5 found the leading value 2.1e-5 low here (truncating hi / lo split + the long float32
+    accumulation chains of the in-place X Y pass; eofx_kernels.hpp `cvt_pk_rn`); with the split rounding to nearest the split-fp16
+    passes reproduce all 20 values to ~1e-7, in place, for the real and for both complex routes."""
+    import torch
+
+    from xeofs_amd import engine
+
+    n, p, r, k = 8000, 720 * 1440, 60, 20
+    rng = np.random.default_rng(7)
+    T = np.empty((n, r))
+    e = rng.standard_normal((n, r))
+    T[0] = e[0]
+    for i in range(1, n):
+        T[i] = 0.8 * T[i - 1] + 0.6 * e[i]
+    T[:, :4] += np.cumsum(rng.standard_normal((n, 4)), axis=0) * 0.05          # a few drifting series
+    W = 0.93 ** np.arange(r) * 3.0
+    dev = torch.device("cuda:0")
+    Td = torch.as_tensor((T * W).astype(np.float32), device=dev)
+    Sd = torch.randn((p, r), device=dev, dtype=torch.float32, generator=torch.Generator(dev).manual_seed(3))
+    X = torch.empty((n, p), dtype=torch.float32, device=dev)
+    for c0 in range(0, p, 65536):
+        X[:, c0:c0 + 65536] = Td @ Sd[c0:c0 + 65536].T
+    # exact values from the factors as the engine sees them (float32-rounded), float64
+    T64 = Td.double().cpu().numpy()
+    Tc = T64 - T64.mean(0)
+    R2 = np.linalg.qr(Sd.double().cpu().numpy(), mode="r")
+    s_real = np.linalg.svd(np.linalg.qr(Tc, mode="r") @ R2.T, compute_uv=False)[:k]
+    ZT = orc.hilbert_transform(Tc, padding="exp", decay_factor=0.2)
+    s_cplx = np.linalg.svd(np.linalg.qr(ZT, mode="r") @ R2.T, compute_uv=False)[:k]
+    del Sd
+    A, _ = engine.preprocess(ctx, X, want_stats=False, in_place=True, for_hilbert=True)
+    _, s, _ = engine.rsvd(ctx, A, k, random_state=5, device_out=True)
+    assert np.all(np.abs(s - s_real) <= 2e-6 * s_real), (np.abs(s - s_real) / s_real).max()
+    sq = engine.hilbert_sumsq(ctx, A, "exp", 0.2)
+    sq_exact = float((np.abs(ZT.imag @ R2.T) ** 2).sum())
+    assert abs(sq - sq_exact) <= 2e-6 * sq_exact
+    _, s1, _ = engine.rsvd_hilbert_c64(ctx, A, k, "exp", 0.2, random_state=5, device_out=True)
+    assert np.all(np.abs(s1 - s_cplx) <= 2e-6 * s_cplx), (np.abs(s1 - s_cplx) / s_cplx).max()
+    B, _ = engine.hilbert(ctx, A, "exp", 0.2)
+    _, s2, _ = engine.rsvd_c64(ctx, A, B, k, random_state=5, device_out=True)
+    assert np.all(np.abs(s2 - s_cplx) <= 2e-6 * s_cplx), (np.abs(s2 - s_cplx) / s_cplx).max()
+    A.free(); B.free()

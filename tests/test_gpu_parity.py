@@ -647,7 +647,9 @@ def test_fused_fit_falls_back(ctx):
     Wd = _field(512, 2048, seed=8)
     Wd[300, 77] = 3.0e7
     mat, st, U, s, V = engine.fit(ctx, Wd, 3, random_state=1)
-    assert not st["fused"] and engine.fit_info(ctx)["reason"] == 4
+    # (4: the range check caught it; 5: the converted value also overflowed to infinity -- the split rounds to nearest since
+    #  round 5 -- which the statistics cannot tell from an infinity in the field; either way the call falls back and recovers)
+    assert not st["fused"] and engine.fit_info(ctx)["reason"] in (4, 5)
     ref = orc.eof_fit(Wd.astype(np.float64), 3, random_state=1)
     assert np.all(np.abs(s - ref["norms"]) <= 1e-5 * ref["norms"][0])
     mat.free()

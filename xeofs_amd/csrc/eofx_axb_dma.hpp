@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void axb_bsplit_kernel(const float* __restrict
   for (int t = 0; t < 8; t += 2) {
     const float v0 = (col < L ? B[(kg * 8 + t) * ldb + col] : 0.f) * b_scale;
     const float v1 = (col < L ? B[(kg * 8 + t + 1) * ldb + col] : 0.f) * b_scale;
-    const fp16x2_t h = __builtin_amdgcn_cvt_pkrtz(v0, v1);
+    const fp16x2_t h = cvt_pk_rn(v0, v1);
     fp16x2_t l;
     l[0] = (__fp16)__builtin_fmaf((float)h[0], m1, v0);
     l[1] = (__fp16)__builtin_fmaf((float)h[1], m1, v1);
@@ -262,8 +262,8 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(176))) void 
   do {                                                                                                 \
     f32x2 v_;                                                                                          \
     asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(v_) : "v"(t_), "v"(fs_[h]), "v"(fl_[h])); \
-    const fp16x2_t p_ = __builtin_amdgcn_cvt_pkrtz(v_[0], v_[1]);                                      \
-    const fp16x2_t q_ = __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf((float)p_[0], m1, v_[0]),            \
+    const fp16x2_t p_ = cvt_pk_rn(v_[0], v_[1]);                                      \
+    const fp16x2_t q_ = cvt_pk_rn(__builtin_fmaf((float)p_[0], m1, v_[0]),            \
                                                    __builtin_fmaf((float)p_[1], m1, v_[1]));            \
     hi_[h] = __builtin_bit_cast(unsigned, p_);                                                         \
     lo_[h] = __builtin_bit_cast(unsigned, q_);                                                         \

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void atb_f16_fit_kernel(const float* __rest
     if (b_loader) _Pragma("unroll") for (int e2 = 0; e2 < 2; ++e2) {                             \
       const bool sec_ = (e2 != 0) != b_odd;                                                      \
       const float v0_ = (sec_ ? bn[1] : bn[0]) * b_scale, v1_ = (sec_ ? bn[3] : bn[2]) * b_scale; \
-      const fp16x2_t h_ = __builtin_amdgcn_cvt_pkrtz(v0_, v1_);                                  \
+      const fp16x2_t h_ = cvt_pk_rn(v0_, v1_);                                  \
       fp16x2_t l_;                                                                               \
       l_[0] = (__fp16)__builtin_fmaf((float)h_[0], m1, v0_);                                     \
       l_[1] = (__fp16)__builtin_fmaf((float)h_[1], m1, v1_);                                     \

@@ -85,8 +85,8 @@ __global__ __launch_bounds__(256) void planes_split_kernel(const float* __restri
     u32x4 hi, lo;
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
-      const fp16x2_t a = __builtin_amdgcn_cvt_pkrtz(v[2 * h], v[2 * h + 1]);
-      const fp16x2_t b = __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf((float)a[0], m1, v[2 * h]), __builtin_fmaf((float)a[1], m1, v[2 * h + 1]));
+      const fp16x2_t a = cvt_pk_rn(v[2 * h], v[2 * h + 1]);
+      const fp16x2_t b = cvt_pk_rn(__builtin_fmaf((float)a[0], m1, v[2 * h]), __builtin_fmaf((float)a[1], m1, v[2 * h + 1]));
       hi[h] = __builtin_bit_cast(unsigned, a);
       lo[h] = __builtin_bit_cast(unsigned, b);
     }
@@ -143,8 +143,8 @@ __global__ __launch_bounds__(256) void planes_split_t_kernel(const float* __rest
 #pragma unroll
   for (int h = 0; h < 8; ++h) {
     const float a0 = tile[16 * q + 2 * h][fl], a1 = tile[16 * q + 2 * h + 1][fl];
-    const fp16x2_t a = __builtin_amdgcn_cvt_pkrtz(a0, a1);
-    const fp16x2_t b = __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf((float)a[0], m1, a0), __builtin_fmaf((float)a[1], m1, a1));
+    const fp16x2_t a = cvt_pk_rn(a0, a1);
+    const fp16x2_t b = cvt_pk_rn(__builtin_fmaf((float)a[0], m1, a0), __builtin_fmaf((float)a[1], m1, a1));
     hi[h >> 2][h & 3] = __builtin_bit_cast(unsigned, a);
     lo[h >> 2][h & 3] = __builtin_bit_cast(unsigned, b);
   }

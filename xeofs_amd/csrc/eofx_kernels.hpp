@@ -344,6 +344,19 @@ __global__ __launch_bounds__(256, 2) void atb_bf16_kernel(const float* __restric
 // ---------------------------------------------------------------------------------
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
+// The hi / lo split of the scaled split-fp16 products rounds TO NEAREST (v_cvt_pk_f16_f32, one instruction on gfx950 like
+// v_cvt_pkrtz).  Round 5: with a truncating split every residual lo = x - hi has the sign of x, so the cross terms hi*lo +
+// lo*hi of a coherent sum (a dominant mode) all push the same way; they are ~2^-11 of the main term, get swamped by a long
+// float32 accumulation chain inside the MFMA accumulator, and the lost part shows up as a NEGATIVE bias of the product
+// (measured: -2e-5 on the leading column of X Y over 1M features, tools/split_precision_probe.py, i.e. 2e-5 on the leading
+// singular value -- above the 1e-5 parity tolerance).  With round-to-nearest the residuals have either sign and the same
+// effect is zero-mean.
+// (inline assembly: written as __builtin_convertvector the conversion costs atb_f16_kernel<2> 33 spilled VGPRs -- 6.4 -> 9.5 ms)
+__device__ __forceinline__ fp16x2_t cvt_pk_rn(float a, float b) {
+  fp16x2_t r;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 
 __device__ __forceinline__ void split_f16(f32x8 r, f16x8 (&out)[2]) {
 #pragma unroll
@@ -351,7 +364,7 @@ __device__ __forceinline__ void split_f16(f32x8 r, f16x8 (&out)[2]) {
     u32x4 pk;
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
-      const fp16x2_t p = __builtin_amdgcn_cvt_pkrtz(r[2 * h], r[2 * h + 1]);
+      const fp16x2_t p = cvt_pk_rn(r[2 * h], r[2 * h + 1]);
       pk[h] = __builtin_bit_cast(unsigned, p);
       if (s == 0) {
         r[2 * h] -= (float)p[0];
@@ -369,8 +382,8 @@ __device__ __forceinline__ void split_f16_mix(const f32x8 r, float m1, f16x8 (&o
   u32x4 hi, lo;
 #pragma unroll
   for (int h = 0; h < 4; ++h) {
-    const fp16x2_t p = __builtin_amdgcn_cvt_pkrtz(r[2 * h], r[2 * h + 1]);
-    const fp16x2_t q = __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf((float)p[0], m1, r[2 * h]),
+    const fp16x2_t p = cvt_pk_rn(r[2 * h], r[2 * h + 1]);
+    const fp16x2_t q = cvt_pk_rn(__builtin_fmaf((float)p[0], m1, r[2 * h]),
                                                   __builtin_fmaf((float)p[1], m1, r[2 * h + 1]));
     hi[h] = __builtin_bit_cast(unsigned, p);
     lo[h] = __builtin_bit_cast(unsigned, q);
@@ -529,7 +542,7 @@ __global__ __launch_bounds__(256, NB > 2 ? 1 : 2) void atb_f16_kernel(const floa
       if (b_item0) _Pragma("unroll") for (int e2 = 0; e2 < 2; ++e2) {                            \
         const bool sec_ = (e2 != 0) != b_odd;        /* which column of the pair this store takes */ \
         const float v0_ = (sec_ ? bn[r][1] : bn[r][0]) * b_scale, v1_ = (sec_ ? bn[r][3] : bn[r][2]) * b_scale; \
-        const fp16x2_t h_ = __builtin_amdgcn_cvt_pkrtz(v0_, v1_);                                \
+        const fp16x2_t h_ = cvt_pk_rn(v0_, v1_);                                \
         fp16x2_t l_;                                                                             \
         l_[0] = (__fp16)__builtin_fmaf((float)h_[0], m1, v0_);                                   \
         l_[1] = (__fp16)__builtin_fmaf((float)h_[1], m1, v1_);                                   \
@@ -789,7 +802,7 @@ __global__ __launch_bounds__(256, 2) void axb_f16_kernel(const float* __restrict
       if (DBG & 32) {   /* raw bits: the loads, the waits and the LDS stores without the arithmetic */   \
         h_ = __builtin_bit_cast(fp16x2_t, bn[0][e]); l_ = __builtin_bit_cast(fp16x2_t, bn[1][e]);      \
       } else {                                                                                         \
-        h_ = __builtin_amdgcn_cvt_pkrtz(v0_, v1_);                                                     \
+        h_ = cvt_pk_rn(v0_, v1_);                                                     \
         l_[0] = (__fp16)__builtin_fmaf((float)h_[0], m1, v0_);                                         \
         l_[1] = (__fp16)__builtin_fmaf((float)h_[1], m1, v1_);                                         \
       }                                                                                                \
@@ -813,8 +826,8 @@ __global__ __launch_bounds__(256, 2) void axb_f16_kernel(const float* __restrict
         asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(t_) : "v"(x_), "v"(fh_[h]));     \
         f32x2 v_;   /* aff_fma: (x - hi) s - lo s, packed (the optimiser splits half of these otherwise) */       \
         asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(v_) : "v"(t_), "v"(fs_[h]), "v"(fl_[h])); \
-        const fp16x2_t p_ = __builtin_amdgcn_cvt_pkrtz(v_[0], v_[1]);                                  \
-        const fp16x2_t q_ = __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf((float)p_[0], m1, v_[0]),        \
+        const fp16x2_t p_ = cvt_pk_rn(v_[0], v_[1]);                                  \
+        const fp16x2_t q_ = cvt_pk_rn(__builtin_fmaf((float)p_[0], m1, v_[0]),        \
                                                        __builtin_fmaf((float)p_[1], m1, v_[1]));        \
         hi_[h] = __builtin_bit_cast(unsigned, p_);                                                     \
         lo_[h] = __builtin_bit_cast(unsigned, q_);                                                     \

@@ -351,6 +351,8 @@ class HilbertEOF(ComplexEOF):
         self.preprocessor.masked_ok = self.preprocessor.in_place and getattr(self, "_hilbert_masked_ok", True)
         A = self.preprocessor.fit_transform(X, dim, weights)
         self.sample_dims = self.preprocessor.sample_dims
+        if centred and self._operator_route_ok(A):
+            return self._fit_operator(A, omega)
         B, A2 = engine.hilbert(self.ctx, A, self.padding, self.decay_factor, want_real=not centred)
         if A2 is not None:          # eof.py:546-555: the analytic signal is re-centred per feature
             A.free()
@@ -362,3 +364,34 @@ class HilbertEOF(ComplexEOF):
             tv_re = A.sumsq() / (A.n - 1)
         tv = tv_re + B.sumsq() / (A.n - 1)
         return self._fit_complex(A, B, tv, omega)
+
+    def _operator_route_ok(self, A):
+        """The imaginary part is never written (engine.rsvd_hilbert_c64): the Hilbert stage is one n x n matrix along the
+        samples, applied to the sample-side panels of the decomposition, and every pass streams the real field once.
+        Needs a centred field (the analytic signal is then centred as the reference re-centres it, eof.py:546-555), a sketch
+        of at most 64 complex columns and a series the resident operator holds; `_hilbert_operator_ok = False` forces the
+        two-part route (comparisons)."""
+        n_over = int(dict(self._solver_kwargs).get("n_oversamples", 10))
+        return (getattr(self, "_hilbert_operator_ok", True) and isinstance(self.n_modes, (int, np.integer))
+                and int(self.n_modes) + n_over <= 64 and A.n <= engine.HILBERT_OPERATOR_MAX_SAMPLES
+                and not (A.masked and A.p < A.n))
+
+    def _fit_operator(self, A, omega):
+        kw = dict(self._solver_kwargs)
+        n_over = int(kw.get("n_oversamples", 10))
+        if A.layout()[1] and not A.layout()[0]:      # in place: the Scaler's statistics already hold it
+            tv_re = float(self.preprocessor.total_variance)
+        else:
+            tv_re = A.sumsq() / (A.n - 1)
+        # total variance of the imaginary part: the transform kernel with its stores switched off (consumes the
+        # sample-contiguous raw field the statistics pass wrote)
+        tv = tv_re + engine.hilbert_sumsq(self.ctx, A, self.padding, self.decay_factor) / (A.n - 1)
+        om = None if omega is None else omega.result()
+        if om is not None and om.shape[0] != min(A.n, A.p):     # samples or features were dropped: draw again
+            om = None
+        U, s, V = engine.rsvd_hilbert_c64(self.ctx, A, int(self.n_modes), self.padding, self.decay_factor, n_over,
+                                          kw.get("n_iter", "auto"), self._params["random_state"], omega=om)
+        s64 = s.astype(np.float64)
+        self.data = dict(input_data=(A, None), components=V, scores=U * s, norms=s64,
+                         explained_variance=s64 ** 2 / (A.n - 1), total_variance=tv)
+        return self
