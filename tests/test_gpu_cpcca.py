@@ -245,6 +245,32 @@ def test_whitener_identity_rule(ctx):
     assert np.allclose(m_near.singular_values().values, ref["singular_values"], rtol=2e-4)
 
 
+@pytest.mark.parametrize("alpha", [0.0, 0.5, [0.0, 1.0]])
+def test_whitener_without_eigendecomposition_equals_the_eigh_route(ctx, alpha):
+    """Round 5: the covariance of PC scores is diagonal up to rounding, so its matrix powers (whitener.py:106-123) follow from
+    first divided differences (near_diagonal_powers) instead of the order-m eigen-decomposition.  Both routes on the same
+    model: same whitener, same fit."""
+    from xeofs_amd.cross import cpcca as mod
+
+    m_new, ref, *_ = _models(alpha, True)
+    routes = [sd.whitener_route for sd in m_new.side if sd.T is not None]
+    assert routes and all(r == "near-diagonal" for r in routes), routes
+    mod._Side._near_diagonal_ok = False
+    try:
+        m_old, *_ = _models(alpha, True)
+    finally:
+        mod._Side._near_diagonal_ok = True
+    assert all(sd.whitener_route == "eigh" for sd in m_old.side if sd.T is not None)
+    for a, b in zip(m_new.side, m_old.side):
+        if a.T is None:
+            assert b.T is None
+            continue
+        assert np.abs(a.T - b.T).max() <= 1e-9 * np.abs(b.T).max()
+        assert np.abs(a.Tinv - b.Tinv).max() <= 1e-9 * np.abs(b.Tinv).max()
+    assert np.allclose(m_new.singular_values().values, m_old.singular_values().values, rtol=1e-6)
+    _check_fit(m_new, ref)
+
+
 @pytest.mark.parametrize("swap", [False, True])
 def test_mca_land_masks_in_place(ctx, swap):
     """MCA(use_pca=False) on two fields with land / sea masks: both stay in place (layout mode 3: all-NaN grid points are

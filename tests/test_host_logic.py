@@ -135,3 +135,38 @@ def test_host_hermitian_top_eigensolver(m, nev):
         T[dead, :] = 0
         T[:, dead] = 0
         run(T)
+
+
+@pytest.mark.parametrize("scale,accepted", [(1e-8, True), (1e-6, True), (1e-3, False)])
+def test_near_diagonal_matrix_powers(scale, accepted):
+    """The whitener of PC scores without an eigen-decomposition (cross/cpcca.py near_diagonal_powers) against the
+    eigen-decomposition route (linalg/_numpy/_utils.py:6-33), with repeated and nearly repeated diagonal entries; a
+    covariance that is not nearly diagonal is refused."""
+    import torch
+
+    from xeofs_amd.cross.cpcca import fractional_matrix_power, near_diagonal_powers
+
+    rng = np.random.default_rng(0)
+    m = 300
+    d = np.sort(rng.uniform(0.5, 2000.0, m))[::-1].copy()
+    d[10] = d[9] * (1 + 1e-9)
+    d[20] = d[19]
+    E = rng.standard_normal((m, m))
+    E = 0.5 * (E + E.T)
+    np.fill_diagonal(E, 0.0)
+    C = np.diag(d) + scale * E * np.sqrt(np.outer(d, d))
+    powers = [-0.5, 0.5, -0.25, 0.0 - 0.35]
+    out = near_diagonal_powers(torch.as_tensor(C), powers)
+    if not accepted:
+        assert out is None
+        return
+    for pw, T in zip(powers, out):
+        ref = fractional_matrix_power(C, pw)
+        assert np.abs(T.numpy() - ref).max() <= 1e-9 * np.abs(ref).max(), pw
+    assert np.abs(out[0].numpy() @ out[1].numpy() - np.eye(m)).max() < 1e-9       # T Tinv = I (whitener.py:117-123)
+    # refused: a non-positive or tiny diagonal entry (the reference's `s > eps` cut would act), non-finite input
+    Cz = C.copy()
+    Cz[5, 5] = 1e-13
+    assert near_diagonal_powers(torch.as_tensor(Cz), powers) is None
+    Cz[5, 5] = np.nan
+    assert near_diagonal_powers(torch.as_tensor(Cz), powers) is None

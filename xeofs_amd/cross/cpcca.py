@@ -40,6 +40,44 @@ def fractional_matrix_power(C, power):
     return (V[:, keep] * w[keep] ** power) @ V[:, keep].T
 
 
+NEAR_DIAGONAL_TOL = 1e-8    # bound on the second-order term of `near_diagonal_powers` (relative to the matrix function)
+
+
+def near_diagonal_powers(C, powers):
+    """C^power for each of `powers` when C is symmetric positive definite and NEARLY DIAGONAL -- the covariance of PC
+    scores (whitener.py:106-123 after pca.py:120-131: the columns are orthogonal up to rounding).  No eigen-decomposition:
+    with C = D + E the matrix function is f(D) + F o E + O(|E|^2), F_ij = (f(d_i) - f(d_j)) / (d_i - d_j) the first divided
+    differences (Daleckii-Krein) -- a bounded factor, so that close diagonal entries are harmless.  The dropped second-order
+    term is at most ~ m rho^2 relative, rho = max |E_ij| / sqrt(d_i d_j); the route is taken when that bound is below
+    NEAR_DIAGONAL_TOL and no diagonal entry is near the reference's cut-off (`s > eps`, linalg/_numpy/_utils.py:20-23).
+    C: float64 torch tensor (any device).  Returns the list of matrices, or None (the caller takes the eigen-decomposition)."""
+    import torch
+
+    m = C.shape[0]
+    d = C.diagonal().clone()
+    if m == 0 or not bool(torch.isfinite(C).all()) or not bool((d > 0).all()):
+        return None
+    dmax, dmin = float(d.max()), float(d.min())
+    if dmin <= 1e-12 * dmax or dmin <= 1e4 * float(torch.finfo(C.dtype).eps):
+        return None
+    r = torch.rsqrt(d)
+    E = C - torch.diag(d)
+    rho = float((E * r[:, None] * r[None, :]).abs().max()) if m > 1 else 0.0
+    if m * rho * rho > NEAR_DIAGONAL_TOL:
+        return None
+    a, b = d[:, None], d[None, :]
+    diff = a - b
+    close = diff.abs() <= 1e-5 * torch.maximum(a, b)
+    safe = torch.where(close, torch.ones_like(diff), diff)
+    mid = 0.5 * (a + b)
+    out = []
+    for power in powers:
+        fd = d ** power
+        F = torch.where(close, power * mid ** (power - 1.0), (fd[:, None] - fd[None, :]) / safe)
+        out.append(torch.diag(fd) + F * E)
+    return out
+
+
 def _whitener_is_identity(alpha) -> bool:
     """preprocessing/whitener.py:54-60: `(1.0 - alpha) < eps` -- every alpha >= 1 (and those within one ulp below it) is the
     identity transform; alpha = 1 - 1e-9 is NOT (np.isclose would call it one)."""
@@ -126,6 +164,9 @@ def _fit_two_pcas(pcas, mats, total_variances):
 class _Side:
     """One field of the cross model: resident matrix, optional PCA, optional whitener, analysis matrix."""
 
+    _near_diagonal_ok = True      # the whitener of PC scores without an eigen-decomposition (near_diagonal_powers)
+    whitener_route = None         # "near-diagonal" | "eigh" once a device whitener ran
+
     def __init__(self, ctx, mat, pca, alpha):
         self.ctx, self.mat, self.pca, self.alpha = ctx, mat, pca, alpha
         self.T = self.Tinv = None
@@ -189,12 +230,21 @@ class _Side:
         Zp = torch.zeros((self.mat.n_pad, Lm), dtype=torch.float32, device=Zd.device)
         Zp[:n, :m] = Zd
         Cm = engine.panel_gram(ctx, Zp)[:m, :m] / n
-        w, V = yield (0.5 * (Cm + Cm.T)).contiguous()
-        keep = w > torch.finfo(w.dtype).eps
-        Vk, wk = V[:, keep], w[keep]
-        T = (Vk * wk ** ((alpha - 1) / 2)) @ Vk.T
-        # np.linalg.inv(T) where T is regular (all eigenvalues kept), its pseudo-inverse otherwise (whitener.py:117-123)
-        Tinv = (Vk * wk ** ((1 - alpha) / 2)) @ Vk.T
+        Cs = (0.5 * (Cm + Cm.T)).contiguous()
+        # PC scores are orthogonal up to rounding: the covariance is diagonal to first order and its matrix powers follow
+        # without the order-m eigen-decomposition (36 ms of rocSOLVER launches at m = 1500); `_near_diagonal_ok = False`
+        # or a covariance that is not nearly diagonal takes the eigen-decomposition
+        short = near_diagonal_powers(Cs, [(alpha - 1) / 2, (1 - alpha) / 2]) if self._near_diagonal_ok else None
+        self.whitener_route = "near-diagonal" if short is not None else "eigh"
+        if short is not None:
+            T, Tinv = short
+        else:
+            w, V = yield Cs
+            keep = w > torch.finfo(w.dtype).eps
+            Vk, wk = V[:, keep], w[keep]
+            T = (Vk * wk ** ((alpha - 1) / 2)) @ Vk.T
+            # np.linalg.inv(T) where T is regular (all eigenvalues kept), its pseudo-inverse otherwise (whitener.py:117-123)
+            Tinv = (Vk * wk ** ((1 - alpha) / 2)) @ Vk.T
         Tp = torch.zeros((Lm, Lm), dtype=torch.float64, device=Zd.device)
         Tp[:m, :m] = T
         self._Zdev = engine.panel_matmul(ctx, Zp, Tp)[:n, :m].contiguous()
