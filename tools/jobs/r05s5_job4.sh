@@ -1,0 +1,11 @@
+cd $GRAFT_REPO_ROOT; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/j4; mkdir -p $O; export TMPDIR=/tmp
+timeout 600 python -m pytest tests/test_gpu_hilbert_operator.py -x -q 2>&1 | tail -5 > $O/pytest.txt
+OVERLAP=0 python tools/c5_operator_probe.py > $O/c5_serial.txt 2>&1
+python tools/c5_operator_probe.py > $O/c5_overlap.txt 2>&1
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/c5 -o p --output-format csv -- python $R/tools/c5_operator_probe.py > $O/c5_probe_rocprof.txt 2>&1
+cd $R
+python tools/prof_summary.py $O/c5 > $O/c5_summary.txt 2>&1
+python tools/trace_tail.py $O/c5 160 100 > $O/c5_timeline.txt 2>&1
+rm -rf $O/c5
+cat $O/pytest.txt; grep rep $O/c5_serial.txt $O/c5_overlap.txt
