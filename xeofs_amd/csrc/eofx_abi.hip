@@ -4140,7 +4140,7 @@ extern "C" int eofx_panel_colargminmax_f32(eofx_ctx* ctx, const float* P, int64_
 static int panel_colargminmax(eofx_ctx* ctx, const float* P, int64_t rows, int L, int64_t* amax, int64_t* amin, const float* rowscale) {
   if (!ctx || !P || !amax || !amin) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
   CHK(set_device(ctx));
-  const int nparts = (int)std::max<int64_t>(1, std::min<int64_t>((rows + 3) / 4, 512));
+  const int nparts = (int)std::max<int64_t>(1, std::min<int64_t>((rows + 15) / 16, 2048));
   CHK(arena_reserve(ctx, (size_t)nparts * L * 24 + 8192));
   ArenaScope scope(ctx);
   ARENA(float, pmx, (size_t)nparts * L);
@@ -4150,7 +4150,7 @@ static int panel_colargminmax(eofx_ctx* ctx, const float* P, int64_t rows, int L
   hipLaunchKernelGGL(colargminmax_part_kernel, dim3(nparts, (L + 63) / 64), dim3(256), 0, ctx->stream, P, rows, L,
                      pmx, imx, pmn, imn, rowscale);
   KCHK();
-  hipLaunchKernelGGL(colargminmax_final_kernel, dim3((L + 63) / 64), dim3(64), 0, ctx->stream, pmx, imx, pmn, imn,
+  hipLaunchKernelGGL(colargminmax_final_kernel, dim3((L + 63) / 64), dim3(1024), 0, ctx->stream, pmx, imx, pmn, imn,
                      nparts, L, amax, amin);
   KCHK();
   return EOFX_OK;

@@ -2714,13 +2714,32 @@ __global__ __launch_bounds__(256) void colargminmax_part_kernel(const float* __r
   const int rl = tid >> 6;
   float mx = -INFINITY, mn = INFINITY;
   int64_t ax = -1, an = -1;
-  if (c < L)
-    for (int64_t r = (int64_t)blockIdx.x * 4 + rl; r < rows; r += (int64_t)gridDim.x * 4) {
+  if (c < L) {
+    // four rows in flight per thread (independent loads; the compares run in increasing row order: ties keep the lowest row)
+    const int64_t step = (int64_t)gridDim.x * 4;
+    int64_t r = (int64_t)blockIdx.x * 4 + rl;
+    for (; r + 3 * step < rows; r += 4 * step) {
+      float v[4];
+      bool live[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        live[u] = !(rowscale && rowscale[r + u * step] == 0.f);
+        v[u] = P[(r + u * step) * L + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (!live[u]) continue;
+        if (v[u] > mx) { mx = v[u]; ax = r + u * step; }
+        if (v[u] < mn) { mn = v[u]; an = r + u * step; }
+      }
+    }
+    for (; r < rows; r += step) {
       if (rowscale && rowscale[r] == 0.f) continue;
       const float v = P[r * L + c];
       if (v > mx) { mx = v; ax = r; }
       if (v < mn) { mn = v; an = r; }
     }
+  }
   smx[rl][tid & 63] = mx; sax[rl][tid & 63] = ax;
   smn[rl][tid & 63] = mn; san[rl][tid & 63] = an;
   __syncthreads();
@@ -2739,18 +2758,27 @@ __global__ void colargminmax_final_kernel(const float* __restrict__ pmx, const i
                                           const float* __restrict__ pmn, const int64_t* __restrict__ imn,
                                           int nparts, int L, int64_t* __restrict__ amax,
                                           int64_t* __restrict__ amin) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= L) return;
+  // block = 64 columns x 16 part lanes; the tie rule names the row explicitly, so any reduction order gives the same answer
+  __shared__ float sa[16][64], sb[16][64];
+  __shared__ int64_t sia[16][64], sib[16][64];
+  const int cl = threadIdx.x & 63, ql = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   float a = -INFINITY, b = INFINITY;
   int64_t ia = -1, ib = -1;
-  for (int q = 0; q < nparts; ++q) {
-    const float va = pmx[(int64_t)q * L + c], vb = pmn[(int64_t)q * L + c];
-    const int64_t ja = imx[(int64_t)q * L + c], jb = imn[(int64_t)q * L + c];
-    if (ja >= 0 && (va > a || (va == a && (ia < 0 || ja < ia)))) { a = va; ia = ja; }
-    if (jb >= 0 && (vb < b || (vb == b && (ib < 0 || jb < ib)))) { b = vb; ib = jb; }
+  auto take = [&](float va, int64_t ja, float vb, int64_t jb) {
+    if (ja >= 0 && (ia < 0 || va > a || (va == a && ja < ia))) { a = va; ia = ja; }
+    if (jb >= 0 && (ib < 0 || vb < b || (vb == b && jb < ib))) { b = vb; ib = jb; }
+  };
+  if (c < L)
+    for (int q = ql; q < nparts; q += 16)
+      take(pmx[(int64_t)q * L + c], imx[(int64_t)q * L + c], pmn[(int64_t)q * L + c], imn[(int64_t)q * L + c]);
+  sa[ql][cl] = a; sia[ql][cl] = ia; sb[ql][cl] = b; sib[ql][cl] = ib;
+  __syncthreads();
+  if (ql == 0 && c < L) {
+    for (int q = 1; q < 16; ++q) take(sa[q][cl], sia[q][cl], sb[q][cl], sib[q][cl]);
+    amax[c] = ia;
+    amin[c] = ib;
   }
-  amax[c] = ia;
-  amin[c] = ib;
 }
 
 // max over the rows of |P[r, c] + i P[r, c + L/2]| for the L/2 complex columns of a [Re | Im] panel -> out[L/2]
