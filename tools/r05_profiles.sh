@@ -24,11 +24,19 @@ for set in "FETCH_SIZE" "WRITE_SIZE" \
   (cd $R && python tools/prof_summary.py $O/pmc$i > $O/pmc${i}_full.txt 2>&1; awk '/^# PMC/{p=1} p' $O/pmc${i}_full.txt | grep -A 9 "atb_f16_fit_kernel\|atb_f16_kernel<2, true\|axb_f16_kernel<4\|axb_f16_dma_kernel\|axb_bsplit\|^# PMC" > $O/pmc${i}_summary.txt)
   rm -rf $O/pmc$i $O/pmc${i}_full.txt
 done
-# config 5 under the kernel trace: every kernel of one call
+# config 5 under the kernel trace: every kernel of one call -- the operator route (the one HilbertEOF and the bench take) ...
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/c5o -o p --output-format csv -- python $R/tools/c5_operator_probe.py > $O/c5_operator_probe_under_rocprof.txt 2>&1
+(cd $R && python tools/prof_summary.py $O/c5o > $O/c5_operator_kernel_trace_summary.txt 2>&1; python tools/trace_gaps.py $O/c5o colstats_tr_kernel > $O/c5_operator_timeline.txt 2>&1)
+rm -rf $O/c5o
+# ... and the two-part route (Im written, both parts streamed)
 ENGINE_ONLY=1 timeout 600 rocprofv3 --kernel-trace --stats -d $O/c5 -o p --output-format csv -- python $R/tools/complex_probe.py 8000 720 1440 20 > $O/complex_probe_under_rocprof.txt 2>&1
 (cd $R && python tools/prof_summary.py $O/c5 > $O/complex_probe_kernel_trace_summary.txt 2>&1)
 rm -rf $O/c5
 cd $R
+python tools/c5_operator_probe.py > $O/c5_operator_probe.txt 2>&1
+python tools/fuzz_operator.py 3 60 > $O/fuzz_operator.txt 2>&1
+python tools/cca_probe.py > $O/cca_probe.txt 2>&1
+python tools/wide_small_probe.py > $O/wide_small_probe.txt 2>&1
 ENGINE_ONLY=1 EOFX_C64_TRACE=1 python tools/complex_probe.py 8000 720 1440 20 > $O/complex_probe.txt 2>&1
 NO_RAWT=1 ENGINE_ONLY=1 python tools/complex_probe.py 8000 720 1440 20 > $O/complex_probe_without_raw_layout.txt 2>&1
 EOFX_C64_KRYLOV=0 ENGINE_ONLY=1 python tools/complex_probe.py 8000 720 1440 20 > $O/complex_probe_subspace_iteration.txt 2>&1

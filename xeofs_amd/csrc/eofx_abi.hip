@@ -973,11 +973,12 @@ static int launch_axb(eofx_ctx* ctx, const float* raw, int64_t ld, int64_t rows,
 // (sketch-width) panels; wide panels already expose (L/64)^2 sub-blocks, so fewer partials (<= 64 MB)
 static int gram_parts(int64_t rows, int L) {
   // workgroups along the rows; every workgroup writes one partial (L x L float64):
-  // >= 8 k-steps (32 rows) per wave, <= 64 MB of partials
+  // >= 8 k-steps (32 rows) per wave, <= 128 MB of partials (a 130 000 x 1536 panel, 300 sub-blocks: 3 row parts 8.9 ms,
+  // 6 .. 24 parts 7.1 ms -- tools/wide_small_probe.py)
   // (one workgroup per CU: the products run at the fp64 MFMA rate either way -- ~45 TFLOP/s here -- and every further
   // partial is 8 L^2 bytes written and read again: 194 / 210 / 243 us for 256 / 512 / 1024 partials of a 1M x 64 panel)
   const int64_t by_rows = std::min<int64_t>((rows + 127) / 128, 256);
-  const int64_t by_mem = ((int64_t)64 << 20) / ((int64_t)L * L * 8);
+  const int64_t by_mem = ((int64_t)128 << 20) / ((int64_t)L * L * 8);
   if (const char* ev = std::getenv("EOFX_GRAM_PARTS")) return std::max(1, atoi(ev));   // tuning hook (tools/small_kernel_probe.py)
   return (int)std::max<int64_t>(1, std::min(by_rows, std::max<int64_t>(by_mem, 1)));
 }
@@ -996,8 +997,12 @@ static int launch_gram(eofx_ctx* ctx, const float* P, int64_t rows, int L, doubl
   return EOFX_OK;
 }
 static int launch_matmul(eofx_ctx* ctx, const float* P, int64_t rows, int L, const double* Mx, int Lo,
-                         float* out) {
-  const int KW = (int)std::min<int64_t>(round_up(L, 64), 256);      // rows of Mx held in LDS at a time
+                         float* out, bool upper = false) {
+  int KW = (int)std::min<int64_t>(round_up(L, 64), 256);            // rows of Mx held in LDS at a time
+  if (L > 256) {                                                    // windowed form: tuning hook (tools/wide_small_probe.py)
+    static const int kw_env = std::getenv("EOFX_PMM_KW") ? atoi(std::getenv("EOFX_PMM_KW")) : 0;
+    if (kw_env == 128 || kw_env == 256) KW = kw_env;
+  }
   const size_t smem = (size_t)KW * PMM_LD * sizeof(double);         // 33 .. 132 KB
   static size_t attr_smem = 0;    // opt in to more than 64 KB of dynamic LDS when a wide panel asks for it
   if (smem > 64 * 1024 && smem > attr_smem) {
@@ -1008,7 +1013,7 @@ static int launch_matmul(eofx_ctx* ctx, const float* P, int64_t rows, int L, con
   const int64_t gx = L <= KW ? std::min<int64_t>(units, 1024) : units;   // windowed form: one group per wave
   dim3 grid((int)std::max<int64_t>(1, gx), (Lo + 63) / 64);
   hipLaunchKernelGGL(panel_matmul_kernel<false>, grid, dim3(256), smem, ctx->stream, P, rows, L, Mx, Lo, out, KW, amax_new(ctx, out),
-                     (int64_t)0, (int64_t)0, 1, (const float*)nullptr);
+                     (int64_t)0, (int64_t)0, 1, (const float*)nullptr, upper ? 1 : 0);
   KCHK();
   return EOFX_OK;
 }
@@ -1096,7 +1101,7 @@ static int launch_cholqr(eofx_ctx* ctx, const float* P, int64_t rows, int L, int
   // (Also for wide sketches the product with R^-1 stays in the float64 kernel: through fp16 planes -- 22-bit operands against the
   // matrix' largest entry, and R^-1 spans orders of magnitude -- Q lost orthonormality, 1.5e-6 instead of 4e-9 at 1510 columns,
   // for 0.75 ms per factorisation.)
-  return launch_matmul(ctx, P, rows, L, Rinv, L, out);
+  return launch_matmul(ctx, P, rows, L, Rinv, L, out, /*upper=*/true);      // (R^-1 is upper triangular, zero below)
 }
 
 static int launch_colminmax(eofx_ctx* ctx, const float* P, int64_t rows, int L, float* mx, float* mn) {

@@ -1704,14 +1704,19 @@ __global__ __launch_bounds__(256) void panel_matmul_kernel(const float* __restri
                                                            float* __restrict__ out, int KW,
                                                            unsigned* __restrict__ amax_out = nullptr,
                                                            int64_t ldp = 0, int64_t slab = 0, int cpb = 1,
-                                                           const float* __restrict__ sub = nullptr) {
+                                                           const float* __restrict__ sub = nullptr, int upper = 0) {
+  // upper != 0: Mx is upper triangular (the R^-1 of a Cholesky-QR): output column block b needs the K chunks 0 .. b only --
+  // half the products of a wide panel; the skipped ones are exact zeros, the result is the same bits
   extern __shared__ __attribute__((aligned(16))) double Ms[];
   float amx = 0.f;   // [KW][PMM_LD]: KW = multiple of 64, the K window in LDS
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lk = lane >> 4;
-  const int c0 = blockIdx.y * 64;
-  const int Lc = (L + 63) / 64;          // K chunks of 64
+  const int by = upper ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;    // (triangular: the long column blocks start first)
+  const int c0 = by * 64;
+  const int Lc_all = (L + 63) / 64;
+  const int Lc = upper ? (Lc_all < by + 1 ? Lc_all : by + 1) : Lc_all;   // K chunks of 64 that matter
+  const int Le = L < 64 * Lc ? L : 64 * Lc;                                                         // ... = inner dimension used
   const int64_t ngroups = (rows + 31) / 32;
   const int64_t g0 = (int64_t)blockIdx.x * 4 + wave;
   auto stage = [&](int k0) {             // rows [k0, k0 + KW) of the 64-column slice of Mx
@@ -1758,7 +1763,7 @@ __global__ __launch_bounds__(256) void panel_matmul_kernel(const float* __restri
           for (int q = 0; q < 4; ++q)
             acc[t][q] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a[t][tt][c], b[q], acc[t][q], 0, 0, 0);
       }
-    if (kc + 64 >= L) {
+    if (kc + 64 >= Le) {
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
