@@ -642,3 +642,38 @@ def test_hilbert_eof_model_on_a_land_masked_field(ctx):
     Z = pre["X"] + 1j * orc.hilbert_transform(pre["X"], padding="exp", decay_factor=0.2).imag
     se = np.linalg.svd(Z, compute_uv=False)[:k]
     assert np.all(np.abs(s1 - se) <= 1e-5 * se)
+
+
+@pytest.mark.parametrize("route", ["two_part", "operator"])
+def test_more_modes_than_numerical_rank_keeps_both_factors_orthonormal(ctx, route):
+    """The analytic signal of a short series has about n / 2 + 1 independent rows: with n = 55 and k = 35 the trailing modes are
+    numerically null (values 1e-7 ... 1e-9 of the leading one).  The reference's solver ends with a dense SVD of A V (scipy svds),
+    so its factors are orthonormal whatever the values; the engine re-orthonormalises such columns of the small-side factor
+    (found by tools/fuzz_complex.py, case 34 of the bulk sweep: U^H U - I was 0.24 there)."""
+    from xeofs_amd import engine
+
+    n, p, k = 55, 112, 35
+    rng = np.random.default_rng(34)
+    t = np.arange(n)[:, None]
+    x = np.linspace(0, 2 * np.pi, p)[None, :]
+    X = 0.5 * rng.standard_normal((n, p))
+    for j in range(11):
+        X += 6.0 * 0.85 ** j * np.cos((0.05 + 0.043 * j) * t - (1 + j % 7) * x + 0.3 * j)
+    X = (X + 20.0).astype(np.float32)
+    A, _ = engine.preprocess(ctx, X, True, False, None, in_place=(route == "operator"))
+    if route == "operator":
+        U, s, V = engine.rsvd_hilbert_c64(ctx, A, k, "exp", 0.2, random_state=260, n_iter="converge")
+    else:
+        B, _ = engine.hilbert(ctx, A, "exp", 0.2)
+        U, s, V = engine.rsvd_c64(ctx, A, B, k, random_state=260, n_iter="converge")
+        B.free()
+    A.free()
+    Xc = X.astype(np.float64) - X.astype(np.float64).mean(0)
+    Z = orc.hilbert_transform(Xc, padding="exp", decay_factor=0.2)
+    se = np.linalg.svd(Z, compute_uv=False)[:k]
+    assert se[-1] < 1e-5 * se[0]                                  # (the case is what it claims to be)
+    assert np.abs(U.conj().T @ U - np.eye(k)).max() < 3e-5
+    assert np.abs(V.conj().T @ V - np.eye(k)).max() < 3e-5
+    clear = se > 1e-3 * se[0]
+    assert np.all(np.abs(s - se)[clear] <= 2e-5 * se[0])
+    assert np.all(s[~clear] <= 2e-3 * se[0])

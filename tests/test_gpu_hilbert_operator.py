@@ -130,3 +130,21 @@ def test_operator_route_argument_errors(ctx):
     with pytest.raises(ValueError, match="sketch width"):
         engine.rsvd_hilbert_c64(ctx, A, 60, n_oversamples=10)          # sketch wider than 64
     A.free()
+
+
+def test_operator_cache_is_bounded(ctx):
+    """the resident n x n operators are a two-entry cache: a third series length evicts the oldest, which is rebuilt (same
+    bits) when it comes back"""
+    from xeofs_amd import engine
+
+    out = {}
+    for rnd in range(2):
+        for n in (120, 200, 260):
+            X = _waves(n, 900, seed=n)
+            A, _ = engine.preprocess(ctx, X, True, False, None)
+            _, s, _ = engine.rsvd_hilbert_c64(ctx, A, 4, "exp", 0.2, random_state=2)
+            A.free()
+            if rnd == 0:
+                out[n] = s
+            else:
+                assert np.array_equal(out[n], s), n

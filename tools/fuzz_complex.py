@@ -67,19 +67,27 @@ for case in range(ncase):
         # iterations, sklearn's rule); modes inside a flat noise bulk are only as good as the iteration count (the
         # reference's svds(lobpcg) would polish them): checked loosely
         clear = se > 4.0 * sall[min(k + 10, len(sall) - 1)]
+        why = []
         ok = np.all(np.abs(s - se)[clear] <= 1e-5 * se[clear] + 3e-6 * se[0]) and np.all(np.abs(s - se) <= 0.1 * se + 5e-4 * se[0])
-        ok &= np.abs(U.conj().T @ U - np.eye(k)).max() < 3e-5 and np.abs(V.conj().T @ V - np.eye(k)).max() < 3e-5
+        if not ok: why.append(f"values (clear modes {float((np.abs(s - se)[clear] / se[clear]).max()) if clear.any() else 0:.2e}, all {float((np.abs(s - se) / se[0]).max()):.2e} of s_1)")
+        ou, ov = np.abs(U.conj().T @ U - np.eye(k)).max(), np.abs(V.conj().T @ V - np.eye(k)).max()
+        if not (ou < 3e-5 and ov < 3e-5): why.append(f"orthonormality U {ou:.2e} V {ov:.2e}")
+        ok &= ou < 3e-5 and ov < 3e-5
         rec = (U.astype(np.complex128) * s) @ V.astype(np.complex128).conj().T
         Ue, sf, Vhe = np.linalg.svd(Z, full_matrices=False)
         best = (Ue[:, :k] * sf[:k]) @ Vhe[:k]
         tiny = int((se < 3e-3 * se[0]).sum())        # numerically zero modes come back with sqrt(eps_f32) s_1 of absolute noise (Gram-based finish)
-        ok &= np.linalg.norm(Z - rec) <= np.linalg.norm(Z - best) * (1 + (1e-4 if clear.all() else 5e-2)) + 1e-6 * np.linalg.norm(Z) + 1e-3 * se[0] * np.sqrt(tiny)
+        rec_ok = np.linalg.norm(Z - rec) <= np.linalg.norm(Z - best) * (1 + (1e-4 if clear.all() else 5e-2)) + 1e-6 * np.linalg.norm(Z) + 1e-3 * se[0] * np.sqrt(tiny)
+        if not rec_ok: why.append(f"reconstruction {np.linalg.norm(Z - rec):.4e} vs best {np.linalg.norm(Z - best):.4e} (tiny modes {tiny})")
+        ok &= rec_ok
+        if not (bool(lean) and (kept == (k + 10 <= 32))): why.append("layout")
         ok &= bool(lean) and (kept == (k + 10 <= 32))
         if bulk_mode:
+            if not le: why.append("per-mode rule vs the reference solver")
             ok &= le
         if not ok:
             bad += 1
-            print("MISMATCH case", case, dict(n=n, p=p, k=k, std=std, w=use_w, padding=padding, seed=seed), "max rel", float(np.max(np.abs(s - se) / se)), lean, kept)
+            print("MISMATCH case", case, dict(n=n, p=p, k=k, std=std, w=use_w, padding=padding, seed=seed), "max rel", float(np.max(np.abs(s - se) / se)), lean, kept, "; ".join(why), "s/s1 tail", (se[-3:] / se[0]).round(9).tolist(), (s[-3:] / se[0]).round(9).tolist())
     except Exception as e:
         bad += 1
         print("EXC case", case, dict(n=n, p=p, k=k, padding=padding), type(e).__name__, str(e)[:160])

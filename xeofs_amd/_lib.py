@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libeofx.so")
+# (EOFX_LIB: another build of the same ABI -- same-box A/B runs of two library versions, tools/jobs/*; never set in tests)
+LIB_PATH = os.environ.get("EOFX_LIB") or os.path.join(_HERE, "lib", "libeofx.so")
 
 EOFX_OK = 0
 ERR_ARG, ERR_HIP, ERR_PARTIAL_NAN, ERR_NAN_MISMATCH, ERR_RANK, ERR_LINALG, ERR_NOMEM, ERR_SHAPE = (

@@ -4351,6 +4351,10 @@ static int get_hilbert_operator(eofx_ctx* ctx, int64_t n, int padding, double de
   CHK(eofx_mat_from_dense_f32(ctx, hc.data(), n, n, n, &m));
   eofx_ctx::HilbertOp h;
   h.n = n; h.padding = padding; h.decay = decay; h.m = m;
+  while (ctx->hops.size() >= 2) {          // a small cache (an operator is up to 2 GB): the oldest one goes
+    (void)eofx_mat_destroy(ctx, ctx->hops.front().m);
+    ctx->hops.erase(ctx->hops.begin());
+  }
   ctx->hops.push_back(h);
   *out = m;
   return EOFX_OK;
@@ -4976,6 +4980,64 @@ static int rsvd_c64_impl(eofx_ctx* ctx, const eofx_mat* A, const eofx_mat* B, co
   }
   CHK(right_mul(Yt, tall_pad, M1, k, Lo, Tv));     // A_op = Tall diag(s) Small^H
   CHK(right_mul(Ws, small_pad, M2, k, Lo, Sv));
+  // Numerically null modes (more modes asked for than the matrix has rank: the analytic signal of a short series has about
+  // n / 2 + 1 independent rows): B^H u / s is rounding noise there.  The reference's solver ends with a dense SVD of A V
+  // (scipy svds, _svds.py), whose left vectors are orthonormal whatever the values; here such columns of the small-side factor
+  // are re-orthonormalised on the host against all the columns before them (two rounds of Gram-Schmidt in float64; a column
+  // that lay inside their span is replaced by the first unit vector that does not).  Values and the tall side are untouched.
+  {
+    int first_null = k;
+    for (int j = k - 1; j >= 0 && (double)hs[j] <= 3e-6 * (double)hs[0]; --j) first_null = j;
+    if (first_null < k && hs[0] > 0.f) {
+      std::vector<float> hp((size_t)small * Lo);
+      HIPCHK(hipMemcpy2DAsync(hp.data(), sizeof(float) * Lo, Sv, sizeof(float) * Lo, sizeof(float) * Lo, (size_t)small, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      auto col = [&](int j, std::vector<zdouble>& v) {
+        v.resize((size_t)small);
+        for (int64_t r = 0; r < small; ++r) v[(size_t)r] = zdouble(hp[(size_t)r * Lo + j], hp[(size_t)r * Lo + ko + j]);
+      };
+      std::vector<std::vector<zdouble>> basis((size_t)k);
+      for (int j = 0; j < first_null; ++j) col(j, basis[(size_t)j]);
+      auto project_out = [&](std::vector<zdouble>& v, int upto) {
+        for (int round = 0; round < 2; ++round)
+          for (int c = 0; c < upto; ++c) {
+            zdouble dot(0.0, 0.0);
+            for (int64_t r = 0; r < small; ++r) dot += std::conj(basis[(size_t)c][(size_t)r]) * v[(size_t)r];
+            for (int64_t r = 0; r < small; ++r) v[(size_t)r] -= dot * basis[(size_t)c][(size_t)r];
+          }
+        double nn = 0.0;
+        for (int64_t r = 0; r < small; ++r) nn += std::norm(v[(size_t)r]);
+        return std::sqrt(nn);
+      };
+      int64_t next_unit = 0;
+      for (int j = first_null; j < k; ++j) {
+        std::vector<zdouble> v;
+        col(j, v);
+        double nn0 = 0.0;
+        for (const zdouble& x : v) nn0 += std::norm(x);
+        double nn = std::isfinite(nn0) && nn0 > 0.0 ? project_out(v, j) / std::sqrt(nn0) : 0.0;
+        while (!(nn > 1e-3) && next_unit < small) {          // inside the span of the others (or not finite): a unit vector instead
+          v.assign((size_t)small, zdouble(0.0, 0.0));
+          v[(size_t)next_unit++] = zdouble(1.0, 0.0);
+          nn = project_out(v, j);
+          if (nn > 0.1) break;
+          nn = 0.0;
+        }
+        double nrm = 0.0;
+        for (const zdouble& x : v) nrm += std::norm(x);
+        nrm = std::sqrt(nrm);
+        for (int64_t r = 0; r < small; ++r) {
+          const zdouble x = nrm > 0.0 ? v[(size_t)r] / nrm : zdouble(0.0, 0.0);
+          v[(size_t)r] = x;
+          hp[(size_t)r * Lo + j] = (float)x.real();
+          hp[(size_t)r * Lo + ko + j] = (float)x.imag();
+        }
+        basis[(size_t)j] = v;
+      }
+      HIPCHK(hipMemcpy2DAsync(Sv, sizeof(float) * Lo, hp.data(), sizeof(float) * Lo, sizeof(float) * Lo, (size_t)small, hipMemcpyHostToDevice, ctx->stream));
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+  }
   const float* Vp = transposed ? Tv : Sv;
   const float* Up = transposed ? Sv : Tv;
   std::vector<double> sign(k, 1.0);
