@@ -945,3 +945,68 @@ def test_axb_dma_kernel_equals_the_register_path_bit_for_bit(monkeypatch, n, P, 
         mat.free()
     assert np.array_equal(outs[0], outs[1])
     assert np.isfinite(outs[1].view(np.float32)).all() and np.abs(outs[1].view(np.float32)[:n]).max() > 0
+
+
+_NULL_SHAPES = [(300, 2000, 5, 10), (2000, 300, 5, 10), (300, 2000, 12, 30), (64, 5000, 3, 8), (1000, 1000, 7, 20)]
+
+
+@pytest.mark.parametrize("n,p,r,k,entry", [sh + (e,) for sh in _NULL_SHAPES for e in ("rsvd", "fit", "fit_masked")
+                                           if not (e == "fit_masked" and sh[0] >= sh[1])])
+def test_more_modes_than_numerical_rank_real_path(ctx, n, p, r, k, entry):
+    """Exactly low-rank data with more modes asked for than it has rank: scikit-learn's randomized_svd (a QR and a dense SVD,
+    sklearn/utils/extmath.py) returns orthonormal factors whatever the values; so does the engine (fix_null_columns: the
+    numerically null columns of both factors are re-orthonormalised against the others; round 5 -- before it they were
+    rounding noise on the small side and zeroed columns on the tall side).  Leading values against the float64 oracle, null
+    values at rounding level, the resolved modes' vectors unchanged by the repair."""
+    from xeofs_amd import engine
+
+    rng = np.random.default_rng(n + p + r)
+    X = (rng.standard_normal((n, r)) * 2.0 ** -np.arange(r)) @ rng.standard_normal((r, p)) + 4.0
+    X = X.astype(np.float32)
+    if entry == "fit_masked":        # (a land mask kept in place: needs more valid features than samples)
+        X[:, rng.choice(p, size=p // 4, replace=False)] = np.nan
+    if entry == "rsvd":
+        mat, _ = engine.preprocess(ctx, X, True, False, None)
+        U, s, V = engine.rsvd(ctx, mat, k, random_state=1)
+        mat.free()
+    else:
+        mat, st, U, s, V = engine.fit(ctx, X, k, random_state=1)
+        mat.free()
+    assert np.isfinite(U).all() and np.isfinite(V).all() and np.isfinite(s).all()
+    assert np.abs(U.T.astype(np.float64) @ U - np.eye(k)).max() < 2e-5
+    assert np.abs(V.T.astype(np.float64) @ V - np.eye(k)).max() < 2e-5
+    Xv = X[:, ~np.isnan(X).all(axis=0)].astype(np.float64)
+    Xc = Xv - Xv.mean(0)
+    se = np.linalg.svd(Xc, compute_uv=False)[:k]
+    good = se > 1e-4 * se[0]
+    assert good.sum() == min(r, k)
+    assert np.all(np.abs(s - se)[good] <= 2e-5 * se[0])
+    assert np.all(s[~good] <= 1e-5 * se[0])
+    # the resolved modes still are singular pairs of the matrix: X v = s u
+    g = int(good.sum())
+    assert V.shape[0] == Xv.shape[1]
+    R = Xc @ V[:, :g].astype(np.float64) - U[:, :g].astype(np.float64) * s[:g]
+    assert np.abs(R).max() <= 5e-5 * se[0]
+
+
+def test_more_modes_than_the_cross_covariance_has_rank(ctx):
+    """MCA on two fields that share three signals only, ten modes asked for: the singular vectors of the (rank-3 plus rounding)
+    cross-covariance matrix stay orthonormal for the null modes too (fix_null_modes in eofx_crosscov_rsvd_f32)."""
+    from xeofs_amd import engine
+
+    rng = np.random.default_rng(8)
+    n, p1, p2, k = 400, 900, 700, 10
+    T = rng.standard_normal((n, 3))
+    X = (T @ rng.standard_normal((3, p1))).astype(np.float32) + 2.0
+    Y = (T @ rng.standard_normal((3, p2))).astype(np.float32) - 1.0
+    mx, _ = engine.preprocess(ctx, X, True, False, None)
+    my, _ = engine.preprocess(ctx, Y, True, False, None)
+    out = engine.crosscov_rsvd(ctx, mx, my, k, random_state=2)
+    Q1, s, Q2 = out["Q1"], out["s"], out["Q2"]
+    mx.free(); my.free()
+    assert np.isfinite(Q1).all() and np.isfinite(Q2).all()
+    assert np.abs(Q1.T.astype(np.float64) @ Q1 - np.eye(k)).max() < 2e-5
+    assert np.abs(Q2.T.astype(np.float64) @ Q2 - np.eye(k)).max() < 2e-5
+    Xc, Yc = X.astype(np.float64) - X.astype(np.float64).mean(0), Y.astype(np.float64) - Y.astype(np.float64).mean(0)
+    se = np.linalg.svd(Xc.T @ Yc / (n - 1), compute_uv=False)[:k]
+    assert np.all(np.abs(s[:3] - se[:3]) <= 2e-5 * se[0]) and np.all(s[3:] <= 1e-4 * se[0])

@@ -2047,6 +2047,7 @@ struct RsvdOut {
   float* Svec;  // [small_pad x Lo]  singular vectors on the small side
   int Lo;
   std::vector<double> s;  // singular values, descending (k of them)
+  int64_t tall_pad = 0, small_pad = 0;   // padded row counts of the two panels
 };
 
 static int rsvd_auto_iters(int k, int64_t n, int64_t p) {
@@ -2338,6 +2339,8 @@ static int rsvd_core(eofx_ctx* ctx, const LinOp& op, int k, int l, int n_iter, c
   out.Tvec = Tv;
   out.Svec = Sv;
   out.Lo = Lo;
+  out.tall_pad = op.tall_pad;
+  out.small_pad = op.small_pad;
   return EOFX_OK;
 }
 
@@ -2372,8 +2375,136 @@ static int sign_rule(eofx_ctx* ctx, const float* Vpanel, int64_t rows, int Lo, i
 }
 
 // sign rule, U / s / V to the caller (host|device)
+// Numerically null modes (more modes asked for than the matrix has numerical rank -- exactly low-rank data, a constant
+// field, k close to min(n, p)): the small-side vectors are B^T u / s with s at rounding level, the tall-side ones may be the
+// zeroed "dead" columns of a Cholesky-QR -- noise or zeros where scikit-learn's randomized_svd (a QR and a dense SVD,
+// extmath.py) returns orthonormal factors whatever the values.  Columns [first, k) of such a factor are re-orthonormalised
+// against the columns before them, keeping their direction where they have one: block Gram-Schmidt through the float64 Gram
+// matrix of the panel (N <- (N - G G^T N) R^-1, host algebra on Lo x Lo, two rounds); a column that is zero, not finite or
+// inside the span of the others is first replaced by a fixed pseudo-random vector (null_fill_kernel).  The columns before
+// `first` keep their bits.
+static int fix_null_columns(eofx_ctx* ctx, float* P, int64_t rows, int64_t rows_pad, int Lo, int k, int first) {
+  if (first >= k || rows <= first) return EOFX_OK;
+  {   // (the repair never turns a working call into an out-of-memory error: without room in the arena the columns stay)
+    const size_t need = (size_t)rows_pad * Lo * 4 + (size_t)(gram_parts(rows_pad, Lo) + 4) * Lo * Lo * 8 + (64 << 10);
+    if (ctx->arena_size - ctx->arena_off < need) return EOFX_OK;
+  }
+  ArenaScope scope(ctx);
+  ARENA(double, G, (size_t)Lo * Lo);
+  ARENA(double, Mx, (size_t)Lo * Lo);
+  ARENA(float, tmp, (size_t)rows_pad * Lo);
+  ARENA(int, dflag, Lo);
+  const int m = k - first;
+  std::vector<double> hG((size_t)Lo * Lo), hM((size_t)Lo * Lo);
+  std::vector<int> flag(Lo, 0);
+  const int blocks = (int)std::min<int64_t>((rows + 255) / 256, 4096);
+  auto gram = [&]() -> int {
+    CHK(launch_gram(ctx, P, rows_pad, Lo, G));
+    HIPCHK(hipMemcpyAsync(hG.data(), G, sizeof(double) * Lo * Lo, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return EOFX_OK;
+  };
+  auto refill = [&]() -> int {
+    HIPCHK(hipMemcpyAsync(dflag, flag.data(), sizeof(int) * Lo, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(null_fill_kernel, dim3(blocks), dim3(256), 0, ctx->stream, P, rows, Lo, first, k, (const int*)dflag);
+    KCHK();
+    HIPCHK(hipStreamSynchronize(ctx->stream));      // (flag is reused)
+    return EOFX_OK;
+  };
+  int rounds_done = 0;
+  for (int attempt = 0; attempt < 8 && rounds_done < 2; ++attempt) {
+    CHK(gram());
+    // columns that cannot be kept: zero (the dead columns of a Cholesky-QR) or not finite
+    bool bad = false;
+    std::fill(flag.begin(), flag.end(), 0);
+    for (int j = first; j < k; ++j) {
+      const double d = hG[(size_t)j * Lo + j];
+      if (!std::isfinite(d) || !(d > 1e-30)) flag[j] = 1, bad = true;
+      for (int i = 0; i < k && !flag[j]; ++i)
+        if (!std::isfinite(hG[(size_t)i * Lo + j])) flag[j] = 1, bad = true;
+    }
+    if (bad && rounds_done == 0) {
+      CHK(refill());
+      continue;
+    }
+    // S = C_NN - C_GN^T C_GN (the columns before `first` are orthonormal), its Cholesky factor R, Mx = [I, -C_GN R^-1; 0, R^-1]
+    std::vector<double> S((size_t)m * m), Ri((size_t)m * m, 0.0);
+    for (int a = 0; a < m; ++a)
+      for (int b = 0; b < m; ++b) {
+        double v = hG[(size_t)(first + a) * Lo + first + b];
+        for (int g = 0; g < first; ++g) v -= hG[(size_t)g * Lo + first + a] * hG[(size_t)g * Lo + first + b];
+        S[(size_t)a * m + b] = v;
+      }
+    // right-looking Cholesky with a pivot floor: a column left with < 1e-6 of its squared length lay inside the span before it
+    bool dependent = false;
+    std::vector<double> A(S);
+    for (int j = 0; j < m; ++j) {
+      const double d = A[(size_t)j * m + j];
+      if (!(d > 1e-6 * std::max(S[(size_t)j * m + j], 1e-300)) || !std::isfinite(d)) {
+        flag[first + j] = 1;          // (all such columns are found in one sweep: this one drops out of the factorisation)
+        dependent = true;
+        for (int c = j; c < m; ++c) A[(size_t)j * m + c] = 0.0;
+        A[(size_t)j * m + j] = 1.0;
+        continue;
+      }
+      const double rjj = std::sqrt(d);
+      A[(size_t)j * m + j] = rjj;
+      for (int c = j + 1; c < m; ++c) A[(size_t)j * m + c] /= rjj;
+      for (int r = j + 1; r < m; ++r) {
+        const double f = A[(size_t)j * m + r];
+        for (int c = r; c < m; ++c) A[(size_t)r * m + c] -= f * A[(size_t)j * m + c];
+      }
+    }
+    if (dependent) {
+      if (rounds_done > 0) break;     // (cannot happen after a successful round; leave what the round produced)
+      CHK(refill());
+      continue;
+    }
+    for (int c = 0; c < m; ++c) {       // R^-1 (upper triangular)
+      Ri[(size_t)c * m + c] = 1.0 / A[(size_t)c * m + c];
+      for (int r = c - 1; r >= 0; --r) {
+        double sum = 0.0;
+        for (int t = r + 1; t <= c; ++t) sum += A[(size_t)r * m + t] * Ri[(size_t)t * m + c];
+        Ri[(size_t)r * m + c] = -sum / A[(size_t)r * m + r];
+      }
+    }
+    std::fill(hM.begin(), hM.end(), 0.0);
+    for (int i = 0; i < first; ++i) hM[(size_t)i * Lo + i] = 1.0;
+    for (int a = 0; a < m; ++a)
+      for (int b = a; b < m; ++b) hM[(size_t)(first + a) * Lo + first + b] = Ri[(size_t)a * m + b];
+    for (int g = 0; g < first; ++g)
+      for (int b = 0; b < m; ++b) {
+        double v = 0.0;
+        for (int a = 0; a <= b; ++a) v += hG[(size_t)g * Lo + first + a] * Ri[(size_t)a * m + b];
+        hM[(size_t)g * Lo + first + b] = -v;
+      }
+    HIPCHK(hipMemcpyAsync(Mx, hM.data(), sizeof(double) * Lo * Lo, hipMemcpyHostToDevice, ctx->stream));
+    CHK(launch_matmul(ctx, P, rows_pad, Lo, Mx, Lo, tmp));
+    // only the re-orthonormalised columns go back: the columns before `first` keep their bits
+    HIPCHK(hipMemcpy2DAsync(P + first, sizeof(float) * Lo, tmp + first, sizeof(float) * Lo, sizeof(float) * (size_t)(k - first), (size_t)rows_pad,
+                            hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));      // (hM is reused)
+    ++rounds_done;
+  }
+  return EOFX_OK;
+}
+
+// both factors of a finished decomposition: modes whose value is below 1e-5 of the leading one (the level from which the
+// eigen-solver's 1e-15 no longer keeps two such vectors orthogonal to 1e-5) go through fix_null_columns
+static int fix_null_modes(eofx_ctx* ctx, const RsvdOut& ro, int64_t tall, int64_t small, int k) {
+  int first_null = k;
+  const double s0 = ro.s.empty() ? 0.0 : ro.s[0];
+  for (int j = k - 1; j >= 0 && !(ro.s[j] > 1e-5 * s0); --j) first_null = j;
+  if (first_null < k && s0 > 0.0 && std::isfinite(s0) && ro.tall_pad >= tall && ro.small_pad >= small) {
+    CHK(fix_null_columns(ctx, ro.Tvec, tall, ro.tall_pad, ro.Lo, k, first_null));
+    CHK(fix_null_columns(ctx, ro.Svec, small, ro.small_pad, ro.Lo, k, first_null));
+  }
+  return EOFX_OK;
+}
+
 static int rsvd_finish(eofx_ctx* ctx, const RsvdOut& ro, bool transposed, int64_t n, int64_t p, int k, int flip,
                        float* U, float* s, float* V) {
+  CHK(fix_null_modes(ctx, ro, transposed ? p : n, transposed ? n : p, k));
   const float* Vp = transposed ? ro.Tvec : ro.Svec;
   const float* Up = transposed ? ro.Svec : ro.Tvec;
   std::vector<double> sign;
@@ -3643,6 +3774,7 @@ static int crosscov_impl(eofx_ctx* ctx, const eofx_mat* x, const eofx_mat* y, in
   } else {
     CHK(rsvd_core(ctx, op, k, l, n_iter, omega, ro));
   }
+  CHK(fix_null_modes(ctx, ro, transposed ? p2 : p1, transposed ? p1 : p2, k));   // (more modes than the cross-covariance has rank)
   const float* Q1p = transposed ? ro.Svec : ro.Tvec;  // left vectors of C  (p1)
   const float* Q2p = transposed ? ro.Tvec : ro.Svec;  // right vectors of C (p2)
   std::vector<double> sign;

@@ -2703,6 +2703,24 @@ __global__ __launch_bounds__(256) void cpanel_export_kernel(const float* __restr
   }
 }
 
+// Replacement columns for a factor whose trailing modes are numerically null (fix_null_columns in eofx_abi.hip): column c with
+// colflag[c] != 0 becomes a fixed pseudo-random vector in (-1, 1) on the rows that carry anything in the columns before
+// `first` (rows of masked features / padding stay zero), zero elsewhere.
+__global__ __launch_bounds__(256) void null_fill_kernel(float* __restrict__ P, int64_t rows, int Lo, int first, int k,
+                                                         const int* __restrict__ colflag) {
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
+    float* row = P + r * Lo;
+    bool live = first == 0;
+    for (int c = 0; c < first; ++c) live = live || row[c] != 0.f;
+    for (int c = first; c < k; ++c) {
+      if (!colflag[c]) continue;
+      unsigned h = (unsigned)(r * 0x9E3779B1ull) ^ ((unsigned)c * 0x85EBCA6Bu + 0xC2B2AE35u);
+      h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+      row[c] = live ? (float)(h >> 8) * (1.f / 8388608.f) - 1.f : 0.f;
+    }
+  }
+}
+
 // per-column arg max / arg min over rows [0, rows): (value, row) partials, ties -> lowest row
 __global__ __launch_bounds__(256) void colargminmax_part_kernel(const float* __restrict__ P, int64_t rows,
                                                                  int L, float* __restrict__ pmx,
