@@ -241,7 +241,9 @@ int eofx_fit_first_f32(eofx_ctx *ctx, const float *X, int64_t n, int64_t P, int 
  * while layout mode 3 is not selected), 3 NaN or inf in the field, 4 provisional fp16 range exceeded (or a finite value
  * in a feature whose sampled rows were all NaN), 5 both (also a value so far outside the provisional range that its fp16
  * conversion is infinite), 6 all-NaN grid points outside the range of the masked in-place
- * layout (40 % of the features or more, or n >= valid features).  In layout mode 3 a field whose NaNs are all-NaN grid
+ * layout (40 % of the features or more, or n >= valid features), 7 standardize with a feature whose standard deviation
+ * is below 2^-14 of the field's largest value (mixed units: the first pass splits raw values against one scale; the
+ * two-step path maps every feature to unit variance first).  In layout mode 3 a field whose NaNs are all-NaN grid
  * points stays on the fused path: the first pass confines and verifies them by itself (xeofs_amd/csrc/eofx_fit.hpp).  */
 int eofx_ctx_fit_info(const eofx_ctx *ctx, double *info3);
 /* ---- feature-sharded fit: one process per GPU, the space axis split over the ranks ---------------------

@@ -655,6 +655,35 @@ def test_fused_fit_falls_back(ctx):
     mat.free()
 
 
+@pytest.mark.parametrize("spread,fused", [(2.0, True), (8.0, False), (16.0, False)])
+def test_standardize_with_mixed_feature_scales(ctx, spread, fused):
+    """Mixed-unit fields (pressure in Pa next to specific humidity) under standardize=True.  The fused first pass splits the
+    RAW values against one scale: a feature whose standard deviation is below 2^-14 of the field's largest value would reach
+    the matrix cores with a fraction of its bits and 1 / std would magnify the loss (round 5, tools/scale_probe.py: 7e-6 at
+    8 orders of magnitude between features, nonsense at 16) -- such a fit goes back to the two-step path (reason 7), which
+    maps every feature to unit variance before the split.  Either way: the float64 oracle's values to 1e-6."""
+    from xeofs_amd import engine
+
+    rng = np.random.default_rng(5)
+    n, p, k = 400, 3000, 8
+    base = (rng.standard_normal((n, 10)) * 2.0 ** -np.arange(10)) @ rng.standard_normal((10, p)) + 0.05 * rng.standard_normal((n, p))
+    X = (base * 10.0 ** rng.uniform(-spread / 2, spread / 2, p)).astype(np.float32)
+    mat, st, U, s, V = engine.fit(ctx, X, k, standardize=True, random_state=1)
+    mat.free()
+    info = engine.fit_info(ctx)
+    assert info["fused"] == fused and (fused or info["reason"] == 7), info
+    ref = orc.eof_fit(X.astype(np.float64), k, standardize=True, random_state=1)
+    assert np.all(np.abs(s - ref["norms"]) <= 1e-6 * ref["norms"][0]), np.abs(s - ref["norms"]).max() / ref["norms"][0]
+    for j in range(4):
+        assert abs(float(np.dot(V[:, j].astype(np.float64), ref["components"][:, j]))) >= 1 - 1e-6, j
+    # without standardize the small features carry no weight: the fused pass stays, and is exact
+    mat, st, U, s, V = engine.fit(ctx, X, k, standardize=False, random_state=1)
+    mat.free()
+    assert engine.fit_info(ctx)["fused"]
+    ref = orc.eof_fit(X.astype(np.float64), k, standardize=False, random_state=1)
+    assert np.all(np.abs(s - ref["norms"]) <= 1e-6 * ref["norms"][0])
+
+
 @pytest.mark.parametrize("opts", [{}, {"standardize": True}, {"weights": True}])
 def test_masked_in_place_layout(ctx, opts):
     """Layout mode 3: a field with all-NaN grid points (land / sea mask, sanitizer.py:80-126) stays IN PLACE -- the masked

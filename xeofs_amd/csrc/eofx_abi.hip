@@ -2748,6 +2748,10 @@ struct FitFirst {
       ctx->fit_info[2] = 2.0 + (double)(hword[2] & 3);   // 3: NaN / inf in the field, 4: fp16 overflow of the provisional scale
       return EOFX_FIT_FALLBACK;                          //    (or a finite value in an all-NaN candidate), 5: both
     }
+    if (hword[2] & 8) {
+      ctx->fit_info[2] = 7.0;    // standardize with feature scales further apart than the first pass's one scale resolves
+      return EOFX_FIT_FALLBACK;
+    }
     if (fs.pv < P) {   // all-NaN grid points: the masked in-place layout, under the conditions of sanitize_and_apply
       if (!(ctx->allow_masked && 10 * fs.pv >= 6 * P && n < fs.pv)) {
         ctx->fit_info[2] = 6.0;                          // a mask outside the in-place range (too many points, n >= valid p)

@@ -338,7 +338,12 @@ __global__ __launch_bounds__(256, 2) void atb_f16_fit_kernel(const float* __rest
 //   mean = cshift + S1 / n;  M2 = S2 / a^2 - S1^2 / n;  std = sqrt(M2 / n) clipped at eps        (scaler.py:101-108)
 //   shift = center ? mean : 0;  scale = (standardize ? 1 / std : 1) * weight                   (scaler.py:128-154)
 // flags: bit 0 a sum is not finite (NaN / inf in the data), bit 1 the provisional fp16 scaling overflowed (or a masked
-// candidate held a finite value), bit 2 all-NaN grid points are present (count 0, zero map: the masked in-place layout).
+// candidate held a finite value), bit 2 all-NaN grid points are present (count 0, zero map: the masked in-place layout),
+// bit 3 (standardize only) a feature's standard deviation is below 2^-14 of the field's largest |x - c|: the first pass
+// splits the RAW values against ONE scale, so such a feature reaches the matrix cores -- and its sum S1 -- with fewer than
+// 16 of its 22 bits (below 2^-33: with none), which 1 / std then magnifies (mixed-unit fields: pressure in Pa next to
+// specific humidity; tools/scale_probe.py: 7e-6 on the values at 8 orders of magnitude between features, nonsense at 16).
+// The two-step path maps every feature to unit variance BEFORE the split and is exact there: the fit goes back to it.
 // Also written: the float triples of the in-place view (aff_pack_kernel's layout), dcorr = shift - cshift for
 // fit_reduce_kernel, and max |(x - shift) * scale| (an upper bound within a factor of two) into *absmax.
 __global__ __launch_bounds__(256) void fit_finalize_kernel(
@@ -390,6 +395,7 @@ __global__ __launch_bounds__(256) void fit_finalize_kernel(
     double M2 = q * ia * ia - S1 * S1 / nn;
     if (!(M2 > 0.0)) M2 = 0.0;
     double sd = sqrt(M2 / nn);
+    if (standardize && sd > eps && sd * (double)a_scale < 0.015625) fl |= 8;
     if (sd < eps) sd = eps;
     const double w = weights ? weights[c] : 1.0;
     const double sh = center ? mu : 0.0, sc = (standardize ? 1.0 / sd : 1.0) * w;
@@ -414,7 +420,7 @@ __global__ __launch_bounds__(256) void fit_finalize_kernel(
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
-  const int anyfl = (__any(fl & 1) ? 1 : 0) | (__any(fl & 2) ? 2 : 0) | (__any(fl & 4) ? 4 : 0);
+  const int anyfl = (__any(fl & 1) ? 1 : 0) | (__any(fl & 2) ? 2 : 0) | (__any(fl & 4) ? 4 : 0) | (__any(fl & 8) ? 8 : 0);
   if ((threadIdx.x & 63) == 0) {
     if (amax > 0.f && amax < INFINITY) atomicMax(absmax, __float_as_uint(amax));
     if (anyfl) atomicOr(flags, anyfl);
