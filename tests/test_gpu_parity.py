@@ -1039,3 +1039,31 @@ def test_more_modes_than_the_cross_covariance_has_rank(ctx):
     Xc, Yc = X.astype(np.float64) - X.astype(np.float64).mean(0), Y.astype(np.float64) - Y.astype(np.float64).mean(0)
     se = np.linalg.svd(Xc.T @ Yc / (n - 1), compute_uv=False)[:k]
     assert np.all(np.abs(s[:3] - se[:3]) <= 2e-5 * se[0]) and np.all(s[3:] <= 1e-4 * se[0])
+
+
+def test_fewer_than_four_features_and_other_edge_inputs(ctx):
+    """Round 5 (tools/edge_shape_probe.py): a field with one to three features divided by zero in the statistics pass's launch
+    arithmetic (SIGFPE); a constant field came back with zero vectors where scikit-learn returns orthonormal ones; an infinity
+    raised the decomposition's error where the reference's Scaler -> Sanitizer order raises the partial-NaN one."""
+    from xeofs_amd import engine
+
+    rng = np.random.default_rng(1)
+    for shape, k in (((50, 1), 1), ((50, 2), 1), ((50, 3), 2), ((3, 5), 2), ((2, 40), 1)):
+        X = rng.standard_normal(shape).astype(np.float32) + 1.0
+        mat, st, U, s, V = engine.fit(ctx, X, k, random_state=1)
+        mat.free()
+        Xc = X.astype(np.float64) - X.astype(np.float64).mean(0)
+        se = np.linalg.svd(Xc, compute_uv=False)[:k]
+        assert np.all(np.abs(s - se) <= 1e-5 * max(se[0], 1e-30)), (shape, s, se)
+        assert np.abs(U.T.astype(np.float64) @ U - np.eye(k)).max() < 1e-5 and np.abs(V.T.astype(np.float64) @ V - np.eye(k)).max() < 1e-5
+    for X in (np.zeros((50, 80), np.float32), np.full((50, 80), 3.25, np.float32)):
+        mat, st, U, s, V = engine.fit(ctx, X, 2, random_state=1)
+        mat.free()
+        assert np.all(s == 0)
+        assert np.abs(U.T.astype(np.float64) @ U - np.eye(2)).max() < 1e-5 and np.abs(V.T.astype(np.float64) @ V - np.eye(2)).max() < 1e-5
+    Xi = (rng.standard_normal((120, 700)) + 2.0).astype(np.float32)
+    Xi[3, 3] = np.inf
+    with pytest.raises(ValueError, match="partial NaN"):          # scaler.py:128-154 then sanitizer.py:109-122
+        engine.fit(ctx, Xi, 4, random_state=1)
+    with pytest.raises(np.linalg.LinAlgError):                    # nothing subtracts: the infinity reaches the decomposition
+        engine.fit(ctx, Xi, 4, center=False, random_state=1)

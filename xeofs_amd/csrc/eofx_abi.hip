@@ -1575,8 +1575,8 @@ static int run_feature_summary(eofx_ctx* ctx, const PreState& ps, int64_t P, Fea
 }
 
 static size_t colstats_scratch(int64_t n, int64_t P) {
-  const int64_t gx = (P / 4 + 255) / 256;      // the four-features-per-thread kernel: fewer workgroups, more row splits
-  int64_t RS = std::max<int64_t>(1, (2048 + gx - 1) / gx);
+  const int64_t gx = std::max<int64_t>(1, (P / 4 + 255) / 256);   // the four-features-per-thread kernel: fewer workgroups, more row splits
+  int64_t RS = std::max<int64_t>(1, (2048 + gx - 1) / gx);      // (fewer than four features: gx was 0 -- a division by zero, round 5)
   RS = std::min<int64_t>(RS, std::max<int64_t>(1, n / 64));
   return (size_t)(RS + 1) * P * 32 + (size_t)P * 64 + (size_t)n * 16 + (1 << 20);
 }
@@ -1585,7 +1585,8 @@ static size_t colstats_scratch(int64_t n, int64_t P) {
 static int sanitize_and_apply(eofx_ctx* ctx, const float* Xd, int64_t n, int64_t P, PreState& ps,
                               bool stats_absmax, const uint8_t* expect_valid, int check_nans, eofx_mat** out,
                               uint8_t* valid_feature, uint8_t* valid_sample, int64_t* n_out,
-                              int64_t* p_out, std::vector<int>& hcnt, FeatSummary* summary = nullptr) {
+                              int64_t* p_out, std::vector<int>& hcnt, FeatSummary* summary = nullptr,
+                              bool map_from_these_stats = false) {
   FeatSummary fs;
   CHK(run_feature_summary(ctx, ps, P, fs));
   if (summary) *summary = fs;
@@ -1615,6 +1616,10 @@ static int sanitize_and_apply(eofx_ctx* ctx, const float* Xd, int64_t n, int64_t
   static const char* kPartial =
       "Input data contains partial NaN entries, which will cause the the SVD to fail.";
   if (check_nans && cmin != cmax) return set_err(ctx, EOFX_ERR_PARTIAL_NAN, kPartial);
+  // an infinity in the field: the Scaler runs BEFORE the Sanitizer (preprocessor.py), the mean of that feature is infinite and
+  // x - mean leaves -inf and one NaN in its column -- the reference stops with the partial-NaN message; only an uncentred,
+  // unstandardised fit carries the infinity into the decomposition (which then fails with its own message)
+  if (check_nans && map_from_these_stats && !std::isfinite(fs.tv)) return set_err(ctx, EOFX_ERR_PARTIAL_NAN, kPartial);
   std::vector<int64_t> row_map;
   int64_t ns = n;
   if (check_nans && cmax < n) {  // some samples are missing entirely: find which
@@ -1755,7 +1760,7 @@ extern "C" int eofx_preprocess_f32(eofx_ctx* ctx, const float* X, int64_t n, int
   int64_t ns = 0, pv = 0;
   FeatSummary fs;
   const int rc_sa = sanitize_and_apply(ctx, st.dev, n, P, ps, true, nullptr, check_nans, out, valid_feature, valid_sample, &ns,
-                                       &pv, hcnt, &fs);
+                                       &pv, hcnt, &fs, center || standardize);
   if (ctx->pending_rawT) {     // the transposed raw field of the statistics pass: to the in-place matrix, or back to the pool
     eofx_mat* m = (rc_sa == EOFX_OK && out) ? *out : nullptr;
     if (m && m->raw && m->aff && !m->X && !m->Xt && m->n == n && m->p == P &&
@@ -2495,7 +2500,8 @@ static int fix_null_modes(eofx_ctx* ctx, const RsvdOut& ro, int64_t tall, int64_
   int first_null = k;
   const double s0 = ro.s.empty() ? 0.0 : ro.s[0];
   for (int j = k - 1; j >= 0 && !(ro.s[j] > 1e-5 * s0); --j) first_null = j;
-  if (first_null < k && s0 > 0.0 && std::isfinite(s0) && ro.tall_pad >= tall && ro.small_pad >= small) {
+  // (a constant field: every value is zero, every column is replaced -- scikit-learn returns arbitrary orthonormal factors there too)
+  if (first_null < k && s0 >= 0.0 && std::isfinite(s0) && ro.tall_pad >= tall && ro.small_pad >= small) {
     CHK(fix_null_columns(ctx, ro.Tvec, tall, ro.tall_pad, ro.Lo, k, first_null));
     CHK(fix_null_columns(ctx, ro.Svec, small, ro.small_pad, ro.Lo, k, first_null));
   }
