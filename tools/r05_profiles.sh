@@ -46,6 +46,7 @@ BULK=1 python tools/fuzz_complex.py 2 60 > $O/fuzz_complex_bulk_converge.txt 2>&
 python tools/fuzz_parity.py 5 60 > $O/fuzz_parity.txt 2>&1
 python tools/fuzz_fit.py 5 60 > $O/fuzz_fit.txt 2>&1
 python tools/fuzz_cpcca.py 5 30 > $O/fuzz_cpcca.txt 2>&1
+(for t in null_mode_probe scale_probe model_scale_probe edge_shape_probe model_edge_probe; do echo "## tools/$t.py"; python tools/$t.py 2>&1 | grep -v amdgpu; done) > $O/robustness_probes.txt
 python tools/mca_default_probe.py > $O/mca_default_probe.txt 2>&1
 python tools/hosteig_probe.py > $O/hosteig_probe.txt 2>&1
 python bench.py --nlon 180 --no-traffic --no-cpu-baseline --no-configs --steps 20 --warmup 5 > $O/eighth.json 2> $O/eighth.err
