@@ -390,3 +390,78 @@ def test_combine_sample_masks_two_ranks_gloo(tmp_path):
         assert m["gf_empty_counts"].tolist() == [5, 0] and m["gf_empty_vs"].tolist() == [True, True, False, True]
         assert "partial NaN entries" in str(m["gf_partial"])
         assert m["gf_partial_unchecked"].tolist() == [True, True, False, True]
+
+
+class _DeadColumnOps(NumpyPanelOps):
+    """NumpyPanelOps whose Cholesky steps behave like the device kernels on a rank-deficient panel: a column left with nothing
+    after the ones before it is dropped (zero column of Q, zero row / column of R^-1) instead of raising."""
+
+    @staticmethod
+    def _rinv(g, l):
+        A = np.array(g[:l, :l], dtype=np.float64)
+        d0 = np.diag(A).copy()
+        R = np.zeros((l, l))
+        dead = np.zeros(l, bool)
+        for j in range(l):
+            d = A[j, j]
+            if not (d > 1e-13 * d0[j]) or not d0[j] > 0:
+                dead[j] = True
+                A[j, :] = 0.0
+                A[:, j] = 0.0
+                continue
+            R[j, j] = np.sqrt(d)
+            R[j, j + 1:] = A[j, j + 1:] / R[j, j]
+            A[j + 1:, j + 1:] -= np.outer(R[j, j + 1:], R[j, j + 1:])
+        Ri = np.zeros((l, l))
+        live = ~dead
+        if live.any():
+            Ri[np.ix_(live, live)] = np.linalg.inv(R[np.ix_(live, live)])
+        return Ri
+
+    def cholqr(self, P, l, G):
+        out = np.zeros_like(P.numpy())
+        out[:, :l] = (P.numpy()[:, :l].astype(np.float64) @ self._rinv(G.numpy(), l)).astype(np.float32)
+        return self._t(out)
+
+    def rinv(self, G, l):
+        out = np.zeros_like(G.numpy())
+        out[:l, :l] = self._rinv(G.numpy(), l)
+        return self._t(out, np.float64)
+
+
+def _lowrank_worker(rank, world, port, n, p, r, k, out_dir):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from xeofs_amd import sharded
+
+    rng = np.random.default_rng(7)
+    X = ((rng.standard_normal((n, r)) * 2.0 ** -np.arange(r)) @ rng.standard_normal((r, p))).astype(np.float32)
+    X = (X - X.mean(axis=0)).astype(np.float32)
+    lo, hi = sharded.shard_bounds(p, world, rank)
+    U, s, V = sharded.sharded_rsvd(_DeadColumnOps(X[:, lo:hi]), sharded.Comm(), k, p, lo, random_state=3)
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), U=U, s=s, V=V, X=X)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,p,r,k", [(120, 700, 4, 9), (600, 90, 3, 7)])
+def test_sharded_rsvd_more_modes_than_rank_two_ranks_gloo(tmp_path, n, p, r, k):
+    """the panel-level (feature-sharded) driver on exactly low-rank data with k > rank: both factors orthonormal over ALL shards
+    (scikit-learn returns orthonormal factors whatever the values; `_fix_null_columns` through the all-reduced Gram matrices)"""
+    import torch.multiprocessing as mp
+
+    world = 2
+    mp.spawn(_lowrank_worker, args=(world, _free_port(), n, p, r, k, str(tmp_path)), nprocs=world, join=True)
+    parts = [np.load(tmp_path / f"r{q}.npz") for q in range(world)]
+    assert np.array_equal(parts[0]["U"], parts[1]["U"]) and np.array_equal(parts[0]["s"], parts[1]["s"])
+    U, s = parts[0]["U"].astype(np.float64), parts[0]["s"].astype(np.float64)
+    V = np.concatenate([q["V"] for q in parts], axis=0).astype(np.float64)
+    assert np.isfinite(U).all() and np.isfinite(V).all()
+    assert np.abs(U.T @ U - np.eye(k)).max() < 1e-5 and np.abs(V.T @ V - np.eye(k)).max() < 1e-5
+    se = np.linalg.svd(parts[0]["X"].astype(np.float64), compute_uv=False)[:k]
+    assert np.all(np.abs(s[:r] - se[:r]) <= 2e-5 * se[0]) and np.all(s[r:] <= 1e-5 * se[0])
+    R = parts[0]["X"].astype(np.float64) @ V[:, :r] - U[:, :r] * s[:r]
+    assert np.abs(R).max() <= 1e-4 * se[0]

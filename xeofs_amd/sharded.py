@@ -267,7 +267,81 @@ def _prec_power(ops) -> str:
     return getattr(ctx, "precision", ("f16x3", "f16x3"))[0]
 
 
-def _rsvd_panels(la, to_tall, to_small, gram_small, gram_tall, Z, l, k, n_iter, orth_tall=False, first_tall=None):
+def _fix_null_columns(la, P, gram, k, first, rows):
+    """Columns [first, k) of a factor panel whose modes are numerically null (value <= 1e-5 of the leading one): rounding noise on
+    the small side, zeroed dead columns of a Cholesky-QR on the tall side, where scikit-learn returns orthonormal factors whatever
+    the values.  The panel-level form of `fix_null_columns` (csrc/eofx_abi.hip): block Gram-Schmidt through the (globally
+    reduced) float64 Gram matrix, N <- (N - G G^T N) R^-1 on the host's L x L algebra, two rounds; a column that is zero, not
+    finite or inside the span of the others is first replaced by a fixed pseudo-random vector.  The columns before `first`
+    keep their bits; rows beyond `rows` (padding) and rows that are zero in all the columns before `first` (masked
+    features) stay zero."""
+    import torch
+
+    if first >= k or rows <= first:
+        return P
+    L = P.shape[1]
+    m = k - first
+
+    def refill(cols):
+        r = torch.arange(P.shape[0], device=P.device, dtype=torch.float64)
+        live = r < rows
+        if first > 0:
+            live = live & (P[:, :first] != 0).any(dim=1)
+        for c in cols:
+            v = torch.frac(torch.sin(r * 12.9898 + (c + 1) * 78.233) * 43758.5453) * 2.0 - 1.0
+            P[:, c] = torch.where(live, v, torch.zeros_like(v)).to(P.dtype)
+
+    rounds = 0
+    for _attempt in range(8):
+        if rounds >= 2:
+            break
+        G = gram(P)
+        G = (G.detach().cpu().numpy() if hasattr(G, "detach") else np.asarray(G)).astype(np.float64)
+        bad = [j for j in range(first, k) if not np.isfinite(G[:k, j]).all() or not G[j, j] > 1e-30]
+        if bad and rounds == 0:
+            refill(bad)
+            continue
+        B = G[:first, first:k]
+        S = G[first:k, first:k] - B.T @ B
+        A = S.copy()
+        dep = []
+        for j in range(m):          # right-looking Cholesky with a pivot floor (a dependent column drops out, is refilled)
+            d = A[j, j]
+            if not np.isfinite(d) or not d > 1e-6 * max(S[j, j], 1e-300):
+                dep.append(first + j)
+                A[j, j:] = 0.0
+                A[j, j] = 1.0
+                continue
+            A[j, j] = np.sqrt(d)
+            A[j, j + 1:] /= A[j, j]
+            for r_ in range(j + 1, m):
+                A[r_, r_:] -= A[j, r_] * A[j, r_:]
+        if dep:
+            if rounds > 0:
+                break
+            refill(dep)
+            continue
+        Ri = np.linalg.inv(np.triu(A))
+        Mx = np.zeros((L, L))
+        Mx[np.arange(first), np.arange(first)] = 1.0
+        Mx[first:k, first:k] = Ri
+        Mx[:first, first:k] = -B @ Ri
+        Q = la.matmul(P, Mx)
+        P[:, first:k] = Q[:, first:k]
+        rounds += 1
+    return P
+
+
+def _first_null(s, k):
+    s0 = float(s[0]) if len(s) else 0.0
+    first = k
+    while first > 0 and not (float(s[first - 1]) > 1e-5 * s0):
+        first -= 1
+    return first if np.isfinite(s0) and s0 >= 0.0 else k
+
+
+def _rsvd_panels(la, to_tall, to_small, gram_small, gram_tall, Z, l, k, n_iter, orth_tall=False, first_tall=None,
+                 rows_tall=None, rows_small=None):
     """The pass sequence of `rsvd_core` (csrc/eofx_abi.hip) on abstract products.
 
     `to_tall(P, final)` / `to_small(P, final)` apply A / A^T to a panel (including whatever reduction
@@ -317,6 +391,11 @@ def _rsvd_panels(la, to_tall, to_small, gram_small, gram_tall, Z, l, k, n_iter, 
     M2[:l, :k] = Uh[:, :k] * inv
     Tv = la.matmul(Q, M1)       # singular vectors on the tall side
     Sv = la.matmul(Bt, M2)      # singular vectors on the small side
+    if rows_tall is not None and rows_small is not None:      # numerically null modes: both factors stay orthonormal
+        first = _first_null(s, k)
+        if first < k:
+            Tv = _fix_null_columns(la, Tv, gram_tall, k, first, rows_tall)
+            Sv = _fix_null_columns(la, Sv, gram_small, k, first, rows_small)
     return Tv, Sv, s
 
 
@@ -376,6 +455,9 @@ def sharded_rsvd(ops, comm: Comm, k: int, p_total: int, p_offset: int, n_oversam
         small, tall = "p", "n"
         Z = ops.import_panel(omega[p_offset:p_offset + p_loc], "p")
 
+    # rows of a feature-side panel that can carry data (a masked in-place matrix keeps its physical rows, zero where masked)
+    p_rows = int(getattr(getattr(ops, "mat", None), "p_phys", p_loc))
+
     def to_side(P, side, final):
         """product that lands on `side` from a panel on the other side; `final` selects the
         precision of the last two passes (eofx_ctx_set_precision)"""
@@ -389,7 +471,8 @@ def sharded_rsvd(ops, comm: Comm, k: int, p_total: int, p_offset: int, n_oversam
 
     Tv, Sv, s = _rsvd_panels(ops, lambda P, f: to_side(P, tall, f), lambda P, f: to_side(P, small, f),
                              lambda P: gram(P, small), lambda P: gram(P, tall), Z, l, k, n_iter,
-                             _orth_tall(n if tall == "n" else p_total, Z.shape[1], _prec_power(ops)), first_tall=first_tall)
+                             _orth_tall(n if tall == "n" else p_total, Z.shape[1], _prec_power(ops)), first_tall=first_tall,
+                             rows_tall=(p_rows if tall == "p" else n), rows_small=(p_rows if small == "p" else n))
     Vp, Up = (Tv, Sv) if transposed else (Sv, Tv)
     sign = _sign_from_extrema(comm, ops, Vp, p_loc, k) if flip else None
     if device_out:   # results stay in HBM (torch tensors); nothing crosses PCIe
