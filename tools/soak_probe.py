@@ -35,8 +35,19 @@ for i in range(N):
             Y = xe.DataArray((X[:, ::-1] * 0.5 + 1).reshape(n, a, b).copy(), dims=("time", "lat", "lon"))
             xe.cross.MCA(n_modes=min(k, 20), use_pca=bool(rng.integers(0, 2)), n_pca_modes=0.9, random_state=1).fit(d, Y, "time").singular_values()
         elif kind == 3:
-            m = xe.single.EOF(n_modes=max(2, min(k, 12)), random_state=1).fit(d, "time")
-            xe.single.EOFRotator(n_modes=max(2, min(k, 12)), power=int(rng.integers(1, 3))).fit(m).components()
+            kk, pw = max(2, min(k, 12)), int(rng.integers(1, 3))
+            m = xe.single.EOF(n_modes=kk, random_state=1).fit(d, "time")
+            try:
+                xe.single.EOFRotator(n_modes=kk, power=pw).fit(m).components()
+            except RuntimeError as e:       # "Rotation process did not converge.": does the reference's loop on the same loadings?
+                from oracle import eof_oracle as orc
+                Xv = X[:, ~np.isnan(X).all(axis=0)].astype(np.float64)
+                ref = orc.eof_fit(Xv, kk, random_state=1)
+                try:
+                    orc.eof_rotator_fit(ref, kk, power=pw)
+                    bad += 1; print("case", i, "rotator raised", str(e)[:60], "but the oracle's loop converged", (n, a, b, kk, pw), flush=True)
+                except RuntimeError as e2:
+                    print("case", i, "rotator and oracle both:", str(e2)[:60], (n, a, b, kk, pw), flush=True)
         else:
             mat, st = engine.preprocess(ctx, np.nan_to_num(X, nan=0.5), True, False, None, in_place=bool(rng.integers(0, 2)))
             engine.rsvd(ctx, mat, k, random_state=2); mat.free()

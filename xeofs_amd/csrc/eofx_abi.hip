@@ -1192,7 +1192,10 @@ static void pool_give(eofx_ctx* ctx, void* p, size_t bytes) {
     (void)hipFree(p);
     return;
   }
-  while (!ctx->pool.empty() && ctx->pool_bytes + bytes > ctx->pool_cap) {
+  // (exact-size reuse: a run of differently shaped fits would otherwise pile up buffers nobody asks for again -- 3.5 MB per fit
+  // in tools/soak_probe.py, up to the byte cap; the entry cap keeps what one or two repeated shapes need)
+  constexpr size_t POOL_MAX_ENTRIES = 48;
+  while (!ctx->pool.empty() && (ctx->pool_bytes + bytes > ctx->pool_cap || ctx->pool.size() >= POOL_MAX_ENTRIES)) {
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(ctx->pool.front().first);
     ctx->pool_bytes -= ctx->pool.front().second;
