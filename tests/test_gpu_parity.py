@@ -1067,3 +1067,45 @@ def test_fewer_than_four_features_and_other_edge_inputs(ctx):
         engine.fit(ctx, Xi, 4, random_state=1)
     with pytest.raises(np.linalg.LinAlgError):                    # nothing subtracts: the infinity reaches the decomposition
         engine.fit(ctx, Xi, 4, center=False, random_state=1)
+
+
+def test_three_threads_with_their_own_contexts_fit_bitwise_like_one(ctx):
+    """Several contexts (each on its own stream) driven from several threads on one GPU: fused in-place fits of different fields at
+    the same time equal the serial results bit for bit (process-wide pieces: the sketch generator's worker team, cached launch
+    attributes, the library's statics).  (FFT-type work beside the passes is a different matter: DESIGN.md section 10.)"""
+    import threading
+
+    import torch
+
+    from xeofs_amd import engine
+
+    rng = np.random.default_rng(0)
+    fields = [(rng.standard_normal((n, 5)) @ rng.standard_normal((5, p)) + 0.2 * rng.standard_normal((n, p)) + 1.0).astype(np.float32)
+              for n, p in ((400, 4096), (700, 2048), (300, 8192), (1000, 1000))]
+
+    def run(c, X, seed):
+        mat, st, U, s, V = engine.fit(c, X, 6, random_state=seed)
+        mat.free()
+        return s, V
+
+    serial = [run(ctx, X, 10 + i) for i, X in enumerate(fields)]
+    bad = []
+
+    def worker(tid):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                c = engine.Context(0)
+                for rep in range(12):
+                    i = (rep + tid) % len(fields)
+                    s, V = run(c, fields[i], 10 + i)
+                    if not (np.array_equal(s, serial[i][0]) and np.array_equal(V, serial[i][1])):
+                        bad.append((tid, rep, i))
+        except BaseException as e:      # noqa: BLE001  (reported by the assertion below)
+            bad.append((tid, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not bad, bad
