@@ -445,11 +445,14 @@ def leg_configs(ctx, device, orc, layout_kw, quick=False):
                           "two_part_route": two_part,
                           # physical bytes: the operator route streams the float32 real field only (n x p x 4 per pass)
                           "physical_GBps_rsvd_phase": round(passes5 * n * P * 4.0 / (t["rsvd"] * 1e-3) / 1e9, 1),
-                          # `frac`: the bytes of the passes of the reference's complex decomposition (passes x n x p x 8) against the WHOLE call
-                          # (preprocess + Hilbert stage + rSVD); the rSVD phase alone beside it
-                          "alg_GBps": round(alg5 / ((t["pre"] + t["hilbert"] + t["rsvd"]) * 1e-3) / 1e9, 1),
-                          "frac": round(alg5 / ((t["pre"] + t["hilbert"] + t["rsvd"]) * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
-                          "frac_rsvd_phase": round(alg5 / (t["rsvd"] * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
+                          # roofline fractions from PHYSICAL bytes only (SURVEY 8d's complex64 bytes, passes x n x p x 8,
+                          # divided by a route that streams half of them gave "fractions" above 1): the rSVD phase streams the real field
+                          # once per pass; the whole call also reads it once in the statistics pass (+ one transposed write) and once in
+                          # the sum of squares of the imaginary part
+                          "frac_rsvd_phase": round(passes5 * n * P * 4.0 / (t["rsvd"] * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
+                          "physical_GBps": round((passes5 + 3) * n * P * 4.0 / ((t["pre"] + t["hilbert"] + t["rsvd"]) * 1e-3) / 1e9, 1),
+                          "frac": round((passes5 + 3) * n * P * 4.0 / ((t["pre"] + t["hilbert"] + t["rsvd"]) * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
+                          "survey_alg_GBps_complex64": round(alg5 / ((t["pre"] + t["hilbert"] + t["rsvd"]) * 1e-3) / 1e9, 1),
                           "parity": {"ZV_eq_Us_relerr": rel5, "orth_U_maxabs": orth_u, "orth_V_maxabs": orth_v,
                                      "s_head": [float(x) for x in np.asarray(s)[:3]]}}
         if not (rel5 <= 1e-5 and orth_u <= 1e-5 and orth_v <= 1e-5 and conv_modes.sum() >= 3 and two_part["sv_relerr_operator_vs_two_part"] <= 2e-6
@@ -606,6 +609,201 @@ def measure_traffic(args, n, P):
                     "of this command; FETCH_SIZE x 2 (gfx950, MI355X_MICROARCH.md), KB units; mean over the 16 passes of a fit"
 
 
+def leg_model_level(device, quick=False):
+    """`xe.single.EOF(n_modes=50, random_state=5).fit(X, "time")`, `.components()`, `.scores()` on a RESIDENT labelled field
+    (a torch tensor in HBM handed over as a DataArray) at the sizes of configs 2 and 4: the engine call plus everything the
+    Python shell adds -- label bookkeeping, the download of the factors (components are p x k float32: 207 MB at config 4)."""
+    import torch
+
+    import xeofs_amd as xe
+
+    out = {}
+    for name, (n, nlat, nlon, k) in (("config2", (5000, 360, 720, 50)), ("config4", (10000, 720, 1440, 50))):
+        if quick and name == "config4":
+            continue
+        X = make_field(n, nlat, nlon, 0, nlat * nlon, device).reshape(n, nlat, nlon)
+        da = xe.DataArray(X, dims=("time", "lat", "lon"))
+
+        def run():
+            t = {}
+            _sync(); a = time.perf_counter()
+            m = xe.single.EOF(n_modes=k, random_state=5).fit(da, "time")
+            _sync(); b = time.perf_counter()
+            c = m.components()
+            _sync(); c1 = time.perf_counter()
+            sc = m.scores()
+            _sync(); d = time.perf_counter()
+            t.update(fit=1e3 * (b - a), components=1e3 * (c1 - b), scores=1e3 * (d - c1))
+            return t, m, c, sc
+
+        run()
+        best = None
+        for _ in range(3):
+            t, m, c, sc = run()
+            tot = sum(t.values())
+            if best is None or tot < best[0]:
+                best = (tot, t, [float(x) for x in np.asarray(m.singular_values().values)[:3]], tuple(np.asarray(c.values).shape),
+                        tuple(np.asarray(sc.values).shape))
+            del m, c, sc
+        out[name] = {"what": f"xe.single.EOF(n_modes={k}, random_state=5).fit(X, 'time') + components() + scores() on a resident "
+                             f"{n}x({nlat}x{nlon}) DataArray (device tensor in, host numpy out)",
+                     "ms": round(best[0], 2), "phase_ms": {kk: round(v, 2) for kk, v in best[1].items()}, "s_head": best[2],
+                     "components_shape": list(best[3]), "scores_shape": list(best[4])}
+        del X, da
+        torch.cuda.empty_cache()
+    return out
+
+
+def leg_sharded_config(cfg, ctx, comm, device, world, rank, native, steps, warmup):
+    """BASELINE config 3 / config 5 as multi-GPU jobs (both are defined at 8 GPUs): every rank generates and keeps its slice of
+    each field's feature axis; with the engine's communicator attached (`native`) a fit is engine calls only -- the global facts
+    of the preprocess through eofx_ctx_comm_allreduce_f64, the decomposition through eofx_crosscov_rsvd_sharded_f32 (config 3)
+    or eofx_rsvd_hilbert_sharded_c64 (config 5: the operator route, the imaginary part is never written) -- otherwise the
+    panel-level python drivers with torch.distributed collectives between engine calls.  World size 1 without a communicator:
+    the single-GPU entries.  -> {"line": the JSON line of `bench.py --config cfg`, "gate": failed size-independent properties}"""
+    import torch
+    import torch.distributed as dist
+
+    from xeofs_amd import engine, sharded
+
+    multi = world > 1 or native
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def gsum(t):
+        if world > 1:
+            dist.all_reduce(t)
+        return t
+
+    gate = []
+    if cfg == 3:
+        n, nlat, nlon, k = 5000, 360, 720, 20
+        Ph = nlat * nlon // 2                  # two halves of 129 600 features each: X = columns [0, Ph), Y = [Ph, 2 Ph)
+        lo1, hi1 = sharded.shard_bounds(Ph, world, rank)
+        X = make_field(n, nlat, nlon, lo1, hi1, device)
+        Y = make_field(n, nlat, nlon, Ph + lo1, Ph + hi1, device)
+        om = engine.sketch_matrix(Ph, k + N_OVERSAMPLES, 5)
+
+        def fit():
+            if native:
+                return sharded.sharded_mca_fit(ctx, X, Y, comm, k, random_state=5, omega=om, native=True)
+            if multi:
+                return sharded.sharded_mca_fit(ctx, X, Y, comm, k, random_state=5, omega=om, native=False)
+            mx, sx = engine.preprocess(ctx, X, want_stats=False, in_place=True)
+            my, sy = engine.preprocess(ctx, Y, want_stats=False, in_place=True)
+            r = engine.crosscov_rsvd(ctx, mx, my, k, random_state=5, omega=om)
+            return dict(input_data1=mx, input_data2=my, components1=r["Q1"], components2=r["Q2"], scores1=r["scores1"],
+                        scores2=r["scores2"], singular_values=r["s"].astype(np.float64),
+                        total_squared_covariance=r["total_squared_covariance"])
+
+        def free(res):
+            res["input_data1"].free()
+            res["input_data2"].free()
+
+        alg = 16 * n * (2 * Ph) * 4.0
+        what = f"xe.cross.MCA n_modes={k} (use_pca=False) on two {n}x({nlat // 2}x{nlon}) halves"
+        entry = ("eofx_preprocess_f32 x2 + eofx_ctx_comm_allreduce_f64 + eofx_crosscov_rsvd_sharded_f32 (collectives issued by the engine)"
+                 if native else "sharded_mca_fit: panel ABI + torch.distributed collectives" if multi else
+                 "eofx_preprocess_f32 x2 + eofx_crosscov_rsvd_lazy_f32")
+    else:
+        n, nlat, nlon, k = 8000, 720, 1440, 20
+        P = nlat * nlon
+        lo1, hi1 = sharded.shard_bounds(P, world, rank)
+        X = make_field(n, nlat, nlon, lo1, hi1, device)
+        om = engine.sketch_matrix(n, k + N_OVERSAMPLES, 5)
+
+        def fit():
+            if multi:
+                return sharded.sharded_hilbert_eof_fit(ctx, X, comm, k, "exp", 0.2, random_state=5, omega=om, operator=True,
+                                                       native=bool(native))
+            A, st = engine.preprocess(ctx, X, want_stats=False, in_place=True, for_hilbert=True)
+            tv = st["total_variance"] + engine.hilbert_sumsq(ctx, A, "exp", 0.2) / (n - 1)
+            U, s_, V = engine.rsvd_hilbert_c64(ctx, A, k, "exp", 0.2, random_state=5, omega=om)
+            return dict(input_data=(A, None), components=V, scores=U * s_, norms=s_.astype(np.float64), total_variance=tv)
+
+        def free(res):
+            for m_ in res["input_data"]:
+                if m_ is not None:
+                    m_.free()
+
+        passes = 2 * sharded.rsvd_auto_iters(k, n, P) + 2
+        alg = passes * n * P * 4.0          # PHYSICAL bytes: the operator route streams the float32 real field once per pass
+        what = f"xe.single.HilbertEOF n_modes={k} (padding='exp') on {n}x({nlat}x{nlon})"
+        entry = ("eofx_preprocess_f32 + eofx_hilbert_sumsq_f64 + eofx_ctx_comm_allreduce_f64 + eofx_rsvd_hilbert_sharded_c64 (operator "
+                 "route; collectives issued by the engine)" if native else
+                 "sharded_hilbert_eof_fit: HilbertOperatorOps over the panel ABI + torch.distributed collectives" if multi else
+                 "eofx_preprocess_f32 + eofx_hilbert_sumsq_f64 + eofx_rsvd_hilbert_c64")
+    for _ in range(max(warmup, 1)):
+        free(fit())
+    if native:
+        engine.comm_stats(ctx)
+    barrier()
+    t0 = time.perf_counter()
+    res = None
+    for _ in range(steps):
+        if res is not None:
+            free(res)
+        res = fit()
+    barrier()
+    dt = time.perf_counter() - t0
+    cstats = engine.comm_stats(ctx) if native else None
+    tt = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    ms = 1e3 * float(tt.item()) / steps
+    # size-independent properties, summed over the ranks
+    par = {}
+    if cfg == 3:
+        S1, S2 = res["scores1"].astype(np.float64), res["scores2"].astype(np.float64)
+        sv = np.asarray(res["singular_values"], dtype=np.float64)
+        Cs = S1.T @ S2 / (n - 1)
+        q1 = torch.as_tensor(np.asarray(res["components1"]), device=device).double()
+        q2 = torch.as_tensor(np.asarray(res["components2"]), device=device).double()
+        g1, g2 = gsum(q1.T @ q1), gsum(q2.T @ q2)
+        eye = torch.eye(k, device=device, dtype=torch.float64)
+        par = {"scores_cov_diag_relerr": float(np.max(np.abs(np.diag(Cs) - sv) / sv[0])),
+               "scores_cov_offdiag_rel": float(np.max(np.abs(Cs - np.diag(np.diag(Cs)))) / sv[0]),
+               "scf_sum": float((sv ** 2).sum() / res["total_squared_covariance"]),
+               "orth_Q1_maxabs": float((g1 - eye).abs().max()), "orth_Q2_maxabs": float((g2 - eye).abs().max()),
+               "s_head": [float(x) for x in sv[:3]]}
+        if not (par["scores_cov_diag_relerr"] <= 1e-5 and par["scores_cov_offdiag_rel"] <= 1e-5 and par["scf_sum"] <= 1 + 1e-6 and
+                par["orth_Q1_maxabs"] <= 1e-5 and par["orth_Q2_maxabs"] <= 1e-5):
+            gate.append(f"config 3 on {world} rank(s): {par}")
+    else:
+        V = torch.as_tensor(np.asarray(res["components"]), device=device).to(torch.complex128)
+        gv = V.conj().T @ V
+        gv = torch.complex(gsum(gv.real.contiguous()), gsum(gv.imag.contiguous()))
+        sv = np.asarray(res["norms"], dtype=np.float64)
+        Us = np.asarray(res["scores"]).astype(np.complex128)
+        Uq = Us / sv
+        par = {"orth_V_maxabs": float((gv - torch.eye(k, device=device, dtype=gv.dtype)).abs().max()),
+               "orth_U_maxabs": float(np.abs(Uq.conj().T @ Uq - np.eye(k)).max()),
+               "explained_over_total_variance": float((sv ** 2).sum() / (n - 1) / res["total_variance"]),
+               "s_head": [float(x) for x in sv[:3]]}
+        if not (par["orth_V_maxabs"] <= 1e-5 and par["orth_U_maxabs"] <= 1e-5 and 0.0 < par["explained_over_total_variance"] <= 1 + 1e-6):
+            gate.append(f"config 5 on {world} rank(s): {par}")
+    free(res)
+    del res, X
+    line = {"metric": ("MCA cross-covariance rSVD GB/s (algorithmic: 16 passes x n x (p1 + p2) x 4 B per fit / fit time)" if cfg == 3 else
+                       "Hilbert EOF complex decomposition GB/s (PHYSICAL: passes x n x p x 4 B per fit -- the operator route streams the "
+                       "real field once per pass -- / whole fit time incl. preprocess and the imaginary part's total variance)"),
+            "value": round(alg / (ms * 1e-3) / 1e9, 2), "unit": "GB/s", "n_gpus": world, "steps": steps, "warmup": max(warmup, 1),
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32 data, split-fp16 MFMA x3, f32 accumulate", "data": "synthetic",
+            "config": {"workload": what + f", feature axis sharded over {world} GPU(s), n_oversamples=10, random_state=5", "entry": entry,
+                       "bytes_per_fit": alg},
+            "frac_of_hbm_peak_aggregate": round(alg / (ms * 1e-3) / 1e9 / (PEAK_HBM_GBPS * world), 4),
+            "modes_per_s": round(k / (ms * 1e-3), 2), "parity": par}
+    if cstats is not None:
+        line["comm"] = {"allreduce_calls_per_fit": round(cstats["calls"] / steps, 1), "allreduce_bytes_per_fit": round(cstats["bytes"] / steps),
+                        "binding": "engine-owned communicator (RCCL on the context's stream, or the host callback in functional tests)"}
+    return {"line": line, "gate": gate}
+
+
 def main():
     # Libraries (RCCL prints a version banner at communicator creation) must not pollute stdout: the
     # contract is ONE JSON line there.  Keep the real stdout aside and point fd 1 at stderr.
@@ -644,6 +842,11 @@ def main():
                     help="skip the float64 CPU leg (config-2 shape: kernel level + whole oracle fit) and its 1e-5 parity gate")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs / the published workload")
     ap.add_argument("--quick-configs", action="store_true", help="configs leg without config 5 (33 GB field)")
+    ap.add_argument("--config", type=int, choices=(3, 4, 5), default=4,
+                    help="4 (default): the headline, EOF k=50 on 10000x(720x1440).  3 / 5: the line is BASELINE config 3 (MCA k=20 on two "
+                         "5000x(360x360) halves) / config 5 (Hilbert EOF k=20 on 8000x(720x1440)) on --gpus N ranks, each field sharded "
+                         "along its feature axis, through the engine's own sharded entries (eofx_crosscov_rsvd_sharded_f32 / "
+                         "eofx_rsvd_hilbert_sharded_c64); a --gpus N run of the headline carries both as `configs_sharded` as well")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -711,6 +914,21 @@ def main():
                                                    "sign_rule_128_f32": round(us[2], 1), "vote_1_i32": round(us[3], 1)}}
         except Exception as e:      # (never fatal: the probe is a diagnosis)
             comm_probe = {"ranks_seen": None, "probe_error": str(e)[:200]}
+
+    if args.config != 4:
+        # the line IS config 3 / config 5 on `world` ranks (engine-owned sharded entries when a communicator is attached)
+        leg = leg_sharded_config(args.config, ctx, comm, device, world, rank, native, args.steps, args.warmup)
+        if rank == 0:
+            leg["line"]["n_gpus"] = world
+            leg["line"]["comm"] = dict(leg["line"].get("comm", {}), **(comm_probe or {}), world=world,
+                                       backend=args.backend + (" (RCCL)" if args.backend == "nccl" else ""))
+            print(json.dumps(leg["line"]), file=real_stdout, flush=True)
+        if world > 1 or args.force_sharded:
+            dist.barrier()
+            dist.destroy_process_group()
+        if leg["gate"]:
+            raise SystemExit("bench.py: PARITY GATE FAILED -- " + "; ".join(leg["gate"]))
+        return
 
     t0 = time.perf_counter()
     Xraw = make_field(n, args.nlat, args.nlon, lo, hi, device)
@@ -1035,6 +1253,9 @@ def main():
                 configs["config2"] = config2
             configs["config4"] = "the timed workload of this line"
             gate_failed += g2
+            # the drop-in surface at config sizes (VERDICT r05 missing 6): the model class on a resident field, with what a user
+            # reads afterwards -- fit + components() + scores() (xeofs/single/base_model_single_set.py:123-161,307-336)
+            configs["model_level"] = leg_model_level(device, quick=args.quick_configs)
             if not args.no_f64_baseline and args.precision == "f16x3" and not args.quick_configs:
                 ctx.trim()
                 torch.cuda.empty_cache()
@@ -1044,6 +1265,28 @@ def main():
                 f64_mode["sv_relerr_of_the_headline_vs_f64_mode"] = float(np.max(
                     np.abs(np.asarray(parity["s_head"]) - np.asarray(f64_mode["s_head"])) / np.asarray(f64_mode["s_head"])))
                 configs["f64_mode"] = f64_mode
+
+    # ---- the 8-GPU forms of configs 3 and 5 on the same ranks: every multi-rank run of the headline also
+    #      times them through the engine's own sharded entries, so the first real --gpus 8 run measures the fast routes
+    configs_sharded = None
+    if (world > 1 or args.force_sharded) and not args.no_configs:
+        try:
+            mat.free()
+        except Exception:
+            pass
+        del Xraw, last
+        torch.cuda.empty_cache()
+        ctx.trim()
+        configs_sharded = {}
+        for cfg in (3, 5):
+            if cfg == 5 and args.quick_configs:
+                continue
+            leg = leg_sharded_config(cfg, ctx, comm, device, world, rank, native, 2, 1)
+            configs_sharded[f"config{cfg}"] = {kk: leg["line"][kk] for kk in ("value", "unit", "ms_per_step", "config", "parity", "comm", "phase_ms")
+                                               if kk in leg["line"]}
+            gate_failed += leg["gate"]
+            ctx.trim()
+            torch.cuda.empty_cache()
 
     if rank == 0:
         # BASELINE.md holds no published number for THIS metric (GB/s at n_modes=50 on the 1M grid; `published` is {}): null.
@@ -1081,6 +1324,8 @@ def main():
         }
         if configs is not None:
             line["configs"] = configs
+        if configs_sharded is not None:
+            line["configs_sharded"] = configs_sharded
         if world > 1 or args.force_sharded:
             line["comm"] = {"backend": args.backend + (" (RCCL)" if args.backend == "nccl" else ""), "world": world,
                             "allreduce_calls_per_fit": round(comm_stats["calls"] / args.steps, 1),

@@ -281,11 +281,50 @@ int eofx_ctx_comm_probe(eofx_ctx *ctx, int ncases, const int64_t *counts, const 
  * sketch [n x (k + n_oversamples)], identical on every rank; needs n < P_total, i.e. the sketch on the sample side).
  * total_variance is the global one; mean / std / valid_feature / V are those of the slice.  Returns 0, or 1 when the
  * fused path is not available on SOME rank (NaN fields, shapes outside eofx_fit_first_f32's range -- the ranks agree on
- * this by a vote): nothing is built then and the caller takes the panel-level route (xeofs_amd/sharded.py). */
+ * this by a vote): nothing is built then and the caller takes the panel-level route (xeofs_amd/sharded.py).
+ * Round 6: with layout mode 3 selected, a field whose NaNs are all-NaN grid points (a land / sea mask, sanitizer.py:80-126)
+ * stays on this entry -- every slice keeps its masked features as zero columns, the ranks sum their valid-feature counts
+ * (the decomposition needs n < that sum) and V comes back with P_local rows, zeros at the masked features; and modes beyond
+ * the numerical rank keep both factors orthonormal as in eofx_fit_f32 (the feature-side one through its all-reduced Gram). */
 int eofx_fit_sharded_f32(eofx_ctx *ctx, const float *X, int64_t n, int64_t P_local, int64_t P_total, int center,
                          int standardize, const double *feat_weights, int k, int n_oversamples, int n_iter,
                          const float *omega, int64_t omega_rows, int flip, eofx_mat **out, double *mean, double *std,
                          uint8_t *valid_feature, double *total_variance, float *U, float *s, float *V);
+
+/* ---- the other two sharded decompositions (round 6: the 8-GPU forms of BASELINE configs 3 and 5) -------------------------
+ * All-reduce of a small HOST vector of doubles over the context's communicator, in stream order: the global facts a sharded
+ * preprocess needs between engine calls (feature counts per rank, the Sanitizer's sample votes -- sanitizer.py:58-126 --,
+ * variances), so that a sharded model issues EVERY collective through the engine.  op: 0 sum, 1 max, 2 min.           */
+int eofx_ctx_comm_allreduce_f64(eofx_ctx *ctx, double *host_buf, int64_t count, int op);
+/* eofx_crosscov_rsvd_f32 (cross/cpcca.py:168-225, 991-1015) with BOTH fields sharded along their own feature axes: x / y
+ * are this rank's slices [n x p1_local], [n x p2_local] of fields with p1_total / p2_total features over all ranks, the
+ * slice's first feature at p1_offset / p2_offset of the global (valid-feature) axis.  C = X^T Y is never formed; both of
+ * its sides are sharded: every sample-side panel (Y Z, X W) is all-reduced (n x L float32), every L x L float64 Gram
+ * matrix of a feature-side panel too, and with tsc != NULL the two n x n sample-space Gram matrices once (the power
+ * iterations then run replicated in sample space without touching the fields or the links).
+ *   omega   host, THIS RANK'S ROWS of the global sketch [min(p1_total, p2_total) x (k + n_oversamples)] (one draw, the
+ *           same on every rank): the rows of the features of the narrower field's slice, [p_local x (k + n_oversamples)]
+ *           (for a masked in-place slice: its physical rows, zero rows at the masked features)
+ * outputs: Q1 / Q2 = this rank's rows [p1_local x k] / [p2_local x k]; s, scores, norms, tsc replicated (bit-identical
+ * on every rank).  At world size 1 the call reproduces eofx_crosscov_rsvd_f32 bit for bit.                           */
+int eofx_crosscov_rsvd_sharded_f32(eofx_ctx *ctx, const eofx_mat *x, const eofx_mat *y, int64_t p1_total,
+                                   int64_t p1_offset, int64_t p2_total, int64_t p2_offset, int k, int n_oversamples,
+                                   int n_iter, const float *omega, int flip, float *Q1, float *s, float *Q2,
+                                   float *scores1, float *scores2, float *norm1, float *norm2, double *tsc);
+/* eofx_rsvd_c64 / eofx_rsvd_hilbert_c64 (decomposer.py:149-160; single/eof.py:433-447,546-555) on this rank's slice of
+ * the feature axis of a complex field / of the analytic signal of a real field with p_total (valid) features over all
+ * ranks, n < p_total.  The block-Krylov recurrence lives on the replicated sample side; per product Z Y one all-reduce of
+ * the n x LP float32 panel, per factorised feature-side panel one of LP x LP float64, two small ones for the sign rule.
+ * The Hilbert operator Hc (n x n, resident on every rank) acts on the replicated sample-side panel, so the operator
+ * route -- every pass streams the REAL slice once, the imaginary part is never written -- shards without further
+ * exchange.  omega: host [n x (k + n_oversamples)], identical on every rank.  U [n x k], s replicated; V = this rank's
+ * rows [p_local x k] (for a masked in-place slice: its physical rows, zeros at masked features).                    */
+int eofx_rsvd_sharded_c64(eofx_ctx *ctx, const eofx_mat *A, const eofx_mat *B, int64_t p_total, int k,
+                          int n_oversamples, int n_iter, const float *omega, int flip_signs, float *U, float *s,
+                          float *V);
+int eofx_rsvd_hilbert_sharded_c64(eofx_ctx *ctx, const eofx_mat *A, int64_t p_total, int padding,
+                                  double decay_factor, int k, int n_oversamples, int n_iter, const float *omega,
+                                  int flip_signs, float *U, float *s, float *V);
 
 /* power iterations the last eofx_rsvd_c64 on this context made (n_iter < 0 there = iterate until the Ritz values stand
  * still: the reference's complex branch, scipy svds(solver="lobpcg"), converges to a tolerance -- decomposer.py:149-160) */
@@ -420,6 +459,10 @@ int eofx_rsvd_c64(eofx_ctx *ctx, const eofx_mat *A, const eofx_mat *B, int k, in
  * use the two calls).  A may be an in-place or masked in-place matrix.                                             */
 int eofx_rsvd_hilbert_c64(eofx_ctx *ctx, const eofx_mat *A, int padding, double decay_factor, int k, int n_oversamples,
                           int n_iter, const float *omega, int flip_signs, float *U, float *s, float *V);
+/* The operator itself: out [n x n] (host, row-major float32) = Hc with Im = Hc A for the Hilbert stage of eofx_hilbert_f32
+ * along the samples (utils/hilbert_transform.py:40-114 is linear in the series; built in float64).  For panel-level
+ * drivers that apply it to a sample-side panel themselves (the feature-sharded fallback driver, xeofs_amd/complex_svd.py). */
+int eofx_hilbert_operator_f32(eofx_ctx *ctx, int64_t n, int padding, double decay_factor, float *out);
 /* sum of squares of the imaginary part eofx_hilbert_f32 would write for `a` (total variance of the analytic signal =
  * (eofx_mat_sumsq_f64(a) + this) / (n - 1); reference single/eof.py:93 on the complex field), computed by the same
  * kernel with its stores switched off; consumes the transposed raw layout of eofx_ctx_set_sample_raw like the stage. */

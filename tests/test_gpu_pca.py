@@ -227,3 +227,74 @@ def test_blocked_device_cholesky_qr(ctx, l):
     Gh = G.cpu().numpy()[np.ix_(keep, keep)]
     Rn = np.linalg.inv(np.linalg.cholesky(Gh).T)
     assert np.allclose(R[np.ix_(keep, keep)], Rn, rtol=1e-6, atol=1e-9 * np.abs(Rn).max())
+
+
+def test_basis_only_fast_path_against_the_eigh_route(ctx):
+    """the `basis_only` fast path (the default of every MCA / CPCCA fit with alpha = 1 whose variance target is out of
+    reach) drops the bottom of the sketch's spectrum through an inverse subspace iteration instead of the order-ell
+    eigen-decomposition.  A/B against the eigh route on the SAME sketch: the iteration's own residual check passes, the kept
+    subspaces agree (largest principal angle, captured variance), the downstream cross-covariance decomposition agrees, and the
+    path does not pretend to have a spectrum (`s` raises, `singular_values_all` is None)."""
+    import torch
+
+    from xeofs_amd import engine
+    from xeofs_amd.pca import ResidentPCA
+
+    n, p = 1280, 6000
+    rng = np.random.default_rng(3)
+    T = rng.standard_normal((n, 30)) * (6.0 * 0.85 ** np.arange(30))
+    X = (T @ rng.standard_normal((30, p)) + 0.5 * rng.standard_normal((n, p))).astype(np.float32)
+    Y = (T[:, :20] @ rng.standard_normal((20, 4000)) + 0.5 * rng.standard_normal((n, 4000))).astype(np.float32)
+    X -= X.mean(0)
+    Y -= Y.mean(0)
+    mx, my = engine.from_dense(ctx, X), engine.from_dense(ctx, Y)
+    tvx, tvy = orc.total_variance(X.astype(np.float64)), orc.total_variance(Y.astype(np.float64))
+    fits = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")      # "Dataset has 384 components, explaining ..." (both routes warn, as the reference)
+        for fast in (True, False):
+            px = ResidentPCA(ctx, 0.999, solver="randomized", random_state=11, basis_only=fast).fit(mx, tvx)
+            py = ResidentPCA(ctx, 0.999, solver="randomized", random_state=12, basis_only=fast).fit(my, tvy)
+            fits[fast] = (px, py)
+    pf, pe = fits[True][0], fits[False][0]
+    assert pf.solver_used == pe.solver_used == "randomized"
+    assert not pf.spectrum_known and pe.spectrum_known and pf.m == pe.m == int(0.3 * n)
+    assert pf.fast_path_residual is not None and pf.fast_path_residual <= 5e-2
+    with pytest.raises(RuntimeError):
+        pf.s
+    assert pf.singular_values_all is None and pe.singular_values_all is not None
+    # kept subspaces: both orthonormal bases of (nearly) the same space
+    Vf = torch.as_tensor(pf.components(), device="cuda").double()
+    Ve = torch.as_tensor(pe.components(), device="cuda").double()
+    eye = torch.eye(pf.m, device="cuda", dtype=torch.float64)
+    assert float((Vf.T @ Vf - eye).abs().max()) < 2e-5 and float((Ve.T @ Ve - eye).abs().max()) < 2e-5
+    cosines = torch.linalg.svdvals(Vf.T @ Ve)
+    # The dropped directions are Ritz directions to 5e-2 of their value.  Where the sketch's spectrum is flat at the cut (here:
+    # a noise tail) WHICH of several directions of equal variance is dropped is not determined at that tolerance -- nor by the
+    # reference, whose sketch is unseeded --, so single principal angles next to the cut may be large; what must hold: the two
+    # bases share all but a sliver (at most n_oversamples directions turned by more than 8 degrees, less than 2.5 dimensions
+    # exchanged in total) and capture the same variance.
+    assert int((cosines < 0.99).sum()) <= pf.n_oversamples, cosines[-16:]
+    assert float((1.0 - cosines ** 2).sum()) <= 2.5, cosines[-16:]
+    assert int((cosines < 1 - 1e-6).sum()) <= 4 * (pf.n_oversamples + 22)
+    # captured variance: the fast path keeps at least as much as exact bottom directions would lose (within 0.3 %)
+    Xd = torch.as_tensor(X, device="cuda").double()
+    cap_f, cap_e = float(((Xd @ Vf) ** 2).sum()), float(((Xd @ Ve) ** 2).sum())
+    assert abs(cap_f - cap_e) <= 3e-3 * cap_e
+    # scores stay X V on both routes
+    assert np.allclose(pf.scores(), (Xd @ Vf).cpu().numpy() * 1.0, rtol=0, atol=2e-4 * np.abs(pe.scores()).max())
+    # downstream: the cross-covariance decomposition on the two pairs of PC scores (what MCA does with them)
+    outs = {}
+    for fast in (True, False):
+        wx = engine.from_dense(ctx, fits[fast][0].scores().astype(np.float32))
+        wy = engine.from_dense(ctx, fits[fast][1].scores().astype(np.float32))
+        r = engine.crosscov_rsvd(ctx, wx, wy, 10, random_state=5)
+        r["c1"] = fits[fast][0].back_project(r["Q1"])
+        outs[fast] = r
+        wx.free(); wy.free()
+    sf, se = outs[True]["s"].astype(np.float64), outs[False]["s"].astype(np.float64)
+    assert np.all(np.abs(sf - se) <= 1e-4 * se[0]), (sf, se)
+    c = np.abs(np.sum(outs[True]["c1"].astype(np.float64) * outs[False]["c1"].astype(np.float64), axis=0))
+    assert np.all(c[:5] >= 1 - 1e-4), c
+    assert abs(outs[True]["total_squared_covariance"] / outs[False]["total_squared_covariance"] - 1) <= 2e-3
+    mx.free(); my.free()

@@ -279,6 +279,120 @@ def test_sharded_complex_rsvd_two_ranks_gloo(tmp_path, n, p, k):
     assert (orc.deterministic_sign_multiplier(V.conj().T) == 1).all()
 
 
+class NumpyHilbertOperatorOps(NumpyComplexOps):
+    """numpy stand-in for complex_svd.HilbertOperatorOps: this rank's REAL slice A and the n x n operator Hc of the Hilbert stage;
+    Z^H W = A^T (W - i Hc^T W), Z Y = (I + i Hc)(A Y) -- the imaginary part is never formed, and (as in the product ops) the
+    operator is applied to the rank's PARTIAL sum A_g Y_g before the driver's all-reduce (linearity)."""
+
+    def __init__(self, A, Hc):
+        NumpyComplexOps.__init__(self, A.astype(np.complex128))
+        self.A = np.asarray(A, dtype=np.float64)
+        self.Hc = np.asarray(Hc, dtype=np.float64)
+
+    def zh_mul(self, Wn, final=False):
+        W = self._c(Wn, self.n)
+        return self._p(self.A.T @ (W - 1j * (self.Hc.T @ W)), self.p_pad)
+
+    def z_mul(self, Yp, final=False):
+        T = self.A @ self._c(Yp, self.p)
+        return self._p(T + 1j * (self.Hc @ T), self.n_pad)
+
+
+def _hilbert_case(n, p, seed):
+    """a centred real field with a few propagating patterns and the operator of the oracle's Hilbert stage (exp padding): the
+    stage is linear along the samples, so its matrix is the transform of the identity"""
+    from oracle import eof_oracle as orc
+
+    rng = np.random.default_rng(seed)
+    t = np.arange(n)[:, None]
+    x = np.linspace(0, 2 * np.pi, p)[None, :]
+    A = sum(a * np.cos(2 * np.pi * t / per - m * x + ph) for a, per, m, ph in
+            [(5.0, 17.0, 1, 0.3), (3.0, 9.0, 2, 1.1), (2.0, 29.0, 3, 2.0), (1.2, 6.0, 4, 0.7)])
+    A = A + 0.2 * rng.standard_normal((n, p))
+    A = A - A.mean(axis=0)
+    Hc = orc.hilbert_transform(np.eye(n), "exp", 0.2).imag      # column j = the (re-centred, eof.py:546-555) transform of e_j
+    return A, Hc
+
+
+def _hworker(rank, world, port, n, p, k, out_dir):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from xeofs_amd import sharded
+    from xeofs_amd.complex_svd import complex_rsvd
+
+    A, Hc = _hilbert_case(n, p, 13)
+    lo, hi = sharded.shard_bounds(p, world, rank)
+    U, s, V = complex_rsvd(None, None, None, k, random_state=4, ops=NumpyHilbertOperatorOps(A[:, lo:hi], Hc),
+                           comm=sharded.Comm(), p_total=p, p_offset=lo)
+    np.savez(os.path.join(out_dir, f"h{rank}.npz"), U=U, s=s, V=V)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,p,k", [(96, 500, 5), (120, 333, 8)])
+def test_sharded_hilbert_operator_route_two_ranks_gloo(tmp_path, n, p, k):
+    """The operator route of the analytic signal, feature-sharded (the panel-level form of eofx_rsvd_hilbert_sharded_c64): every
+    rank holds its REAL slice and the n x n Hilbert operator; result = exact SVD of the oracle's analytic signal of the whole
+    field (single/eof.py:546-555 -> utils/hilbert_transform.py -> decomposer.py:149-160)."""
+    import torch.multiprocessing as mp
+
+    from oracle import eof_oracle as orc
+
+    mp.spawn(_hworker, args=(2, _free_port(), n, p, k, str(tmp_path)), nprocs=2, join=True)
+    parts = [np.load(tmp_path / f"h{r}.npz") for r in range(2)]
+    assert np.array_equal(parts[0]["U"], parts[1]["U"]) and np.array_equal(parts[0]["s"], parts[1]["s"])
+    V = np.concatenate([q["V"] for q in parts], axis=0)
+    U, s = parts[0]["U"], parts[0]["s"]
+    A, _ = _hilbert_case(n, p, 13)
+    Z = orc.hilbert_transform(A, "exp", 0.2)
+    Z = Z - Z.mean(axis=0)
+    Ue, se, Vhe = np.linalg.svd(Z, full_matrices=False)
+    assert np.all(np.abs(s - se[:k]) <= 2e-5 * se[:k] + 2e-6 * se[0])
+    for j in range(k):
+        if min(se[j - 1] - se[j] if j else np.inf, se[j] - se[j + 1]) < 2e-2 * se[j]:
+            continue
+        assert abs(np.vdot(Vhe[j].conj(), V[:, j])) >= 1 - 1e-4
+        assert abs(np.vdot(Ue[:, j], U[:, j])) >= 1 - 1e-4
+    assert (orc.deterministic_sign_multiplier(V.conj().T) == 1).all()
+
+
+def _cnull_worker(rank, world, port, n, p, r, k, out_dir):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from xeofs_amd import sharded
+    from xeofs_amd.complex_svd import complex_rsvd
+
+    rng = np.random.default_rng(21)
+    Z = (rng.standard_normal((n, r)) + 1j * rng.standard_normal((n, r))) @ (rng.standard_normal((r, p)) + 1j * rng.standard_normal((r, p)))
+    lo, hi = sharded.shard_bounds(p, world, rank)
+    U, s, V = complex_rsvd(None, None, None, k, random_state=4, ops=NumpyComplexOps(Z[:, lo:hi]),
+                           comm=sharded.Comm(), p_total=p, p_offset=lo)
+    np.savez(os.path.join(out_dir, f"n{rank}.npz"), U=U, s=s, V=V)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_complex_more_modes_than_rank_two_ranks_gloo(tmp_path):
+    """k = 8 modes of an exactly rank-3 complex field: the reference's solver (scipy svds ends in a dense SVD of A V) returns
+    orthonormal left vectors whatever the values; the panel-level complex driver re-orthonormalises the null columns of its
+    replicated sample-side factor on the host (round 6; the engine entry has done so since round 5)."""
+    import torch.multiprocessing as mp
+
+    n, p, r, k = 80, 300, 3, 8
+    mp.spawn(_cnull_worker, args=(2, _free_port(), n, p, r, k, str(tmp_path)), nprocs=2, join=True)
+    parts = [np.load(tmp_path / f"n{q}.npz") for q in range(2)]
+    assert np.array_equal(parts[0]["U"], parts[1]["U"])
+    U, s = parts[0]["U"].astype(np.complex128), parts[0]["s"]
+    assert np.all(s[r:] <= 1e-4 * s[0]) and np.all(s[:r] > 1e-2 * s[0])
+    assert np.abs(U.conj().T @ U - np.eye(k)).max() <= 1e-5
+
+
 # --------------------------------------------------------------------------- cross-covariance path, 2 ranks
 def _xy(n, p1, p2):
     rng = np.random.default_rng(9)

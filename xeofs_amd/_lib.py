@@ -84,8 +84,14 @@ SIGNATURES = {
     "eofx_ctx_comm_probe": (_int, [_vp, _int, _vp, _vp, _int, _vp, _vp]),
     "eofx_fit_sharded_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _int, _int, _vp, _int, _int, _int, _vp, _i64, _int,
                                     C.POINTER(_vp), _vp, _vp, _vp, _pd, _vp, _vp, _vp]),
+    "eofx_ctx_comm_allreduce_f64": (_int, [_vp, _vp, _i64, _int]),
+    "eofx_crosscov_rsvd_sharded_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _int, _int, _vp, _int, _vp, _vp,
+                                              _vp, _vp, _vp, _vp, _vp, _pd]),
+    "eofx_rsvd_sharded_c64": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _vp, _int, _vp, _vp, _vp]),
+    "eofx_rsvd_hilbert_sharded_c64": (_int, [_vp, _vp, _i64, _int, C.c_double, _int, _int, _int, _vp, _int, _vp, _vp, _vp]),
     "eofx_rsvd_c64": (_int, [_vp, _vp, _vp, _int, _int, _int, _vp, _int, _vp, _vp, _vp]),
     "eofx_rsvd_hilbert_c64": (_int, [_vp, _vp, _int, C.c_double, _int, _int, _int, _vp, _int, _vp, _vp, _vp]),
+    "eofx_hilbert_operator_f32": (_int, [_vp, _i64, _int, C.c_double, _vp]),
     "eofx_hilbert_sumsq_f64": (_int, [_vp, _vp, _int, C.c_double, C.POINTER(C.c_double)]),
     "eofx_orth_tall_rule": (_int, [_i64, _int, _int]),
     "eofx_peaked_spectrum": (_int, [_vp, _int, _int]),

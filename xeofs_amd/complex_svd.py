@@ -97,7 +97,41 @@ class ComplexOps:
         return engine.panel_export(self.ctx, P, rows, 2 * self.half, sign)
 
 
-KRYLOV_MAX_ORDER = 8 * 64       # (numpy solves the Rayleigh-Ritz problem here: every sketch width up to 64 at 7 products)
+class HilbertOperatorOps(ComplexOps):
+    """The analytic signal Z = (I + i Hc) A of this rank's REAL slice A without its imaginary part (the panel-level form of
+    the engine's operator route, eofx_rsvd_hilbert_c64): Hc is the n x n matrix of the Hilbert stage along the samples
+    (`engine.hilbert_operator`), resident as a matrix of its own; Z^H W = A^T (W - i Hc^T W) and Z Y = (I + i Hc)(A Y), so every
+    product streams the real slice once and applies Hc to an n x LP sample-side panel.  Feature-sharded: A Y is a partial sum
+    over the rank's features and (I + i Hc) is linear, so the driver's all-reduce of the finished panel gives the same sum.
+    Reference: single/eof.py:546-555 (the analytic signal) -> linalg/decomposer.py:149-160."""
+
+    def __init__(self, ctx, A, Hop):
+        if A.masked:
+            raise NotImplementedError("panel-level operator route on a masked in-place slice (preprocess without allow_masked)")
+        if Hop.n != A.n or Hop.p != A.n:
+            raise ValueError("the Hilbert operator must be n x n")
+        self.ctx, self.A, self.B, self.Hop = ctx, A, None, Hop
+        self.n, self.p, self.n_pad, self.p_pad = A.n, A.p, A.n_pad, A.p_pad
+        self.half = HALF
+
+    def zh_mul(self, Wn, final=False):
+        pr = self.ctx.precision[1 if final else 0]
+        T = engine.panel_tmul(self.ctx, self.Hop, Wn, prec=pr)                  # Hc^T [Wr | Wi]
+        R = engine.cpanel_combine(self.ctx, Wn, T, True, out=T)                 # W - i Hc^T W
+        return engine.panel_tmul(self.ctx, self.A, R, prec=pr)
+
+    def z_mul(self, Yp, final=False):
+        pr = self.ctx.precision[1 if final else 0]
+        T = engine.panel_mul(self.ctx, self.A, Yp, prec=pr)                     # A [Yr | Yi]  (partial sum over this slice)
+        HT = engine.panel_mul(self.ctx, self.Hop, T, prec=pr)                   # Hc T
+        return engine.cpanel_combine(self.ctx, T, HT, False, out=T)             # T + i Hc T
+
+
+# numpy solves the Rayleigh-Ritz problem here: every sketch width up to 64 at 7 products fits WITHOUT a restart.  The engine entry
+# (rsvd_c64_impl, csrc/eofx_abi.hip) keeps its host solver below order 384 with thick restarts instead, so for sketches of
+# 49 .. 64 columns the two drivers run different recurrences (same Krylov space up to the restart, both converge to the same
+# modes; results agree to the convergence level, not mode for mode in the unconverged tail) -- a deliberate divergence.
+KRYLOV_MAX_ORDER = 8 * 64
 
 
 def _block_krylov(ops, comm, Z0, q, l, half, small, tall, fwd, bwd, gram, orth, orth_tall):
@@ -230,8 +264,51 @@ class _NoComm:
         return t
 
 
+def _fix_null_small(P, rows, k, first, half):
+    """Numerically null modes (more modes asked for than the matrix has rank): the small-side vectors B^H u / s are rounding noise
+    there, where the reference's solver (scipy svds ends in a dense SVD of A V) returns orthonormal columns whatever the values.
+    Columns [first, k) of the REPLICATED small-side panel [Re | Im] are re-orthonormalised on the host against all the columns
+    before them (two rounds of Gram-Schmidt in complex128; a column inside their span is replaced by the first unit vector that
+    is not) -- the host algorithm of the engine entry (csrc/eofx_abi.hip, rsvd_c64_impl); values and the tall side are untouched."""
+    torch = engine._torch()
+    h = P.detach().cpu().numpy() if torch.is_tensor(P) else np.asarray(P)
+    Z = h[:rows, :k].astype(np.complex128) + 1j * h[:rows, half:half + k].astype(np.complex128)
+
+    def project_out(v, upto):
+        for _ in range(2):
+            for c in range(upto):
+                v = v - np.vdot(Z[:, c], v) * Z[:, c]
+        return v, float(np.linalg.norm(v))
+
+    next_unit = 0
+    for j in range(first, k):
+        v = Z[:, j].copy()
+        nn0 = float(np.linalg.norm(v))
+        if np.isfinite(nn0) and nn0 > 0.0:
+            v, nn = project_out(v, j)
+            nn /= nn0
+        else:
+            nn = 0.0
+        while not nn > 1e-3 and next_unit < rows:
+            v = np.zeros(rows, np.complex128)
+            v[next_unit] = 1.0
+            next_unit += 1
+            v, nn = project_out(v, j)
+            if nn > 0.1:
+                break
+            nn = 0.0
+        nrm = float(np.linalg.norm(v))
+        Z[:, j] = v / nrm if nrm > 0.0 else 0.0
+    out = h.copy()
+    out[:rows, first:k] = Z[:, first:k].real.astype(np.float32)
+    out[:rows, half + first:half + k] = Z[:, first:k].imag.astype(np.float32)
+    if torch.is_tensor(P):
+        return torch.as_tensor(out, device=P.device)
+    return out
+
+
 def complex_rsvd(ctx, A, B, k: int, n_oversamples: int = 10, n_iter="auto", random_state=None, flip=True,
-                 ops=None, comm=None, p_total=None, p_offset=0):
+                 ops=None, comm=None, p_total=None, p_offset=0, omega=None):
     """-> (U[n,k] complex64, s[k] float32, V[p_local,k] complex64) with Z ~ U diag(s) V^H, V = conj(VT).T.
 
     Single GPU: `complex_rsvd(ctx, A, B, k, ...)`.  Feature-sharded: every rank passes its slice
@@ -258,6 +335,11 @@ def complex_rsvd(ctx, A, B, k: int, n_oversamples: int = 10, n_iter="auto", rand
         n_iter = 7 if k < 0.1 * r else 4
     if l == r:      # full-width sketch spans everything: identity, not an ill-conditioned square Gaussian
         omega = np.eye(r, dtype=np.float32)
+    elif omega is not None:                                                       # the caller's draw (one for all ranks)
+        omega = np.asarray(omega.result() if hasattr(omega, "result") else omega, dtype=np.float32)
+        if omega.shape != (r, k + n_oversamples):
+            raise ValueError(f"omega must have shape {(r, k + n_oversamples)}")
+        omega = omega[:, :l]
     else:
         omega = engine.sketch_matrix(r, k + n_oversamples, random_state)[:, :l]   # real Gaussian start
     transposed = n < p      # A_op = Z^H: tall side = features (sharded), small side = samples
@@ -321,6 +403,13 @@ def complex_rsvd(ctx, A, B, k: int, n_oversamples: int = 10, n_iter="auto", rand
         inv = np.where(s > 0, 1.0 / s, 0.0)
     Tall = ops.right_mul(Q, Uh)                         # A_op = Tall diag(s) Small^H
     Small = ops.right_mul(Bt, Uh * inv)
+    # numerically null modes: the small-side factor stays orthonormal (the replicated sample side of the sharded case, or any
+    # single-rank call; a SHARDED small side would need its Gram matrix reduced -- n >= p_total, not a sharded use case)
+    first_null = k
+    while first_null > 0 and not (s[first_null - 1] > 3e-6 * s[0]):
+        first_null -= 1
+    if first_null < k and s[0] > 0.0 and (small == "n" or getattr(comm, "world", 1) == 1):
+        Small = _fix_null_small(Small, n if small == "n" else p_loc, k, first_null, half)
     Up, Vp = (Small, Tall) if transposed else (Tall, Small)
     sign = np.ones(k)
     if flip:

@@ -26,6 +26,7 @@
 #include <string>
 #include <thread>
 #include <mutex>
+#include <shared_mutex>
 #include <condition_variable>
 #include <deque>
 #include <memory>
@@ -262,6 +263,64 @@ static int set_device(eofx_ctx* ctx) {
   return EOFX_OK;
 }
 
+// ------------------------------------------------------------------------------------
+// Fence between the contexts of ONE process on one GPU.  Measured on this platform: FFT-type kernels -- the
+// engine's transform kernel and rocFFT alike -- return occasional wrong 64-byte pieces while the split-fp16 in-place streaming
+// kernels of ANOTHER stream share the chip (tools/thread_probe2/3/5.py: 72 % of rocFFT calls beside the in-place X^T Z kernel, 0
+// alone; rocSOLVER's eigh, elementwise kernels and sorts are never affected; LDS / register canaries stay intact).  The cause is
+// below the engine; the engine's own transform kernel is fenced instead: every entry point holds this device's lock SHARED
+// for its duration, the Hilbert entries hold it EXCLUSIVE -- they first wait for the kernels every other context of the device
+// has queued, and finish their own before they let go.  Re-entrant per thread (entries call entries); uncontended cost: one
+// shared-lock acquisition per entry (~50 ns).  Other processes on the same GPU, and FFT work the host application runs on its own
+// streams, are outside this fence.
+// ------------------------------------------------------------------------------------
+constexpr int EOFX_MAX_DEVICES = 64;
+struct DeviceFence {
+  std::shared_mutex mu;
+  std::mutex reg_mu;
+  std::vector<eofx_ctx*> ctxs;      // live contexts on this device
+};
+static DeviceFence g_fence[EOFX_MAX_DEVICES];
+static thread_local int t_fence_depth[EOFX_MAX_DEVICES];
+struct FenceGuard {
+  eofx_ctx* ctx;
+  int dev = -1;
+  bool took = false, excl = false;
+  FenceGuard(eofx_ctx* c, bool exclusive) : ctx(c) {
+    if (!c || c->device < 0 || c->device >= EOFX_MAX_DEVICES) return;
+    dev = c->device;
+    if (t_fence_depth[dev]++ > 0) return;        // nested entry on this thread: the outermost guard holds the lock
+    took = true;
+    excl = exclusive;
+    DeviceFence& f = g_fence[dev];
+    if (!exclusive) {
+      f.mu.lock_shared();
+      return;
+    }
+    f.mu.lock();                                  // no other entry of this process is running on the device now ...
+    std::lock_guard<std::mutex> g(f.reg_mu);
+    for (eofx_ctx* o : f.ctxs)                    // ... and what the other contexts left queued has finished
+      if (o != c && o->stream != c->stream) (void)hipStreamSynchronize(o->stream);
+  }
+  ~FenceGuard() {
+    if (dev < 0) return;
+    const bool outermost = --t_fence_depth[dev] == 0;
+    if (!took || !outermost) return;
+    if (excl) {
+      (void)hipStreamSynchronize(ctx->stream);    // the transform has finished before any other context may queue a pass
+      g_fence[dev].mu.unlock();
+    } else {
+      g_fence[dev].mu.unlock_shared();
+    }
+  }
+};
+#define ENTER(c)          \
+  FenceGuard _fence((c), false); \
+  CHK(set_device(c))
+#define ENTER_EXCLUSIVE(c)      \
+  FenceGuard _fence((c), true); \
+  CHK(set_device(c))
+
 extern "C" int eofx_abi_version(void) { return EOFX_ABI_VERSION; }
 
 extern "C" int eofx_ctx_create(int device, void* stream, eofx_ctx** out) {
@@ -275,11 +334,23 @@ extern "C" int eofx_ctx_create(int device, void* stream, eofx_ctx** out) {
     *out = nullptr;
     return EOFX_ERR_HIP;
   }
+  if (device >= 0 && device < EOFX_MAX_DEVICES) {
+    std::lock_guard<std::mutex> g(g_fence[device].reg_mu);
+    g_fence[device].ctxs.push_back(ctx);
+  }
   *out = ctx;
   return EOFX_OK;
 }
 extern "C" int eofx_ctx_destroy(eofx_ctx* ctx) {
   if (!ctx) return EOFX_OK;
+  {
+    FenceGuard fence(ctx, false);
+    if (ctx->device >= 0 && ctx->device < EOFX_MAX_DEVICES) {
+      std::lock_guard<std::mutex> g(g_fence[ctx->device].reg_mu);
+      auto& v = g_fence[ctx->device].ctxs;
+      v.erase(std::remove(v.begin(), v.end(), ctx), v.end());
+    }
+  }
   (void)hipSetDevice(ctx->device);
   if (ctx->arena) {
     (void)hipStreamSynchronize(ctx->stream);
@@ -314,7 +385,7 @@ extern "C" int eofx_ctx_destroy(eofx_ctx* ctx) {
 // driver, the model classes' glue) are ordered with the engine's kernels on any stream, not only on the default one.
 extern "C" int eofx_ctx_set_stream(eofx_ctx* ctx, void* stream) {
   if (!ctx) return EOFX_ERR_ARG;
-  CHK(set_device(ctx));
+  ENTER(ctx);
   if ((hipStream_t)stream == ctx->stream) return EOFX_OK;
   HIPCHK(hipStreamSynchronize(ctx->stream));
   ctx->stream = (hipStream_t)stream;
@@ -328,7 +399,7 @@ extern "C" int eofx_ctx_set_stream(eofx_ctx* ctx, void* stream) {
 }
 extern "C" int eofx_ctx_synchronize(eofx_ctx* ctx) {
   if (!ctx) return EOFX_ERR_ARG;
-  CHK(set_device(ctx));
+  ENTER(ctx);
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return EOFX_OK;
 }
@@ -342,7 +413,7 @@ extern "C" int eofx_ctx_profile(eofx_ctx* ctx, int enable) {
 extern "C" int eofx_ctx_profile_read(eofx_ctx* ctx, int64_t* launches, double* total_ms, double* flops,
                                      double* bytes) {
   if (!ctx) return EOFX_ERR_ARG;
-  CHK(set_device(ctx));
+  ENTER(ctx);
   HIPCHK(hipStreamSynchronize(ctx->stream));
   double ms = 0.0;
   for (int k = 0; k < 3; ++k) {
@@ -1004,11 +1075,10 @@ static int launch_matmul(eofx_ctx* ctx, const float* P, int64_t rows, int L, con
     if (kw_env == 128 || kw_env == 256) KW = kw_env;
   }
   const size_t smem = (size_t)KW * PMM_LD * sizeof(double);         // 33 .. 132 KB
-  static size_t attr_smem = 0;    // opt in to more than 64 KB of dynamic LDS when a wide panel asks for it
-  if (smem > 64 * 1024 && smem > attr_smem) {
+  // opt in to more than 64 KB of dynamic LDS when a wide panel asks for it.  The attribute belongs to the (device, function) pair:
+  // set whenever needed (a cheap host call), not remembered in a process-global -- contexts on several devices or threads
+  if (smem > 64 * 1024)
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_matmul_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    attr_smem = smem;
-  }
   const int64_t units = (rows + 127) / 128;        // 4 waves x 32 rows
   const int64_t gx = L <= KW ? std::min<int64_t>(units, 1024) : units;   // windowed form: one group per wave
   dim3 grid((int)std::max<int64_t>(1, gx), (Lo + 63) / 64);
@@ -1023,11 +1093,8 @@ static int launch_matmul_gen(eofx_ctx* ctx, const float* P, int64_t ldp, int64_t
                              const float* sub, float* out) {
   const int KW = (int)std::min<int64_t>(round_up(L, 64), 256);
   const size_t smem = (size_t)KW * PMM_LD * sizeof(double);
-  static size_t attr_smem = 0;
-  if (smem > 64 * 1024 && smem > attr_smem) {
+  if (smem > 64 * 1024)      // (per device and function: set whenever needed, see launch_matmul)
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_matmul_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    attr_smem = smem;
-  }
   const int64_t units = (rows + 127) / 128;
   const int64_t gx = L <= KW ? std::min<int64_t>(units, 1024) : units;
   dim3 grid((int)std::max<int64_t>(1, gx), (Lo + 63) / 64);
@@ -1194,12 +1261,19 @@ static void pool_give(eofx_ctx* ctx, void* p, size_t bytes) {
   }
   // (exact-size reuse: a run of differently shaped fits would otherwise pile up buffers nobody asks for again -- 3.5 MB per fit
   // in tools/soak_probe.py, up to the byte cap; the entry cap keeps what one or two repeated shapes need)
-  constexpr size_t POOL_MAX_ENTRIES = 48;
-  while (!ctx->pool.empty() && (ctx->pool_bytes + bytes > ctx->pool_cap || ctx->pool.size() >= POOL_MAX_ENTRIES)) {
+  // Eviction is BATCHED: a workload whose steady state cycles through more shapes than the pool holds would
+  // otherwise pay a stream synchronisation (and hipFree's own device synchronisation) on every give; when a cap is hit the
+  // oldest quarter of the entries goes in one sweep behind ONE synchronisation, so at most one give in twelve stalls.
+  constexpr size_t POOL_MAX_ENTRIES = 48, POOL_EVICT_BATCH = 12;
+  if (!ctx->pool.empty() && (ctx->pool_bytes + bytes > ctx->pool_cap || ctx->pool.size() >= POOL_MAX_ENTRIES)) {
     (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(ctx->pool.front().first);
-    ctx->pool_bytes -= ctx->pool.front().second;
-    ctx->pool.erase(ctx->pool.begin());
+    size_t evicted = 0;
+    while (!ctx->pool.empty() && (evicted < POOL_EVICT_BATCH || ctx->pool_bytes + bytes > ctx->pool_cap)) {
+      (void)hipFree(ctx->pool.front().first);
+      ctx->pool_bytes -= ctx->pool.front().second;
+      ctx->pool.erase(ctx->pool.begin());
+      ++evicted;
+    }
   }
   ctx->pool.emplace_back(p, bytes);
   ctx->pool_bytes += bytes;
@@ -1397,7 +1471,7 @@ extern "C" int eofx_ctx_set_sample_raw(eofx_ctx* ctx, int on) {
 }
 extern "C" int eofx_mat_release_raw(eofx_ctx* ctx, eofx_mat* m) {
   if (!ctx || !m) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
-  CHK(set_device(ctx));
+  ENTER(ctx);
   if (m->raw && !m->Xt && !m->X) CHK(ensure_Xt(ctx, m));   // in place: the field is the only copy -- materialise first
   HIPCHK(hipStreamSynchronize(ctx->stream));   // passes still reading the raw field
   if (m->raw_owned) pool_give(ctx, m->raw_owned, m->raw_owned_bytes);
@@ -1412,7 +1486,7 @@ extern "C" int eofx_mat_release_raw(eofx_ctx* ctx, eofx_mat* m) {
 // with 8 GB to spare.  Masked in-place matrices keep their single layout.
 extern "C" int eofx_mat_ensure_sample_layout(eofx_ctx* ctx, eofx_mat* m, int only_if_room, int* built) {
   if (!ctx || !m) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
-  CHK(set_device(ctx));
+  ENTER(ctx);
   if (built) *built = m->Xt != nullptr;
   if (m->Xt || m->masked) return EOFX_OK;
   if (only_if_room) {
@@ -1432,7 +1506,7 @@ extern "C" int eofx_mat_ensure_sample_layout(eofx_ctx* ctx, eofx_mat* m, int onl
 // The memory goes back to the context's pool.  A matrix whose only data is that layout keeps it (EOFX_OK, nothing done).
 extern "C" int eofx_mat_release_sample_layout(eofx_ctx* ctx, eofx_mat* m) {
   if (!ctx || !m) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
-  CHK(set_device(ctx));
+  ENTER(ctx);
   if (!m->Xt || !(m->X || (m->raw && m->aff))) return EOFX_OK;
   HIPCHK(hipStreamSynchronize(ctx->stream));   // kernels that read it may still be in flight
   pool_give(ctx, m->Xt, (size_t)m->n_pad * m->p_pad * sizeof(float));
@@ -1455,7 +1529,7 @@ extern "C" int eofx_mat_layout(const eofx_mat* m, int* has_x, int* has_raw) {
 extern "C" int eofx_mat_from_dense_f32(eofx_ctx* ctx, const float* X, int64_t n, int64_t p, int64_t ld,
                                        eofx_mat** out) {
   if (!ctx || !X || !out || n <= 0 || p <= 0 || ld < p) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
-  CHK(set_device(ctx));
+  ENTER(ctx);
   Staged st;
   CHK(stage_input(ctx, X, (size_t)n * ld, st));
   eofx_mat* m = nullptr;
@@ -1476,7 +1550,7 @@ extern "C" int eofx_mat_from_dense_f32(eofx_ctx* ctx, const float* X, int64_t n,
 
 extern "C" int eofx_mat_download_f32(eofx_ctx* ctx, const eofx_mat* m, float* dst) {
   if (!ctx || !m || !dst) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
-  CHK(set_device(ctx));
+  ENTER(ctx);
   const int64_t total = m->n * m->p;
   const bool dev = is_device_ptr(dst);
   float* tmp = dst;
@@ -1730,7 +1804,7 @@ extern "C" int eofx_preprocess_f32(eofx_ctx* ctx, const float* X, int64_t n, int
                                    uint8_t* valid_sample, int64_t* n_out, int64_t* p_out,
                                    double* total_variance) {
   if (!ctx || !X || n <= 0 || P <= 0) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
-  CHK(set_device(ctx));
+  ENTER(ctx);
   Staged st;
   CHK(stage_input(ctx, X, (size_t)n * P, st));
   CHK(arena_reserve(ctx, colstats_scratch(n, P)));
@@ -1789,7 +1863,7 @@ extern "C" int eofx_apply_f32(eofx_ctx* ctx, const float* X, int64_t n, int64_t 
                               const double* std_, const double* feat_weights, const uint8_t* valid_feature,
                               int check_nans, eofx_mat** out, uint8_t* valid_sample, int64_t* n_out) {
   if (!ctx || !X || !out || n <= 0 || P <= 0) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
-  CHK(set_device(ctx));
+  ENTER(ctx);
   Staged st;
   CHK(stage_input(ctx, X, (size_t)n * P, st));
   CHK(arena_reserve(ctx, colstats_scratch(n, P)));
@@ -1843,7 +1917,7 @@ extern "C" int eofx_apply_f32(eofx_ctx* ctx, const float* X, int64_t n, int64_t 
 extern "C" int eofx_resample_f32(eofx_ctx* ctx, const eofx_mat* src, const int64_t* rows, int64_t n_rows,
                                  int center, eofx_mat** out, double* mean, double* total_variance) {
   if (!ctx || !src || !rows || !out || n_rows <= 0) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
-  CHK(set_device(ctx));
+  ENTER(ctx);
   for (int64_t i = 0; i < n_rows; ++i)
     if (rows[i] < 0 || rows[i] >= src->n)
       return set_err(ctx, EOFX_ERR_ARG, "row index %lld out of range [0, %lld)", (long long)rows[i], (long long)src->n);
@@ -1971,7 +2045,7 @@ extern "C" int eofx_ctx_set_precision(eofx_ctx* ctx, int power_passes, int final
 extern "C" int eofx_panel_tmul_f32(eofx_ctx* ctx, const eofx_mat* m, const float* Zn, float* Yp, int L,
                                    int prec) {
   if (!ctx || !m || !Zn || !Yp || !valid_prec(prec)) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
-  CHK(set_device(ctx));
+  ENTER(ctx);
   size_t need = atb_scratch_bytes(m->p_pad, round_up(m->n, ATB_KG), L);
   if (prec == EOFX_PREC_F16X3 && tmul_nt_ok(m, L)) need = std::max(need, tmul_nt_scratch(ctx, m, L));
   CHK(arena_reserve(ctx, need));
@@ -1980,33 +2054,33 @@ extern "C" int eofx_panel_tmul_f32(eofx_ctx* ctx, const eofx_mat* m, const float
 extern "C" int eofx_panel_mul_f32(eofx_ctx* ctx, const eofx_mat* m, const float* Yp, float* Wn, int L,
                                   int prec) {
   if (!ctx || !m || !Wn || !Yp || !valid_prec(prec)) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
-  CHK(set_device(ctx));
+  ENTER(ctx);
   CHK(arena_reserve(ctx, atb_scratch_bytes(m->n_pad, round_up(m->p, ATB_KG), L)));
   return panel_mul(ctx, m, Yp, Wn, L, prec);
 }
 extern "C" int eofx_panel_gram_f64(eofx_ctx* ctx, const float* P, int64_t rows_pad, int L, double* G) {
   if (!ctx || !P || !G || L % 32) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
-  CHK(set_device(ctx));
+  ENTER(ctx);
   CHK(arena_reserve(ctx, (size_t)(4 * gram_parts(rows_pad, L) + 1) * L * L * sizeof(double)));
   return launch_gram(ctx, P, rows_pad, L, G);
 }
 extern "C" int eofx_panel_cholqr_f32(eofx_ctx* ctx, const float* P, int64_t rows_pad, int L, int l,
                                      const double* G, float* out) {
   if (!ctx || !P || !G || !out || P == out) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
-  CHK(set_device(ctx));
+  ENTER(ctx);
   CHK(arena_reserve(ctx, (size_t)2 * L * L * sizeof(double) + (l > 64 ? rinv_blocked_bytes(l) : 0)));
   return launch_cholqr(ctx, P, rows_pad, L, l, G, out);
 }
 extern "C" int eofx_panel_rinv_f64(eofx_ctx* ctx, const double* G, int L, int l, double* Rinv) {
   if (!ctx || !G || !Rinv || L <= 0 || l <= 0 || l > L || G == Rinv) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
-  CHK(set_device(ctx));
+  ENTER(ctx);
   if (l > 64) CHK(arena_reserve(ctx, rinv_blocked_bytes(l)));
   return launch_rinv(ctx, G, L, l, Rinv);
 }
 extern "C" int eofx_panel_matmul_f32(eofx_ctx* ctx, const float* P, int64_t rows_pad, int L,
                                      const double* M, int Lo, float* out) {
   if (!ctx || !P || !M || !out || P == out) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
-  CHK(set_device(ctx));
+  ENTER(ctx);
   // a wide panel times a wide matrix (the PCA pre-reduction's V = B W: 129 600 x 1536 by 1536 x 1504, 0.6 TFLOP) belongs on the
   // matrix cores: fp16 planes of both operands and the tiled NT kernel of eofx_gram.hpp (2.4 ms instead of 22 ms in the float64
   // VALU kernel below, which is made for panels of up to 256 columns)
@@ -2019,21 +2093,21 @@ extern "C" int eofx_panel_matmul_f32(eofx_ctx* ctx, const float* P, int64_t rows
 extern "C" int eofx_panel_colminmax_f32(eofx_ctx* ctx, const float* P, int64_t rows, int L, float* mx,
                                         float* mn) {
   if (!ctx || !P || !mx || !mn) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
-  CHK(set_device(ctx));
+  ENTER(ctx);
   CHK(arena_reserve(ctx, (size_t)2 * 1024 * L * sizeof(float) + 4096));
   return launch_colminmax(ctx, P, rows, L, mx, mn);
 }
 extern "C" int eofx_panel_export_f32(eofx_ctx* ctx, const float* P, int64_t rows, int L, int k,
                                      const double* sign, float* dst) {
   if (!ctx || !P || !dst || k > L) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
-  CHK(set_device(ctx));
+  ENTER(ctx);
   CHK(arena_reserve(ctx, (size_t)rows * k * sizeof(float) + 8192));
   return export_panel(ctx, P, rows, L, k, sign, dst);
 }
 extern "C" int eofx_panel_import_f32(eofx_ctx* ctx, const float* src, int64_t rows, int l, float* P,
                                      int64_t rows_pad, int L) {
   if (!ctx || !P || !src || l > L || rows > rows_pad) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
-  CHK(set_device(ctx));
+  ENTER(ctx);
   CHK(arena_reserve(ctx, (size_t)rows * l * sizeof(float) + 8192));
   return import_panel(ctx, src, rows, l, P, rows_pad, L);
 }
@@ -2048,6 +2122,11 @@ struct LinOp {
   // rows of the tall side sharded over ranks (eofx_fit_sharded_f32): every L x L float64 Gram matrix of a tall panel is
   // summed over the ranks by this hook (count doubles, device, in place, stream order); bwd then includes its own reduction
   std::function<int(double*, int64_t)> reduce_tall_gram;
+  // the same for the small side, when that is sharded as well (the cross-covariance operator X^T Y of two sharded fields)
+  std::function<int(double*, int64_t)> reduce_small_gram;
+  // padded row count of the WHOLE tall side over all ranks (0 = tall_pad): the rule that decides whether the tall panel is
+  // re-normalised in every iteration must come out the same on every rank -- it decides which collectives are issued
+  int64_t rule_tall_pad = 0;
 };
 
 struct RsvdOut {
@@ -2239,6 +2318,10 @@ static int rsvd_core(eofx_ctx* ctx, const LinOp& op, int k, int l, int n_iter, c
     CHK(launch_gram(ctx, Pn, op.tall_pad, L, Gout));
     return op.reduce_tall_gram ? op.reduce_tall_gram(Gout, (int64_t)L * L) : EOFX_OK;
   };
+  auto gram_small = [&](const float* Pn, double* Gout) -> int {
+    CHK(launch_gram(ctx, Pn, op.small_pad, L, Gout));
+    return op.reduce_small_gram ? op.reduce_small_gram(Gout, (int64_t)L * L) : EOFX_OK;
+  };
   // power iterations: Z <- orth(A^T (A Z)).  Only the small-side panel is orthonormalised
   // (Cholesky-QR with a float64 Gram matrix); the tall panel is never factorised here.
   const int pp = ctx->prec_power, pf = ctx->prec_final;
@@ -2248,7 +2331,7 @@ static int rsvd_core(eofx_ctx* ctx, const LinOp& op, int k, int l, int n_iter, c
   // Where the tall panel is small (<= EOFX_ORTH_TALL_BYTES) the extra Cholesky-QR costs microseconds and is
   // done; for large panels it made no measurable difference (tools/cond_study.py) and would cost 6 % of a
   // config-4 fit, so it is skipped there.
-  const bool orth_always = orth_tall_rule(op.tall_pad, L, pp);
+  const bool orth_always = orth_tall_rule(op.rule_tall_pad > 0 ? op.rule_tall_pad : op.tall_pad, L, pp);
   bool orth_rest = orth_always;
   // The peaked-spectrum question (one L x L download per fit) is asked after the first iteration and answered in the
   // MIDDLE of the second: the copy goes to page-locked memory behind an event, the next product is launched, and the
@@ -2274,7 +2357,7 @@ static int rsvd_core(eofx_ctx* ctx, const LinOp& op, int k, int l, int n_iter, c
     }
     if (rc != EOFX_OK) break;
     const bool ask = it == 0 && !orth_always && n_iter > 1;
-    if ((rc = launch_gram(ctx, Ws, op.small_pad, L, ask ? G0 : G)) != EOFX_OK) break;
+    if ((rc = gram_small(Ws, ask ? G0 : G)) != EOFX_OK) break;
     if (ask) {   // peaked spectrum?
       if (hipMemcpyAsync(pin, G0, sizeof(double) * L * L, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
           (!peaked_ev && hipEventCreateWithFlags(&peaked_ev, hipEventDisableTiming) != hipSuccess) ||
@@ -2306,7 +2389,7 @@ static int rsvd_core(eofx_ctx* ctx, const LinOp& op, int k, int l, int n_iter, c
   // B^T = A^T Q  (small x l);  B B^T = (B^T)^T (B^T)
   CHK(op.bwd(Qt, Zs, L, pf));                                  // A^T Q1 (Zs is free now)
   CHK(launch_matmul(ctx, Zs, op.small_pad, L, R2, L, Ws));     // (A^T Q1) R2^-1
-  CHK(launch_gram(ctx, Ws, op.small_pad, L, G));
+  CHK(gram_small(Ws, G));
   double* hG = pin;
   double* hR2 = pin + (size_t)L * L;
   HIPCHK(hipMemcpyAsync(hG, G, sizeof(double) * L * L, hipMemcpyDeviceToHost, ctx->stream));
@@ -2367,12 +2450,22 @@ static size_t rsvd_scratch_bytes(int64_t tall_pad, int64_t small_pad, int l, int
 }
 
 // xeofs sign rule (xarray_utils.py:273-301) from the per-mode max/min of VT
+static int comm_allreduce(eofx_ctx* ctx, void* buf, int64_t count, int dtype, int op);
+// over_ranks: the rows of Vpanel are this rank's slice of the feature axis -- one all-reduce(max) of [max | -min] over the
+// communicator of the context makes the extrema (and so the signs) global
 static int sign_rule(eofx_ctx* ctx, const float* Vpanel, int64_t rows, int Lo, int k,
-                     std::vector<double>& sign) {
+                     std::vector<double>& sign, bool over_ranks = false) {
   ArenaScope scope(ctx);
-  ARENA(float, mx, Lo);
-  ARENA(float, mn, Lo);
+  ARENA(float, mx, 2 * (size_t)Lo);
+  float* mn = mx + Lo;
   CHK(launch_colminmax(ctx, Vpanel, rows, Lo, mx, mn));
+  if (over_ranks) {
+    hipLaunchKernelGGL(negate_kernel, dim3(1), dim3(256), 0, ctx->stream, mn, Lo);
+    KCHK();
+    CHK(comm_allreduce(ctx, mx, 2 * (int64_t)Lo, 0, 1));
+    hipLaunchKernelGGL(negate_kernel, dim3(1), dim3(256), 0, ctx->stream, mn, Lo);
+    KCHK();
+  }
   std::vector<float> hmx(Lo), hmn(Lo);
   HIPCHK(hipMemcpyAsync(hmx.data(), mx, sizeof(float) * Lo, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipMemcpyAsync(hmn.data(), mn, sizeof(float) * Lo, hipMemcpyDeviceToHost, ctx->stream));
@@ -2391,9 +2484,14 @@ static int sign_rule(eofx_ctx* ctx, const float* Vpanel, int64_t rows, int Lo, i
 // matrix of the panel (N <- (N - G G^T N) R^-1, host algebra on Lo x Lo, two rounds); a column that is zero, not finite or
 // inside the span of the others is first replaced by a fixed pseudo-random vector (null_fill_kernel).  The columns before
 // `first` keep their bits.
-static int fix_null_columns(eofx_ctx* ctx, float* P, int64_t rows, int64_t rows_pad, int Lo, int k, int first) {
-  if (first >= k || rows <= first) return EOFX_OK;
-  {   // (the repair never turns a working call into an out-of-memory error: without room in the arena the columns stay)
+// `reduce` (optional): the rows of P are sharded over ranks -- the Gram matrix is summed over them (Lo x Lo doubles, device, in
+// place) and `rows_total` is the row count over all ranks; every rank then takes the same decisions from the same matrix.
+typedef std::function<int(double*, int64_t)> GramReduce;
+static int fix_null_columns(eofx_ctx* ctx, float* P, int64_t rows, int64_t rows_pad, int Lo, int k, int first,
+                            const GramReduce* reduce = nullptr, int64_t rows_total = -1) {
+  if (rows_total < 0) rows_total = rows;
+  if (first >= k || rows_total <= first) return EOFX_OK;
+  if (!reduce) {   // (the repair never turns a working call into an out-of-memory error: without room in the arena the columns stay)
     const size_t need = (size_t)rows_pad * Lo * 4 + (size_t)(gram_parts(rows_pad, Lo) + 4) * Lo * Lo * 8 + (64 << 10);
     if (ctx->arena_size - ctx->arena_off < need) return EOFX_OK;
   }
@@ -2405,9 +2503,10 @@ static int fix_null_columns(eofx_ctx* ctx, float* P, int64_t rows, int64_t rows_
   const int m = k - first;
   std::vector<double> hG((size_t)Lo * Lo), hM((size_t)Lo * Lo);
   std::vector<int> flag(Lo, 0);
-  const int blocks = (int)std::min<int64_t>((rows + 255) / 256, 4096);
+  const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((rows + 255) / 256, 4096));
   auto gram = [&]() -> int {
     CHK(launch_gram(ctx, P, rows_pad, Lo, G));
+    if (reduce && *reduce) CHK((*reduce)(G, (int64_t)Lo * Lo));
     HIPCHK(hipMemcpyAsync(hG.data(), G, sizeof(double) * Lo * Lo, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return EOFX_OK;
@@ -2499,14 +2598,16 @@ static int fix_null_columns(eofx_ctx* ctx, float* P, int64_t rows, int64_t rows_
 
 // both factors of a finished decomposition: modes whose value is below 1e-5 of the leading one (the level from which the
 // eigen-solver's 1e-15 no longer keeps two such vectors orthogonal to 1e-5) go through fix_null_columns
-static int fix_null_modes(eofx_ctx* ctx, const RsvdOut& ro, int64_t tall, int64_t small, int k) {
+static int fix_null_modes(eofx_ctx* ctx, const RsvdOut& ro, int64_t tall, int64_t small, int k,
+                          const GramReduce* reduce_tall = nullptr, int64_t tall_total = -1,
+                          const GramReduce* reduce_small = nullptr, int64_t small_total = -1) {
   int first_null = k;
   const double s0 = ro.s.empty() ? 0.0 : ro.s[0];
   for (int j = k - 1; j >= 0 && !(ro.s[j] > 1e-5 * s0); --j) first_null = j;
   // (a constant field: every value is zero, every column is replaced -- scikit-learn returns arbitrary orthonormal factors there too)
   if (first_null < k && s0 >= 0.0 && std::isfinite(s0) && ro.tall_pad >= tall && ro.small_pad >= small) {
-    CHK(fix_null_columns(ctx, ro.Tvec, tall, ro.tall_pad, ro.Lo, k, first_null));
-    CHK(fix_null_columns(ctx, ro.Svec, small, ro.small_pad, ro.Lo, k, first_null));
+    CHK(fix_null_columns(ctx, ro.Tvec, tall, ro.tall_pad, ro.Lo, k, first_null, reduce_tall, tall_total));
+    CHK(fix_null_columns(ctx, ro.Svec, small, ro.small_pad, ro.Lo, k, first_null, reduce_small, small_total));
   }
   return EOFX_OK;
 }
@@ -2532,7 +2633,7 @@ static int rsvd_finish(eofx_ctx* ctx, const RsvdOut& ro, bool transposed, int64_
 extern "C" int eofx_rsvd_f32(eofx_ctx* ctx, const eofx_mat* m, int k, int n_oversamples, int n_iter,
                              const float* omega, int flip, float* U, float* s, float* V) {
   if (!ctx || !m || !omega || k <= 0 || n_oversamples < 0) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
-  CHK(set_device(ctx));
+  ENTER(ctx);
   const int64_t n = m->n, p = m->p, r = std::min(n, p);
   if (k > r)
     return set_err(ctx, EOFX_ERR_RANK,
@@ -2596,6 +2697,7 @@ struct FitFirst {
   unsigned* hword = nullptr;
   float a_scale = 1.f;
   bool maybe_masked = false;
+  bool sharded = false;      // a slice of a sharded field: the range rule of the masked layout is the caller's (global counts)
   eofx_mat* m = nullptr;
   FeatSummary fs;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -2762,7 +2864,7 @@ struct FitFirst {
       return EOFX_FIT_FALLBACK;
     }
     if (fs.pv < P) {   // all-NaN grid points: the masked in-place layout, under the conditions of sanitize_and_apply
-      if (!(ctx->allow_masked && 10 * fs.pv >= 6 * P && n < fs.pv)) {
+      if (!(ctx->allow_masked && (sharded || (10 * fs.pv >= 6 * P && n < fs.pv)))) {
         ctx->fit_info[2] = 6.0;                          // a mask outside the in-place range (too many points, n >= valid p)
         return EOFX_FIT_FALLBACK;
       }
@@ -2850,7 +2952,7 @@ extern "C" int eofx_fit_first_f32(eofx_ctx* ctx, const float* X, int64_t n, int6
                                   int64_t* n_out, int64_t* p_out, double* total_variance, int* fused) {
   if (!ctx || !X || !out || !Zn || !Yp || n <= 0 || P <= 0 || L <= 0 || L % 32 || l <= 0 || l > L)
     return set_err(ctx, EOFX_ERR_ARG, "bad argument");
-  CHK(set_device(ctx));
+  ENTER(ctx);
   if (fused) *fused = 0;
   ctx->fit_info[0] = ctx->fit_info[1] = ctx->fit_info[2] = 0.0;
   Staged st;
@@ -2902,7 +3004,7 @@ extern "C" int eofx_fit_f32(eofx_ctx* ctx, const float* X, int64_t n, int64_t P,
                             double* total_variance, float* U, float* s, float* V, int* fused) {
   if (!ctx || !X || !out || !omega || n <= 0 || P <= 0 || k <= 0 || n_oversamples < 0)
     return set_err(ctx, EOFX_ERR_ARG, "bad argument");
-  CHK(set_device(ctx));
+  ENTER(ctx);
   if (fused) *fused = 0;
   ctx->fit_info[0] = ctx->fit_info[1] = ctx->fit_info[2] = 0.0;
   Staged st;
@@ -3014,7 +3116,7 @@ extern "C" int eofx_ctx_comm_clear(eofx_ctx* ctx) {
 }
 extern "C" int eofx_ctx_comm_init_rccl(eofx_ctx* ctx, const char* id128, int world, int rank) {
   if (!ctx || !id128 || world < 1 || rank < 0 || rank >= world) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
-  CHK(set_device(ctx));
+  ENTER(ctx);
   CHK(eofx_ctx_comm_clear(ctx));
   RcclApi api;
   CHK(rccl_open(ctx, api));
@@ -3050,7 +3152,7 @@ extern "C" int eofx_ctx_comm_stats(eofx_ctx* ctx, int64_t* calls, int64_t* bytes
   if (!ctx) return EOFX_ERR_ARG;
   double t = 0.0;
   if (ctx->comm) {
-    CHK(set_device(ctx));
+    ENTER(ctx);
     HIPCHK(hipStreamSynchronize(ctx->stream));
     for (auto& e : ctx->comm->events) {
       float dt = 0.f;
@@ -3108,13 +3210,29 @@ static int comm_vote(eofx_ctx* ctx, int local, int* global) {
   return EOFX_OK;
 }
 
+// sum of one integer per rank (float64 carries integers below 2^53 exactly); one all-reduce + a host read
+static int comm_sum_i64(eofx_ctx* ctx, int64_t local, int64_t* global) {
+  *global = local;
+  if (!ctx->comm) return EOFX_OK;
+  ArenaScope scope(ctx);
+  ARENA(double, d, 2);
+  const double v = (double)local;
+  double r = 0.0;
+  HIPCHK(hipMemcpyAsync(d, &v, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  CHK(comm_allreduce(ctx, d, 1, 1, 0));
+  HIPCHK(hipMemcpyAsync(&r, d, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  *global = (int64_t)std::llround(r);
+  return EOFX_OK;
+}
+
 // One round of each collective the sharded fit uses, on known values: sum / max / min of float32, sum of float64, max of
 // int32 over {rank + 1}.  *ok = 1 when every result is what `world` ranks must produce.  Collective: every rank calls it.
 extern "C" int eofx_ctx_comm_selftest(eofx_ctx* ctx, int* ok) {
   if (!ctx || !ok) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
   *ok = 0;
   if (!ctx->comm) return set_err(ctx, EOFX_ERR_ARG, "no communicator attached");
-  CHK(set_device(ctx));
+  ENTER(ctx);
   CHK(arena_reserve(ctx, 4096));
   ArenaScope scope(ctx);
   ARENA(double, d, 8);
@@ -3155,13 +3273,19 @@ extern "C" int eofx_ctx_comm_probe(eofx_ctx* ctx, int ncases, const int64_t* cou
                                    double* us) {
   if (!ctx || !counts || !dtypes || !ranks_seen || !us || ncases < 0 || reps <= 0) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
   if (!ctx->comm) return set_err(ctx, EOFX_ERR_ARG, "no communicator attached");
-  CHK(set_device(ctx));
+  ENTER(ctx);
   int64_t most = 8;
   for (int i = 0; i < ncases; ++i) {
-    if (counts[i] <= 0 || dtypes[i] < 0 || dtypes[i] > 2) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+    if (counts[i] <= 0 || dtypes[i] < 0 || dtypes[i] > 2) return set_err(ctx, EOFX_ERR_ARG, "bad argument");    // (the same on every rank)
     most = std::max<int64_t>(most, counts[i] * 8);
   }
-  CHK(arena_reserve(ctx, (size_t)most + 4096));
+  {   // a rank-local failure before the first collective (growing the arena) becomes a vote: every rank leaves together
+    const int rc_local = arena_reserve(ctx, (size_t)most + 4096);
+    const std::string err_local = rc_local != EOFX_OK ? ctx->err : std::string();
+    int verdict = 0;
+    CHK(comm_vote(ctx, rc_local != EOFX_OK ? 2 : 0, &verdict));
+    if (verdict != 0) return rc_local != EOFX_OK ? (ctx->err = err_local, rc_local) : set_err(ctx, EOFX_ERR_HIP, "the communicator probe failed on another rank");
+  }
   ArenaScope scope(ctx);
   ARENA(char, buf, (size_t)most);
   HIPCHK(hipMemsetAsync(buf, 0, (size_t)most, ctx->stream));
@@ -3174,21 +3298,25 @@ extern "C" int eofx_ctx_comm_probe(eofx_ctx* ctx, int ncases, const int64_t* cou
   HIPCHK(hipStreamSynchronize(ctx->stream));
   *ranks_seen = (double)seen;
   HIPCHK(hipMemsetAsync(buf, 0, (size_t)most, ctx->stream));
-  hipEvent_t e0, e1;
-  HIPCHK(hipEventCreate(&e0));
-  HIPCHK(hipEventCreate(&e1));
+  struct Events {        // destroyed on every path out of the function
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ~Events() {
+      if (e0) (void)hipEventDestroy(e0);
+      if (e1) (void)hipEventDestroy(e1);
+    }
+  } ev;
+  HIPCHK(hipEventCreate(&ev.e0));
+  HIPCHK(hipEventCreate(&ev.e1));
   for (int i = 0; i < ncases; ++i) {
     CHK(comm_allreduce(ctx, buf, counts[i], dtypes[i], 0));
-    HIPCHK(hipEventRecord(e0, ctx->stream));
+    HIPCHK(hipEventRecord(ev.e0, ctx->stream));
     for (int r = 0; r < reps; ++r) CHK(comm_allreduce(ctx, buf, counts[i], dtypes[i], 0));
-    HIPCHK(hipEventRecord(e1, ctx->stream));
-    HIPCHK(hipEventSynchronize(e1));
+    HIPCHK(hipEventRecord(ev.e1, ctx->stream));
+    HIPCHK(hipEventSynchronize(ev.e1));
     float ms = 0.f;
-    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    HIPCHK(hipEventElapsedTime(&ms, ev.e0, ev.e1));
     us[i] = 1e3 * (double)ms / reps;
   }
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
   return EOFX_OK;
 }
 
@@ -3201,7 +3329,7 @@ extern "C" int eofx_fit_sharded_f32(eofx_ctx* ctx, const float* X, int64_t n, in
     return set_err(ctx, EOFX_ERR_ARG, "bad argument");
   if (!ctx->comm) return set_err(ctx, EOFX_ERR_ARG, "no communicator attached (eofx_ctx_comm_init_rccl / eofx_ctx_comm_set_callback)");
   if (!(n < P_total)) return set_err(ctx, EOFX_ERR_ARG, "the sharded fit needs the sketch on the sample side (n < P_total)");
-  CHK(set_device(ctx));
+  ENTER(ctx);
   ctx->fit_info[0] = ctx->fit_info[1] = ctx->fit_info[2] = 0.0;
   // A failure of THIS rank before the first vote (staging the slice, growing the arena) must not return here: the other ranks
   // would wait in the vote's all-reduce for ever.  It becomes this rank's verdict (2) and every rank leaves together.
@@ -3211,9 +3339,14 @@ extern "C" int eofx_fit_sharded_f32(eofx_ctx* ctx, const float* X, int64_t n, in
   const int l = (int)std::min<int64_t>(l_req, n);
   const int iters = n_iter < 0 ? rsvd_auto_iters(k, n, P_total) : n_iter;
   const int64_t p_pad = round_up(P, ATB_BM), n_pad = round_up(n, ATB_BM);
-  if (rc == EOFX_OK) rc = arena_reserve(ctx, rsvd_scratch_bytes(p_pad, n_pad, l, k) + FitFirst::bytes(n, P, l) + (1 << 16));
+  if (rc == EOFX_OK) {
+    const size_t Lo_ = (size_t)round_up(k, 32);
+    rc = arena_reserve(ctx, rsvd_scratch_bytes(p_pad, n_pad, l, k) + FitFirst::bytes(n, P, l) + (1 << 16) +
+                                (size_t)p_pad * Lo_ * 4 + (size_t)(gram_parts(p_pad, (int)Lo_) + 4) * Lo_ * Lo_ * 8 + (64 << 10));
+  }
   ArenaScope scope(ctx);
   FitFirst ff;
+  ff.sharded = true;
   if (rc == EOFX_OK) {
     const bool eligible = fit_first_eligible(ctx, st.dev, n, P, l) && k <= n && l == l_req && omega_rows >= n && !is_device_ptr(omega);
     rc = eligible ? ff.prepare(ctx, st.dev, n, P, center, standardize, feat_weights, l) : EOFX_FIT_FALLBACK;
@@ -3231,7 +3364,16 @@ extern "C" int eofx_fit_sharded_f32(eofx_ctx* ctx, const float* X, int64_t n, in
     int v = 0;
     CHK(comm_vote(ctx, r1 < 0 ? 2 : r1 > 0 ? 1 : 0, &v));
     if (v == 2) return r1 < 0 ? (ctx->err = e1, r1) : set_err(ctx, EOFX_ERR_HIP, "the sharded fit failed on another rank");
-    return v == 1 ? EOFX_FIT_FALLBACK : EOFX_OK;
+    if (v == 1) return EOFX_FIT_FALLBACK;
+    // all-NaN grid points (a land / sea mask) stay as zero columns of every slice: the decomposition needs more valid features
+    // over ALL slices than samples (the sketch sits on the sample side); one int32 sum, the same verdict on every rank
+    int64_t pv_total = 0;
+    CHK(comm_sum_i64(ctx, ff.m->masked ? ff.m->p_valid : P, &pv_total));
+    if (!(n < pv_total) || k > std::min<int64_t>(n, pv_total)) {
+      ctx->fit_info[2] = 6.0;
+      return EOFX_FIT_FALLBACK;
+    }
+    return EOFX_OK;
   };
   const eofx_mat* m = ff.m;
   LinOp op = {P, n, p_pad, n_pad,
@@ -3244,9 +3386,13 @@ extern "C" int eofx_fit_sharded_f32(eofx_ctx* ctx, const float* X, int64_t n, in
                 return comm_allreduce(ctx, w, (int64_t)n_pad * LL, 0, 0);
               }};
   op.reduce_tall_gram = [&](double* G, int64_t count) { return comm_allreduce(ctx, G, count, 1, 0); };
+  op.rule_tall_pad = round_up(P_total, ATB_BM);
   RsvdOut ro;
   rc = rsvd_core(ctx, op, k, l, iters, omega, ro, &first);
   if (rc != EOFX_OK) return rc;       // (EOFX_FIT_FALLBACK: every rank leaves here together)
+  // numerically null modes (more modes than the field has rank): both factors stay orthonormal, as in eofx_fit_f32 -- the
+  // feature-side factor through its all-reduced Gram matrix, the replicated sample-side one locally (same bits on every rank)
+  CHK(fix_null_modes(ctx, ro, P, n, k, &op.reduce_tall_gram, P_total));
   // sign rule over all slices: one all-reduce(max) of [max | -min]
   std::vector<double> sign(k, 1.0);
   if (flip) {
@@ -3291,7 +3437,7 @@ extern "C" int eofx_panel_bootstrap_f32(eofx_ctx* ctx, const float* P_in, int64_
                                         float* P_out) {
   if (!ctx || !P_in || !P_out || P_in == P_out || !idx || !order || !rowptr || n <= 0 || rows_pad < n || L <= 0 || L % 4)
     return set_err(ctx, EOFX_ERR_ARG, "bad argument");
-  CHK(set_device(ctx));
+  ENTER(ctx);
   const int NPART = 64;
   CHK(arena_reserve(ctx, (size_t)(NPART + 1) * L * 8 + 4096));
   ArenaScope scope(ctx);
@@ -3334,7 +3480,7 @@ extern "C" int eofx_ctx_last_iterations(const eofx_ctx* ctx, int* iterations) {
 
 extern "C" int eofx_project_f32(eofx_ctx* ctx, const eofx_mat* m, const float* V, int k, float* out) {
   if (!ctx || !m || !V || !out || k <= 0) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
-  CHK(set_device(ctx));
+  ENTER(ctx);
   const int Lo = (int)round_up(k, 32);
   CHK(arena_reserve(ctx, (size_t)(m->p_pad + m->n_pad) * Lo * 4 * 2 + atb_scratch_bytes(m->n_pad, round_up(m->p, ATB_KG), Lo) +
                              (size_t)(m->p + m->n) * k * 4 + (1 << 20)));
@@ -3351,7 +3497,7 @@ extern "C" int eofx_project_f32(eofx_ctx* ctx, const eofx_mat* m, const float* V
 extern "C" int eofx_reconstruct_f32(eofx_ctx* ctx, const float* S, const float* V, int64_t n, int64_t p,
                                     int k, float* out) {
   if (!ctx || !S || !V || !out || k <= 0) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
-  CHK(set_device(ctx));
+  ENTER(ctx);
   Staged ss, sv;
   CHK(stage_input(ctx, S, (size_t)n * k, ss));
   CHK(stage_input(ctx, V, (size_t)p * k, sv));
@@ -3637,7 +3783,7 @@ static int device_dot(eofx_ctx* ctx, const float* a, const float* b, int64_t cou
 
 extern "C" int eofx_mat_gram_f32(eofx_ctx* ctx, const eofx_mat* m, int side, float* G) {
   if (!ctx || !m || !G || (side != 0 && side != 1)) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
-  CHK(set_device(ctx));
+  ENTER(ctx);
   const int64_t d = side ? m->p_pad : m->n_pad, o = side ? m->n_pad : m->p_pad;
   if (d > (1 << 16)) return set_err(ctx, EOFX_ERR_ARG, "Gram side of %lld is too large", (long long)d);
   // sample side, more features than samples: the MFMA-bound tiled kernel over the fp16 planes (eofx_gram.hpp)
@@ -3654,7 +3800,7 @@ extern "C" int eofx_mat_gram_f32(eofx_ctx* ctx, const eofx_mat* m, int side, flo
 extern "C" int eofx_mat_cross_gram_f32(eofx_ctx* ctx, const eofx_mat* a, const eofx_mat* b, int side, float* G) {
   if (!ctx || !a || !b || !G || (side != 0 && side != 1)) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
   if (a->n != b->n || a->p != b->p) return set_err(ctx, EOFX_ERR_SHAPE, "the two matrices must have the same shape");
-  CHK(set_device(ctx));
+  ENTER(ctx);
   const int64_t d = side ? a->p_pad : a->n_pad, o = side ? a->n_pad : a->p_pad;
   if (d > (1 << 16)) return set_err(ctx, EOFX_ERR_ARG, "Gram side of %lld is too large", (long long)d);
   CHK(arena_reserve(ctx, atb_scratch_bytes(d, o, (int)d) + (1 << 20)));
@@ -3673,24 +3819,41 @@ extern "C" int eofx_mat_cross_gram_f32(eofx_ctx* ctx, const eofx_mat* a, const e
 
 extern "C" int eofx_vec_dot_f64(eofx_ctx* ctx, const float* a, const float* b, int64_t count, double* out) {
   if (!ctx || !a || !b || !out || count < 0) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
-  CHK(set_device(ctx));
+  ENTER(ctx);
   return device_dot(ctx, a, b, count, out);
 }
 
 // ------------------------------------------------------------------------------------
 // cross-covariance path (MCA): matrix-free rSVD of C = X^T Y / (n-1)
 // ------------------------------------------------------------------------------------
+// sh != nullptr (eofx_crosscov_rsvd_sharded_f32): x and y are this rank's slices of two fields whose feature axes are split
+// over the ranks of the context's communicator -- p*_total features over all ranks, this rank's first one at p*_offset of the
+// global axis.  Both sides of C = X^T Y are then sharded: every sample-side panel (Y Z, X W: partial sums over a rank's
+// features) is all-reduced, every Gram matrix of a feature-side panel too, the two n x n sample-space Gram matrices once;
+// everything on the sample side is replicated and computed redundantly (bit-identical on every rank).
+struct CrossShard {
+  int64_t p1_total, p1_offset, p2_total, p2_offset;
+};
 static int crosscov_impl(eofx_ctx* ctx, const eofx_mat* x, const eofx_mat* y, int k,
                          int n_oversamples, int n_iter, const float* omega, eofx_sketch_fn omega_fn, void* omega_user, int flip,
                          float* Q1, float* s, float* Q2, float* scores1, float* scores2,
-                         float* norm1, float* norm2, double* tsc) {
+                         float* norm1, float* norm2, double* tsc, const CrossShard* sh = nullptr) {
   if (!ctx || !x || !y || (!omega && !omega_fn) || k <= 0) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
-  CHK(set_device(ctx));
+  ENTER(ctx);
   if (x->n != y->n)
     return set_err(ctx, EOFX_ERR_SHAPE,
                    "Both data matrices must have the same number of samples but found %lld in the first and %lld in the second.",
                    (long long)x->n, (long long)y->n);
-  const int64_t n = x->n, p1 = x->p, p2 = y->p, r = std::min(p1, p2);
+  const bool shd = sh != nullptr;
+  const int64_t n = x->n, p1 = x->p, p2 = y->p;
+  const int64_t P1 = shd ? sh->p1_total : p1, P2 = shd ? sh->p2_total : p2, r = std::min(P1, P2);
+  auto reduce_panel = [&](float* Pn, int64_t count) -> int {      // a sample-side panel: sum of the ranks' partial sums
+    if (!shd) return EOFX_OK;
+    amax_forget(ctx, Pn);
+    return comm_allreduce(ctx, Pn, count, 0, 0);
+  };
+  GramReduce reduce_gram;
+  if (shd) reduce_gram = [&](double* Gm, int64_t count) { return comm_allreduce(ctx, Gm, count, 1, 0); };
   if (k > r)
     return set_err(ctx, EOFX_ERR_RANK,
                    "n_modes must be less than or equal to the rank of the dataset (rank = %lld).", (long long)r);
@@ -3698,9 +3861,9 @@ static int crosscov_impl(eofx_ctx* ctx, const eofx_mat* x, const eofx_mat* y, in
   const int l = (int)std::min<int64_t>(l_req, r);
   if (l > EOFX_MAX_SKETCH) return set_err(ctx, EOFX_ERR_ARG, "sketch width %d > %d is not supported", l, EOFX_MAX_SKETCH);
   if (l != l_req) return set_err(ctx, EOFX_ERR_ARG, "sketch wider than rank not supported on the cross path");
-  if (n_iter < 0) n_iter = rsvd_auto_iters(k, p1, p2);
+  if (n_iter < 0) n_iter = rsvd_auto_iters(k, P1, P2);
   const int L = (int)round_up(l, 32);
-  const bool transposed = p1 < p2;  // C is (p1 x p2): sklearn transposes when rows < cols
+  const bool transposed = P1 < P2;  // C is (p1 x p2): sklearn transposes when rows < cols
   const int64_t npad = x->n_pad;
   // The total squared covariance needs the two sample-space Gram matrices (below).  With them resident the power
   // iterations need not touch the fields at all: A = Ft^T Fs (Ft the field on the tall side), A Z = Ft^T (Fs Z) and
@@ -3708,9 +3871,17 @@ static int crosscov_impl(eofx_ctx* ctx, const eofx_mat* x, const eofx_mat* y, in
   // (tens of microseconds) instead of four passes over the fields.  Same subspace in exact arithmetic as scikit-learn's
   // iteration on C (range of (C C^T)^q C Omega); the range basis and the projection that decides the singular values are
   // still computed from the fields themselves.  Taken when the TSC is asked for and both fields are wider than long.
-  const bool gram_route = tsc && n < p1 && n < p2 && gram_fast_ok(x) && gram_fast_ok(y) && !std::getenv("EOFX_CROSS_NO_GRAM");
+  bool gram_route = tsc && n < P1 && n < P2 && gram_fast_ok(x) && gram_fast_ok(y) && !std::getenv("EOFX_CROSS_NO_GRAM");
   size_t need = rsvd_scratch_bytes(std::max(x->p_pad, y->p_pad), std::max(x->p_pad, y->p_pad), l, k) +
                 (size_t)npad * L * 4 * 2 + atb_scratch_bytes(npad, std::max(x->p_pad, y->p_pad), L);
+  if (shd) {   // the Gram route is a collective decision (a rank's slice may not qualify); and room for the null-mode repair
+    int worst = 0;
+    CHK(comm_vote(ctx, gram_route ? 0 : 1, &worst));
+    gram_route = worst == 0;
+    const size_t Lo_ = (size_t)round_up(k, 32), pp_ = (size_t)std::max(x->p_pad, y->p_pad);
+    need += pp_ * Lo_ * 4 + (size_t)(gram_parts((int64_t)pp_, (int)Lo_) + 4) * Lo_ * Lo_ * 8 + (64 << 10);
+    if (tsc && !gram_route) need += std::max(gram_fast_scratch(ctx, x), gram_fast_scratch(ctx, y));
+  }
   if (tsc) need += (size_t)npad * npad * 4 * 2 + (1 << 20);
   if (gram_route)
     need += std::max(gram_fast_scratch(ctx, x), gram_fast_scratch(ctx, y)) + (size_t)npad * L * 4 * 2 + atb_scratch_bytes(npad, npad, L);
@@ -3727,15 +3898,19 @@ static int crosscov_impl(eofx_ctx* ctx, const eofx_mat* x, const eofx_mat* y, in
   }
   if (gram_route) {
     CHK(mat_gram_fast(ctx, x, Gx));
+    if (shd) CHK(comm_allreduce(ctx, Gx, npad * npad, 0, 0));      // X X^T = sum over the slices
     CHK(mat_gram_fast(ctx, y, Gy));
+    if (shd) CHK(comm_allreduce(ctx, Gy, npad * npad, 0, 0));
   }
   // C   Z = X^T (Y Z);   C^T W = Y^T (X W)     (scaling by 1/(n-1) is applied to s at the end)
   auto C_mul = [&](const float* z2, float* out1, int LL, int pr) {
     CHK(panel_mul(ctx, y, z2, Tn, LL, pr));
+    CHK(reduce_panel(Tn, npad * LL));
     return panel_tmul(ctx, x, Tn, out1, LL, pr);
   };
   auto Ct_mul = [&](const float* z1, float* out2, int LL, int pr) {
     CHK(panel_mul(ctx, x, z1, Tn, LL, pr));
+    CHK(reduce_panel(Tn, npad * LL));
     return panel_tmul(ctx, y, Tn, out2, LL, pr);
   };
   LinOp op;
@@ -3743,6 +3918,11 @@ static int crosscov_impl(eofx_ctx* ctx, const eofx_mat* x, const eofx_mat* y, in
     op = {p2, p1, y->p_pad, x->p_pad, Ct_mul, C_mul};  // A = C^T (p2 x p1)
   else
     op = {p1, p2, x->p_pad, y->p_pad, C_mul, Ct_mul};  // A = C   (p1 x p2)
+  if (shd) {
+    op.reduce_tall_gram = reduce_gram;
+    op.reduce_small_gram = reduce_gram;
+    op.rule_tall_pad = round_up(transposed ? P2 : P1, ATB_BM);
+  }
   // the sketch is asked for only now: on the Gram route ~18 ms of matrix work are already queued behind which the caller's
   // generator (scikit-learn's legacy stream: ~5 ms for 129 600 x 30 deviates) finishes unnoticed
   if (!omega) {
@@ -3750,7 +3930,7 @@ static int crosscov_impl(eofx_ctx* ctx, const eofx_mat* x, const eofx_mat* y, in
     if (!omega) return set_err(ctx, EOFX_ERR_ARG, "the sketch callback returned no matrix");
   }
   std::vector<float> om_eye;
-  if (l == r) {   // full-width sketch: identity (see eofx_rsvd_f32)
+  if (l == r && !shd) {   // full-width sketch: identity (see eofx_rsvd_f32); a sharded caller hands over its rows of it
     om_eye.assign((size_t)op.small * l, 0.f);
     for (int64_t i = 0; i < l; ++i) om_eye[(size_t)i * l + i] = 1.f;
     omega = om_eye.data();
@@ -3774,6 +3954,7 @@ static int crosscov_impl(eofx_ctx* ctx, const eofx_mat* x, const eofx_mat* y, in
         return launch_atb(ctx, Gm, npad, npad, npad, in, LL, LL, outp, EOFX_PREC_F32);
       };
       CHK(panel_mul(ctx, fs, Zs, Tn, LL, ctx->prec_power));      // T = Fs Z
+      CHK(reduce_panel(Tn, npad * LL));
       for (int it = 0; it < n_iter; ++it) {
         CHK(orth(Tn, T2));
         CHK(gmul(Gt, T2, Tn));
@@ -3787,11 +3968,16 @@ static int crosscov_impl(eofx_ctx* ctx, const eofx_mat* x, const eofx_mat* y, in
   } else {
     CHK(rsvd_core(ctx, op, k, l, n_iter, omega, ro));
   }
-  CHK(fix_null_modes(ctx, ro, transposed ? p2 : p1, transposed ? p1 : p2, k));   // (more modes than the cross-covariance has rank)
+  // (more modes than the cross-covariance has rank)
+  if (shd)
+    CHK(fix_null_modes(ctx, ro, transposed ? p2 : p1, transposed ? p1 : p2, k, &reduce_gram, transposed ? P2 : P1, &reduce_gram,
+                       transposed ? P1 : P2));
+  else
+    CHK(fix_null_modes(ctx, ro, transposed ? p2 : p1, transposed ? p1 : p2, k));
   const float* Q1p = transposed ? ro.Svec : ro.Tvec;  // left vectors of C  (p1)
   const float* Q2p = transposed ? ro.Tvec : ro.Svec;  // right vectors of C (p2)
   std::vector<double> sign;
-  if (flip) CHK(sign_rule(ctx, Q2p, p2, ro.Lo, k, sign));
+  if (flip) CHK(sign_rule(ctx, Q2p, p2, ro.Lo, k, sign, shd));
   const double* sg = flip ? sign.data() : nullptr;
   CHK(export_panel(ctx, Q1p, p1, ro.Lo, k, sg, Q1));
   CHK(export_panel(ctx, Q2p, p2, ro.Lo, k, sg, Q2));
@@ -3811,6 +3997,7 @@ static int crosscov_impl(eofx_ctx* ctx, const eofx_mat* x, const eofx_mat* y, in
       float* nr = which ? norm2 : norm1;
       if (!sc && !nr) continue;
       CHK(panel_mul(ctx, mm, Qp, Sn, ro.Lo, ctx->prec_final));
+      CHK(reduce_panel(Sn, npad * ro.Lo));
       CHK(export_panel(ctx, Sn, n, ro.Lo, k, sg, sc));
       if (nr) {
         CHK(launch_gram(ctx, Sn, npad, ro.Lo, Gs));
@@ -3827,7 +4014,9 @@ static int crosscov_impl(eofx_ctx* ctx, const eofx_mat* x, const eofx_mat* y, in
   if (tsc) {
     if (!gram_route) {
       CHK(sample_gram(ctx, x, Gx));
+      if (shd) CHK(comm_allreduce(ctx, Gx, npad * npad, 0, 0));
       CHK(sample_gram(ctx, y, Gy));
+      if (shd) CHK(comm_allreduce(ctx, Gy, npad * npad, 0, 0));
     }
     double t = 0.0;
     CHK(device_dot(ctx, Gx, Gy, npad * npad, &t));
@@ -3850,6 +4039,39 @@ extern "C" int eofx_crosscov_rsvd_lazy_f32(eofx_ctx* ctx, const eofx_mat* x, con
                                            float* norm1, float* norm2, double* tsc) {
   if (!omega_fn) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
   return crosscov_impl(ctx, x, y, k, n_oversamples, n_iter, nullptr, omega_fn, omega_user, flip, Q1, s, Q2, scores1, scores2, norm1, norm2, tsc);
+}
+
+extern "C" int eofx_crosscov_rsvd_sharded_f32(eofx_ctx* ctx, const eofx_mat* x, const eofx_mat* y, int64_t p1_total,
+                                              int64_t p1_offset, int64_t p2_total, int64_t p2_offset, int k, int n_oversamples,
+                                              int n_iter, const float* omega, int flip, float* Q1, float* s, float* Q2,
+                                              float* scores1, float* scores2, float* norm1, float* norm2, double* tsc) {
+  if (!ctx || !x || !y || !omega) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  if (!ctx->comm) return set_err(ctx, EOFX_ERR_ARG, "no communicator attached (eofx_ctx_comm_init_rccl / eofx_ctx_comm_set_callback)");
+  // (a masked in-place slice counts its VALID features on the global axis; its zero columns are not part of it)
+  if (p1_offset < 0 || p2_offset < 0 || p1_offset + (x->masked ? x->p_valid : x->p) > p1_total ||
+      p2_offset + (y->masked ? y->p_valid : y->p) > p2_total)
+    return set_err(ctx, EOFX_ERR_ARG, "the slice [offset, offset + p) lies outside the global feature axis");
+  if (is_device_ptr(omega)) return set_err(ctx, EOFX_ERR_ARG, "omega must be a host pointer");
+  const CrossShard sh{p1_total, p1_offset, p2_total, p2_offset};
+  return crosscov_impl(ctx, x, y, k, n_oversamples, n_iter, omega, nullptr, nullptr, flip, Q1, s, Q2, scores1, scores2, norm1, norm2,
+                       tsc, &sh);
+}
+
+// all-reduce of a small HOST vector over the context's communicator (the global facts of a sharded preprocess: feature counts,
+// sample votes, variances): staged through the arena, in stream order with the kernels already queued.  op: 0 sum, 1 max, 2 min
+extern "C" int eofx_ctx_comm_allreduce_f64(eofx_ctx* ctx, double* host_buf, int64_t count, int op) {
+  if (!ctx || !host_buf || count <= 0 || op < 0 || op > 2) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  if (!ctx->comm) return set_err(ctx, EOFX_ERR_ARG, "no communicator attached");
+  ENTER(ctx);
+  CHK(arena_reserve(ctx, (size_t)count * sizeof(double) + 4096));
+  ArenaScope scope(ctx);
+  ARENA(double, d, (size_t)count);
+  HIPCHK(hipMemcpyAsync(d, host_buf, sizeof(double) * count, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  CHK(comm_allreduce(ctx, d, count, 1, op));
+  HIPCHK(hipMemcpyAsync(host_buf, d, sizeof(double) * count, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return EOFX_OK;
 }
 
 // ------------------------------------------------------------------------------------
@@ -4074,7 +4296,7 @@ extern "C" int eofx_hilbert_f32(eofx_ctx* ctx, const eofx_mat* a, int padding, d
                                 eofx_mat** out_imag, eofx_mat** out_real) {
   if (!ctx || !a || !out_imag) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
   if (padding && !(decay_factor > 0.0)) return set_err(ctx, EOFX_ERR_ARG, "decay_factor must be positive");
-  CHK(set_device(ctx));
+  ENTER_EXCLUSIVE(ctx);
   const int64_t n = a->n, p = a->p, n_pad = a->n_pad, p_pad = a->p_pad;
   int L = 0;
   const int64_t P = hilbert_length(n, &L);  // circular length: power of two >= 2n
@@ -4210,7 +4432,7 @@ done:
 extern "C" int eofx_hilbert_sumsq_f64(eofx_ctx* ctx, const eofx_mat* a, int padding, double decay_factor, double* out) {
   if (!ctx || !a || !out) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
   if (padding && !(decay_factor > 0.0)) return set_err(ctx, EOFX_ERR_ARG, "decay_factor must be positive");
-  CHK(set_device(ctx));
+  ENTER_EXCLUSIVE(ctx);
   const int64_t n = a->n, p = a->p, n_pad = a->n_pad, p_pad = a->p_pad;
   int L = 0;
   const int64_t P = hilbert_length(n, &L);
@@ -4274,7 +4496,7 @@ extern "C" int eofx_hilbert_sumsq_f64(eofx_ctx* ctx, const eofx_mat* a, int padd
 extern "C" int eofx_cpanel_combine_f32(eofx_ctx* ctx, const float* P1, const float* P2, int conj_left,
                                        int64_t rows_pad, int L, float* out) {
   if (!ctx || !P1 || !P2 || !out || L % 2) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
-  CHK(set_device(ctx));
+  ENTER(ctx);
   const int64_t total = rows_pad * (L / 2);
   hipLaunchKernelGGL(cpanel_combine_kernel, dim3((int)std::min<int64_t>((total + 255) / 256, 8192)), dim3(256), 0,
                      ctx->stream, P1, P2, conj_left ? 1.f : -1.f, rows_pad, L, out);
@@ -4289,7 +4511,7 @@ extern "C" int eofx_panel_colargminmax_f32(eofx_ctx* ctx, const float* P, int64_
 }
 static int panel_colargminmax(eofx_ctx* ctx, const float* P, int64_t rows, int L, int64_t* amax, int64_t* amin, const float* rowscale) {
   if (!ctx || !P || !amax || !amin) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
-  CHK(set_device(ctx));
+  ENTER(ctx);
   const int nparts = (int)std::max<int64_t>(1, std::min<int64_t>((rows + 15) / 16, 2048));
   CHK(arena_reserve(ctx, (size_t)nparts * L * 24 + 8192));
   ArenaScope scope(ctx);
@@ -4437,12 +4659,29 @@ static void embed_right(const std::vector<zdouble>& M, int l, int mcols, int LP,
 // with T[t][s] = kappa(N, t - s), a0^T y = c0 and a1^T y = c1 the coefficients of the linear fit, and u1..u4 the
 // correction vectors of get_hilbert_setup.  Built in float64 on the host, held as a resident n x n matrix (both layouts)
 // per (n, padding, decay): eofx_rsvd_hilbert_c64 applies it to the SAMPLE-side panels instead of materialising Im.
+static int build_hilbert_operator_host(eofx_ctx* ctx, int64_t n, int padding, double decay, std::vector<float>& hc);
 static int get_hilbert_operator(eofx_ctx* ctx, int64_t n, int padding, double decay, const eofx_mat** out) {
   for (auto& h : ctx->hops)
     if (h.n == n && h.padding == padding && (!padding || h.decay == decay)) {
       *out = h.m;
       return EOFX_OK;
     }
+  std::vector<float> hc;
+  CHK(build_hilbert_operator_host(ctx, n, padding, decay, hc));
+  eofx_mat* m = nullptr;
+  CHK(eofx_mat_from_dense_f32(ctx, hc.data(), n, n, n, &m));
+  eofx_ctx::HilbertOp h;
+  h.n = n; h.padding = padding; h.decay = decay; h.m = m;
+  while (ctx->hops.size() >= 2) {          // a small cache (an operator is up to 2 GB): the oldest one goes
+    (void)eofx_mat_destroy(ctx, ctx->hops.front().m);
+    ctx->hops.erase(ctx->hops.begin());
+  }
+  ctx->hops.push_back(h);
+  *out = m;
+  return EOFX_OK;
+}
+// Hc [n x n] row-major float32 on the host: Im = Hc A for the Hilbert stage of eofx_hilbert_f32 along the samples (built in float64)
+static int build_hilbert_operator_host(eofx_ctx* ctx, int64_t n, int padding, double decay, std::vector<float>& hc) {
   const int64_t N = padding ? 3 * n : n;
   std::vector<double> kap((size_t)(2 * n + 1)), pre((size_t)(2 * n + 2), 0.0);   // kappa(N, d), d = -n .. n, and its prefix sums
   for (int64_t d = -n; d <= n; ++d) kap[(size_t)(d + n)] = hilbert_kappa(N, d);
@@ -4464,7 +4703,6 @@ static int get_hilbert_operator(eofx_ctx* ctx, int64_t n, int padding, double de
       ubar[k] = m / (double)n;
     }
   }
-  std::vector<float> hc;
   try {
     hc.resize((size_t)n * n);
   } catch (const std::bad_alloc&) {
@@ -4492,16 +4730,16 @@ static int get_hilbert_operator(eofx_ctx* ctx, int64_t n, int padding, double de
   const int64_t step = (n + nt - 1) / nt;
   for (int t = 0; t < nt; ++t) th.emplace_back(work, t * step, std::min<int64_t>(n, (t + 1) * step));
   for (auto& t : th) t.join();
-  eofx_mat* m = nullptr;
-  CHK(eofx_mat_from_dense_f32(ctx, hc.data(), n, n, n, &m));
-  eofx_ctx::HilbertOp h;
-  h.n = n; h.padding = padding; h.decay = decay; h.m = m;
-  while (ctx->hops.size() >= 2) {          // a small cache (an operator is up to 2 GB): the oldest one goes
-    (void)eofx_mat_destroy(ctx, ctx->hops.front().m);
-    ctx->hops.erase(ctx->hops.begin());
-  }
-  ctx->hops.push_back(h);
-  *out = m;
+  return EOFX_OK;
+}
+extern "C" int eofx_hilbert_operator_f32(eofx_ctx* ctx, int64_t n, int padding, double decay_factor, float* out) {
+  if (!ctx || !out || n <= 0) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  if (padding && !(decay_factor > 0.0)) return set_err(ctx, EOFX_ERR_ARG, "decay_factor must be positive");
+  if (n > EOFX_HILBERT_OP_MAX_N) return set_err(ctx, EOFX_ERR_ARG, "the Hilbert operator is limited to %d samples", EOFX_HILBERT_OP_MAX_N);
+  if (is_device_ptr(out)) return set_err(ctx, EOFX_ERR_ARG, "out must be a host pointer");
+  std::vector<float> hc;
+  CHK(build_hilbert_operator_host(ctx, n, padding ? 1 : 0, decay_factor, hc));
+  std::memcpy(out, hc.data(), sizeof(float) * hc.size());
   return EOFX_OK;
 }
 
@@ -4640,7 +4878,7 @@ extern "C" int eofx_cmat_mul_f32(eofx_ctx* ctx, const eofx_mat* A, const eofx_ma
   if (!ctx || !A || !B || !Pin || !Pout) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
   if (A->n != B->n || A->p != B->p) return set_err(ctx, EOFX_ERR_SHAPE, "real and imaginary parts must have the same shape");
   if (L != 64 && L != 128) return set_err(ctx, EOFX_ERR_ARG, "complex panels are 64 or 128 real columns wide");
-  CHK(set_device(ctx));
+  ENTER(ctx);
   const int prec = final_pass ? ctx->prec_final : ctx->prec_power;
   const bool lean = cplx_lean(A, B, L, prec, prec);
   if (!lean) {
@@ -4680,20 +4918,31 @@ extern "C" int eofx_cmat_mul_f32(eofx_ctx* ctx, const eofx_mat* A, const eofx_ma
 //   n_iter >= 0: that many products;  -1: scikit-learn's count (7 if k < 0.1 min(n, p) else 4);
 //   -2 ("converge"): restarted cycles of that count, each starting from the Ritz block of the previous one, until the leading k
 //        values move by <= 1e-6 (relative, squared values) or 20 products have been made (lobpcg's own limit under svds).
-// Sketches whose Krylov space would exceed order 384 (k + n_oversamples > 48 at q = 7) keep the subspace iteration of rounds 1-4
-// (EOFX_C64_KRYLOV=0 forces it, for comparisons).
+// Sketches whose Krylov space would exceed order 384 (k + n_oversamples > 48 at q = 7) are THICK-RESTARTED (`compress`: the Ritz
+// block + the newest block) so that the host's Rayleigh-Ritz problem stays below that order; sketches so wide that fewer than 3
+// blocks fit (l > 128: not reachable, l <= 64) would keep the subspace iteration of rounds 1-4 (EOFX_C64_KRYLOV=0 forces it, for
+// comparisons).  The panel-level driver (xeofs_amd/complex_svd.py) solves its Rayleigh-Ritz problem with numpy and keeps up to
+// order 512 WITHOUT a restart: for 48 < l <= 64 at q = 7 the two drivers run different (both convergent) recurrences -- by design.
 // B != nullptr: Z = A + i B (both resident).  B == nullptr: Z = (I + i Hc) A with the resident Hilbert operator Hop.
+// p_total > 0 (eofx_rsvd_sharded_c64 / eofx_rsvd_hilbert_sharded_c64): A (and B) are this rank's slice of the feature axis of a
+// field with p_total (valid) features over all ranks of the context's communicator, n < p_total.  The recurrence lives on the
+// sample side, which is replicated: the only collectives are one all-reduce(sum) of the n x LP sample-side panel per product
+// Z Y, one of the LP x LP float64 Gram matrix per feature-side panel that is factorised, and two small ones for the sign rule.
+// The Hilbert operator acts on the replicated sample-side panel, so the operator route shards without further exchange.
 static int rsvd_c64_impl(eofx_ctx* ctx, const eofx_mat* A, const eofx_mat* B, const eofx_mat* Hop, int k, int n_oversamples,
-                         int n_iter, const float* omega, int flip_signs, float* U, float* s, float* V) {
+                         int n_iter, const float* omega, int flip_signs, float* U, float* s, float* V, int64_t p_total = 0) {
   if (!ctx || !A || (!B && !Hop) || !omega || !s || k <= 0 || n_oversamples < 0)
     return set_err(ctx, EOFX_ERR_ARG, "bad argument");
   if (B && (A->n != B->n || A->p != B->p)) return set_err(ctx, EOFX_ERR_SHAPE, "real and imaginary parts must have the same shape");
-  CHK(set_device(ctx));
-  const int64_t n = A->n, p = A->p, r = std::min(n, A->masked ? A->p_valid : p);
+  ENTER(ctx);
+  const bool shd = p_total > 0;
+  if (shd && !ctx->comm) return set_err(ctx, EOFX_ERR_ARG, "no communicator attached (eofx_ctx_comm_init_rccl / eofx_ctx_comm_set_callback)");
+  if (shd && !(A->n < p_total)) return set_err(ctx, EOFX_ERR_ARG, "the sharded complex decomposition needs the sketch on the sample side (n < p_total)");
+  const int64_t n = A->n, p = A->p, r = std::min(n, shd ? p_total : (A->masked ? A->p_valid : p));
   if (k > r) return set_err(ctx, EOFX_ERR_RANK, "n_modes must be less than or equal to the rank of the dataset (rank = %lld).", (long long)r);
   const int l = (int)std::min<int64_t>(k + n_oversamples, r);
   if (l > 64) return set_err(ctx, EOFX_ERR_ARG, "complex sketch width %d > 64 is not supported (n_modes + n_oversamples <= 64)", l);
-  if (A->masked && !(n < A->p_valid)) return set_err(ctx, EOFX_ERR_ARG, "masked in-place matrix with fewer valid features than samples");
+  if (!shd && A->masked && !(n < A->p_valid)) return set_err(ctx, EOFX_ERR_ARG, "masked in-place matrix with fewer valid features than samples");
   const bool adaptive = n_iter == -2;
   const int auto_count = k < 0.1 * (double)r ? 7 : 4;
   if (n_iter == -1) n_iter = auto_count;
@@ -4707,7 +4956,7 @@ static int rsvd_c64_impl(eofx_ctx* ctx, const eofx_mat* A, const eofx_mat* B, co
     CHK(ensure_X(ctx, A));   // (ensure_X builds the sample-contiguous layout first where that is missing too)
     CHK(ensure_X(ctx, B));
   }
-  const bool transposed = n < p;     // A_op = Z^H: tall side = features
+  const bool transposed = shd || n < p;     // A_op = Z^H: tall side = features
   const int64_t small = transposed ? n : p;
   const int64_t small_pad = transposed ? A->n_pad : A->p_pad, tall_pad = transposed ? A->p_pad : A->n_pad;
   const int64_t big = std::max(A->n_pad, A->p_pad);
@@ -4755,11 +5004,20 @@ static int rsvd_c64_impl(eofx_ctx* ctx, const eofx_mat* A, const eofx_mat* B, co
   if (lean) CHK(cplx_lean_setup(ctx, ops));
   const int pp = ctx->prec_power, pf = ctx->prec_final;
   auto fwd = [&](const float* in, float* out, int prec) { return transposed ? ops.zh_mul(in, out, prec) : ops.z_mul(in, out, prec); };
-  auto bwd = [&](const float* in, float* out, int prec) { return transposed ? ops.z_mul(in, out, prec) : ops.zh_mul(in, out, prec); };
+  auto bwd = [&](const float* in, float* out, int prec) -> int {
+    if (!transposed) return ops.zh_mul(in, out, prec);
+    CHK(ops.z_mul(in, out, prec));
+    if (shd) {                       // the partial sum over this rank's features -> the sum over all of them
+      amax_forget(ctx, out);
+      CHK(comm_allreduce(ctx, out, small_pad * LP, 0, 0));
+    }
+    return EOFX_OK;
+  };
   std::vector<double> hG((size_t)LP * LP), hE;
   std::vector<zdouble> H, T;
-  auto gram_h = [&](const float* P, int64_t rows_pad) -> int {
+  auto gram_h = [&](const float* P, int64_t rows_pad, bool tall_side = false) -> int {
     CHK(launch_gram(ctx, P, rows_pad, LP, G));
+    if (shd && tall_side) CHK(comm_allreduce(ctx, G, (int64_t)LP * LP, 1, 0));     // rows sharded over the ranks
     HIPCHK(hipMemcpyAsync(hG.data(), G, sizeof(double) * LP * LP, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     hermitian_from_real(hG, LP, l, H);
@@ -4775,8 +5033,8 @@ static int rsvd_c64_impl(eofx_ctx* ctx, const eofx_mat* A, const eofx_mat* B, co
     HIPCHK(hipStreamSynchronize(ctx->stream));    // hE / Ed are reused
     return EOFX_OK;
   };
-  auto orth = [&](const float* P, int64_t rows_pad, float* out) -> int {
-    CHK(gram_h(P, rows_pad));
+  auto orth = [&](const float* P, int64_t rows_pad, float* out, bool tall_side = false) -> int {
+    CHK(gram_h(P, rows_pad, tall_side));
     host_zchol_rinv(H, l, T, 1e-13);
     return right_mul(P, rows_pad, T, l, LP, out);
   };
@@ -4789,7 +5047,7 @@ static int rsvd_c64_impl(eofx_ctx* ctx, const eofx_mat* A, const eofx_mat* B, co
   }
   // (adaptive subspace iteration: the tall panel is orthonormalised in every iteration -- only then is W^H W the Rayleigh
   // quotient whose eigenvalues are compared)
-  const bool orth_always = (adaptive && !krylov) || orth_tall_rule(tall_pad, LP, pp);
+  const bool orth_always = (adaptive && !krylov) || orth_tall_rule(shd ? round_up(p_total, ATB_BM) : tall_pad, LP, pp);
   const bool trace = std::getenv("EOFX_C64_TRACE") != nullptr;
   ctx->last_iters = 0;
 
@@ -4846,7 +5104,7 @@ static int rsvd_c64_impl(eofx_ctx* ctx, const eofx_mat* A, const eofx_mat* B, co
     Rf[b].clear();
     if (ctx->last_iters == 0 || orth_rest) {
       CHK(fwd(Zs, Yt, pp));
-      CHK(gram_h(Yt, tall_pad));
+      CHK(gram_h(Yt, tall_pad, true));
       host_zchol_rinv(H, l, T, 1e-13, &Rf[b]);
       CHK(right_mul(Yt, tall_pad, T, l, LP, slot));
     } else {
@@ -5046,13 +5304,13 @@ static int rsvd_c64_impl(eofx_ctx* ctx, const eofx_mat* A, const eofx_mat* B, co
       Rf[b].clear();
       if (orth_rest || ctx->last_iters == 0) {
         CHK(fwd(Zs, Yt, pp));
-        CHK(gram_h(Yt, tall_pad));
+        CHK(gram_h(Yt, tall_pad, true));
         Hqq = H;
         host_zchol_rinv(H, l, T, 1e-13, &Rf[b]);
         CHK(right_mul(Yt, tall_pad, T, l, LP, slot));
       } else {
         CHK(fwd(Zs, slot, pp));
-        CHK(gram_h(slot, tall_pad));
+        CHK(gram_h(slot, tall_pad, true));
         Hqq = H;
       }
       with_last = true;
@@ -5061,8 +5319,8 @@ static int rsvd_c64_impl(eofx_ctx* ctx, const eofx_mat* A, const eofx_mat* B, co
     if (trace) fprintf(stderr, "[eofx_rsvd_c64] Rayleigh-Ritz over %d blocks (order %d) after %d products: leading Ritz values %.6e %.6e ... %.6e\n", nb, nb * l, ctx->last_iters, wv[0], l > 1 ? wv[1] : 0.0, wv[l - 1]);
     CHK(coeff_stack(nb, true));
     CHK(launch_matmul_gen(ctx, Pt, LP, tall_pad * LP, LP / 64, tall_pad, nb * LP, Eall, LP, nullptr, Yt));   // A_op K y
-    CHK(orth(Yt, tall_pad, Qt));
-    CHK(orth(Qt, tall_pad, Yt));                     // Q in Yt (CholeskyQR2)
+    CHK(orth(Yt, tall_pad, Qt, true));
+    CHK(orth(Qt, tall_pad, Yt, true));                     // Q in Yt (CholeskyQR2)
     CHK(bwd(Yt, Ws, pf));                            // B^H, B = Q^H A_op
     CHK(gram_h(Ws, small_pad));                      // B B^H
     if (host_heigh(H, l, w, Uh) != EOFX_OK) return set_err(ctx, EOFX_ERR_LINALG, "complex SVD: Hermitian eigen-solver failed");
@@ -5073,7 +5331,7 @@ static int rsvd_c64_impl(eofx_ctx* ctx, const eofx_mat* A, const eofx_mat* B, co
     for (int it = 0; it < n_iter; ++it) {
       CHK(fwd(Zs, Yt, pp));
       if (it == 0 || orth_rest) {
-        CHK(orth(Yt, tall_pad, Qt));
+        CHK(orth(Yt, tall_pad, Qt, true));
         CHK(bwd(Qt, Ws, pp));
       } else {
         CHK(bwd(Yt, Ws, pp));
@@ -5106,8 +5364,8 @@ static int rsvd_c64_impl(eofx_ctx* ctx, const eofx_mat* A, const eofx_mat* B, co
       if (done) break;
     }
     CHK(fwd(Zs, Yt, pp));
-    CHK(orth(Yt, tall_pad, Qt));
-    CHK(orth(Qt, tall_pad, Yt));                     // Q in Yt (CholeskyQR2)
+    CHK(orth(Yt, tall_pad, Qt, true));
+    CHK(orth(Qt, tall_pad, Yt, true));                     // Q in Yt (CholeskyQR2)
     CHK(bwd(Yt, Ws, pf));                            // B^H, B = Q^H A_op
     CHK(gram_h(Ws, small_pad));                      // B B^H
     if (host_heigh(H, l, w, Uh) != EOFX_OK) return set_err(ctx, EOFX_ERR_LINALG, "complex SVD: Hermitian eigen-solver failed");
@@ -5197,8 +5455,36 @@ static int rsvd_c64_impl(eofx_ctx* ctx, const eofx_mat* A, const eofx_mat* B, co
     std::vector<float> c(4 * (size_t)k);
     HIPCHK(hipMemcpyAsync(c.data(), picks, sizeof(float) * 4 * k, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    std::vector<double> mag(2 * (size_t)k);
+    for (int j = 0; j < k; ++j) {
+      mag[j] = std::hypot((double)c[4 * j], (double)c[4 * j + 1]);
+      mag[k + j] = std::hypot((double)c[4 * j + 2], (double)c[4 * j + 3]);
+    }
+    if (shd) {
+      // global lexicographic extrema over the slices: the largest / smallest real part wins (all-reduce(max) of [re_max | -re_min]),
+      // the rank that holds it contributes the magnitude of its entry (all-reduce(max) of float64, -1 from the others)
+      ARENA(float, dre, 2 * (size_t)k);
+      ARENA(double, dmag, 2 * (size_t)k);
+      std::vector<float> re(2 * (size_t)k), gre(2 * (size_t)k);
+      for (int j = 0; j < k; ++j) {
+        re[j] = p > 0 ? c[4 * j] : -INFINITY;
+        re[k + j] = p > 0 ? -c[4 * j + 2] : -INFINITY;
+      }
+      HIPCHK(hipMemcpyAsync(dre, re.data(), sizeof(float) * 2 * k, hipMemcpyHostToDevice, ctx->stream));
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      CHK(comm_allreduce(ctx, dre, 2 * (int64_t)k, 0, 1));
+      HIPCHK(hipMemcpyAsync(gre.data(), dre, sizeof(float) * 2 * k, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      for (int j = 0; j < 2 * k; ++j)
+        if (!(p > 0 && re[j] == gre[j])) mag[j] = -1.0;
+      HIPCHK(hipMemcpyAsync(dmag, mag.data(), sizeof(double) * 2 * k, hipMemcpyHostToDevice, ctx->stream));
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      CHK(comm_allreduce(ctx, dmag, 2 * (int64_t)k, 1, 1));
+      HIPCHK(hipMemcpyAsync(mag.data(), dmag, sizeof(double) * 2 * k, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
     for (int j = 0; j < k; ++j)   // |max| >= |min| in numpy's lexicographic complex order (real part decides)
-      sign[j] = std::hypot((double)c[4 * j], (double)c[4 * j + 1]) >= std::hypot((double)c[4 * j + 2], (double)c[4 * j + 3]) ? 1.0 : -1.0;
+      sign[j] = mag[j] >= mag[k + j] ? 1.0 : -1.0;
   }
   // interleaved complex64 exports
   auto export_c = [&](const float* P, int64_t rows, float* dst) -> int {
@@ -5247,17 +5533,37 @@ extern "C" int eofx_rsvd_hilbert_c64(eofx_ctx* ctx, const eofx_mat* A, int paddi
   if (A->n > EOFX_HILBERT_OP_MAX_N)
     return set_err(ctx, EOFX_ERR_ARG, "the resident Hilbert operator is limited to %d samples (got %lld): use eofx_hilbert_f32 + eofx_rsvd_c64",
                    EOFX_HILBERT_OP_MAX_N, (long long)A->n);
-  CHK(set_device(ctx));
+  ENTER(ctx);
   const eofx_mat* Hop = nullptr;
   CHK(get_hilbert_operator(ctx, A->n, padding ? 1 : 0, decay_factor, &Hop));
   return rsvd_c64_impl(ctx, A, nullptr, Hop, k, n_oversamples, n_iter, omega, flip_signs, U, s, V);
+}
+
+extern "C" int eofx_rsvd_sharded_c64(eofx_ctx* ctx, const eofx_mat* A, const eofx_mat* B, int64_t p_total, int k, int n_oversamples,
+                                     int n_iter, const float* omega, int flip_signs, float* U, float* s, float* V) {
+  if (!B || p_total <= 0) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  return rsvd_c64_impl(ctx, A, B, nullptr, k, n_oversamples, n_iter, omega, flip_signs, U, s, V, p_total);
+}
+
+extern "C" int eofx_rsvd_hilbert_sharded_c64(eofx_ctx* ctx, const eofx_mat* A, int64_t p_total, int padding, double decay_factor,
+                                             int k, int n_oversamples, int n_iter, const float* omega, int flip_signs, float* U,
+                                             float* s, float* V) {
+  if (!ctx || !A || p_total <= 0) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
+  if (padding && !(decay_factor > 0.0)) return set_err(ctx, EOFX_ERR_ARG, "decay_factor must be positive");
+  if (A->n > EOFX_HILBERT_OP_MAX_N)
+    return set_err(ctx, EOFX_ERR_ARG, "the resident Hilbert operator is limited to %d samples (got %lld): use eofx_hilbert_f32 + eofx_rsvd_sharded_c64",
+                   EOFX_HILBERT_OP_MAX_N, (long long)A->n);
+  ENTER(ctx);
+  const eofx_mat* Hop = nullptr;
+  CHK(get_hilbert_operator(ctx, A->n, padding ? 1 : 0, decay_factor, &Hop));
+  return rsvd_c64_impl(ctx, A, nullptr, Hop, k, n_oversamples, n_iter, omega, flip_signs, U, s, V, p_total);
 }
 
 // sum of squares of the resident matrix in float64 (fixed tree); for zero-mean columns
 // total variance = sumsq / (n - 1)
 extern "C" int eofx_mat_sumsq_f64(eofx_ctx* ctx, const eofx_mat* m, double* out) {
   if (!ctx || !m || !out) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
-  CHK(set_device(ctx));
+  ENTER(ctx);
   const int nb = 2048;
   CHK(arena_reserve(ctx, nb * sizeof(double) + 4096));
   ArenaScope scope(ctx);
@@ -5620,13 +5926,13 @@ static int launch_rownorm(eofx_ctx* ctx, const float* P, int64_t rows, int64_t L
 }
 extern "C" int eofx_panel_rownorm_f64(eofx_ctx* ctx, const float* P, int64_t rows, int L, double* out) {
   if (!ctx || !P || !out || rows <= 0 || L <= 0) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
-  CHK(set_device(ctx));
+  ENTER(ctx);
   CHK(arena_reserve(ctx, (size_t)rows * sizeof(double) + 4096));
   return launch_rownorm(ctx, P, rows, L, L, out);
 }
 extern "C" int eofx_mat_feature_norms_f64(eofx_ctx* ctx, const eofx_mat* m, double* out) {
   if (!ctx || !m || !out) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
-  CHK(set_device(ctx));
+  ENTER(ctx);
   CHK(arena_reserve(ctx, (size_t)m->p * sizeof(double) + 4096));
   CHK(ensure_Xt(ctx, m));
   return launch_rownorm(ctx, m->Xt, m->p, m->n, m->n_pad, out);   // rows of X^T = features
@@ -5636,7 +5942,7 @@ extern "C" int eofx_mat_feature_norms_f64(eofx_ctx* ctx, const eofx_mat* m, doub
 // for an in-place matrix (the raw field goes through the Scaler map on the fly)
 extern "C" int eofx_mat_sample_norms_f64(eofx_ctx* ctx, const eofx_mat* m, double* out) {
   if (!ctx || !m || !out) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
-  CHK(set_device(ctx));
+  ENTER(ctx);
   CHK(arena_reserve(ctx, (size_t)m->n * sizeof(double) + 4096));
   if (!m->X && m->raw && m->aff) {
     ArenaScope scope(ctx);
@@ -5654,7 +5960,7 @@ extern "C" int eofx_mat_sample_norms_f64(eofx_ctx* ctx, const eofx_mat* m, doubl
 
 extern "C" int eofx_panel_row_normalize_f32(eofx_ctx* ctx, const float* P, int64_t rows_pad, int L, float* out) {
   if (!ctx || !P || !out) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
-  CHK(set_device(ctx));
+  ENTER(ctx);
   hipLaunchKernelGGL(row_normalize_kernel, dim3((int)((rows_pad + 3) / 4)), dim3(256), 0, ctx->stream, P, rows_pad, L,
                      2.220446049250313e-16, out);
   KCHK();
@@ -5664,7 +5970,7 @@ extern "C" int eofx_panel_row_normalize_f32(eofx_ctx* ctx, const float* P, int64
 // max |column| over the rows of a complex [Re | Im] panel (L = 2 h columns, h a power of two <= 128) -> out[h] (device)
 extern "C" int eofx_cpanel_colabsmax_f32(eofx_ctx* ctx, const float* P, int64_t rows, int L, float* out) {
   if (!ctx || !P || !out || L < 2 || L > 256 || (L & (L - 1))) return set_err(ctx, EOFX_ERR_ARG, "bad argument");
-  CHK(set_device(ctx));
+  ENTER(ctx);
   HIPCHK(hipMemsetAsync(out, 0, sizeof(float) * (L / 2), ctx->stream));
   const int rstep = 256 / (L / 2);
   hipLaunchKernelGGL(cpanel_colabsmax_kernel, dim3((int)std::max<int64_t>(1, std::min<int64_t>((rows + rstep - 1) / rstep, 2048))),
@@ -5697,7 +6003,7 @@ extern "C" int eofx_panel_rot_step_f64(eofx_ctx* ctx, const float* X, int64_t ro
   if (!ctx || !X || !R || !aux || !G || (L != 32 && L != 64 && L != 128 && L != 256) || mode < 0 || mode > 3 ||
       (mode >= 2 && L < 64))
     return set_err(ctx, EOFX_ERR_ARG, "bad argument (L = 32, 64, 128 or 256; the complex modes 2 / 3 need a [Re | Im] panel of L >= 64)");
-  CHK(set_device(ctx));
+  ENTER(ctx);
   if (L == 128) return launch_rot_step_wide<128>(ctx, X, rows_pad, R, aux, mode, power, G);
   if (L == 256) return launch_rot_step_wide<256>(ctx, X, rows_pad, R, aux, mode, power, G);
   const int nbx = (int)std::max<int64_t>(1, std::min<int64_t>((rows_pad + 31) / 32, 512));

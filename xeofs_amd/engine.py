@@ -469,6 +469,7 @@ def comm_init_rccl(ctx: Context, unique_id: bytes, world: int, rank: int):
     """attach an RCCL communicator to the context: its collectives are enqueued on the context's own stream"""
     raise_for(ctx.lib.eofx_ctx_comm_init_rccl(ctx.handle, C.c_char_p(bytes(unique_id)), int(world), int(rank)), ctx.handle)
     ctx._comm_cb = None
+    ctx._comm_attached = (int(world), int(rank))
 
 
 def comm_set_callback(ctx: Context, fn, world: int, rank: int):
@@ -484,11 +485,18 @@ def comm_set_callback(ctx: Context, fn, world: int, rank: int):
     cb = _lib.ALLREDUCE_FN(tramp)
     raise_for(ctx.lib.eofx_ctx_comm_set_callback(ctx.handle, cb, None, int(world), int(rank)), ctx.handle)
     ctx._comm_cb = cb      # keep the trampoline alive
+    ctx._comm_attached = (int(world), int(rank))
 
 
 def comm_clear(ctx: Context):
     raise_for(ctx.lib.eofx_ctx_comm_clear(ctx.handle), ctx.handle)
     ctx._comm_cb = None
+    ctx._comm_attached = None
+
+
+def comm_attached(ctx: Context):
+    """(world, rank) of the communicator attached to the context, or None"""
+    return getattr(ctx, "_comm_attached", None)
 
 
 def comm_selftest(ctx: Context) -> bool:
@@ -768,6 +776,70 @@ def crosscov_rsvd(ctx: Context, x: ResidentMatrix, y: ResidentMatrix, k: int, n_
                 total_squared_covariance=tsc.value)
 
 
+def comm_allreduce_host(ctx: Context, values, op: str = "sum") -> np.ndarray:
+    """all-reduce of a small host vector of doubles over the communicator attached to the context
+    (eofx_ctx_comm_allreduce_f64): the global facts a sharded model needs between engine calls"""
+    buf = np.ascontiguousarray(np.atleast_1d(values), dtype=np.float64).copy()
+    ctx._comm_err = None
+    rc = ctx.lib.eofx_ctx_comm_allreduce_f64(ctx.handle, ptr(buf), buf.size, {"sum": 0, "max": 1, "min": 2}[op])
+    if getattr(ctx, "_comm_err", None) is not None:
+        raise ctx._comm_err
+    raise_for(rc, ctx.handle)
+    return buf
+
+
+def crosscov_rsvd_sharded(ctx: Context, x: ResidentMatrix, y: ResidentMatrix, k: int, p1_total: int, p1_offset: int,
+                          p2_total: int, p2_offset: int, n_oversamples: int = 10, n_iter: int | str = "auto",
+                          random_state=None, flip: bool = True, omega=None, want_tsc: bool = True):
+    """`crosscov_rsvd` with both fields sharded along their feature axes (eofx_crosscov_rsvd_sharded_f32; the communicator is
+    the one attached to the context).  x / y: this rank's slices; p*_total / p*_offset: feature counts over all ranks and this
+    slice's position on the global VALID-feature axis.  omega: the GLOBAL sketch [min(p1_total, p2_total), k + n_oversamples]
+    (one draw, identical on every rank; drawn here from random_state when None).  Q1 / Q2 come back as this rank's rows."""
+    k = int(k)
+    if x.n != y.n:
+        raise ValueError(f"Both data matrices must have the same number of samples but found {x.n} in the first and "
+                         f"{y.n} in the second.")
+    small = min(int(p1_total), int(p2_total))
+    if k > small:
+        raise ValueError(f"n_modes must be less than or equal to the rank of the dataset (rank = {small}).")
+    l_req = k + int(n_oversamples)
+    if l_req > small:
+        raise ValueError("sketch wider than rank not supported on the cross path")
+    on_x = int(p1_total) < int(p2_total)            # the sketch lives on the narrower field's feature axis
+    sm, off = (x, int(p1_offset)) if on_x else (y, int(p2_offset))
+    om = omega.result() if hasattr(omega, "result") else omega
+    if l_req == small:      # full-width sketch: the identity (see eofx_rsvd_f32)
+        om = np.eye(small, dtype=np.float32)
+    elif om is None:
+        om = sketch_matrix(small, l_req, random_state)
+    om = np.asarray(om, dtype=np.float32)
+    if om.shape != (small, l_req):
+        raise ValueError(f"omega must have shape {(small, l_req)}")
+    rows = np.ascontiguousarray(sm.scatter_rows(np.ascontiguousarray(om[off:off + sm.p])), dtype=np.float32)
+    if rows.shape[0] == 0:
+        rows = np.zeros((1, l_req), np.float32)
+    n = x.n
+    Q1 = np.empty((max(x.p_phys, 1), k), np.float32)
+    Q2 = np.empty((max(y.p_phys, 1), k), np.float32)
+    s = np.empty(k, np.float32)
+    s1 = np.empty((n, k), np.float32)
+    s2 = np.empty((n, k), np.float32)
+    n1 = np.empty(k, np.float32)
+    n2 = np.empty(k, np.float32)
+    tsc = C.c_double(float("nan"))
+    it = -1 if n_iter == "auto" else int(n_iter)
+    ctx._comm_err = None
+    rc = ctx.lib.eofx_crosscov_rsvd_sharded_f32(ctx.handle, x.handle, y.handle, int(p1_total), int(p1_offset), int(p2_total),
+                                                int(p2_offset), k, int(n_oversamples), it, ptr(rows), int(flip), ptr(Q1),
+                                                ptr(s), ptr(Q2), ptr(s1), ptr(s2), ptr(n1), ptr(n2),
+                                                C.byref(tsc) if want_tsc else None)
+    if getattr(ctx, "_comm_err", None) is not None:
+        raise ctx._comm_err
+    raise_for(rc, ctx.handle)
+    return dict(Q1=x.compact_rows(Q1[:x.p_phys]), Q2=y.compact_rows(Q2[:y.p_phys]), s=s, scores1=s1, scores2=s2, norm1=n1,
+                norm2=n2, total_squared_covariance=tsc.value)
+
+
 def host_eigh(A: np.ndarray):
     A = np.ascontiguousarray(A, dtype=np.float64)
     n = A.shape[0]
@@ -1045,6 +1117,72 @@ def rsvd_c64(ctx: Context, A: ResidentMatrix, B: ResidentMatrix, k: int, n_overs
     return U, s, A.compact_rows(V)       # (masked real part: the rows of the valid features)
 
 
+def _c64_sharded_arguments(ctx: Context, A: ResidentMatrix, k: int, p_total: int, n_oversamples: int, n_iter, random_state,
+                           omega, device_out: bool):
+    """as `_c64_arguments` for a slice of a field with `p_total` valid features over all ranks (n < p_total: the start matrix
+    lives on the replicated sample side -- one draw, identical on every rank)"""
+    n = A.n
+    if not n < int(p_total):
+        raise ValueError("the sharded complex decomposition needs more features over all ranks than samples")
+    if k > n:
+        raise ValueError(f"n_modes must be less than or equal to the rank of the dataset (rank = {n}).")
+    l = min(k + n_oversamples, n)
+    if l == n:
+        omega = np.zeros((n, k + n_oversamples), np.float32)
+        omega[np.arange(l), np.arange(l)] = 1.0
+    elif omega is None:
+        omega = np.ascontiguousarray(sketch_matrix(n, k + n_oversamples, random_state), dtype=np.float32)
+    else:
+        omega = np.ascontiguousarray(omega.result() if hasattr(omega, "result") else omega, dtype=np.float32)
+        if omega.shape != (n, k + n_oversamples):
+            raise ValueError(f"omega must have shape {(n, k + n_oversamples)}")
+    it = -1 if n_iter in ("auto", None) else -2 if n_iter == "converge" else int(n_iter)
+    rows_v = max(A.p_phys, 1)
+    if device_out:
+        torch = _torch()
+        dev = f"cuda:{ctx.device}"
+        U = torch.empty((n, k), dtype=torch.complex64, device=dev)
+        V = torch.empty((rows_v, k), dtype=torch.complex64, device=dev)
+    else:
+        U = _host_out((n, k), np.complex64)
+        V = _host_out((rows_v, k), np.complex64)
+    return omega, it, U, np.empty(k, np.float32), V
+
+
+def rsvd_sharded_c64(ctx: Context, A: ResidentMatrix, B: ResidentMatrix, k: int, p_total: int, n_oversamples: int = 10,
+                     n_iter="auto", random_state=None, flip: bool = True, omega=None, device_out: bool = False):
+    """`rsvd_c64` on this rank's slice of the feature axis (eofx_rsvd_sharded_c64; collectives through the communicator
+    attached to the context) -> (U[n,k] replicated, s[k], V[p_local,k])"""
+    k = int(k)
+    if B.masked or (A.masked and B.p_phys != A.p_phys):
+        raise NotImplementedError("masked in-place real part: the imaginary part must be a written matrix over the same physical columns")
+    omega, it, U, s, V = _c64_sharded_arguments(ctx, A, k, p_total, n_oversamples, n_iter, random_state, omega, device_out)
+    ctx._comm_err = None
+    rc = ctx.lib.eofx_rsvd_sharded_c64(ctx.handle, A.handle, B.handle, int(p_total), k, int(n_oversamples), it, ptr(omega),
+                                       int(flip), ptr(U), ptr(s), ptr(V))
+    if getattr(ctx, "_comm_err", None) is not None:
+        raise ctx._comm_err
+    raise_for(rc, ctx.handle)
+    return U, s, A.compact_rows(V[:A.p_phys])
+
+
+def rsvd_hilbert_sharded_c64(ctx: Context, A: ResidentMatrix, k: int, p_total: int, padding="exp", decay_factor: float = 0.2,
+                             n_oversamples: int = 10, n_iter="auto", random_state=None, flip: bool = True, omega=None,
+                             device_out: bool = False):
+    """`rsvd_hilbert_c64` on this rank's slice (eofx_rsvd_hilbert_sharded_c64): the operator route of the analytic signal,
+    feature-sharded -- every pass streams the rank's REAL slice once, the Hilbert operator acts on the replicated sample-side
+    panel.  Reference: single/eof.py:546-555 -> linalg/decomposer.py:149-160."""
+    k = int(k)
+    omega, it, U, s, V = _c64_sharded_arguments(ctx, A, k, p_total, n_oversamples, n_iter, random_state, omega, device_out)
+    ctx._comm_err = None
+    rc = ctx.lib.eofx_rsvd_hilbert_sharded_c64(ctx.handle, A.handle, int(p_total), int(padding == "exp"), float(decay_factor), k,
+                                               int(n_oversamples), it, ptr(omega), int(flip), ptr(U), ptr(s), ptr(V))
+    if getattr(ctx, "_comm_err", None) is not None:
+        raise ctx._comm_err
+    raise_for(rc, ctx.handle)
+    return U, s, A.compact_rows(V[:A.p_phys])
+
+
 HILBERT_OPERATOR_MAX_SAMPLES = 16384      # eofx_rsvd_hilbert_c64 holds the n x n operator resident (2 GB at the limit)
 
 
@@ -1061,6 +1199,13 @@ def rsvd_hilbert_c64(ctx: Context, A: ResidentMatrix, k: int, padding="exp", dec
     raise_for(ctx.lib.eofx_rsvd_hilbert_c64(ctx.handle, A.handle, int(padding == "exp"), float(decay_factor), k,
                                             int(n_oversamples), it, ptr(omega), int(flip), ptr(U), ptr(s), ptr(V)), ctx.handle)
     return U, s, A.compact_rows(V)
+
+
+def hilbert_operator(ctx: Context, n: int, padding="exp", decay_factor: float = 0.2) -> np.ndarray:
+    """Hc [n, n] float32 with Im = Hc A for the Hilbert stage along the samples (eofx_hilbert_operator_f32)"""
+    out = np.empty((int(n), int(n)), np.float32)
+    raise_for(ctx.lib.eofx_hilbert_operator_f32(ctx.handle, int(n), int(padding == "exp"), float(decay_factor), ptr(out)), ctx.handle)
+    return out
 
 
 def hilbert_sumsq(ctx: Context, A: ResidentMatrix, padding="exp", decay_factor: float = 0.2) -> float:

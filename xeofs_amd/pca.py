@@ -241,12 +241,29 @@ class ResidentPCA:
         self.sign = sign.cpu().numpy()
         self.m, self.Lm, self.n, self.p, self.p_pad = m, Lm, n, p, mat.p_pad
         self.p_phys, self._masked_index = mat.p_phys, (mat.valid_index if mat.masked else None)
-        self.s = s.cpu().numpy()
+        # `_col_scale`: what the scores are scaled by (X V = U * _col_scale): the singular values, or -- on the basis-only path,
+        # where no individual mode exists -- the norms of the columns of X V; `s` is the spectrum and says so when there is none
+        self._col_scale = s.cpu().numpy()
         Ud = U * sign                                   # n x m float64 (device)
         self._U_dev, self._U_host = Ud, None            # downloaded on first use (60 MB at config 3)
         self._scores_dev = (Ud * s).float().contiguous()   # X V on the device: the analysis matrix of the cross models
-        self.singular_values_all = np.sqrt(lam_h)
+        self.singular_values_all = np.sqrt(lam_h) if self.spectrum_known else None
         self.total_variance = total_variance
+
+    @property
+    def s(self):
+        """singular values of the kept modes.  The basis-only path (a cross model with alpha = 1 that keeps every computed
+        direction) forms no individual mode: there is no spectrum to return, and a placeholder would be silently wrong."""
+        if not getattr(self, "spectrum_known", True):
+            raise RuntimeError("this PCA was fitted on the basis-only path (basis_only=True, variance target out of reach): the "
+                               "kept SUBSPACE is exact but no individual mode / singular value was computed; fit with "
+                               "basis_only=False for the spectrum")
+        return self._col_scale
+
+    @s.setter
+    def s(self, value):      # (the complex subclass assigns its spectrum directly)
+        self._col_scale = value
+        self.spectrum_known = True
 
     def _basis_without_spectrum(self, M, Mfull, ell, n_pre, n, total_variance):
         """The randomized route when only the kept SUBSPACE matters and every computed mode is kept (`basis_only`, variance
@@ -263,18 +280,7 @@ class ResidentPCA:
         ctx = self.ctx
         dev = M.device
         nb = ell - n_pre
-        import os, time
-        trace = bool(os.environ.get("EOFX_PCA_TRACE"))
-        def tick(label, t0=[None]):
-            if trace:
-                torch.cuda.synchronize()
-                now = time.perf_counter()
-                if t0[0] is not None:
-                    print(f"[pca fast path] {label}: {1e3 * (now - t0[0]):.2f} ms")
-                t0[0] = now
-        tick("start")
         Ri = engine.panel_rinv(ctx, Mfull.contiguous(), ell)[:ell, :ell]      # upper triangular, M^-1 = Ri Ri^T
-        tick("panel_rinv")
         d = Ri.diagonal()
         if not bool(torch.isfinite(Ri).all()) or bool((d <= 0).any()):
             return None
@@ -291,28 +297,41 @@ class ResidentPCA:
                 Lc = torch.linalg.cholesky(Z.T @ Z)
                 return torch.linalg.solve_triangular(Lc, Z.T, upper=False).T
 
-            # (the bottom of the sketch's spectrum decays smoothly: a fixed 20 steps, one Rayleigh-Ritz step at the end -- the dropped
-            # subspace then differs from the exact bottom one by directions whose variance is within a fraction of a per cent of it, far inside what the reference's unseeded sketch varies by from run to run)
-            for outer in range(4):
+            # The bottom of the sketch's spectrum decays smoothly, so the iteration is CHECKED, not trusted: after
+            # 4 x 5 inverse steps and a Rayleigh-Ritz step, the residual |M w - theta w| / theta of each of the nb dropped Ritz
+            # directions must be <= 5e-2 (a dropped direction then mixes at most that much of a kept one: its variance is within
+            # 0.3 % of an exact bottom direction's, far inside what the reference's unseeded sketch varies by from run to run);
+            # two more rounds are tried, then the caller takes the order-ell eigen-decomposition (return None).
+            self.fast_path_residual = None
+            for outer in range(6):
                 for _ in range(5):                                            # five inverse steps between orthonormalisations
                     Y = Ri @ (RiT @ Y)
                     Y = Y / Y.norm(dim=0, keepdim=True)
                 Y = cholqr(Y)
-            Y = cholqr(Y)
-            T = (Y.T @ (M @ Y)).cpu().numpy()                                 # 32 x 32: the host solves it
-            tv_h, Ws_h = np.linalg.eigh(0.5 * (T + T.T))                      # ascending: the bottom of the spectrum first
-            tick(f"inverse subspace iteration ({outer + 1} x 5 steps)")
-            Wb = Y @ torch.as_tensor(Ws_h[:, :nb], device=dev)
-            lam_bottom = np.maximum(tv_h[:nb], 0.0)
+                if outer < 3:
+                    continue
+                Yq = cholqr(Y)
+                MY = M @ Yq
+                T = (Yq.T @ MY).cpu().numpy()                                 # 32 x 32: the host solves it
+                tv_h, Ws_h = np.linalg.eigh(0.5 * (T + T.T))                  # ascending: the bottom of the spectrum first
+                Wsb = torch.as_tensor(Ws_h[:, :nb], device=dev)
+                Wb = Yq @ Wsb
+                lam_bottom = np.maximum(tv_h[:nb], 0.0)
+                res = (MY @ Wsb - Wb * torch.as_tensor(tv_h[:nb], device=dev)).norm(dim=0).cpu().numpy()
+                self.fast_path_residual = float(np.max(res / np.maximum(np.abs(tv_h[:nb]), 1e-300)))
+                if self.fast_path_residual <= 5e-2:
+                    break
+            else:
+                return None
             D = torch.linalg.solve_triangular(Ri, Wb, upper=True)             # R w_bottom
             Qf, _ = torch.linalg.qr(D, mode="complete")
             Wm = Ri @ Qf[:, nb:]
-            tick("complement basis (QR complete + product)")
         kept = float(M.diagonal().sum()) - float(lam_bottom.sum())
         warnings.warn(f"Dataset has {n_pre} components, explaining {kept / (n - 1) / total_variance:.2%} of the variance. However, "
                       f"{self.n_modes:.2%} explained variance was requested. Please consider increasing "
                       "`init_rank_reduction`.")
-        lam_h = np.full(n_pre, kept / max(n_pre, 1))       # (not the spectrum: its sum is right, the modes are not separated)
+        lam_h = np.full(n_pre, np.nan)                     # (no spectrum on this path: `s` / `singular_values_all` say so)
+        self._kept_variance = kept / (n - 1)
         return Wm, lam_h
 
     def _truncate(self, lam_h, n_pre, n, total_variance):
@@ -378,7 +397,7 @@ class ResidentPCA:
     # ------------------------------------------------------------------ PC-space views
     def scores(self):
         """X V = U s  (n x m), what `PCA.transform` returns for the training data (pca.py:125-134)."""
-        return self.U * self.s
+        return self.U * self._col_scale
 
     def _compact(self, V):
         """rows of the valid features of an exported factor with p_phys rows"""

@@ -87,6 +87,23 @@ class Comm:
         return self._reduce(t, self.dist.ReduceOp.MIN)
 
 
+class NativeComm:
+    """rank / world of the communicator attached to an engine context (`attach_native`, or `engine.comm_init_rccl` by a host
+    that brings its own rendezvous): what the model-level drivers below need when EVERY collective goes through the engine
+    (`native=True`) and no torch.distributed process group exists."""
+
+    active = False
+    group = None
+
+    def __init__(self, ctx):
+        from . import engine
+
+        att = engine.comm_attached(ctx)
+        if att is None:
+            raise ValueError("no communicator is attached to the engine context")
+        self.world, self.rank = att
+
+
 class _DeviceView:
     """a raw device pointer as something torch.as_tensor accepts (zero copy)"""
 
@@ -587,7 +604,37 @@ def _sum_scalar(comm: Comm, value: float) -> float:
     return float(comm.sum_(torch.tensor([value], dtype=torch.float64, device=dev)).cpu()[0])
 
 
-def global_facts(comm: Comm, p_local: int, valid_sample, check_nans: bool, total_variance: float, bad: float = 0.0):
+def use_native(ctx, native=None) -> bool:
+    """does this call issue its collectives through the engine's own communicator?  `native=None`: yes when one is attached
+    to the context (`attach_native`); `native=True` insists on it."""
+    from . import engine
+
+    att = ctx is not None and engine.comm_attached(ctx) is not None
+    if native is None:
+        return att
+    if native and not att:
+        raise ValueError("no communicator is attached to the engine context (xeofs_amd.sharded.attach_native)")
+    return bool(native)
+
+
+def _sum_host(comm: Comm, buf, native_ctx=None):
+    """all-reduce(sum) of a small float64 host vector: through the engine's communicator (eofx_ctx_comm_allreduce_f64) when
+    `native_ctx` is given, else through torch.distributed"""
+    buf = np.ascontiguousarray(buf, dtype=np.float64)
+    if native_ctx is not None:
+        from . import engine
+
+        return engine.comm_allreduce_host(native_ctx, buf)
+    if getattr(comm, "active", False):
+        import torch
+
+        dev = f"cuda:{torch.cuda.current_device()}" if comm.dist.get_backend(comm.group) == "nccl" else "cpu"
+        return comm.sum_(torch.from_numpy(buf.copy()).to(dev)).cpu().numpy()
+    return buf
+
+
+def global_facts(comm: Comm, p_local: int, valid_sample, check_nans: bool, total_variance: float, bad: float = 0.0,
+                 native_ctx=None):
     """The global facts of a feature-sharded preprocess in ONE all-reduce instead of four small ones
     (each is a collective launch plus a host round trip): the number of valid features of every rank (one-hot slots),
     the votes of `combine_sample_masks` (same rule, same error), the total variance and a veto flag.
@@ -601,9 +648,7 @@ def global_facts(comm: Comm, p_local: int, valid_sample, check_nans: bool, total
     buf[comm.rank] = float(p_local)
     buf[W:W + n] = vs & has
     buf[W + n], buf[W + n + 1], buf[W + n + 2] = float(has), float(total_variance), float(bad)
-    if comm.active:
-        dev = f"cuda:{torch.cuda.current_device()}" if comm.dist.get_backend(comm.group) == "nccl" else "cpu"
-        buf = comm.sum_(torch.from_numpy(buf).to(dev)).cpu().numpy()
+    buf = _sum_host(comm, buf, native_ctx)
     counts = np.rint(buf[:W]).astype(np.int64)
     votes, shards = np.rint(buf[W:W + n]).astype(np.int64), int(round(buf[W + n]))
     if check_nans and np.any((votes != 0) & (votes != shards)):
@@ -612,7 +657,8 @@ def global_facts(comm: Comm, p_local: int, valid_sample, check_nans: bool, total
 
 
 def sharded_preprocess(ctx, X_local, comm: Comm, center=True, standardize=False, feature_weights=None,
-                       check_nans=True, want_stats=True, keep_raw=False, in_place=False):
+                       check_nans=True, want_stats=True, keep_raw=False, in_place=False, allow_masked=False, for_hilbert=False,
+                       native=False):
     """Scaler + Sanitizer + total variance (rows R1-R6) of this rank's slice of the stacked feature axis.
 
     Per-feature statistics, masks and the compaction are local (`eofx_preprocess_f32`); the global
@@ -624,8 +670,10 @@ def sharded_preprocess(ctx, X_local, comm: Comm, center=True, standardize=False,
     from . import engine
 
     mat, st = engine.preprocess(ctx, X_local, center=center, standardize=standardize, feature_weights=feature_weights,
-                                check_nans=check_nans, want_stats=want_stats, keep_raw=keep_raw, in_place=in_place)
-    counts, vs, tv, _ = global_facts(comm, mat.p, st["valid_sample"], check_nans, st["total_variance"])
+                                check_nans=check_nans, want_stats=want_stats, keep_raw=keep_raw, in_place=in_place,
+                                allow_masked=allow_masked, for_hilbert=for_hilbert)
+    counts, vs, tv, _ = global_facts(comm, mat.p, st["valid_sample"], check_nans, st["total_variance"],
+                                     native_ctx=ctx if native else None)
     st["p_total"] = int(counts.sum())
     st["p_offset"] = int(counts[:comm.rank].sum())
     st["valid_sample"] = vs
@@ -673,7 +721,7 @@ def sharded_fit_first(ctx, X_local, comm: Comm, k: int, p_total: int, center=Tru
 
 def sharded_eof_fit(ctx, X_local, comm: Comm, n_modes: int, center=True, standardize=False, feature_weights=None,
                     check_nans=True, random_state=None, n_oversamples: int = 10, n_iter="auto", omega=None,
-                    device_out: bool = False):
+                    device_out: bool = False, native=None):
     """`EOF.fit` (single/eof.py:85-118) with the space axis sharded: X_local is this rank's
     (n, P_g) slice of the stacked raw field.  Returns the DataContainer entries as a dict; `components`
     holds this rank's rows, everything else is replicated.  Where the shapes allow, every rank takes the statistics of its
@@ -681,9 +729,29 @@ def sharded_eof_fit(ctx, X_local, comm: Comm, n_modes: int, center=True, standar
     from . import engine
 
     n = X_local.shape[0]
-    p_raw_total = int(_gather_counts(comm, X_local.shape[1]).sum())
+    nat = use_native(ctx, native)
+    if nat:
+        p_raw_total = int(round(_sum_host(comm, [float(X_local.shape[1])], ctx)[0]))
+    else:
+        p_raw_total = int(_gather_counts(comm, X_local.shape[1]).sum())
     if omega is None and n < p_raw_total:     # one draw for both steps (scikit-learn's stream for this seed)
         omega = engine.sketch_matrix(n, int(n_modes) + int(n_oversamples), random_state)
+    if nat and n < p_raw_total and int(n_modes) <= n:
+        # ONE engine call per rank (eofx_fit_sharded_f32): statistics during the first product, every collective issued by the
+        # engine on its own stream; a land / sea mask stays in place as zero columns of every slice.  None = the ranks voted for
+        # the panel-level driver below (isolated NaNs, shapes outside the fused pass): nothing was built.
+        res = engine.fit_sharded(ctx, X_local, int(n_modes), p_raw_total, center, standardize, feature_weights, n_oversamples,
+                                 n_iter, random_state, omega=omega, device_out=device_out, allow_masked=True)
+        if res is not None:
+            mat, st, U, s, V = res
+            counts = _sum_host(comm, np.eye(1, comm.world, comm.rank).ravel() * float(mat.p), ctx)
+            st["p_total"] = int(round(counts.sum()))
+            st["p_offset"] = int(round(counts[:comm.rank].sum()))
+            st["native"] = True
+            s64 = np.asarray(s, dtype=np.float64)
+            sc = U * (s if not device_out else engine._torch().as_tensor(s, device=U.device))
+            return dict(input_data=mat, components=V, scores=sc, norms=s64, explained_variance=s64 ** 2 / (mat.n - 1),
+                        total_variance=st["total_variance"], U=U, stats=st)
     mat, st, first = sharded_fit_first(ctx, X_local, comm, n_modes, p_raw_total, center, standardize, feature_weights,
                                        check_nans, True, n_oversamples, omega, random_state)
     ops = HipPanelOps(ctx, mat)
@@ -702,11 +770,29 @@ def sharded_eof_fit(ctx, X_local, comm: Comm, n_modes: int, center=True, standar
 def sharded_mca_fit(ctx, X_local, Y_local, comm: Comm, n_modes: int, standardize=(False, False),
                     feature_weights=(None, None), check_nans=(True, True), random_state=None,
                     n_oversamples: int = 10, n_iter="auto", omega=None, want_tsc: bool = True, use_pca: bool = False,
-                    n_pca_modes=0.999, pca_init_rank_reduction=0.3):
+                    n_pca_modes=0.999, pca_init_rank_reduction=0.3, native=None):
     """`MCA.fit` (cross/base_model_cross_set.py:269-321 + cross/cpcca.py:168-225) with both fields sharded
     along their own space axes.  With `use_pca` (the reference default) each field is first reduced by a
     feature-sharded `ResidentPCA` (all-reduced n x n Gram matrix); the analysis on the replicated PC scores
     needs no further communication and the components come back as this rank's rows of V Q."""
+    nat = use_native(ctx, native) and not use_pca
+    if nat:
+        # the engine's own sharded cross-covariance entry (eofx_crosscov_rsvd_sharded_f32): both slices stay where they lie (the
+        # in-place layout, a land / sea mask as zero columns), the global facts of the two preprocesses and every collective of
+        # the decomposition go through the engine's communicator
+        from . import engine
+
+        mx, sx = sharded_preprocess(ctx, X_local, comm, True, standardize[0], feature_weights[0], check_nans[0], in_place=True,
+                                    allow_masked=True, native=True)
+        my, sy = sharded_preprocess(ctx, Y_local, comm, True, standardize[1], feature_weights[1], check_nans[1], in_place=True,
+                                    allow_masked=True, native=True)
+        out = engine.crosscov_rsvd_sharded(ctx, mx, my, n_modes, sx["p_total"], sx["p_offset"], sy["p_total"], sy["p_offset"],
+                                           n_oversamples, n_iter, random_state=random_state, omega=omega, want_tsc=want_tsc)
+        s = out["s"].astype(np.float64)
+        return dict(input_data1=mx, input_data2=my, components1=out["Q1"], components2=out["Q2"],
+                    scores1=out["scores1"], scores2=out["scores2"], singular_values=s, squared_covariance=s ** 2,
+                    total_squared_covariance=out.get("total_squared_covariance") if want_tsc else None, norm1=out["norm1"],
+                    norm2=out["norm2"], stats1=sx, stats2=sy, native=True)
     mx, sx = sharded_preprocess(ctx, X_local, comm, True, standardize[0], feature_weights[0], check_nans[0])
     my, sy = sharded_preprocess(ctx, Y_local, comm, True, standardize[1], feature_weights[1], check_nans[1])
     if use_pca:
@@ -741,6 +827,68 @@ def sharded_mca_fit(ctx, X_local, Y_local, comm: Comm, n_modes: int, standardize
                 scores1=out["scores1"], scores2=out["scores2"], singular_values=s, squared_covariance=s ** 2,
                 total_squared_covariance=out.get("total_squared_covariance"), norm1=out["norm1"], norm2=out["norm2"],
                 stats1=sx, stats2=sy)
+
+
+def sharded_hilbert_eof_fit(ctx, X_local, comm: Comm, n_modes: int, padding="exp", decay_factor: float = 0.2, standardize=False,
+                            feature_weights=None, check_nans=True, random_state=None, n_oversamples: int = 10, n_iter="auto",
+                            omega=None, operator=True, native=None):
+    """`HilbertEOF.fit` (single/eof.py:449-560: centred field -> analytic signal along the samples, utils/hilbert_transform.py
+    -> complex decomposition, linalg/decomposer.py:149-160) with the space axis sharded: X_local is this rank's (n, P_g) slice of
+    the stacked raw field.  Returns the DataContainer entries as a dict; `components` holds this rank's rows (complex64),
+    everything else is replicated.
+
+    operator=True (BASELINE config 5 as its 8-GPU form): the OPERATOR route -- the Hilbert stage is one n x n matrix Hc along the
+    samples, applied to the replicated sample-side panel; every pass streams the rank's REAL slice once and the imaginary part
+    is never written (half the bytes of the two-part route, no second resident field).  With the engine's communicator attached
+    (`attach_native`) that is ONE engine call per rank, `eofx_rsvd_hilbert_sharded_c64`, which issues its own collectives; without it
+    the panel-level driver (`complex_svd.complex_rsvd` over `HilbertOperatorOps`) runs the same recurrence with torch.distributed
+    all-reduces between engine calls.  operator=False: the two-part route (Im written per slice, `eofx_hilbert_f32`)."""
+    from . import engine
+    from .complex_svd import ComplexOps, HilbertOperatorOps, complex_rsvd
+
+    nat = use_native(ctx, native)
+    k = int(n_modes)
+    n = X_local.shape[0]
+    use_op = bool(operator) and n <= engine.HILBERT_OPERATOR_MAX_SAMPLES and k + int(n_oversamples) <= 64
+    # the statistics pass leaves the slice in place (the raw field through the Scaler map) and, for the sum of squares of the
+    # imaginary part, writes the transposed raw copy the transform kernel reads; a land / sea mask stays in place on the
+    # engine's own route only (the panel-level operator driver works on compacted slices)
+    mat, st = sharded_preprocess(ctx, X_local, comm, True, standardize, feature_weights, check_nans, in_place=True,
+                                 allow_masked=nat and use_op, for_hilbert=True, native=nat)
+    if mat.n != n:
+        raise NotImplementedError("feature-sharded HilbertEOF with all-NaN samples (the slices would need a common compaction)")
+    if not n < st["p_total"]:
+        mat.free()
+        raise ValueError("the feature-sharded complex decomposition needs more valid features over all ranks than samples")
+    if omega is not None and hasattr(omega, "result"):
+        omega = omega.result()
+    if use_op:
+        im2 = engine.hilbert_sumsq(ctx, mat, padding, decay_factor)
+        tv = st["total_variance"] + float(_sum_host(comm, [im2], ctx if nat else None)[0]) / (n - 1)
+        if nat:
+            U, s, V = engine.rsvd_hilbert_sharded_c64(ctx, mat, k, st["p_total"], padding, decay_factor, n_oversamples, n_iter,
+                                                      random_state, omega=omega)
+            parts = (mat, None)
+        else:
+            Hop = engine.from_dense(ctx, engine.hilbert_operator(ctx, n, padding, decay_factor))
+            try:
+                U, s, V = complex_rsvd(ctx, mat, None, k, n_oversamples, n_iter, random_state, ops=HilbertOperatorOps(ctx, mat, Hop),
+                                       comm=comm, p_total=st["p_total"], p_offset=st["p_offset"], omega=omega)
+            finally:
+                Hop.free()
+            parts = (mat, None)
+    else:
+        B, _ = engine.hilbert(ctx, mat, padding, decay_factor)
+        tv = st["total_variance"] + float(_sum_host(comm, [B.sumsq()], ctx if nat else None)[0]) / (n - 1)
+        if nat:
+            U, s, V = engine.rsvd_sharded_c64(ctx, mat, B, k, st["p_total"], n_oversamples, n_iter, random_state, omega=omega)
+        else:
+            U, s, V = complex_rsvd(ctx, mat, B, k, n_oversamples, n_iter, random_state, ops=ComplexOps(ctx, mat, B), comm=comm,
+                                   p_total=st["p_total"], p_offset=st["p_offset"], omega=omega)
+        parts = (mat, B)
+    s64 = np.asarray(s, dtype=np.float64)
+    return dict(input_data=parts, components=V, scores=U * s, norms=s64, explained_variance=s64 ** 2 / (n - 1),
+                total_variance=tv, stats=st, native=bool(nat), operator=bool(use_op))
 
 
 def shard_bounds(p_total: int, world: int, rank: int):

@@ -374,6 +374,7 @@ class HilbertEOF(ComplexEOF):
         n_over = int(dict(self._solver_kwargs).get("n_oversamples", 10))
         return (getattr(self, "_hilbert_operator_ok", True) and isinstance(self.n_modes, (int, np.integer))
                 and int(self.n_modes) + n_over <= 64 and A.n <= engine.HILBERT_OPERATOR_MAX_SAMPLES
+                and 2 * A.n <= A.p          # the n x n operator must be cheaper to hold and stream than the n x p imaginary part
                 and not (A.masked and A.p < A.n))
 
     def _fit_operator(self, A, omega):
