@@ -440,10 +440,12 @@ int eofx_vec_dot_f64(eofx_ctx *ctx, const float *a, const float *b, int64_t coun
  * xarray_utils.py:273-301, with numpy's lexicographic complex max / min).  A pass over the data is one launch of the
  * streaming kernel in its two-matrix form; the l x l Hermitian factorisations run on the host in float64.
  * omega: host [min(n,p) x (k + n_oversamples)] REAL start matrix (the Gaussian numpy's RandomState draws; the
- * identity when k + n_oversamples >= min(n, p)); n_iter = -1: scikit-learn's "auto" count (7 or 4), n_iter = -2: iterate
- * until the leading k Ritz values stand still (relative change <= 1e-6 twice in a row; 2 .. 20 iterations -- lobpcg
- * converges to a tolerance, which matters when the wanted modes run into a flat noise bulk; eofx_ctx_last_iterations
- * reports the count).  U [n x k], V [p x k]:
+ * identity when k + n_oversamples >= min(n, p)); n_iter = -1: scikit-learn's "auto" count (7 or 4 products of the block
+ * Krylov recurrence), n_iter = -2 ("converge"): continue the recurrence until every wanted singular value is good to 2e-6
+ * and every wanted vector separated from its neighbours by 2 % to |cos| >= 1 - 5e-6, judged from the Ritz values' own
+ * convergence history (a host Rayleigh-Ritz solve every third product), at most 20 products -- lobpcg converges to a
+ * tolerance, within at most 20 iterations under svds, which matters when wanted modes sit next to a flat noise bulk
+ * (profiles/r06_r9_evidence.txt); eofx_ctx_last_iterations reports the count.  U [n x k], V [p x k]:
  * complex64, row-major, interleaved (re, im), host|device; s [k] float32.  k + n_oversamples <= 64
  * (EOFX_ERR_ARG beyond); vectors are defined up to a unit phase per mode, as in the reference.                   */
 int eofx_rsvd_c64(eofx_ctx *ctx, const eofx_mat *A, const eofx_mat *B, int k, int n_oversamples, int n_iter,

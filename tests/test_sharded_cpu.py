@@ -314,7 +314,7 @@ def _hilbert_case(n, p, seed):
     return A, Hc
 
 
-def _hworker(rank, world, port, n, p, k, out_dir):
+def _hworker(rank, world, port, n, p, k, out_dir, rule="auto"):
     import torch.distributed as dist
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -326,14 +326,14 @@ def _hworker(rank, world, port, n, p, k, out_dir):
     A, Hc = _hilbert_case(n, p, 13)
     lo, hi = sharded.shard_bounds(p, world, rank)
     U, s, V = complex_rsvd(None, None, None, k, random_state=4, ops=NumpyHilbertOperatorOps(A[:, lo:hi], Hc),
-                           comm=sharded.Comm(), p_total=p, p_offset=lo)
+                           comm=sharded.Comm(), p_total=p, p_offset=lo, n_iter=rule)
     np.savez(os.path.join(out_dir, f"h{rank}.npz"), U=U, s=s, V=V)
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n,p,k", [(96, 500, 5), (120, 333, 8)])
-def test_sharded_hilbert_operator_route_two_ranks_gloo(tmp_path, n, p, k):
+@pytest.mark.parametrize("n,p,k,rule", [(96, 500, 5, "auto"), (120, 333, 8, "auto"), (120, 333, 12, "converge")])
+def test_sharded_hilbert_operator_route_two_ranks_gloo(tmp_path, n, p, k, rule):
     """The operator route of the analytic signal, feature-sharded (the panel-level form of eofx_rsvd_hilbert_sharded_c64): every
     rank holds its REAL slice and the n x n Hilbert operator; result = exact SVD of the oracle's analytic signal of the whole
     field (single/eof.py:546-555 -> utils/hilbert_transform.py -> decomposer.py:149-160)."""
@@ -341,7 +341,7 @@ def test_sharded_hilbert_operator_route_two_ranks_gloo(tmp_path, n, p, k):
 
     from oracle import eof_oracle as orc
 
-    mp.spawn(_hworker, args=(2, _free_port(), n, p, k, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_hworker, args=(2, _free_port(), n, p, k, str(tmp_path), rule), nprocs=2, join=True)
     parts = [np.load(tmp_path / f"h{r}.npz") for r in range(2)]
     assert np.array_equal(parts[0]["U"], parts[1]["U"]) and np.array_equal(parts[0]["s"], parts[1]["s"])
     V = np.concatenate([q["V"] for q in parts], axis=0)

@@ -134,14 +134,21 @@ class HilbertOperatorOps(ComplexOps):
 KRYLOV_MAX_ORDER = 8 * 64
 
 
-def _block_krylov(ops, comm, Z0, q, l, half, small, tall, fwd, bwd, gram, orth, orth_tall):
+def _block_krylov(ops, comm, Z0, q, l, half, small, tall, fwd, bwd, gram, orth, orth_tall, adaptive=False, k=None, q_first_check=4,
+                  products=None):
     """The q products of the decomposition as a block Lanczos recurrence on the small side with a Rayleigh-Ritz step over the
     whole Krylov space (the engine entry `eofx_rsvd_c64` does the same on one GPU, csrc/eofx_abi.hip; round 5: the reference's
     complex branch is a block Krylov-class solver, scipy svds(lobpcg), decomposer.py:149-160).  Returns the tall Ritz panel
     A_op K y -- a linear combination of the tall panels of the products, no extra pass.  Sharded: the small-side Gram matrices
-    are all-reduced when the small side is the feature side; everything else is local or replicated."""
+    are all-reduced when the small side is the feature side; everything else is local or replicated.
+    adaptive (n_iter="converge"): q is the LIMIT; every third product from `q_first_check` on the Ritz values of the blocks multiplied
+    so far are compared with those of the previous check and the recurrence stops when every wanted value is good to 2e-6 by its
+    own history -- the rule of the engine entry (rsvd_c64_impl, csrc/eofx_abi.hip: rise D_c between two checks, ratio rho of two
+    successive rises, distance to go D_c rho / (1 - rho); vectors of modes separated by 4 % in sigma^2: error / gap <= 1e-5).
+    `products` (a list) receives the number of products made."""
     torch = engine._torch()
     lp = 2 * half
+    k = l if k is None else int(k)
 
     def real_gram(P, side):
         G = ops.gram_real(P)
@@ -181,6 +188,33 @@ def _block_krylov(ops, comm, Z0, q, l, half, small, tall, fwd, bwd, gram, orth, 
     def embed_stack(blocks):                     # real (len(blocks) lp) x lp matrix applying complex l x l blocks on the right
         return np.concatenate([_embed_right(c, half) for c in blocks], axis=0)
 
+    def assemble(nbr, nWr, last=None):
+        """H = K^H M K over the first nbr blocks from the products of the first nWr ones (+ the last diagonal block)"""
+        G = real_gram(torch.cat(K[:nbr] + W[:nWr], dim=1), small)
+        m = nbr * l
+        raw = {}
+        for i in range(nWr):
+            for j in range(nbr):
+                cb = cblock(G, j * lp, (nbr + i) * lp)
+                raw[(j, i)] = cb if Rf[i] is None else cb @ Rf[i]
+        if last is not None:
+            raw[(nbr - 1, nbr - 1)] = last
+        Hm = np.zeros((m, m), complex)
+        for a in range(nbr):
+            for b in range(a, nbr):
+                u, v = raw.get((a, b)), raw.get((b, a))
+                if u is None and v is None:
+                    continue
+                val = u if v is None else (v.conj().T if u is None else 0.5 * (u + v.conj().T))
+                Hm[a * l:(a + 1) * l, b * l:(b + 1) * l] = val
+                if a != b:
+                    Hm[b * l:(b + 1) * l, a * l:(a + 1) * l] = val.conj().T
+        return 0.5 * (Hm + Hm.conj().T)
+
+    def ritz_values(nbr):
+        return np.linalg.eigvalsh(assemble(nbr, nbr))[::-1][:l]
+
+    next_check, th_prev, rise_prev = int(q_first_check), None, None
     K, W, slots, Rf = [], [], [], []
     Zb, _, _, _ = cholqr(Z0, small)
     K.append(Zb)
@@ -217,6 +251,30 @@ def _block_krylov(ops, comm, Z0, q, l, half, small, tall, fwd, bwd, gram, orth, 
             exhausted = True
             break
         K.append(Zn)
+        if adaptive and it + 1 >= next_check and it + 1 < q:
+            th = ritz_values(len(W))
+            worst = 1e300 if th_prev is None else 0.0
+            rise = np.zeros(k)
+            if th_prev is not None:
+                for j in range(k):
+                    t = max(th[j], 1e-300)
+                    rise[j] = abs(th[j] - th_prev[j]) / t
+                    rho = 0.5 if rise_prev is None or not rise_prev[j] > 0.0 else min(0.7, max(0.02, rise[j] / rise_prev[j]))
+                    est = rise[j] * rho / (1.0 - rho)
+                    score = est / 4e-6
+                    gaps = ([(th[j - 1] - th[j]) / t] if j > 0 else []) + ([(th[j] - th[j + 1]) / t] if j + 1 < len(th) else [])
+                    gap = min(gaps) if gaps else 1e300
+                    if 0.04 <= gap < 1e300:
+                        score = max(score, est / gap / 1e-5)
+                    worst = max(worst, score)
+            if worst <= 1.0:
+                break
+            if th_prev is not None:
+                rise_prev = rise
+            th_prev = th[:k].copy()
+            next_check = it + 1 + 3
+    if products is not None:
+        products.append(len(W))
     nb, nW = len(K), len(W)
     Hqq = None
     if not exhausted:
@@ -229,25 +287,7 @@ def _block_krylov(ops, comm, Z0, q, l, half, small, tall, fwd, bwd, gram, orth, 
         else:
             Rf.append(None)
         slots.append(Y)
-    G = real_gram(torch.cat(K + W, dim=1), small)
-    m = nb * l
-    raw = {}
-    for i in range(nW):
-        for j in range(nb):
-            cb = cblock(G, j * lp, (nb + i) * lp)
-            raw[(j, i)] = cb if Rf[i] is None else cb @ Rf[i]
-    if Hqq is not None:
-        raw[(nb - 1, nb - 1)] = Hqq
-    Hm = np.zeros((m, m), complex)
-    for a in range(nb):
-        for b in range(a, nb):
-            u, v = raw.get((a, b)), raw.get((b, a))
-            if u is None and v is None:
-                continue
-            val = u if v is None else (v.conj().T if u is None else 0.5 * (u + v.conj().T))
-            Hm[a * l:(a + 1) * l, b * l:(b + 1) * l] = val
-            if a != b:
-                Hm[b * l:(b + 1) * l, a * l:(a + 1) * l] = val.conj().T
+    Hm = assemble(nb, nW, Hqq)
     wv, y = np.linalg.eigh(0.5 * (Hm + Hm.conj().T))
     y = y[:, ::-1][:, :l]
     coeff = []
@@ -331,8 +371,12 @@ def complex_rsvd(ctx, A, B, k: int, n_oversamples: int = 10, n_iter="auto", rand
     elif half != HALF:
         raise NotImplementedError(f"these panel operations hold {HALF} complex columns (sketch width {l})")
     lp = 2 * half
+    adaptive = n_iter == "converge"
+    auto_count = 7 if k < 0.1 * r else 4
     if n_iter == "auto" or n_iter is None:
-        n_iter = 7 if k < 0.1 * r else 4
+        n_iter = auto_count
+    elif adaptive:      # until every wanted value is good to 2e-6 (at most 20 products, and what the Rayleigh-Ritz order allows)
+        n_iter = max(2, min(20, KRYLOV_MAX_ORDER // max(l, 1) - 1))
     if l == r:      # full-width sketch spans everything: identity, not an ill-conditioned square Gaussian
         omega = np.eye(r, dtype=np.float32)
     elif omega is not None:                                                       # the caller's draw (one for all ranks)
@@ -380,8 +424,10 @@ def complex_rsvd(ctx, A, B, k: int, n_oversamples: int = 10, n_iter="auto", rand
     orth_tall = _orth_tall(tall_total, lp, getattr(ctx, "precision", ("f16x3",))[0])
     orth_rest = orth_tall
     q = int(n_iter)
+    made = []
     if q >= 1 and (q + 1) * l <= KRYLOV_MAX_ORDER and hasattr(ops, "matmul_real"):
-        Yx = _block_krylov(ops, comm, Z, q, l, half, small, tall, fwd, bwd, gram, orth, orth_tall)
+        Yx = _block_krylov(ops, comm, Z, q, l, half, small, tall, fwd, bwd, gram, orth, orth_tall, adaptive=adaptive, k=k,
+                           q_first_check=max(2, auto_count - 3), products=made)
         Q = orth(orth(Yx, tall), tall)
     else:
         for it in range(q):

@@ -830,7 +830,7 @@ def sharded_mca_fit(ctx, X_local, Y_local, comm: Comm, n_modes: int, standardize
 
 
 def sharded_hilbert_eof_fit(ctx, X_local, comm: Comm, n_modes: int, padding="exp", decay_factor: float = 0.2, standardize=False,
-                            feature_weights=None, check_nans=True, random_state=None, n_oversamples: int = 10, n_iter="auto",
+                            feature_weights=None, check_nans=True, random_state=None, n_oversamples: int = 10, n_iter="converge",
                             omega=None, operator=True, native=None):
     """`HilbertEOF.fit` (single/eof.py:449-560: centred field -> analytic signal along the samples, utils/hilbert_transform.py
     -> complex decomposition, linalg/decomposer.py:149-160) with the space axis sharded: X_local is this rank's (n, P_g) slice of
@@ -888,7 +888,8 @@ def sharded_hilbert_eof_fit(ctx, X_local, comm: Comm, n_modes: int, padding="exp
         parts = (mat, B)
     s64 = np.asarray(s, dtype=np.float64)
     return dict(input_data=parts, components=V, scores=U * s, norms=s64, explained_variance=s64 ** 2 / (n - 1),
-                total_variance=tv, stats=st, native=bool(nat), operator=bool(use_op))
+                total_variance=tv, stats=st, native=bool(nat), operator=bool(use_op),
+                products=engine.last_iterations(ctx) if (nat or comm is None or getattr(comm, "world", 1) == 1) else None)
 
 
 def shard_bounds(p_total: int, world: int, rank: int):
