@@ -99,7 +99,7 @@ def main():
         ref = engine.crosscov_rsvd(ctx, mx, my, k, 10, "auto", random_state=seed)
         mh, sth = engine.preprocess(ctx, H, in_place=True, allow_masked=True, for_hilbert=True)
         tv_h = sth["total_variance"] + engine.hilbert_sumsq(ctx, mh, "exp", 0.2) / (n - 1)
-        Uh, sh, Vhr = engine.rsvd_hilbert_c64(ctx, mh, k, "exp", 0.2, random_state=seed)
+        Uh, sh, Vhr = engine.rsvd_hilbert_c64(ctx, mh, k, "exp", 0.2, random_state=seed, n_iter="converge")   # the sharded drivers' default rule
         nres = 4 if a.lowrank else k          # modes that carry a value (directions of null modes are arbitrary)
         res = dict(world=world, attached=bool(attached), mask=bool(a.mask), lowrank=bool(a.lowrank),
                    native=[bool(eof["stats"].get("native")), bool(mca.get("native")), bool(hop["native"]), bool(h2p["native"])],
