@@ -1311,11 +1311,11 @@ def main():
     #      times them through the engine's own sharded entries, so the first real --gpus 8 run measures the fast routes
     configs_sharded = None
     if (world > 1 or args.force_sharded) and not args.no_configs:
-        try:
+        try:            # (a world-1 --force-sharded run has been through the CPU-baseline leg, which released these already)
             mat.free()
         except Exception:
             pass
-        del Xraw, last
+        Xraw = last = None
         torch.cuda.empty_cache()
         ctx.trim()
         configs_sharded = {}
@@ -1323,7 +1323,7 @@ def main():
             if cfg == 5 and args.quick_configs:
                 continue
             leg = leg_sharded_config(cfg, ctx, comm, device, world, rank, native, 2, 1)
-            configs_sharded[f"config{cfg}"] = {kk: leg["line"][kk] for kk in ("value", "unit", "ms_per_step", "config", "parity", "comm", "phase_ms")
+            configs_sharded[f"config{cfg}"] = {kk: leg["line"][kk] for kk in ("value", "unit", "ms_per_step", "config", "parity", "comm", "fixed_count_rule")
                                                if kk in leg["line"]}
             gate_failed += leg["gate"]
             ctx.trim()
