@@ -267,5 +267,8 @@ def test_two_rank_engine_owned_entries_on_one_gpu(ctx, variant):
     assert d["eof_scores"] < 1e-4 and d["mca_scores1"] < 1e-4 and d["mca_scores2"] < 1e-4 and d["mca_norm1"] < 1e-4, d
     assert d["eof_tv"] < 1e-6 and d["mca_tsc"] < 1e-5 and d["hop_tv"] < 1e-6 and d["h2p_tv"] < 1e-6, d
     # orthonormal factors, also where more modes were asked for than the fields have rank (variant "lowrank")
-    for key in ("eof_orth_v", "eof_orth_u", "mca_orth_q1", "mca_orth_q2", "hop_orth_v", "hop_orth_u", "h2p_orth_v"):
+    for key in ("eof_orth_v", "eof_orth_u", "mca_orth_q1", "mca_orth_q2", "hop_orth_v", "hop_orth_u", "h2p_orth_v", "hpy_orth_v"):
         assert d[key] < 2e-5, (key, d[key])
+    # the panel-level operator route (no engine communicator: HilbertOperatorOps + torch.distributed) agrees as well
+    assert d["hpy_operator"] and not d["hpy_native"]
+    assert d["hpy_s"] < 2e-5 and d["hpy_v_cos"] > 1 - 1e-4 and d["hpy_tv"] < 1e-6, d

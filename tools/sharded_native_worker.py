@@ -79,6 +79,9 @@ def main():
     calls_hop = engine.comm_stats(ctx)["calls"]
     h2p = sharded.sharded_hilbert_eof_fit(ctx, Hl, comm, k, random_state=seed, operator=False, native=True)
     calls_h2p = engine.comm_stats(ctx)["calls"]
+    # the panel-level form of the operator route (HilbertOperatorOps over the panel ABI, torch.distributed collectives between
+    # engine calls): the fallback when no engine communicator is attached; on a land-masked field it works on compacted slices
+    hpy = sharded.sharded_hilbert_eof_fit(ctx, Hl, comm, k, random_state=seed, operator=True, native=False)
 
     def gather_rows(local):
         parts = [None] * world
@@ -86,7 +89,7 @@ def main():
         return np.concatenate(parts, axis=0)
 
     V, Q1, Q2 = gather_rows(eof["components"]), gather_rows(mca["components1"]), gather_rows(mca["components2"])
-    Vh, Vh2 = gather_rows(hop["components"]), gather_rows(h2p["components"])
+    Vh, Vh2, Vhp = gather_rows(hop["components"]), gather_rows(h2p["components"]), gather_rows(hpy["components"])
     res = None
     if rank == 0:
         engine.comm_clear(ctx)      # the references below are single-GPU entries on the whole fields
@@ -118,6 +121,8 @@ def main():
                    mca_orth_q1=orth(Q1), mca_orth_q2=orth(Q2),
                    hop_s=rel(hop["norms"], sh), hop_v_cos=cosmin(Vh[:, :4], Vhr[:, :4]), hop_tv=abs(hop["total_variance"] / tv_h - 1.0),
                    hop_orth_v=orth(Vh), hop_orth_u=orth(hop["scores"] / hop["norms"]),
+                   hpy_s=rel(hpy["norms"], sh), hpy_v_cos=cosmin(Vhp[:, :4], Vhr[:, :4]), hpy_tv=abs(hpy["total_variance"] / tv_h - 1.0),
+                   hpy_orth_v=orth(Vhp), hpy_native=bool(hpy["native"]), hpy_operator=bool(hpy["operator"]),
                    h2p_s=rel(h2p["norms"], sh), h2p_v_cos=cosmin(Vh2[:, :4], Vhr[:, :4]), h2p_tv=abs(h2p["total_variance"] / tv_h - 1.0),
                    h2p_orth_v=orth(Vh2))
     dist.barrier()

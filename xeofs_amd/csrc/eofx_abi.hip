@@ -3874,20 +3874,28 @@ static int crosscov_impl(eofx_ctx* ctx, const eofx_mat* x, const eofx_mat* y, in
   bool gram_route = tsc && n < P1 && n < P2 && gram_fast_ok(x) && gram_fast_ok(y) && !std::getenv("EOFX_CROSS_NO_GRAM");
   size_t need = rsvd_scratch_bytes(std::max(x->p_pad, y->p_pad), std::max(x->p_pad, y->p_pad), l, k) +
                 (size_t)npad * L * 4 * 2 + atb_scratch_bytes(npad, std::max(x->p_pad, y->p_pad), L);
-  if (shd) {   // the Gram route is a collective decision (a rank's slice may not qualify); and room for the null-mode repair
-    int worst = 0;
-    CHK(comm_vote(ctx, gram_route ? 0 : 1, &worst));
-    gram_route = worst == 0;
-    const size_t Lo_ = (size_t)round_up(k, 32), pp_ = (size_t)std::max(x->p_pad, y->p_pad);
-    need += pp_ * Lo_ * 4 + (size_t)(gram_parts((int64_t)pp_, (int)Lo_) + 4) * Lo_ * Lo_ * 8 + (64 << 10);
-    if (tsc && !gram_route) need += std::max(gram_fast_scratch(ctx, x), gram_fast_scratch(ctx, y));
-  }
   if (tsc) need += (size_t)npad * npad * 4 * 2 + (1 << 20);
-  if (gram_route)
-    need += std::max(gram_fast_scratch(ctx, x), gram_fast_scratch(ctx, y)) + (size_t)npad * L * 4 * 2 + atb_scratch_bytes(npad, npad, L);
-  else if (tsc)
-    need += atb_scratch_bytes(npad, std::max(x->p_pad, y->p_pad), (int)npad);
-  CHK(arena_reserve(ctx, need));
+  const size_t need_gram = gram_fast_ok(x) && gram_fast_ok(y)
+                               ? std::max(gram_fast_scratch(ctx, x), gram_fast_scratch(ctx, y)) + (size_t)npad * L * 4 * 2 + atb_scratch_bytes(npad, npad, L)
+                               : 0;
+  const size_t need_plain = tsc ? atb_scratch_bytes(npad, std::max(x->p_pad, y->p_pad), (int)npad) : 0;
+  if (shd) {
+    // The Gram route is a collective decision (a rank's slice may not qualify), and so is an error of this rank before the first
+    // data collective (growing the arena): one vote -- 0 go on with the Gram route, 1 without it, 2 some rank failed.  The arena is
+    // sized for either route up front (+ room for the null-mode repair of a sharded factor).
+    const size_t Lo_ = (size_t)round_up(k, 32), pp_ = (size_t)std::max(x->p_pad, y->p_pad);
+    need += pp_ * Lo_ * 4 + (size_t)(gram_parts((int64_t)pp_, (int)Lo_) + 4) * Lo_ * Lo_ * 8 + (64 << 10) + std::max(need_gram, need_plain);
+    const int rc_local = arena_reserve(ctx, need);
+    const std::string err_local = rc_local != EOFX_OK ? ctx->err : std::string();
+    int worst = 0;
+    CHK(comm_vote(ctx, rc_local != EOFX_OK ? 2 : gram_route ? 0 : 1, &worst));
+    if (worst == 2)
+      return rc_local != EOFX_OK ? (ctx->err = err_local, rc_local) : set_err(ctx, EOFX_ERR_HIP, "the sharded cross-covariance fit failed on another rank");
+    gram_route = worst == 0;
+  } else {
+    need += gram_route ? need_gram : need_plain;
+    CHK(arena_reserve(ctx, need));
+  }
   ArenaScope scope(ctx);
   ARENA(float, Tn, (size_t)npad * L);
   float *Gx = nullptr, *Gy = nullptr;
@@ -4952,9 +4960,13 @@ static int rsvd_c64_impl(eofx_ctx* ctx, const eofx_mat* A, const eofx_mat* B, co
   const int h = l <= 32 ? 32 : 64, LP = 2 * h;
   const int ko = (int)round_up(k, 16), Lo = 2 * ko;       // output panels [Re(ko) | Im(ko)]
   const bool lean = B && cplx_lean(A, B, LP, ctx->prec_power, ctx->prec_final);
+  // (sharded: a rank-local failure of the steps before the first collective -- building a layout, growing the arena -- must not
+  // leave the other ranks in an all-reduce: it becomes this rank's vote below and every rank returns together)
+  int rc_local = EOFX_OK;
   if (B && !lean) {
-    CHK(ensure_X(ctx, A));   // (ensure_X builds the sample-contiguous layout first where that is missing too)
-    CHK(ensure_X(ctx, B));
+    rc_local = ensure_X(ctx, A);   // (ensure_X builds the sample-contiguous layout first where that is missing too)
+    if (rc_local == EOFX_OK) rc_local = ensure_X(ctx, B);
+    if (!shd) CHK(rc_local);
   }
   const bool transposed = shd || n < p;     // A_op = Z^H: tall side = features
   const int64_t small = transposed ? n : p;
@@ -4974,7 +4986,16 @@ static int rsvd_c64_impl(eofx_ctx* ctx, const eofx_mat* A, const eofx_mat* B, co
   if (krylov)
     need += (size_t)nbmax * (2 * small_pad + tall_pad) * LP * 4 + (size_t)small_pad * LP * 4 + (size_t)(3 + nbmax) * nbmax * LP * LP * 8 +
             ((size_t)48 << 20);
-  CHK(arena_reserve(ctx, need));
+  if (rc_local == EOFX_OK) rc_local = arena_reserve(ctx, need);
+  if (shd) {
+    const std::string err_local = rc_local != EOFX_OK ? ctx->err : std::string();
+    int verdict = 0;
+    CHK(comm_vote(ctx, rc_local != EOFX_OK ? 2 : 0, &verdict));
+    if (verdict != 0)
+      return rc_local != EOFX_OK ? (ctx->err = err_local, rc_local) : set_err(ctx, EOFX_ERR_HIP, "the sharded complex decomposition failed on another rank");
+  } else {
+    CHK(rc_local);
+  }
   ArenaScope scope(ctx);
   ARENA(float, Zs, (size_t)small_pad * LP);
   ARENA(float, Ws, (size_t)small_pad * LP);
@@ -5593,9 +5614,17 @@ extern "C" int eofx_rsvd_hilbert_sharded_c64(eofx_ctx* ctx, const eofx_mat* A, i
   if (A->n > EOFX_HILBERT_OP_MAX_N)
     return set_err(ctx, EOFX_ERR_ARG, "the resident Hilbert operator is limited to %d samples (got %lld): use eofx_hilbert_f32 + eofx_rsvd_sharded_c64",
                    EOFX_HILBERT_OP_MAX_N, (long long)A->n);
+  if (!ctx->comm) return set_err(ctx, EOFX_ERR_ARG, "no communicator attached (eofx_ctx_comm_init_rccl / eofx_ctx_comm_set_callback)");
   ENTER(ctx);
   const eofx_mat* Hop = nullptr;
-  CHK(get_hilbert_operator(ctx, A->n, padding ? 1 : 0, decay_factor, &Hop));
+  {   // building the operator (host memory, an upload) can fail on one rank alone: the ranks agree before the first collective
+    const int rc_local = get_hilbert_operator(ctx, A->n, padding ? 1 : 0, decay_factor, &Hop);
+    const std::string err_local = rc_local != EOFX_OK ? ctx->err : std::string();
+    int verdict = 0;
+    CHK(comm_vote(ctx, rc_local != EOFX_OK ? 2 : 0, &verdict));
+    if (verdict != 0)
+      return rc_local != EOFX_OK ? (ctx->err = err_local, rc_local) : set_err(ctx, EOFX_ERR_HIP, "the sharded Hilbert decomposition failed on another rank");
+  }
   return rsvd_c64_impl(ctx, A, nullptr, Hop, k, n_oversamples, n_iter, omega, flip_signs, U, s, V, p_total);
 }
 
