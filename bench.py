@@ -1322,7 +1322,12 @@ def main():
         for cfg in (3, 5):
             if cfg == 5 and args.quick_configs:
                 continue
-            leg = leg_sharded_config(cfg, ctx, comm, device, world, rank, native, 2, 1)
+            try:
+                leg = leg_sharded_config(cfg, ctx, comm, device, world, rank, native, 2, 1)
+            except Exception as e:      # the headline line must not be lost to a leg (a symmetric failure: every rank leaves the leg)
+                configs_sharded[f"config{cfg}"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+                print(f"[bench] configs_sharded.config{cfg} failed on rank {rank}: {e!r}", file=sys.stderr)
+                break
             configs_sharded[f"config{cfg}"] = {kk: leg["line"][kk] for kk in ("value", "unit", "ms_per_step", "config", "parity", "comm", "fixed_count_rule")
                                                if kk in leg["line"]}
             gate_failed += leg["gate"]

@@ -72,8 +72,11 @@ def test_config5_path_default_rule_vs_exact_and_reference_solver(ctx):
     X = bench.make_field(n, nlat, nlon, 0, nlat * nlon, "cuda:0", seed=51_000)
     A, _ = engine.preprocess(ctx, X, want_stats=False, in_place=True)
     B, _ = engine.hilbert(ctx, A, "exp", 0.2)
-    U, s, V = engine.rsvd_c64(ctx, A, B, k, random_state=5)          # the rule bench.py times (n_iter="auto")
+    U, s, V = engine.rsvd_c64(ctx, A, B, k, random_state=5)          # the fixed count (n_iter="auto": scikit-learn's 7 products)
     assert engine.last_iterations(ctx) == 7
+    # the rule bench.py times and the models default to since round 6: to convergence, on the operator route HilbertEOF takes
+    Uc, sc, Vc = engine.rsvd_hilbert_c64(ctx, A, k, "exp", 0.2, random_state=5, n_iter="converge")
+    its_c = engine.last_iterations(ctx)
     A.free(); B.free()
     x64 = X.cpu().numpy().astype(np.float64)
     z = orc.hilbert_transform(x64 - x64.mean(axis=0), padding="exp", decay_factor=0.2)
@@ -86,3 +89,7 @@ def test_config5_path_default_rule_vs_exact_and_reference_solver(ctx):
     assert np.all(e <= np.maximum(1e-5, e_ref)), (e, e_ref)
     vg = bench.vector_gate(sz[:k], np.asarray(V), vhz[:k].conj().T, complex_phase=True)
     assert vg["min_abs_cos"] >= 1 - 1e-5, vg
+    ec = np.abs(np.asarray(sc, dtype=np.float64) - sz[:k]) / sz[:k]
+    assert np.all(ec <= np.maximum(1e-5, e_ref)) and ec.max() <= 2e-6 and 4 <= its_c <= 20, (ec, its_c)
+    vgc = bench.vector_gate(sz[:k], np.asarray(Vc), vhz[:k].conj().T, complex_phase=True)
+    assert vgc["min_abs_cos"] >= 1 - 1e-5, vgc
