@@ -99,7 +99,13 @@ def main():
         matf, stf, U1, s1, V1 = engine.fit(ctx, X, k, random_state=seed, allow_masked=True)
         mx, stx = engine.preprocess(ctx, X, in_place=True, allow_masked=True)
         my, sty = engine.preprocess(ctx, Y, in_place=True, allow_masked=True)
-        ref = engine.crosscov_rsvd(ctx, mx, my, k, 10, "auto", random_state=seed)
+        try:
+            ref = engine.crosscov_rsvd(ctx, mx, my, k, 10, "auto", random_state=seed)
+        except NotImplementedError:      # (a single-GPU limit of masked in-place pairs, engine.crosscov_rsvd: compacted matrices instead)
+            mx.free(); my.free()
+            mx, stx = engine.preprocess(ctx, X)
+            my, sty = engine.preprocess(ctx, Y)
+            ref = engine.crosscov_rsvd(ctx, mx, my, k, 10, "auto", random_state=seed)
         mh, sth = engine.preprocess(ctx, H, in_place=True, allow_masked=True, for_hilbert=True)
         tv_h = sth["total_variance"] + engine.hilbert_sumsq(ctx, mh, "exp", 0.2) / (n - 1)
         Uh, sh, Vhr = engine.rsvd_hilbert_c64(ctx, mh, k, "exp", 0.2, random_state=seed, n_iter="converge")   # the sharded drivers' default rule

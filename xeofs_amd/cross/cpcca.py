@@ -449,8 +449,8 @@ class CPCCA(Deferred):
             return engine.crosscov_rsvd(self.ctx, sx.work, sy.work, k, n_over, n_iter, random_state=self.random_state,
                                         want_tsc=identity, omega=omega)
         except NotImplementedError:
-            # a masked in-place pair the engine cannot orient like the reference (valid and physical widths order
-            # differently, or fewer valid features than samples): compact the fields and go again
+            # a masked in-place pair the engine cannot take (a sketch as wide as the rank on a masked field): compact the
+            # fields and go again
             if not (sx.work.masked or sy.work.masked):
                 raise
             import logging

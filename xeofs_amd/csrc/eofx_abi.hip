@@ -3846,7 +3846,10 @@ static int crosscov_impl(eofx_ctx* ctx, const eofx_mat* x, const eofx_mat* y, in
                    (long long)x->n, (long long)y->n);
   const bool shd = sh != nullptr;
   const int64_t n = x->n, p1 = x->p, p2 = y->p;
-  const int64_t P1 = shd ? sh->p1_total : p1, P2 = shd ? sh->p2_total : p2, r = std::min(P1, P2);
+  // the VALID feature counts decide the orientation, the rank and the iteration count, as in the reference (a masked in-place
+  // matrix carries its all-NaN grid points as zero columns: p1 / p2 below are the physical widths of the panels)
+  const int64_t P1 = shd ? sh->p1_total : (x->masked ? x->p_valid : p1), P2 = shd ? sh->p2_total : (y->masked ? y->p_valid : p2),
+                r = std::min(P1, P2);
   auto reduce_panel = [&](float* Pn, int64_t count) -> int {      // a sample-side panel: sum of the ranks' partial sums
     if (!shd) return EOFX_OK;
     amax_forget(ctx, Pn);
@@ -3939,6 +3942,8 @@ static int crosscov_impl(eofx_ctx* ctx, const eofx_mat* x, const eofx_mat* y, in
   }
   std::vector<float> om_eye;
   if (l == r && !shd) {   // full-width sketch: identity (see eofx_rsvd_f32); a sharded caller hands over its rows of it
+    if ((transposed ? x : y)->masked)
+      return set_err(ctx, EOFX_ERR_ARG, "a sketch as wide as the rank on a masked in-place matrix is not supported (compact the field)");
     om_eye.assign((size_t)op.small * l, 0.f);
     for (int64_t i = 0; i < l; ++i) om_eye[(size_t)i * l + i] = 1.f;
     omega = om_eye.data();

@@ -723,14 +723,14 @@ def crosscov_rsvd(ctx: Context, x: ResidentMatrix, y: ResidentMatrix, k: int, n_
     small = min(x.p, y.p)
     if (x.masked or y.masked) and k > small:
         raise ValueError(f"n_modes must be less than or equal to the rank of the dataset (rank = {small}).")
-    if (x.masked or y.masked) and ((x.p < y.p) != (x.p_phys < y.p_phys) or min(x.p, y.p) <= x.n):
-        # the engine orients C by the PHYSICAL column counts; the reference by the valid ones (sklearn transposes when
-        # rows < cols): where the two disagree the sketch would live on the other side
-        raise NotImplementedError("cross-covariance of masked in-place matrices whose valid and physical widths order differently")
+    # the engine orients C by the VALID feature counts, as the reference does (sklearn transposes when rows < cols; round 6 --
+    # before, it used the physical widths and pairs whose two orders disagree had to be compacted)
+    small_mat = x if x.p < y.p else y
+    if small_mat.masked and k + n_oversamples >= small:
+        raise NotImplementedError("a sketch as wide as the rank on a masked in-place matrix (compact the field)")
     if x.n != y.n:
         raise ValueError(f"Both data matrices must have the same number of samples but found {x.n} in the first and "
                          f"{y.n} in the second.")
-    small_mat = x if x.p_phys < y.p_phys else y
 
     def sketch():
         om = omega.result() if hasattr(omega, "result") else omega     # a SketchFuture is joined as late as possible
